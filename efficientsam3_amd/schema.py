@@ -1,0 +1,334 @@
+"""State-dict schema of the EfficientSAM3 image hot path + a seeded initialiser.
+
+The reference's checkpoints (``state_dict`` of ``Sam3Image``) are the weight
+interchange format between the reference, the oracle and the HIP engine
+(SURVEY.md §5 "Checkpoint / resume", Appendix C).  No checkpoint exists
+offline, so this module re-creates the *names and shapes* of every tensor the
+hot path reads and fills them from a seeded generator with realistic
+statistics (randomised BatchNorm running stats, fan-in scaled weights) so that
+activations and mask logits have O(1) magnitudes instead of the ~0.02 that
+default ``nn.Module`` init produces.
+
+Key layout follows (reference file:line):
+  * EfficientViT backbone ........ sam3/sam3/backbones/efficientvit/efficientvit/backbone.py:33-156
+  * ConvLayer / DSConv / MBConv /
+    LiteMLA / EfficientViTBlock .. sam3/sam3/backbones/efficientvit/nn/ops.py:39-80,273-367,521-733
+  * student head ................. sam3/sam3/model_builder.py:764-787
+  * dual ViTDet neck ............. sam3/sam3/model/necks.py:13-98
+  * prompt encoder ............... sam3/sam3/sam/prompt_encoder.py:12-61,203-212
+  * two-way transformer .......... sam3/sam3/sam/transformer.py:16-60,108-153,185-215
+  * mask decoder ................. sam3/sam3/sam/mask_decoder.py:12-105,294-319
+  * tracker wrapper params ....... sam3/sam3/model/sam3_tracker_base.py:110,179-218
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Tuple
+
+import torch
+
+Shape = Tuple[int, ...]
+
+TRUNK = "backbone.vision_backbone.trunk.model."  # ListWrapper -> ImageStudentEncoder
+EV_BB = TRUNK + "backbone.model."  # EfficientViTTrunkWrapper -> EfficientViTBackbone
+NECK = "backbone.vision_backbone."
+SAM = "inst_interactive_predictor.model."
+
+EFFICIENTVIT_CFG = {
+    # name: (width_list, depth_list, dim)   backbone.py:159-196
+    "b0": ([8, 16, 32, 64, 128], [1, 2, 2, 2, 2], 16),
+    "b1": ([16, 32, 64, 128, 256], [1, 2, 3, 3, 4], 16),
+    "b2": ([24, 48, 96, 192, 384], [1, 3, 4, 4, 6], 32),
+}
+
+EMBED_DIM = 1024  # ImageStudentEncoder embed_dim (model_builder.py:913-919)
+D_MODEL = 256
+
+
+# ----------------------------------------------------------------------------
+# schema builders: name -> (shape, kind)
+#   kind in {"conv", "dw", "linear", "bias", "bn_w", "bn_b", "bn_m", "bn_v",
+#            "bn_n", "ln_w", "ln_b", "embed", "gauss"}
+# ----------------------------------------------------------------------------
+class _Schema(OrderedDict):
+    def conv(self, name: str, cout: int, cin: int, k: int, groups: int = 1, bias: bool = False):
+        kind = "dw" if groups == cin and groups == cout and groups > 1 else "conv"
+        self[name + ".weight"] = ((cout, cin // groups, k, k), kind)
+        if bias:
+            self[name + ".bias"] = ((cout,), "bias")
+
+    def convT(self, name: str, cin: int, cout: int, k: int):
+        self[name + ".weight"] = ((cin, cout, k, k), "convT")
+        self[name + ".bias"] = ((cout,), "bias")
+
+    def bn(self, name: str, c: int):
+        self[name + ".weight"] = ((c,), "bn_w")
+        self[name + ".bias"] = ((c,), "bn_b")
+        self[name + ".running_mean"] = ((c,), "bn_m")
+        self[name + ".running_var"] = ((c,), "bn_v")
+        self[name + ".num_batches_tracked"] = ((), "bn_n")
+
+    def ln(self, name: str, c: int):
+        self[name + ".weight"] = ((c,), "ln_w")
+        self[name + ".bias"] = ((c,), "ln_b")
+
+    def linear(self, name: str, cout: int, cin: int):
+        self[name + ".weight"] = ((cout, cin), "linear")
+        self[name + ".bias"] = ((cout,), "bias")
+
+    # EfficientViT ConvLayer = conv (+bias) (+BN)
+    def conv_layer(self, name: str, cin: int, cout: int, k: int, groups: int = 1,
+                   bias: bool = False, norm: bool = True):
+        self.conv(name + ".conv", cout, cin, k, groups=groups, bias=bias)
+        if norm:
+            self.bn(name + ".norm", cout)
+
+
+def efficientvit_schema(model_name: str = "b1") -> _Schema:
+    """EfficientViT-B{0,1,2} backbone tensors (backbone.py:33-156)."""
+    widths, depths, dim = EFFICIENTVIT_CFG[model_name]
+    s = _Schema()
+    p = EV_BB
+    # input stem: ConvLayer 3x3 s2 + depth_list[0] x Residual(DSConv)
+    s.conv_layer(p + "input_stem.op_list.0", 3, widths[0], 3)
+    for i in range(depths[0]):
+        q = p + f"input_stem.op_list.{i + 1}.main."
+        s.conv_layer(q + "depth_conv", widths[0], widths[0], 3, groups=widths[0])
+        s.conv_layer(q + "point_conv", widths[0], widths[0], 1)
+    cin = widths[0]
+    # stages 1-2: MBConv (expand 4), BN after every conv
+    for si, (w, d) in enumerate(zip(widths[1:3], depths[1:3])):
+        for i in range(d):
+            q = p + f"stages.{si}.op_list.{i}.main."
+            mid = round(cin * 4)
+            s.conv_layer(q + "inverted_conv", cin, mid, 1)
+            s.conv_layer(q + "depth_conv", mid, mid, 3, groups=mid)
+            s.conv_layer(q + "point_conv", mid, w, 1)
+            cin = w
+    # stages 3-4: MBConv s2 (fewer_norm) + d x EfficientViTBlock
+    for si, (w, d) in enumerate(zip(widths[3:], depths[3:]), start=2):
+        q = p + f"stages.{si}.op_list.0.main."
+        mid = round(cin * 4)
+        s.conv_layer(q + "inverted_conv", cin, mid, 1, bias=True, norm=False)
+        s.conv_layer(q + "depth_conv", mid, mid, 3, groups=mid, bias=True, norm=False)
+        s.conv_layer(q + "point_conv", mid, w, 1)
+        cin = w
+        heads = cin // dim
+        total = heads * dim
+        for i in range(d):
+            q = p + f"stages.{si}.op_list.{i + 1}."
+            c = q + "context_module.main."
+            s.conv_layer(c + "qkv", cin, 3 * total, 1, norm=False)
+            s.conv(c + "aggreg.0.0", 3 * total, 3 * total, 5, groups=3 * total)
+            s.conv(c + "aggreg.0.1", 3 * total, 3 * total, 1, groups=3 * heads)
+            s.conv_layer(c + "proj", 2 * total, cin, 1)
+            m = q + "local_module.main."
+            mid = round(cin * 4)
+            s.conv_layer(m + "inverted_conv", cin, mid, 1, bias=True, norm=False)
+            s.conv_layer(m + "depth_conv", mid, mid, 3, groups=mid, bias=True, norm=False)
+            s.conv_layer(m + "point_conv", mid, cin, 1)
+    return s
+
+
+def student_head_schema(c_backbone: int) -> _Schema:
+    """ImageStudentEncoder.head (model_builder.py:770-775)."""
+    s = _Schema()
+    s.conv(TRUNK + "head.0", EMBED_DIM, c_backbone, 1, bias=False)
+    s.bn(TRUNK + "head.1", EMBED_DIM)
+    s.conv(TRUNK + "head.3", EMBED_DIM, EMBED_DIM, 3, bias=True)
+    return s
+
+
+def neck_schema(which: str) -> _Schema:
+    """One SimpleFPN neck, ``which`` in {"convs", "sam2_convs"} (necks.py:36-98)."""
+    s = _Schema()
+    p = NECK + which + "."
+    dim = EMBED_DIM
+    s.convT(p + "0.dconv_2x2_0", dim, dim // 2, 2)
+    s.convT(p + "0.dconv_2x2_1", dim // 2, dim // 4, 2)
+    s.conv(p + "0.conv_1x1", D_MODEL, dim // 4, 1, bias=True)
+    s.conv(p + "0.conv_3x3", D_MODEL, D_MODEL, 3, bias=True)
+    s.convT(p + "1.dconv_2x2", dim, dim // 2, 2)
+    s.conv(p + "1.conv_1x1", D_MODEL, dim // 2, 1, bias=True)
+    s.conv(p + "1.conv_3x3", D_MODEL, D_MODEL, 3, bias=True)
+    for lvl in (2, 3):
+        s.conv(p + f"{lvl}.conv_1x1", D_MODEL, dim, 1, bias=True)
+        s.conv(p + f"{lvl}.conv_3x3", D_MODEL, D_MODEL, 3, bias=True)
+    return s
+
+
+def _attention_schema(s: _Schema, p: str, embed: int, internal: int):
+    for n in ("q_proj", "k_proj", "v_proj"):
+        s.linear(p + n, internal, embed)
+    s.linear(p + "out_proj", embed, internal)
+
+
+def _mlp_schema(s: _Schema, p: str, cin: int, hidden: int, cout: int, n: int = 3):
+    dims = [cin] + [hidden] * (n - 1) + [cout]
+    for i in range(n):
+        s.linear(p + f"layers.{i}", dims[i + 1], dims[i])
+
+
+def sam_heads_schema() -> _Schema:
+    """Prompt encoder + mask decoder + no_mem_embed (sam3_tracker_base.py:110,179-218)."""
+    s = _Schema()
+    s[SAM + "no_mem_embed"] = ((1, 1, D_MODEL), "embed")
+    pe = SAM + "sam_prompt_encoder."
+    s[pe + "pe_layer.positional_encoding_gaussian_matrix"] = ((2, D_MODEL // 2), "gauss")
+    for i in range(4):
+        s[pe + f"point_embeddings.{i}.weight"] = ((1, D_MODEL), "embed")
+    s[pe + "not_a_point_embed.weight"] = ((1, D_MODEL), "embed")
+    # mask_downscaling (mask_in_chans = 16): conv k2s2 1->4, LN2d, GELU, conv k2s2 4->16, LN2d, GELU, conv1x1 16->256
+    s.conv(pe + "mask_downscaling.0", 4, 1, 2, bias=True)
+    s.ln(pe + "mask_downscaling.1", 4)
+    s.conv(pe + "mask_downscaling.3", 16, 4, 2, bias=True)
+    s.ln(pe + "mask_downscaling.4", 16)
+    s.conv(pe + "mask_downscaling.6", D_MODEL, 16, 1, bias=True)
+    s[pe + "no_mask_embed.weight"] = ((1, D_MODEL), "embed")
+
+    md = SAM + "sam_mask_decoder."
+    for li in range(2):
+        q = md + f"transformer.layers.{li}."
+        _attention_schema(s, q + "self_attn.", D_MODEL, D_MODEL)
+        s.ln(q + "norm1", D_MODEL)
+        _attention_schema(s, q + "cross_attn_token_to_image.", D_MODEL, D_MODEL // 2)
+        s.ln(q + "norm2", D_MODEL)
+        s.linear(q + "mlp.lin1", 2048, D_MODEL)
+        s.linear(q + "mlp.lin2", D_MODEL, 2048)
+        s.ln(q + "norm3", D_MODEL)
+        s.ln(q + "norm4", D_MODEL)
+        _attention_schema(s, q + "cross_attn_image_to_token.", D_MODEL, D_MODEL // 2)
+    _attention_schema(s, md + "transformer.final_attn_token_to_image.", D_MODEL, D_MODEL // 2)
+    s.ln(md + "transformer.norm_final_attn", D_MODEL)
+    s[md + "iou_token.weight"] = ((1, D_MODEL), "embed")
+    s[md + "mask_tokens.weight"] = ((4, D_MODEL), "embed")
+    s[md + "obj_score_token.weight"] = ((1, D_MODEL), "embed")
+    s.convT(md + "output_upscaling.0", D_MODEL, D_MODEL // 4, 2)
+    s.ln(md + "output_upscaling.1", D_MODEL // 4)
+    s.convT(md + "output_upscaling.3", D_MODEL // 4, D_MODEL // 8, 2)
+    s.conv(md + "conv_s0", D_MODEL // 8, D_MODEL, 1, bias=True)
+    s.conv(md + "conv_s1", D_MODEL // 4, D_MODEL, 1, bias=True)
+    for i in range(4):
+        _mlp_schema(s, md + f"output_hypernetworks_mlps.{i}.", D_MODEL, D_MODEL, D_MODEL // 8)
+    _mlp_schema(s, md + "iou_prediction_head.", D_MODEL, 256, 4)
+    _mlp_schema(s, md + "pred_obj_score_head.", D_MODEL, D_MODEL, 1)
+    return s
+
+
+def image_path_schema(backbone_type: str = "efficientvit", model_name: str = "b1",
+                      enable_inst_interactivity: bool = True) -> _Schema:
+    """All tensors read by set_image + predict_inst for a student model."""
+    if backbone_type != "efficientvit":
+        raise NotImplementedError(
+            f"backbone_type={backbone_type!r}: only the EfficientViT family is built so far")
+    s = _Schema()
+    s.update(efficientvit_schema(model_name))
+    s.update(student_head_schema(EFFICIENTVIT_CFG[model_name][0][-1]))
+    s.update(neck_schema("convs"))
+    if enable_inst_interactivity:
+        s.update(neck_schema("sam2_convs"))
+        s.update(sam_heads_schema())
+    return s
+
+
+# ----------------------------------------------------------------------------
+# seeded "realistic" initialiser
+# ----------------------------------------------------------------------------
+# Which activation follows a conv decides its variance-preserving gain: layers feeding
+# Hardswish / GELU / ReLU get ~2/fan_in, linear layers 1/fan_in.  BatchNorms that close a
+# residual branch get a small gamma (as trained networks have) so that residual stacks do
+# not blow the activation scale up.
+_ACT_FOLLOWS = ("inverted_conv.conv", "depth_conv.conv", "input_stem.op_list.0.conv",
+                "dconv_2x2_0", "output_upscaling.0", "output_upscaling.3", "mask_downscaling.0",
+                "mask_downscaling.3")
+
+
+def _conv_gain(name: str) -> float:
+    if any(k in name for k in _ACT_FOLLOWS):
+        return 2.0
+    if "head.0." in name:
+        return 1.0
+    return 1.0
+
+
+def _linear_gain(name: str) -> float:
+    if "mlp.lin1" in name or ".layers.0." in name or ".layers.1." in name:
+        return 2.0  # followed by ReLU
+    return 1.0
+
+
+def _is_residual_branch_end(name: str) -> bool:
+    return ("point_conv.norm" in name or "proj.norm" in name) and "stages.0.op_list.0." not in name \
+        and "stages.1.op_list.0." not in name
+
+
+def init_state_dict(schema: _Schema, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic fp32 CPU state dict for ``schema``.
+
+    One ``torch.Generator`` seeded with ``seed`` is consumed in schema order, so
+    the result depends only on (schema, seed, torch's CPU Philox/MT stream).
+    Weights are fan-in scaled so that every layer roughly preserves variance.
+    """
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+
+    def randn(shape):
+        return torch.randn(shape, generator=g, dtype=torch.float32)
+
+    def rand(shape, lo, hi):
+        return torch.rand(shape, generator=g, dtype=torch.float32) * (hi - lo) + lo
+
+    for name, (shape, kind) in schema.items():
+        if kind in ("conv", "dw"):
+            fan_in = shape[1] * shape[2] * shape[3]
+            t = randn(shape) * math.sqrt(_conv_gain(name) / fan_in)
+        elif kind == "convT":
+            # ConvTranspose2d weight is (cin, cout, k, k); with k == stride each
+            # output pixel sees exactly cin inputs.
+            t = randn(shape) * math.sqrt(_conv_gain(name) / shape[0])
+        elif kind == "linear":
+            t = randn(shape) * math.sqrt(_linear_gain(name) / shape[1])
+        elif kind == "bias":
+            t = randn(shape) * 0.1
+        elif kind == "bn_w":
+            t = rand(shape, 0.25, 0.6) if _is_residual_branch_end(name) else rand(shape, 0.7, 1.3)
+        elif kind == "bn_b":
+            t = randn(shape) * 0.1
+        elif kind == "bn_m":
+            t = randn(shape) * 0.1
+        elif kind == "bn_v":
+            t = rand(shape, 0.5, 1.5)
+        elif kind == "bn_n":
+            t = torch.tensor(1000, dtype=torch.int64)
+        elif kind == "ln_w":
+            t = rand(shape, 0.8, 1.2)
+        elif kind == "ln_b":
+            t = randn(shape) * 0.05
+        elif kind == "embed":
+            t = randn(shape) * 0.5
+        elif kind == "gauss":
+            t = randn(shape)
+        else:  # pragma: no cover
+            raise ValueError(kind)
+        sd[name] = t
+    return sd
+
+
+def synthetic_state_dict(backbone_type: str = "efficientvit", model_name: str = "b1",
+                         seed: int = 0, enable_inst_interactivity: bool = True):
+    return init_state_dict(
+        image_path_schema(backbone_type, model_name, enable_inst_interactivity), seed)
+
+
+def shapes(schema: _Schema) -> Dict[str, Shape]:
+    return {k: v[0] for k, v in schema.items()}
+
+
+def param_count(schema: _Schema) -> int:
+    n = 0
+    for shape, kind in schema.values():
+        if kind != "bn_n":
+            n += int(math.prod(shape)) if shape else 1
+    return n

@@ -1,0 +1,67 @@
+"""Seeded synthetic inputs shared by tests, golden generation and bench.py.
+
+SURVEY.md §8(d) "Synthetic inputs": uniform-noise images (seed 0), smooth
+low-frequency sinusoid mixes (seed 1) so masks are not pure noise, and one
+positive point + one XYXY box per image (seed 2).  Everything is numpy
+``default_rng`` based so the byte streams are identical on every machine.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+NET_RES = 1008  # the network's native resolution (sam3_image_processor.py:17,27)
+
+
+def smooth_image_u8(seed: int = 1, size: int = NET_RES, n_waves: int = 8) -> np.ndarray:
+    """HWC uint8 image: per channel a sum of ``n_waves`` random low-frequency
+    sinusoids plus a little noise."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.arange(size, dtype=np.float64), np.arange(size, dtype=np.float64),
+                         indexing="ij")
+    img = np.zeros((size, size, 3), dtype=np.float64)
+    for c in range(3):
+        acc = np.zeros((size, size), dtype=np.float64)
+        for _ in range(n_waves):
+            fx, fy = rng.uniform(-6.0, 6.0, size=2) * (2 * np.pi / size)
+            ph = rng.uniform(0, 2 * np.pi)
+            amp = rng.uniform(0.3, 1.0)
+            acc += amp * np.sin(fx * xx + fy * yy + ph)
+        acc = (acc - acc.min()) / (acc.max() - acc.min() + 1e-12)
+        img[:, :, c] = acc
+    img = img * 235.0 + rng.uniform(0.0, 20.0, size=img.shape)
+    return np.clip(np.floor(img), 0, 255).astype(np.uint8)
+
+
+def noise_image_u8(seed: int = 0, size: int = NET_RES) -> np.ndarray:
+    return np.random.default_rng(seed).integers(0, 256, (size, size, 3), dtype=np.uint8)
+
+
+def image_batch_u8(batch: int, seed: int = 1, size: int = NET_RES) -> np.ndarray:
+    """[B,H,W,3] uint8: even indices smooth, odd indices noise."""
+    out = np.empty((batch, size, size, 3), dtype=np.uint8)
+    for i in range(batch):
+        out[i] = smooth_image_u8(seed + i, size) if i % 2 == 0 else noise_image_u8(seed + i, size)
+    return out
+
+
+def normalise_to_chw_f32(img_hwc_u8: np.ndarray) -> np.ndarray:
+    """Sam3Processor.transform for an already-1008^2 image: /255, (x-.5)/.5, CHW."""
+    x = img_hwc_u8.astype(np.float32) / np.float32(255.0)
+    x = (x - np.float32(0.5)) / np.float32(0.5)
+    return np.ascontiguousarray(np.moveaxis(x, -1, -3))
+
+
+def prompts(batch: int, seed: int = 2, size: int = NET_RES):
+    """Per image: one positive point uniform in [64, size-64)^2 and one XYXY box with
+    side >= 64 px.  Returns (points [B,1,2] f32, labels [B,1] i32, boxes [B,4] f32)."""
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(64, size - 64, size=(batch, 1, 2)).astype(np.float32)
+    labels = np.ones((batch, 1), dtype=np.int32)
+    x0 = rng.uniform(0, size - 128, size=(batch,))
+    y0 = rng.uniform(0, size - 128, size=(batch,))
+    bw = rng.uniform(64, size - 64, size=(batch,))
+    bh = rng.uniform(64, size - 64, size=(batch,))
+    x1 = np.minimum(x0 + bw, size - 1)
+    y1 = np.minimum(y0 + bh, size - 1)
+    boxes = np.stack([x0, y0, x1, y1], axis=1).astype(np.float32)
+    return pts, labels, boxes

@@ -1,0 +1,200 @@
+"""ORACLE tooling (test infrastructure only): pin ``oracle/ref_model.py`` against the
+REAL reference and generate the golden fixtures under ``tests/golden/``.
+
+Runs only in the build container, where ``/root/reference`` exists:
+
+    PYTHONDONTWRITEBYTECODE=1 CUDA_VISIBLE_DEVICES="" HIP_VISIBLE_DEVICES="" \
+    PYTHONPATH=oracle/shims:/root/reference/sam3:. python oracle/gen_golden.py
+
+What it does
+  1. builds the reference EV-M model (``build_efficientsam3_image_model``, CPU, fp32,
+     interactivity on) and loads the seeded synthetic state dict
+     (``efficientsam3_amd.schema.synthetic_state_dict(seed=0)``) -- every schema key
+     must be consumed (``unexpected_keys == []``);
+  2. runs ``Sam3Processor.set_image`` + ``model.predict_inst`` of the reference on
+     seeded synthetic inputs for a list of prompt cases;
+  3. runs ``oracle/ref_model.py`` on the same inputs and records max-abs-err per
+     stage boundary and per output (must be ~1e-5 or below: same fp32 math);
+  4. writes the REFERENCE's outputs as fixtures: strided samples + moments of every
+     stage tensor, low-res logits (fp32), IoU scores and bit-packed final masks.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from efficientsam3_amd import schema, synth  # noqa: E402
+from oracle import ref_model  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+SAMPLE = 4096  # strided sample length per stage tensor
+
+
+def sample(t: torch.Tensor) -> np.ndarray:
+    flat = t.detach().reshape(-1)
+    step = max(1, flat.numel() // SAMPLE)
+    return flat[::step][:SAMPLE].to(torch.float32).numpy().copy()
+
+
+def moments(t: torch.Tensor):
+    t = t.detach().double()
+    return [float(t.mean()), float(t.std()), float(t.abs().max())]
+
+
+def maxerr(a, b) -> float:
+    a = torch.as_tensor(np.asarray(a), dtype=torch.float64) if not torch.is_tensor(a) else a.double()
+    b = torch.as_tensor(np.asarray(b), dtype=torch.float64) if not torch.is_tensor(b) else b.double()
+    return float((a - b).abs().max())
+
+
+CASES = [
+    # name, orig_hw, kwargs for predict_inst
+    dict(name="point_multimask", hw=(1008, 1008),
+         kw=dict(point_coords=[[400.0, 520.0]], point_labels=[1], multimask_output=True)),
+    dict(name="box_single", hw=(1008, 1008),
+         kw=dict(box=[180.0, 240.0, 700.0, 820.0], multimask_output=False)),
+    dict(name="point_box_single", hw=(1008, 1008),
+         kw=dict(point_coords=[[450.0, 500.0]], point_labels=[1],
+                 box=[180.0, 240.0, 700.0, 820.0], multimask_output=False)),
+    dict(name="two_boxes_batched", hw=(1008, 1008),
+         kw=dict(box=[[100.0, 120.0, 500.0, 600.0], [420.0, 380.0, 960.0, 900.0]],
+                 multimask_output=False)),
+    dict(name="neg_pos_points_orig600x800", hw=(600, 800),
+         kw=dict(point_coords=[[300.0, 200.0], [640.0, 480.0]], point_labels=[1, 0],
+                 multimask_output=True)),
+    dict(name="point_logits_orig480x640", hw=(480, 640),
+         kw=dict(point_coords=[[320.0, 240.0]], point_labels=[1], multimask_output=False,
+                 return_logits=True)),
+]
+
+
+def np_kw(kw):
+    out = {}
+    for k, v in kw.items():
+        out[k] = np.asarray(v, dtype=np.float32 if k != "point_labels" else np.int32) \
+            if isinstance(v, list) else v
+    return out
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count() or 8)
+    os.makedirs(GOLD, exist_ok=True)
+    from sam3 import build_efficientsam3_image_model  # the REAL reference
+    from sam3.model.sam3_image_processor import Sam3Processor
+
+    t0 = time.time()
+    model = build_efficientsam3_image_model(
+        device="cpu", checkpoint_path=None, load_from_HF=False, enable_inst_interactivity=True,
+        backbone_type="efficientvit", model_name="b1", text_encoder_type="MobileCLIP-S0",
+        text_encoder_context_length=16)
+    sd = schema.synthetic_state_dict("efficientvit", "b1", seed=0)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected[:5]
+    print(f"reference built+loaded in {time.time() - t0:.1f}s; schema keys {len(sd)}; "
+          f"reference keys not in hot-path schema: {len(missing)}")
+    proc = Sam3Processor(model, device="cpu")
+
+    manifest = {"weights_seed": 0, "model": "efficientvit-b1", "cases": {}, "stages": {},
+                "oracle_vs_reference_maxabs": {}}
+
+    # ---- image 0: smooth synthetic, image 1: noise -------------------------------
+    imgs_u8 = [synth.smooth_image_u8(seed=1), synth.noise_image_u8(seed=3)]
+    for ii, img_u8 in enumerate(imgs_u8):
+        chw_u8 = torch.from_numpy(np.ascontiguousarray(np.moveaxis(img_u8, -1, 0)))
+        x = ref_model.normalise_image_u8(chw_u8)[None]
+        assert np.array_equal(x[0].numpy(), synth.normalise_to_chw_f32(img_u8))
+
+        # reference stage tensors
+        with torch.inference_mode():
+            t1 = time.time()
+            stages_ref = model.backbone.vision_backbone.trunk.model.backbone.model(x)
+            trunk_ref = model.backbone.vision_backbone.trunk(x)[0]
+            state = proc.set_image(chw_u8)
+            t_set = time.time() - t1
+        bo = state["backbone_out"]
+        ref_t = {f"stage{i}": stages_ref[f"stage{i}"] for i in range(5)}
+        ref_t["trunk"] = trunk_ref
+        for i in range(3):
+            ref_t[f"sam3_fpn{i}"] = bo["backbone_fpn"][i]
+            ref_t[f"sam2_fpn{i}"] = bo["sam2_backbone_out"]["backbone_fpn"][i]
+            ref_t[f"pos{i}"] = bo["vision_pos_enc"][i]
+
+        # oracle stage tensors
+        taps = {}
+        with torch.inference_mode():
+            t1 = time.time()
+            ostate = ref_model.set_image(sd, x, (1008, 1008), "b1", taps)
+            t_or = time.time() - t1
+        obo = ostate["backbone_out"]
+        or_t = {f"stage{i}": taps[f"stage{i}"] for i in range(5)}
+        or_t["trunk"] = taps["trunk"]
+        for i in range(3):
+            or_t[f"sam3_fpn{i}"] = obo["backbone_fpn"][i]
+            or_t[f"sam2_fpn{i}"] = obo["sam2_backbone_out"]["backbone_fpn"][i]
+            or_t[f"pos{i}"] = obo["vision_pos_enc"][i]
+        print(f"image {ii}: reference set_image {t_set:.2f}s, oracle {t_or:.2f}s")
+        arrays = {}
+        for k in ref_t:
+            e = maxerr(ref_t[k], or_t[k])
+            manifest["oracle_vs_reference_maxabs"][f"img{ii}/{k}"] = e
+            manifest["stages"][f"img{ii}/{k}"] = {"shape": list(ref_t[k].shape),
+                                                  "moments": moments(ref_t[k])}
+            arrays[k] = sample(ref_t[k])
+            print(f"  {k:12s} shape {tuple(ref_t[k].shape)} |ref| max {moments(ref_t[k])[2]:.3f} "
+                  f"oracle-ref maxabs {e:.2e}")
+        np.savez_compressed(os.path.join(GOLD, f"stages_img{ii}.npz"), **arrays)
+
+        if ii != 0:
+            continue
+        # ---- prompt cases on image 0 --------------------------------------------
+        for case in CASES:
+            h, w = case["hw"]
+            state["original_height"], state["original_width"] = h, w
+            ostate["original_height"], ostate["original_width"] = h, w
+            kw = np_kw(case["kw"])
+            with torch.inference_mode():
+                masks_r, iou_r, low_r = model.predict_inst(state, **kw)
+                masks_o, iou_o, low_o = ref_model.predict_inst(sd, ostate, **kw)
+            e_low, e_iou = maxerr(low_r, low_o), maxerr(iou_r, iou_o)
+            if kw.get("return_logits"):
+                e_mask = maxerr(masks_r, masks_o)
+                inter = np.logical_and(masks_r > 0, masks_o > 0).sum()
+                union = np.logical_or(masks_r > 0, masks_o > 0).sum()
+            else:
+                e_mask = float((masks_r != masks_o).mean())
+                inter = np.logical_and(masks_r > 0, masks_o > 0).sum()
+                union = np.logical_or(masks_r > 0, masks_o > 0).sum()
+            miou = float(inter / max(union, 1))
+            manifest["oracle_vs_reference_maxabs"][f"case/{case['name']}"] = {
+                "low_res": e_low, "iou": e_iou, "mask": e_mask, "mask_iou": miou}
+            print(f"  case {case['name']:28s} low_res shape {low_r.shape} range "
+                  f"[{low_r.min():.2f},{low_r.max():.2f}] fg {float((masks_r > 0).mean()):.3f} "
+                  f"oracle-ref: low {e_low:.2e} iou {e_iou:.2e} mask {e_mask:.2e} IoU {miou:.6f}")
+            out = {"low_res": low_r.astype(np.float32), "iou": iou_r.astype(np.float32),
+                   "mask_shape": np.asarray(masks_r.shape, dtype=np.int64)}
+            if kw.get("return_logits"):
+                out["mask_logits_sample"] = masks_r.reshape(-1)[::97].astype(np.float32)
+            out["mask_bits"] = np.packbits((masks_r > 0).reshape(-1))
+            np.savez_compressed(os.path.join(GOLD, f"case_{case['name']}.npz"), **out)
+            manifest["cases"][case["name"]] = {
+                "hw": [h, w],
+                "kw": {k: (v.tolist() if isinstance(v, np.ndarray) else v)
+                       for k, v in kw.items()},
+            }
+
+    with open(os.path.join(GOLD, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print("wrote", GOLD)
+
+
+if __name__ == "__main__":
+    main()
