@@ -1,0 +1,102 @@
+"""ctypes binding of ``libesam3_hip.so`` (C ABI declared in ``include/esam3.h``).
+
+There is deliberately no fallback: if the shared library is missing or fails to load the
+import raises -- the product path never routes through PyTorch CPU/eager code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libesam3_hip.so")
+
+ESAM3_F32 = 0
+ESAM3_BF16 = 1
+
+
+class Esam3Error(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("backbone", C.c_int), ("model_name", C.c_char * 16),
+                ("device", C.c_int), ("interactive", C.c_int)]
+
+
+class ImageFeatures(C.Structure):
+    _fields_ = [("sam3_fpn_dev", C.c_void_p * 3), ("sam2_fpn_dev", C.c_void_p * 3),
+                ("trunk_dev", C.c_void_p), ("stages_dev", C.c_void_p * 5)]
+
+
+class Prompts(C.Structure):
+    _fields_ = [("sam2_fpn_dev", C.c_void_p * 3), ("n_images", C.c_int), ("n_prompts", C.c_int),
+                ("prompt_image_dev", C.c_void_p), ("coords_dev", C.c_void_p),
+                ("labels_dev", C.c_void_p), ("n_points", C.c_int), ("mask_input_dev", C.c_void_p),
+                ("multimask_output", C.c_int)]
+
+
+class DecodeOut(C.Structure):
+    _fields_ = [("low_res_dev", C.c_void_p), ("iou_dev", C.c_void_p), ("obj_score_dev", C.c_void_p)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_F = C.c_float
+_FP = C.POINTER(C.c_float)
+
+# name -> (restype, argtypes); must list every symbol include/esam3.h declares
+SIGNATURES = {
+    "esam3_last_error": (C.c_char_p, []),
+    "esam3_create": (_I, [C.POINTER(Config), C.POINTER(_P)]),
+    "esam3_destroy": (None, [_P]),
+    "esam3_load_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(_L), _I]),
+    "esam3_finalize": (_I, [_P]),
+    "esam3_encode_image": (_I, [_P, _P, _I, C.POINTER(ImageFeatures), _P]),
+    "esam3_decode": (_I, [_P, C.POINTER(Prompts), C.POINTER(DecodeOut), _P]),
+    "esam3_postprocess_masks": (_I, [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P]),
+    "esam3_clamp_f32": (_I, [_P, _P, _L, _F, _F, _P]),
+    "esam3_workspace_bytes": (_L, [_P]),
+    "esam3_elem_size": (_I, [_P]),
+    "esam3_preprocess_u8": (_I, [_P, _P, _I, _I, _I, _P]),
+    "esam3_op_linear": (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "esam3_op_conv2d": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "esam3_op_conv_transpose2x2": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "esam3_op_dwconv": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "esam3_op_stem": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "esam3_op_lite_mla": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
+    "esam3_op_grouped_pw": (_I, [_I, _P, _P, _P, _L, _I, _I, _P]),
+    "esam3_op_resize_bilinear": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "esam3_op_layernorm": (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
+    "esam3_op_attention": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "esam3_op_fill_holes": (_I, [_P, _P, _I, _I, _I, _F, _F, _P]),
+    "esam3_op_upsample_masks": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "esam3_op_cast": (_I, [_I, _I, _P, _P, _L, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP extension (once).  Raises ``Esam3Error`` if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Esam3Error(
+            f"{LIB_PATH} is missing: build it with `python -c \"import __graft_entry__ as g; "
+            "g.build()\"` (or `make -C efficientsam3_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "esam3 call"):
+    if rc != 0:
+        msg = load().esam3_last_error()
+        raise Esam3Error(f"{what} failed: {msg.decode() if msg else 'unknown error'}")

@@ -1,0 +1,975 @@
+// Host-side engine: weight store (BN folding, GEMM packing), stack arena, and the
+// kernel graphs of the hot path (image encoder, prompt encoder + two-way mask decoder,
+// mask post-processing) behind the C ABI of include/esam3.h.
+//
+// Graph structure follows the reference module tree (file:line cited per function);
+// nothing here calls into PyTorch or any CPU fallback -- every tensor op is a HIP kernel
+// from gemm_conv.hip / kernels_backbone.hip / kernels_decoder.hip.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/esam3.h"
+#include "kernels.h"
+
+// --------------------------------------------------------------------------------------
+// error channel
+// --------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+void esam3_set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+extern "C" const char* esam3_last_error(void) { return g_err.c_str(); }
+
+#define CK(expr)            \
+  do {                      \
+    if ((expr) != 0) return -1; \
+  } while (0)
+
+namespace {
+
+constexpr int IMG = 1008;   // network resolution (sam3_image_processor.py:17)
+constexpr int EMB = 72;     // embedding grid (model_builder.py:913-919)
+constexpr int DM = 256;     // d_model
+constexpr int TRUNK_C = 1024;
+constexpr float BN_EPS = 1e-5f;
+
+const std::string TRUNK = "backbone.vision_backbone.trunk.model.";
+const std::string EVBB = TRUNK + "backbone.model.";
+const std::string NECK = "backbone.vision_backbone.";
+const std::string SAM = "inst_interactive_predictor.model.";
+const std::string MD = SAM + "sam_mask_decoder.";
+const std::string PE = SAM + "sam_prompt_encoder.";
+
+struct HostTensor {
+  std::vector<float> d;
+  std::vector<int64_t> shape;
+};
+
+struct PackedGemm {
+  void* w = nullptr;      // [Np][Kp] activation dtype
+  float* bias = nullptr;  // [N] (or [Cout] for convT) fp32
+  int N = 0, K = 0, Kp = 0, Np = 0, ksize = 1, cin = 0, convt_cout = 0;
+};
+struct PackedDw {
+  float* w = nullptr;  // [k*k][C]
+  float* bias = nullptr;
+  int C = 0, ks = 3;
+};
+
+struct T4 {  // NHWC activation view
+  void* p = nullptr;
+  int B = 0, H = 0, W = 0, C = 0;
+  int ld = 0;  // row stride in elements
+  int64_t rows() const { return (int64_t)B * H * W; }
+};
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, top = 0, peak = 0;
+  bool dry = false;
+  static size_t align(size_t x) { return (x + 255) & ~(size_t)255; }
+  void* alloc(size_t bytes) {
+    const size_t a = align(top);
+    top = a + bytes;
+    if (top > peak) peak = top;
+    if (dry) return reinterpret_cast<void*>(a + 4096);  // never dereferenced
+    if (top > cap) return nullptr;
+    return base + a;
+  }
+  size_t mark() const { return top; }
+  void release(size_t m) { top = m; }
+};
+
+}  // namespace
+
+struct esam3_engine {
+  esam3_config cfg{};
+  int dtype = 1;
+  size_t esz = 2;
+  std::vector<int> widths, depths;
+  int dim = 16;
+  std::unordered_map<std::string, HostTensor> raw;
+  std::unordered_map<std::string, PackedGemm> gemms;
+  std::unordered_map<std::string, PackedDw> dws;
+  std::unordered_map<std::string, float*> fbufs;
+  std::unordered_map<std::string, void*> tbufs;
+  std::vector<void*> owned;
+  Arena arena;
+  bool finalized = false;
+  bool dry = false;  // allocate + pack only, launch nothing
+  hipStream_t st = nullptr;
+
+  // ---------------- raw weight access ----------------
+  const HostTensor* find(const std::string& n) const {
+    auto it = raw.find(n);
+    return it == raw.end() ? nullptr : &it->second;
+  }
+  const HostTensor* need(const std::string& n) const {
+    const HostTensor* t = find(n);
+    if (!t) esam3_set_error("missing weight '%s'", n.c_str());
+    return t;
+  }
+
+  void* dev_upload(const void* src, size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 256) != hipSuccess) {
+      esam3_set_error("hipMalloc(%zu) failed", bytes);
+      return nullptr;
+    }
+    if (bytes && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+      esam3_set_error("hipMemcpy H2D failed");
+      return nullptr;
+    }
+    owned.push_back(p);
+    return p;
+  }
+  void* upload_T(const std::vector<float>& v) {  // host fp32 -> device activation dtype
+    if (dtype == 0) return dev_upload(v.data(), v.size() * 4);
+    std::vector<bf16_t> h(v.size());
+    for (size_t i = 0; i < v.size(); ++i) h[i] = f32_to_bf16(v[i]);
+    return dev_upload(h.data(), h.size() * 2);
+  }
+  float* fvec(const std::string& name) {  // upload a raw tensor as fp32 (cached)
+    auto it = fbufs.find(name);
+    if (it != fbufs.end()) return it->second;
+    const HostTensor* t = need(name);
+    if (!t) return nullptr;
+    float* p = (float*)dev_upload(t->d.data(), t->d.size() * 4);
+    fbufs[name] = p;
+    return p;
+  }
+  float* fvec_raw(const std::string& key, const std::vector<float>& v) {
+    auto it = fbufs.find(key);
+    if (it != fbufs.end()) return it->second;
+    float* p = (float*)dev_upload(v.data(), v.size() * 4);
+    fbufs[key] = p;
+    return p;
+  }
+
+  // BatchNorm (eval) folded into per-channel scale/shift: y = x*scale + shift
+  bool bn_fold(const std::string& bn, int C, std::vector<float>& scale, std::vector<float>& shift) {
+    scale.assign(C, 1.f);
+    shift.assign(C, 0.f);
+    if (bn.empty()) return true;
+    const HostTensor *g = need(bn + ".weight"), *b = need(bn + ".bias"),
+                     *m = need(bn + ".running_mean"), *v = need(bn + ".running_var");
+    if (!g || !b || !m || !v) return false;
+    for (int c = 0; c < C; ++c) {
+      const float s = g->d[c] / std::sqrt(v->d[c] + BN_EPS);
+      scale[c] = s;
+      shift[c] = b->d[c] - m->d[c] * s;
+    }
+    return true;
+  }
+
+  // dense conv (k = 1 or 3) [Cout][Cin][k][k] (+bias) (+BN) -> packed GEMM
+  PackedGemm* pk_conv(const std::string& wname, const std::string& bname, const std::string& bn) {
+    auto it = gemms.find(wname);
+    if (it != gemms.end()) return &it->second;
+    const HostTensor* w = need(wname);
+    if (!w) return nullptr;
+    const int N = (int)w->shape[0], cin = (int)w->shape[1], ks = (int)w->shape[2];
+    std::vector<float> scale, shift;
+    if (!bn_fold(bn, N, scale, shift)) return nullptr;
+    std::vector<float> bias(N, 0.f);
+    bool has_bias = !bn.empty();
+    if (!bname.empty()) {
+      const HostTensor* b = need(bname);
+      if (!b) return nullptr;
+      for (int n = 0; n < N; ++n) bias[n] = b->d[n] * scale[n];
+      has_bias = true;
+    }
+    for (int n = 0; n < N; ++n) bias[n] += shift[n];
+    PackedGemm g;
+    g.N = N; g.cin = cin; g.ksize = ks; g.K = cin * ks * ks;
+    g.Kp = esam3_gemm_pad_k(g.K, (int)esz);
+    g.Np = esam3_gemm_pad_n(N);
+    std::vector<float> pk((size_t)g.Np * g.Kp, 0.f);
+    for (int n = 0; n < N; ++n)
+      for (int c = 0; c < cin; ++c)
+        for (int t = 0; t < ks * ks; ++t)
+          pk[(size_t)n * g.Kp + (size_t)t * cin + c] = w->d[((size_t)n * cin + c) * ks * ks + t] * scale[n];
+    g.w = upload_T(pk);
+    g.bias = has_bias ? (float*)dev_upload(bias.data(), bias.size() * 4) : nullptr;
+    if (!g.w) return nullptr;
+    return &(gemms[wname] = g);
+  }
+  // ConvTranspose2d k2 s2: [Cin][Cout][2][2] -> GEMM with N = 4*Cout, n = tap*Cout + co
+  PackedGemm* pk_convT(const std::string& wname, const std::string& bname) {
+    auto it = gemms.find(wname);
+    if (it != gemms.end()) return &it->second;
+    const HostTensor* w = need(wname);
+    const HostTensor* b = need(bname);
+    if (!w || !b) return nullptr;
+    const int cin = (int)w->shape[0], cout = (int)w->shape[1];
+    PackedGemm g;
+    g.N = 4 * cout; g.cin = cin; g.ksize = 1; g.K = cin; g.convt_cout = cout;
+    g.Kp = esam3_gemm_pad_k(g.K, (int)esz);
+    g.Np = esam3_gemm_pad_n(g.N);
+    std::vector<float> pk((size_t)g.Np * g.Kp, 0.f);
+    for (int ci = 0; ci < cin; ++ci)
+      for (int co = 0; co < cout; ++co)
+        for (int t = 0; t < 4; ++t)
+          pk[((size_t)t * cout + co) * g.Kp + ci] = w->d[((size_t)ci * cout + co) * 4 + t];
+    g.w = upload_T(pk);
+    g.bias = (float*)dev_upload(b->d.data(), b->d.size() * 4);
+    if (!g.w) return nullptr;
+    return &(gemms[wname] = g);
+  }
+  PackedGemm* pk_linear(const std::string& prefix, bool bias = true) {
+    return pk_conv_like_linear(prefix + ".weight", bias ? prefix + ".bias" : "");
+  }
+  PackedGemm* pk_conv_like_linear(const std::string& wname, const std::string& bname) {
+    auto it = gemms.find(wname);
+    if (it != gemms.end()) return &it->second;
+    const HostTensor* w = need(wname);
+    if (!w) return nullptr;
+    const int N = (int)w->shape[0], K = (int)w->shape[1];
+    PackedGemm g;
+    g.N = N; g.cin = K; g.ksize = 1; g.K = K;
+    g.Kp = esam3_gemm_pad_k(K, (int)esz);
+    g.Np = esam3_gemm_pad_n(N);
+    std::vector<float> pk((size_t)g.Np * g.Kp, 0.f);
+    for (int n = 0; n < N; ++n)
+      for (int k = 0; k < K; ++k) pk[(size_t)n * g.Kp + k] = w->d[(size_t)n * K + k];
+    g.w = upload_T(pk);
+    if (!bname.empty()) {
+      const HostTensor* b = need(bname);
+      if (!b) return nullptr;
+      g.bias = (float*)dev_upload(b->d.data(), b->d.size() * 4);
+    }
+    if (!g.w) return nullptr;
+    return &(gemms[wname] = g);
+  }
+  PackedDw* pk_dw(const std::string& wname, const std::string& bname, const std::string& bn) {
+    auto it = dws.find(wname);
+    if (it != dws.end()) return &it->second;
+    const HostTensor* w = need(wname);
+    if (!w) return nullptr;
+    const int C = (int)w->shape[0], ks = (int)w->shape[2];
+    std::vector<float> scale, shift;
+    if (!bn_fold(bn, C, scale, shift)) return nullptr;
+    std::vector<float> pk((size_t)ks * ks * C), bias(C, 0.f);
+    for (int c = 0; c < C; ++c)
+      for (int t = 0; t < ks * ks; ++t) pk[(size_t)t * C + c] = w->d[(size_t)c * ks * ks + t] * scale[c];
+    bool has_bias = !bn.empty();
+    if (!bname.empty()) {
+      const HostTensor* b = need(bname);
+      if (!b) return nullptr;
+      for (int c = 0; c < C; ++c) bias[c] = b->d[c] * scale[c];
+      has_bias = true;
+    }
+    for (int c = 0; c < C; ++c) bias[c] += shift[c];
+    PackedDw d;
+    d.C = C; d.ks = ks;
+    d.w = (float*)dev_upload(pk.data(), pk.size() * 4);
+    d.bias = has_bias ? (float*)dev_upload(bias.data(), bias.size() * 4) : nullptr;
+    if (!d.w) return nullptr;
+    return &(dws[wname] = d);
+  }
+
+  // ---------------- arena helpers ----------------
+  T4 alloc4(int B, int H, int W, int C) {
+    T4 t;
+    t.B = B; t.H = H; t.W = W; t.C = C; t.ld = C;
+    t.p = arena.alloc((size_t)B * H * W * C * esz);
+    return t;
+  }
+  void* allocb(size_t bytes) { return arena.alloc(bytes); }
+  bool ok(const void* p) {
+    if (!p) esam3_set_error("workspace arena exhausted (cap %zu, need %zu)", arena.cap, arena.top);
+    return p != nullptr;
+  }
+
+  // ---------------- launch helpers ----------------
+  int gemm(const PackedGemm* g, const void* A, int lda, int64_t M, int H, int W, void* out, int ldc,
+           int act, const void* res = nullptr, int ldr = 0, int res_after_act = 1, int res_mod = 0,
+           const int* res_bidx = nullptr) {
+    if (!g) return -1;
+    if (dry) return 0;
+    GemmParams p{};
+    p.A = A; p.Wt = g->w; p.bias = g->bias; p.res = res; p.out = out;
+    p.M = M; p.N = g->N; p.K = g->K; p.Kp = g->Kp;
+    p.H = H; p.W = W; p.Cin = g->cin; p.ksize = g->ksize;
+    p.lda = lda; p.ldc = ldc; p.ldr = ldr; p.act = act; p.res_mod = res_mod;
+    p.out_mode = g->convt_cout ? OUT_CONVT2X2 : OUT_PLAIN;
+    p.convt_cout = g->convt_cout;
+    p.res_after_act = res_after_act;
+    p.res_bidx = res_bidx;
+    return esam3_launch_gemm(dtype, p, st);
+  }
+  // 1x1 / 3x3 conv on an NHWC view -> new tensor (or into `dst` if given)
+  int conv(const std::string& prefix, bool convlayer, const T4& x, int act, T4* y, const T4* res = nullptr,
+           const T4* dst = nullptr) {
+    // convlayer: EfficientViT ConvLayer naming (.conv.weight/.conv.bias/.norm.*); else plain nn.Conv2d
+    PackedGemm* g;
+    if (convlayer) {
+      const bool has_b = find(prefix + ".conv.bias") != nullptr;
+      const bool has_bn = find(prefix + ".norm.weight") != nullptr;
+      g = pk_conv(prefix + ".conv.weight", has_b ? prefix + ".conv.bias" : "", has_bn ? prefix + ".norm" : "");
+    } else {
+      const bool has_b = find(prefix + ".bias") != nullptr;
+      g = pk_conv(prefix + ".weight", has_b ? prefix + ".bias" : "", "");
+    }
+    if (!g) return -1;
+    if (g->cin != x.C) { esam3_set_error("conv %s: Cin %d != %d", prefix.c_str(), g->cin, x.C); return -1; }
+    if (dst) *y = *dst; else *y = alloc4(x.B, x.H, x.W, g->N);
+    if (!ok(y->p)) return -1;
+    return gemm(g, x.p, x.ld, x.rows(), x.H, x.W, y->p, y->ld, act, res ? res->p : nullptr, res ? res->ld : 0);
+  }
+  int convT(const std::string& prefix, const T4& x, int act, T4* y, const void* res = nullptr, int ldr = 0,
+            int res_after_act = 1, const int* res_bidx = nullptr) {
+    PackedGemm* g = pk_convT(prefix + ".weight", prefix + ".bias");
+    if (!g) return -1;
+    *y = alloc4(x.B, 2 * x.H, 2 * x.W, g->convt_cout);
+    if (!ok(y->p)) return -1;
+    return gemm(g, x.p, x.ld, x.rows(), x.H, x.W, y->p, y->ld, act, res, ldr, res_after_act, 0, res_bidx);
+  }
+  int dwconv(const std::string& prefix, bool convlayer, const T4& x, int stride, int act, T4* y) {
+    PackedDw* d;
+    if (convlayer) {
+      const bool has_b = find(prefix + ".conv.bias") != nullptr;
+      const bool has_bn = find(prefix + ".norm.weight") != nullptr;
+      d = pk_dw(prefix + ".conv.weight", has_b ? prefix + ".conv.bias" : "", has_bn ? prefix + ".norm" : "");
+    } else {
+      d = pk_dw(prefix + ".weight", find(prefix + ".bias") ? prefix + ".bias" : "", "");
+    }
+    if (!d) return -1;
+    *y = alloc4(x.B, (x.H + stride - 1) / stride, (x.W + stride - 1) / stride, x.C);
+    if (!ok(y->p)) return -1;
+    if (dry) return 0;
+    return esam3_launch_dwconv(dtype, x.p, x.ld, d->w, d->bias, y->p, y->ld, x.B, x.H, x.W, x.C, d->ks,
+                               stride, act, st);
+  }
+  int linear(const std::string& prefix, const void* A, int lda, int64_t M, void* out, int ldc, int act,
+             const void* res = nullptr, int ldr = 0, int res_mod = 0) {
+    PackedGemm* g = pk_linear(prefix);
+    if (!g) return -1;
+    return gemm(g, A, lda, M, 1, 1, out, ldc, act, res, ldr, 1, res_mod);
+  }
+  int layernorm(const std::string& prefix, const void* x, void* out, int64_t rows, int C, float eps,
+                int act = ACT_NONE) {
+    float* g = fvec(prefix + ".weight");
+    float* b = fvec(prefix + ".bias");
+    if (!g || !b) return -1;
+    if (dry) return 0;
+    return esam3_launch_layernorm(dtype, x, nullptr, g, b, out, rows, C, eps, act, st);
+  }
+
+  // ---------------- graphs ----------------
+  int mbconv(const std::string& p, const T4& x, int stride, bool residual, T4* y);
+  int evit_block(const std::string& p, const T4& x, T4* y);
+  int backbone(const float* img, int B, const esam3_image_features* out, T4* feat);
+  int neck(const std::string& which, const T4& trunk, void* const outs[3], bool sam2);
+  int encode(const float* img, int B, const esam3_image_features* out);
+  int decode(const esam3_prompts* pr, const esam3_decode_out* out);
+  int precompute_pe();
+  int ensure_arena(size_t need);
+};
+
+using E = esam3_engine;
+
+// MBConv (ops.py:315-367): 1x1 expand (+BN/bias, Hardswish) -> dw3x3 (stride) -> 1x1 project (+BN),
+// optional identity shortcut fused into the projection's epilogue (ops.py:761-770).
+int E::mbconv(const std::string& p, const T4& x, int stride, bool residual, T4* y) {
+  const HostTensor* pw = need(p + "point_conv.conv.weight");
+  if (!pw) return -1;
+  *y = alloc4(x.B, (x.H + stride - 1) / stride, (x.W + stride - 1) / stride, (int)pw->shape[0]);
+  if (!ok(y->p)) return -1;
+  const size_t mk = arena.mark();
+  T4 a, b, yy;
+  CK(conv(p + "inverted_conv", true, x, ACT_HSWISH, &a));
+  CK(dwconv(p + "depth_conv", true, a, stride, ACT_HSWISH, &b));
+  CK(conv(p + "point_conv", true, b, ACT_NONE, &yy, residual ? &x : nullptr, y));
+  arena.release(mk);
+  return 0;
+}
+
+// EfficientViTBlock (ops.py:674-733) = x + LiteMLA(x) ; then x + MBConv(x)
+int E::evit_block(const std::string& p, const T4& x, T4* y) {
+  const std::string c = p + "context_module.main.";
+  const HostTensor* qw = need(c + "qkv.conv.weight");
+  if (!qw) return -1;
+  const int total3 = (int)qw->shape[0];  // 3 * heads * dim
+  const int heads = total3 / (3 * dim);
+  T4 x1 = alloc4(x.B, x.H, x.W, x.C);
+  *y = alloc4(x.B, x.H, x.W, x.C);
+  if (!ok(x1.p) || !ok(y->p)) return -1;
+  const size_t mk = arena.mark();
+  {
+    // multi-scale qkv tensor [B,H,W, 2*total3]: [qkv | aggreg(qkv)]   (ops.py:656-662)
+    T4 ms = alloc4(x.B, x.H, x.W, 2 * total3);
+    if (!ok(ms.p)) return -1;
+    T4 qkv = ms;
+    qkv.C = total3;
+    T4 tmp;
+    CK(conv(c + "qkv", true, x, ACT_NONE, &tmp, nullptr, &qkv));
+    T4 agg;
+    CK(dwconv(c + "aggreg.0.0", false, qkv, 1, ACT_NONE, &agg));
+    {
+      const std::string wn = c + "aggreg.0.1.weight";
+      float* gw = fvec(wn);
+      if (!gw) return -1;
+      const int gs = (int)need(wn)->shape[1];
+      if (!dry)
+        CK(esam3_launch_grouped_pw(dtype, agg.p, agg.ld, gw, (char*)ms.p + (size_t)total3 * esz, ms.ld,
+                                   ms.rows(), total3, gs, st));
+    }
+    T4 att = alloc4(x.B, x.H, x.W, 2 * heads * dim);
+    float* kv = (float*)allocb(sizeof(float) * (size_t)x.B * 2 * heads * (dim + 1) * dim);
+    if (!ok(att.p) || !ok(kv)) return -1;
+    if (!dry)
+      CK(esam3_launch_lite_mla(dtype, ms.p, ms.ld, att.p, att.ld, kv, x.B, x.H * x.W, 2 * heads, dim, st));
+    T4 t2;
+    CK(conv(c + "proj", true, att, ACT_NONE, &t2, &x, &x1));
+  }
+  arena.release(mk);
+  {
+    const std::string m = p + "local_module.main.";
+    T4 a, b, t;
+    CK(conv(m + "inverted_conv", true, x1, ACT_HSWISH, &a));
+    CK(dwconv(m + "depth_conv", true, a, 1, ACT_HSWISH, &b));
+    CK(conv(m + "point_conv", true, b, ACT_NONE, &t, &x1, y));
+  }
+  arena.release(mk);
+  return 0;
+}
+
+// EfficientViTBackbone.forward -> stage_final (backbone.py:150-156)
+int E::backbone(const float* img, int B, const esam3_image_features* out, T4* feat) {
+  auto tap = [&](int i, const T4& t) -> int {
+    if (out && out->stages_dev[i] && !dry)
+      HIP_CHECK_RET(hipMemcpyAsync(out->stages_dev[i], t.p, (size_t)t.rows() * t.C * esz,
+                                   hipMemcpyDeviceToDevice, st));
+    return 0;
+  };
+  // E0 stem: 3x3 s2 conv + BN + Hardswish, straight from the NCHW fp32 input
+  T4 x = alloc4(B, IMG / 2, IMG / 2, widths[0]);
+  if (!ok(x.p)) return -1;
+  {
+    const std::string p = EVBB + "input_stem.op_list.0";
+    const std::string key = p + ".stem_packed";
+    float *sw = nullptr, *sb = nullptr;
+    auto it = fbufs.find(key);
+    if (it == fbufs.end()) {
+      const HostTensor* w = need(p + ".conv.weight");
+      if (!w) return -1;
+      std::vector<float> scale, shift;
+      if (!bn_fold(p + ".norm", widths[0], scale, shift)) return -1;
+      std::vector<float> pk(27 * (size_t)widths[0]);
+      for (int co = 0; co < widths[0]; ++co)
+        for (int c = 0; c < 3; ++c)
+          for (int t = 0; t < 9; ++t)
+            pk[(size_t)(t * 3 + c) * widths[0] + co] = w->d[((size_t)co * 3 + c) * 9 + t] * scale[co];
+      sw = fvec_raw(key, pk);
+      sb = fvec_raw(key + ".bias", shift);
+    } else {
+      sw = it->second;
+      sb = fbufs[key + ".bias"];
+    }
+    if (!sw || !sb) return -1;
+    if (!dry) CK(esam3_launch_stem(dtype, img, sw, sb, x.p, B, IMG, IMG, widths[0], ACT_HSWISH, st));
+  }
+  for (int i = 0; i < depths[0]; ++i) {  // Residual(DSConv)  ops.py:273-312
+    const std::string p = EVBB + "input_stem.op_list." + std::to_string(i + 1) + ".main.";
+    T4 y = alloc4(x.B, x.H, x.W, x.C);
+    if (!ok(y.p)) return -1;
+    const size_t mk = arena.mark();
+    T4 a, t;
+    CK(dwconv(p + "depth_conv", true, x, 1, ACT_HSWISH, &a));
+    CK(conv(p + "point_conv", true, a, ACT_NONE, &t, &x, &y));
+    arena.release(mk);
+    x = y;
+  }
+  CK(tap(0, x));
+  for (int si = 0; si < 2; ++si) {
+    for (int i = 0; i < depths[si + 1]; ++i) {
+      const std::string p = EVBB + "stages." + std::to_string(si) + ".op_list." + std::to_string(i) + ".main.";
+      T4 y;
+      CK(mbconv(p, x, i == 0 ? 2 : 1, i != 0, &y));
+      x = y;
+    }
+    CK(tap(si + 1, x));
+  }
+  for (int si = 2; si < 4; ++si) {
+    const std::string sp = EVBB + "stages." + std::to_string(si) + ".op_list.";
+    T4 y;
+    CK(mbconv(sp + "0.main.", x, 2, false, &y));
+    x = y;
+    for (int i = 0; i < depths[si + 1]; ++i) {
+      CK(evit_block(sp + std::to_string(i + 1) + ".", x, &y));
+      x = y;
+    }
+    CK(tap(si + 1, x));
+  }
+  *feat = x;
+  return 0;
+}
+
+// One SimpleFPN neck (necks.py:100-125), levels x4, x2, x1; level x0.5 is computed and
+// then dropped by the reference (vl_combiner.py:94-104, scalp=1) and has no observable
+// output, so it is not executed.  sam2=true additionally applies conv_s0 / conv_s1
+// (sam3_image_processor.py:62-75) and writes the 32/64-channel projections.
+int E::neck(const std::string& which, const T4& trunk, void* const outs[3], bool sam2) {
+  const std::string p = NECK + which + ".";
+  const int B = trunk.B;
+  auto outT = [&](void* ptr, int H, int C) {
+    T4 t;
+    t.p = ptr; t.B = B; t.H = H; t.W = H; t.C = C; t.ld = C;
+    return t;
+  };
+  const size_t mk = arena.mark();
+  if (outs[0]) {  // level 0: ConvT -> GELU -> ConvT -> 1x1 -> 3x3   @288
+    T4 a, b, c, d, t;
+    CK(convT(p + "0.dconv_2x2_0", trunk, ACT_GELU, &a));
+    CK(convT(p + "0.dconv_2x2_1", a, ACT_NONE, &b));
+    CK(conv(p + "0.conv_1x1", false, b, ACT_NONE, &c));
+    if (sam2) {
+      CK(conv(p + "0.conv_3x3", false, c, ACT_NONE, &d));
+      T4 o = outT(outs[0], 4 * EMB, 32);
+      CK(conv(MD + "conv_s0", false, d, ACT_NONE, &t, nullptr, &o));
+    } else {
+      T4 o = outT(outs[0], 4 * EMB, DM);
+      CK(conv(p + "0.conv_3x3", false, c, ACT_NONE, &t, nullptr, &o));
+    }
+    arena.release(mk);
+  }
+  if (outs[1]) {  // level 1: ConvT -> 1x1 -> 3x3   @144
+    T4 a, c, d, t;
+    CK(convT(p + "1.dconv_2x2", trunk, ACT_NONE, &a));
+    CK(conv(p + "1.conv_1x1", false, a, ACT_NONE, &c));
+    if (sam2) {
+      CK(conv(p + "1.conv_3x3", false, c, ACT_NONE, &d));
+      T4 o = outT(outs[1], 2 * EMB, 64);
+      CK(conv(MD + "conv_s1", false, d, ACT_NONE, &t, nullptr, &o));
+    } else {
+      T4 o = outT(outs[1], 2 * EMB, DM);
+      CK(conv(p + "1.conv_3x3", false, c, ACT_NONE, &t, nullptr, &o));
+    }
+    arena.release(mk);
+  }
+  if (outs[2]) {  // level 2: 1x1 -> 3x3   @72
+    T4 c, t;
+    CK(conv(p + "2.conv_1x1", false, trunk, ACT_NONE, &c));
+    T4 o = outT(outs[2], EMB, DM);
+    CK(conv(p + "2.conv_3x3", false, c, ACT_NONE, &t, nullptr, &o));
+    arena.release(mk);
+  }
+  return 0;
+}
+
+// SAM3VLBackbone.forward_image (vl_combiner.py:81-124) for a student trunk
+// (ImageStudentEncoder, model_builder.py:764-787).
+int E::encode(const float* img, int B, const esam3_image_features* out) {
+  arena.top = 0;
+  T4 feat;
+  CK(backbone(img, B, out, &feat));
+  // head: 1x1 (no bias) + BN + GELU, 3x3 + bias, bilinear 32 -> 72
+  T4 h1, h2;
+  {
+    PackedGemm* g = pk_conv(TRUNK + "head.0.weight", "", TRUNK + "head.1");
+    if (!g) return -1;
+    h1 = alloc4(feat.B, feat.H, feat.W, g->N);
+    if (!ok(h1.p)) return -1;
+    CK(gemm(g, feat.p, feat.ld, feat.rows(), feat.H, feat.W, h1.p, h1.ld, ACT_GELU));
+  }
+  CK(conv(TRUNK + "head.3", false, h1, ACT_NONE, &h2));
+  T4 trunk = h2;
+  if (h2.H != EMB || h2.W != EMB) {
+    trunk = alloc4(B, EMB, EMB, h2.C);
+    if (!ok(trunk.p)) return -1;
+    if (!dry) CK(esam3_launch_resize_bilinear(dtype, h2.p, trunk.p, B, h2.H, h2.W, EMB, EMB, h2.C, st));
+  }
+  if (out->trunk_dev && !dry)
+    HIP_CHECK_RET(hipMemcpyAsync(out->trunk_dev, trunk.p, (size_t)trunk.rows() * trunk.C * esz,
+                                 hipMemcpyDeviceToDevice, st));
+  if (out->sam3_fpn_dev[0] || out->sam3_fpn_dev[1] || out->sam3_fpn_dev[2])
+    CK(neck("convs", trunk, out->sam3_fpn_dev, false));
+  if (out->sam2_fpn_dev[0] || out->sam2_fpn_dev[1] || out->sam2_fpn_dev[2]) {
+    if (!cfg.interactive) { esam3_set_error("sam2 features requested but engine built with interactive=0"); return -1; }
+    CK(neck("sam2_convs", trunk, out->sam2_fpn_dev, true));
+  }
+  return 0;
+}
+
+// PositionEmbeddingRandom on the 72x72 grid (prompt_encoder.py:223-234) and its projections
+// through the k_proj / q_proj weights of the image-side cross attentions, so that
+// proj(keys + pe) = proj(keys) + PEproj is a residual in the GEMM epilogue.
+int E::precompute_pe() {
+  const HostTensor* g = need(PE + "pe_layer.positional_encoding_gaussian_matrix");
+  if (!g) return -1;
+  std::vector<float> pe((size_t)EMB * EMB * DM);
+  for (int y = 0; y < EMB; ++y)
+    for (int x = 0; x < EMB; ++x) {
+      const float cx = 2.f * (((float)x + 0.5f) / (float)EMB) - 1.f;
+      const float cy = 2.f * (((float)y + 0.5f) / (float)EMB) - 1.f;
+      for (int f = 0; f < 128; ++f) {
+        const float ang = 6.283185307179586f * (cx * g->d[f] + cy * g->d[128 + f]);
+        pe[((size_t)y * EMB + x) * DM + f] = std::sin(ang);
+        pe[((size_t)y * EMB + x) * DM + 128 + f] = std::cos(ang);
+      }
+    }
+  void* pe_dev = upload_T(pe);
+  if (!pe_dev) return -1;
+  tbufs["dense_pe"] = pe_dev;
+  const std::string names[5] = {
+      MD + "transformer.layers.0.cross_attn_token_to_image.k_proj",
+      MD + "transformer.layers.0.cross_attn_image_to_token.q_proj",
+      MD + "transformer.layers.1.cross_attn_token_to_image.k_proj",
+      MD + "transformer.layers.1.cross_attn_image_to_token.q_proj",
+      MD + "transformer.final_attn_token_to_image.k_proj"};
+  for (const auto& n : names) {
+    // weight-only copy of the projection (bias belongs to the main GEMM)
+    const HostTensor* w = need(n + ".weight");
+    if (!w) return -1;
+    const std::string key = n + ".weight#nobias";
+    raw[key] = *w;
+    PackedGemm* gm = pk_conv_like_linear(key, "");
+    if (!gm) return -1;
+    void* o = nullptr;
+    HIP_CHECK_RET(hipMalloc(&o, (size_t)EMB * EMB * gm->N * esz));
+    owned.push_back(o);
+    const bool was_dry = dry;
+    dry = false;
+    const int rc = gemm(gm, pe_dev, DM, (int64_t)EMB * EMB, 1, 1, o, gm->N, ACT_NONE);
+    dry = was_dry;
+    if (rc) return -1;
+    tbufs[n + "#pe"] = o;
+  }
+  HIP_CHECK_RET(hipStreamSynchronize(st));
+  return 0;
+}
+
+// Prompt encoder + MaskDecoder.forward (sam1_task_predictor.py:385-421, mask_decoder.py:107-242)
+int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
+  if (pr->mask_input_dev) { esam3_set_error("mask_input prompts are not supported by this build yet"); return -1; }
+  arena.top = 0;
+  const int Bp = pr->n_prompts, Np = pr->n_points;
+  const int pad = Np > 0 ? 1 : 0;  // _embed_points appends a pad point (prompt_encoder.py:84-88)
+  const int T = 6 + Np + pad;      // output tokens + points (boxes are passed as points) + pad
+  const int64_t P = (int64_t)EMB * EMB;
+  const int64_t TR = (int64_t)Bp * T;
+  const std::string tp = MD + "transformer.";
+
+  // ---- tokens (sparse prompt embeddings) ------------------------------------------------
+  void* tokens0 = allocb((size_t)TR * DM * esz);
+  void* queries = allocb((size_t)TR * DM * esz);
+  if (!ok(tokens0) || !ok(queries)) return -1;
+  {
+    const std::string key = "out_tokens_cat";
+    float* ot = nullptr;
+    auto it = fbufs.find(key);
+    if (it == fbufs.end()) {
+      const HostTensor *a = need(MD + "obj_score_token.weight"), *b = need(MD + "iou_token.weight"),
+                       *c = need(MD + "mask_tokens.weight");
+      if (!a || !b || !c) return -1;
+      std::vector<float> cat;
+      cat.insert(cat.end(), a->d.begin(), a->d.end());
+      cat.insert(cat.end(), b->d.begin(), b->d.end());
+      cat.insert(cat.end(), c->d.begin(), c->d.end());
+      ot = fvec_raw(key, cat);
+      std::vector<float> pemb;
+      for (int i = 0; i < 4; ++i) {
+        const HostTensor* e = need(PE + "point_embeddings." + std::to_string(i) + ".weight");
+        if (!e) return -1;
+        pemb.insert(pemb.end(), e->d.begin(), e->d.end());
+      }
+      fvec_raw("point_emb_cat", pemb);
+      const HostTensor *nm = need(SAM + "no_mem_embed"), *nk = need(PE + "no_mask_embed.weight");
+      if (!nm || !nk) return -1;
+      std::vector<float> cb(DM);
+      for (int i = 0; i < DM; ++i) cb[i] = nm->d[i] + nk->d[i];
+      fvec_raw("src_cbias", cb);
+    } else {
+      ot = it->second;
+    }
+    float* gauss = fvec(PE + "pe_layer.positional_encoding_gaussian_matrix");
+    float* nap = fvec(PE + "not_a_point_embed.weight");
+    if (!ot || !gauss || !nap) return -1;
+    if (!dry) {
+      CK(esam3_launch_build_tokens(dtype, ot, pr->coords_dev, pr->labels_dev, gauss, fbufs["point_emb_cat"],
+                                   nap, tokens0, Bp, Np, pad, (float)IMG, st));
+      HIP_CHECK_RET(hipMemcpyAsync(queries, tokens0, (size_t)TR * DM * esz, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  // ---- src = image_embed[img] + no_mem_embed + dense(no_mask) ------------------------------
+  void* keys = allocb((size_t)Bp * P * DM * esz);
+  if (!ok(keys)) return -1;
+  if (!dry)
+    CK(esam3_launch_gather_add(dtype, pr->sam2_fpn_dev[2], pr->prompt_image_dev, fbufs["src_cbias"], nullptr,
+                               keys, Bp, P, DM, st));
+
+  // scratch
+  void* qin = allocb((size_t)TR * DM * esz);
+  void* tq = allocb((size_t)TR * DM * esz);
+  void* tk = allocb((size_t)TR * DM * esz);
+  void* tv = allocb((size_t)TR * DM * esz);
+  void* ta = allocb((size_t)TR * DM * esz);
+  void* th = allocb((size_t)TR * 2048 * esz);
+  void* ik = allocb((size_t)Bp * P * 128 * esz);
+  void* iv = allocb((size_t)Bp * P * 128 * esz);
+  if (!ok(qin) || !ok(tq) || !ok(tk) || !ok(tv) || !ok(ta) || !ok(th) || !ok(ik) || !ok(iv)) return -1;
+
+  auto add = [&](const void* a, const void* b, void* o, int64_t n) -> int {
+    if (dry) return 0;
+    return esam3_launch_add(dtype, a, b, o, n, st);
+  };
+  auto ln = [&](const std::string& name, void* x, int64_t rows) -> int {
+    return layernorm(name, x, x, rows, DM, 1e-5f);
+  };
+  // token -> image cross attention, result added to queries and normalised
+  auto t2i = [&](const std::string& ap, const std::string& norm) -> int {
+    CK(add(queries, tokens0, qin, TR * DM));
+    CK(linear(ap + "q_proj", qin, DM, TR, tq, 128, ACT_NONE));
+    CK(linear(ap + "k_proj", keys, DM, Bp * P, ik, 128, ACT_NONE, tbufs[ap + "k_proj#pe"], 128, (int)P));
+    CK(linear(ap + "v_proj", keys, DM, Bp * P, iv, 128, ACT_NONE));
+    if (!dry) CK(esam3_launch_attn(dtype, tq, 128, ik, 128, iv, 128, ta, 128, Bp, T, (int)P, 8, 16, st));
+    CK(linear(ap + "out_proj", ta, 128, TR, queries, DM, ACT_NONE, queries, DM));
+    return ln(norm, queries, TR);
+  };
+
+  for (int li = 0; li < 2; ++li) {
+    const std::string lp = tp + "layers." + std::to_string(li) + ".";
+    // (1) token self attention (transformer.py:155-163)
+    const void* qk_in = queries;
+    if (li > 0) { CK(add(queries, tokens0, qin, TR * DM)); qk_in = qin; }
+    CK(linear(lp + "self_attn.q_proj", qk_in, DM, TR, tq, DM, ACT_NONE));
+    CK(linear(lp + "self_attn.k_proj", qk_in, DM, TR, tk, DM, ACT_NONE));
+    CK(linear(lp + "self_attn.v_proj", queries, DM, TR, tv, DM, ACT_NONE));
+    if (!dry) CK(esam3_launch_attn(dtype, tq, DM, tk, DM, tv, DM, ta, DM, Bp, T, T, 8, 32, st));
+    if (li == 0) CK(linear(lp + "self_attn.out_proj", ta, DM, TR, queries, DM, ACT_NONE));
+    else CK(linear(lp + "self_attn.out_proj", ta, DM, TR, queries, DM, ACT_NONE, queries, DM));
+    CK(ln(lp + "norm1", queries, TR));
+    // (2) tokens attend to the image (transformer.py:165-170)
+    CK(t2i(lp + "cross_attn_token_to_image.", lp + "norm2"));
+    // (3) MLP on tokens (transformer.py:172-175)
+    CK(linear(lp + "mlp.lin1", queries, DM, TR, th, 2048, ACT_RELU));
+    CK(linear(lp + "mlp.lin2", th, 2048, TR, queries, DM, ACT_NONE, queries, DM));
+    CK(ln(lp + "norm3", queries, TR));
+    // (4) image attends to the tokens (transformer.py:177-182)
+    const std::string ip = lp + "cross_attn_image_to_token.";
+    CK(add(queries, tokens0, qin, TR * DM));
+    CK(linear(ip + "q_proj", keys, DM, Bp * P, ik, 128, ACT_NONE, tbufs[ip + "q_proj#pe"], 128, (int)P));
+    CK(linear(ip + "k_proj", qin, DM, TR, tk, 128, ACT_NONE));
+    CK(linear(ip + "v_proj", queries, DM, TR, tv, 128, ACT_NONE));
+    if (!dry) CK(esam3_launch_attn_fewkeys(dtype, ik, 128, tk, 128, tv, 128, iv, 128, Bp, (int)P, T, 8, 16, st));
+    CK(linear(ip + "out_proj", iv, 128, Bp * P, keys, DM, ACT_NONE, keys, DM));
+    CK(ln(lp + "norm4", keys, Bp * P));
+  }
+  CK(t2i(tp + "final_attn_token_to_image.", tp + "norm_final_attn"));
+  // queries == hs [Bp][T][256]; keys == src [Bp][72*72][256]
+
+  // ---- upscaling with high-res features (mask_decoder.py:213-222) -------------------------
+  T4 src;
+  src.p = keys; src.B = Bp; src.H = EMB; src.W = EMB; src.C = DM; src.ld = DM;
+  T4 u1, u2;
+  CK(convT(MD + "output_upscaling.0", src, ACT_NONE, &u1, pr->sam2_fpn_dev[1], 64, 1, pr->prompt_image_dev));
+  CK(layernorm(MD + "output_upscaling.1", u1.p, u1.p, u1.rows(), u1.C, 1e-6f, ACT_GELU));
+  CK(convT(MD + "output_upscaling.3", u1, ACT_GELU, &u2, pr->sam2_fpn_dev[0], 32, 0, pr->prompt_image_dev));
+
+  // ---- hypernetwork MLPs, IoU head, object-score head (mask_decoder.py:224-242) ------------
+  void* hyper = allocb((size_t)Bp * 4 * 32 * esz);
+  void* h1 = allocb((size_t)Bp * DM * esz);
+  void* h2 = allocb((size_t)Bp * DM * esz);
+  void* iou4 = allocb((size_t)Bp * 8 * esz);
+  void* obj = allocb((size_t)Bp * 8 * esz);
+  float* all_masks = (float*)allocb(sizeof(float) * (size_t)Bp * 4 * 16 * P);
+  int* counters = (int*)allocb(sizeof(int) * 2 * (size_t)Bp);
+  if (!ok(hyper) || !ok(h1) || !ok(h2) || !ok(iou4) || !ok(obj) || !ok(all_masks) || !ok(counters)) return -1;
+  const size_t tok_stride = (size_t)DM * esz;
+  for (int i = 0; i < 4; ++i) {
+    const std::string hp = MD + "output_hypernetworks_mlps." + std::to_string(i) + ".layers.";
+    const char* tok = (const char*)queries + (size_t)(2 + i) * tok_stride;  // mask token i of every prompt
+    CK(linear(hp + "0", tok, T * DM, Bp, h1, DM, ACT_RELU));
+    CK(linear(hp + "1", h1, DM, Bp, h2, DM, ACT_RELU));
+    CK(linear(hp + "2", h2, DM, Bp, (char*)hyper + (size_t)i * 32 * esz, 4 * 32, ACT_NONE));
+  }
+  {
+    const std::string hp = MD + "iou_prediction_head.layers.";
+    const char* tok = (const char*)queries + (size_t)1 * tok_stride;
+    CK(linear(hp + "0", tok, T * DM, Bp, h1, DM, ACT_RELU));
+    CK(linear(hp + "1", h1, DM, Bp, h2, DM, ACT_RELU));
+    CK(linear(hp + "2", h2, DM, Bp, iou4, 8, ACT_SIGMOID));
+  }
+  {
+    const std::string hp = MD + "pred_obj_score_head.layers.";
+    CK(linear(hp + "0", queries, T * DM, Bp, h1, DM, ACT_RELU));
+    CK(linear(hp + "1", h1, DM, Bp, h2, DM, ACT_RELU));
+    CK(linear(hp + "2", h2, DM, Bp, obj, 8, ACT_NONE));
+  }
+  const int64_t P4 = 16 * P;  // 288 * 288
+  if (!dry) {
+    CK(esam3_launch_mask_product(dtype, hyper, 32, u2.p, all_masks, Bp, P4, 32, st));
+    CK(esam3_launch_select_masks(dtype, all_masks, iou4, 8, out->low_res_dev, out->iou_dev, counters, Bp, P4,
+                                 pr->multimask_output, 0.05f, 0.98f, st));
+    if (out->obj_score_dev) CK(esam3_launch_strided_to_f32(dtype, obj, 8, out->obj_score_dev, Bp, st));
+  }
+  return 0;
+}
+
+int E::ensure_arena(size_t need_bytes) {
+  if (need_bytes <= arena.cap) return 0;
+  if (arena.base) {
+    HIP_CHECK_RET(hipDeviceSynchronize());
+    HIP_CHECK_RET(hipFree(arena.base));
+    arena.base = nullptr;
+    arena.cap = 0;
+  }
+  const size_t cap = need_bytes + (need_bytes >> 4) + (1 << 20);
+  void* p = nullptr;
+  if (hipMalloc(&p, cap) != hipSuccess) {
+    esam3_set_error("hipMalloc of %zu-byte workspace failed", cap);
+    return -1;
+  }
+  arena.base = (char*)p;
+  arena.cap = cap;
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------
+// C ABI
+// --------------------------------------------------------------------------------------
+extern "C" {
+
+int esam3_create(const esam3_config* cfg, esam3_engine** out) {
+  if (!cfg || !out) { esam3_set_error("esam3_create: null argument"); return -1; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    esam3_set_error("no HIP device available (the engine has no CPU fallback)");
+    return -1;
+  }
+  if (cfg->device < 0 || cfg->device >= ndev) { esam3_set_error("bad device ordinal %d", cfg->device); return -1; }
+  HIP_CHECK_RET(hipSetDevice(cfg->device));
+  if (cfg->backbone != ESAM3_BACKBONE_EFFICIENTVIT) { esam3_set_error("unsupported backbone %d", cfg->backbone); return -1; }
+  esam3_engine* e = new esam3_engine();
+  e->cfg = *cfg;
+  e->dtype = cfg->dtype == ESAM3_F32 ? 0 : 1;
+  e->esz = e->dtype == 0 ? 4 : 2;
+  const std::string mn(cfg->model_name);
+  if (mn == "b0") { e->widths = {8, 16, 32, 64, 128}; e->depths = {1, 2, 2, 2, 2}; e->dim = 16; }
+  else if (mn == "b1") { e->widths = {16, 32, 64, 128, 256}; e->depths = {1, 2, 3, 3, 4}; e->dim = 16; }
+  else if (mn == "b2") { e->widths = {24, 48, 96, 192, 384}; e->depths = {1, 3, 4, 4, 6}; e->dim = 32; }
+  else { esam3_set_error("unknown EfficientViT model '%s'", mn.c_str()); delete e; return -1; }
+  *out = e;
+  return 0;
+}
+
+void esam3_destroy(esam3_engine* e) {
+  if (!e) return;
+  hipDeviceSynchronize();
+  for (void* p : e->owned) hipFree(p);
+  if (e->arena.base) hipFree(e->arena.base);
+  delete e;
+}
+
+int esam3_load_weight(esam3_engine* e, const char* name, const float* data, const int64_t* shape, int ndim) {
+  if (!e || !name || !data) { esam3_set_error("esam3_load_weight: null argument"); return -1; }
+  if (e->finalized) { esam3_set_error("esam3_load_weight after esam3_finalize"); return -1; }
+  HostTensor t;
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= shape[i]; }
+  t.d.assign(data, data + n);
+  e->raw[name] = std::move(t);
+  return 0;
+}
+
+int esam3_finalize(esam3_engine* e) {
+  if (!e) { esam3_set_error("null engine"); return -1; }
+  HIP_CHECK_RET(hipSetDevice(e->cfg.device));
+  // dry run of both graphs at B = 1: packs every weight the graphs touch
+  e->dry = true;
+  e->arena.dry = true;
+  esam3_image_features f{};
+  void* dummy = reinterpret_cast<void*>(4096);
+  for (int i = 0; i < 3; ++i) f.sam3_fpn_dev[i] = dummy;
+  if (e->cfg.interactive) for (int i = 0; i < 3; ++i) f.sam2_fpn_dev[i] = dummy;
+  int rc = e->encode(nullptr, 1, &f);
+  if (rc == 0 && e->cfg.interactive) {
+    esam3_prompts pr{};
+    pr.n_images = 1; pr.n_prompts = 1; pr.n_points = 1;
+    esam3_decode_out o{};
+    rc = e->decode(&pr, &o);
+  }
+  e->dry = false;
+  e->arena.dry = false;
+  e->arena.top = e->arena.peak = 0;
+  if (rc) return -1;
+  if (e->cfg.interactive) CK(e->precompute_pe());
+  e->finalized = true;
+  return 0;
+}
+
+static int run_sized(esam3_engine* e, void* stream, const std::function<int()>& graph) {
+  // pass 1 (dry): measure arena peak; pass 2: launch
+  e->st = (hipStream_t)stream;
+  e->dry = true; e->arena.dry = true; e->arena.peak = 0;
+  int rc = graph();
+  e->dry = false; e->arena.dry = false;
+  if (rc) return -1;
+  CK(e->ensure_arena(e->arena.peak));
+  return graph();
+}
+
+int esam3_encode_image(esam3_engine* e, const float* img, int B, const esam3_image_features* out, void* stream) {
+  if (!e || !out || !img || B <= 0) { esam3_set_error("esam3_encode_image: bad argument"); return -1; }
+  if (!e->finalized) { esam3_set_error("esam3_finalize has not been called"); return -1; }
+  return run_sized(e, stream, [&]() { return e->encode(img, B, out); });
+}
+
+int esam3_decode(esam3_engine* e, const esam3_prompts* pr, const esam3_decode_out* out, void* stream) {
+  if (!e || !pr || !out) { esam3_set_error("esam3_decode: null argument"); return -1; }
+  if (!e->finalized || !e->cfg.interactive) { esam3_set_error("engine not finalized / not interactive"); return -1; }
+  if (pr->n_prompts <= 0 || pr->n_points < 0 || !pr->prompt_image_dev || !out->low_res_dev || !out->iou_dev) {
+    esam3_set_error("esam3_decode: bad prompt/out description");
+    return -1;
+  }
+  if (pr->n_points > 0 && (!pr->coords_dev || !pr->labels_dev)) { esam3_set_error("esam3_decode: null coords/labels"); return -1; }
+  return run_sized(e, stream, [&]() { return e->decode(pr, out); });
+}
+
+int esam3_postprocess_masks(esam3_engine* e, const float* low_res, int n, int oh, int ow, float max_hole_area,
+                            float thr, uint8_t* masks_u8, float* masks_logits, void* stream) {
+  if (!e || !low_res || n <= 0) { esam3_set_error("esam3_postprocess_masks: bad argument"); return -1; }
+  const int LR = 4 * EMB;
+  const size_t px = (size_t)n * LR * LR;
+  return run_sized(e, stream, [&]() -> int {
+    e->arena.top = 0;
+    const float* src = low_res;
+    if (max_hole_area > 0.f) {
+      float* filled = (float*)e->allocb(px * 4);
+      int* labels = (int*)e->allocb(px * 4);
+      int* areas = (int*)e->allocb(px * 4);
+      if (!e->ok(filled) || !e->ok(labels) || !e->ok(areas)) return -1;
+      if (!e->dry) CK(esam3_launch_fill_holes(low_res, filled, labels, areas, n, LR, LR, thr, max_hole_area, e->st));
+      src = filled;
+    }
+    if (!e->dry) CK(esam3_launch_upsample_masks(src, masks_logits, masks_u8, n, LR, LR, oh, ow, thr, e->st));
+    return 0;
+  });
+}
+
+int esam3_clamp_f32(esam3_engine* e, float* x, int64_t n, float lo, float hi, void* stream) {
+  (void)e;
+  return esam3_launch_clamp(x, n, lo, hi, (hipStream_t)stream);
+}
+
+int esam3_preprocess_u8(const uint8_t* in, float* out, int B, int H, int W, void* stream) {
+  if (!in || !out || B <= 0) { esam3_set_error("esam3_preprocess_u8: bad argument"); return -1; }
+  return esam3_launch_preprocess_u8(in, out, B, H, W, (hipStream_t)stream);
+}
+
+int64_t esam3_workspace_bytes(const esam3_engine* e) { return e ? (int64_t)e->arena.cap : 0; }
+int esam3_elem_size(const esam3_engine* e) { return e ? (int)e->esz : 0; }
+
+}  // extern "C"

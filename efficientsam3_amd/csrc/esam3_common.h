@@ -1,0 +1,92 @@
+// Shared device/host definitions for the EfficientSAM3 gfx950 engine.
+// Activations are NHWC; element type T is `float` (validation mode) or bf16
+// stored as uint16_t (throughput mode).  All accumulation is fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_v;
+typedef __attribute__((ext_vector_type(16))) float f32x16_v;
+typedef __attribute__((ext_vector_type(4))) float f32x4_v;
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_HSWISH = 3, ACT_SIGMOID = 4 };
+
+__host__ __device__ inline float bf16_to_f32(bf16_t v) {
+  union { uint32_t u; float f; } x;
+  x.u = ((uint32_t)v) << 16;
+  return x.f;
+}
+__host__ __device__ inline bf16_t f32_to_bf16(float f) {  // round-to-nearest-even
+  union { uint32_t u; float f; } x;
+  x.f = f;
+  uint32_t u = x.u;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct ElemOps;
+template <> struct ElemOps<float> {
+  static __host__ __device__ inline float ld(float v) { return v; }
+  static __host__ __device__ inline float st(float v) { return v; }
+};
+template <> struct ElemOps<bf16_t> {
+  static __host__ __device__ inline float ld(bf16_t v) { return bf16_to_f32(v); }
+  static __host__ __device__ inline bf16_t st(float v) { return f32_to_bf16(v); }
+};
+template <typename T> __host__ __device__ inline float to_f32(T v) { return ElemOps<T>::ld(v); }
+template <typename T> __host__ __device__ inline T from_f32(float v) { return ElemOps<T>::st(v); }
+
+__device__ inline float act_apply(float x, int act) {
+  switch (act) {
+    case ACT_RELU: return x > 0.f ? x : 0.f;
+    case ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));  // exact erf GELU
+    case ACT_HSWISH: {  // x * relu6(x + 3) / 6
+      float r = fminf(fmaxf(x + 3.f, 0.f), 6.f);
+      return x * r * (1.f / 6.f);
+    }
+    case ACT_SIGMOID: return 1.f / (1.f + expf(-x));
+    default: return x;
+  }
+}
+
+// ---- implicit-GEMM convolution / linear ------------------------------------------
+// out[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias[n] ) (+ res)
+//   m = flattened (b, oh, ow) output pixel (or token row), n = output channel,
+//   k = (tap, cin) with cin fastest; Wt is packed [Np][Kp] K-contiguous, zero padded.
+enum OutMode { OUT_PLAIN = 0, OUT_CONVT2X2 = 1 };
+
+struct GemmParams {
+  const void* A;      // activations, NHWC, row stride `lda` elements
+  const void* Wt;     // packed weights [Np][Kp]
+  const float* bias;  // [N] fp32 (BN folded) or nullptr
+  const void* res;    // residual, indexed like `out` (or by m % res_mod) or nullptr
+  void* out;
+  int64_t M;          // rows (B*OH*OW)
+  int N, K, Kp;       // logical out channels, logical K, padded K
+  int H, W, Cin;      // input spatial dims and channels (3x3 gather); H*W = pixels/img
+  int ksize;          // 1 or 3 (stride 1, pad ksize/2)
+  int lda;            // input row stride in elements (>= Cin)
+  int ldc;            // output row stride in elements
+  int ldr;            // residual row stride in elements
+  int act;            // Act
+  int res_mod;        // >0: residual row = m % res_mod (batch-broadcast residual)
+  int out_mode;       // OutMode
+  int convt_cout;     // OUT_CONVT2X2: Cout per tap (N == 4*Cout)
+  int res_after_act;  // 1: out = act(acc+bias) + res ; 0: out = act(acc+bias+res)
+  const int* res_bidx;  // optional: residual batch index per output batch item (gather)
+};
+
+// ---- error handling ---------------------------------------------------------------
+void esam3_set_error(const char* fmt, ...);
+#define HIP_CHECK_RET(expr)                                                        \
+  do {                                                                             \
+    hipError_t _e = (expr);                                                        \
+    if (_e != hipSuccess) {                                                        \
+      esam3_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                      __FILE__, __LINE__);                                         \
+      return -1;                                                                   \
+    }                                                                              \
+  } while (0)

@@ -1,0 +1,92 @@
+// Host-callable launchers of the non-GEMM kernels (definitions in *.hip).
+// dtype: 0 = f32 activations, 1 = bf16 activations.  All tensors NHWC / row-major.
+#pragma once
+#include "esam3_common.h"
+
+int esam3_gemm_pad_n(int N);
+int esam3_gemm_pad_k(int K, int elem_size);
+int esam3_launch_gemm(int dtype, const GemmParams& p, hipStream_t stream);
+
+// E0: stem 3x3/s2 conv on the NCHW fp32 network input -> NHWC T, + bias + Hardswish.
+int esam3_launch_stem(int dtype, const float* img_nchw, const float* w /*[27][Cout]*/,
+                      const float* bias, void* out, int B, int H, int W, int Cout, int act,
+                      hipStream_t s);
+
+// depthwise k x k (k in {3,5}), stride in {1,2}, pad k/2.  w: fp32 [k*k][C]; bias fp32 or null.
+int esam3_launch_dwconv(int dtype, const void* in, int ld_in, const float* w, const float* bias,
+                        void* out, int ld_out, int B, int H, int W, int C, int ksize, int stride,
+                        int act, hipStream_t s);
+
+// grouped 1x1 conv with `gs` in/out channels per group (LiteMLA aggreg.0.1), no bias.
+// w: fp32 [C/gs][gs out][gs in].
+int esam3_launch_grouped_pw(int dtype, const void* in, int ld_in, const float* w, void* out,
+                            int ld_out, int64_t rows, int C, int gs, hipStream_t s);
+
+// LiteMLA ReLU linear attention (ops.py:584-621).  ms: [B][N][ld] with `groups` groups of
+// (q|k|v) x dim channels; kv: fp32 scratch [B][groups][dim+1][dim]; out: [B][N][ld_out].
+int esam3_launch_lite_mla(int dtype, const void* ms, int ld, void* out, int ld_out, float* kv,
+                          int B, int N, int groups, int dim, hipStream_t s);
+
+// bilinear resize, align_corners=False (F.interpolate), NHWC T -> NHWC T.
+int esam3_launch_resize_bilinear(int dtype, const void* in, void* out, int B, int IH, int IW,
+                                 int OH, int OW, int C, hipStream_t s);
+
+// y = act(LN(x (+ res))) over the last dim C (biased variance), one wavefront per row.
+int esam3_launch_layernorm(int dtype, const void* x, const void* res, const float* gamma,
+                           const float* beta, void* out, int64_t rows, int C, float eps, int act,
+                           hipStream_t s);
+
+// out[bp][p][c] = in[src_img[bp]][p][c] + cbias[c] (+ dense[bp][p][c])
+int esam3_launch_gather_add(int dtype, const void* in, const int* src_img, const float* cbias,
+                            const void* dense, void* out, int Bp, int64_t P, int C, hipStream_t s);
+
+// softmax attention, few queries vs many keys (token -> image):  q [Bq][Nq][ldq] etc.
+int esam3_launch_attn(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v,
+                      int ldv, void* o, int ldo, int B, int Nq, int Nk, int heads, int hd,
+                      hipStream_t s);
+// softmax attention, many queries vs few keys (image -> token), Nk <= 64.
+int esam3_launch_attn_fewkeys(int dtype, const void* q, int ldq, const void* k, int ldk,
+                              const void* v, int ldv, void* o, int ldo, int B, int Nq, int Nk,
+                              int heads, int hd, hipStream_t s);
+
+// tokens[bp] = [obj | iou | mask x4 | sparse prompt embeddings]  (prompt_encoder.py:74-118,
+// mask_decoder.py:177-197).  coords: [Bp][Np][2] in network pixels (NOT yet +0.5),
+// labels [Bp][Np] in {-1,0,1,2,3}; a pad point (label -1) is appended when `pad`.
+int esam3_launch_build_tokens(int dtype, const float* out_tokens /*[6][256]*/,
+                              const float* coords, const int* labels, const float* gauss /*[2][128]*/,
+                              const float* point_emb /*[4][256]*/, const float* not_a_point /*[256]*/,
+                              void* tokens, int Bp, int Np, int pad, float img_size, hipStream_t s);
+
+// masks[bp][k][p] = sum_c hyper[bp][k][c] * up[bp][p][c]   (k < 4, c < 32), fp32 out.
+int esam3_launch_mask_product(int dtype, const void* hyper, int ld_h, const void* up, float* masks,
+                              int Bp, int64_t P, int C, hipStream_t s);
+
+// output selection (mask_decoder.py:142-163,244-292).  all_masks [Bp][4][P] fp32, all_iou [Bp][4]
+// (T).  multimask: out = masks 1..3; else dynamic stability fallback.  counters: int[2*Bp] scratch.
+int esam3_launch_select_masks(int dtype, const float* all_masks, const void* all_iou, int ld_iou,
+                              float* out_masks, float* out_iou, int* counters, int Bp, int64_t P,
+                              int multimask, float delta, float thresh, hipStream_t s);
+
+// post-processing (sam1_utils.py:77-119): fill background holes (8-connected components of
+// score <= thr with area <= max_area) with thr + 10.  labels: int32 scratch [n][H*W] x2.
+int esam3_launch_fill_holes(const float* in, float* out, int* labels, int* areas, int n, int H,
+                            int W, float thr, float max_area, hipStream_t s);
+
+// bilinear upsample of fp32 masks [n][IH][IW] -> [n][OH][OW]; optionally threshold to u8.
+int esam3_launch_upsample_masks(const float* in, float* out_f32, uint8_t* out_u8, int n, int IH,
+                                int IW, int OH, int OW, float thr, hipStream_t s);
+
+// out = a + b (elementwise, activation dtype)
+int esam3_launch_add(int dtype, const void* a, const void* b, void* out, int64_t n, hipStream_t s);
+// out[i] = f32(in[i * ld]) for i < n
+int esam3_launch_strided_to_f32(int dtype, const void* in, int ld, float* out, int64_t n, hipStream_t s);
+// clamp fp32 buffer in place to [lo, hi]
+int esam3_launch_clamp(float* x, int64_t n, float lo, float hi, hipStream_t s);
+// dtype conversion helpers
+int esam3_launch_cast_to_f32(int dtype, const void* in, float* out, int64_t n, hipStream_t s);
+int esam3_launch_cast_from_f32(int dtype, const float* in, void* out, int64_t n, hipStream_t s);
+// NHWC T -> NCHW fp32 (API boundary helper for callers that need the reference layout)
+int esam3_launch_nhwc_to_nchw_f32(int dtype, const void* in, float* out, int B, int H, int W, int C,
+                                  hipStream_t s);
+// uint8 HWC -> fp32 NCHW, x/255 then (x-0.5)/0.5
+int esam3_launch_preprocess_u8(const uint8_t* in, float* out, int B, int H, int W, hipStream_t s);

@@ -1,0 +1,549 @@
+// HBM-bound kernels of the student image encoder (EfficientViT family) and shared
+// elementwise helpers.  NHWC activations, 16-byte (8 x bf16 / 2x4 x f32) channel vectors
+// per lane so that a wavefront's accesses are contiguous along C.
+#include "kernels.h"
+
+namespace {
+
+constexpr int VEC = 8;  // channels per thread for vectorised NHWC kernels
+
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16_t> {
+  static __device__ inline void load(const bf16_t* p, float* v) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ inline void store(bf16_t* p, const float* v) {
+    uint4 o;
+    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+    o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = o;
+  }
+};
+template <> struct Vec8<float> {
+  static __device__ inline void load(const float* p, float* v) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ inline void store(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+
+// ------------------------------------------------------------------------------------
+// E0 stem: 3x3 stride-2 pad-1 conv, Cin = 3, NCHW fp32 in -> NHWC T out
+// (efficientvit/backbone.py:48-56).  One thread per output pixel, Cout <= 32.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void stem_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                            const float* __restrict__ bias, T* __restrict__ out, int B, int H, int W,
+                            int Cout, int act) {
+  __shared__ float sw[27 * 32];
+  __shared__ float sb[32];
+  for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) sw[i] = w[i];
+  for (int i = threadIdx.x; i < Cout; i += blockDim.x) sb[i] = bias ? bias[i] : 0.f;
+  __syncthreads();
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const int64_t total = (int64_t)B * OH * OW;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int ow = (int)(idx % OW);
+  const int oh = (int)((idx / OW) % OH);
+  const int64_t b = idx / ((int64_t)OW * OH);
+  float x[27];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ih = 2 * oh + kh - 1, iw = 2 * ow + kw - 1;
+        const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        x[(kh * 3 + kw) * 3 + c] = ok ? img[((b * 3 + c) * H + ih) * (int64_t)W + iw] : 0.f;
+      }
+  T* o = out + idx * Cout;
+  for (int co0 = 0; co0 < Cout; co0 += VEC) {
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = sb[co0 + e];
+#pragma unroll
+    for (int k = 0; k < 27; ++k)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] = fmaf(x[k], sw[k * Cout + co0 + e], acc[e]);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = act_apply(acc[e], act);
+    Vec8<T>::store(o + co0, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// depthwise k x k conv (k = 3 or 5), stride 1 or 2, pad k/2, + bias + activation
+// (DSConv / MBConv depth_conv, ops.py:290-299,344-353; LiteMLA aggreg.0.0, ops.py:560-567).
+// thread = (output pixel, 8-channel group); channel groups are the fastest index.
+// ------------------------------------------------------------------------------------
+template <typename T, int KS>
+__global__ void dwconv_kernel(const T* __restrict__ in, int ld_in, const float* __restrict__ w,
+                              const float* __restrict__ bias, T* __restrict__ out, int ld_out, int B,
+                              int H, int W, int C, int stride, int act) {
+  const int CG = C / VEC;
+  const int OH = (H + stride - 1) / stride, OW = (W + stride - 1) / stride;
+  const int64_t total = (int64_t)B * OH * OW * CG;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = (int)(idx % CG);
+  const int64_t pix = idx / CG;
+  const int ow = (int)(pix % OW);
+  const int oh = (int)((pix / OW) % OH);
+  const int64_t b = pix / ((int64_t)OW * OH);
+  const int c0 = cg * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = bias ? bias[c0 + e] : 0.f;
+  constexpr int P = KS / 2;
+#pragma unroll
+  for (int kh = 0; kh < KS; ++kh) {
+    const int ih = oh * stride + kh - P;
+    if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+    for (int kw = 0; kw < KS; ++kw) {
+      const int iw = ow * stride + kw - P;
+      if ((unsigned)iw >= (unsigned)W) continue;
+      float x[VEC];
+      Vec8<T>::load(in + ((b * H + ih) * (int64_t)W + iw) * ld_in + c0, x);
+      const float4 w0 = *reinterpret_cast<const float4*>(w + (kh * KS + kw) * C + c0);
+      const float4 w1 = *reinterpret_cast<const float4*>(w + (kh * KS + kw) * C + c0 + 4);
+      acc[0] = fmaf(x[0], w0.x, acc[0]); acc[1] = fmaf(x[1], w0.y, acc[1]);
+      acc[2] = fmaf(x[2], w0.z, acc[2]); acc[3] = fmaf(x[3], w0.w, acc[3]);
+      acc[4] = fmaf(x[4], w1.x, acc[4]); acc[5] = fmaf(x[5], w1.y, acc[5]);
+      acc[6] = fmaf(x[6], w1.z, acc[6]); acc[7] = fmaf(x[7], w1.w, acc[7]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = act_apply(acc[e], act);
+  Vec8<T>::store(out + pix * ld_out + c0, acc);
+}
+
+// ------------------------------------------------------------------------------------
+// grouped 1x1 conv, gs(=8 or 16 or 32) channels per group in and out, no bias
+// (LiteMLA aggreg.0.1, ops.py:568).  thread = (row, group, 8-output-channel chunk).
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void grouped_pw_kernel(const T* __restrict__ in, int ld_in, const float* __restrict__ w,
+                                  T* __restrict__ out, int ld_out, int64_t rows, int C, int gs) {
+  const int chunks = C / VEC;  // output chunks per row
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * chunks) return;
+  const int ch = (int)(idx % chunks);
+  const int64_t row = idx / chunks;
+  const int co0 = ch * VEC;
+  const int grp = co0 / gs;
+  const T* x = in + row * ld_in + grp * gs;
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  for (int ci0 = 0; ci0 < gs; ci0 += VEC) {
+    float xv[VEC];
+    Vec8<T>::load(x + ci0, xv);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float* wr = w + (int64_t)(co0 + e) * gs + ci0;  // w[cout][cin_in_group]
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[e] = fmaf(xv[i], wr[i], acc[e]);
+    }
+  }
+  Vec8<T>::store(out + row * ld_out + co0, acc);
+}
+
+// ------------------------------------------------------------------------------------
+// LiteMLA ReLU linear attention (ops.py:584-621), two kernels:
+//   kv[b][g][dv][dk] = sum_n v1[n][dv] * relu(k[n][dk]),  v1 = [v ; 1]   (dv in [0, dim])
+//   out[n][d]       = (sum_dk kv[d][dk] relu(q[n][dk])) / (sum_dk kv[dim][dk] relu(q[n][dk]) + 1e-15)
+// fp32 accumulation and fp32 division regardless of T (the reference keeps this island
+// out of autocast, ops.py:586-589,616-618).
+// ------------------------------------------------------------------------------------
+template <typename T, int DIM>
+__global__ void mla_kv_kernel(const T* __restrict__ ms, int ld, float* __restrict__ kv, int N,
+                              int groups, int n_split) {
+  // block = (b, group, split); 256 threads
+  constexpr int CH = 64;                 // positions per LDS chunk
+  __shared__ float sk[CH][DIM + 1];
+  __shared__ float sv[CH][DIM + 1];
+  const int split = blockIdx.x % n_split;
+  const int bg = blockIdx.x / n_split;
+  const int g = bg % groups;
+  const int64_t b = bg / groups;
+  const T* base = ms + (b * N) * (int64_t)ld + g * 3 * DIM;
+  constexpr int PAIRS = (DIM + 1) * DIM;
+  constexpr int PPT = (PAIRS + 255) / 256;
+  float acc[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) acc[i] = 0.f;
+  const int per = (N + n_split - 1) / n_split;
+  const int n_begin = split * per, n_end = min(N, n_begin + per);
+  for (int nb = n_begin; nb < n_end; nb += CH) {
+    for (int i = threadIdx.x; i < CH * DIM; i += 256) {
+      const int r = i / DIM, d = i - r * DIM;
+      const int n = nb + r;
+      float kk = 0.f, vv = 0.f;
+      if (n < n_end) {
+        kk = to_f32<T>(base[(int64_t)n * ld + DIM + d]);
+        vv = to_f32<T>(base[(int64_t)n * ld + 2 * DIM + d]);
+        kk = kk > 0.f ? kk : 0.f;
+      }
+      sk[r][d] = kk;
+      sv[r][d] = vv;
+    }
+    __syncthreads();
+    const int cnt = min(CH, n_end - nb);
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int pr = threadIdx.x + 256 * i;
+      if (pr < PAIRS) {
+        const int dv = pr / DIM, dk = pr - dv * DIM;
+        float a = acc[i];
+        if (dv < DIM) {
+          for (int r = 0; r < cnt; ++r) a = fmaf(sv[r][dv], sk[r][dk], a);
+        } else {
+          for (int r = 0; r < cnt; ++r) a += sk[r][dk];
+        }
+        acc[i] = a;
+      }
+    }
+    __syncthreads();
+  }
+  float* o = kv + (b * groups + g) * (int64_t)PAIRS;
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int pr = threadIdx.x + 256 * i;
+    if (pr < PAIRS) {
+      if (n_split == 1) o[pr] = acc[i];
+      else atomicAdd(o + pr, acc[i]);
+    }
+  }
+}
+
+template <typename T, int DIM>
+__global__ void mla_apply_kernel(const T* __restrict__ ms, int ld, const float* __restrict__ kv,
+                                 T* __restrict__ out, int ld_out, int N, int groups) {
+  // grid = (ceil(N / rows_per_block), B); thread = (row_local, group) with group fastest
+  extern __shared__ float skv[];  // [groups][(DIM+1)*DIM]
+  constexpr int PAIRS = (DIM + 1) * DIM;
+  const int64_t b = blockIdx.y;
+  for (int i = threadIdx.x; i < groups * PAIRS; i += blockDim.x)
+    skv[i] = kv[b * groups * (int64_t)PAIRS + i];
+  __syncthreads();
+  const int rows_per_block = blockDim.x / groups;
+  const int rl = threadIdx.x / groups, g = threadIdx.x - rl * groups;
+  const int n = blockIdx.x * rows_per_block + rl;
+  if (n >= N || rl >= rows_per_block) return;
+  const T* qp = ms + (b * N + n) * (int64_t)ld + g * 3 * DIM;
+  float q[DIM];
+#pragma unroll
+  for (int d0 = 0; d0 < DIM; d0 += VEC) {
+    Vec8<T>::load(qp + d0, q + d0);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) q[d0 + e] = q[d0 + e] > 0.f ? q[d0 + e] : 0.f;
+  }
+  const float* kvg = skv + g * PAIRS;
+  float den = 0.f;
+#pragma unroll
+  for (int dk = 0; dk < DIM; ++dk) den = fmaf(kvg[DIM * DIM + dk], q[dk], den);
+  const float inv = 1.f / (den + 1e-15f);
+  T* op = out + (b * N + n) * (int64_t)ld_out + g * DIM;
+#pragma unroll
+  for (int d0 = 0; d0 < DIM; d0 += VEC) {
+    float o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float a = 0.f;
+#pragma unroll
+      for (int dk = 0; dk < DIM; ++dk) a = fmaf(kvg[(d0 + e) * DIM + dk], q[dk], a);
+      o[e] = a * inv;
+    }
+    Vec8<T>::store(op + d0, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// bilinear resize, align_corners=False (model_builder.py:779-786)
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void resize_bilinear_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int IH,
+                                       int IW, int OH, int OW, int C) {
+  const int CG = C / VEC;
+  const int64_t total = (int64_t)B * OH * OW * CG;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = (int)(idx % CG);
+  const int64_t pix = idx / CG;
+  const int ox = (int)(pix % OW);
+  const int oy = (int)((pix / OW) % OH);
+  const int64_t b = pix / ((int64_t)OW * OH);
+  const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+  float fy = ((float)oy + 0.5f) * sy - 0.5f;
+  float fx = ((float)ox + 0.5f) * sx - 0.5f;
+  fy = fy < 0.f ? 0.f : fy;
+  fx = fx < 0.f ? 0.f : fx;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < IH - 1 ? 1 : 0), x1 = x0 + (x0 < IW - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const T* base = in + b * IH * (int64_t)IW * C + cg * VEC;
+  float a[VEC], bb[VEC], c[VEC], d[VEC], o[VEC];
+  Vec8<T>::load(base + ((int64_t)y0 * IW + x0) * C, a);
+  Vec8<T>::load(base + ((int64_t)y0 * IW + x1) * C, bb);
+  Vec8<T>::load(base + ((int64_t)y1 * IW + x0) * C, c);
+  Vec8<T>::load(base + ((int64_t)y1 * IW + x1) * C, d);
+#pragma unroll
+  for (int e = 0; e < VEC; ++e)
+    o[e] = hy * (hx * a[e] + lx * bb[e]) + ly * (hx * c[e] + lx * d[e]);
+  Vec8<T>::store(out + pix * C + cg * VEC, o);
+}
+
+// ------------------------------------------------------------------------------------
+// LayerNorm over the last dim (nn.LayerNorm, transformer.py:136-146; LayerNorm2d in NHWC,
+// sam/common.py:27-39), optional residual add before and activation after.
+// One wavefront per row; C <= 64 * MAXPL.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                 T* __restrict__ out, int64_t rows, int C, float eps, int act) {
+  constexpr int MAXPL = 16;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* xp = x + row * C;
+  const T* rp = res ? res + row * C : nullptr;
+  float v[MAXPL];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) {
+    const int c = lane + 64 * i;
+    float t = 0.f;
+    if (c < C) {
+      t = to_f32<T>(xp[c]);
+      if (rp) t += to_f32<T>(rp[c]);
+    }
+    v[i] = t;
+    sum += t;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) {
+    const int c = lane + 64 * i;
+    const float d = c < C ? v[i] - mean : 0.f;
+    sq += d * d;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  const float rstd = 1.f / sqrtf(sq / (float)C + eps);
+  T* op = out + row * C;
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c < C) {
+      float y = (v[i] - mean) * rstd * gamma[c] + beta[c];
+      op[c] = from_f32<T>(act_apply(y, act));
+    }
+  }
+}
+
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = to_f32<T>(in[i]);
+}
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ in, T* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = from_f32<T>(in[i]);
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_f32_kernel(const T* __restrict__ in, float* __restrict__ out, int HW,
+                                        int C) {
+  // 32x32 LDS tile transpose per (b): in [HW][C] -> out [C][HW]
+  __shared__ float tile[32][33];
+  const int64_t b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty in [0,8)
+  for (int r = ty; r < 32; r += 8) {
+    const int p = p0 + r, c = c0 + tx;
+    tile[r][tx] = (p < HW && c < C) ? to_f32<T>(in[(b * HW + p) * (int64_t)C + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r, p = p0 + tx;
+    if (c < C && p < HW) out[(b * C + c) * (int64_t)HW + p] = tile[tx][r];
+  }
+}
+
+__global__ void preprocess_u8_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int64_t HW,
+                                     int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, pixel)
+  if (i >= total) return;
+  const int64_t b = i / HW, p = i - b * HW;
+  const uint8_t* s = in + i * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float x = (float)s[c] / 255.0f;
+    out[(b * 3 + c) * HW + p] = (x - 0.5f) / 0.5f;
+  }
+}
+
+inline unsigned blocks_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace
+
+int esam3_launch_preprocess_u8(const uint8_t* in, float* out, int B, int H, int W, hipStream_t s) {
+  const int64_t HW = (int64_t)H * W, total = HW * B;
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, in, out, HW, total);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+#define DISPATCH_T(dtype, ...)                  \
+  do {                                          \
+    if ((dtype) == 0) { using T = float; __VA_ARGS__; } \
+    else { using T = bf16_t; __VA_ARGS__; }     \
+  } while (0)
+
+int esam3_launch_stem(int dtype, const float* img, const float* w, const float* bias, void* out,
+                      int B, int H, int W, int Cout, int act, hipStream_t s) {
+  if (Cout > 32 || Cout % VEC) { esam3_set_error("stem: Cout=%d unsupported", Cout); return -1; }
+  const int64_t total = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s,
+                                       img, w, bias, (T*)out, B, H, W, Cout, act));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_dwconv(int dtype, const void* in, int ld_in, const float* w, const float* bias,
+                        void* out, int ld_out, int B, int H, int W, int C, int ksize, int stride,
+                        int act, hipStream_t s) {
+  if (C % VEC || (ksize != 3 && ksize != 5) || (stride != 1 && stride != 2)) {
+    esam3_set_error("dwconv: unsupported C=%d k=%d s=%d", C, ksize, stride);
+    return -1;
+  }
+  const int OH = (H + stride - 1) / stride, OW = (W + stride - 1) / stride;
+  const int64_t total = (int64_t)B * OH * OW * (C / VEC);
+  if (ksize == 3) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv_kernel<T, 3>), dim3(blocks_for(total, 256)), dim3(256),
+                                         0, s, (const T*)in, ld_in, w, bias, (T*)out, ld_out, B, H, W,
+                                         C, stride, act));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv_kernel<T, 5>), dim3(blocks_for(total, 256)), dim3(256),
+                                         0, s, (const T*)in, ld_in, w, bias, (T*)out, ld_out, B, H, W,
+                                         C, stride, act));
+  }
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_grouped_pw(int dtype, const void* in, int ld_in, const float* w, void* out,
+                            int ld_out, int64_t rows, int C, int gs, hipStream_t s) {
+  if (C % VEC || gs % VEC || C % gs) { esam3_set_error("grouped_pw: C=%d gs=%d", C, gs); return -1; }
+  const int64_t total = rows * (C / VEC);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(grouped_pw_kernel<T>, dim3(blocks_for(total, 256)), dim3(256),
+                                       0, s, (const T*)in, ld_in, w, (T*)out, ld_out, rows, C, gs));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+template <typename T, int DIM>
+static int lite_mla_t(const void* ms, int ld, void* out, int ld_out, float* kv, int B, int N,
+                      int groups, hipStream_t s) {
+  constexpr int PAIRS = (DIM + 1) * DIM;
+  int n_split = 1;
+  while ((int64_t)B * groups * n_split < 512 && N / (n_split * 2) >= 256) n_split *= 2;
+  if (n_split > 1)
+    HIP_CHECK_RET(hipMemsetAsync(kv, 0, sizeof(float) * (size_t)B * groups * PAIRS, s));
+  hipLaunchKernelGGL((mla_kv_kernel<T, DIM>), dim3((unsigned)(B * groups * n_split)), dim3(256), 0, s,
+                     (const T*)ms, ld, kv, N, groups, n_split);
+  int threads = 256;
+  if (groups > threads) { esam3_set_error("lite_mla: groups=%d too large", groups); return -1; }
+  const int rpb = threads / groups;
+  threads = rpb * groups;
+  const size_t lds = sizeof(float) * (size_t)groups * PAIRS;
+  hipLaunchKernelGGL((mla_apply_kernel<T, DIM>), dim3((unsigned)((N + rpb - 1) / rpb), (unsigned)B),
+                     dim3(threads), lds, s, (const T*)ms, ld, kv, (T*)out, ld_out, N, groups);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_lite_mla(int dtype, const void* ms, int ld, void* out, int ld_out, float* kv, int B,
+                          int N, int groups, int dim, hipStream_t s) {
+  if (dim == 16) {
+    return dtype == 0 ? lite_mla_t<float, 16>(ms, ld, out, ld_out, kv, B, N, groups, s)
+                      : lite_mla_t<bf16_t, 16>(ms, ld, out, ld_out, kv, B, N, groups, s);
+  } else if (dim == 32) {
+    return dtype == 0 ? lite_mla_t<float, 32>(ms, ld, out, ld_out, kv, B, N, groups, s)
+                      : lite_mla_t<bf16_t, 32>(ms, ld, out, ld_out, kv, B, N, groups, s);
+  }
+  esam3_set_error("lite_mla: dim=%d unsupported", dim);
+  return -1;
+}
+
+int esam3_launch_resize_bilinear(int dtype, const void* in, void* out, int B, int IH, int IW, int OH,
+                                 int OW, int C, hipStream_t s) {
+  if (C % VEC) { esam3_set_error("resize: C=%d", C); return -1; }
+  const int64_t total = (int64_t)B * OH * OW * (C / VEC);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(resize_bilinear_kernel<T>, dim3(blocks_for(total, 256)),
+                                       dim3(256), 0, s, (const T*)in, (T*)out, B, IH, IW, OH, OW, C));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_layernorm(int dtype, const void* x, const void* res, const float* gamma,
+                           const float* beta, void* out, int64_t rows, int C, float eps, int act,
+                           hipStream_t s) {
+  if (C > 1024) { esam3_set_error("layernorm: C=%d > 1024", C); return -1; }
+  DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_kernel<T>, dim3(blocks_for(rows, 4)), dim3(256), 0, s,
+                                       (const T*)x, (const T*)res, gamma, beta, (T*)out, rows, C, eps,
+                                       act));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_cast_to_f32(int dtype, const void* in, float* out, int64_t n, hipStream_t s) {
+  const unsigned g = (unsigned)min((int64_t)4096, (n + 255) / 256);
+  if (n == 0) return 0;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(cast_to_f32_kernel<T>, dim3(g), dim3(256), 0, s, (const T*)in,
+                                       out, n));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int esam3_launch_cast_from_f32(int dtype, const float* in, void* out, int64_t n, hipStream_t s) {
+  const unsigned g = (unsigned)min((int64_t)4096, (n + 255) / 256);
+  if (n == 0) return 0;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(cast_from_f32_kernel<T>, dim3(g), dim3(256), 0, s, in, (T*)out,
+                                       n));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_nhwc_to_nchw_f32(int dtype, const void* in, float* out, int B, int H, int W, int C,
+                                  hipStream_t s) {
+  const int HW = H * W;
+  dim3 grid((HW + 31) / 32, (C + 31) / 32, B);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel<T>, grid, dim3(256), 0, s,
+                                       (const T*)in, out, HW, C));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,518 @@
+// Prompt-encoder / two-way mask-decoder / post-processing kernels
+// (sam/prompt_encoder.py, sam/transformer.py, sam/mask_decoder.py, model/utils/sam1_utils.py).
+#include "kernels.h"
+
+namespace {
+
+inline unsigned blocks_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+// ------------------------------------------------------------------------------------
+// out[bp][p][c] = in[src_img[bp]][p][c] + cbias[c] (+ dense[bp][p][c])
+// (sam3_image.py:618-620 no_mem_embed; mask_decoder.py:199-206 repeat_interleave + dense)
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void gather_add_kernel(const T* __restrict__ in, const int* __restrict__ src_img,
+                                  const float* __restrict__ cbias, const T* __restrict__ dense,
+                                  T* __restrict__ out, int Bp, int64_t P, int C) {
+  const int64_t total = (int64_t)Bp * P * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int64_t bp = i / (P * C);
+    const int64_t pc = i - bp * P * C;
+    float v = to_f32<T>(in[(int64_t)src_img[bp] * P * C + pc]) + cbias[c];
+    if (dense) v += to_f32<T>(dense[i]);
+    out[i] = from_f32<T>(v);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Softmax attention with few queries and many keys (token -> image cross attention and
+// token self attention; transformer.py:226-264).  grid = (B*heads, ceil(Nq/16));
+// block = 16 queries x 16 key-lanes; each thread runs an online softmax over its strided
+// subset of keys, then the 16 key-lanes of a query merge with wavefront shuffles.
+// ------------------------------------------------------------------------------------
+template <typename T, int HD>
+__global__ void attn_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+                            const T* __restrict__ v, int ldv, T* __restrict__ o, int ldo, int Nq, int Nk,
+                            int heads) {
+  const int h = blockIdx.x % heads;
+  const int64_t b = blockIdx.x / heads;
+  const int qi = blockIdx.y * 16 + (threadIdx.x >> 4);
+  const int kl = threadIdx.x & 15;
+  const bool q_ok = qi < Nq;
+  float qv[HD];
+  const float scale = rsqrtf((float)HD);
+  if (q_ok) {
+    const T* qp = q + (b * Nq + qi) * (int64_t)ldq + h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) qv[d] = to_f32<T>(qp[d]) * scale;
+  } else {
+#pragma unroll
+    for (int d = 0; d < HD; ++d) qv[d] = 0.f;
+  }
+  float m = -3.0e38f, l = 0.f;
+  float acc[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+  for (int j = kl; j < Nk; j += 16) {
+    const T* kp = k + (b * Nk + j) * (int64_t)ldk + h * HD;
+    const T* vp = v + (b * Nk + j) * (int64_t)ldv + h * HD;
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) s = fmaf(qv[d], to_f32<T>(kp[d]), s);
+    const float mn = fmaxf(m, s);
+    const float alpha = __expf(m - mn);
+    const float pexp = __expf(s - mn);
+    l = l * alpha + pexp;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] = acc[d] * alpha + pexp * to_f32<T>(vp[d]);
+    m = mn;
+  }
+  // merge the 16 key-lanes (xor 1,2,4,8 stays inside the query's 16-lane group)
+#pragma unroll
+  for (int off = 1; off < 16; off <<= 1) {
+    const float m2 = __shfl_xor(m, off);
+    const float l2 = __shfl_xor(l, off);
+    const float mn = fmaxf(m, m2);
+    const float a1 = __expf(m - mn), a2 = __expf(m2 - mn);
+    l = l * a1 + l2 * a2;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+      const float x2 = __shfl_xor(acc[d], off);
+      acc[d] = acc[d] * a1 + x2 * a2;
+    }
+    m = mn;
+  }
+  if (q_ok && kl == 0) {
+    T* op = o + (b * Nq + qi) * (int64_t)ldo + h * HD;
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) op[d] = from_f32<T>(acc[d] * inv);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Softmax attention with many queries and few keys (image -> token, Nk <= 64):
+// thread = (query, head), head fastest, K/V of the batch item staged in LDS as fp32.
+// ------------------------------------------------------------------------------------
+template <typename T, int HD>
+__global__ void attn_fewkeys_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+                                    const T* __restrict__ v, int ldv, T* __restrict__ o, int ldo,
+                                    int Nq, int Nk, int heads) {
+  extern __shared__ float skv[];  // K [Nk][heads*HD] then V [Nk][heads*HD]
+  const int64_t b = blockIdx.y;
+  const int D = heads * HD;
+  float* sk = skv;
+  float* sv = skv + Nk * D;
+  for (int i = threadIdx.x; i < Nk * D; i += blockDim.x) {
+    const int j = i / D, d = i - j * D;
+    sk[i] = to_f32<T>(k[(b * Nk + j) * (int64_t)ldk + d]);
+    sv[i] = to_f32<T>(v[(b * Nk + j) * (int64_t)ldv + d]);
+  }
+  __syncthreads();
+  const int qpb = blockDim.x / heads;
+  const int ql = threadIdx.x / heads, h = threadIdx.x - ql * heads;
+  const int qi = blockIdx.x * qpb + ql;
+  if (qi >= Nq || ql >= qpb) return;
+  const float scale = rsqrtf((float)HD);
+  const T* qp = q + (b * Nq + qi) * (int64_t)ldq + h * HD;
+  float qv[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) qv[d] = to_f32<T>(qp[d]) * scale;
+  float m = -3.0e38f;
+  for (int j = 0; j < Nk; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) s = fmaf(qv[d], sk[j * D + h * HD + d], s);
+    m = fmaxf(m, s);
+  }
+  float l = 0.f, acc[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+  for (int j = 0; j < Nk; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) s = fmaf(qv[d], sk[j * D + h * HD + d], s);
+    const float pexp = __expf(s - m);
+    l += pexp;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] = fmaf(pexp, sv[j * D + h * HD + d], acc[d]);
+  }
+  const float inv = 1.f / l;
+  T* op = o + (b * Nq + qi) * (int64_t)ldo + h * HD;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) op[d] = from_f32<T>(acc[d] * inv);
+}
+
+// ------------------------------------------------------------------------------------
+// tokens = [obj_score | iou | mask x4 | sparse prompt embeddings]
+// PositionEmbeddingRandom on (coords + 0.5) / img_size, label embeddings
+// (prompt_encoder.py:74-118,214-243; mask_decoder.py:177-197).  fp32 math.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ void build_tokens_kernel(const float* __restrict__ out_tokens, const float* __restrict__ coords,
+                                    const int* __restrict__ labels, const float* __restrict__ gauss,
+                                    const float* __restrict__ point_emb,
+                                    const float* __restrict__ not_a_point, T* __restrict__ tokens, int Bp,
+                                    int Np, int pad, float img_size) {
+  const int Tn = 6 + Np + (pad ? 1 : 0);
+  const int64_t total = (int64_t)Bp * Tn * 256;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int c = (int)(i & 255);
+  const int t = (int)((i >> 8) % Tn);
+  const int64_t bp = (i >> 8) / Tn;
+  float val;
+  if (t < 6) {
+    val = out_tokens[t * 256 + c];
+  } else {
+    const int pi = t - 6;
+    int lab = -1;
+    float x = 0.f, y = 0.f;
+    if (pi < Np) {
+      lab = labels[bp * Np + pi];
+      x = coords[(bp * Np + pi) * 2 + 0];
+      y = coords[(bp * Np + pi) * 2 + 1];
+    }
+    if (lab == -1) {
+      val = not_a_point[c];
+    } else {
+      const float cx = 2.f * ((x + 0.5f) / img_size) - 1.f;
+      const float cy = 2.f * ((y + 0.5f) / img_size) - 1.f;
+      const int f = c & 127;
+      const float ang = 6.283185307179586f * (cx * gauss[f] + cy * gauss[128 + f]);
+      val = (c < 128) ? sinf(ang) : cosf(ang);
+      if (lab >= 0 && lab < 4) val += point_emb[lab * 256 + c];
+    }
+  }
+  tokens[i] = from_f32<T>(val);
+}
+
+// ------------------------------------------------------------------------------------
+// masks[bp][k][p] = sum_c hyper[bp][k][c] * up[bp][p][c]   (mask_decoder.py:230-231)
+// ------------------------------------------------------------------------------------
+template <typename T, int C>
+__global__ void mask_product_kernel(const T* __restrict__ hyper, int ld_h, const T* __restrict__ up,
+                                    float* __restrict__ masks, int64_t P) {
+  __shared__ float sh[4 * C];
+  const int64_t bp = blockIdx.y;
+  for (int i = threadIdx.x; i < 4 * C; i += blockDim.x)
+    sh[i] = to_f32<T>(hyper[(bp * 4 + i / C) * (int64_t)ld_h + (i % C)]);
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const T* u = up + (bp * P + p) * C;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float x = to_f32<T>(u[c]);
+    a0 = fmaf(sh[c], x, a0);
+    a1 = fmaf(sh[C + c], x, a1);
+    a2 = fmaf(sh[2 * C + c], x, a2);
+    a3 = fmaf(sh[3 * C + c], x, a3);
+  }
+  float* m = masks + bp * 4 * P + p;
+  m[0] = a0; m[P] = a1; m[2 * P] = a2; m[3 * P] = a3;
+}
+
+// stability counters for mask 0: cnt[2*bp] = #(m > delta), cnt[2*bp+1] = #(m > -delta)
+__global__ void stability_count_kernel(const float* __restrict__ all_masks, int* __restrict__ cnt,
+                                       int64_t P, float delta) {
+  const int64_t bp = blockIdx.y;
+  const float* m = all_masks + bp * 4 * P;
+  int ci = 0, cu = 0;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P;
+       p += (int64_t)gridDim.x * blockDim.x) {
+    const float x = m[p];
+    ci += x > delta;
+    cu += x > -delta;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { ci += __shfl_xor(ci, o); cu += __shfl_xor(cu, o); }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(cnt + 2 * bp, ci);
+    atomicAdd(cnt + 2 * bp + 1, cu);
+  }
+}
+
+template <typename T>
+__global__ void select_masks_kernel(const float* __restrict__ all_masks, const T* __restrict__ all_iou,
+                                    int ld_iou, float* __restrict__ out_masks, float* __restrict__ out_iou,
+                                    const int* __restrict__ cnt, int64_t P, int multimask, float thresh) {
+  const int64_t bp = blockIdx.y;
+  const float* src = all_masks + bp * 4 * P;
+  float iou[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) iou[i] = to_f32<T>(all_iou[bp * ld_iou + i]);
+  if (multimask) {
+    float* dst = out_masks + bp * 3 * P;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < 3 * P;
+         p += (int64_t)gridDim.x * blockDim.x)
+      dst[p] = src[P + p];
+    if (blockIdx.x == 0 && threadIdx.x < 3) out_iou[bp * 3 + threadIdx.x] = iou[1 + threadIdx.x];
+  } else {
+    const float ai = (float)cnt[2 * bp], au = (float)cnt[2 * bp + 1];
+    const float stab = au > 0.f ? ai / au : 1.f;
+    int sel = 0;
+    if (!(stab >= thresh)) {  // fall back to the best of masks 1..3 (first max, torch.argmax)
+      sel = 1;
+      if (iou[2] > iou[sel]) sel = 2;
+      if (iou[3] > iou[sel]) sel = 3;
+    }
+    float* dst = out_masks + bp * P;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P;
+         p += (int64_t)gridDim.x * blockDim.x)
+      dst[p] = src[sel * P + p];
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_iou[bp] = iou[sel];
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Hole filling (sam1_utils.py:77-104 + perflib/connected_components.py): 8-connected
+// components of background pixels (score <= thr); components with area <= max_area are
+// set to thr + 10.  One workgroup per mask; union-find with atomicMin on int32 labels
+// living in global memory (324 KB per 288x288 mask -> L2 resident).  Only component
+// *areas* are consumed, so label values need not match any other implementation.
+// ------------------------------------------------------------------------------------
+__device__ inline int uf_find(int* lab, int x) {
+  int r = x;
+  while (true) {
+    const int p = __hip_atomic_load(lab + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == r) break;
+    r = p;
+  }
+  return r;
+}
+__device__ inline void uf_union(int* lab, int a, int b) {
+  while (true) {
+    a = uf_find(lab, a);
+    b = uf_find(lab, b);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }  // a > b: hook a under b
+    const int old = atomicMin(lab + a, b);
+    if (old == a) return;
+    a = old;  // somebody else re-hooked a; retry with its new parent
+  }
+}
+
+__global__ void fill_holes_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                  int* __restrict__ labels, int* __restrict__ areas, int H, int W,
+                                  float thr, float max_area) {
+  const int64_t n = blockIdx.x;
+  const int HW = H * W;
+  const float* src = in + n * HW;
+  float* dst = out + n * HW;
+  int* lab = labels + n * HW;
+  int* area = areas + n * HW;
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    lab[i] = (src[i] <= thr) ? i : -1;
+    area[i] = 0;
+  }
+  __threadfence();
+  __syncthreads();
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    if (lab[i] < 0) continue;
+    const int y = i / W, x = i - y * W;
+    // union with W, NW, N, NE neighbours that are background
+    if (x > 0 && src[i - 1] <= thr) uf_union(lab, i, i - 1);
+    if (y > 0) {
+      if (src[i - W] <= thr) uf_union(lab, i, i - W);
+      if (x > 0 && src[i - W - 1] <= thr) uf_union(lab, i, i - W - 1);
+      if (x < W - 1 && src[i - W + 1] <= thr) uf_union(lab, i, i - W + 1);
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    if (lab[i] < 0) continue;
+    const int r = uf_find(lab, i);
+    atomicAdd(area + r, 1);
+  }
+  __threadfence();
+  __syncthreads();
+  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+    float v = src[i];
+    if (v <= thr) {
+      const int r = uf_find(lab, i);
+      const int a = __hip_atomic_load(area + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((float)a <= max_area) v = thr + 10.f;
+    }
+    dst[i] = v;
+  }
+}
+
+// bilinear upsample (align_corners=False) of fp32 masks, optional > thr -> u8
+__global__ void upsample_masks_kernel(const float* __restrict__ in, float* __restrict__ out_f32,
+                                      uint8_t* __restrict__ out_u8, int IH, int IW, int OH, int OW,
+                                      float thr) {
+  const int64_t n = blockIdx.y;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)OH * OW) return;
+  const int ox = (int)(idx % OW), oy = (int)(idx / OW);
+  const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+  float fy = ((float)oy + 0.5f) * sy - 0.5f;
+  float fx = ((float)ox + 0.5f) * sx - 0.5f;
+  fy = fy < 0.f ? 0.f : fy;
+  fx = fx < 0.f ? 0.f : fx;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < IH - 1 ? 1 : 0), x1 = x0 + (x0 < IW - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float* s = in + n * IH * (int64_t)IW;
+  const float v = hy * (hx * s[y0 * IW + x0] + lx * s[y0 * IW + x1]) +
+                  ly * (hx * s[y1 * IW + x0] + lx * s[y1 * IW + x1]);
+  if (out_f32) out_f32[n * OH * (int64_t)OW + idx] = v;
+  if (out_u8) out_u8[n * OH * (int64_t)OW + idx] = v > thr ? 1 : 0;
+}
+
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    o[i] = from_f32<T>(to_f32<T>(a[i]) + to_f32<T>(b[i]));
+}
+template <typename T>
+__global__ void strided_to_f32_kernel(const T* __restrict__ in, int ld, float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = to_f32<T>(in[i * ld]);
+}
+
+__global__ void clamp_kernel(float* x, int64_t n, float lo, float hi) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = fminf(fmaxf(x[i], lo), hi);
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                  \
+  do {                                          \
+    if ((dtype) == 0) { using T = float; __VA_ARGS__; } \
+    else { using T = bf16_t; __VA_ARGS__; }     \
+  } while (0)
+
+int esam3_launch_gather_add(int dtype, const void* in, const int* src_img, const float* cbias,
+                            const void* dense, void* out, int Bp, int64_t P, int C, hipStream_t s) {
+  const int64_t total = (int64_t)Bp * P * C;
+  const unsigned g = (unsigned)min((int64_t)8192, (total + 255) / 256);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(gather_add_kernel<T>, dim3(g), dim3(256), 0, s, (const T*)in,
+                                       src_img, cbias, (const T*)dense, (T*)out, Bp, P, C));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_attn(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                      void* o, int ldo, int B, int Nq, int Nk, int heads, int hd, hipStream_t s) {
+  dim3 grid((unsigned)(B * heads), (unsigned)((Nq + 15) / 16));
+  if (hd == 16) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((attn_kernel<T, 16>), grid, dim3(256), 0, s, (const T*)q, ldq,
+                                         (const T*)k, ldk, (const T*)v, ldv, (T*)o, ldo, Nq, Nk, heads));
+  } else if (hd == 32) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL((attn_kernel<T, 32>), grid, dim3(256), 0, s, (const T*)q, ldq,
+                                         (const T*)k, ldk, (const T*)v, ldv, (T*)o, ldo, Nq, Nk, heads));
+  } else {
+    esam3_set_error("attn: head dim %d unsupported", hd);
+    return -1;
+  }
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_attn_fewkeys(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v,
+                              int ldv, void* o, int ldo, int B, int Nq, int Nk, int heads, int hd,
+                              hipStream_t s) {
+  if (hd != 16 || Nk > 64 || 256 % heads) {
+    esam3_set_error("attn_fewkeys: hd=%d Nk=%d heads=%d unsupported", hd, Nk, heads);
+    return -1;
+  }
+  const int qpb = 256 / heads;
+  dim3 grid((unsigned)((Nq + qpb - 1) / qpb), (unsigned)B);
+  const size_t lds = sizeof(float) * 2 * (size_t)Nk * heads * hd;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((attn_fewkeys_kernel<T, 16>), grid, dim3(256), lds, s,
+                                       (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, (T*)o, ldo,
+                                       Nq, Nk, heads));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_build_tokens(int dtype, const float* out_tokens, const float* coords, const int* labels,
+                              const float* gauss, const float* point_emb, const float* not_a_point,
+                              void* tokens, int Bp, int Np, int pad, float img_size, hipStream_t s) {
+  const int Tn = 6 + Np + (pad ? 1 : 0);
+  const int64_t total = (int64_t)Bp * Tn * 256;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(build_tokens_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0,
+                                       s, out_tokens, coords, labels, gauss, point_emb, not_a_point,
+                                       (T*)tokens, Bp, Np, pad, img_size));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_mask_product(int dtype, const void* hyper, int ld_h, const void* up, float* masks,
+                              int Bp, int64_t P, int C, hipStream_t s) {
+  if (C != 32) { esam3_set_error("mask_product: C=%d unsupported", C); return -1; }
+  dim3 grid(blocks_for(P, 256), (unsigned)Bp);
+  DISPATCH_T(dtype, hipLaunchKernelGGL((mask_product_kernel<T, 32>), grid, dim3(256), 0, s,
+                                       (const T*)hyper, ld_h, (const T*)up, masks, P));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_select_masks(int dtype, const float* all_masks, const void* all_iou, int ld_iou,
+                              float* out_masks, float* out_iou, int* counters, int Bp, int64_t P,
+                              int multimask, float delta, float thresh, hipStream_t s) {
+  if (!multimask) {
+    HIP_CHECK_RET(hipMemsetAsync(counters, 0, sizeof(int) * 2 * (size_t)Bp, s));
+    hipLaunchKernelGGL(stability_count_kernel, dim3(32, (unsigned)Bp), dim3(256), 0, s, all_masks,
+                       counters, P, delta);
+  }
+  DISPATCH_T(dtype, hipLaunchKernelGGL(select_masks_kernel<T>, dim3(64, (unsigned)Bp), dim3(256), 0, s,
+                                       all_masks, (const T*)all_iou, ld_iou, out_masks, out_iou, counters,
+                                       P, multimask, thresh));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_fill_holes(const float* in, float* out, int* labels, int* areas, int n, int H, int W,
+                            float thr, float max_area, hipStream_t s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(fill_holes_kernel, dim3((unsigned)n), dim3(1024), 0, s, in, out, labels, areas, H,
+                     W, thr, max_area);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_upsample_masks(const float* in, float* out_f32, uint8_t* out_u8, int n, int IH, int IW,
+                                int OH, int OW, float thr, hipStream_t s) {
+  if (n <= 0) return 0;
+  dim3 grid(blocks_for((int64_t)OH * OW, 256), (unsigned)n);
+  hipLaunchKernelGGL(upsample_masks_kernel, grid, dim3(256), 0, s, in, out_f32, out_u8, IH, IW, OH, OW,
+                     thr);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_clamp(float* x, int64_t n, float lo, float hi, hipStream_t s) {
+  if (n <= 0) return 0;
+  const unsigned g = (unsigned)min((int64_t)4096, (n + 255) / 256);
+  hipLaunchKernelGGL(clamp_kernel, dim3(g), dim3(256), 0, s, x, n, lo, hi);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_add(int dtype, const void* a, const void* b, void* out, int64_t n, hipStream_t s) {
+  if (n <= 0) return 0;
+  const unsigned g = (unsigned)min((int64_t)4096, (n + 255) / 256);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(add_kernel<T>, dim3(g), dim3(256), 0, s, (const T*)a, (const T*)b,
+                                       (T*)out, n));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_strided_to_f32(int dtype, const void* in, int ld, float* out, int64_t n, hipStream_t s) {
+  if (n <= 0) return 0;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(strided_to_f32_kernel<T>, dim3(blocks_for(n, 256)), dim3(256), 0, s,
+                                       (const T*)in, ld, out, n));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,215 @@
+// Single-operator C entry points (include/esam3.h, "esam3_op_*").  They pack host fp32
+// weights exactly like the engine does and launch the same kernels, so unit parity tests
+// can compare one operator at a time against the oracle.  Test-sized: every call uploads
+// its weights, synchronises and frees them.
+#include <vector>
+
+#include "../../include/esam3.h"
+#include "kernels.h"
+
+namespace {
+
+struct Tmp {  // scoped device allocations
+  std::vector<void*> ptrs;
+  ~Tmp() {
+    for (void* p : ptrs) hipFree(p);
+  }
+  void* up(const void* src, size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 256) != hipSuccess) return nullptr;
+    ptrs.push_back(p);
+    if (bytes && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return p;
+  }
+  void* upT(int dtype, const std::vector<float>& v) {
+    if (dtype == 0) return up(v.data(), v.size() * 4);
+    std::vector<bf16_t> h(v.size());
+    for (size_t i = 0; i < v.size(); ++i) h[i] = f32_to_bf16(v[i]);
+    return up(h.data(), h.size() * 2);
+  }
+  void* raw(size_t bytes) {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 256) != hipSuccess) return nullptr;
+    ptrs.push_back(p);
+    return p;
+  }
+};
+
+int fail(const char* what) {
+  esam3_set_error("%s: device allocation/upload failed", what);
+  return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int esam3_op_linear(int dtype, const void* a, const float* w, const float* bias, const void* res, void* out,
+                    int64_t M, int N, int K, int act, void* stream) {
+  Tmp t;
+  const int esz = dtype == 0 ? 4 : 2;
+  const int Kp = esam3_gemm_pad_k(K, esz), Np = esam3_gemm_pad_n(N);
+  std::vector<float> pk((size_t)Np * Kp, 0.f);
+  for (int n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) pk[(size_t)n * Kp + k] = w[(size_t)n * K + k];
+  GemmParams p{};
+  p.A = a; p.Wt = t.upT(dtype, pk); p.bias = bias ? (float*)t.up(bias, (size_t)N * 4) : nullptr;
+  if (!p.Wt || (bias && !p.bias)) return fail("op_linear");
+  p.res = res; p.out = out; p.M = M; p.N = N; p.K = K; p.Kp = Kp; p.H = 1; p.W = 1; p.Cin = K; p.ksize = 1;
+  p.lda = K; p.ldc = N; p.ldr = N; p.act = act; p.res_after_act = 1;
+  if (esam3_launch_gemm(dtype, p, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int esam3_op_conv2d(int dtype, const void* x, const float* w, const float* bias, const void* res, void* out,
+                    int B, int H, int W, int Cin, int Cout, int ks, int act, void* stream) {
+  Tmp t;
+  const int esz = dtype == 0 ? 4 : 2;
+  const int K = Cin * ks * ks;
+  const int Kp = esam3_gemm_pad_k(K, esz), Np = esam3_gemm_pad_n(Cout);
+  std::vector<float> pk((size_t)Np * Kp, 0.f);
+  for (int n = 0; n < Cout; ++n)
+    for (int c = 0; c < Cin; ++c)
+      for (int tp = 0; tp < ks * ks; ++tp)
+        pk[(size_t)n * Kp + (size_t)tp * Cin + c] = w[((size_t)n * Cin + c) * ks * ks + tp];
+  GemmParams p{};
+  p.A = x; p.Wt = t.upT(dtype, pk); p.bias = bias ? (float*)t.up(bias, (size_t)Cout * 4) : nullptr;
+  if (!p.Wt || (bias && !p.bias)) return fail("op_conv2d");
+  p.res = res; p.out = out; p.M = (int64_t)B * H * W; p.N = Cout; p.K = K; p.Kp = Kp; p.H = H; p.W = W;
+  p.Cin = Cin; p.ksize = ks; p.lda = Cin; p.ldc = Cout; p.ldr = Cout; p.act = act; p.res_after_act = 1;
+  if (esam3_launch_gemm(dtype, p, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int esam3_op_conv_transpose2x2(int dtype, const void* x, const float* w, const float* bias, const void* res,
+                               void* out, int B, int H, int W, int Cin, int Cout, int act, int res_after_act,
+                               void* stream) {
+  Tmp t;
+  const int esz = dtype == 0 ? 4 : 2;
+  const int N = 4 * Cout;
+  const int Kp = esam3_gemm_pad_k(Cin, esz), Np = esam3_gemm_pad_n(N);
+  std::vector<float> pk((size_t)Np * Kp, 0.f);
+  for (int ci = 0; ci < Cin; ++ci)
+    for (int co = 0; co < Cout; ++co)
+      for (int tp = 0; tp < 4; ++tp) pk[((size_t)tp * Cout + co) * Kp + ci] = w[((size_t)ci * Cout + co) * 4 + tp];
+  GemmParams p{};
+  p.A = x; p.Wt = t.upT(dtype, pk); p.bias = bias ? (float*)t.up(bias, (size_t)Cout * 4) : nullptr;
+  if (!p.Wt || (bias && !p.bias)) return fail("op_conv_transpose2x2");
+  p.res = res; p.out = out; p.M = (int64_t)B * H * W; p.N = N; p.K = Cin; p.Kp = Kp; p.H = H; p.W = W;
+  p.Cin = Cin; p.ksize = 1; p.lda = Cin; p.ldc = Cout; p.ldr = Cout; p.act = act;
+  p.out_mode = OUT_CONVT2X2; p.convt_cout = Cout; p.res_after_act = res_after_act;
+  if (esam3_launch_gemm(dtype, p, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int esam3_op_dwconv(int dtype, const void* x, const float* w, const float* bias, void* out, int B, int H, int W,
+                    int C, int ks, int stride, int act, void* stream) {
+  Tmp t;
+  std::vector<float> pk((size_t)ks * ks * C);
+  for (int c = 0; c < C; ++c)
+    for (int tp = 0; tp < ks * ks; ++tp) pk[(size_t)tp * C + c] = w[(size_t)c * ks * ks + tp];
+  float* dw = (float*)t.up(pk.data(), pk.size() * 4);
+  float* db = bias ? (float*)t.up(bias, (size_t)C * 4) : nullptr;
+  if (!dw || (bias && !db)) return fail("op_dwconv");
+  if (esam3_launch_dwconv(dtype, x, C, dw, db, out, C, B, H, W, C, ks, stride, act, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int esam3_op_stem(int dtype, const float* img, const float* w, const float* bias, void* out, int B, int H, int W,
+                  int Cout, int act, void* stream) {
+  Tmp t;
+  std::vector<float> pk(27 * (size_t)Cout);
+  for (int co = 0; co < Cout; ++co)
+    for (int c = 0; c < 3; ++c)
+      for (int tp = 0; tp < 9; ++tp) pk[(size_t)(tp * 3 + c) * Cout + co] = w[((size_t)co * 3 + c) * 9 + tp];
+  float* dw = (float*)t.up(pk.data(), pk.size() * 4);
+  float* db = bias ? (float*)t.up(bias, (size_t)Cout * 4) : nullptr;
+  if (!dw || (bias && !db)) return fail("op_stem");
+  if (esam3_launch_stem(dtype, img, dw, db, out, B, H, W, Cout, act, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int esam3_op_lite_mla(int dtype, const void* ms, void* out, int B, int N, int groups, int dim, void* stream) {
+  Tmp t;
+  float* kv = (float*)t.raw(sizeof(float) * (size_t)B * groups * (dim + 1) * dim);
+  if (!kv) return fail("op_lite_mla");
+  if (esam3_launch_lite_mla(dtype, ms, groups * 3 * dim, out, groups * dim, kv, B, N, groups, dim,
+                            (hipStream_t)stream))
+    return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int esam3_op_grouped_pw(int dtype, const void* x, const float* w, void* out, int64_t rows, int C, int gs,
+                        void* stream) {
+  Tmp t;
+  float* dw = (float*)t.up(w, (size_t)C * gs * 4);
+  if (!dw) return fail("op_grouped_pw");
+  if (esam3_launch_grouped_pw(dtype, x, C, dw, out, C, rows, C, gs, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int esam3_op_resize_bilinear(int dtype, const void* x, void* out, int B, int IH, int IW, int OH, int OW, int C,
+                             void* stream) {
+  if (esam3_launch_resize_bilinear(dtype, x, out, B, IH, IW, OH, OW, C, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int esam3_op_layernorm(int dtype, const void* x, const void* res, const float* gamma, const float* beta,
+                       void* out, int64_t rows, int C, float eps, int act, void* stream) {
+  Tmp t;
+  float* g = (float*)t.up(gamma, (size_t)C * 4);
+  float* b = (float*)t.up(beta, (size_t)C * 4);
+  if (!g || !b) return fail("op_layernorm");
+  if (esam3_launch_layernorm(dtype, x, res, g, b, out, rows, C, eps, act, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int esam3_op_attention(int dtype, const void* q, const void* k, const void* v, void* out, int B, int Nq, int Nk,
+                       int heads, int hd, int few_keys, void* stream) {
+  const int D = heads * hd;
+  int rc;
+  if (few_keys)
+    rc = esam3_launch_attn_fewkeys(dtype, q, D, k, D, v, D, out, D, B, Nq, Nk, heads, hd, (hipStream_t)stream);
+  else
+    rc = esam3_launch_attn(dtype, q, D, k, D, v, D, out, D, B, Nq, Nk, heads, hd, (hipStream_t)stream);
+  if (rc) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int esam3_op_fill_holes(const float* in, float* out, int n, int H, int W, float thr, float max_area,
+                        void* stream) {
+  Tmp t;
+  int* labels = (int*)t.raw((size_t)n * H * W * 4);
+  int* areas = (int*)t.raw((size_t)n * H * W * 4);
+  if (!labels || !areas) return fail("op_fill_holes");
+  if (esam3_launch_fill_holes(in, out, labels, areas, n, H, W, thr, max_area, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int esam3_op_upsample_masks(const float* in, float* out_f32, uint8_t* out_u8, int n, int IH, int IW, int OH,
+                            int OW, float thr, void* stream) {
+  if (esam3_launch_upsample_masks(in, out_f32, out_u8, n, IH, IW, OH, OW, thr, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int esam3_op_cast(int dtype, int to_f32, const void* in, void* out, int64_t n, void* stream) {
+  int rc = to_f32 ? esam3_launch_cast_to_f32(dtype, in, (float*)out, n, (hipStream_t)stream)
+                  : esam3_launch_cast_from_f32(dtype, (const float*)in, out, n, (hipStream_t)stream);
+  if (rc) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,180 @@
+"""Thin Python owner of an ``esam3_engine`` handle (C ABI in include/esam3.h).
+
+PyTorch is used only for device memory (``torch.empty`` on ``cuda``), the current HIP
+stream and host<->device copies; every tensor operation runs inside libesam3_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+NET_RES = 1008
+EMB = 72
+LOW_RES = 4 * EMB
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class HipEngine:
+    """One engine per (device, activation dtype)."""
+
+    def __init__(self, backbone_type: str = "efficientvit", model_name: str = "b1",
+                 dtype: str = "bf16", device: Optional[torch.device] = None,
+                 interactive: bool = True):
+        if not torch.cuda.is_available():
+            raise _lib.Esam3Error("no HIP device visible: the EfficientSAM3 engine has no CPU path")
+        if backbone_type != "efficientvit":
+            raise NotImplementedError(f"backbone_type={backbone_type!r} is not built yet")
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise _lib.Esam3Error(f"device {self.device} is not a HIP device")
+        self.dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", self.dev_index)
+        self.dtype_name = dtype
+        self.esam_dtype = _lib.ESAM3_F32 if dtype in ("f32", "fp32", "float32") else _lib.ESAM3_BF16
+        self.torch_dtype = torch.float32 if self.esam_dtype == _lib.ESAM3_F32 else torch.bfloat16
+        self.interactive = interactive
+        self.model_name = model_name
+        cfg = _lib.Config(dtype=self.esam_dtype, backbone=0, model_name=model_name.encode(),
+                          device=self.dev_index, interactive=int(interactive))
+        h = C.c_void_p()
+        _lib.check(self.lib.esam3_create(C.byref(cfg), C.byref(h)), "esam3_create")
+        self.handle = h
+        self.finalized = False
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            try:
+                self.lib.esam3_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+    # ---- weights -----------------------------------------------------------------------
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        for name, t in sd.items():
+            if not torch.is_tensor(t) or not t.is_floating_point():
+                continue
+            a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape) if a.ndim else (C.c_int64 * 1)(1)
+            _lib.check(self.lib.esam3_load_weight(self.handle, name.encode(), a.ctypes.data_as(C.c_void_p),
+                                                  shape, a.ndim), f"esam3_load_weight({name})")
+
+    def finalize(self):
+        with torch.cuda.device(self.dev_index):
+            _lib.check(self.lib.esam3_finalize(self.handle), "esam3_finalize")
+        self.finalized = True
+
+    # ---- image encoder -------------------------------------------------------------------
+    def preprocess_u8(self, img_hwc_u8: torch.Tensor) -> torch.Tensor:
+        """[B,H,W,3] uint8 on device -> [B,3,H,W] fp32 normalised (sam3_image_processor.py:24-31)."""
+        assert img_hwc_u8.dtype == torch.uint8 and img_hwc_u8.dim() == 4 and img_hwc_u8.shape[-1] == 3
+        img_hwc_u8 = img_hwc_u8.contiguous()
+        b, h, w, _ = img_hwc_u8.shape
+        out = torch.empty((b, 3, h, w), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.esam3_preprocess_u8(_ptr(img_hwc_u8), _ptr(out), b, h, w, _stream()),
+                   "esam3_preprocess_u8")
+        return out
+
+    def encode(self, img_nchw: torch.Tensor, want_sam3: bool = True, want_sam2: bool = True,
+               want_trunk: bool = False, want_stages: bool = False) -> dict:
+        """img_nchw: [B,3,1008,1008] fp32 normalised, on this engine's device."""
+        assert img_nchw.is_cuda and img_nchw.dtype == torch.float32
+        assert tuple(img_nchw.shape[1:]) == (3, NET_RES, NET_RES), img_nchw.shape
+        img_nchw = img_nchw.contiguous()
+        b = img_nchw.shape[0]
+        dt, dev = self.torch_dtype, self.device
+        feats = _lib.ImageFeatures()
+        out: dict = {}
+
+        def buf(h, c):
+            return torch.empty((b, h, h, c), dtype=dt, device=dev)
+
+        if want_sam3:
+            out["sam3_fpn"] = [buf(288, 256), buf(144, 256), buf(72, 256)]
+            for i, t in enumerate(out["sam3_fpn"]):
+                feats.sam3_fpn_dev[i] = t.data_ptr()
+        if want_sam2:
+            out["sam2_fpn"] = [buf(288, 32), buf(144, 64), buf(72, 256)]
+            for i, t in enumerate(out["sam2_fpn"]):
+                feats.sam2_fpn_dev[i] = t.data_ptr()
+        if want_trunk:
+            out["trunk"] = buf(72, 1024)
+            feats.trunk_dev = out["trunk"].data_ptr()
+        if want_stages:
+            widths = {"b0": [8, 16, 32, 64, 128], "b1": [16, 32, 64, 128, 256],
+                      "b2": [24, 48, 96, 192, 384]}[self.model_name]
+            sizes = [504, 252, 126, 63, 32]
+            out["stages"] = [torch.empty((b, s, s, c), dtype=dt, device=dev) for s, c in zip(sizes, widths)]
+            for i, t in enumerate(out["stages"]):
+                feats.stages_dev[i] = t.data_ptr()
+        with torch.cuda.device(self.dev_index):
+            _lib.check(self.lib.esam3_encode_image(self.handle, _ptr(img_nchw), b, C.byref(feats), _stream()),
+                       "esam3_encode_image")
+        return out
+
+    # ---- prompt decode -----------------------------------------------------------------------
+    def decode(self, sam2_fpn: Sequence[torch.Tensor], prompt_image: torch.Tensor, coords: torch.Tensor,
+               labels: torch.Tensor, multimask_output: bool, want_obj: bool = False):
+        """coords [Bp,Np,2] fp32 network pixels, labels [Bp,Np] int32, prompt_image [Bp] int32 (device).
+        Returns (low_res [Bp,C,288,288] fp32 unclamped, iou [Bp,C] fp32[, obj [Bp]])."""
+        bp, npts = coords.shape[0], coords.shape[1]
+        c = 3 if multimask_output else 1
+        low = torch.empty((bp, c, LOW_RES, LOW_RES), dtype=torch.float32, device=self.device)
+        iou = torch.empty((bp, c), dtype=torch.float32, device=self.device)
+        obj = torch.empty((bp,), dtype=torch.float32, device=self.device) if want_obj else None
+        pr = _lib.Prompts()
+        for i in range(3):
+            pr.sam2_fpn_dev[i] = sam2_fpn[i].data_ptr()
+        pr.n_images = sam2_fpn[2].shape[0]
+        pr.n_prompts = bp
+        pr.prompt_image_dev = prompt_image.data_ptr()
+        pr.coords_dev = coords.data_ptr() if npts > 0 else None
+        pr.labels_dev = labels.data_ptr() if npts > 0 else None
+        pr.n_points = npts
+        pr.mask_input_dev = None
+        pr.multimask_output = int(bool(multimask_output))
+        od = _lib.DecodeOut(low_res_dev=low.data_ptr(), iou_dev=iou.data_ptr(),
+                            obj_score_dev=obj.data_ptr() if obj is not None else None)
+        with torch.cuda.device(self.dev_index):
+            _lib.check(self.lib.esam3_decode(self.handle, C.byref(pr), C.byref(od), _stream()), "esam3_decode")
+        return (low, iou, obj) if want_obj else (low, iou)
+
+    def postprocess(self, low_res: torch.Tensor, orig_hw: Tuple[int, int], return_logits: bool,
+                    max_hole_area: float = 256.0, mask_threshold: float = 0.0) -> torch.Tensor:
+        """low_res [..., 288, 288] fp32 -> masks [..., H, W]: uint8 0/1, or fp32 logits."""
+        lead = low_res.shape[:-2]
+        n = int(np.prod(lead)) if len(lead) else 1
+        h, w = int(orig_hw[0]), int(orig_hw[1])
+        low_res = low_res.contiguous()
+        if return_logits:
+            out = torch.empty((*lead, h, w), dtype=torch.float32, device=self.device)
+            u8, f32 = None, out
+        else:
+            out = torch.empty((*lead, h, w), dtype=torch.uint8, device=self.device)
+            u8, f32 = out, None
+        with torch.cuda.device(self.dev_index):
+            _lib.check(self.lib.esam3_postprocess_masks(self.handle, _ptr(low_res), n, h, w, float(max_hole_area),
+                                                        float(mask_threshold), _ptr(u8), _ptr(f32), _stream()),
+                       "esam3_postprocess_masks")
+        return out
+
+    def clamp_(self, x: torch.Tensor, lo: float, hi: float) -> torch.Tensor:
+        _lib.check(self.lib.esam3_clamp_f32(self.handle, _ptr(x), x.numel(), lo, hi, _stream()), "esam3_clamp_f32")
+        return x
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.esam3_workspace_bytes(self.handle))

@@ -1,0 +1,311 @@
+"""Host-side mirror of the reference's image model objects for the hot path.
+
+Same names, argument meaning and error behaviour as the reference so callers
+(``eval/eval_coco.py``, the example scripts) run unchanged:
+
+  * ``Sam3Image.predict_inst`` / ``predict_inst_batch``  <- sam3/sam3/model/sam3_image.py:599-684
+  * prompt preparation / output conventions              <- sam3/sam3/model/sam1_task_predictor.py:168-430
+  * coordinate transforms                                <- sam3/sam3/model/utils/sam1_utils.py:47-75
+  * ``backbone.forward_image`` result dictionary         <- sam3/sam3/model/vl_combiner.py:81-124
+
+All tensor math happens in libesam3_hip.so (``HipEngine``); this file only shuffles
+prompts (a handful of floats, on the host) and wraps device buffers.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import schema
+from .engine import EMB, LOW_RES, NET_RES, HipEngine
+
+
+def _sine_position_encoding(h: int, w: int, num_pos_feats: int = 256, temperature: float = 10000.0) -> np.ndarray:
+    """PositionEmbeddingSine (normalize=True, scale=2*pi) -- a constant per (h, w)
+    (sam3/sam3/model/position_encoding.py:92-127); fp32 numpy, [C,H,W]."""
+    half = num_pos_feats // 2
+    y = np.arange(1, h + 1, dtype=np.float32)[:, None].repeat(w, 1)
+    x = np.arange(1, w + 1, dtype=np.float32)[None, :].repeat(h, 0)
+    eps = np.float32(1e-6)
+    scale = np.float32(2 * math.pi)
+    y = y / (y[-1:, :] + eps) * scale
+    x = x / (x[:, -1:] + eps) * scale
+    dim_t = np.arange(half, dtype=np.float32)
+    dim_t = (np.float32(temperature) ** (2 * (dim_t // 2) / np.float32(half))).astype(np.float32)
+    px = x[:, :, None] / dim_t
+    py = y[:, :, None] / dim_t
+    px = np.stack((np.sin(px[:, :, 0::2]), np.cos(px[:, :, 1::2])), axis=3).reshape(h, w, -1)
+    py = np.stack((np.sin(py[:, :, 0::2]), np.cos(py[:, :, 1::2])), axis=3).reshape(h, w, -1)
+    return np.ascontiguousarray(np.concatenate((py, px), axis=2).transpose(2, 0, 1)).astype(np.float32)
+
+
+def _nchw_view(t_nhwc: torch.Tensor) -> torch.Tensor:
+    """Logical NCHW view (channels-last memory) of an NHWC buffer: zero copy."""
+    return t_nhwc.permute(0, 3, 1, 2)
+
+
+class _Trunk:
+    """``model.backbone.vision_backbone.trunk(x) -> [Tensor[B,1024,72,72]]`` (stage1/model.py:237)."""
+
+    def __init__(self, owner: "Sam3Image"):
+        self._o = owner
+        self.channel_list = [1024]
+
+    def __call__(self, x):
+        x = x[0] if isinstance(x, list) else x
+        out = self._o.engine.encode(self._o._to_input(x), want_sam3=False, want_sam2=False, want_trunk=True)
+        return [_nchw_view(out["trunk"])]
+
+
+class _VisionBackbone:
+    def __init__(self, owner: "Sam3Image"):
+        self.trunk = _Trunk(owner)
+
+
+class _VLBackbone:
+    """Stand-in for SAM3VLBackbone (image half)."""
+
+    def __init__(self, owner: "Sam3Image"):
+        self._o = owner
+        self.vision_backbone = _VisionBackbone(owner)
+        self.language_backbone = None
+        self.scalp = 1
+
+    def forward_image(self, samples: torch.Tensor) -> dict:
+        return self._o._forward_image(samples)
+
+    def forward_text(self, captions, input_boxes=None, additional_text=None, device=None):
+        raise NotImplementedError("the text encoder is not part of this build yet (SURVEY.md §8 row T0-T4)")
+
+
+class _InteractivePredictorInfo:
+    """Marker object: ``model.inst_interactive_predictor is not None`` <=> interactivity enabled."""
+
+    mask_threshold = 0.0
+    max_hole_area = 256.0
+    max_sprinkle_area = 0.0
+    _bb_feat_sizes = [(288, 288), (144, 144), (72, 72)]
+
+
+class Sam3Image:
+    """EfficientSAM3 image model whose forward passes run on the HIP engine."""
+
+    def __init__(self, backbone_type: str, model_name: str, enable_inst_interactivity: bool,
+                 dtype: str = "bf16", device=None, dual_neck: bool = True):
+        self.backbone_type = backbone_type
+        self.model_name = model_name
+        self.dual_neck = dual_neck
+        self.engine = HipEngine(backbone_type, model_name, dtype=dtype, device=device,
+                                interactive=enable_inst_interactivity)
+        self.device = self.engine.device
+        self.backbone = _VLBackbone(self)
+        self.inst_interactive_predictor = _InteractivePredictorInfo() if enable_inst_interactivity else None
+        self._schema = schema.image_path_schema(backbone_type, model_name, enable_inst_interactivity)
+        self._sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        self._pos_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+        self.training = False
+
+    # ---- nn.Module-like surface -------------------------------------------------------------
+    def eval(self):
+        return self
+
+    def to(self, device=None, *a, **k):
+        if device is not None and torch.device(device).type != "cuda":
+            raise RuntimeError("this model lives on a HIP device; there is no CPU path")
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+    def parameters(self):
+        return iter(self._sd.values())
+
+    def state_dict(self):
+        return OrderedDict(self._sd)
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = False):
+        """Reference key names (Appendix C of SURVEY.md).  Keys outside the hot-path schema are
+        ignored like ``strict=False`` does upstream (model_builder.py:584-630)."""
+        if self.engine.finalized:
+            raise RuntimeError("weights are already packed on the device; build a new model to reload")
+        missing = [k for k, (shape, kind) in self._schema.items() if k not in sd and kind != "bn_n"]
+        unexpected = [k for k in sd if k not in self._schema]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"missing keys: {missing[:5]} unexpected: {unexpected[:5]}")
+        if missing:
+            raise KeyError(f"checkpoint lacks {len(missing)} tensors the hot path needs, e.g. {missing[:3]}")
+        for k, (shape, kind) in self._schema.items():
+            if kind == "bn_n":
+                continue
+            t = sd[k]
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f"{k}: shape {tuple(t.shape)} != expected {tuple(shape)}")
+            self._sd[k] = t.detach().to("cpu", torch.float32)
+        self.engine.load_state_dict(self._sd)
+        self.engine.finalize()
+        return missing, unexpected
+
+    # ---- image encoder ------------------------------------------------------------------------
+    def _to_input(self, samples: torch.Tensor) -> torch.Tensor:
+        if samples.dim() == 3:
+            samples = samples[None]
+        return samples.to(self.device, torch.float32)
+
+    def _pos(self, b: int, h: int, w: int) -> torch.Tensor:
+        key = (h, w)
+        if key not in self._pos_cache:
+            self._pos_cache[key] = torch.from_numpy(_sine_position_encoding(h, w)).to(
+                self.device, self.engine.torch_dtype)
+        return self._pos_cache[key][None].expand(b, -1, -1, -1)
+
+    def _forward_image(self, samples: torch.Tensor) -> dict:
+        """Same dictionary as SAM3VLBackbone.forward_image (vl_combiner.py:106-124); the sam2
+        levels 0/1 already carry the conv_s0/conv_s1 projection that Sam3Processor applies
+        right after (sam3_image_processor.py:62-75) -- flagged by ``_esam3_projected``."""
+        x = self._to_input(samples)
+        interactive = self.inst_interactive_predictor is not None
+        out = self.engine.encode(x, want_sam3=self.dual_neck, want_sam2=interactive)
+        b = x.shape[0]
+        res = {"vision_features": None, "vision_pos_enc": None, "backbone_fpn": None,
+               "sam2_backbone_out": None}
+        if self.dual_neck:
+            fpn = [_nchw_view(t) for t in out["sam3_fpn"]]
+            res.update(vision_features=fpn[-1], backbone_fpn=fpn,
+                       vision_pos_enc=[self._pos(b, t.shape[-2], t.shape[-1]) for t in fpn])
+        if interactive:
+            fpn2 = [_nchw_view(t) for t in out["sam2_fpn"]]
+            res["sam2_backbone_out"] = {
+                "vision_features": fpn2[-1], "backbone_fpn": fpn2,
+                "vision_pos_enc": [self._pos(b, t.shape[-2], t.shape[-1]) for t in fpn2],
+                "_esam3_projected": True, "_esam3_nhwc": out["sam2_fpn"]}
+        return res
+
+    # ---- prompt handling (host side, a handful of floats) -------------------------------------
+    @staticmethod
+    def _prep_prompts(point_coords, point_labels, box, normalize_coords, orig_hw):
+        """-> (coords [Bp,Np,2] f32 network px, labels [Bp,Np] i32) or (None, None).
+        sam1_task_predictor.py:298-326,385-396 + sam1_utils.py:47-75."""
+        h, w = orig_hw
+        coords = labels = None
+        if point_coords is not None:
+            assert point_labels is not None, "point_labels must be supplied if point_coords is supplied."
+            coords = np.array(point_coords, dtype=np.float32, copy=True)
+            if normalize_coords:
+                coords[..., 0] = coords[..., 0] / np.float32(w)
+                coords[..., 1] = coords[..., 1] / np.float32(h)
+            coords = coords * np.float32(NET_RES)
+            labels = np.asarray(point_labels).astype(np.int32)
+            if coords.ndim == 2:
+                coords, labels = coords[None], labels[None]
+        if box is not None:
+            bx = np.array(box, dtype=np.float32, copy=True).reshape(-1, 2, 2)
+            if normalize_coords:
+                bx[..., 0] = bx[..., 0] / np.float32(w)
+                bx[..., 1] = bx[..., 1] / np.float32(h)
+            bx = bx * np.float32(NET_RES)
+            bl = np.tile(np.array([[2, 3]], dtype=np.int32), (bx.shape[0], 1))
+            if coords is not None:
+                coords = np.concatenate([bx, coords], axis=1)
+                labels = np.concatenate([bl, labels], axis=1)
+            else:
+                coords, labels = bx, bl
+        return coords, labels
+
+    def _decode(self, sam2_nhwc: Sequence[torch.Tensor], coords: np.ndarray, labels: np.ndarray,
+                prompt_image: np.ndarray, multimask_output: bool):
+        dev = self.device
+        c = torch.from_numpy(np.ascontiguousarray(coords, dtype=np.float32)).to(dev)
+        l = torch.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)).to(dev)
+        pi = torch.from_numpy(np.ascontiguousarray(prompt_image, dtype=np.int32)).to(dev)
+        return self.engine.decode(sam2_nhwc, pi, c, l, multimask_output)
+
+    def _check_state(self, inference_state):
+        if self.inst_interactive_predictor is None:
+            raise RuntimeError("model was built with enable_inst_interactivity=False")
+        bo = inference_state["backbone_out"]["sam2_backbone_out"]
+        if bo is None or "_esam3_nhwc" not in bo:
+            raise RuntimeError("An image must be set with .set_image(...) before mask prediction.")
+        return bo["_esam3_nhwc"]
+
+    def predict_inst(self, inference_state, point_coords=None, point_labels=None, box=None,
+                     mask_input=None, multimask_output: bool = True, return_logits: bool = False,
+                     normalize_coords: bool = True) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Same contract as the reference (sam3_image.py:599-636): returns numpy
+        (masks [C,H,W] float32 0/1 or logits, iou [C], low_res [C,288,288]); K boxes keep a
+        leading K dimension."""
+        sam2 = self._check_state(inference_state)
+        if mask_input is not None:
+            raise NotImplementedError("mask_input prompts are not supported by this build yet")
+        h, w = inference_state["original_height"], inference_state["original_width"]
+        coords, labels = self._prep_prompts(point_coords, point_labels, box, normalize_coords, (h, w))
+        if coords is None:
+            raise NotImplementedError("predict_inst without point or box prompts is not supported yet")
+        bp = coords.shape[0]
+        low, iou = self._decode(sam2, coords, labels, np.zeros((bp,), np.int32), multimask_output)
+        masks = self.engine.postprocess(low, (h, w), return_logits)
+        self.engine.clamp_(low, -32.0, 32.0)
+        masks_np = masks.squeeze(0).float().cpu().numpy()
+        return masks_np, iou.squeeze(0).cpu().numpy(), low.squeeze(0).cpu().numpy()
+
+    def predict_inst_batch(self, inference_state, point_coords_batch=None, point_labels_batch=None,
+                           box_batch=None, mask_input_batch=None, multimask_output: bool = True,
+                           return_logits: bool = False, normalize_coords: bool = True):
+        """sam3_image.py:638-684 / sam1_task_predictor.py:168-228, but all images that share a
+        prompt layout are decoded in ONE engine call instead of a Python loop with a D2H sync per
+        image.  Returns three lists (masks, ious, low_res), one entry per image."""
+        sam2 = self._check_state(inference_state)
+        if mask_input_batch is not None:
+            raise NotImplementedError("mask_input prompts are not supported by this build yet")
+        hs, ws = inference_state["original_heights"], inference_state["original_widths"]
+        n_img = sam2[2].shape[0]
+        assert n_img == len(hs) == len(ws), \
+            f"Batch size mismatch in predict_inst_batch. Got {n_img}, {len(hs)}, {len(ws)}"
+        per = []
+        for i in range(n_img):
+            pc = point_coords_batch[i] if point_coords_batch is not None else None
+            pl = point_labels_batch[i] if point_labels_batch is not None else None
+            bx = box_batch[i] if box_batch is not None else None
+            c, l = self._prep_prompts(pc, pl, bx, normalize_coords, (hs[i], ws[i]))
+            if c is None:
+                raise NotImplementedError("predict_inst_batch needs a point or box prompt per image")
+            per.append((c, l))
+        # group images by prompt layout (Bp_i, Np)
+        groups: Dict[Tuple[int, int], List[int]] = {}
+        for i, (c, _) in enumerate(per):
+            groups.setdefault((c.shape[0], c.shape[1]), []).append(i)
+        masks_out: List[Optional[np.ndarray]] = [None] * n_img
+        iou_out: List[Optional[np.ndarray]] = [None] * n_img
+        low_out: List[Optional[np.ndarray]] = [None] * n_img
+        for (bpi, _), idxs in groups.items():
+            coords = np.concatenate([per[i][0] for i in idxs], axis=0)
+            labels = np.concatenate([per[i][1] for i in idxs], axis=0)
+            pimg = np.repeat(np.asarray(idxs, dtype=np.int32), bpi)
+            low, iou = self._decode(sam2, coords, labels, pimg, multimask_output)
+            # post-process per distinct original size
+            by_size: Dict[Tuple[int, int], List[int]] = {}
+            for j, i in enumerate(idxs):
+                by_size.setdefault((hs[i], ws[i]), []).append(j)
+            low_g = low.view(len(idxs), bpi, *low.shape[1:])
+            iou_g = iou.view(len(idxs), bpi, -1)
+            for (h, w), js in by_size.items():
+                sel = low_g[js] if len(js) != len(idxs) else low_g
+                m = self.engine.postprocess(sel.contiguous(), (h, w), return_logits).float().cpu().numpy()
+                for k, j in enumerate(js):
+                    masks_out[idxs[j]] = m[k].squeeze(0) if bpi == 1 else m[k]
+            self.engine.clamp_(low, -32.0, 32.0)
+            low_np, iou_np = low_g.cpu().numpy(), iou_g.cpu().numpy()
+            for j, i in enumerate(idxs):
+                low_out[i] = low_np[j].squeeze(0) if bpi == 1 else low_np[j]
+                iou_out[i] = iou_np[j].squeeze(0) if bpi == 1 else iou_np[j]
+        return masks_out, iou_out, low_out
+
+    # ---- text / grounding path: SURVEY.md §8 marks it "next" ------------------------------------
+    def forward_grounding(self, *a, **k):
+        raise NotImplementedError("the PCS text-grounding detector is not part of this build yet")
+
+    def _get_dummy_prompt(self, *a, **k):
+        raise NotImplementedError("the PCS text-grounding detector is not part of this build yet")

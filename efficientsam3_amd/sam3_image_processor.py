@@ -1,0 +1,120 @@
+"""``Sam3Processor`` with the reference's interface
+(sam3/sam3/model/sam3_image_processor.py:14-113).  Pre-processing (uint8 -> normalised
+NCHW fp32) is a HIP kernel; the encoder is the HIP engine."""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from .engine import NET_RES
+
+try:  # PIL is optional at import time
+    import PIL.Image as _PILImage
+except Exception:  # pragma: no cover
+    _PILImage = None
+
+
+class Sam3Processor:
+    def __init__(self, model, resolution=NET_RES, device=None, confidence_threshold=0.5):
+        if resolution != NET_RES:
+            raise ValueError(f"the network resolution is fixed at {NET_RES}")
+        self.model = model
+        self.resolution = resolution
+        self.device = model.device if device is None else torch.device(device)
+        self.confidence_threshold = confidence_threshold
+
+    # ---- helpers -------------------------------------------------------------------------------
+    def _to_hwc_u8(self, image):
+        """-> (uint8 HWC tensor on device, height, width) following set_image's type handling
+        (sam3_image_processor.py:50-57): PIL -> size; ndarray/Tensor -> shape[-2:]."""
+        if _PILImage is not None and isinstance(image, _PILImage.Image):
+            width, height = image.size
+            arr = np.asarray(image.convert("RGB"))
+            t = torch.from_numpy(np.ascontiguousarray(arr))
+        elif isinstance(image, np.ndarray):
+            height, width = image.shape[-2:]  # (sic) the reference reads CHW-style dims here
+            arr = image if image.ndim == 3 else image[:, :, None]
+            t = torch.from_numpy(np.ascontiguousarray(arr))
+        elif isinstance(image, torch.Tensor):
+            height, width = image.shape[-2:]
+            t = image.permute(1, 2, 0) if image.dim() == 3 else image  # CHW -> HWC
+        else:
+            raise ValueError("Image must be a PIL image or a tensor")
+        if t.dtype != torch.uint8:
+            if t.is_floating_point():  # v2.ToDtype(uint8, scale=True)
+                t = (t * 255.999).clamp(0, 255).to(torch.uint8)
+            else:
+                t = t.to(torch.uint8)
+        return t.contiguous(), int(height), int(width)
+
+    def _preprocess(self, hwc_u8_list: List[torch.Tensor]) -> torch.Tensor:
+        for t in hwc_u8_list:
+            if tuple(t.shape[:2]) != (self.resolution, self.resolution):
+                raise NotImplementedError(
+                    f"input of size {tuple(t.shape[:2])}: the uint8 antialiased resize to "
+                    f"{self.resolution}x{self.resolution} (torchvision v2.Resize) is not built yet; "
+                    "pass images already at the network resolution")
+        batch = torch.stack([t.to(self.device) for t in hwc_u8_list], dim=0)
+        return self.model.engine.preprocess_u8(batch)
+
+    # ---- reference API ---------------------------------------------------------------------------
+    @torch.inference_mode()
+    def set_image(self, image, state=None):
+        """Sets the image on which we want to do predictions."""
+        if state is None:
+            state = {}
+        t, height, width = self._to_hwc_u8(image)
+        x = self._preprocess([t])
+        state["original_height"] = height
+        state["original_width"] = width
+        state["backbone_out"] = self.model.backbone.forward_image(x)
+        return state
+
+    @torch.inference_mode()
+    def set_image_batch(self, images, state=None):
+        """Sets the image batch on which we want to do predictions."""
+        if state is None:
+            state = {}
+        if not isinstance(images, list):
+            raise ValueError("Images must be a list of PIL images or tensors")
+        assert len(images) > 0, "Images list must not be empty"
+        assert _PILImage is not None and isinstance(images[0], _PILImage.Image), \
+            "Images must be a list of PIL images"
+        state["original_heights"] = [image.height for image in images]
+        state["original_widths"] = [image.width for image in images]
+        x = self._preprocess([self._to_hwc_u8(im)[0] for im in images])
+        state["backbone_out"] = self.model.backbone.forward_image(x)
+        return state
+
+    @torch.inference_mode()
+    def set_image_tensor_batch(self, images_nchw_f32: torch.Tensor, original_hw=None, state=None):
+        """Extension (no reference counterpart): batch that is already normalised NCHW fp32 on
+        the device -- the "tensor-in" timing variant of SURVEY.md §8(d)."""
+        if state is None:
+            state = {}
+        b = images_nchw_f32.shape[0]
+        hw = original_hw if original_hw is not None else [(self.resolution, self.resolution)] * b
+        state["original_heights"] = [h for h, _ in hw]
+        state["original_widths"] = [w for _, w in hw]
+        state["backbone_out"] = self.model.backbone.forward_image(images_nchw_f32)
+        return state
+
+    def set_text_prompt(self, prompt: str, state: Dict):
+        if "backbone_out" not in state:
+            raise ValueError("You must call set_image before set_text_prompt")
+        raise NotImplementedError("text prompts (PCS detector) are not part of this build yet")
+
+    def add_geometric_prompt(self, box, label, state):
+        if "backbone_out" not in state:
+            raise ValueError("You must call set_image before set_text_prompt")
+        raise NotImplementedError("geometric PCS prompts are not part of this build yet")
+
+    def reset_all_prompts(self, state):
+        for k in ("geometric_prompt", "boxes", "masks", "masks_logits", "scores"):
+            state.pop(k, None)
+
+    def set_confidence_threshold(self, threshold: float, state=None):
+        self.confidence_threshold = threshold
+        return state

@@ -1,0 +1,149 @@
+/* esam3.h -- C ABI of the MI355X-native EfficientSAM3 image hot path (libesam3_hip.so).
+ *
+ * The reference is pure Python/PyTorch, so it has no FFI of its own; these entry points
+ * are what a binding for the hot path would call, one per reference call site:
+ *
+ *   esam3_create / esam3_load_weight / esam3_finalize
+ *       <- sam3/sam3/model_builder.py:944-1053 build_efficientsam3_image_model +
+ *          _load_checkpoint (:584-630): one call per state_dict entry, reference key names.
+ *   esam3_encode_image
+ *       <- SAM3VLBackbone.forward_image (sam3/sam3/model/vl_combiner.py:81-124) plus the
+ *          conv_s0/conv_s1 projection Sam3Processor.set_image[_batch] applies
+ *          (sam3/sam3/model/sam3_image_processor.py:62-75,98-112).
+ *   esam3_decode
+ *       <- SAM3InteractiveImagePredictor._predict up to the mask decoder
+ *          (sam3/sam3/model/sam1_task_predictor.py:328-421): prompt encoder
+ *          (sam/prompt_encoder.py:155-197) + MaskDecoder.forward (sam/mask_decoder.py:107-163).
+ *   esam3_postprocess_masks
+ *       <- SAM2Transforms.postprocess_masks (sam3/sam3/model/utils/sam1_utils.py:77-119) and
+ *          the `> mask_threshold` of sam1_task_predictor.py:423-428.
+ *
+ * Conventions: every pointer named *_dev is device memory owned by the caller; tensors are
+ * NHWC (channels innermost) in the engine's activation dtype unless stated; all functions
+ * return 0 on success and -1 on error (message via esam3_last_error()); no function
+ * synchronises the stream; one engine per device, not thread-safe per engine.
+ */
+#ifndef ESAM3_H
+#define ESAM3_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct esam3_engine esam3_engine;
+
+enum { ESAM3_F32 = 0, ESAM3_BF16 = 1 };
+enum { ESAM3_BACKBONE_EFFICIENTVIT = 0 };
+
+typedef struct esam3_config {
+  int dtype;            /* ESAM3_F32 (validation) or ESAM3_BF16 (throughput) activations */
+  int backbone;         /* ESAM3_BACKBONE_* */
+  char model_name[16];  /* "b0" | "b1" | "b2" */
+  int device;           /* HIP device ordinal */
+  int interactive;      /* 1: sam2 neck + SAM heads are present (enable_inst_interactivity) */
+} esam3_config;
+
+/* Outputs of the image encoder; NULL members are skipped.  B = batch.
+ *   sam3_fpn: [B,288,288,256] [B,144,144,256] [B,72,72,256]   (all NULL -> sam3 neck not run)
+ *   sam2_fpn: [B,288,288,32]  [B,144,144,64]  [B,72,72,256]   (after conv_s0 / conv_s1)
+ *   trunk:    [B,72,72,1024]  ImageStudentEncoder output
+ *   stages:   backbone stage0..stage4 outputs (validation taps) */
+typedef struct esam3_image_features {
+  void* sam3_fpn_dev[3];
+  void* sam2_fpn_dev[3];
+  void* trunk_dev;
+  void* stages_dev[5];
+} esam3_image_features;
+
+typedef struct esam3_prompts {
+  const void* sam2_fpn_dev[3];  /* features of n_images images, as produced by esam3_encode_image */
+  int n_images;
+  int n_prompts;                /* Bp: independent prompt sets */
+  const int32_t* prompt_image_dev; /* [Bp] image index of each prompt set */
+  const float* coords_dev;      /* [Bp][n_points][2] (x, y) in network pixels (0..1008), may be NULL */
+  const int32_t* labels_dev;    /* [Bp][n_points]: 0 neg, 1 pos, 2 box TL, 3 box BR, -1 pad */
+  int n_points;
+  const float* mask_input_dev;  /* optional [Bp][288][288] fp32 low-res mask logits */
+  int multimask_output;
+} esam3_prompts;
+
+typedef struct esam3_decode_out {
+  float* low_res_dev;   /* [Bp][C][288][288] fp32 logits (unclamped), C = 3 if multimask else 1 */
+  float* iou_dev;       /* [Bp][C] */
+  float* obj_score_dev; /* [Bp] object score logits, may be NULL */
+} esam3_decode_out;
+
+const char* esam3_last_error(void);
+int esam3_create(const esam3_config* cfg, esam3_engine** out);
+void esam3_destroy(esam3_engine* e);
+/* host fp32 tensor with the reference's state_dict key; unknown keys are ignored */
+int esam3_load_weight(esam3_engine* e, const char* name, const float* host_data,
+                      const int64_t* shape, int ndim);
+/* fold BatchNorm, pack to the GEMM layouts, upload; must precede encode/decode */
+int esam3_finalize(esam3_engine* e);
+
+int esam3_encode_image(esam3_engine* e, const float* img_nchw_f32_dev, int B,
+                       const esam3_image_features* out, void* hip_stream);
+int esam3_decode(esam3_engine* e, const esam3_prompts* prompts, const esam3_decode_out* out,
+                 void* hip_stream);
+/* low_res: [n][288][288] fp32 -> masks at (out_h, out_w); either output may be NULL */
+int esam3_postprocess_masks(esam3_engine* e, const float* low_res_dev, int n_masks, int out_h,
+                            int out_w, float max_hole_area, float mask_threshold,
+                            uint8_t* masks_u8_dev, float* masks_logits_dev, void* hip_stream);
+/* in-place clamp of fp32 logits (sam1_task_predictor.py:426) */
+int esam3_clamp_f32(esam3_engine* e, float* x_dev, int64_t n, float lo, float hi, void* hip_stream);
+
+/* Sam3Processor.transform for an already network-sized image (sam3_image_processor.py:24-31):
+ * uint8 HWC [B][H][W][3] -> fp32 NCHW [B][3][H][W], x/255 then (x-0.5)/0.5 */
+int esam3_preprocess_u8(const uint8_t* img_hwc_u8_dev, float* out_nchw_f32_dev, int B, int H, int W,
+                        void* hip_stream);
+
+/* bytes of engine workspace currently reserved, and size of one activation element */
+int64_t esam3_workspace_bytes(const esam3_engine* e);
+int esam3_elem_size(const esam3_engine* e);
+
+/* ---- single-operator entry points (unit parity tests; same kernels as the engine) ---- */
+/* out[M][N] = act(A[M][K] @ W[N][K]^T + bias) (+res); W/bias host fp32, A/out device engine dtype */
+int esam3_op_linear(int dtype, const void* a_dev, const float* w_host, const float* bias_host,
+                    const void* res_dev, void* out_dev, int64_t M, int N, int K, int act,
+                    void* hip_stream);
+/* dense 3x3/s1/p1 or 1x1 conv, NHWC; w_host is the PyTorch [Cout][Cin][k][k] fp32 weight */
+int esam3_op_conv2d(int dtype, const void* x_dev, const float* w_host, const float* bias_host,
+                    const void* res_dev, void* out_dev, int B, int H, int W, int Cin, int Cout,
+                    int ksize, int act, void* hip_stream);
+/* ConvTranspose2d k2 s2, NHWC; w_host is the PyTorch [Cin][Cout][2][2] fp32 weight */
+int esam3_op_conv_transpose2x2(int dtype, const void* x_dev, const float* w_host,
+                               const float* bias_host, const void* res_dev, void* out_dev, int B,
+                               int H, int W, int Cin, int Cout, int act, int res_after_act,
+                               void* hip_stream);
+/* depthwise k x k (3|5), stride 1|2; w_host PyTorch [C][1][k][k] */
+int esam3_op_dwconv(int dtype, const void* x_dev, const float* w_host, const float* bias_host,
+                    void* out_dev, int B, int H, int W, int C, int ksize, int stride, int act,
+                    void* hip_stream);
+int esam3_op_stem(int dtype, const float* img_nchw_dev, const float* w_host /*[Cout][3][3][3]*/,
+                  const float* bias_host, void* out_dev, int B, int H, int W, int Cout, int act,
+                  void* hip_stream);
+/* LiteMLA linear attention on a [B][N][2*3*heads*dim] multi-scale qkv tensor */
+int esam3_op_lite_mla(int dtype, const void* ms_dev, void* out_dev, int B, int N, int groups,
+                      int dim, void* hip_stream);
+int esam3_op_grouped_pw(int dtype, const void* x_dev, const float* w_host /*[C][gs]*/,
+                        void* out_dev, int64_t rows, int C, int gs, void* hip_stream);
+int esam3_op_resize_bilinear(int dtype, const void* x_dev, void* out_dev, int B, int IH, int IW,
+                             int OH, int OW, int C, void* hip_stream);
+int esam3_op_layernorm(int dtype, const void* x_dev, const void* res_dev, const float* gamma_host,
+                       const float* beta_host, void* out_dev, int64_t rows, int C, float eps,
+                       int act, void* hip_stream);
+int esam3_op_attention(int dtype, const void* q_dev, const void* k_dev, const void* v_dev,
+                       void* out_dev, int B, int Nq, int Nk, int heads, int head_dim,
+                       int few_keys, void* hip_stream);
+int esam3_op_fill_holes(const float* in_dev, float* out_dev, int n, int H, int W, float thr,
+                        float max_area, void* hip_stream);
+int esam3_op_upsample_masks(const float* in_dev, float* out_f32_dev, uint8_t* out_u8_dev, int n,
+                            int IH, int IW, int OH, int OW, float thr, void* hip_stream);
+int esam3_op_cast(int dtype, int to_f32, const void* in_dev, void* out_dev, int64_t n,
+                  void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESAM3_H */

@@ -103,7 +103,12 @@ def main():
           f"reference keys not in hot-path schema: {len(missing)}")
     proc = Sam3Processor(model, device="cpu")
 
-    manifest = {"weights_seed": 0, "model": "efficientvit-b1", "cases": {}, "stages": {},
+    import hashlib
+    digest = hashlib.sha256()
+    for k, v in sd.items():
+        digest.update(k.encode())
+        digest.update(np.ascontiguousarray(v.numpy()).tobytes())
+    manifest = {"weights_sha256": digest.hexdigest(), "weights_seed": 0, "model": "efficientvit-b1", "cases": {}, "stages": {},
                 "oracle_vs_reference_maxabs": {}}
 
     # ---- image 0: smooth synthetic, image 1: noise -------------------------------

@@ -1,0 +1,275 @@
+"""GPU parity of every HIP operator (through the C ABI) against plain PyTorch fp32 on CPU.
+
+Each kernel of the hot path is exercised in both activation modes: "f32" (validation,
+exact-f32 MFMA; tight tolerance) and "bf16" (throughput; tolerance = bf16 input/output
+rounding).  Shapes include ragged tails (M, N, K not multiples of the tile) and the edge
+cases the graphs rely on (K < one K-tile, N in {1, 4}, stride-2 odd sizes, batch gather).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+MODES = ["f32", "bf16"]
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _q(x, mode):
+    """quantise an input the way the device sees it"""
+    return x.to(torch.bfloat16).float() if mode == "bf16" else x
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("M,N,K,act,res", [
+    (8, 256, 256, None, False), (300, 128, 256, "relu", True), (1000, 2048, 256, "relu", False),
+    (77, 256, 2048, None, True), (5, 4, 256, "sigmoid", False), (3, 1, 256, None, False),
+    (513, 32, 16, "hswish", False), (129, 64, 24, "gelu", True), (64, 384, 128, None, False),
+])
+def test_linear(mode, M, N, K, act, res):
+    d, tdt = U.DT[mode]
+    a, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2) / K ** 0.5, _rand(N, seed=3) * 0.1
+    r = _rand(M, N, seed=4) if res else None
+    aq, wq = _q(a, mode), _q(w, mode)
+    ref = F.linear(aq, wq, b)
+    ref = {None: lambda t: t, "relu": F.relu, "gelu": F.gelu, "hswish": F.hardswish,
+           "sigmoid": torch.sigmoid}[act](ref)
+    if res:
+        ref = ref + _q(r, mode)
+    a_d = a.to("cuda", tdt)
+    r_d = r.to("cuda", tdt) if res else None
+    out = torch.empty((M, N), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_linear(d, U.P(a_d), U.H(U.np32(w)), U.H(U.np32(b)), U.P(r_d), U.P(out),
+                                    M, N, K, U.ACT[act], None), "op_linear")
+    U.assert_close(out.float().cpu(), ref, mode, f"linear {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ks,act,res", [
+    (2, 20, 24, 256, 256, 3, None, False), (1, 9, 7, 64, 32, 3, "gelu", False),
+    (1, 33, 31, 16, 64, 1, "hswish", False), (2, 12, 12, 1024, 256, 1, None, True),
+    (1, 16, 16, 1024, 1024, 3, None, False), (1, 5, 5, 8, 8, 3, None, True),
+])
+def test_conv2d(mode, B, H, W, Cin, Cout, ks, act, res):
+    d, tdt = U.DT[mode]
+    x = _rand(B, Cin, H, W, seed=1)
+    w = _rand(Cout, Cin, ks, ks, seed=2) / (Cin * ks * ks) ** 0.5
+    b = _rand(Cout, seed=3) * 0.1
+    r = _rand(B, Cout, H, W, seed=4) if res else None
+    ref = F.conv2d(_q(x, mode), _q(w, mode), b, padding=ks // 2)
+    ref = {None: lambda t: t, "gelu": F.gelu, "hswish": F.hardswish}[act](ref)
+    if res:
+        ref = ref + _q(r, mode)
+    x_d = U.to_dev_nhwc(x, tdt)
+    r_d = U.to_dev_nhwc(r, tdt) if res else None
+    out = torch.empty((B, H, W, Cout), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_conv2d(d, U.P(x_d), U.H(U.np32(w)), U.H(U.np32(b)), U.P(r_d), U.P(out),
+                                    B, H, W, Cin, Cout, ks, U.ACT[act], None), "op_conv2d")
+    U.assert_close(U.from_dev_nhwc(out), ref, mode, f"conv{ks}x{ks} {Cin}->{Cout}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act,res,after", [
+    (2, 9, 9, 1024, 512, "gelu", False, 1), (1, 12, 10, 512, 256, None, False, 1),
+    (2, 8, 8, 256, 64, None, True, 1), (2, 10, 10, 64, 32, "gelu", True, 0),
+])
+def test_conv_transpose(mode, B, H, W, Cin, Cout, act, res, after):
+    d, tdt = U.DT[mode]
+    x = _rand(B, Cin, H, W, seed=1)
+    w = _rand(Cin, Cout, 2, 2, seed=2) / Cin ** 0.5
+    b = _rand(Cout, seed=3) * 0.1
+    r = _rand(B, Cout, 2 * H, 2 * W, seed=4) if res else None
+    y = F.conv_transpose2d(_q(x, mode), _q(w, mode), b, stride=2)
+    fn = {None: lambda t: t, "gelu": F.gelu}[act]
+    if res and not after:
+        ref = fn(y + _q(r, mode))
+    else:
+        ref = fn(y) + (_q(r, mode) if res else 0)
+    x_d = U.to_dev_nhwc(x, tdt)
+    r_d = U.to_dev_nhwc(r, tdt) if res else None
+    out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_conv_transpose2x2(d, U.P(x_d), U.H(U.np32(w)), U.H(U.np32(b)), U.P(r_d), U.P(out),
+                                               B, H, W, Cin, Cout, U.ACT[act], after, None), "op_convT")
+    U.assert_close(U.from_dev_nhwc(out), ref, mode, f"convT {Cin}->{Cout}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("B,H,W,C,ks,stride,act", [
+    (2, 17, 19, 64, 3, 1, "hswish"), (1, 18, 18, 128, 3, 2, "hswish"), (1, 15, 13, 16, 3, 2, None),
+    (2, 11, 11, 384, 5, 1, None), (1, 63, 63, 256, 3, 2, "hswish"),
+])
+def test_dwconv(mode, B, H, W, C, ks, stride, act):
+    d, tdt = U.DT[mode]
+    x = _rand(B, C, H, W, seed=1)
+    w = _rand(C, 1, ks, ks, seed=2) / ks
+    b = _rand(C, seed=3) * 0.1
+    ref = F.conv2d(_q(x, mode), w, b, stride=stride, padding=ks // 2, groups=C)
+    ref = F.hardswish(ref) if act else ref
+    x_d = U.to_dev_nhwc(x, tdt)
+    OH, OW = ref.shape[-2:]
+    out = torch.empty((B, OH, OW, C), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_dwconv(d, U.P(x_d), U.H(U.np32(w)), U.H(U.np32(b)), U.P(out), B, H, W, C, ks,
+                                    stride, U.ACT[act], None), "op_dwconv")
+    U.assert_close(U.from_dev_nhwc(out), ref, mode, f"dw{ks} s{stride}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("Cout", [16, 8, 24])
+def test_stem(mode, Cout):
+    d, tdt = U.DT[mode]
+    B, H, W = 2, 38, 42
+    x = _rand(B, 3, H, W, seed=1)
+    w = _rand(Cout, 3, 3, 3, seed=2) / 27 ** 0.5
+    b = _rand(Cout, seed=3) * 0.1
+    ref = F.hardswish(F.conv2d(x, w, b, stride=2, padding=1))
+    x_d = x.to("cuda")
+    out = torch.empty((B, (H + 1) // 2, (W + 1) // 2, Cout), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_stem(d, U.P(x_d), U.H(U.np32(w)), U.H(U.np32(b)), U.P(out), B, H, W, Cout,
+                                  U.ACT["hswish"], None), "op_stem")
+    U.assert_close(U.from_dev_nhwc(out), ref, mode, "stem")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("B,N,heads,dim", [(2, 700, 8, 16), (1, 3969, 8, 16), (3, 1024, 16, 16), (1, 500, 6, 32)])
+def test_lite_mla(mode, B, N, heads, dim):
+    """ops.py:584-621 on a [B, 2*heads groups x (q|k|v) x dim, N] tensor."""
+    d, tdt = U.DT[mode]
+    groups = 2 * heads
+    ms = _rand(B, groups * 3 * dim, N, seed=1)
+    msq = _q(ms, mode)
+    t = msq.reshape(B, groups, 3 * dim, N)
+    q, k, v = F.relu(t[:, :, :dim]), F.relu(t[:, :, dim:2 * dim]), t[:, :, 2 * dim:]
+    v1 = F.pad(v, (0, 0, 0, 1), value=1.0)
+    out = torch.matmul(torch.matmul(v1, k.transpose(-1, -2)), q)
+    ref = (out[:, :, :-1] / (out[:, :, -1:] + 1e-15)).reshape(B, groups * dim, N)
+    ms_d = ms.permute(0, 2, 1).contiguous().to("cuda", tdt)  # [B][N][C]
+    o_d = torch.empty((B, N, groups * dim), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_lite_mla(d, U.P(ms_d), U.P(o_d), B, N, groups, dim, None), "op_lite_mla")
+    U.assert_close(o_d.float().cpu().permute(0, 2, 1), ref, mode, "lite_mla")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("C,gs", [(384, 16), (768, 16), (576, 32)])
+def test_grouped_pw(mode, C, gs):
+    d, tdt = U.DT[mode]
+    rows = 999
+    x = _rand(1, C, rows, 1, seed=1)
+    w = _rand(C, gs, 1, 1, seed=2) / gs ** 0.5
+    ref = F.conv2d(_q(x, mode), w, None, groups=C // gs)
+    x_d = x[0, :, :, 0].t().contiguous().to("cuda", tdt)
+    o_d = torch.empty((rows, C), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_grouped_pw(d, U.P(x_d), U.H(U.np32(w)), U.P(o_d), rows, C, gs, None), "op_grouped_pw")
+    U.assert_close(o_d.float().cpu().t(), ref[0, :, :, 0], mode, "grouped_pw")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_resize_bilinear(mode):
+    d, tdt = U.DT[mode]
+    x = _rand(2, 64, 32, 32, seed=1)
+    ref = F.interpolate(_q(x, mode), size=(72, 72), mode="bilinear", align_corners=False)
+    o_d = torch.empty((2, 72, 72, 64), dtype=tdt, device="cuda")
+    x_d = U.to_dev_nhwc(x, tdt)
+    U.check(U.lib().esam3_op_resize_bilinear(d, U.P(x_d), U.P(o_d), 2, 32, 32, 72, 72, 64, None),
+            "op_resize")
+    U.assert_close(U.from_dev_nhwc(o_d), ref, mode, "resize")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("rows,C,eps,act,res", [(1000, 256, 1e-5, None, True), (777, 64, 1e-6, "gelu", False),
+                                               (9, 256, 1e-5, None, False)])
+def test_layernorm(mode, rows, C, eps, act, res):
+    d, tdt = U.DT[mode]
+    x, r = _rand(rows, C, seed=1) * 2 + 0.3, _rand(rows, C, seed=2)
+    g, b = _rand(C, seed=3) * 0.2 + 1, _rand(C, seed=4) * 0.1
+    xin = _q(x, mode) + (_q(r, mode) if res else 0)
+    ref = F.layer_norm(xin, (C,), g, b, eps)
+    ref = F.gelu(ref) if act else ref
+    o_d = torch.empty((rows, C), dtype=tdt, device="cuda")
+    x_d, r_d = x.to("cuda", tdt), r.to("cuda", tdt)  # keep alive: U.P() only takes the address
+    U.check(U.lib().esam3_op_layernorm(d, U.P(x_d), U.P(r_d) if res else None,
+                                       U.H(U.np32(g)), U.H(U.np32(b)), U.P(o_d), rows, C, eps, U.ACT[act], None),
+            "op_layernorm")
+    U.assert_close(o_d.float().cpu(), ref, mode, "layernorm")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("B,Nq,Nk,heads,hd,few", [(2, 8, 5184, 8, 16, 0), (3, 10, 10, 8, 32, 0), (1, 23, 700, 8, 16, 0),
+                                                 (2, 5184, 9, 8, 16, 1), (1, 1000, 1, 8, 16, 1)])
+def test_attention(mode, B, Nq, Nk, heads, hd, few):
+    d, tdt = U.DT[mode]
+    D = heads * hd
+    q, k, v = _rand(B, Nq, D, seed=1), _rand(B, Nk, D, seed=2), _rand(B, Nk, D, seed=3)
+
+    def split(t):
+        return _q(t, mode).reshape(t.shape[0], t.shape[1], heads, hd).transpose(1, 2)
+
+    ref = F.scaled_dot_product_attention(split(q), split(k), split(v)).transpose(1, 2).reshape(B, Nq, D)
+    o_d = torch.empty((B, Nq, D), dtype=tdt, device="cuda")
+    q_d, k_d, v_d = q.to("cuda", tdt), k.to("cuda", tdt), v.to("cuda", tdt)  # keep alive
+    U.check(U.lib().esam3_op_attention(d, U.P(q_d), U.P(k_d), U.P(v_d), U.P(o_d), B, Nq, Nk, heads, hd, few, None),
+            "op_attention")
+    U.assert_close(o_d.float().cpu(), ref, mode, "attention")
+
+
+def _cpu_fill_holes(m, thr, max_area):
+    from scipy import ndimage
+    out = m.copy()
+    st = np.ones((3, 3), dtype=np.int32)
+    for i in range(m.shape[0]):
+        bg = m[i] <= thr
+        lab, n = ndimage.label(bg, structure=st)
+        if n:
+            areas = np.bincount(lab.ravel(), minlength=n + 1)
+            out[i][(lab > 0) & (areas[lab] <= max_area)] = thr + 10.0
+    return out
+
+
+@pytest.mark.parametrize("kind", ["noise", "blobs", "all_bg", "all_fg", "checker"])
+def test_fill_holes(kind):
+    """Hole filling is integer work: bit-exact vs scipy 8-connected labelling."""
+    rng = np.random.default_rng(7)
+    n, H, W = 4, 288, 288
+    if kind == "noise":
+        m = rng.normal(0.3, 1.0, (n, H, W)).astype(np.float32)
+    elif kind == "blobs":
+        yy, xx = np.mgrid[0:H, 0:W]
+        m = np.ones((n, H, W), np.float32)
+        for i in range(n):
+            for _ in range(60):
+                cy, cx, r = rng.integers(0, H), rng.integers(0, W), rng.integers(1, 14)
+                m[i][(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = -1.0
+    elif kind == "all_bg":
+        m = -np.ones((n, H, W), np.float32)
+    elif kind == "all_fg":
+        m = np.ones((n, H, W), np.float32)
+    else:
+        yy, xx = np.mgrid[0:H, 0:W]
+        m = np.where(((yy // 3) + (xx // 5)) % 2 == 0, 1.0, -1.0).astype(np.float32)[None].repeat(n, 0)
+    ref = _cpu_fill_holes(m, 0.0, 256.0)
+    m_d = torch.from_numpy(m).to("cuda")
+    o_d = torch.empty_like(m_d)
+    U.check(U.lib().esam3_op_fill_holes(U.P(m_d), U.P(o_d), n, H, W, 0.0, 256.0, None), "op_fill_holes")
+    assert np.array_equal(o_d.cpu().numpy(), ref), kind
+
+
+def test_upsample_masks():
+    m = _rand(3, 1, 288, 288, seed=5)
+    for (oh, ow) in [(1008, 1008), (600, 800), (333, 517)]:
+        ref = F.interpolate(m, (oh, ow), mode="bilinear", align_corners=False)[:, 0]
+        f_d = torch.empty((3, oh, ow), dtype=torch.float32, device="cuda")
+        u_d = torch.empty((3, oh, ow), dtype=torch.uint8, device="cuda")
+        m_d = m.to("cuda")
+        U.check(U.lib().esam3_op_upsample_masks(U.P(m_d), U.P(f_d), U.P(u_d), 3, 288, 288, oh, ow, 0.0, None),
+                "op_upsample")
+        got = f_d.cpu()
+        assert float((got - ref).abs().max()) < 2e-5
+        mism = (u_d.cpu().bool() != (ref > 0)) & ((ref.abs() > 1e-5))
+        assert not mism.any()
