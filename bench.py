@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""Throughput benchmark of the EfficientSAM3 hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+
+A "step" = one pass of the hot path over one batch of synthetic input per rank:
+  encode  : EV-M (EfficientViT-B1) backbone + student head + BOTH ViTDet FPN necks + conv_s0/s1
+            (the full SAM3VLBackbone.forward_image graph; only the x0.5 level that the reference
+            computes and immediately discards is not executed) on [32,3,1008,1008] fp32 inputs
+            already resident in HBM (BASELINE.json configs[1]: "EV-M bf16 batch=32 @1024^2,
+            point+box prompts, 1xMI355X"; the network's native resolution is 1008);
+  decode  : prompt encoder + two-way mask decoder for one point+box prompt per image;
+  post    : hole filling + bilinear upsample to 1008x1008 + threshold (uint8 masks, on device).
+For N > 1 every rank processes its own 32-image shard (weak scaling, no data-path collective in
+the model) and rank 0 gathers the uint8 masks over RCCL each step (the only exchange step the
+path has).
+
+The JSON line also carries:
+  roofline     : the dominant kernel (implicit-GEMM conv, level-0 3x3 of the necks) timed live
+                 with HIP events on its launch stream inside the timed steps.
+  cpu_baseline : the oracle (oracle/ref_model.py, a port of the reference's fp32 CPU path) timed
+                 on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH = 32
+FLOPS_PER_IMAGE_G = {  # SURVEY.md §8(d) numerators (GFLOP / image, 2*MAC)
+    "backbone": 20.3, "head": 19.9, "necks": 429.8 - 2 * 2.2, "conv_s0s1": 2.04, "decode": 4.49}
+PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(sample_images: int = 2):
+    """Time the oracle on the host cores: set_image + one predict_inst per image."""
+    import numpy as np
+    import torch
+
+    from efficientsam3_amd import schema, synth
+    from oracle import ref_model
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    sd = schema.synthetic_state_dict("efficientvit", "b1", seed=0)
+    pts, labels, boxes = synth.prompts(sample_images + 1, seed=2)
+    times = []
+    for i in range(sample_images + 1):  # first one is warm-up
+        img = synth.smooth_image_u8(seed=100 + i)
+        x = torch.from_numpy(synth.normalise_to_chw_f32(img))[None]
+        t0 = time.perf_counter()
+        with torch.inference_mode():
+            st = ref_model.set_image(sd, x, (1008, 1008), "b1")
+            ref_model.predict_inst(sd, st, point_coords=pts[i], point_labels=labels[i], box=boxes[i],
+                                   multimask_output=False)
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return {"value": round(1.0 / t, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{sample_images} images (after 1 warm-up) of the same synthetic workload, "
+                      f"fp32 oracle, set_image + predict_inst(point+box), torch CPU {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sam2-only", action="store_true",
+                    help="consumer-minimal graph (skip the sam3 neck); NOT the headline number")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from efficientsam3_amd import build_efficientsam3_image_model, schema, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    sd = schema.synthetic_state_dict("efficientvit", "b1", seed=0)
+    model = build_efficientsam3_image_model(device=dev, enable_inst_interactivity=True,
+                                            backbone_type="efficientvit", model_name="b1",
+                                            dtype=args.dtype, state_dict=sd, dual_neck=not args.sam2_only)
+    eng = model.engine
+    B = args.batch
+    # synthetic batch, resident in HBM before the timed region: 4 distinct images tiled to B
+    base = [synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=1 + 7 * rank)),
+            synth.normalise_to_chw_f32(synth.noise_image_u8(seed=2 + 7 * rank)),
+            synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=3 + 7 * rank)),
+            synth.normalise_to_chw_f32(synth.noise_image_u8(seed=4 + 7 * rank))]
+    x = torch.from_numpy(np.stack([base[i % 4] for i in range(B)])).to(dev)
+    pts, labels, boxes = synth.prompts(B, seed=2 + rank)
+    coords, labs = model._prep_prompts(pts, labels, boxes, True, (1008, 1008))  # [B,3,2] box+point
+    c_d = torch.from_numpy(coords).to(dev)
+    l_d = torch.from_numpy(labs).to(dev)
+    pi_d = torch.arange(B, dtype=torch.int32, device=dev)
+    gather_list = None
+    if world > 1 and rank == 0:
+        gather_list = [torch.empty((B, 1, 1008, 1008), dtype=torch.uint8, device=dev) for _ in range(world)]
+
+    def step():
+        out = eng.encode(x, want_sam3=not args.sam2_only, want_sam2=True)
+        low, iou = eng.decode(out["sam2_fpn"], pi_d, c_d, l_d, multimask_output=False)
+        masks = eng.postprocess(low, (1008, 1008), return_logits=False)
+        if world > 1:
+            dist.gather(masks, gather_list, dst=0)
+        return masks, iou
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        masks, iou = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_report()
+    eng.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    fg = float(masks.float().mean().item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        # ---- roofline of the dominant kernel (by measured time) --------------------------------
+        dom = prof[0] if prof else None
+        roof = None
+        if dom is not None:
+            avg_ms = dom["ms"] / dom["launches"]
+            tflops = dom["flops"] / (avg_ms * 1e-3) / 1e12
+            gbs = dom["bytes"] / (avg_ms * 1e-3) / 1e9
+            mfma_bound = dom["flops"] / (PEAK_BF16_TFLOPS * 1e12) >= dom["bytes"] / (PEAK_HBM_GBS * 1e9)
+            traffic = None
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
+            if os.path.exists(pmc_path):
+                try:
+                    traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            if mfma_bound:
+                roof = {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic}
+            else:
+                roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic}
+            roof.update(kernel="conv_gemm_kernel<bf16,128,128>", tag=dom["tag"], launches_per_step=dom["launches"] // args.steps,
+                        avg_launch_ms=round(avg_ms, 4), algorithmic_flops_per_launch=dom["flops"],
+                        algorithmic_bytes_per_launch=dom["bytes"])
+        gf_img = sum(FLOPS_PER_IMAGE_G.values()) - (FLOPS_PER_IMAGE_G["necks"] / 2 if args.sam2_only else 0.0)
+        total_k = sum(p["ms"] for p in prof)
+        stage_ms = {}
+        for p_ in prof:
+            t_ = p_["tag"]
+            key = ("neck" if ".convs." in t_ or ".sam2_convs." in t_ or "conv_s0" in t_ or "conv_s1" in t_
+                   else "head" if ".head." in t_
+                   else "backbone" if "trunk.model.backbone" in t_ or t_.startswith(("dwconv", "stem", "lite_mla", "grouped_pw", "resize"))
+                   else "decode+post")
+            stage_ms[key] = stage_ms.get(key, 0.0) + p_["ms"] / args.steps
+        out = {
+            "metric": "images/sec encode+decode @1024^2 (EV-M bf16)", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic (seeded images at the network's native 1008x1008, seeded realistic random-init weights)",
+            "config": {"workload": "EV-M (EfficientViT-B1) set_image_batch + predict_inst(point+box) per image, "
+                                   "batch=32 per GPU, full dual-neck graph" + (" [sam2-only variant]" if args.sam2_only else ""),
+                       "global_batch": world * B, "resolution": 1008, "prompts_per_image": 1,
+                       "parallelism": f"dp{world} (image shards, RCCL gather of uint8 masks)" if world > 1 else "single GPU",
+                       "gflop_per_image": round(gf_img, 1),
+                       "end_to_end_mfma_frac": round(value * gf_img * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+                       "kernel_ms_per_step_by_stage": {k: round(v, 3) for k, v in sorted(stage_ms.items())},
+                       "kernel_ms_per_step_total": round(total_k / args.steps, 3),
+                       "mask_fg_fraction": round(fg, 4), "workspace_gb": round(eng.workspace_bytes() / 2 ** 30, 2)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+        if os.environ.get("ESAM3_BENCH_PROFILE_OUT"):
+            with open(os.environ["ESAM3_BENCH_PROFILE_OUT"], "w") as f:
+                json.dump({"per_tag": prof, "steps": args.steps, "batch": B}, f, indent=1)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

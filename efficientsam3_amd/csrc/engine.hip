@@ -5,6 +5,7 @@
 // Graph structure follows the reference module tree (file:line cited per function);
 // nothing here calls into PyTorch or any CPU fallback -- every tensor op is a HIP kernel
 // from gemm_conv.hip / kernels_backbone.hip / kernels_decoder.hip.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -60,6 +61,7 @@ struct PackedGemm {
   void* w = nullptr;      // [Np][Kp] activation dtype
   float* bias = nullptr;  // [N] (or [Cout] for convT) fp32
   int N = 0, K = 0, Kp = 0, Np = 0, ksize = 1, cin = 0, convt_cout = 0;
+  std::string tag;
 };
 struct PackedDw {
   float* w = nullptr;  // [k*k][C]
@@ -109,6 +111,22 @@ struct esam3_engine {
   bool finalized = false;
   bool dry = false;  // allocate + pack only, launch nothing
   hipStream_t st = nullptr;
+
+  // ---------------- optional per-launch profiler (HIP events on the launch stream) --------
+  struct ProfRec { std::string tag; hipEvent_t a, b; double flops, bytes; };
+  bool prof = false;
+  std::vector<ProfRec> recs;
+  int prof_launch(const std::string& tag, double flops, double bytes, const std::function<int()>& fn) {
+    if (!prof) return fn();
+    ProfRec r{tag, nullptr, nullptr, flops, bytes};
+    HIP_CHECK_RET(hipEventCreate(&r.a));
+    HIP_CHECK_RET(hipEventCreate(&r.b));
+    HIP_CHECK_RET(hipEventRecord(r.a, st));
+    const int rc = fn();
+    HIP_CHECK_RET(hipEventRecord(r.b, st));
+    recs.push_back(r);
+    return rc;
+  }
 
   // ---------------- raw weight access ----------------
   const HostTensor* find(const std::string& n) const {
@@ -203,6 +221,7 @@ struct esam3_engine {
     g.w = upload_T(pk);
     g.bias = has_bias ? (float*)dev_upload(bias.data(), bias.size() * 4) : nullptr;
     if (!g.w) return nullptr;
+    g.tag = wname;
     return &(gemms[wname] = g);
   }
   // ConvTranspose2d k2 s2: [Cin][Cout][2][2] -> GEMM with N = 4*Cout, n = tap*Cout + co
@@ -225,6 +244,7 @@ struct esam3_engine {
     g.w = upload_T(pk);
     g.bias = (float*)dev_upload(b->d.data(), b->d.size() * 4);
     if (!g.w) return nullptr;
+    g.tag = wname;
     return &(gemms[wname] = g);
   }
   PackedGemm* pk_linear(const std::string& prefix, bool bias = true) {
@@ -250,6 +270,7 @@ struct esam3_engine {
       g.bias = (float*)dev_upload(b->d.data(), b->d.size() * 4);
     }
     if (!g.w) return nullptr;
+    g.tag = wname;
     return &(gemms[wname] = g);
   }
   PackedDw* pk_dw(const std::string& wname, const std::string& bname, const std::string& bn) {
@@ -307,7 +328,9 @@ struct esam3_engine {
     p.convt_cout = g->convt_cout;
     p.res_after_act = res_after_act;
     p.res_bidx = res_bidx;
-    return esam3_launch_gemm(dtype, p, st);
+    const double uniq_in = (double)M * g->cin * (g->ksize == 3 ? 1 : 1);
+    const double bytes = (uniq_in + (double)g->N * g->K + (double)M * g->N + (res ? (double)M * g->N : 0.0)) * (double)esz;
+    return prof_launch(g->tag, 2.0 * (double)M * g->N * g->K, bytes, [&]() { return esam3_launch_gemm(dtype, p, st); });
   }
   // 1x1 / 3x3 conv on an NHWC view -> new tensor (or into `dst` if given)
   int conv(const std::string& prefix, bool convlayer, const T4& x, int act, T4* y, const T4* res = nullptr,
@@ -349,8 +372,12 @@ struct esam3_engine {
     *y = alloc4(x.B, (x.H + stride - 1) / stride, (x.W + stride - 1) / stride, x.C);
     if (!ok(y->p)) return -1;
     if (dry) return 0;
-    return esam3_launch_dwconv(dtype, x.p, x.ld, d->w, d->bias, y->p, y->ld, x.B, x.H, x.W, x.C, d->ks,
-                               stride, act, st);
+    const double px_in = (double)x.rows() * x.C, px_out = (double)y->rows() * y->C;
+    return prof_launch("dwconv" + std::to_string(d->ks) + "s" + std::to_string(stride), 2.0 * px_out * d->ks * d->ks,
+                       (px_in + px_out) * (double)esz, [&]() {
+                         return esam3_launch_dwconv(dtype, x.p, x.ld, d->w, d->bias, y->p, y->ld, x.B, x.H, x.W,
+                                                    x.C, d->ks, stride, act, st);
+                       });
   }
   int linear(const std::string& prefix, const void* A, int lda, int64_t M, void* out, int ldc, int act,
              const void* res = nullptr, int ldr = 0, int res_mod = 0) {
@@ -364,7 +391,8 @@ struct esam3_engine {
     float* b = fvec(prefix + ".bias");
     if (!g || !b) return -1;
     if (dry) return 0;
-    return esam3_launch_layernorm(dtype, x, nullptr, g, b, out, rows, C, eps, act, st);
+    return prof_launch("layernorm", 8.0 * (double)rows * C, 2.0 * (double)rows * C * (double)esz,
+                       [&]() { return esam3_launch_layernorm(dtype, x, nullptr, g, b, out, rows, C, eps, act, st); });
   }
 
   // ---------------- graphs ----------------
@@ -423,14 +451,19 @@ int E::evit_block(const std::string& p, const T4& x, T4* y) {
       if (!gw) return -1;
       const int gs = (int)need(wn)->shape[1];
       if (!dry)
-        CK(esam3_launch_grouped_pw(dtype, agg.p, agg.ld, gw, (char*)ms.p + (size_t)total3 * esz, ms.ld,
-                                   ms.rows(), total3, gs, st));
+        CK(prof_launch("grouped_pw", 2.0 * (double)ms.rows() * total3 * gs, 2.0 * (double)ms.rows() * total3 * (double)esz, [&]() {
+          return esam3_launch_grouped_pw(dtype, agg.p, agg.ld, gw, (char*)ms.p + (size_t)total3 * esz, ms.ld,
+                                         ms.rows(), total3, gs, st);
+        }));
     }
     T4 att = alloc4(x.B, x.H, x.W, 2 * heads * dim);
     float* kv = (float*)allocb(sizeof(float) * (size_t)x.B * 2 * heads * (dim + 1) * dim);
     if (!ok(att.p) || !ok(kv)) return -1;
     if (!dry)
-      CK(esam3_launch_lite_mla(dtype, ms.p, ms.ld, att.p, att.ld, kv, x.B, x.H * x.W, 2 * heads, dim, st));
+      CK(prof_launch("lite_mla", 4.0 * (double)ms.rows() * 2 * heads * (dim + 1) * dim,
+                     (double)ms.rows() * (2.0 * total3 + 2.0 * heads * dim) * (double)esz, [&]() {
+                       return esam3_launch_lite_mla(dtype, ms.p, ms.ld, att.p, att.ld, kv, x.B, x.H * x.W, 2 * heads, dim, st);
+                     }));
     T4 t2;
     CK(conv(c + "proj", true, att, ACT_NONE, &t2, &x, &x1));
   }
@@ -479,7 +512,7 @@ int E::backbone(const float* img, int B, const esam3_image_features* out, T4* fe
       sb = fbufs[key + ".bias"];
     }
     if (!sw || !sb) return -1;
-    if (!dry) CK(esam3_launch_stem(dtype, img, sw, sb, x.p, B, IMG, IMG, widths[0], ACT_HSWISH, st));
+    if (!dry) CK(prof_launch("stem", 0.0, 0.0, [&]() { return esam3_launch_stem(dtype, img, sw, sb, x.p, B, IMG, IMG, widths[0], ACT_HSWISH, st); }));
   }
   for (int i = 0; i < depths[0]; ++i) {  // Residual(DSConv)  ops.py:273-312
     const std::string p = EVBB + "input_stem.op_list." + std::to_string(i + 1) + ".main.";
@@ -589,7 +622,7 @@ int E::encode(const float* img, int B, const esam3_image_features* out) {
   if (h2.H != EMB || h2.W != EMB) {
     trunk = alloc4(B, EMB, EMB, h2.C);
     if (!ok(trunk.p)) return -1;
-    if (!dry) CK(esam3_launch_resize_bilinear(dtype, h2.p, trunk.p, B, h2.H, h2.W, EMB, EMB, h2.C, st));
+    if (!dry) CK(prof_launch("resize_bilinear", 0.0, 0.0, [&]() { return esam3_launch_resize_bilinear(dtype, h2.p, trunk.p, B, h2.H, h2.W, EMB, EMB, h2.C, st); }));
   }
   if (out->trunk_dev && !dry)
     HIP_CHECK_RET(hipMemcpyAsync(out->trunk_dev, trunk.p, (size_t)trunk.rows() * trunk.C * esz,
@@ -707,8 +740,10 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
   void* keys = allocb((size_t)Bp * P * DM * esz);
   if (!ok(keys)) return -1;
   if (!dry)
-    CK(esam3_launch_gather_add(dtype, pr->sam2_fpn_dev[2], pr->prompt_image_dev, fbufs["src_cbias"], nullptr,
-                               keys, Bp, P, DM, st));
+    CK(prof_launch("gather_add", (double)Bp * P * DM, 2.0 * (double)Bp * P * DM * (double)esz, [&]() {
+      return esam3_launch_gather_add(dtype, pr->sam2_fpn_dev[2], pr->prompt_image_dev, fbufs["src_cbias"], nullptr,
+                                     keys, Bp, P, DM, st);
+    }));
 
   // scratch
   void* qin = allocb((size_t)TR * DM * esz);
@@ -734,7 +769,7 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
     CK(linear(ap + "q_proj", qin, DM, TR, tq, 128, ACT_NONE));
     CK(linear(ap + "k_proj", keys, DM, Bp * P, ik, 128, ACT_NONE, tbufs[ap + "k_proj#pe"], 128, (int)P));
     CK(linear(ap + "v_proj", keys, DM, Bp * P, iv, 128, ACT_NONE));
-    if (!dry) CK(esam3_launch_attn(dtype, tq, 128, ik, 128, iv, 128, ta, 128, Bp, T, (int)P, 8, 16, st));
+    if (!dry) CK(prof_launch("attn", 0.0, 0.0, [&]() { return esam3_launch_attn(dtype, tq, 128, ik, 128, iv, 128, ta, 128, Bp, T, (int)P, 8, 16, st); }));
     CK(linear(ap + "out_proj", ta, 128, TR, queries, DM, ACT_NONE, queries, DM));
     return ln(norm, queries, TR);
   };
@@ -747,7 +782,7 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
     CK(linear(lp + "self_attn.q_proj", qk_in, DM, TR, tq, DM, ACT_NONE));
     CK(linear(lp + "self_attn.k_proj", qk_in, DM, TR, tk, DM, ACT_NONE));
     CK(linear(lp + "self_attn.v_proj", queries, DM, TR, tv, DM, ACT_NONE));
-    if (!dry) CK(esam3_launch_attn(dtype, tq, DM, tk, DM, tv, DM, ta, DM, Bp, T, T, 8, 32, st));
+    if (!dry) CK(prof_launch("attn", 0.0, 0.0, [&]() { return esam3_launch_attn(dtype, tq, DM, tk, DM, tv, DM, ta, DM, Bp, T, T, 8, 32, st); }));
     if (li == 0) CK(linear(lp + "self_attn.out_proj", ta, DM, TR, queries, DM, ACT_NONE));
     else CK(linear(lp + "self_attn.out_proj", ta, DM, TR, queries, DM, ACT_NONE, queries, DM));
     CK(ln(lp + "norm1", queries, TR));
@@ -763,7 +798,7 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
     CK(linear(ip + "q_proj", keys, DM, Bp * P, ik, 128, ACT_NONE, tbufs[ip + "q_proj#pe"], 128, (int)P));
     CK(linear(ip + "k_proj", qin, DM, TR, tk, 128, ACT_NONE));
     CK(linear(ip + "v_proj", queries, DM, TR, tv, 128, ACT_NONE));
-    if (!dry) CK(esam3_launch_attn_fewkeys(dtype, ik, 128, tk, 128, tv, 128, iv, 128, Bp, (int)P, T, 8, 16, st));
+    if (!dry) CK(prof_launch("attn_fewkeys", 0.0, 0.0, [&]() { return esam3_launch_attn_fewkeys(dtype, ik, 128, tk, 128, tv, 128, iv, 128, Bp, (int)P, T, 8, 16, st); }));
     CK(linear(ip + "out_proj", iv, 128, Bp * P, keys, DM, ACT_NONE, keys, DM));
     CK(ln(lp + "norm4", keys, Bp * P));
   }
@@ -967,6 +1002,44 @@ int esam3_clamp_f32(esam3_engine* e, float* x, int64_t n, float lo, float hi, vo
 int esam3_preprocess_u8(const uint8_t* in, float* out, int B, int H, int W, void* stream) {
   if (!in || !out || B <= 0) { esam3_set_error("esam3_preprocess_u8: bad argument"); return -1; }
   return esam3_launch_preprocess_u8(in, out, B, H, W, (hipStream_t)stream);
+}
+
+int esam3_profile_enable(esam3_engine* e, int on) {
+  if (!e) return -1;
+  for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  e->recs.clear();
+  e->prof = on != 0;
+  return 0;
+}
+
+// JSON array, one object per tag sorted by total time:
+// {"tag":..., "launches":n, "ms":total, "flops":per-launch algorithmic, "bytes":per-launch algorithmic}
+int esam3_profile_report(esam3_engine* e, char* buf, int64_t buf_size) {
+  if (!e || !buf || buf_size <= 2) { esam3_set_error("esam3_profile_report: bad argument"); return -1; }
+  HIP_CHECK_RET(hipDeviceSynchronize());
+  struct Agg { double ms = 0, flops = 0, bytes = 0; int n = 0; };
+  std::unordered_map<std::string, Agg> agg;
+  for (auto& r : e->recs) {
+    float ms = 0.f;
+    HIP_CHECK_RET(hipEventElapsedTime(&ms, r.a, r.b));
+    Agg& a = agg[r.tag];
+    a.ms += ms; a.n += 1; a.flops = r.flops; a.bytes = r.bytes;
+    hipEventDestroy(r.a); hipEventDestroy(r.b);
+  }
+  e->recs.clear();
+  std::vector<std::pair<std::string, Agg>> v(agg.begin(), agg.end());
+  std::sort(v.begin(), v.end(), [](const auto& x, const auto& y) { return x.second.ms > y.second.ms; });
+  std::string out = "[";
+  for (size_t i = 0; i < v.size(); ++i) {
+    char line[768];
+    snprintf(line, sizeof(line), "%s{\"tag\":\"%s\",\"launches\":%d,\"ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e}",
+             i ? "," : "", v[i].first.c_str(), v[i].second.n, v[i].second.ms, v[i].second.flops, v[i].second.bytes);
+    if ((int64_t)(out.size() + strlen(line) + 2) >= buf_size) break;
+    out += line;
+  }
+  out += "]";
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return 0;
 }
 
 int64_t esam3_workspace_bytes(const esam3_engine* e) { return e ? (int64_t)e->arena.cap : 0; }

@@ -176,5 +176,16 @@ class HipEngine:
         _lib.check(self.lib.esam3_clamp_f32(self.handle, _ptr(x), x.numel(), lo, hi, _stream()), "esam3_clamp_f32")
         return x
 
+    def profile_enable(self, on: bool = True):
+        _lib.check(self.lib.esam3_profile_enable(self.handle, int(on)), "esam3_profile_enable")
+
+    def profile_report(self) -> list:
+        """Per-tag HIP-event timings recorded since profile_enable(True): list of dicts
+        {tag, launches, ms (total), flops, bytes (algorithmic, per launch)} sorted by time."""
+        import json
+        buf = C.create_string_buffer(1 << 20)
+        _lib.check(self.lib.esam3_profile_report(self.handle, buf, len(buf)), "esam3_profile_report")
+        return json.loads(buf.value.decode())
+
     def workspace_bytes(self) -> int:
         return int(self.lib.esam3_workspace_bytes(self.handle))

@@ -98,6 +98,11 @@ int esam3_clamp_f32(esam3_engine* e, float* x_dev, int64_t n, float lo, float hi
 int esam3_preprocess_u8(const uint8_t* img_hwc_u8_dev, float* out_nchw_f32_dev, int B, int H, int W,
                         void* hip_stream);
 
+/* Per-launch timing with HIP events on the launch stream (bench.py roofline leg): enable,
+ * run encode/decode, then fetch a JSON report (syncs the device, clears the records). */
+int esam3_profile_enable(esam3_engine* e, int on);
+int esam3_profile_report(esam3_engine* e, char* json_buf, int64_t buf_size);
+
 /* bytes of engine workspace currently reserved, and size of one activation element */
 int64_t esam3_workspace_bytes(const esam3_engine* e);
 int esam3_elem_size(const esam3_engine* e);
