@@ -21,7 +21,7 @@ class Esam3Error(RuntimeError):
 
 class Config(C.Structure):
     _fields_ = [("dtype", C.c_int), ("backbone", C.c_int), ("model_name", C.c_char * 16),
-                ("device", C.c_int), ("interactive", C.c_int)]
+                ("device", C.c_int), ("interactive", C.c_int), ("fuse_linear_chains", C.c_int)]
 
 
 class ImageFeatures(C.Structure):

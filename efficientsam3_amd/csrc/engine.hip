@@ -247,6 +247,80 @@ struct esam3_engine {
     g.tag = wname;
     return &(gemms[wname] = g);
   }
+  // ---- exact algebraic composition of linear chains (no activation in between) ----------
+  // ConvTranspose2d(k2,s2) followed by a 1x1 conv == one ConvTranspose2d with
+  //   W'[ci][co][t] = sum_m W[ci][m][t] * w1[co][m],  b'[co] = sum_m w1[co][m] * b[m] + b1[co]
+  // (necks.py:42-92: dconv_2x2(_1) -> conv_1x1).  fp64 accumulation on the host.
+  bool compose_convT_1x1(const std::string& tprefix, const std::string& cprefix, const std::string& key) {
+    if (find(key + ".weight")) return true;
+    const HostTensor *w = need(tprefix + ".weight"), *b = need(tprefix + ".bias"),
+                     *w1 = need(cprefix + ".weight"), *b1 = need(cprefix + ".bias");
+    if (!w || !b || !w1 || !b1) return false;
+    const int cin = (int)w->shape[0], cm = (int)w->shape[1], co = (int)w1->shape[0];
+    std::vector<double> w1t((size_t)cm * co);
+    for (int o = 0; o < co; ++o)
+      for (int m = 0; m < cm; ++m) w1t[(size_t)m * co + o] = w1->d[(size_t)o * cm + m];
+    HostTensor ow, ob;
+    ow.shape = {cin, co, 2, 2};
+    ow.d.assign((size_t)cin * co * 4, 0.f);
+    std::vector<double> acc(co);
+    for (int ci = 0; ci < cin; ++ci)
+      for (int t = 0; t < 4; ++t) {
+        std::fill(acc.begin(), acc.end(), 0.0);
+        for (int m = 0; m < cm; ++m) {
+          const double a = w->d[((size_t)ci * cm + m) * 4 + t];
+          const double* r = &w1t[(size_t)m * co];
+          for (int o = 0; o < co; ++o) acc[o] += a * r[o];
+        }
+        for (int o = 0; o < co; ++o) ow.d[((size_t)ci * co + o) * 4 + t] = (float)acc[o];
+      }
+    ob.shape = {co};
+    ob.d.resize(co);
+    for (int o = 0; o < co; ++o) {
+      double a = b1->d[o];
+      for (int m = 0; m < cm; ++m) a += (double)w1->d[(size_t)o * cm + m] * b->d[m];
+      ob.d[o] = (float)a;
+    }
+    raw[key + ".weight"] = std::move(ow);
+    raw[key + ".bias"] = std::move(ob);
+    return true;
+  }
+  // k x k conv followed by a 1x1 conv == one k x k conv with
+  //   W'[o][c][t] = sum_m w1[o][m] * W[m][c][t],  b'[o] = sum_m w1[o][m] * b[m] + b1[o]
+  // (conv_3x3 -> conv_s0/conv_s1, sam3_image_processor.py:62-75); exact also at the zero-padded
+  // border because the 1x1 acts on the 3x3's output pixel.
+  bool compose_conv_1x1(const std::string& kprefix, const std::string& cprefix, const std::string& key) {
+    if (find(key + ".weight")) return true;
+    const HostTensor *w = need(kprefix + ".weight"), *b = need(kprefix + ".bias"),
+                     *w1 = need(cprefix + ".weight"), *b1 = need(cprefix + ".bias");
+    if (!w || !b || !w1 || !b1) return false;
+    const int cm = (int)w->shape[0], cin = (int)w->shape[1], ks = (int)w->shape[2], co = (int)w1->shape[0];
+    const size_t inner = (size_t)cin * ks * ks;
+    HostTensor ow, ob;
+    ow.shape = {co, cin, ks, ks};
+    ow.d.resize((size_t)co * inner);
+    std::vector<double> acc(inner);
+    for (int o = 0; o < co; ++o) {
+      std::fill(acc.begin(), acc.end(), 0.0);
+      for (int m = 0; m < cm; ++m) {
+        const double a = w1->d[(size_t)o * cm + m];
+        const float* r = &w->d[(size_t)m * inner];
+        for (size_t j = 0; j < inner; ++j) acc[j] += a * r[j];
+      }
+      for (size_t j = 0; j < inner; ++j) ow.d[(size_t)o * inner + j] = (float)acc[j];
+    }
+    ob.shape = {co};
+    ob.d.resize(co);
+    for (int o = 0; o < co; ++o) {
+      double a = b1->d[o];
+      for (int m = 0; m < cm; ++m) a += (double)w1->d[(size_t)o * cm + m] * b->d[m];
+      ob.d[o] = (float)a;
+    }
+    raw[key + ".weight"] = std::move(ow);
+    raw[key + ".bias"] = std::move(ob);
+    return true;
+  }
+
   PackedGemm* pk_linear(const std::string& prefix, bool bias = true) {
     return pk_conv_like_linear(prefix + ".weight", bias ? prefix + ".bias" : "");
   }
@@ -563,15 +637,28 @@ int E::neck(const std::string& which, const T4& trunk, void* const outs[3], bool
     return t;
   };
   const size_t mk = arena.mark();
+  const bool fuse = cfg.fuse_linear_chains != 0;
   if (outs[0]) {  // level 0: ConvT -> GELU -> ConvT -> 1x1 -> 3x3   @288
     T4 a, b, c, d, t;
     CK(convT(p + "0.dconv_2x2_0", trunk, ACT_GELU, &a));
-    CK(convT(p + "0.dconv_2x2_1", a, ACT_NONE, &b));
-    CK(conv(p + "0.conv_1x1", false, b, ACT_NONE, &c));
+    if (fuse) {  // ConvT o 1x1 composed into one ConvT 512 -> 256
+      const std::string k = p + "0.dconv_2x2_1+conv_1x1";
+      if (!compose_convT_1x1(p + "0.dconv_2x2_1", p + "0.conv_1x1", k)) return -1;
+      CK(convT(k, a, ACT_NONE, &c));
+    } else {
+      CK(convT(p + "0.dconv_2x2_1", a, ACT_NONE, &b));
+      CK(conv(p + "0.conv_1x1", false, b, ACT_NONE, &c));
+    }
     if (sam2) {
-      CK(conv(p + "0.conv_3x3", false, c, ACT_NONE, &d));
       T4 o = outT(outs[0], 4 * EMB, 32);
-      CK(conv(MD + "conv_s0", false, d, ACT_NONE, &t, nullptr, &o));
+      if (fuse) {  // 3x3 o conv_s0 composed into one 3x3 conv 256 -> 32
+        const std::string k = p + "0.conv_3x3+conv_s0";
+        if (!compose_conv_1x1(p + "0.conv_3x3", MD + "conv_s0", k)) return -1;
+        CK(conv(k, false, c, ACT_NONE, &t, nullptr, &o));
+      } else {
+        CK(conv(p + "0.conv_3x3", false, c, ACT_NONE, &d));
+        CK(conv(MD + "conv_s0", false, d, ACT_NONE, &t, nullptr, &o));
+      }
     } else {
       T4 o = outT(outs[0], 4 * EMB, DM);
       CK(conv(p + "0.conv_3x3", false, c, ACT_NONE, &t, nullptr, &o));
@@ -580,12 +667,24 @@ int E::neck(const std::string& which, const T4& trunk, void* const outs[3], bool
   }
   if (outs[1]) {  // level 1: ConvT -> 1x1 -> 3x3   @144
     T4 a, c, d, t;
-    CK(convT(p + "1.dconv_2x2", trunk, ACT_NONE, &a));
-    CK(conv(p + "1.conv_1x1", false, a, ACT_NONE, &c));
+    if (fuse) {  // ConvT o 1x1 composed into one ConvT 1024 -> 256
+      const std::string k = p + "1.dconv_2x2+conv_1x1";
+      if (!compose_convT_1x1(p + "1.dconv_2x2", p + "1.conv_1x1", k)) return -1;
+      CK(convT(k, trunk, ACT_NONE, &c));
+    } else {
+      CK(convT(p + "1.dconv_2x2", trunk, ACT_NONE, &a));
+      CK(conv(p + "1.conv_1x1", false, a, ACT_NONE, &c));
+    }
     if (sam2) {
-      CK(conv(p + "1.conv_3x3", false, c, ACT_NONE, &d));
       T4 o = outT(outs[1], 2 * EMB, 64);
-      CK(conv(MD + "conv_s1", false, d, ACT_NONE, &t, nullptr, &o));
+      if (fuse) {
+        const std::string k = p + "1.conv_3x3+conv_s1";
+        if (!compose_conv_1x1(p + "1.conv_3x3", MD + "conv_s1", k)) return -1;
+        CK(conv(k, false, c, ACT_NONE, &t, nullptr, &o));
+      } else {
+        CK(conv(p + "1.conv_3x3", false, c, ACT_NONE, &d));
+        CK(conv(MD + "conv_s1", false, d, ACT_NONE, &t, nullptr, &o));
+      }
     } else {
       T4 o = outT(outs[1], 2 * EMB, DM);
       CK(conv(p + "1.conv_3x3", false, c, ACT_NONE, &t, nullptr, &o));

@@ -296,50 +296,99 @@ __device__ inline void uf_union(int* lab, int a, int b) {
   }
 }
 
-__global__ void fill_holes_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                  int* __restrict__ labels, int* __restrict__ areas, int H, int W,
-                                  float thr, float max_area) {
-  const int64_t n = blockIdx.x;
-  const int HW = H * W;
+// Four grid-wide passes (the kernel boundaries are the global barriers):
+//   cc_init  : label = first pixel of the horizontal background run (inside the wavefront's
+//              64-pixel segment), so most pixels start already merged;
+//   cc_merge : lock-free unions with the W / N / NW / NE neighbours, skipping the ones that
+//              are implied by the neighbour's own unions;
+//   cc_count : per-root areas, one atomicAdd per (wavefront, run of equal roots);
+//   cc_apply : write thr+10 into components of area <= max_area.
+__global__ void cc_init_kernel(const float* __restrict__ in, int* __restrict__ lab, int* __restrict__ area,
+                               int W, int HW, int64_t total, float thr) {
+  const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = gi < total;
+  const int lane = threadIdx.x & 63;
+  const int i = valid ? (int)(gi % HW) : 0;
+  const bool bg = valid && in[gi] <= thr;
+  const unsigned long long m = __ballot(bg);
+  if (!valid) return;
+  int v = -1;
+  if (bg) {
+    const unsigned long long below = ~m & ((1ull << lane) - 1ull);
+    int start = below ? 64 - __clzll(below) : 0;  // first lane of this run inside the wave
+    const int x = i % W;
+    if (lane - x > start) start = lane - x;       // runs do not cross the row start
+    v = i - (lane - start);
+  }
+  lab[gi] = v;
+  area[gi] = 0;
+}
+
+__global__ void cc_merge_kernel(const float* __restrict__ in, int* __restrict__ labels, int W, int H, int HW,
+                                int64_t total, float thr) {
+  const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= total) return;
+  const int64_t n = gi / HW;
+  const int i = (int)(gi - n * HW);
   const float* src = in + n * HW;
-  float* dst = out + n * HW;
+  if (!(src[i] <= thr)) return;
   int* lab = labels + n * HW;
-  int* area = areas + n * HW;
-  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-    lab[i] = (src[i] <= thr) ? i : -1;
-    area[i] = 0;
-  }
-  __threadfence();
-  __syncthreads();
-  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-    if (lab[i] < 0) continue;
-    const int y = i / W, x = i - y * W;
-    // union with W, NW, N, NE neighbours that are background
-    if (x > 0 && src[i - 1] <= thr) uf_union(lab, i, i - 1);
-    if (y > 0) {
-      if (src[i - W] <= thr) uf_union(lab, i, i - W);
-      if (x > 0 && src[i - W - 1] <= thr) uf_union(lab, i, i - W - 1);
-      if (x < W - 1 && src[i - W + 1] <= thr) uf_union(lab, i, i - W + 1);
+  const int y = i / W, x = i - y * W;
+  const bool w_bg = x > 0 && src[i - 1] <= thr;
+  // cc_init merged runs only inside one 64-pixel wavefront segment: stitch the seams
+  if (w_bg && (gi & 63) == 0) uf_union(lab, i, i - 1);
+  if (y > 0) {
+    const bool n_bg = src[i - W] <= thr;
+    const bool nw_bg = x > 0 && src[i - W - 1] <= thr;
+    const bool ne_bg = x < W - 1 && src[i - W + 1] <= thr;
+    if (n_bg) {
+      if (!(w_bg && nw_bg)) uf_union(lab, i, i - W);
+    } else {
+      if (nw_bg && !w_bg) uf_union(lab, i, i - W - 1);
+      if (ne_bg) uf_union(lab, i, i - W + 1);
     }
   }
-  __threadfence();
-  __syncthreads();
-  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-    if (lab[i] < 0) continue;
-    const int r = uf_find(lab, i);
-    atomicAdd(area + r, 1);
-  }
-  __threadfence();
-  __syncthreads();
-  for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-    float v = src[i];
-    if (v <= thr) {
+}
+
+__global__ void cc_count_kernel(int* __restrict__ labels, int* __restrict__ areas, int HW, int64_t total) {
+  const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = gi < total;
+  const int lane = threadIdx.x & 63;
+  int64_t key = -1;  // global index of the root, -1 = not a background pixel
+  if (valid) {
+    const int64_t n = gi / HW;
+    const int i = (int)(gi - n * HW);
+    int* lab = labels + n * HW;
+    if (__hip_atomic_load(lab + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) {
       const int r = uf_find(lab, i);
-      const int a = __hip_atomic_load(area + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((float)a <= max_area) v = thr + 10.f;
+      __hip_atomic_store(lab + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // path compression
+      key = n * HW + r;
     }
-    dst[i] = v;
   }
+  // run-length aggregate equal keys of consecutive lanes
+  const int64_t prev = __shfl_up(key, 1);
+  const bool leader = key >= 0 && (lane == 0 || prev != key);
+  const bool brk = lane == 0 || prev != key;  // any change of key starts a new run
+  const unsigned long long bm = __ballot(brk);
+  if (leader) {
+    const unsigned long long above = lane == 63 ? 0ull : (bm >> (lane + 1));
+    const int len = above ? __ffsll((long long)above) : 64 - lane;
+    atomicAdd(areas + key, len);
+  }
+}
+
+__global__ void cc_apply_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                const int* __restrict__ labels, const int* __restrict__ areas, int HW,
+                                int64_t total, float thr, float max_area) {
+  const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= total) return;
+  float v = in[gi];
+  if (v <= thr) {
+    const int64_t n = gi / HW;
+    const int r = labels[gi];  // compressed to the root by cc_count
+    if ((float)areas[n * HW + r] <= max_area) v = thr + 10.f;
+  }
+  out[gi] = v;
 }
 
 // bilinear upsample (align_corners=False) of fp32 masks, optional > thr -> u8
@@ -476,8 +525,13 @@ int esam3_launch_select_masks(int dtype, const float* all_masks, const void* all
 int esam3_launch_fill_holes(const float* in, float* out, int* labels, int* areas, int n, int H, int W,
                             float thr, float max_area, hipStream_t s) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(fill_holes_kernel, dim3((unsigned)n), dim3(1024), 0, s, in, out, labels, areas, H,
-                     W, thr, max_area);
+  const int HW = H * W;
+  const int64_t total = (int64_t)n * HW;
+  const dim3 grid(blocks_for(total, 256)), blk(256);
+  hipLaunchKernelGGL(cc_init_kernel, grid, blk, 0, s, in, labels, areas, W, HW, total, thr);
+  hipLaunchKernelGGL(cc_merge_kernel, grid, blk, 0, s, in, labels, W, H, HW, total, thr);
+  hipLaunchKernelGGL(cc_count_kernel, grid, blk, 0, s, labels, areas, HW, total);
+  hipLaunchKernelGGL(cc_apply_kernel, grid, blk, 0, s, in, out, labels, areas, HW, total, thr, max_area);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

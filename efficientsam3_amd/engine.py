@@ -31,7 +31,7 @@ class HipEngine:
 
     def __init__(self, backbone_type: str = "efficientvit", model_name: str = "b1",
                  dtype: str = "bf16", device: Optional[torch.device] = None,
-                 interactive: bool = True):
+                 interactive: bool = True, fuse_linear_chains: bool = True):
         if not torch.cuda.is_available():
             raise _lib.Esam3Error("no HIP device visible: the EfficientSAM3 engine has no CPU path")
         if backbone_type != "efficientvit":
@@ -48,7 +48,8 @@ class HipEngine:
         self.interactive = interactive
         self.model_name = model_name
         cfg = _lib.Config(dtype=self.esam_dtype, backbone=0, model_name=model_name.encode(),
-                          device=self.dev_index, interactive=int(interactive))
+                          device=self.dev_index, interactive=int(interactive),
+                          fuse_linear_chains=int(fuse_linear_chains))
         h = C.c_void_p()
         _lib.check(self.lib.esam3_create(C.byref(cfg), C.byref(h)), "esam3_create")
         self.handle = h

@@ -59,6 +59,7 @@ def build_efficientsam3_image_model(
     state_dict: Optional[Dict[str, torch.Tensor]] = None,
     synthetic_seed: int = 0,
     dual_neck: bool = True,
+    fuse_linear_chains: bool = True,
 ) -> Sam3Image:
     """Build an EfficientSAM3 image model whose encode/decode run as HIP kernels on MI355X.
 
@@ -66,13 +67,15 @@ def build_efficientsam3_image_model(
     tracing compiler; the engine *is* the compiled graph).  ``text_encoder_type`` /
     ``enable_segmentation`` configure the text-grounding path, which this build does not run yet.
     ``dtype``: "bf16" (throughput) or "f32" (validation: exact-f32 MFMA).
+    ``fuse_linear_chains``: compose the neck's ConvT->1x1 and 3x3->conv_s0/s1 weight chains at
+    load time (exact algebra, same outputs, fewer FLOPs); False runs the reference's layer list.
     """
     if efficientvit_model is not None:
         backbone_type, model_name = "efficientvit", efficientvit_model
     if str(device).startswith("cpu"):
         raise RuntimeError("EfficientSAM3-AMD has no CPU path; pass a HIP device (device='cuda')")
     model = Sam3Image(backbone_type, model_name, bool(enable_inst_interactivity), dtype=dtype,
-                      device=device, dual_neck=dual_neck)
+                      device=device, dual_neck=dual_neck, fuse_linear_chains=fuse_linear_chains)
     if state_dict is None and checkpoint_path is not None:
         with open(checkpoint_path, "rb") as f:
             ckpt = torch.load(f, map_location="cpu", weights_only=True)

@@ -95,12 +95,14 @@ class Sam3Image:
     """EfficientSAM3 image model whose forward passes run on the HIP engine."""
 
     def __init__(self, backbone_type: str, model_name: str, enable_inst_interactivity: bool,
-                 dtype: str = "bf16", device=None, dual_neck: bool = True):
+                 dtype: str = "bf16", device=None, dual_neck: bool = True,
+                 fuse_linear_chains: bool = True):
         self.backbone_type = backbone_type
         self.model_name = model_name
         self.dual_neck = dual_neck
         self.engine = HipEngine(backbone_type, model_name, dtype=dtype, device=device,
-                                interactive=enable_inst_interactivity)
+                                interactive=enable_inst_interactivity,
+                                fuse_linear_chains=fuse_linear_chains)
         self.device = self.engine.device
         self.backbone = _VLBackbone(self)
         self.inst_interactive_predictor = _InteractivePredictorInfo() if enable_inst_interactivity else None

@@ -41,6 +41,8 @@ typedef struct esam3_config {
   char model_name[16];  /* "b0" | "b1" | "b2" */
   int device;           /* HIP device ordinal */
   int interactive;      /* 1: sam2 neck + SAM heads are present (enable_inst_interactivity) */
+  int fuse_linear_chains; /* 1: compose ConvT->1x1 and 3x3->conv_s0/s1 weight chains at finalize
+                           (exact algebra, fewer FLOPs); 0: run the reference's layer list */
 } esam3_config;
 
 /* Outputs of the image encoder; NULL members are skipped.  B = batch.
