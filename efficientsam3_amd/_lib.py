@@ -64,6 +64,7 @@ SIGNATURES = {
     "esam3_preprocess_u8": (_I, [_P, _P, _I, _I, _I, _P]),
     "esam3_op_linear": (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "esam3_op_conv2d": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "esam3_op_conv3x3_padded": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_conv_transpose2x2": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_dwconv": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_stem": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -73,6 +73,7 @@ struct T4 {  // NHWC activation view
   void* p = nullptr;
   int B = 0, H = 0, W = 0, C = 0;
   int ld = 0;  // row stride in elements
+  int pad = 0; // 1: memory is [B][H+2][W+2][ld] with a zero border (input of a 3x3 conv)
   int64_t rows() const { return (int64_t)B * H * W; }
 };
 
@@ -381,6 +382,14 @@ struct esam3_engine {
     t.p = arena.alloc((size_t)B * H * W * C * esz);
     return t;
   }
+  // tensor with a 1-pixel zero border; the border is (re)zeroed here, producers fill the interior
+  int alloc4_padded(int B, int H, int W, int C, T4* t) {
+    t->B = B; t->H = H; t->W = W; t->C = C; t->ld = C; t->pad = 1;
+    t->p = arena.alloc((size_t)B * (H + 2) * (W + 2) * C * esz);
+    if (!ok(t->p)) return -1;
+    if (dry) return 0;
+    return prof_launch("zero_border", 0.0, 0.0, [&]() { return esam3_launch_zero_border(dtype, t->p, B, H + 2, W + 2, C, st); });
+  }
   void* allocb(size_t bytes) { return arena.alloc(bytes); }
   bool ok(const void* p) {
     if (!p) esam3_set_error("workspace arena exhausted (cap %zu, need %zu)", arena.cap, arena.top);
@@ -390,8 +399,9 @@ struct esam3_engine {
   // ---------------- launch helpers ----------------
   int gemm(const PackedGemm* g, const void* A, int lda, int64_t M, int H, int W, void* out, int ldc,
            int act, const void* res = nullptr, int ldr = 0, int res_after_act = 1, int res_mod = 0,
-           const int* res_bidx = nullptr) {
+           const int* res_bidx = nullptr, int in_pad = 0, int out_pad = 0) {
     if (!g) return -1;
+    if (in_pad && g->ksize != 3) { esam3_set_error("padded input given to a %dx%d conv", g->ksize, g->ksize); return -1; }
     if (dry) return 0;
     GemmParams p{};
     p.A = A; p.Wt = g->w; p.bias = g->bias; p.res = res; p.out = out;
@@ -402,13 +412,15 @@ struct esam3_engine {
     p.convt_cout = g->convt_cout;
     p.res_after_act = res_after_act;
     p.res_bidx = res_bidx;
+    p.in_pad = in_pad;
+    p.out_pad = out_pad;
     const double uniq_in = (double)M * g->cin * (g->ksize == 3 ? 1 : 1);
     const double bytes = (uniq_in + (double)g->N * g->K + (double)M * g->N + (res ? (double)M * g->N : 0.0)) * (double)esz;
     return prof_launch(g->tag, 2.0 * (double)M * g->N * g->K, bytes, [&]() { return esam3_launch_gemm(dtype, p, st); });
   }
   // 1x1 / 3x3 conv on an NHWC view -> new tensor (or into `dst` if given)
   int conv(const std::string& prefix, bool convlayer, const T4& x, int act, T4* y, const T4* res = nullptr,
-           const T4* dst = nullptr) {
+           const T4* dst = nullptr, bool out_pad = false) {
     // convlayer: EfficientViT ConvLayer naming (.conv.weight/.conv.bias/.norm.*); else plain nn.Conv2d
     PackedGemm* g;
     if (convlayer) {
@@ -421,17 +433,21 @@ struct esam3_engine {
     }
     if (!g) return -1;
     if (g->cin != x.C) { esam3_set_error("conv %s: Cin %d != %d", prefix.c_str(), g->cin, x.C); return -1; }
-    if (dst) *y = *dst; else *y = alloc4(x.B, x.H, x.W, g->N);
+    if (dst) *y = *dst;
+    else if (out_pad) { if (alloc4_padded(x.B, x.H, x.W, g->N, y)) return -1; }
+    else *y = alloc4(x.B, x.H, x.W, g->N);
     if (!ok(y->p)) return -1;
-    return gemm(g, x.p, x.ld, x.rows(), x.H, x.W, y->p, y->ld, act, res ? res->p : nullptr, res ? res->ld : 0);
+    return gemm(g, x.p, x.ld, x.rows(), x.H, x.W, y->p, y->ld, act, res ? res->p : nullptr, res ? res->ld : 0,
+                1, 0, nullptr, x.pad, y->pad);
   }
   int convT(const std::string& prefix, const T4& x, int act, T4* y, const void* res = nullptr, int ldr = 0,
-            int res_after_act = 1, const int* res_bidx = nullptr) {
+            int res_after_act = 1, const int* res_bidx = nullptr, bool out_pad = false) {
     PackedGemm* g = pk_convT(prefix + ".weight", prefix + ".bias");
     if (!g) return -1;
-    *y = alloc4(x.B, 2 * x.H, 2 * x.W, g->convt_cout);
+    if (out_pad) { if (alloc4_padded(x.B, 2 * x.H, 2 * x.W, g->convt_cout, y)) return -1; }
+    else *y = alloc4(x.B, 2 * x.H, 2 * x.W, g->convt_cout);
     if (!ok(y->p)) return -1;
-    return gemm(g, x.p, x.ld, x.rows(), x.H, x.W, y->p, y->ld, act, res, ldr, res_after_act, 0, res_bidx);
+    return gemm(g, x.p, x.ld, x.rows(), x.H, x.W, y->p, y->ld, act, res, ldr, res_after_act, 0, res_bidx, 0, y->pad);
   }
   int dwconv(const std::string& prefix, bool convlayer, const T4& x, int stride, int act, T4* y) {
     PackedDw* d;
@@ -644,10 +660,10 @@ int E::neck(const std::string& which, const T4& trunk, void* const outs[3], bool
     if (fuse) {  // ConvT o 1x1 composed into one ConvT 512 -> 256
       const std::string k = p + "0.dconv_2x2_1+conv_1x1";
       if (!compose_convT_1x1(p + "0.dconv_2x2_1", p + "0.conv_1x1", k)) return -1;
-      CK(convT(k, a, ACT_NONE, &c));
+      CK(convT(k, a, ACT_NONE, &c, nullptr, 0, 1, nullptr, true));
     } else {
       CK(convT(p + "0.dconv_2x2_1", a, ACT_NONE, &b));
-      CK(conv(p + "0.conv_1x1", false, b, ACT_NONE, &c));
+      CK(conv(p + "0.conv_1x1", false, b, ACT_NONE, &c, nullptr, nullptr, true));
     }
     if (sam2) {
       T4 o = outT(outs[0], 4 * EMB, 32);
@@ -670,10 +686,10 @@ int E::neck(const std::string& which, const T4& trunk, void* const outs[3], bool
     if (fuse) {  // ConvT o 1x1 composed into one ConvT 1024 -> 256
       const std::string k = p + "1.dconv_2x2+conv_1x1";
       if (!compose_convT_1x1(p + "1.dconv_2x2", p + "1.conv_1x1", k)) return -1;
-      CK(convT(k, trunk, ACT_NONE, &c));
+      CK(convT(k, trunk, ACT_NONE, &c, nullptr, 0, 1, nullptr, true));
     } else {
       CK(convT(p + "1.dconv_2x2", trunk, ACT_NONE, &a));
-      CK(conv(p + "1.conv_1x1", false, a, ACT_NONE, &c));
+      CK(conv(p + "1.conv_1x1", false, a, ACT_NONE, &c, nullptr, nullptr, true));
     }
     if (sam2) {
       T4 o = outT(outs[1], 2 * EMB, 64);
@@ -693,7 +709,7 @@ int E::neck(const std::string& which, const T4& trunk, void* const outs[3], bool
   }
   if (outs[2]) {  // level 2: 1x1 -> 3x3   @72
     T4 c, t;
-    CK(conv(p + "2.conv_1x1", false, trunk, ACT_NONE, &c));
+    CK(conv(p + "2.conv_1x1", false, trunk, ACT_NONE, &c, nullptr, nullptr, true));
     T4 o = outT(outs[2], EMB, DM);
     CK(conv(p + "2.conv_3x3", false, c, ACT_NONE, &t, nullptr, &o));
     arena.release(mk);
@@ -712,9 +728,8 @@ int E::encode(const float* img, int B, const esam3_image_features* out) {
   {
     PackedGemm* g = pk_conv(TRUNK + "head.0.weight", "", TRUNK + "head.1");
     if (!g) return -1;
-    h1 = alloc4(feat.B, feat.H, feat.W, g->N);
-    if (!ok(h1.p)) return -1;
-    CK(gemm(g, feat.p, feat.ld, feat.rows(), feat.H, feat.W, h1.p, h1.ld, ACT_GELU));
+    if (alloc4_padded(feat.B, feat.H, feat.W, g->N, &h1)) return -1;
+    CK(gemm(g, feat.p, feat.ld, feat.rows(), feat.H, feat.W, h1.p, h1.ld, ACT_GELU, nullptr, 0, 1, 0, nullptr, 0, 1));
   }
   CK(conv(TRUNK + "head.3", false, h1, ACT_NONE, &h2));
   T4 trunk = h2;

@@ -77,6 +77,8 @@ struct GemmParams {
   int convt_cout;     // OUT_CONVT2X2: Cout per tap (N == 4*Cout)
   int res_after_act;  // 1: out = act(acc+bias) + res ; 0: out = act(acc+bias+res)
   const int* res_bidx;  // optional: residual batch index per output batch item (gather)
+  int in_pad;         // 1 (ksize 3 only): A is [B][H+2][W+2][lda] with a zero border -> no bounds checks
+  int out_pad;        // 1: write the output inside a 1-pixel border ([B][OH+2][OW+2][ldc])
 };
 
 // ---- error handling ---------------------------------------------------------------

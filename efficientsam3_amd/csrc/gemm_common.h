@@ -1,0 +1,101 @@
+// Pieces shared by the implicit-GEMM kernels (gemm_conv.hip): MFMA wrappers, the LDS
+// swizzle and the fused epilogue (bias / activation / residual / ConvT pixel-shuffle /
+// zero-border padded output) for one 8-channel chunk of one output row.
+#pragma once
+#include "esam3_common.h"
+
+// 16-byte register value as a first-class vector (an array of struct uint4 is not reliably
+// promoted out of scratch by the compiler).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct MmaOps;
+template <> struct MmaOps<bf16_t> {
+  // one 16-byte fragment = 8 bf16 along K -> one v_mfma_f32_32x32x16_bf16
+  static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& a, f32x16_v& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, w),
+                                                  __builtin_bit_cast(bf16x8_v, a), acc, 0, 0, 0);
+  }
+};
+template <> struct MmaOps<float> {
+  // one 16-byte fragment = 4 f32 along K -> four v_mfma_f32_32x32x2_f32 (exact f32 FMA chain)
+  static __device__ __forceinline__ void mma(const u32x4& w, const u32x4& a, f32x16_v& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.x), __uint_as_float(a.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.y), __uint_as_float(a.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.z), __uint_as_float(a.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(w.w), __uint_as_float(a.w), acc, 0, 0, 0);
+  }
+};
+
+// LDS tiles are [rows][128 B]; the 16-byte slot index is XOR-ed with (row>>1)&7 so that the
+// 16-lane ds_read_b128 groups and the 8-lane ds_write_b128 groups touch distinct banks.
+__device__ __forceinline__ int swz(int row, int slot) { return (slot ^ ((row >> 1) & 7)) << 4; }
+
+// Epilogue for output row m, channels [n, n+8): v holds the raw accumulators.
+template <typename T>
+__device__ __forceinline__ void epilogue_chunk(const GemmParams& p, int64_t m, int n, float (&v)[8]) {
+  constexpr int OC = 8;
+  T* __restrict__ gO = reinterpret_cast<T*>(p.out);
+  const T* __restrict__ gR = reinterpret_cast<const T*>(p.res);
+  const int HW = p.H * p.W;
+  const int P = p.out_pad;  // 0 or 1: output written inside a zero border
+  int64_t o_off, r_off;
+  int bias_n = n;
+  if (p.out_mode == OUT_CONVT2X2) {
+    const int tap = n / p.convt_cout, co = n - tap * p.convt_cout;
+    const int64_t b = m / HW;
+    const int rem = (int)(m - b * HW);
+    const int h = rem / p.W, w = rem - h * p.W;
+    const int oh = 2 * h + (tap >> 1), ow = 2 * w + (tap & 1);
+    const int OHp = 2 * p.H + 2 * P, OWp = 2 * p.W + 2 * P;
+    o_off = ((b * OHp + oh + P) * (int64_t)OWp + ow + P) * p.ldc + co;
+    const int64_t rb = p.res_bidx ? (int64_t)p.res_bidx[b] : b;
+    r_off = (rb * 4 * HW + (int64_t)oh * (2 * p.W) + ow) * p.ldr + co;
+    bias_n = co;
+  } else {
+    if (P) {
+      const int64_t b = m / HW;
+      const int rem = (int)(m - b * HW);
+      const int h = rem / p.W, w = rem - h * p.W;
+      o_off = ((b * (p.H + 2) + h + 1) * (int64_t)(p.W + 2) + w + 1) * p.ldc + n;
+    } else {
+      o_off = m * (int64_t)p.ldc + n;
+    }
+    int64_t rrow = m;
+    if (p.res_mod > 0) rrow = m % p.res_mod;
+    else if (p.res_bidx) {
+      const int64_t b = m / HW;
+      rrow = (int64_t)p.res_bidx[b] * HW + (m - b * HW);
+    }
+    r_off = rrow * (int64_t)p.ldr + n;
+  }
+  const int valid = (p.N - n) < OC ? (p.N - n) : OC;
+#pragma unroll
+  for (int e = 0; e < OC; ++e) {
+    if (e < valid) {
+      float x = v[e];
+      if (p.bias) x += p.bias[bias_n + e];
+      if (gR && !p.res_after_act) x += to_f32<T>(gR[r_off + e]);
+      x = act_apply(x, p.act);
+      if (gR && p.res_after_act) x += to_f32<T>(gR[r_off + e]);
+      v[e] = x;
+    }
+  }
+  const bool vec = (valid == OC) && (((uintptr_t)(gO + o_off)) & 15) == 0;
+  if (vec) {
+    if constexpr (sizeof(T) == 2) {
+      u32x4 o;
+      o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+      o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+      o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+      o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+      *reinterpret_cast<u32x4*>(gO + o_off) = o;
+    } else {
+      *reinterpret_cast<float4*>(gO + o_off) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(gO + o_off + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < OC; ++e)
+      if (e < valid) gO[o_off + e] = from_f32<T>(v[e]);
+  }
+}

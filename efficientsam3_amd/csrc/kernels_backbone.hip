@@ -407,9 +407,37 @@ __global__ void preprocess_u8_kernel(const uint8_t* __restrict__ in, float* __re
   }
 }
 
+// border pixels of [B][Hp][Wp][C]: rows 0 and Hp-1, columns 0 and Wp-1; 16 bytes per thread
+__global__ void zero_border_kernel(char* __restrict__ x, int B, int Hp, int Wp, int row_bytes) {
+  const int per_img = 2 * Wp + 2 * (Hp - 2);  // border pixels per image
+  const int chunks = row_bytes / 16;
+  const int64_t total = (int64_t)B * per_img * chunks;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ch = (int)(i % chunks);
+  const int64_t pi = i / chunks;
+  const int k = (int)(pi % per_img);
+  const int64_t b = pi / per_img;
+  int y, xx;
+  if (k < Wp) { y = 0; xx = k; }
+  else if (k < 2 * Wp) { y = Hp - 1; xx = k - Wp; }
+  else { const int r = k - 2 * Wp; y = 1 + (r >> 1); xx = (r & 1) ? Wp - 1 : 0; }
+  uint4* dst = reinterpret_cast<uint4*>(x + ((b * Hp + y) * (int64_t)Wp + xx) * row_bytes) + ch;
+  *dst = make_uint4(0, 0, 0, 0);
+}
+
 inline unsigned blocks_for(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 }  // namespace
+
+int esam3_launch_zero_border(int dtype, void* x, int B, int Hp, int Wp, int C, hipStream_t s) {
+  const int row_bytes = C * (dtype == 0 ? 4 : 2);
+  if (row_bytes % 16) { esam3_set_error("zero_border: C=%d not 16-byte aligned", C); return -1; }
+  const int64_t total = (int64_t)B * (2 * Wp + 2 * (Hp - 2)) * (row_bytes / 16);
+  hipLaunchKernelGGL(zero_border_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, (char*)x, B, Hp, Wp, row_bytes);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
 
 int esam3_launch_preprocess_u8(const uint8_t* in, float* out, int B, int H, int W, hipStream_t s) {
   const int64_t HW = (int64_t)H * W, total = HW * B;

@@ -83,6 +83,28 @@ int esam3_op_conv2d(int dtype, const void* x, const float* w, const float* bias,
   return 0;
 }
 
+int esam3_op_conv3x3_padded(int dtype, const void* x_padded, const float* w, const float* bias, void* out, int B,
+                            int H, int W, int Cin, int Cout, int act, int out_pad, void* stream) {
+  Tmp t;
+  const int esz = dtype == 0 ? 4 : 2;
+  const int K = Cin * 9;
+  const int Kp = esam3_gemm_pad_k(K, esz), Np = esam3_gemm_pad_n(Cout);
+  std::vector<float> pk((size_t)Np * Kp, 0.f);
+  for (int n = 0; n < Cout; ++n)
+    for (int c = 0; c < Cin; ++c)
+      for (int tp = 0; tp < 9; ++tp) pk[(size_t)n * Kp + (size_t)tp * Cin + c] = w[((size_t)n * Cin + c) * 9 + tp];
+  GemmParams p{};
+  p.A = x_padded; p.Wt = t.upT(dtype, pk); p.bias = bias ? (float*)t.up(bias, (size_t)Cout * 4) : nullptr;
+  if (!p.Wt || (bias && !p.bias)) return fail("op_conv3x3_padded");
+  p.out = out; p.M = (int64_t)B * H * W; p.N = Cout; p.K = K; p.Kp = Kp; p.H = H; p.W = W;
+  p.Cin = Cin; p.ksize = 3; p.lda = Cin; p.ldc = Cout; p.ldr = Cout; p.act = act; p.res_after_act = 1;
+  p.in_pad = 1; p.out_pad = out_pad;
+  if (out_pad && esam3_launch_zero_border(dtype, out, B, H + 2, W + 2, Cout, (hipStream_t)stream)) return -1;
+  if (esam3_launch_gemm(dtype, p, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
 int esam3_op_conv_transpose2x2(int dtype, const void* x, const float* w, const float* bias, const void* res,
                                void* out, int B, int H, int W, int Cin, int Cout, int act, int res_after_act,
                                void* stream) {

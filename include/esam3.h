@@ -118,6 +118,11 @@ int esam3_op_linear(int dtype, const void* a_dev, const float* w_host, const flo
 int esam3_op_conv2d(int dtype, const void* x_dev, const float* w_host, const float* bias_host,
                     const void* res_dev, void* out_dev, int B, int H, int W, int Cin, int Cout,
                     int ksize, int act, void* hip_stream);
+/* 3x3/s1/p1 conv whose NHWC input already carries a 1-pixel zero border ([B][H+2][W+2][Cin]);
+ * out_pad=1 writes the output inside a zero border too ([B][H+2][W+2][Cout]) */
+int esam3_op_conv3x3_padded(int dtype, const void* x_padded_dev, const float* w_host,
+                            const float* bias_host, void* out_dev, int B, int H, int W, int Cin,
+                            int Cout, int act, int out_pad, void* hip_stream);
 /* ConvTranspose2d k2 s2, NHWC; w_host is the PyTorch [Cin][Cout][2][2] fp32 weight */
 int esam3_op_conv_transpose2x2(int dtype, const void* x_dev, const float* w_host,
                                const float* bias_host, const void* res_dev, void* out_dev, int B,

@@ -77,6 +77,36 @@ def test_conv2d(mode, B, H, W, Cin, Cout, ks, act, res):
 
 
 @pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,out_pad", [
+    (2, 24, 24, 256, 256, 0),   # 256x256 LDS-DMA kernel, M = 1152 (ragged last tile)
+    (1, 16, 16, 1024, 1024, 0),  # head.3 shape
+    (3, 19, 17, 256, 256, 1),   # ragged M + padded output
+    (2, 12, 12, 256, 32, 0),    # composed 3x3 o conv_s0 shape -> 128x32 kernel with in_pad
+    (1, 9, 9, 64, 64, 1),       # small-K register-staged path with in_pad
+])
+def test_conv3x3_padded(mode, B, H, W, Cin, Cout, out_pad):
+    """3x3 conv reading a zero-bordered NHWC input (no bounds checks; serves the DMA kernel)."""
+    d, tdt = U.DT[mode]
+    x = _rand(B, Cin, H, W, seed=1)
+    w = _rand(Cout, Cin, 3, 3, seed=2) / (Cin * 9) ** 0.5
+    b = _rand(Cout, seed=3) * 0.1
+    ref = F.conv2d(_q(x, mode), _q(w, mode), b, padding=1)
+    xp = F.pad(x, (1, 1, 1, 1)).permute(0, 2, 3, 1).contiguous().to("cuda", tdt)  # [B,H+2,W+2,C]
+    if out_pad:
+        out = torch.full((B, H + 2, W + 2, Cout), 7.0, dtype=tdt, device="cuda")
+    else:
+        out = torch.empty((B, H, W, Cout), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_conv3x3_padded(d, U.P(xp), U.H(U.np32(w)), U.H(U.np32(b)), U.P(out), B, H, W, Cin,
+                                            Cout, 0, out_pad, None), "op_conv3x3_padded")
+    got = out.float().cpu()
+    if out_pad:
+        assert float(got[:, 0].abs().max()) == 0 and float(got[:, -1].abs().max()) == 0
+        assert float(got[:, :, 0].abs().max()) == 0 and float(got[:, :, -1].abs().max()) == 0
+        got = got[:, 1:-1, 1:-1]
+    U.assert_close(got.permute(0, 3, 1, 2), ref, mode, f"conv3x3 padded {Cin}->{Cout}")
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout,act,res,after", [
     (2, 9, 9, 1024, 512, "gelu", False, 1), (1, 12, 10, 512, 256, None, False, 1),
     (2, 8, 8, 256, 64, None, True, 1), (2, 10, 10, 64, 32, "gelu", True, 0),
