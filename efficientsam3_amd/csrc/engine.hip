@@ -218,7 +218,7 @@ struct esam3_engine {
     for (int n = 0; n < N; ++n)
       for (int c = 0; c < cin; ++c)
         for (int t = 0; t < ks * ks; ++t)
-          pk[(size_t)n * g.Kp + (size_t)t * cin + c] = w->d[((size_t)n * cin + c) * ks * ks + t] * scale[n];
+          pk[(size_t)n * g.Kp + esam3_conv_k_index(cin, ks, (int)esz, t, c)] = w->d[((size_t)n * cin + c) * ks * ks + t] * scale[n];
     g.w = upload_T(pk);
     g.bias = has_bias ? (float*)dev_upload(bias.data(), bias.size() * 4) : nullptr;
     if (!g.w) return nullptr;
@@ -407,6 +407,7 @@ struct esam3_engine {
     p.A = A; p.Wt = g->w; p.bias = g->bias; p.res = res; p.out = out;
     p.M = M; p.N = g->N; p.K = g->K; p.Kp = g->Kp;
     p.H = H; p.W = W; p.Cin = g->cin; p.ksize = g->ksize;
+    p.korder = g->convt_cout ? 0 : esam3_conv_korder(g->cin, g->ksize, (int)esz);
     p.lda = lda; p.ldc = ldc; p.ldr = ldr; p.act = act; p.res_mod = res_mod;
     p.out_mode = g->convt_cout ? OUT_CONVT2X2 : OUT_PLAIN;
     p.convt_cout = g->convt_cout;

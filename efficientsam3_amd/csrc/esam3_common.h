@@ -52,6 +52,27 @@ __device__ inline float act_apply(float x, int act) {
   }
 }
 
+// Same activation on N values with the (wave-uniform) selection hoisted out of the loop: one
+// branch per call instead of one switch per element (a per-element switch in an unrolled
+// epilogue multiplies the code size and thrashes the instruction cache).
+template <int N>
+__device__ __forceinline__ void act_apply_n(float (&v)[N], int act) {
+  if (act == ACT_NONE) return;
+  if (act == ACT_RELU) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
+  } else if (act == ACT_GELU) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = 0.5f * v[i] * (1.f + erff(v[i] * 0.70710678118654752440f));
+  } else if (act == ACT_HSWISH) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v[i] * fminf(fmaxf(v[i] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+  } else if (act == ACT_SIGMOID) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = 1.f / (1.f + expf(-v[i]));
+  }
+}
+
 // ---- implicit-GEMM convolution / linear ------------------------------------------
 // out[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias[n] ) (+ res)
 //   m = flattened (b, oh, ow) output pixel (or token row), n = output channel,
@@ -79,6 +100,10 @@ struct GemmParams {
   const int* res_bidx;  // optional: residual batch index per output batch item (gather)
   int in_pad;         // 1 (ksize 3 only): A is [B][H+2][W+2][lda] with a zero border -> no bounds checks
   int out_pad;        // 1: write the output inside a 1-pixel border ([B][OH+2][OW+2][ldc])
+  int korder;         // ksize 3: 0 -> k = tap*Cin + c ; 1 -> k = (c/BKE)*9*BKE + tap*BKE + c%BKE
+                      // (channel-chunk major: the 9 taps of one 128-byte channel chunk are
+                      //  consecutive K tiles, so shifted re-reads of the same pixels hit in L2)
+  int debug;          // development switches (ESAM3_GEMM_DEBUG): 1 skip epilogue, 2 skip DMA, 4 skip MFMA
 };
 
 // ---- error handling ---------------------------------------------------------------

@@ -32,7 +32,8 @@ __device__ __forceinline__ int swz(int row, int slot) { return (slot ^ ((row >> 
 
 // Epilogue for output row m, channels [n, n+8): v holds the raw accumulators.
 template <typename T>
-__device__ __forceinline__ void epilogue_chunk(const GemmParams& p, int64_t m, int n, float (&v)[8]) {
+__device__ __forceinline__ void epilogue_chunk(const GemmParams& p, int64_t m64, int n, float (&v)[8]) {
+  const unsigned m = (unsigned)m64;  // the launcher guarantees M < 2^31: 32-bit divisions only
   constexpr int OC = 8;
   T* __restrict__ gO = reinterpret_cast<T*>(p.out);
   const T* __restrict__ gR = reinterpret_cast<const T*>(p.res);
@@ -42,43 +43,44 @@ __device__ __forceinline__ void epilogue_chunk(const GemmParams& p, int64_t m, i
   int bias_n = n;
   if (p.out_mode == OUT_CONVT2X2) {
     const int tap = n / p.convt_cout, co = n - tap * p.convt_cout;
-    const int64_t b = m / HW;
-    const int rem = (int)(m - b * HW);
-    const int h = rem / p.W, w = rem - h * p.W;
-    const int oh = 2 * h + (tap >> 1), ow = 2 * w + (tap & 1);
+    const unsigned b = m / (unsigned)HW;
+    const unsigned rem = m - b * (unsigned)HW;
+    const unsigned h = rem / (unsigned)p.W, w = rem - h * (unsigned)p.W;
+    const unsigned oh = 2 * h + (tap >> 1), ow = 2 * w + (tap & 1);
     const int OHp = 2 * p.H + 2 * P, OWp = 2 * p.W + 2 * P;
-    o_off = ((b * OHp + oh + P) * (int64_t)OWp + ow + P) * p.ldc + co;
-    const int64_t rb = p.res_bidx ? (int64_t)p.res_bidx[b] : b;
-    r_off = (rb * 4 * HW + (int64_t)oh * (2 * p.W) + ow) * p.ldr + co;
+    o_off = ((int64_t)(b * (unsigned)OHp + oh + P) * OWp + ow + P) * p.ldc + co;
+    const unsigned rb = p.res_bidx ? (unsigned)p.res_bidx[b] : b;
+    r_off = ((int64_t)rb * 4 * HW + (int64_t)oh * (2 * p.W) + ow) * p.ldr + co;
     bias_n = co;
   } else {
     if (P) {
-      const int64_t b = m / HW;
-      const int rem = (int)(m - b * HW);
-      const int h = rem / p.W, w = rem - h * p.W;
-      o_off = ((b * (p.H + 2) + h + 1) * (int64_t)(p.W + 2) + w + 1) * p.ldc + n;
+      const unsigned b = m / (unsigned)HW;
+      const unsigned rem = m - b * (unsigned)HW;
+      const unsigned h = rem / (unsigned)p.W, w = rem - h * (unsigned)p.W;
+      o_off = ((int64_t)(b * (unsigned)(p.H + 2) + h + 1) * (p.W + 2) + w + 1) * p.ldc + n;
     } else {
-      o_off = m * (int64_t)p.ldc + n;
+      o_off = (int64_t)m * p.ldc + n;
     }
-    int64_t rrow = m;
-    if (p.res_mod > 0) rrow = m % p.res_mod;
+    unsigned rrow = m;
+    if (p.res_mod > 0) rrow = m % (unsigned)p.res_mod;
     else if (p.res_bidx) {
-      const int64_t b = m / HW;
-      rrow = (int64_t)p.res_bidx[b] * HW + (m - b * HW);
+      const unsigned b = m / (unsigned)HW;
+      rrow = (unsigned)p.res_bidx[b] * (unsigned)HW + (m - b * (unsigned)HW);
     }
-    r_off = rrow * (int64_t)p.ldr + n;
+    r_off = (int64_t)rrow * p.ldr + n;
   }
   const int valid = (p.N - n) < OC ? (p.N - n) : OC;
+  float r[OC];
 #pragma unroll
   for (int e = 0; e < OC; ++e) {
-    if (e < valid) {
-      float x = v[e];
-      if (p.bias) x += p.bias[bias_n + e];
-      if (gR && !p.res_after_act) x += to_f32<T>(gR[r_off + e]);
-      x = act_apply(x, p.act);
-      if (gR && p.res_after_act) x += to_f32<T>(gR[r_off + e]);
-      v[e] = x;
-    }
+    r[e] = (gR && e < valid) ? to_f32<T>(gR[r_off + e]) : 0.f;
+    if (p.bias && e < valid) v[e] += p.bias[bias_n + e];
+    if (!p.res_after_act) v[e] += r[e];
+  }
+  act_apply_n<OC>(v, p.act);
+  if (p.res_after_act) {
+#pragma unroll
+    for (int e = 0; e < OC; ++e) v[e] += r[e];
   }
   const bool vec = (valid == OC) && (((uintptr_t)(gO + o_off)) & 15) == 0;
   if (vec) {

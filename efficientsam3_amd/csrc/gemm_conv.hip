@@ -87,12 +87,12 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(GemmParams p) {
     a_ow[i] = 0;
     if (m < p.M) {
       if (p.ksize == 3) {
-        const int64_t b = m / HW;
-        const int rem = (int)(m - b * HW);
-        a_oh[i] = rem / p.W;
-        a_ow[i] = rem - a_oh[i] * p.W;
+        const unsigned b = (unsigned)m / (unsigned)HW;  // launcher guarantees M < 2^31
+        const unsigned rem = (unsigned)m - b * (unsigned)HW;
+        a_oh[i] = (int)(rem / (unsigned)p.W);
+        a_ow[i] = (int)rem - a_oh[i] * p.W;
         if (p.in_pad)  // origin = top-left pixel of the 3x3 window in the padded buffer
-          a_off[i] = ((b * (p.H + 2) + a_oh[i]) * (int64_t)Wp + a_ow[i]) * p.lda;
+          a_off[i] = ((int64_t)(b * (unsigned)(p.H + 2) + a_oh[i]) * Wp + a_ow[i]) * p.lda;
         else           // origin = centre pixel
           a_off[i] = m * (int64_t)p.lda;
       } else {
@@ -133,9 +133,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(GemmParams p) {
       }
       const bool k_ok = k_lin < p.K;
       if (p.ksize == 3) {
-        const int kh = k_tap / 3, kw = k_tap - kh * 3;
+        int tap_ = k_tap, kc_ = k_c;
+        if (p.korder) {  // K tile kt+1 = (channel chunk, tap)
+          const int chunk = (kt + 1) / 9;
+          tap_ = (kt + 1) - chunk * 9;
+          kc_ = chunk * BKE + slot * EPC;
+        }
+        const int kh = tap_ / 3, kw = tap_ - kh * 3;
         if (p.in_pad) {
-          const int64_t toff = ((int64_t)kh * Wp + kw) * p.lda + k_c;
+          const int64_t toff = ((int64_t)kh * Wp + kw) * p.lda + kc_;
 #pragma unroll
           for (int i = 0; i < A_ITERS; ++i) {
             u32x4 v = {0u, 0u, 0u, 0u};
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(GemmParams p) {
             const int ih = a_oh[i] + dh, iw = a_ow[i] + dw;
             const bool okk = k_ok && a_off[i] >= 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (okk) v = *reinterpret_cast<const u32x4*>(gA + a_off[i] + ((int64_t)dh * p.W + dw) * p.lda + k_c);
+            if (okk) v = *reinterpret_cast<const u32x4*>(gA + a_off[i] + ((int64_t)dh * p.W + dw) * p.lda + kc_);
             ra[i] = v;
           }
         }
@@ -244,30 +250,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T>
+// ACT is a compile-time parameter: with a run-time activation switch the fully unrolled
+// epilogue carries every activation's code 128 times (28k instructions) and stalls on the
+// instruction cache.
+template <typename T, int ACT>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
-  constexpr int BM = 256, BN = 256, NT = 512;
+  constexpr int BM = 256, BN = 256;
   constexpr int EPC = 16 / (int)sizeof(T);
   constexpr int BKE = 128 / (int)sizeof(T);
   constexpr int STAGE = (BM + BN) * 128;  // 64 KB
-  constexpr int LDN = BN + 4;
-  constexpr int EROWS = 64;                // epilogue pass height
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* lds_c = reinterpret_cast<float*>(smem);
 
   const int tiles_n = (p.N + BN - 1) / BN;
   const int64_t tiles_m = (p.M + BM - 1) / BM;
   const int64_t nblk = tiles_m * tiles_n;
-  int64_t bid = blockIdx.x;
-  {
-    const int64_t q = nblk / 8, r = nblk % 8;
-    const int64_t xcd = bid % 8, idx = bid / 8;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int tile_n = (int)(bid % tiles_n);
-  const int64_t m0 = (bid / tiles_n) * BM;
-  const int n0 = tile_n * BN;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -277,49 +274,73 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 
   const T* __restrict__ gA = reinterpret_cast<const T*>(p.A);
   const T* __restrict__ gW = reinterpret_cast<const T*>(p.Wt);
+  T* __restrict__ gO = reinterpret_cast<T*>(p.out);
+  const T* __restrict__ gR = reinterpret_cast<const T*>(p.res);
   const int HW = p.H * p.W;
   const int Wp = p.W + 2 * p.in_pad;
+  const int P = p.out_pad;
+  const bool convt = p.out_mode == OUT_CONVT2X2;
+  const int nk = p.K / BKE;
+
+  // 3x3 convs: a 256-row tile is a 16x16 pixel patch (halo 18x18 = 324 px instead of 3x258),
+  // when the image tiles evenly; otherwise (and for 1x1 / ConvT) 256 consecutive pixels.
+  const bool patch = p.ksize == 3 && (p.H % 16 == 0) && (p.W % 16 == 0);
+  const int tiles_x = patch ? p.W / 16 : 1, tiles_img = patch ? (p.H / 16) * tiles_x : 1;
+  // pixel indices fit 32 bits (checked by the launcher): all divisions below are 32-bit
+  auto row_to_m = [&](unsigned m0, int row) -> unsigned {
+    if (!patch) return m0 + (unsigned)row;
+    const unsigned t = m0 >> 8;  // tile index
+    const unsigned b = t / (unsigned)tiles_img;
+    const unsigned ti = t - b * (unsigned)tiles_img;
+    const unsigned ty = ti / (unsigned)tiles_x, tx = ti - ty * (unsigned)tiles_x;
+    return b * (unsigned)HW + (ty * 16 + ((unsigned)row >> 4)) * (unsigned)p.W + tx * 16 + ((unsigned)row & 15);
+  };
+
+  // Persistent workgroups (one per CU): work item w of this workgroup is the logical tile
+  // xcd_first + (blockIdx/8) + w * (wgs on this XCD); logical tiles of one XCD are contiguous so
+  // neighbouring tiles (shared halo rows, the same weight panel) meet in that XCD's L2.
+  const int64_t nwg = gridDim.x;
+  const int64_t xcd = blockIdx.x % 8, wg_in_xcd = blockIdx.x / 8;
+  const int64_t wgs_this_xcd = nwg / 8 + (xcd < nwg % 8 ? 1 : 0);
+  const int64_t q_ = nblk / 8, r_ = nblk % 8;
+  const int64_t xcd_first = xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_;
+  const int64_t xcd_count = q_ + (xcd < r_ ? 1 : 0);
 
   // ---- DMA descriptors: wave w fills tile rows [32w, 32w+32) of A and of B, 8 rows (1 KB)
   //      per instruction; lane -> (row = 8j + lane/8, physical slot = lane%8); the logical slot
   //      it fetches is physical ^ ((row>>1)&7)  (source-side swizzle).
   int64_t a_src[4], b_src[4];
+  const unsigned M32 = (unsigned)p.M;
+  auto setup = [&](unsigned m0, int n0) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = wave * 32 + j * 8 + (lane >> 3);
-    const int lslot = (lane & 7) ^ ((row >> 1) & 7);
-    int64_t m = m0 + row;
-    if (m >= p.M) m = p.M - 1;  // clamp: rows past M are computed but never stored
-    int64_t off;
-    if (p.ksize == 3) {
-      const int64_t b = m / HW;
-      const int rem = (int)(m - b * HW);
-      const int oh = rem / p.W, ow = rem - oh * p.W;
-      off = ((b * (p.H + 2) + oh) * (int64_t)Wp + ow) * p.lda;  // in_pad is required for ksize 3
-    } else {
-      off = m * (int64_t)p.lda;
+    for (int j = 0; j < 4; ++j) {
+      const int row = wave * 32 + j * 8 + (lane >> 3);
+      const int lslot = (lane & 7) ^ ((row >> 1) & 7);
+      unsigned m = row_to_m(m0, row);
+      if (m >= M32) m = M32 - 1;  // clamp: rows past M are computed but never stored
+      int64_t off;
+      if (p.ksize == 3) {
+        const unsigned b = m / (unsigned)HW;
+        const unsigned rem = m - b * (unsigned)HW;
+        const unsigned oh = rem / (unsigned)p.W, ow = rem - oh * (unsigned)p.W;
+        off = ((int64_t)(b * (unsigned)(p.H + 2) + oh) * Wp + ow) * p.lda;  // in_pad is required for ksize 3
+      } else {
+        off = (int64_t)m * p.lda;
+      }
+      a_src[j] = off + lslot * EPC;
+      b_src[j] = (int64_t)(n0 + row) * p.Kp + lslot * EPC;
     }
-    a_src[j] = off + lslot * EPC;
-    b_src[j] = (int64_t)(n0 + row) * p.Kp + lslot * EPC;
-  }
+  };
 
-  f32x16_v acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = p.K / BKE;
 #define ESAM3_ISSUE_TILE(KT)                                                          \
   do {                                                                                \
     char* sa_ = smem + ((KT) & 1) * STAGE + wave * 32 * 128;                          \
     char* sb_ = sa_ + BM * 128;                                                       \
     int64_t koff_ = (int64_t)(KT) * BKE;                                              \
     if (p.ksize == 3) {                                                               \
-      const int k0_ = (KT) * BKE;                                                     \
-      const int tap_ = k0_ / p.Cin, c0_ = k0_ - tap_ * p.Cin;                         \
+      int tap_, c0_;                                                                  \
+      if (p.korder) { const int ch_ = (KT) / 9; tap_ = (KT) - ch_ * 9; c0_ = ch_ * BKE; } \
+      else { const int k0_ = (KT) * BKE; tap_ = k0_ / p.Cin; c0_ = k0_ - tap_ * p.Cin; } \
       const int kh_ = tap_ / 3, kw_ = tap_ - kh_ * 3;                                 \
       koff_ = ((int64_t)kh_ * Wp + kw_) * p.lda + c0_;                                \
     }                                                                                 \
@@ -329,77 +350,192 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         glds16(gW + b_src[j_] + (int64_t)(KT) * BKE, sb_ + j_ * 1024);                \
   } while (0)
 
-  ESAM3_ISSUE_TILE(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {
-      ESAM3_ISSUE_TILE(kt + 1);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile kt landed; tile kt+1 stays in flight
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int64_t w = 0;
+  if (wg_in_xcd >= xcd_count) return;
+  {
+    const unsigned lt = (unsigned)(xcd_first + wg_in_xcd);
+    setup((lt / (unsigned)tiles_n) * BM, (int)(lt % (unsigned)tiles_n) * BN);
+    ESAM3_ISSUE_TILE(0);
+  }
+  for (;; ++w) {
+    const unsigned lt = (unsigned)(xcd_first + wg_in_xcd + w * wgs_this_xcd);
+    const unsigned m0 = (lt / (unsigned)tiles_n) * BM;
+    const int n0 = (int)(lt % (unsigned)tiles_n) * BN;
+    const unsigned lt_next = lt + (unsigned)wgs_this_xcd;
+    const bool has_next = (wg_in_xcd + (w + 1) * wgs_this_xcd) < xcd_count;
+
+    f32x16_v acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk && !(p.debug & 2)) {
+        ESAM3_ISSUE_TILE(kt + 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile kt landed; tile kt+1 stays in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      const char* la = smem + (kt & 1) * STAGE;
+      const char* lb = la + BM * 128;
+      // fragments are double buffered: the ds_reads of K-chunk ck+1 are issued before the MFMAs
+      // of chunk ck so LDS latency hides under the matrix pipe
+      u32x4 fa[2][4], fw[2][2];
+#define ESAM3_LOAD_FRAGS(CK, BUF)                                                              \
+  do {                                                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                          \
+      const int row_ = wm * 128 + i_ * 32 + l31;                                               \
+      fa[BUF][i_] = *reinterpret_cast<const u32x4*>(la + row_ * 128 + swz(row_, (CK) * 2 + g)); \
+    }                                                                                          \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                          \
+      const int row_ = wn * 64 + j_ * 32 + l31;                                                \
+      fw[BUF][j_] = *reinterpret_cast<const u32x4*>(lb + row_ * 128 + swz(row_, (CK) * 2 + g)); \
+    }                                                                                          \
+  } while (0)
+      ESAM3_LOAD_FRAGS(0, 0);
+#pragma unroll
+      for (int ck = 0; ck < 4; ++ck) {
+        if (ck < 3) ESAM3_LOAD_FRAGS(ck + 1, (ck + 1) & 1);
+        if (!(p.debug & 4)) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) MmaOps<T>::mma(fw[ck & 1][j], fa[ck & 1][i], acc[i][j]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[ck & 1][i]));
+#pragma unroll
+          for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(fw[ck & 1][j]));
+        }
+      }
+#undef ESAM3_LOAD_FRAGS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all ds_reads of this buffer retired
+      __builtin_amdgcn_s_barrier();                      // before anybody's DMA overwrites it
     }
-    __builtin_amdgcn_s_barrier();
-    const char* la = smem + (kt & 1) * STAGE;
-    const char* lb = la + BM * 128;
+
+    // ---- output descriptors of THIS tile (before the DMA descriptors move on) ---------------
+    int64_t obase[4], rbase[4];
+    bool rok[4];
 #pragma unroll
-    for (int ck = 0; ck < 4; ++ck) {
-      u32x4 fa[4], fw[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = wm * 128 + i * 32 + l31;
-        fa[i] = *reinterpret_cast<const u32x4*>(la + row * 128 + swz(row, ck * 2 + g));
+    for (int i = 0; i < 4; ++i) {
+      const unsigned m = row_to_m((p.debug & 32) ? 0u : m0, wm * 128 + i * 32 + l31);
+      rok[i] = m < M32;
+      const unsigned mm = rok[i] ? m : 0u;
+      const unsigned b = mm / (unsigned)HW;
+      const unsigned rem = mm - b * (unsigned)HW;
+      const unsigned h = rem / (unsigned)p.W, ww = rem - h * (unsigned)p.W;
+      if (convt) {
+        const int OHp = 2 * p.H + 2 * P, OWp = 2 * p.W + 2 * P;
+        obase[i] = ((int64_t)(b * (unsigned)OHp + 2 * h + P) * OWp + 2 * ww + P) * p.ldc;
+        const unsigned rb = p.res_bidx ? (unsigned)p.res_bidx[b] : b;
+        rbase[i] = ((int64_t)(rb * 2u * p.H + 2 * h) * (2 * p.W) + 2 * ww) * p.ldr;
+      } else {
+        obase[i] = (P ? ((int64_t)(b * (unsigned)(p.H + 2) + h + 1) * (p.W + 2) + ww + 1) : (int64_t)mm) * p.ldc;
+        unsigned rrow = mm;
+        if (p.res_mod > 0) rrow = mm % (unsigned)p.res_mod;
+        else if (p.res_bidx) rrow = (unsigned)p.res_bidx[b] * (unsigned)HW + rem;
+        rbase[i] = (int64_t)rrow * p.ldr;
       }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int row = wn * 64 + j * 32 + l31;
-        fw[j] = *reinterpret_cast<const u32x4*>(lb + row * 128 + swz(row, ck * 2 + g));
-      }
+    }
+    // ---- start the next tile's first K tile now: its DMA runs under this tile's epilogue -----
+    if (has_next) {
+      setup((lt_next / (unsigned)tiles_n) * BM, (int)(lt_next % (unsigned)tiles_n) * BN);
+      ESAM3_ISSUE_TILE(0);
+    }
+
+    // ---- epilogue straight from the accumulators: no LDS round trip, no barriers ----------
+    // Lane (l31, g) holds, for pixel row i*32 + l31 and channel block (j, q), the four channels
+    // 8q + 4g + {0..3}.  bias / residual / activation are applied in fp32; bf16 outputs are then
+    // packed and the two half-waves exchange their halves (v_permlane32_swap) so that each lane
+    // stores 8 consecutive channels = 16 bytes.
+    if (p.debug & 1) {  // development: keep ALL accumulators alive, store nothing
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) MmaOps<T>::mma(fw[j], fa[i], acc[i][j]);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all ds_reads of this buffer retired
-    __builtin_amdgcn_s_barrier();                      // before anybody's DMA overwrites it
-  }
-#undef ESAM3_ISSUE_TILE
-
-  // ---- epilogue in 4 passes of 64 pixels: accumulators -> LDS fp32 -> coalesced stores ----
+        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else {
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    if (wm == (pass >> 1)) {
+      for (int j = 0; j < 2; ++j) {
+        const int nb = n0 + wn * 64 + j * 32;  // first channel of this 32-wide block (wave-uniform)
+        if (nb >= p.N) continue;
+        int64_t ocol = nb, rcol = nb;
+        int bias_n = nb;
+        if (convt) {  // a 32-channel block never straddles a tap (Cout % 32 == 0)
+          const int tap = nb / p.convt_cout, co = nb - tap * p.convt_cout;
+          const int OWp = 2 * p.W + 2 * P;
+          ocol = ((int64_t)(tap >> 1) * OWp + (tap & 1)) * p.ldc + co;
+          rcol = ((int64_t)(tap >> 1) * (2 * p.W) + (tap & 1)) * p.ldr + co;
+          bias_n = co;
+        }
+        float4 bq[4];
 #pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
+        for (int q = 0; q < 4; ++q)
+          bq[q] = p.bias ? *reinterpret_cast<const float4*>(p.bias + bias_n + 8 * q + 4 * g)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 4; ++i) {
+          float v[16], r16[16];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int i = 2 * (pass & 1) + ii;
-            const int ml = ii * 32 + l31;
-            const int nl = wn * 64 + j * 32 + 8 * q + 4 * g;
-            float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2],
-                                   acc[i][j][4 * q + 3]);
-            *reinterpret_cast<float4*>(lds_c + ml * LDN + nl) = v;
-          }
-    }
-    __syncthreads();
-    constexpr int CPR = BN / 8;
+            float r4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gR && rok[i]) {
+              const T* rp = gR + rbase[i] + rcol + 8 * q + 4 * g;
+              if constexpr (sizeof(T) == 2) {
+                const uint2 u = *reinterpret_cast<const uint2*>(rp);
+                r4[0] = __uint_as_float(u.x << 16); r4[1] = __uint_as_float(u.x & 0xffff0000u);
+                r4[2] = __uint_as_float(u.y << 16); r4[3] = __uint_as_float(u.y & 0xffff0000u);
+              } else {
+                const float4 u = *reinterpret_cast<const float4*>(rp);
+                r4[0] = u.x; r4[1] = u.y; r4[2] = u.z; r4[3] = u.w;
+              }
+            }
+            const float bb[4] = {bq[q].x, bq[q].y, bq[q].z, bq[q].w};
 #pragma unroll
-    for (int it = 0; it < EROWS * CPR / NT; ++it) {
-      const int c = tid + it * NT;
-      const int ml = c / CPR, cc = c - ml * CPR;
-      const int64_t m = m0 + pass * EROWS + ml;
-      const int n = n0 + cc * 8;
-      if (m < p.M && n < p.N) {
-        float v[8];
-        const float4 v0 = *reinterpret_cast<const float4*>(lds_c + ml * LDN + cc * 8);
-        const float4 v1 = *reinterpret_cast<const float4*>(lds_c + ml * LDN + cc * 8 + 4);
-        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w;
-        v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-        epilogue_chunk<T>(p, m, n, v);
+            for (int e = 0; e < 4; ++e) {
+              r16[4 * q + e] = r4[e];
+              v[4 * q + e] = acc[i][j][4 * q + e] + bb[e] + (p.res_after_act ? 0.f : r4[e]);
+            }
+          }
+          act_apply_n<16>(v, ACT);
+          if (p.res_after_act && gR) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] += r16[e];
+          }
+          T* op = gO + obase[i] + ocol;
+          if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+              uint32_t a0 = (uint32_t)f32_to_bf16(v[8 * qp + 0]) | ((uint32_t)f32_to_bf16(v[8 * qp + 1]) << 16);
+              uint32_t a1 = (uint32_t)f32_to_bf16(v[8 * qp + 2]) | ((uint32_t)f32_to_bf16(v[8 * qp + 3]) << 16);
+              uint32_t b0 = (uint32_t)f32_to_bf16(v[8 * qp + 4]) | ((uint32_t)f32_to_bf16(v[8 * qp + 5]) << 16);
+              uint32_t b1 = (uint32_t)f32_to_bf16(v[8 * qp + 6]) | ((uint32_t)f32_to_bf16(v[8 * qp + 7]) << 16);
+              // half-wave exchange: lanes 0-31 end with channels 16qp..16qp+7, lanes 32-63 with +8..+15
+              auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+              auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+              if (p.debug & 16) {
+                asm volatile("" ::"v"(s0), "v"(s1));
+              } else if (rok[i]) {
+                u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                *reinterpret_cast<u32x4*>(op + 16 * qp + 8 * g) = o;
+              }
+            }
+          } else {
+            if (rok[i]) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(op + 8 * q + 4 * g) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            }
+          }
+        }
       }
     }
-    __syncthreads();
+    if (!has_next) break;
   }
+#undef ESAM3_ISSUE_TILE
 }
 
 // ======================================================================================
@@ -429,14 +565,28 @@ template <typename T>
 int launch_256(const GemmParams& p, hipStream_t stream) {
   constexpr size_t lds = 2 * (size_t)(256 + 256) * 128;  // 128 KB (epilogue needs 66.5 KB)
   static bool attr_set = false;
-  auto kern = gemm256_kernel<T>;
+  void (*kerns[5])(GemmParams) = {gemm256_kernel<T, ACT_NONE>, gemm256_kernel<T, ACT_RELU>,
+                                  gemm256_kernel<T, ACT_GELU>, gemm256_kernel<T, ACT_HSWISH>,
+                                  gemm256_kernel<T, ACT_SIGMOID>};
+  if (p.act < 0 || p.act > 4) { esam3_set_error("gemm: bad activation %d", p.act); return -1; }
   if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (auto k : kerns)
+      HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
+  auto kern = kerns[p.act];
   const int64_t tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, stream, p);
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HIP_CHECK_RET(hipGetDevice(&dev));
+    HIP_CHECK_RET(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int64_t grid = tiles < n_cu ? tiles : n_cu;  // persistent: one 128 KB-LDS workgroup per CU
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -444,7 +594,10 @@ int launch_256(const GemmParams& p, hipStream_t stream) {
 template <typename T>
 bool use_256(const GemmParams& p) {
   constexpr int BKE = 128 / (int)sizeof(T);
-  if (p.N < 128 || p.M < 256 || p.K % BKE != 0 || p.K != p.Kp) return false;
+  if (p.M >= (int64_t)1 << 31) return false;
+  if (p.N < 192 || p.N % 32 != 0 || p.M < 256 || p.K % BKE != 0 || p.K != p.Kp) return false;
+  if (p.out_mode == OUT_CONVT2X2 && p.convt_cout % 32 != 0) return false;
+  if ((p.ldc * (int)sizeof(T)) % 16 != 0 || (p.res && (p.ldr * (int)sizeof(T)) % 8 != 0)) return false;
   if (p.ksize == 3 && (!p.in_pad || p.Cin % BKE != 0)) return false;
   if (p.lda % (16 / (int)sizeof(T)) != 0) return false;
   return true;
@@ -466,13 +619,28 @@ int esam3_gemm_pad_n(int N) {
   const int bn = N >= 128 ? 256 : (N > 64 ? 128 : (N > 32 ? 64 : 32));
   return (N + bn - 1) / bn * bn;
 }
+int esam3_conv_korder(int cin, int ksize, int elem_size) {
+  return (ksize == 3 && cin % (128 / elem_size) == 0) ? 1 : 0;
+}
+int esam3_conv_k_index(int cin, int ksize, int elem_size, int tap, int c) {
+  if (!esam3_conv_korder(cin, ksize, elem_size)) return tap * cin + c;
+  const int bke = 128 / elem_size;
+  return (c / bke) * 9 * bke + tap * bke + (c % bke);
+}
 int esam3_gemm_pad_k(int K, int elem_size) {
   const int bke = 128 / elem_size;
   return (K + bke - 1) / bke * bke;
 }
 
 int esam3_launch_gemm(int dtype /*0 f32, 1 bf16*/, const GemmParams& p, hipStream_t stream) {
+  if (p.M >= ((int64_t)1 << 31)) { esam3_set_error("gemm: M=%lld rows exceed the 32-bit pixel index", (long long)p.M); return -1; }
   static const int force_small = getenv("ESAM3_GEMM_SMALL") ? atoi(getenv("ESAM3_GEMM_SMALL")) : 0;
+  static const int dbg = getenv("ESAM3_GEMM_DEBUG") ? atoi(getenv("ESAM3_GEMM_DEBUG")) : 0;
+  if (dbg) {
+    GemmParams q = p;
+    q.debug = dbg;
+    return dtype == 0 ? launch_gemm_t<float>(q, stream, force_small) : launch_gemm_t<bf16_t>(q, stream, force_small);
+  }
   return dtype == 0 ? launch_gemm_t<float>(p, stream, force_small)
                     : launch_gemm_t<bf16_t>(p, stream, force_small);
 }

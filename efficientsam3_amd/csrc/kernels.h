@@ -6,6 +6,9 @@
 int esam3_gemm_pad_n(int N);
 int esam3_gemm_pad_k(int K, int elem_size);
 int esam3_launch_gemm(int dtype, const GemmParams& p, hipStream_t stream);
+// K ordering of packed dense-conv weights: korder (see GemmParams) and the packed k index of (tap, c)
+int esam3_conv_korder(int cin, int ksize, int elem_size);
+int esam3_conv_k_index(int cin, int ksize, int elem_size, int tap, int c);
 
 // E0: stem 3x3/s2 conv on the NCHW fp32 network input -> NHWC T, + bias + Hardswish.
 int esam3_launch_stem(int dtype, const float* img_nchw, const float* w /*[27][Cout]*/,

@@ -2,6 +2,7 @@
 // weights exactly like the engine does and launch the same kernels, so unit parity tests
 // can compare one operator at a time against the oracle.  Test-sized: every call uploads
 // its weights, synchronises and frees them.
+#include <algorithm>
 #include <vector>
 
 #include "../../include/esam3.h"
@@ -72,12 +73,13 @@ int esam3_op_conv2d(int dtype, const void* x, const float* w, const float* bias,
   for (int n = 0; n < Cout; ++n)
     for (int c = 0; c < Cin; ++c)
       for (int tp = 0; tp < ks * ks; ++tp)
-        pk[(size_t)n * Kp + (size_t)tp * Cin + c] = w[((size_t)n * Cin + c) * ks * ks + tp];
+        pk[(size_t)n * Kp + esam3_conv_k_index(Cin, ks, esz, tp, c)] = w[((size_t)n * Cin + c) * ks * ks + tp];
   GemmParams p{};
   p.A = x; p.Wt = t.upT(dtype, pk); p.bias = bias ? (float*)t.up(bias, (size_t)Cout * 4) : nullptr;
   if (!p.Wt || (bias && !p.bias)) return fail("op_conv2d");
   p.res = res; p.out = out; p.M = (int64_t)B * H * W; p.N = Cout; p.K = K; p.Kp = Kp; p.H = H; p.W = W;
   p.Cin = Cin; p.ksize = ks; p.lda = Cin; p.ldc = Cout; p.ldr = Cout; p.act = act; p.res_after_act = 1;
+  p.korder = esam3_conv_korder(Cin, ks, esz);
   if (esam3_launch_gemm(dtype, p, (hipStream_t)stream)) return -1;
   HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
   return 0;
@@ -92,12 +94,13 @@ int esam3_op_conv3x3_padded(int dtype, const void* x_padded, const float* w, con
   std::vector<float> pk((size_t)Np * Kp, 0.f);
   for (int n = 0; n < Cout; ++n)
     for (int c = 0; c < Cin; ++c)
-      for (int tp = 0; tp < 9; ++tp) pk[(size_t)n * Kp + (size_t)tp * Cin + c] = w[((size_t)n * Cin + c) * 9 + tp];
+      for (int tp = 0; tp < 9; ++tp) pk[(size_t)n * Kp + esam3_conv_k_index(Cin, 3, esz, tp, c)] = w[((size_t)n * Cin + c) * 9 + tp];
   GemmParams p{};
   p.A = x_padded; p.Wt = t.upT(dtype, pk); p.bias = bias ? (float*)t.up(bias, (size_t)Cout * 4) : nullptr;
   if (!p.Wt || (bias && !p.bias)) return fail("op_conv3x3_padded");
   p.out = out; p.M = (int64_t)B * H * W; p.N = Cout; p.K = K; p.Kp = Kp; p.H = H; p.W = W;
   p.Cin = Cin; p.ksize = 3; p.lda = Cin; p.ldc = Cout; p.ldr = Cout; p.act = act; p.res_after_act = 1;
+  p.korder = esam3_conv_korder(Cin, 3, esz);
   p.in_pad = 1; p.out_pad = out_pad;
   if (out_pad && esam3_launch_zero_border(dtype, out, B, H + 2, W + 2, Cout, (hipStream_t)stream)) return -1;
   if (esam3_launch_gemm(dtype, p, (hipStream_t)stream)) return -1;
@@ -235,3 +238,47 @@ int esam3_op_cast(int dtype, int to_f32, const void* in, void* out, int64_t n, v
 }
 
 }  // extern "C"
+
+// ---- kernel micro-benchmark (development aid): times one GEMM/conv shape on random data ----
+extern "C" int esam3_bench_gemm(int dtype, int B, int H, int W, int Cin, int N, int ksize, int convt, int iters,
+                                float* avg_ms) {
+  Tmp t;
+  const int esz = dtype == 0 ? 4 : 2;
+  const int K = Cin * ksize * ksize;
+  const int Kp = esam3_gemm_pad_k(K, esz), Np = esam3_gemm_pad_n(N);
+  const int64_t M = (int64_t)B * H * W;
+  const int pad = ksize == 3 ? 1 : 0;
+  const size_t a_elems = (size_t)B * (H + 2 * pad) * (W + 2 * pad) * Cin;
+  const size_t o_elems = (size_t)M * N;
+  std::vector<float> hw((size_t)Np * Kp), ha(1 << 20);
+  uint32_t s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
+  for (auto& v : hw) v = rnd() * 0.05f;
+  for (auto& v : ha) v = rnd();
+  void* w = t.upT(dtype, hw);
+  void* a = t.raw(a_elems * esz);
+  void* o = t.raw(o_elems * esz);
+  void* chunk = t.upT(dtype, ha);
+  if (!w || !a || !o || !chunk) return fail("bench_gemm");
+  for (size_t off = 0; off < a_elems; off += ha.size()) {
+    const size_t n = std::min(ha.size(), a_elems - off);
+    hipMemcpy((char*)a + off * esz, chunk, n * esz, hipMemcpyDeviceToDevice);
+  }
+  GemmParams p{};
+  p.A = a; p.Wt = w; p.out = o; p.M = M; p.N = N; p.K = K; p.Kp = Kp; p.H = H; p.W = W; p.Cin = Cin;
+  p.ksize = ksize; p.lda = Cin; p.ldc = convt ? N / 4 : N; p.ldr = p.ldc; p.in_pad = pad; p.res_after_act = 1;
+  p.korder = esam3_conv_korder(Cin, ksize, esz);
+  if (convt) { p.out_mode = OUT_CONVT2X2; p.convt_cout = N / 4; }
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) if (esam3_launch_gemm(dtype, p, nullptr)) return -1;
+  hipEventRecord(e0, nullptr);
+  for (int i = 0; i < iters; ++i) if (esam3_launch_gemm(dtype, p, nullptr)) return -1;
+  hipEventRecord(e1, nullptr);
+  HIP_CHECK_RET(hipDeviceSynchronize());
+  float ms = 0.f;
+  hipEventElapsedTime(&ms, e0, e1);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  *avg_ms = ms / iters;
+  return 0;
+}

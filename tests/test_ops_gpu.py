@@ -79,7 +79,9 @@ def test_conv2d(mode, B, H, W, Cin, Cout, ks, act, res):
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout,out_pad", [
     (2, 24, 24, 256, 256, 0),   # 256x256 LDS-DMA kernel, M = 1152 (ragged last tile)
-    (1, 16, 16, 1024, 1024, 0),  # head.3 shape
+    (1, 16, 16, 1024, 1024, 0),  # head.3 shape (16x16 patch tiles)
+    (2, 32, 48, 256, 256, 0),   # several 16x16 patch tiles per image
+    (1, 32, 32, 128, 256, 1),   # patch tiles + padded output
     (3, 19, 17, 256, 256, 1),   # ragged M + padded output
     (2, 12, 12, 256, 32, 0),    # composed 3x3 o conv_s0 shape -> 128x32 kernel with in_pad
     (1, 9, 9, 64, 64, 1),       # small-K register-staged path with in_pad

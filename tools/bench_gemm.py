@@ -1,0 +1,28 @@
+"""Development aid: time the implicit-GEMM kernels on the neck/head shapes (B=32)."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from efficientsam3_amd import _lib  # noqa: E402
+
+SHAPES = [  # name, B, H, W, Cin, N, ksize, convt
+    ("neck L0 3x3 256->256 @288", 32, 288, 288, 256, 256, 3, 0),
+    ("neck L1 3x3 256->256 @144", 32, 144, 144, 256, 256, 3, 0),
+    ("head.3 3x3 1024->1024 @32", 32, 32, 32, 1024, 1024, 3, 0),
+    ("neck L0 convT0 1024->512 @72", 32, 72, 72, 1024, 2048, 1, 1),
+    ("neck L0 convT1' 512->256 @144", 32, 144, 144, 512, 1024, 1, 1),
+    ("neck L1 convT' 1024->256 @72", 32, 72, 72, 1024, 1024, 1, 1),
+    ("neck L2 1x1 1024->256 @72", 32, 72, 72, 1024, 256, 1, 0),
+    ("sam2 L0 3x3 256->32 @288", 32, 288, 288, 256, 32, 3, 0),
+]
+lib = C.CDLL(_lib.LIB_PATH)
+lib.esam3_bench_gemm.argtypes = [C.c_int] * 9 + [C.POINTER(C.c_float)]
+only = sys.argv[1] if len(sys.argv) > 1 else None
+for name, B, H, W, Cin, N, ks, ct in SHAPES:
+    if only and only not in name:
+        continue
+    ms = C.c_float()
+    rc = lib.esam3_bench_gemm(1, B, H, W, Cin, N, ks, ct, 10, C.byref(ms))
+    fl = 2.0 * B * H * W * N * Cin * ks * ks
+    print(f"{name:34s} rc={rc} {ms.value:8.3f} ms  {fl / ms.value / 1e9:8.1f} TF/s", flush=True)
