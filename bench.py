@@ -185,7 +185,7 @@ def main():
             t_ = p_["tag"]
             key = ("neck" if ".convs." in t_ or ".sam2_convs." in t_ or "conv_s0" in t_ or "conv_s1" in t_
                    else "head" if ".head." in t_
-                   else "backbone" if "trunk.model.backbone" in t_ or t_.startswith(("dwconv", "stem", "lite_mla", "grouped_pw", "resize"))
+                   else "backbone" if "trunk.model.backbone" in t_ or t_.startswith(("dwconv", "stem", "lite_mla", "grouped_pw", "resize", "mbconv_fused"))
                    else "decode+post")
             stage_ms[key] = stage_ms.get(key, 0.0) + p_["ms"] / args.steps
         out = {

@@ -7,6 +7,7 @@
 // from gemm_conv.hip / kernels_backbone.hip / kernels_decoder.hip.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -487,7 +488,7 @@ struct esam3_engine {
   }
 
   // ---------------- graphs ----------------
-  int mbconv(const std::string& p, const T4& x, int stride, bool residual, T4* y);
+  int mbconv(const std::string& p, const T4& x, int stride, bool residual, T4* y, const T4* dst = nullptr);
   int evit_block(const std::string& p, const T4& x, T4* y);
   int backbone(const float* img, int B, const esam3_image_features* out, T4* feat);
   int neck(const std::string& which, const T4& trunk, void* const outs[3], bool sam2);
@@ -501,11 +502,39 @@ using E = esam3_engine;
 
 // MBConv (ops.py:315-367): 1x1 expand (+BN/bias, Hardswish) -> dw3x3 (stride) -> 1x1 project (+BN),
 // optional identity shortcut fused into the projection's epilogue (ops.py:761-770).
-int E::mbconv(const std::string& p, const T4& x, int stride, bool residual, T4* y) {
+int E::mbconv(const std::string& p, const T4& x, int stride, bool residual, T4* y, const T4* dst) {
   const HostTensor* pw = need(p + "point_conv.conv.weight");
   if (!pw) return -1;
-  *y = alloc4(x.B, (x.H + stride - 1) / stride, (x.W + stride - 1) / stride, (int)pw->shape[0]);
+  if (dst) *y = *dst;
+  else *y = alloc4(x.B, (x.H + stride - 1) / stride, (x.W + stride - 1) / stride, (int)pw->shape[0]);
   if (!ok(y->p)) return -1;
+  // the fused kernel is correct but still latency-bound (slower than the layer-by-layer path):
+  // opt-in until it wins
+  static const bool no_fused = getenv("ESAM3_FUSED_MBCONV") == nullptr;
+  const HostTensor* ew = need(p + "inverted_conv.conv.weight");
+  if (!ew) return -1;
+  const int cmid = (int)ew->shape[0];
+  if (!no_fused && esam3_mbconv_fused_lds(dtype, x.C, cmid, y->C, stride) > 0 && x.ld == x.C) {
+    auto pkc = [&](const std::string& q) {
+      return pk_conv(q + ".conv.weight", find(q + ".conv.bias") ? q + ".conv.bias" : "",
+                     find(q + ".norm.weight") ? q + ".norm" : "");
+    };
+    PackedGemm* g1 = pkc(p + "inverted_conv");
+    PackedGemm* g2 = pkc(p + "point_conv");
+    PackedDw* dw = pk_dw(p + "depth_conv.conv.weight", find(p + "depth_conv.conv.bias") ? p + "depth_conv.conv.bias" : "",
+                         find(p + "depth_conv.norm.weight") ? p + "depth_conv.norm" : "");
+    if (!g1 || !g2 || !dw) return -1;
+    if (!g1->bias || !g2->bias) { esam3_set_error("mbconv %s: missing folded bias", p.c_str()); return -1; }
+    if (dry) return 0;
+    const double px = (double)x.rows(), opx = (double)y->rows();
+    return prof_launch("mbconv_fused_s" + std::to_string(stride) + ":" + p.substr(p.size() > 40 ? p.size() - 40 : 0),
+                       2.0 * (px * x.C * cmid + opx * cmid * 9 + opx * cmid * y->C),
+                       (px * x.C * (residual ? 2 : 1) + opx * y->C) * (double)esz, [&]() {
+                         return esam3_launch_mbconv_fused(dtype, x.p, y->p, g1->w, g1->Kp, g1->bias, dw->w, dw->bias,
+                                                          g2->w, g2->Kp, g2->bias, x.B, x.H, x.W, x.C, cmid, y->C,
+                                                          stride, residual ? 1 : 0, st);
+                       });
+  }
   const size_t mk = arena.mark();
   T4 a, b, yy;
   CK(conv(p + "inverted_conv", true, x, ACT_HSWISH, &a));
@@ -559,14 +588,13 @@ int E::evit_block(const std::string& p, const T4& x, T4* y) {
     CK(conv(c + "proj", true, att, ACT_NONE, &t2, &x, &x1));
   }
   arena.release(mk);
-  {
-    const std::string m = p + "local_module.main.";
-    T4 a, b, t;
-    CK(conv(m + "inverted_conv", true, x1, ACT_HSWISH, &a));
-    CK(dwconv(m + "depth_conv", true, a, 1, ACT_HSWISH, &b));
-    CK(conv(m + "point_conv", true, b, ACT_NONE, &t, &x1, y));
-  }
   arena.release(mk);
+  {  // local module = Residual(MBConv): same fused kernel, writing into y
+    const std::string m = p + "local_module.main.";
+    T4 ynew;
+    CK(mbconv(m, x1, 1, true, &ynew, y));
+    arena.release(mk);
+  }
   return 0;
 }
 

@@ -18,7 +18,12 @@ __host__ __device__ inline float bf16_to_f32(bf16_t v) {
   x.u = ((uint32_t)v) << 16;
   return x.f;
 }
+typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+typedef float f32x2_v __attribute__((ext_vector_type(2)));
 __host__ __device__ inline bf16_t f32_to_bf16(float f) {  // round-to-nearest-even
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_bit_cast(uint16_t, (__bf16)f);  // one v_cvt_pk_bf16_f32
+#endif
   union { uint32_t u; float f; } x;
   x.f = f;
   uint32_t u = x.u;
@@ -26,6 +31,14 @@ __host__ __device__ inline bf16_t f32_to_bf16(float f) {  // round-to-nearest-ev
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+
+#if defined(__HIPCC__)
+// two floats -> packed bf16 pair (lo in bits 0..15): a single v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const f32x2_v f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_v));
+}
+#endif
 
 template <typename T> struct ElemOps;
 template <> struct ElemOps<float> {

@@ -86,10 +86,10 @@ __device__ __forceinline__ void epilogue_chunk(const GemmParams& p, int64_t m64,
   if (vec) {
     if constexpr (sizeof(T) == 2) {
       u32x4 o;
-      o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-      o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-      o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-      o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+      o.x = pack_bf16x2(v[0], v[1]);
+      o.y = pack_bf16x2(v[2], v[3]);
+      o.z = pack_bf16x2(v[4], v[5]);
+      o.w = pack_bf16x2(v[6], v[7]);
       *reinterpret_cast<u32x4*>(gO + o_off) = o;
     } else {
       *reinterpret_cast<float4*>(gO + o_off) = make_float4(v[0], v[1], v[2], v[3]);

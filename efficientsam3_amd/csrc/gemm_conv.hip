@@ -509,10 +509,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
           if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int qp = 0; qp < 2; ++qp) {
-              uint32_t a0 = (uint32_t)f32_to_bf16(v[8 * qp + 0]) | ((uint32_t)f32_to_bf16(v[8 * qp + 1]) << 16);
-              uint32_t a1 = (uint32_t)f32_to_bf16(v[8 * qp + 2]) | ((uint32_t)f32_to_bf16(v[8 * qp + 3]) << 16);
-              uint32_t b0 = (uint32_t)f32_to_bf16(v[8 * qp + 4]) | ((uint32_t)f32_to_bf16(v[8 * qp + 5]) << 16);
-              uint32_t b1 = (uint32_t)f32_to_bf16(v[8 * qp + 6]) | ((uint32_t)f32_to_bf16(v[8 * qp + 7]) << 16);
+              uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]);
+              uint32_t a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
+              uint32_t b0 = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]);
+              uint32_t b1 = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
               // half-wave exchange: lanes 0-31 end with channels 16qp..16qp+7, lanes 32-63 with +8..+15
               auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
               auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
@@ -536,6 +536,154 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     if (!has_next) break;
   }
 #undef ESAM3_ISSUE_TILE
+}
+
+// ======================================================================================
+// thin GEMM: K*N small, M huge (the backbone's 1x1 convs at 504^2 / 252^2) -- HBM-bound.
+// No LDS and no barriers: every wavefront owns 32-row tiles, reads its A fragments straight
+// from global memory in MFMA layout (a 32-row x 32-byte K chunk is one contiguous 1 KB
+// request when the row pitch is 32 B), keeps the whole (tiny) weight matrix in registers,
+// and streams the result out with 16-byte stores.  Grid-stride over row tiles.
+// ======================================================================================
+template <typename T, int NT, int KCH>  // NT n-tiles of 32 channels, KCH 32-byte K chunks
+__global__ __launch_bounds__(256) void thin_gemm_kernel(GemmParams p) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int lane = threadIdx.x & 63;
+  const int l31 = lane & 31, g = lane >> 5;
+  const T* __restrict__ gA = reinterpret_cast<const T*>(p.A);
+  const T* __restrict__ gW = reinterpret_cast<const T*>(p.Wt);
+  T* __restrict__ gO = reinterpret_cast<T*>(p.out);
+  const T* __restrict__ gR = reinterpret_cast<const T*>(p.res);
+
+  // the weight fragments are loop invariant: NT*KCH 16-byte registers per lane
+  u32x4 fw[NT][KCH];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc)
+      fw[j][kc] = *reinterpret_cast<const u32x4*>(gW + (int64_t)(j * 32 + l31) * p.Kp + (kc * 2 + g) * EPC);
+  float4 bq[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = j * 32 + 8 * q + 4 * g;
+      bq[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) {
+        bq[j][q].x = n + 0 < p.N ? p.bias[n + 0] : 0.f;
+        bq[j][q].y = n + 1 < p.N ? p.bias[n + 1] : 0.f;
+        bq[j][q].z = n + 2 < p.N ? p.bias[n + 2] : 0.f;
+        bq[j][q].w = n + 3 < p.N ? p.bias[n + 3] : 0.f;
+      }
+    }
+
+  const unsigned M32 = (unsigned)p.M;
+  const unsigned ntile = (M32 + 31) / 32;
+  const unsigned wstride = gridDim.x * 4;
+  for (unsigned rt = blockIdx.x * 4 + (threadIdx.x >> 6); rt < ntile; rt += wstride) {
+    const unsigned m = rt * 32 + l31;
+    const bool rok = m < M32;
+    const T* arow = gA + (int64_t)(rok ? m : 0) * p.lda;
+    u32x4 fa[KCH];
+#pragma unroll
+    for (int kc = 0; kc < KCH; ++kc) {
+      fa[kc] = u32x4{0u, 0u, 0u, 0u};
+      if (rok && (kc * 2 + g) * EPC < p.K) fa[kc] = *reinterpret_cast<const u32x4*>(arow + (kc * 2 + g) * EPC);
+    }
+    f32x16_v acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < KCH; ++kc) MmaOps<T>::mma(fw[j][kc], fa[kc], acc[j]);
+    }
+    const int64_t obase = (int64_t)m * p.ldc, rbase = (int64_t)m * p.ldr;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (j * 32 >= p.N) continue;
+      float v[16], r16[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = j * 32 + 8 * q + 4 * g;
+        float r4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gR && rok && n < p.N) {
+          if constexpr (sizeof(T) == 2) {
+            const uint2 u = *reinterpret_cast<const uint2*>(gR + rbase + n);
+            r4[0] = __uint_as_float(u.x << 16); r4[1] = __uint_as_float(u.x & 0xffff0000u);
+            r4[2] = __uint_as_float(u.y << 16); r4[3] = __uint_as_float(u.y & 0xffff0000u);
+          } else {
+            const float4 u = *reinterpret_cast<const float4*>(gR + rbase + n);
+            r4[0] = u.x; r4[1] = u.y; r4[2] = u.z; r4[3] = u.w;
+          }
+        }
+        const float bb[4] = {bq[j][q].x, bq[j][q].y, bq[j][q].z, bq[j][q].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          r16[4 * q + e] = r4[e];
+          v[4 * q + e] = acc[j][4 * q + e] + bb[e] + (p.res_after_act ? 0.f : r4[e]);
+        }
+      }
+      act_apply_n<16>(v, p.act);
+      if (p.res_after_act && gR) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += r16[e];
+      }
+      T* op = gO + obase + j * 32;
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
+          uint32_t b0 = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]), b1 = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
+          auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+          auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+          const int n8 = j * 32 + 16 * qp + 8 * g;
+          if (rok && n8 < p.N) {
+            u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+            *reinterpret_cast<u32x4*>(op + 16 * qp + 8 * g) = o;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (rok && j * 32 + 8 * q + 4 * g < p.N)
+            *reinterpret_cast<float4*>(op + 8 * q + 4 * g) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      }
+    }
+  }
+}
+
+template <typename T, int NT, int KCH>
+int launch_thin(const GemmParams& p, hipStream_t stream) {
+  const int64_t tiles = (p.M + 31) / 32;
+  const int64_t blocks = (tiles + 3) / 4;
+  const unsigned grid = (unsigned)(blocks < 256 * 8 ? blocks : 256 * 8);
+  hipLaunchKernelGGL((thin_gemm_kernel<T, NT, KCH>), dim3(grid), dim3(256), 0, stream, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// thin path: plain 1x1 / Linear, N <= 128 (multiple of 8), K <= 128 bytes-chunks budget, big M
+template <typename T>
+int try_thin(const GemmParams& p, hipStream_t stream, bool* done) {
+  *done = false;
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int chunk = 32 / (int)sizeof(T);
+  if (p.ksize != 1 || p.out_mode != OUT_PLAIN || p.out_pad || p.in_pad || p.res_mod || p.res_bidx) return 0;
+  if (p.M < 4096 || p.N > 128 || p.N % 8 || p.K % EPC || p.lda % EPC || p.ldc % 8 || (p.res && p.ldr % 4)) return 0;
+  const int kch = (p.K + chunk - 1) / chunk;
+  const int nt = (p.N + 31) / 32;
+  if (kch * nt > 16 || kch > 8) return 0;
+  if ((((uintptr_t)p.out) & 15) || (((uintptr_t)p.A) & 15)) return 0;
+  *done = true;
+#define ESAM3_THIN(NT_, KCH_) if (nt == NT_ && kch == KCH_) return launch_thin<T, NT_, KCH_>(p, stream);
+  ESAM3_THIN(1, 1) ESAM3_THIN(1, 2) ESAM3_THIN(1, 4) ESAM3_THIN(1, 8)
+  ESAM3_THIN(2, 1) ESAM3_THIN(2, 2) ESAM3_THIN(2, 4) ESAM3_THIN(2, 8)
+  ESAM3_THIN(3, 1) ESAM3_THIN(3, 2) ESAM3_THIN(3, 4)
+  ESAM3_THIN(4, 1) ESAM3_THIN(4, 2) ESAM3_THIN(4, 4)
+#undef ESAM3_THIN
+  *done = false;
+  return 0;
 }
 
 // ======================================================================================
@@ -606,6 +754,11 @@ bool use_256(const GemmParams& p) {
 template <typename T>
 int launch_gemm_t(const GemmParams& p, hipStream_t stream, int force_small) {
   if (!force_small && use_256<T>(p)) return launch_256<T>(p, stream);
+  if (!(force_small & 2)) {
+    bool done = false;
+    const int rc = try_thin<T>(p, stream, &done);
+    if (done || rc) return rc;
+  }
   if (p.N > 64) return launch_cfg<T, 128, 128, 2, 2>(p, stream);
   if (p.N > 32) return launch_cfg<T, 128, 64, 2, 2>(p, stream);
   return launch_cfg<T, 128, 32, 4, 1>(p, stream);

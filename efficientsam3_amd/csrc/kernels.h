@@ -95,3 +95,9 @@ int esam3_launch_nhwc_to_nchw_f32(int dtype, const void* in, float* out, int B, 
 int esam3_launch_preprocess_u8(const uint8_t* in, float* out, int B, int H, int W, hipStream_t s);
 // zero the 1-pixel border of a [B][Hp][Wp][C] tensor (Hp = H+2, Wp = W+2)
 int esam3_launch_zero_border(int dtype, void* x, int B, int Hp, int Wp, int C, hipStream_t s);
+// fused MBConv (mbconv_fused.hip): returns LDS bytes needed, 0 if the shape is unsupported
+size_t esam3_mbconv_fused_lds(int dtype, int Cin, int Cmid, int Cout, int stride);
+int esam3_launch_mbconv_fused(int dtype, const void* x, void* out, const void* w1, int Kp1, const float* b1,
+                              const float* wd, const float* bd, const void* w2, int Kp2, const float* b2, int B,
+                              int H, int W, int Cin, int Cmid, int Cout, int stride, int residual,
+                              hipStream_t stream);

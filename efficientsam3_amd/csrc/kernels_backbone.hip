@@ -20,10 +20,10 @@ template <> struct Vec8<bf16_t> {
   }
   static __device__ inline void store(bf16_t* p, const float* v) {
     uint4 o;
-    o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-    o.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-    o.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]);
+    o.w = pack_bf16x2(v[6], v[7]);
     *reinterpret_cast<uint4*>(p) = o;
   }
 };
@@ -45,45 +45,46 @@ template <> struct Vec8<float> {
 // (efficientvit/backbone.py:48-56).  One thread per output pixel, Cout <= 32.
 // ------------------------------------------------------------------------------------
 template <typename T>
-__global__ void stem_kernel(const float* __restrict__ img, const float* __restrict__ w,
-                            const float* __restrict__ bias, T* __restrict__ out, int B, int H, int W,
-                            int Cout, int act) {
+__global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                   const float* __restrict__ bias, T* __restrict__ out, int B,
+                                                   int H, int W, int Cout, int act) {
+  // thread = (output pixel, 8-channel group); weights [27][Cout] + bias in LDS
   __shared__ float sw[27 * 32];
   __shared__ float sb[32];
   for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) sw[i] = w[i];
   for (int i = threadIdx.x; i < Cout; i += blockDim.x) sb[i] = bias ? bias[i] : 0.f;
   __syncthreads();
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
-  const int64_t total = (int64_t)B * OH * OW;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int ow = (int)(idx % OW);
-  const int oh = (int)((idx / OW) % OH);
-  const int64_t b = idx / ((int64_t)OW * OH);
-  float x[27];
+  const unsigned CG = (unsigned)Cout / VEC;
+  const unsigned xi = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned cg = xi % CG, ow = xi / CG;
+  if ((int)ow >= OW) return;
+  const unsigned b = blockIdx.y / (unsigned)OH;
+  const int oh = (int)(blockIdx.y - b * (unsigned)OH);
+  const int co0 = (int)cg * VEC;
+  float acc[VEC];
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
+  for (int e = 0; e < VEC; ++e) acc[e] = sb[co0 + e];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+  for (int c = 0; c < 3; ++c) {
+    const float* plane = img + ((int64_t)(b * 3 + c) * H) * W;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = 2 * oh + kh - 1;
+      if ((unsigned)ih >= (unsigned)H) continue;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        const int ih = 2 * oh + kh - 1, iw = 2 * ow + kw - 1;
-        const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
-        x[(kh * 3 + kw) * 3 + c] = ok ? img[((b * 3 + c) * H + ih) * (int64_t)W + iw] : 0.f;
+        const int iw = 2 * (int)ow + kw - 1;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const float xv = plane[(int64_t)ih * W + iw];
+        const float* wk = sw + ((kh * 3 + kw) * 3 + c) * Cout + co0;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = fmaf(xv, wk[e], acc[e]);
       }
-  T* o = out + idx * Cout;
-  for (int co0 = 0; co0 < Cout; co0 += VEC) {
-    float acc[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[e] = sb[co0 + e];
-#pragma unroll
-    for (int k = 0; k < 27; ++k)
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) acc[e] = fmaf(x[k], sw[k * Cout + co0 + e], acc[e]);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[e] = act_apply(acc[e], act);
-    Vec8<T>::store(o + co0, acc);
+    }
   }
+  act_apply_n<VEC>(acc, act);
+  Vec8<T>::store(out + (((int64_t)b * OH + oh) * OW + ow) * Cout + co0, acc);
 }
 
 // ------------------------------------------------------------------------------------
@@ -91,46 +92,64 @@ __global__ void stem_kernel(const float* __restrict__ img, const float* __restri
 // (DSConv / MBConv depth_conv, ops.py:290-299,344-353; LiteMLA aggreg.0.0, ops.py:560-567).
 // thread = (output pixel, 8-channel group); channel groups are the fastest index.
 // ------------------------------------------------------------------------------------
-template <typename T, int KS>
+// grid.y = (image, output row): no per-thread divisions by run-time 64-bit values; a thread
+// produces NP horizontally adjacent outputs for 8 channels from a sliding window, so every input
+// vector is loaded once per (row tap) instead of once per tap.
+template <typename T, int KS, int STRIDE, int NP>
 __global__ void dwconv_kernel(const T* __restrict__ in, int ld_in, const float* __restrict__ w,
-                              const float* __restrict__ bias, T* __restrict__ out, int ld_out, int B,
-                              int H, int W, int C, int stride, int act) {
-  const int CG = C / VEC;
-  const int OH = (H + stride - 1) / stride, OW = (W + stride - 1) / stride;
-  const int64_t total = (int64_t)B * OH * OW * CG;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int cg = (int)(idx % CG);
-  const int64_t pix = idx / CG;
-  const int ow = (int)(pix % OW);
-  const int oh = (int)((pix / OW) % OH);
-  const int64_t b = pix / ((int64_t)OW * OH);
-  const int c0 = cg * VEC;
-  float acc[VEC];
-#pragma unroll
-  for (int e = 0; e < VEC; ++e) acc[e] = bias ? bias[c0 + e] : 0.f;
+                              const float* __restrict__ bias, T* __restrict__ out, int ld_out, int H,
+                              int W, int C, int OH, int OW, int act) {
   constexpr int P = KS / 2;
+  constexpr int WIN = (NP - 1) * STRIDE + KS;  // input columns touched by NP outputs
+  const unsigned CG = (unsigned)C / VEC;
+  const unsigned xi = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned cg = xi % CG, pg = xi / CG;  // channel group, group of NP output pixels
+  const int ow0 = (int)pg * NP;
+  if (ow0 >= OW) return;
+  const unsigned b = blockIdx.y / (unsigned)OH;
+  const int oh = (int)(blockIdx.y - b * (unsigned)OH);
+  const int c0 = (int)cg * VEC;
+  float acc[NP][VEC];
+#pragma unroll
+  for (int j = 0; j < NP; ++j)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[j][e] = bias ? bias[c0 + e] : 0.f;
+  const int iw0 = ow0 * STRIDE - P;
 #pragma unroll
   for (int kh = 0; kh < KS; ++kh) {
-    const int ih = oh * stride + kh - P;
+    const int ih = oh * STRIDE + kh - P;
     if ((unsigned)ih >= (unsigned)H) continue;
+    const T* row = in + ((int64_t)(b * (unsigned)H + ih) * W) * ld_in + c0;
+    float x[WIN][VEC];
+#pragma unroll
+    for (int t = 0; t < WIN; ++t) {
+      const int iw = iw0 + t;
+      if ((unsigned)iw < (unsigned)W) {
+        Vec8<T>::load(row + (int64_t)iw * ld_in, x[t]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) x[t][e] = 0.f;
+      }
+    }
 #pragma unroll
     for (int kw = 0; kw < KS; ++kw) {
-      const int iw = ow * stride + kw - P;
-      if ((unsigned)iw >= (unsigned)W) continue;
-      float x[VEC];
-      Vec8<T>::load(in + ((b * H + ih) * (int64_t)W + iw) * ld_in + c0, x);
       const float4 w0 = *reinterpret_cast<const float4*>(w + (kh * KS + kw) * C + c0);
       const float4 w1 = *reinterpret_cast<const float4*>(w + (kh * KS + kw) * C + c0 + 4);
-      acc[0] = fmaf(x[0], w0.x, acc[0]); acc[1] = fmaf(x[1], w0.y, acc[1]);
-      acc[2] = fmaf(x[2], w0.z, acc[2]); acc[3] = fmaf(x[3], w0.w, acc[3]);
-      acc[4] = fmaf(x[4], w1.x, acc[4]); acc[5] = fmaf(x[5], w1.y, acc[5]);
-      acc[6] = fmaf(x[6], w1.z, acc[6]); acc[7] = fmaf(x[7], w1.w, acc[7]);
+      const float ww[VEC] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[j][e] = fmaf(x[j * STRIDE + kw][e], ww[e], acc[j][e]);
     }
   }
+  T* orow = out + ((int64_t)(b * (unsigned)OH + oh) * OW) * ld_out + c0;
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) acc[e] = act_apply(acc[e], act);
-  Vec8<T>::store(out + pix * ld_out + c0, acc);
+  for (int j = 0; j < NP; ++j) {
+    if (ow0 + j < OW) {
+      act_apply_n<VEC>(acc[j], act);
+      Vec8<T>::store(orow + (int64_t)(ow0 + j) * ld_out, acc[j]);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -455,9 +474,10 @@ int esam3_launch_preprocess_u8(const uint8_t* in, float* out, int B, int H, int 
 int esam3_launch_stem(int dtype, const float* img, const float* w, const float* bias, void* out,
                       int B, int H, int W, int Cout, int act, hipStream_t s) {
   if (Cout > 32 || Cout % VEC) { esam3_set_error("stem: Cout=%d unsupported", Cout); return -1; }
-  const int64_t total = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s,
-                                       img, w, bias, (T*)out, B, H, W, Cout, act));
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const dim3 grid(blocks_for((int64_t)OW * (Cout / VEC), 256), (unsigned)(B * OH));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_kernel<T>, grid, dim3(256), 0, s, img, w, bias, (T*)out, B, H, W,
+                                       Cout, act));
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -470,16 +490,18 @@ int esam3_launch_dwconv(int dtype, const void* in, int ld_in, const float* w, co
     return -1;
   }
   const int OH = (H + stride - 1) / stride, OW = (W + stride - 1) / stride;
-  const int64_t total = (int64_t)B * OH * OW * (C / VEC);
-  if (ksize == 3) {
-    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv_kernel<T, 3>), dim3(blocks_for(total, 256)), dim3(256),
-                                         0, s, (const T*)in, ld_in, w, bias, (T*)out, ld_out, B, H, W,
-                                         C, stride, act));
-  } else {
-    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv_kernel<T, 5>), dim3(blocks_for(total, 256)), dim3(256),
-                                         0, s, (const T*)in, ld_in, w, bias, (T*)out, ld_out, B, H, W,
-                                         C, stride, act));
-  }
+#define ESAM3_DW(KS, ST, NP)                                                                        \
+  do {                                                                                              \
+    const unsigned gx = blocks_for((int64_t)((OW + NP - 1) / NP) * (C / VEC), 256);                 \
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv_kernel<T, KS, ST, NP>), dim3(gx, (unsigned)(B * OH)), \
+                                         dim3(256), 0, s, (const T*)in, ld_in, w, bias, (T*)out, ld_out, \
+                                         H, W, C, OH, OW, act));                                    \
+  } while (0)
+  if (ksize == 3 && stride == 1) ESAM3_DW(3, 1, 4);
+  else if (ksize == 3) ESAM3_DW(3, 2, 2);
+  else if (stride == 1) ESAM3_DW(5, 1, 2);
+  else ESAM3_DW(5, 2, 1);
+#undef ESAM3_DW
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

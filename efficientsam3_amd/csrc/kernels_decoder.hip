@@ -350,7 +350,8 @@ __global__ void cc_merge_kernel(const float* __restrict__ in, int* __restrict__ 
   }
 }
 
-__global__ void cc_count_kernel(int* __restrict__ labels, int* __restrict__ areas, int HW, int64_t total) {
+__global__ void cc_count_kernel(int* __restrict__ labels, int* __restrict__ areas, int HW, int64_t total,
+                                int sat) {
   const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = gi < total;
   const int lane = threadIdx.x & 63;
@@ -373,7 +374,10 @@ __global__ void cc_count_kernel(int* __restrict__ labels, int* __restrict__ area
   if (leader) {
     const unsigned long long above = lane == 63 ? 0ull : (bm >> (lane + 1));
     const int len = above ? __ffsll((long long)above) : 64 - lane;
-    atomicAdd(areas + key, len);
+    // only "area <= max_area" is consumed: once a component is known to exceed `sat`, further
+    // (heavily contended) atomics on its root are skipped -- the count stays > max_area
+    if (__hip_atomic_load(areas + key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= sat)
+      atomicAdd(areas + key, len);
   }
 }
 
@@ -530,7 +534,7 @@ int esam3_launch_fill_holes(const float* in, float* out, int* labels, int* areas
   const dim3 grid(blocks_for(total, 256)), blk(256);
   hipLaunchKernelGGL(cc_init_kernel, grid, blk, 0, s, in, labels, areas, W, HW, total, thr);
   hipLaunchKernelGGL(cc_merge_kernel, grid, blk, 0, s, in, labels, W, H, HW, total, thr);
-  hipLaunchKernelGGL(cc_count_kernel, grid, blk, 0, s, labels, areas, HW, total);
+  hipLaunchKernelGGL(cc_count_kernel, grid, blk, 0, s, labels, areas, HW, total, (int)max_area);
   hipLaunchKernelGGL(cc_apply_kernel, grid, blk, 0, s, in, out, labels, areas, HW, total, thr, max_area);
   HIP_CHECK_RET(hipGetLastError());
   return 0;

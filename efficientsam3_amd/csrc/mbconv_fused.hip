@@ -1,0 +1,326 @@
+// Fused MBConv for gfx950: 1x1 expand (+bias/BN, Hardswish) -> depthwise 3x3 (stride 1|2,
+// +bias/BN, Hardswish) -> 1x1 project (+BN) (+identity shortcut) in ONE kernel
+// (efficientvit/nn/ops.py:315-367 MBConv; ResidualBlock :740-770).
+//
+// Why: the 4x-expanded tensor is by far the largest activation of the backbone (64 ch at
+// 504^2 = 1.04 GB per 32 images); executed layer by layer it is written and read twice
+// (expand -> dw -> project).  Here it never leaves the CU: a workgroup owns an 8x8 tile of
+// OUTPUT pixels, stages the (8s+2)^2 input halo tile in LDS, and loops over the expanded
+// channels in chunks of 128 bytes (64 bf16 / 32 f32):
+//   E: mid[halo px][chunk]   = hswish(x_tile @ W1[chunk]^T + b1)        MFMA, result -> LDS
+//      (halo pixels outside the image are written as 0: they are the dw conv's zero padding)
+//   D: dwo[64 px][chunk]     = hswish(dw3x3(mid) + bd)                  VALU from LDS -> LDS
+//   P: acc[64 px][Cout]     += dwo @ W2[:, chunk]^T                     MFMA, accumulators in regs
+// and finally out = acc + b2 (+ x).  HBM traffic per layer: the input once (+ halo), the
+// output once.  Weights come straight from L1/L2 as MFMA fragments (they are tiny).
+#include "gemm_common.h"
+#include "kernels.h"
+
+namespace {
+
+struct MbParams {
+  const void* x;     // [B][H][W][Cin]
+  void* out;         // [B][OH][OW][Cout]
+  const void* w1;    // packed [>=Cmid][Kp1]  (expand)
+  const float* b1;   // [Cmid]
+  const float* wd;   // [9][Cmid] fp32
+  const float* bd;   // [Cmid] or null
+  const void* w2;    // packed [>=Cout32][Kp2] (project)
+  const float* b2;   // [Cout]
+  int B, H, W, OH, OW, Cin, Cmid, Cout, Kp1, Kp2;
+  int residual;      // 1: out += x (stride 1, Cin == Cout)
+  int x_pitch;       // bytes per pixel row of the x tile in LDS (Cin padded to a 32-byte chunk)
+  int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ float hswish(float x) {
+  return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
+}
+
+// 16-byte slot swizzle for a tile with `slots` 16-byte slots per row (power of two), so that
+// 16 consecutive rows at the same logical slot fall into 16 different bank slots
+__device__ __forceinline__ int swz_slot(int row, int slot, int slots) {
+  if (slots >= 16) return slot ^ (row & 15);
+  if (slots == 8) return slot ^ ((row >> 1) & 7);
+  if (slots == 4) return slot ^ ((row >> 2) & 3);
+  if (slots == 2) return slot ^ ((row >> 3) & 1);
+  return slot;
+}
+
+template <typename T, int S>
+__global__ __launch_bounds__(256) void mbconv_fused_kernel(MbParams p) {
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int EPC = 16 / ESZ;            // elements per 16-byte slot
+  constexpr int MC = 128 / ESZ;            // expanded channels per chunk (128-byte rows)
+  constexpr int TS = 8;                    // output tile side
+  constexpr int HS = TS * S + (S == 1 ? 2 : 1);  // halo side: 10 (s1) / 17 (s2)
+  constexpr int HP = HS * HS;              // halo pixels
+  constexpr int MP = (HP + 31) / 32 * 32;  // padded to MFMA tile rows: 128 / 320
+  constexpr int MT_E = MP / 32;            // expand m-tiles: 4 / 10
+  constexpr int NT_E = 2;                  // expand n-tiles (64 bf16 ... for f32 MC = 32 -> 1)
+  constexpr int NTE = MC / 32;             // 2 (bf16) or 1 (f32)
+  constexpr int TILES_E = MT_E * NTE;
+  constexpr int TPW_E = (TILES_E + 3) / 4;  // expand tiles per wave
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* xs = smem;                                 // [MP][x_pitch]
+  char* mid = xs + MP * p.x_pitch;                 // [MP][128 B] swizzled (S=8)
+  char* dwo = mid + MP * 128;                      // [64][128 B] swizzled
+  float* wds = reinterpret_cast<float*>(dwo + 64 * 128);  // [9][MC] + bd [MC]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, g = lane >> 5;
+
+  // tile coordinates
+  const unsigned tpi = (unsigned)(p.tiles_x * p.tiles_y);
+  const unsigned b = blockIdx.x / tpi;
+  const unsigned ti = blockIdx.x - b * tpi;
+  const int ty = (int)(ti / (unsigned)p.tiles_x), tx = (int)(ti - ty * p.tiles_x);
+  const int oy0 = ty * TS, ox0 = tx * TS;
+  const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+
+  const T* __restrict__ gx = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ gw1 = reinterpret_cast<const T*>(p.w1);
+  const T* __restrict__ gw2 = reinterpret_cast<const T*>(p.w2);
+  T* __restrict__ go = reinterpret_cast<T*>(p.out);
+
+  // ---- stage the input halo tile (zero outside the image / beyond Cin) -------------------
+  const int xslots = p.x_pitch / 16;
+  const bool xpow2 = (xslots & (xslots - 1)) == 0;
+  for (int idx = tid; idx < MP * xslots; idx += 256) {
+    const int pix = idx / xslots, slot = idx - pix * xslots;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (pix < HP) {
+      const int hy = pix / HS, hx = pix - hy * HS;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && slot * EPC < p.Cin)
+        v = *reinterpret_cast<const u32x4*>(gx + ((int64_t)(b * p.H + iy) * p.W + ix) * p.Cin + slot * EPC);
+    }
+    const int ps = xpow2 ? swz_slot(pix, slot, xslots) : slot;
+    *reinterpret_cast<u32x4*>(xs + pix * p.x_pitch + ps * 16) = v;
+  }
+
+  // project accumulators: tiles (mt in 0..1, nt in 0..Cout/32) round-robin over the 4 waves
+  const int nt_p = (p.Cout + 31) / 32;
+  const int tiles_p = 2 * nt_p;
+  f32x16_v accp[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[t][r] = 0.f;
+
+  const int kch_e = p.x_pitch / 32;  // 32-byte K chunks of the expand GEMM
+  const int nchunks = (p.Cmid + MC - 1) / MC;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int c0 = ch * MC;  // first expanded channel of this chunk
+    // dw weights / bias of the chunk -> LDS (fp32)
+    for (int i = tid; i < 10 * MC; i += 256) {
+      const int r = i / MC, c = i - r * MC;
+      float v = 0.f;
+      if (c0 + c < p.Cmid) v = r < 9 ? p.wd[r * p.Cmid + c0 + c] : (p.bd ? p.bd[c0 + c] : 0.f);
+      wds[i] = v;
+    }
+    __syncthreads();  // x tile (first iteration) + previous chunk's project reads are done
+
+    // ---- E: expand GEMM for this chunk over all halo pixels --------------------------------
+#pragma unroll
+    for (int tw = 0; tw < TPW_E; ++tw) {
+      const int t = wave + 4 * tw;
+      if (t < TILES_E) {
+        const int mt = t / NTE, nt = t - mt * NTE;
+        f32x16_v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int prow = mt * 32 + l31;
+        const T* wrow = gw1 + (int64_t)(c0 + nt * 32 + l31) * p.Kp1;
+        for (int kc = 0; kc < kch_e; ++kc) {
+          const int slot = kc * 2 + g;
+          const int ps = xpow2 ? swz_slot(prow, slot, xslots) : slot;
+          const u32x4 fa = *reinterpret_cast<const u32x4*>(xs + prow * p.x_pitch + ps * 16);
+          const u32x4 fw = *reinterpret_cast<const u32x4*>(wrow + slot * EPC);
+          MmaOps<T>::mma(fw, fa, acc);
+        }
+        // epilogue: + b1, hswish, zero outside the image, -> mid[pixel][channel]
+        const int hy = prow / HS, hx = prow - hy * HS;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool inimg = prow < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int nl = nt * 32 + 8 * q + 4 * g;  // channel within the chunk
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = c0 + nl + e;
+            const float bias = c < p.Cmid ? p.b1[c] : 0.f;
+            v[e] = inimg ? hswish(acc[4 * q + e] + bias) : 0.f;
+          }
+          const int slot = (nl * ESZ) / 16, inner = (nl * ESZ) & 15;
+          char* dst = mid + prow * 128 + swz_slot(prow, slot, 8) * 16 + inner;
+          if constexpr (ESZ == 2) {
+            uint2 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(dst) = o;
+          } else {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- D: depthwise 3x3 + bias + hswish: 64 output pixels x 8 channel groups -------------
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = tid + 256 * it;
+      const int op = item >> 3, cg = item & 7;
+      const int oy = op >> 3, ox = op & 7;
+      float a[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) a[e] = wds[9 * MC + cg * EPC + e];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int hp = (oy * S + kh) * HS + ox * S + kw;
+          const u32x4 m = *reinterpret_cast<const u32x4*>(mid + hp * 128 + swz_slot(hp, cg, 8) * 16);
+          const float* wt = wds + (kh * 3 + kw) * MC + cg * EPC;
+          if constexpr (ESZ == 2) {
+            const uint32_t ww[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              a[2 * e] = fmaf(__uint_as_float(ww[e] << 16), wt[2 * e], a[2 * e]);
+              a[2 * e + 1] = fmaf(__uint_as_float(ww[e] & 0xffff0000u), wt[2 * e + 1], a[2 * e + 1]);
+            }
+          } else {
+            a[0] = fmaf(__uint_as_float(m.x), wt[0], a[0]);
+            a[1] = fmaf(__uint_as_float(m.y), wt[1], a[1]);
+            a[2] = fmaf(__uint_as_float(m.z), wt[2], a[2]);
+            a[3] = fmaf(__uint_as_float(m.w), wt[3], a[3]);
+          }
+        }
+      u32x4 o;
+      if constexpr (ESZ == 2) {
+        o.x = pack_bf16x2(hswish(a[0]), hswish(a[1]));
+        o.y = pack_bf16x2(hswish(a[2]), hswish(a[3]));
+        o.z = pack_bf16x2(hswish(a[4]), hswish(a[5]));
+        o.w = pack_bf16x2(hswish(a[6]), hswish(a[7]));
+      } else {
+        o.x = __float_as_uint(hswish(a[0])); o.y = __float_as_uint(hswish(a[1]));
+        o.z = __float_as_uint(hswish(a[2])); o.w = __float_as_uint(hswish(a[3]));
+      }
+      *reinterpret_cast<u32x4*>(dwo + op * 128 + swz_slot(op, cg, 8) * 16) = o;
+    }
+    __syncthreads();
+
+    // ---- P: project GEMM step  acc[px][co] += dwo[px][chunk] * W2[co][chunk] ----------------
+#pragma unroll
+    for (int tw = 0; tw < 4; ++tw) {
+      const int t = wave + 4 * tw;
+      if (t < tiles_p) {
+        const int mt = t & 1, nt = t >> 1;
+        const int prow = mt * 32 + l31;
+        const T* wrow = gw2 + (int64_t)(nt * 32 + l31) * p.Kp2 + c0;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+          const int slot = kc * 2 + g;
+          const u32x4 fa = *reinterpret_cast<const u32x4*>(dwo + prow * 128 + swz_slot(prow, slot, 8) * 16);
+          u32x4 fw = {0u, 0u, 0u, 0u};
+          if (c0 + slot * EPC < p.Kp2) fw = *reinterpret_cast<const u32x4*>(wrow + slot * EPC);
+          MmaOps<T>::mma(fw, fa, accp[tw]);
+        }
+      }
+    }
+    // (the barrier at the top of the next chunk protects dwo / wds / mid)
+  }
+
+  // ---- final epilogue: + b2 (+ shortcut) -> NHWC store -------------------------------------
+#pragma unroll
+  for (int tw = 0; tw < 4; ++tw) {
+    const int t = wave + 4 * tw;
+    if (t >= tiles_p) continue;
+    const int mt = t & 1, nt = t >> 1;
+    const int op = mt * 32 + l31;
+    const int oy = oy0 + (op >> 3), ox = ox0 + (op & 7);
+    if (oy >= p.OH || ox >= p.OW) continue;
+    const int64_t opix = ((int64_t)b * p.OH + oy) * p.OW + ox;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = nt * 32 + 8 * q + 4 * g;
+      if (n >= p.Cout) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = accp[tw][4 * q + e] + (n + e < p.Cout ? p.b2[n + e] : 0.f);
+      if (p.residual) {  // identity shortcut: same pixel of the input (stride 1, Cin == Cout)
+        const T* rp = gx + opix * p.Cin + n;
+        if constexpr (ESZ == 2) {
+          const uint2 u = *reinterpret_cast<const uint2*>(rp);
+          v[0] += __uint_as_float(u.x << 16); v[1] += __uint_as_float(u.x & 0xffff0000u);
+          v[2] += __uint_as_float(u.y << 16); v[3] += __uint_as_float(u.y & 0xffff0000u);
+        } else {
+          const float4 u = *reinterpret_cast<const float4*>(rp);
+          v[0] += u.x; v[1] += u.y; v[2] += u.z; v[3] += u.w;
+        }
+      }
+      T* dst = go + opix * p.Cout + n;
+      if constexpr (ESZ == 2) {
+        uint2 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(dst) = o;
+      } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <typename T, int S>
+int launch_mb(const MbParams& p, size_t lds, hipStream_t stream) {
+  static bool attr_set = false;
+  auto kern = mbconv_fused_kernel<T, S>;
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)p.B * p.tiles_x * p.tiles_y;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// LDS bytes the fused kernel needs (0 = configuration not supported -> caller runs layer by layer)
+size_t esam3_mbconv_fused_lds(int dtype, int Cin, int Cmid, int Cout, int stride) {
+  const int esz = dtype == 0 ? 4 : 2;
+  const int chunk_e = 32 / esz;  // elements per 32-byte K chunk
+  if (Cin % (16 / esz) || Cmid % (16 / esz) || Cout % 4 || Cout > 256 || (stride != 1 && stride != 2)) return 0;
+  const int cin_p = (Cin + chunk_e - 1) / chunk_e * chunk_e;
+  const int mc = 128 / esz;
+  const int hs = 8 * stride + (stride == 1 ? 2 : 1);
+  const int mp = (hs * hs + 31) / 32 * 32;
+  const size_t lds = (size_t)mp * cin_p * esz + (size_t)mp * 128 + 64 * 128 + (size_t)10 * mc * 4;
+  return lds <= 160 * 1024 ? lds : 0;
+}
+
+int esam3_launch_mbconv_fused(int dtype, const void* x, void* out, const void* w1, int Kp1, const float* b1,
+                              const float* wd, const float* bd, const void* w2, int Kp2, const float* b2, int B,
+                              int H, int W, int Cin, int Cmid, int Cout, int stride, int residual,
+                              hipStream_t stream) {
+  const size_t lds = esam3_mbconv_fused_lds(dtype, Cin, Cmid, Cout, stride);
+  if (!lds) { esam3_set_error("mbconv_fused: unsupported configuration"); return -1; }
+  const int esz = dtype == 0 ? 4 : 2;
+  const int chunk_e = 32 / esz;
+  MbParams p{};
+  p.x = x; p.out = out; p.w1 = w1; p.b1 = b1; p.wd = wd; p.bd = bd; p.w2 = w2; p.b2 = b2;
+  p.B = B; p.H = H; p.W = W; p.OH = (H + stride - 1) / stride; p.OW = (W + stride - 1) / stride;
+  p.Cin = Cin; p.Cmid = Cmid; p.Cout = Cout; p.Kp1 = Kp1; p.Kp2 = Kp2; p.residual = residual;
+  p.x_pitch = (Cin + chunk_e - 1) / chunk_e * chunk_e * esz;
+  p.tiles_x = (p.OW + 7) / 8; p.tiles_y = (p.OH + 7) / 8;
+  if (p.x_pitch / esz > Kp1) { esam3_set_error("mbconv_fused: Kp1 too small"); return -1; }
+  if (stride == 1) return dtype == 0 ? launch_mb<float, 1>(p, lds, stream) : launch_mb<bf16_t, 1>(p, lds, stream);
+  return dtype == 0 ? launch_mb<float, 2>(p, lds, stream) : launch_mb<bf16_t, 2>(p, lds, stream);
+}

@@ -130,6 +130,35 @@ int esam3_op_conv_transpose2x2(int dtype, const void* x, const float* w, const f
   return 0;
 }
 
+// fused MBConv: w1 [Cmid][Cin], wd [Cmid][1][3][3], w2 [Cout][Cmid] (PyTorch layouts, BN already folded)
+int esam3_op_mbconv_fused(int dtype, const void* x, const float* w1, const float* b1, const float* wd,
+                          const float* bd, const float* w2, const float* b2, void* out, int B, int H, int W,
+                          int Cin, int Cmid, int Cout, int stride, int residual, void* stream) {
+  Tmp t;
+  const int esz = dtype == 0 ? 4 : 2;
+  const int Kp1 = esam3_gemm_pad_k(Cin, esz), Np1 = esam3_gemm_pad_n(Cmid);
+  const int Kp2 = esam3_gemm_pad_k(Cmid, esz), Np2 = esam3_gemm_pad_n(Cout);
+  std::vector<float> p1((size_t)Np1 * Kp1, 0.f), p2((size_t)Np2 * Kp2, 0.f), pd((size_t)9 * Cmid);
+  for (int n = 0; n < Cmid; ++n)
+    for (int k = 0; k < Cin; ++k) p1[(size_t)n * Kp1 + k] = w1[(size_t)n * Cin + k];
+  for (int n = 0; n < Cout; ++n)
+    for (int k = 0; k < Cmid; ++k) p2[(size_t)n * Kp2 + k] = w2[(size_t)n * Cmid + k];
+  for (int c = 0; c < Cmid; ++c)
+    for (int tp = 0; tp < 9; ++tp) pd[(size_t)tp * Cmid + c] = wd[(size_t)c * 9 + tp];
+  void* d1 = t.upT(dtype, p1);
+  void* d2 = t.upT(dtype, p2);
+  float* dd = (float*)t.up(pd.data(), pd.size() * 4);
+  float* db1 = (float*)t.up(b1, (size_t)Cmid * 4);
+  float* dbd = bd ? (float*)t.up(bd, (size_t)Cmid * 4) : nullptr;
+  float* db2 = (float*)t.up(b2, (size_t)Cout * 4);
+  if (!d1 || !d2 || !dd || !db1 || !db2) return fail("op_mbconv_fused");
+  if (esam3_launch_mbconv_fused(dtype, x, out, d1, Kp1, db1, dd, dbd, d2, Kp2, db2, B, H, W, Cin, Cmid, Cout, stride,
+                                residual, (hipStream_t)stream))
+    return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
 int esam3_op_dwconv(int dtype, const void* x, const float* w, const float* bias, void* out, int B, int H, int W,
                     int C, int ks, int stride, int act, void* stream) {
   Tmp t;

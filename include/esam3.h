@@ -128,6 +128,12 @@ int esam3_op_conv_transpose2x2(int dtype, const void* x_dev, const float* w_host
                                const float* bias_host, const void* res_dev, void* out_dev, int B,
                                int H, int W, int Cin, int Cout, int act, int res_after_act,
                                void* hip_stream);
+/* fused MBConv (1x1 expand + Hardswish -> dw3x3 stride 1|2 + Hardswish -> 1x1 project [+ x]), NHWC;
+ * w1 [Cmid][Cin], wd [Cmid][1][3][3], w2 [Cout][Cmid] host fp32 with BatchNorm already folded */
+int esam3_op_mbconv_fused(int dtype, const void* x_dev, const float* w1_host, const float* b1_host,
+                          const float* wd_host, const float* bd_host, const float* w2_host,
+                          const float* b2_host, void* out_dev, int B, int H, int W, int Cin, int Cmid,
+                          int Cout, int stride, int residual, void* hip_stream);
 /* depthwise k x k (3|5), stride 1|2; w_host PyTorch [C][1][k][k] */
 int esam3_op_dwconv(int dtype, const void* x_dev, const float* w_host, const float* bias_host,
                     void* out_dev, int B, int H, int W, int C, int ksize, int stride, int act,

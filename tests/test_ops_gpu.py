@@ -154,6 +154,40 @@ def test_dwconv(mode, B, H, W, C, ks, stride, act):
 
 
 @pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("B,H,W,Cin,Cmid,Cout,stride,res", [
+    (2, 40, 40, 16, 64, 32, 2, 0),     # stages.0.op_list.0 shape family
+    (1, 30, 26, 32, 128, 32, 1, 1),    # residual MBConv, ragged tiles
+    (2, 21, 19, 64, 256, 128, 2, 0),   # odd input size, stride 2 (126 -> 63 style)
+    (1, 16, 16, 128, 512, 128, 1, 1),  # EfficientViTBlock local module (stage 3)
+    (1, 9, 9, 256, 1024, 256, 1, 1),   # stage 4 local module: 16 channel chunks, Cout 256
+    (1, 17, 17, 24, 96, 48, 2, 0),     # EfficientViT-B2 widths (Cin not a power of two)
+])
+def test_mbconv_fused(mode, B, H, W, Cin, Cmid, Cout, stride, res):
+    """Fused expand -> dw3x3 -> project kernel vs the three-layer PyTorch reference
+    (efficientvit/nn/ops.py:315-367 with Hardswish, BN folded into weights/biases)."""
+    d, tdt = U.DT[mode]
+    x = _rand(B, Cin, H, W, seed=1)
+    w1, b1 = _rand(Cmid, Cin, 1, 1, seed=2) * (2.0 / Cin) ** 0.5, _rand(Cmid, seed=3) * 0.1
+    wd, bd = _rand(Cmid, 1, 3, 3, seed=4) * 0.4, _rand(Cmid, seed=5) * 0.1
+    w2, b2 = _rand(Cout, Cmid, 1, 1, seed=6) / Cmid ** 0.5, _rand(Cout, seed=7) * 0.1
+    xq = _q(x, mode)
+    m = F.hardswish(F.conv2d(xq, _q(w1, mode), b1))
+    m = _q(m, mode)  # the kernel keeps the expanded tile in the activation dtype
+    m = F.hardswish(F.conv2d(m, wd, bd, stride=stride, padding=1, groups=Cmid))
+    m = _q(m, mode)
+    ref = F.conv2d(m, _q(w2, mode), b2)
+    if res:
+        ref = ref + xq
+    x_d = U.to_dev_nhwc(x, tdt)
+    OH, OW = ref.shape[-2:]
+    out = torch.empty((B, OH, OW, Cout), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_mbconv_fused(d, U.P(x_d), U.H(U.np32(w1)), U.H(U.np32(b1)), U.H(U.np32(wd)),
+                                          U.H(U.np32(bd)), U.H(U.np32(w2)), U.H(U.np32(b2)), U.P(out), B, H, W,
+                                          Cin, Cmid, Cout, stride, res, None), "op_mbconv_fused")
+    U.assert_close(U.from_dev_nhwc(out), ref, mode, f"mbconv {Cin}->{Cmid}->{Cout} s{stride}", scale=2.0)
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("Cout", [16, 8, 24])
 def test_stem(mode, Cout):
     d, tdt = U.DT[mode]
