@@ -566,15 +566,27 @@ int E::evit_block(const std::string& p, const T4& x, T4* y) {
     T4 agg;
     CK(dwconv(c + "aggreg.0.0", false, qkv, 1, ACT_NONE, &agg));
     {
+      // grouped 1x1 (groups = 3*heads, dim -> dim each): executed as ONE dense GEMM with the
+      // block-diagonal [3C x 3C] weight matrix -- the zero blocks cost MFMA flops that are free
+      // here (the op is HBM-bound), and the GEMM kernel streams at several TB/s where a
+      // per-pixel 16x16 mat-vec kernel is bound by its weight reads.
       const std::string wn = c + "aggreg.0.1.weight";
-      float* gw = fvec(wn);
-      if (!gw) return -1;
-      const int gs = (int)need(wn)->shape[1];
-      if (!dry)
-        CK(prof_launch("grouped_pw", 2.0 * (double)ms.rows() * total3 * gs, 2.0 * (double)ms.rows() * total3 * (double)esz, [&]() {
-          return esam3_launch_grouped_pw(dtype, agg.p, agg.ld, gw, (char*)ms.p + (size_t)total3 * esz, ms.ld,
-                                         ms.rows(), total3, gs, st);
-        }));
+      const std::string key = wn + "#blockdiag";
+      if (!find(key)) {
+        const HostTensor* gwt = need(wn);
+        if (!gwt) return -1;
+        const int gs = (int)gwt->shape[1];
+        HostTensor bd;
+        bd.shape = {total3, total3};
+        bd.d.assign((size_t)total3 * total3, 0.f);
+        for (int co = 0; co < total3; ++co)
+          for (int ci = 0; ci < gs; ++ci)
+            bd.d[(size_t)co * total3 + (co / gs) * gs + ci] = gwt->d[(size_t)co * gs + ci];
+        raw[key] = std::move(bd);
+      }
+      PackedGemm* gbd = pk_conv_like_linear(key, "");
+      if (!gbd) return -1;
+      CK(gemm(gbd, agg.p, agg.ld, ms.rows(), 1, 1, (char*)ms.p + (size_t)total3 * esz, ms.ld, ACT_NONE));
     }
     T4 att = alloc4(x.B, x.H, x.W, 2 * heads * dim);
     float* kv = (float*)allocb(sizeof(float) * (size_t)x.B * 2 * heads * (dim + 1) * dim);

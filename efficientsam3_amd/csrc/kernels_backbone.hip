@@ -7,6 +7,18 @@ namespace {
 
 constexpr int VEC = 8;  // channels per thread for vectorised NHWC kernels
 
+// Workgroups are dispatched round-robin over the 8 XCDs (linear id % 8), each with a private
+// L2.  Stencil kernels whose neighbouring workgroups share input rows remap the linear id so
+// that every XCD owns one contiguous band of rows and the shared rows hit in its L2.
+__device__ __forceinline__ void xcd_remap_2d(unsigned gx, unsigned gy, unsigned& bx, unsigned& by) {
+  const unsigned nb = gx * gy;
+  const unsigned L = blockIdx.x;  // launched as a 1-D grid of gx*gy workgroups
+  const unsigned q = nb / 8, r = nb % 8, xcd = L % 8, idx = L / 8;
+  const unsigned Lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  bx = Lp % gx;
+  by = Lp / gx;
+}
+
 template <typename T> struct Vec8;
 template <> struct Vec8<bf16_t> {
   static __device__ inline void load(const bf16_t* p, float* v) {
@@ -47,7 +59,7 @@ template <> struct Vec8<float> {
 template <typename T>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                    const float* __restrict__ bias, T* __restrict__ out, int B,
-                                                   int H, int W, int Cout, int act) {
+                                                   int H, int W, int Cout, int act, unsigned gx, unsigned gy) {
   // thread = (output pixel, 8-channel group); weights [27][Cout] + bias in LDS
   __shared__ float sw[27 * 32];
   __shared__ float sb[32];
@@ -56,11 +68,13 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
   __syncthreads();
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   const unsigned CG = (unsigned)Cout / VEC;
-  const unsigned xi = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned bx, by;
+  xcd_remap_2d(gx, gy, bx, by);
+  const unsigned xi = bx * blockDim.x + threadIdx.x;
   const unsigned cg = xi % CG, ow = xi / CG;
   if ((int)ow >= OW) return;
-  const unsigned b = blockIdx.y / (unsigned)OH;
-  const int oh = (int)(blockIdx.y - b * (unsigned)OH);
+  const unsigned b = by / (unsigned)OH;
+  const int oh = (int)(by - b * (unsigned)OH);
   const int co0 = (int)cg * VEC;
   float acc[VEC];
 #pragma unroll
@@ -98,16 +112,18 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
 template <typename T, int KS, int STRIDE, int NP>
 __global__ void dwconv_kernel(const T* __restrict__ in, int ld_in, const float* __restrict__ w,
                               const float* __restrict__ bias, T* __restrict__ out, int ld_out, int H,
-                              int W, int C, int OH, int OW, int act) {
+                              int W, int C, int OH, int OW, int act, unsigned gx, unsigned gy) {
   constexpr int P = KS / 2;
   constexpr int WIN = (NP - 1) * STRIDE + KS;  // input columns touched by NP outputs
   const unsigned CG = (unsigned)C / VEC;
-  const unsigned xi = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned bx, by;
+  xcd_remap_2d(gx, gy, bx, by);
+  const unsigned xi = bx * blockDim.x + threadIdx.x;
   const unsigned cg = xi % CG, pg = xi / CG;  // channel group, group of NP output pixels
   const int ow0 = (int)pg * NP;
   if (ow0 >= OW) return;
-  const unsigned b = blockIdx.y / (unsigned)OH;
-  const int oh = (int)(blockIdx.y - b * (unsigned)OH);
+  const unsigned b = by / (unsigned)OH;
+  const int oh = (int)(by - b * (unsigned)OH);
   const int c0 = (int)cg * VEC;
   float acc[NP][VEC];
 #pragma unroll
@@ -475,9 +491,9 @@ int esam3_launch_stem(int dtype, const float* img, const float* w, const float* 
                       int B, int H, int W, int Cout, int act, hipStream_t s) {
   if (Cout > 32 || Cout % VEC) { esam3_set_error("stem: Cout=%d unsupported", Cout); return -1; }
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
-  const dim3 grid(blocks_for((int64_t)OW * (Cout / VEC), 256), (unsigned)(B * OH));
-  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_kernel<T>, grid, dim3(256), 0, s, img, w, bias, (T*)out, B, H, W,
-                                       Cout, act));
+  const unsigned gx = blocks_for((int64_t)OW * (Cout / VEC), 256), gy = (unsigned)(B * OH);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_kernel<T>, dim3(gx * gy), dim3(256), 0, s, img, w, bias, (T*)out, B,
+                                       H, W, Cout, act, gx, gy));
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -493,11 +509,12 @@ int esam3_launch_dwconv(int dtype, const void* in, int ld_in, const float* w, co
 #define ESAM3_DW(KS, ST, NP)                                                                        \
   do {                                                                                              \
     const unsigned gx = blocks_for((int64_t)((OW + NP - 1) / NP) * (C / VEC), 256);                 \
-    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv_kernel<T, KS, ST, NP>), dim3(gx, (unsigned)(B * OH)), \
-                                         dim3(256), 0, s, (const T*)in, ld_in, w, bias, (T*)out, ld_out, \
-                                         H, W, C, OH, OW, act));                                    \
+    const unsigned gy = (unsigned)(B * OH);                                                         \
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv_kernel<T, KS, ST, NP>), dim3(gx * gy), dim3(256), 0, s, \
+                                         (const T*)in, ld_in, w, bias, (T*)out, ld_out, H, W, C, OH, OW, \
+                                         act, gx, gy));                                             \
   } while (0)
-  if (ksize == 3 && stride == 1) ESAM3_DW(3, 1, 4);
+  if (ksize == 3 && stride == 1) ESAM3_DW(3, 1, 2);
   else if (ksize == 3) ESAM3_DW(3, 2, 2);
   else if (stride == 1) ESAM3_DW(5, 1, 2);
   else ESAM3_DW(5, 2, 1);
