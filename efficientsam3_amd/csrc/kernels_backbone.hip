@@ -168,6 +168,89 @@ __global__ void dwconv_kernel(const T* __restrict__ in, int ld_in, const float* 
   }
 }
 
+// 3x3 depthwise conv, column-strip variant: a thread keeps the 9 x 8 weights of its channel group
+// in registers and walks R output rows downwards with a rotating 3-row register window, so every
+// input vector is loaded (R+2)/R times instead of 3 and the weights once per R*NP outputs.
+template <typename T, int STRIDE, int NP, int R>
+__global__ __launch_bounds__(256) void dwconv3_strip_kernel(const T* __restrict__ in, int ld_in,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ bias, T* __restrict__ out,
+                                                            int ld_out, int H, int W, int C, int OH, int OW,
+                                                            int act, unsigned gx, unsigned gy, int strips) {
+  constexpr int KS = 3;
+  constexpr int WIN = (NP - 1) * STRIDE + KS;
+  const unsigned CG = (unsigned)C / VEC;
+  unsigned bx, by;
+  xcd_remap_2d(gx, gy, bx, by);
+  const unsigned xi = bx * blockDim.x + threadIdx.x;
+  const unsigned cg = xi % CG, pg = xi / CG;
+  const int ow0 = (int)pg * NP;
+  if (ow0 >= OW) return;
+  const unsigned b = by / (unsigned)strips;
+  const int oh0 = (int)(by - b * (unsigned)strips) * R;
+  const int c0 = (int)cg * VEC;
+  float wt[KS * KS][VEC], bs[VEC];
+#pragma unroll
+  for (int t = 0; t < KS * KS; ++t) {
+    const float4 w0 = *reinterpret_cast<const float4*>(w + t * C + c0);
+    const float4 w1 = *reinterpret_cast<const float4*>(w + t * C + c0 + 4);
+    wt[t][0] = w0.x; wt[t][1] = w0.y; wt[t][2] = w0.z; wt[t][3] = w0.w;
+    wt[t][4] = w1.x; wt[t][5] = w1.y; wt[t][6] = w1.z; wt[t][7] = w1.w;
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) bs[e] = bias ? bias[c0 + e] : 0.f;
+  const int iw0 = ow0 * STRIDE - 1;
+  const int ih0 = oh0 * STRIDE - 1;  // input row of window-relative row 0
+  const T* img = in + (int64_t)b * H * W * ld_in + c0;
+  float x[KS][WIN][VEC];
+  auto load_row = [&](int rel) {  // window-relative input row -> slot rel % KS
+    const int ih = ih0 + rel;
+    const bool rok = (unsigned)ih < (unsigned)H;
+    const T* row = img + (int64_t)ih * W * ld_in;
+#pragma unroll
+    for (int t = 0; t < WIN; ++t) {
+      const int iw = iw0 + t;
+      if (rok && (unsigned)iw < (unsigned)W) {
+        Vec8<T>::load(row + (int64_t)iw * ld_in, x[rel % KS][t]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) x[rel % KS][t][e] = 0.f;
+      }
+    }
+  };
+#pragma unroll
+  for (int rel = 0; rel < KS - STRIDE; ++rel) load_row(rel);
+  T* obase = out + (int64_t)b * OH * OW * ld_out + c0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (oh0 + r >= OH) break;
+#pragma unroll
+    for (int q = 0; q < STRIDE; ++q) load_row(r * STRIDE + KS - STRIDE + q);
+    float acc[NP][VEC];
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[j][e] = bs[e];
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < KS; ++kw)
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            acc[j][e] = fmaf(x[(r * STRIDE + kh) % KS][j * STRIDE + kw][e], wt[kh * KS + kw][e], acc[j][e]);
+    T* orow = obase + (int64_t)(oh0 + r) * OW * ld_out;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      if (ow0 + j < OW) {
+        act_apply_n<VEC>(acc[j], act);
+        Vec8<T>::store(orow + (int64_t)(ow0 + j) * ld_out, acc[j]);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // grouped 1x1 conv, gs(=8 or 16 or 32) channels per group in and out, no bias
 // (LiteMLA aggreg.0.1, ops.py:568).  thread = (row, group, 8-output-channel chunk).
@@ -207,7 +290,7 @@ __global__ void grouped_pw_kernel(const T* __restrict__ in, int ld_in, const flo
 // out of autocast, ops.py:586-589,616-618).
 // ------------------------------------------------------------------------------------
 template <typename T, int DIM>
-__global__ void mla_kv_kernel(const T* __restrict__ ms, int ld, float* __restrict__ kv, int N,
+__global__ void mla_kv_generic_kernel(const T* __restrict__ ms, int ld, float* __restrict__ kv, int N,
                               int groups, int n_split) {
   // block = (b, group, split); 256 threads
   constexpr int CH = 64;                 // positions per LDS chunk
@@ -267,45 +350,139 @@ __global__ void mla_kv_kernel(const T* __restrict__ ms, int ld, float* __restric
   }
 }
 
+
+template <typename T> __device__ inline void load4(const T* p, float* v);
+template <> __device__ inline void load4<bf16_t>(const bf16_t* p, float* v) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(u.x << 16);
+  v[1] = __uint_as_float(u.x & 0xffff0000u);
+  v[2] = __uint_as_float(u.y << 16);
+  v[3] = __uint_as_float(u.y & 0xffff0000u);
+}
+template <> __device__ inline void load4<float>(const float* p, float* v) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+}
+
+// kv reduction with every accumulator in registers: block = (image, token split), thread =
+// (token lane, group, part) where a part owns 4 of the DIM v-rows of its group's (DIM+1) x DIM
+// matrix.  A token's row of `ms` is read by groups*DIM/4 adjacent threads, i.e. fully coalesced;
+// the token lanes are merged through LDS atomics and the splits through global atomics.
 template <typename T, int DIM>
-__global__ void mla_apply_kernel(const T* __restrict__ ms, int ld, const float* __restrict__ kv,
-                                 T* __restrict__ out, int ld_out, int N, int groups) {
-  // grid = (ceil(N / rows_per_block), B); thread = (row_local, group) with group fastest
-  extern __shared__ float skv[];  // [groups][(DIM+1)*DIM]
+__global__ __launch_bounds__(256) void mla_kv_kernel(const T* __restrict__ ms, int ld, float* __restrict__ kv,
+                                                     int N, int groups, int n_split) {
+  constexpr int P = DIM / 4;
+  constexpr int PAIRS = (DIM + 1) * DIM;
+  extern __shared__ float skv[];  // [groups][PAIRS]
+  for (int i = threadIdx.x; i < groups * PAIRS; i += 256) skv[i] = 0.f;
+  __syncthreads();
+  const int tpt = groups * P, TL = 256 / tpt;
+  const int split = blockIdx.x % n_split;
+  const int64_t b = blockIdx.x / n_split;
+  const int tl = threadIdx.x / tpt, r = threadIdx.x - tl * tpt;
+  const int g = r / P, part = r - g * P;
+  const int per = (N + n_split - 1) / n_split;
+  const int n_begin = split * per, n_end = min(N, n_begin + per);
+  if (tl < TL) {
+    float acc[4][DIM], ksum[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+      ksum[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][j] = 0.f;
+    }
+    const T* base = ms + (b * N) * (int64_t)ld + g * 3 * DIM;
+#pragma unroll 2
+    for (int n = n_begin + tl; n < n_end; n += TL) {
+      const T* row = base + (int64_t)n * ld;
+      float k[DIM], v[4];
+#pragma unroll
+      for (int d0 = 0; d0 < DIM; d0 += VEC) Vec8<T>::load(row + DIM + d0, k + d0);
+      load4<T>(row + 2 * DIM + 4 * part, v);
+#pragma unroll
+      for (int j = 0; j < DIM; ++j) {
+        k[j] = k[j] > 0.f ? k[j] : 0.f;
+        ksum[j] += k[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = fmaf(v[i], k[j], acc[i][j]);
+      }
+    }
+    float* o = skv + g * PAIRS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < DIM; ++j) atomicAdd(&o[(4 * part + i) * DIM + j], acc[i][j]);
+    if (part == 0) {
+#pragma unroll
+      for (int j = 0; j < DIM; ++j) atomicAdd(&o[DIM * DIM + j], ksum[j]);
+    }
+  }
+  __syncthreads();
+  float* out = kv + b * groups * (int64_t)PAIRS;
+  for (int i = threadIdx.x; i < groups * PAIRS; i += 256) {
+    if (n_split == 1) out[i] = skv[i];
+    else unsafeAtomicAdd(out + i, skv[i]);
+  }
+}
+
+// out = (kv . relu(q)) / den.  kv sits in LDS as [pair/4][group][4] so that the 16-lane groups of
+// a ds_read_b128 (lanes = consecutive groups) touch distinct banks; every thread serves
+// `tokens_per_thread` tokens of its group to amortise the LDS fill.
+template <typename T, int DIM>
+__global__ __launch_bounds__(256) void mla_apply_kernel(const T* __restrict__ ms, int ld,
+                                                        const float* __restrict__ kv, T* __restrict__ out,
+                                                        int ld_out, int N, int groups, int tokens_per_thread) {
+  extern __shared__ float skv[];
   constexpr int PAIRS = (DIM + 1) * DIM;
   const int64_t b = blockIdx.y;
-  for (int i = threadIdx.x; i < groups * PAIRS; i += blockDim.x)
-    skv[i] = kv[b * groups * (int64_t)PAIRS + i];
+  for (int i = threadIdx.x; i < groups * PAIRS; i += blockDim.x) {
+    const int g = i / PAIRS, idx = i - g * PAIRS;
+    skv[((idx >> 2) * groups + g) * 4 + (idx & 3)] = kv[b * groups * (int64_t)PAIRS + i];
+  }
   __syncthreads();
   const int rows_per_block = blockDim.x / groups;
   const int rl = threadIdx.x / groups, g = threadIdx.x - rl * groups;
-  const int n = blockIdx.x * rows_per_block + rl;
-  if (n >= N || rl >= rows_per_block) return;
-  const T* qp = ms + (b * N + n) * (int64_t)ld + g * 3 * DIM;
-  float q[DIM];
+  const float4* kv4 = reinterpret_cast<const float4*>(skv) + g;
+  for (int it = 0; it < tokens_per_thread; ++it) {
+    const int n = (blockIdx.x * tokens_per_thread + it) * rows_per_block + rl;
+    if (n >= N) return;
+    const T* qp = ms + (b * N + n) * (int64_t)ld + g * 3 * DIM;
+    float q[DIM];
 #pragma unroll
-  for (int d0 = 0; d0 < DIM; d0 += VEC) {
-    Vec8<T>::load(qp + d0, q + d0);
+    for (int d0 = 0; d0 < DIM; d0 += VEC) {
+      Vec8<T>::load(qp + d0, q + d0);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) q[d0 + e] = q[d0 + e] > 0.f ? q[d0 + e] : 0.f;
-  }
-  const float* kvg = skv + g * PAIRS;
-  float den = 0.f;
-#pragma unroll
-  for (int dk = 0; dk < DIM; ++dk) den = fmaf(kvg[DIM * DIM + dk], q[dk], den);
-  const float inv = 1.f / (den + 1e-15f);
-  T* op = out + (b * N + n) * (int64_t)ld_out + g * DIM;
-#pragma unroll
-  for (int d0 = 0; d0 < DIM; d0 += VEC) {
-    float o[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float a = 0.f;
-#pragma unroll
-      for (int dk = 0; dk < DIM; ++dk) a = fmaf(kvg[(d0 + e) * DIM + dk], q[dk], a);
-      o[e] = a * inv;
+      for (int e = 0; e < VEC; ++e) q[d0 + e] = q[d0 + e] > 0.f ? q[d0 + e] : 0.f;
     }
-    Vec8<T>::store(op + d0, o);
+    float den = 0.f;
+#pragma unroll
+    for (int c = 0; c < DIM / 4; ++c) {
+      const float4 w = kv4[(DIM * DIM / 4 + c) * groups];
+      den = fmaf(w.x, q[4 * c], den);
+      den = fmaf(w.y, q[4 * c + 1], den);
+      den = fmaf(w.z, q[4 * c + 2], den);
+      den = fmaf(w.w, q[4 * c + 3], den);
+    }
+    const float inv = 1.f / (den + 1e-15f);
+    T* op = out + (b * N + n) * (int64_t)ld_out + g * DIM;
+#pragma unroll
+    for (int d0 = 0; d0 < DIM; d0 += VEC) {
+      float o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < DIM / 4; ++c) {
+          const float4 w = kv4[((d0 + e) * (DIM / 4) + c) * groups];
+          a = fmaf(w.x, q[4 * c], a);
+          a = fmaf(w.y, q[4 * c + 1], a);
+          a = fmaf(w.z, q[4 * c + 2], a);
+          a = fmaf(w.w, q[4 * c + 3], a);
+        }
+        o[e] = a * inv;
+      }
+      Vec8<T>::store(op + d0, o);
+    }
   }
 }
 
@@ -514,11 +691,24 @@ int esam3_launch_dwconv(int dtype, const void* in, int ld_in, const float* w, co
                                          (const T*)in, ld_in, w, bias, (T*)out, ld_out, H, W, C, OH, OW, \
                                          act, gx, gy));                                             \
   } while (0)
-  if (ksize == 3 && stride == 1) ESAM3_DW(3, 1, 2);
+#define ESAM3_DW3(ST, NP, R)                                                                        \
+  do {                                                                                              \
+    const unsigned gx = blocks_for((int64_t)((OW + NP - 1) / NP) * (C / VEC), 256);                 \
+    const int strips = (OH + R - 1) / R;                                                            \
+    const unsigned gy = (unsigned)(B * strips);                                                     \
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3_strip_kernel<T, ST, NP, R>), dim3(gx * gy), dim3(256), 0, \
+                                         s, (const T*)in, ld_in, w, bias, (T*)out, ld_out, H, W, C, OH,  \
+                                         OW, act, gx, gy, strips));                                 \
+  } while (0)
+  static const int no_strip = getenv("ESAM3_DW_NOSTRIP") ? atoi(getenv("ESAM3_DW_NOSTRIP")) : 0;
+  if (ksize == 3 && stride == 1 && !no_strip) ESAM3_DW3(1, 2, 8);
+  else if (ksize == 3 && !no_strip) ESAM3_DW3(2, 2, 4);
+  else if (ksize == 3 && stride == 1) ESAM3_DW(3, 1, 2);
   else if (ksize == 3) ESAM3_DW(3, 2, 2);
   else if (stride == 1) ESAM3_DW(5, 1, 2);
   else ESAM3_DW(5, 2, 1);
 #undef ESAM3_DW
+#undef ESAM3_DW3
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -537,19 +727,30 @@ template <typename T, int DIM>
 static int lite_mla_t(const void* ms, int ld, void* out, int ld_out, float* kv, int B, int N,
                       int groups, hipStream_t s) {
   constexpr int PAIRS = (DIM + 1) * DIM;
-  int n_split = 1;
-  while ((int64_t)B * groups * n_split < 512 && N / (n_split * 2) >= 256) n_split *= 2;
-  if (n_split > 1)
-    HIP_CHECK_RET(hipMemsetAsync(kv, 0, sizeof(float) * (size_t)B * groups * PAIRS, s));
-  hipLaunchKernelGGL((mla_kv_kernel<T, DIM>), dim3((unsigned)(B * groups * n_split)), dim3(256), 0, s,
-                     (const T*)ms, ld, kv, N, groups, n_split);
-  int threads = 256;
-  if (groups > threads) { esam3_set_error("lite_mla: groups=%d too large", groups); return -1; }
-  const int rpb = threads / groups;
-  threads = rpb * groups;
+  if (groups > 256) { esam3_set_error("lite_mla: groups=%d too large", groups); return -1; }
   const size_t lds = sizeof(float) * (size_t)groups * PAIRS;
-  hipLaunchKernelGGL((mla_apply_kernel<T, DIM>), dim3((unsigned)((N + rpb - 1) / rpb), (unsigned)B),
-                     dim3(threads), lds, s, (const T*)ms, ld, kv, (T*)out, ld_out, N, groups);
+  const int tpt = groups * (DIM / 4);
+  int n_split = 1;
+  if (tpt <= 256 && lds <= 64 * 1024) {
+    const int TL = 256 / tpt;
+    while ((int64_t)B * n_split < 1024 && N / (n_split * 2) >= 16 * TL) n_split *= 2;
+    if (n_split > 1)
+      HIP_CHECK_RET(hipMemsetAsync(kv, 0, sizeof(float) * (size_t)B * groups * PAIRS, s));
+    hipLaunchKernelGGL((mla_kv_kernel<T, DIM>), dim3((unsigned)(B * n_split)), dim3(256), lds, s,
+                       (const T*)ms, ld, kv, N, groups, n_split);
+  } else {
+    while ((int64_t)B * groups * n_split < 512 && N / (n_split * 2) >= 256) n_split *= 2;
+    if (n_split > 1)
+      HIP_CHECK_RET(hipMemsetAsync(kv, 0, sizeof(float) * (size_t)B * groups * PAIRS, s));
+    hipLaunchKernelGGL((mla_kv_generic_kernel<T, DIM>), dim3((unsigned)(B * groups * n_split)), dim3(256),
+                       0, s, (const T*)ms, ld, kv, N, groups, n_split);
+  }
+  const int rpb = 256 / groups;
+  const int threads = rpb * groups;
+  int tptok = 8;
+  while (tptok > 1 && (int64_t)B * ((N + rpb * tptok - 1) / (rpb * tptok)) < 1024) tptok /= 2;
+  hipLaunchKernelGGL((mla_apply_kernel<T, DIM>), dim3((unsigned)((N + rpb * tptok - 1) / (rpb * tptok)), (unsigned)B),
+                     dim3(threads), lds, s, (const T*)ms, ld, kv, (T*)out, ld_out, N, groups, tptok);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
