@@ -85,17 +85,14 @@ def main():
     import torch.distributed as dist
 
     from efficientsam3_amd import build_efficientsam3_image_model, schema, synth
+    from efficientsam3_amd import dist as esdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local_rank, world = esdist.env_ranks()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
+    esdist.init_process_group("nccl", dev)
 
     sd = schema.synthetic_state_dict("efficientvit", "b1", seed=0)
     model = build_efficientsam3_image_model(device=dev, enable_inst_interactivity=True,
@@ -115,16 +112,12 @@ def main():
     c_d = torch.from_numpy(coords).to(dev)
     l_d = torch.from_numpy(labs).to(dev)
     pi_d = torch.arange(B, dtype=torch.int32, device=dev)
-    gather_list = None
-    if world > 1 and rank == 0:
-        gather_list = [torch.empty((B, 1, 1008, 1008), dtype=torch.uint8, device=dev) for _ in range(world)]
-
     def step():
         out = eng.encode(x, want_sam3=not args.sam2_only, want_sam2=True)
         low, iou = eng.decode(out["sam2_fpn"], pi_d, c_d, l_d, multimask_output=False)
         masks = eng.postprocess(low, (1008, 1008), return_logits=False)
-        if world > 1:
-            dist.gather(masks, gather_list, dst=0)
+        if world > 1:  # the path's only exchange step: uint8 masks of every shard -> rank 0
+            esdist.gather_to_root(masks, n_items=world * B, dst=0)
         return masks, iou
 
     def sync():
@@ -173,7 +166,7 @@ def main():
             else:
                 roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": traffic}
-            roof.update(kernel="conv_gemm_kernel<bf16,128,128>", tag=dom["tag"], launches_per_step=dom["launches"] // args.steps,
+            roof.update(kernel=dom.get("kernel", dom["tag"]), tag=dom["tag"], launches_per_step=dom["launches"] // args.steps,
                         avg_launch_ms=round(avg_ms, 4), algorithmic_flops_per_launch=dom["flops"],
                         algorithmic_bytes_per_launch=dom["bytes"])
         gf_ref = sum(FLOPS_PER_IMAGE_G.values())  # reference layer list

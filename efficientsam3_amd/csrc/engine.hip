@@ -115,17 +115,19 @@ struct esam3_engine {
   hipStream_t st = nullptr;
 
   // ---------------- optional per-launch profiler (HIP events on the launch stream) --------
-  struct ProfRec { std::string tag; hipEvent_t a, b; double flops, bytes; };
+  struct ProfRec { std::string tag; hipEvent_t a, b; double flops, bytes; const char* kernel; };
   bool prof = false;
   std::vector<ProfRec> recs;
   int prof_launch(const std::string& tag, double flops, double bytes, const std::function<int()>& fn) {
     if (!prof) return fn();
-    ProfRec r{tag, nullptr, nullptr, flops, bytes};
+    ProfRec r{tag, nullptr, nullptr, flops, bytes, nullptr};
+    esam3_take_last_gemm_kernel();
     HIP_CHECK_RET(hipEventCreate(&r.a));
     HIP_CHECK_RET(hipEventCreate(&r.b));
     HIP_CHECK_RET(hipEventRecord(r.a, st));
     const int rc = fn();
     HIP_CHECK_RET(hipEventRecord(r.b, st));
+    r.kernel = esam3_take_last_gemm_kernel();
     recs.push_back(r);
     return rc;
   }
@@ -1172,13 +1174,13 @@ int esam3_profile_enable(esam3_engine* e, int on) {
 int esam3_profile_report(esam3_engine* e, char* buf, int64_t buf_size) {
   if (!e || !buf || buf_size <= 2) { esam3_set_error("esam3_profile_report: bad argument"); return -1; }
   HIP_CHECK_RET(hipDeviceSynchronize());
-  struct Agg { double ms = 0, flops = 0, bytes = 0; int n = 0; };
+  struct Agg { double ms = 0, flops = 0, bytes = 0; int n = 0; const char* kernel = nullptr; };
   std::unordered_map<std::string, Agg> agg;
   for (auto& r : e->recs) {
     float ms = 0.f;
     HIP_CHECK_RET(hipEventElapsedTime(&ms, r.a, r.b));
     Agg& a = agg[r.tag];
-    a.ms += ms; a.n += 1; a.flops = r.flops; a.bytes = r.bytes;
+    a.ms += ms; a.n += 1; a.flops = r.flops; a.bytes = r.bytes; a.kernel = r.kernel;
     hipEventDestroy(r.a); hipEventDestroy(r.b);
   }
   e->recs.clear();
@@ -1187,8 +1189,9 @@ int esam3_profile_report(esam3_engine* e, char* buf, int64_t buf_size) {
   std::string out = "[";
   for (size_t i = 0; i < v.size(); ++i) {
     char line[768];
-    snprintf(line, sizeof(line), "%s{\"tag\":\"%s\",\"launches\":%d,\"ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e}",
-             i ? "," : "", v[i].first.c_str(), v[i].second.n, v[i].second.ms, v[i].second.flops, v[i].second.bytes);
+    snprintf(line, sizeof(line), "%s{\"tag\":\"%s\",\"launches\":%d,\"ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e,\"kernel\":\"%s\"}",
+             i ? "," : "", v[i].first.c_str(), v[i].second.n, v[i].second.ms, v[i].second.flops, v[i].second.bytes,
+             v[i].second.kernel ? v[i].second.kernel : v[i].first.c_str());
     if ((int64_t)(out.size() + strlen(line) + 2) >= buf_size) break;
     out += line;
   }

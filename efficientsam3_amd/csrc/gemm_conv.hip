@@ -751,14 +751,23 @@ bool use_256(const GemmParams& p) {
   return true;
 }
 
+thread_local const char* g_last_kernel = nullptr;  // name of the kernel the last launch chose (profiler)
+
 template <typename T>
 int launch_gemm_t(const GemmParams& p, hipStream_t stream, int force_small) {
-  if (!force_small && use_256<T>(p)) return launch_256<T>(p, stream);
+  constexpr bool bf = sizeof(T) == 2;
+  if (!force_small && use_256<T>(p)) {
+    g_last_kernel = bf ? "gemm256_kernel<bf16> (256x256x64, 8 waves, glds double buffer, persistent)"
+                       : "gemm256_kernel<f32>";
+    return launch_256<T>(p, stream);
+  }
   if (!(force_small & 2)) {
     bool done = false;
     const int rc = try_thin<T>(p, stream, &done);
+    if (done) g_last_kernel = bf ? "thin_gemm_kernel<bf16> (LDS-free, weights in registers)" : "thin_gemm_kernel<f32>";
     if (done || rc) return rc;
   }
+  g_last_kernel = bf ? "conv_gemm_kernel<bf16> (128xBN, register-staged)" : "conv_gemm_kernel<f32>";
   if (p.N > 64) return launch_cfg<T, 128, 128, 2, 2>(p, stream);
   if (p.N > 32) return launch_cfg<T, 128, 64, 2, 2>(p, stream);
   return launch_cfg<T, 128, 32, 4, 1>(p, stream);
@@ -783,6 +792,12 @@ int esam3_conv_k_index(int cin, int ksize, int elem_size, int tap, int c) {
 int esam3_gemm_pad_k(int K, int elem_size) {
   const int bke = 128 / elem_size;
   return (K + bke - 1) / bke * bke;
+}
+
+const char* esam3_take_last_gemm_kernel() {
+  const char* k = g_last_kernel;
+  g_last_kernel = nullptr;
+  return k;
 }
 
 int esam3_launch_gemm(int dtype /*0 f32, 1 bf16*/, const GemmParams& p, hipStream_t stream) {

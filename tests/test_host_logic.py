@@ -1,0 +1,96 @@
+"""CPU: host-side logic of the drop-in (no GPU, no compute through the HIP library):
+prompt preparation, position encoding, checkpoint key remapping, schema, and the loud failure
+of the product path when no HIP device is present."""
+import numpy as np
+import pytest
+import torch
+
+from efficientsam3_amd import model_builder, schema, synth
+from efficientsam3_amd.sam3_image import Sam3Image, _sine_position_encoding
+from oracle import ref_model
+
+
+def test_sine_position_encoding_matches_oracle():
+    for h, w in ((72, 72), (144, 144), (5, 9)):
+        mine = _sine_position_encoding(h, w)
+        ref = ref_model.position_embedding_sine(h, w).reshape(256, h, w).numpy()
+        assert mine.shape == ref.shape == (256, h, w)
+        assert np.abs(mine - ref).max() <= 2e-6
+
+
+@pytest.mark.parametrize("orig_hw", [(1008, 1008), (600, 800)])
+def test_prep_prompts_follows_reference_rules(orig_hw):
+    """sam1_task_predictor.py:298-326 + sam1_utils.py:47-75: px -> /orig -> *1008; box corners get
+    labels 2,3 and are placed BEFORE the points."""
+    h, w = orig_hw
+    pts = np.array([[100.0, 50.0], [10.5, 20.25]], np.float32)
+    lab = np.array([1, 0])
+    box = np.array([30.0, 40.0, 300.0, 400.0], np.float32)
+    c, l = Sam3Image._prep_prompts(pts, lab, box, True, orig_hw)
+    assert c.shape == (1, 4, 2) and l.shape == (1, 4) and c.dtype == np.float32 and l.dtype == np.int32
+    s = np.array([1008.0 / w, 1008.0 / h], np.float32)
+    np.testing.assert_allclose(c[0, :2], box.reshape(2, 2) * s, rtol=1e-6)
+    np.testing.assert_allclose(c[0, 2:], pts * s, rtol=1e-6)
+    assert l.tolist() == [[2, 3, 1, 0]]
+    # K boxes -> Bp = K prompts, no points
+    boxes = np.array([[1, 2, 3, 4], [5, 6, 7, 8], [9, 10, 11, 12]], np.float32)
+    c, l = Sam3Image._prep_prompts(None, None, boxes, True, orig_hw)
+    assert c.shape == (3, 2, 2) and l.tolist() == [[2, 3]] * 3
+    # normalize_coords=False: coordinates are already in [0,1] and only scaled by 1008
+    c, l = Sam3Image._prep_prompts(np.array([[0.5, 0.25]]), np.array([1]), None, False, orig_hw)
+    np.testing.assert_allclose(c, [[[504.0, 252.0]]])
+    # nothing given
+    assert Sam3Image._prep_prompts(None, None, None, True, orig_hw) == (None, None)
+    with pytest.raises(AssertionError):
+        Sam3Image._prep_prompts(pts, None, None, True, orig_hw)
+    # the inputs are not modified in place
+    assert pts[0, 0] == 100.0 and box[0] == 30.0
+
+
+def test_checkpoint_key_remap():
+    """model_builder.py:584-630: 'detector.' and 'student_trunk.' are stripped; tracker.* is
+    duplicated under inst_interactive_predictor.model.* when interactivity is on."""
+    t = torch.zeros(1)
+    ck = {"model": {"detector.backbone.vision_backbone.trunk.model.student_trunk.backbone.x": t,
+                    "detector.backbone.vision_backbone.convs.0.conv_1x1.weight": t,
+                    "tracker.sam_mask_decoder.iou_token.weight": t}}
+    out = model_builder._clean_checkpoint_keys(ck, interactive=True)
+    assert "backbone.vision_backbone.trunk.model.backbone.x" in out
+    assert "backbone.vision_backbone.convs.0.conv_1x1.weight" in out
+    assert "inst_interactive_predictor.model.sam_mask_decoder.iou_token.weight" in out
+    out = model_builder._clean_checkpoint_keys(ck, interactive=False)
+    assert not any(k.startswith("inst_interactive_predictor") for k in out)
+
+
+def test_size_aliases_and_schema_names():
+    assert model_builder.SIZE_ALIASES["efficientvit"]["m"] == "b1"
+    assert model_builder.SIZE_ALIASES["repvit"]["m"] == "m1.1"
+    assert model_builder.SIZE_ALIASES["tinyvit"]["m"] == "11m"
+    sch = dict(schema.image_path_schema("efficientvit", "b1", True))
+    # a few names the reference's checkpoints carry (model_builder.py:764-787, necks.py:13-125)
+    for k in ("backbone.vision_backbone.trunk.model.head.0.weight",
+              "backbone.vision_backbone.sam2_convs.0.dconv_2x2_0.weight",
+              "inst_interactive_predictor.model.sam_mask_decoder.conv_s0.weight",
+              "inst_interactive_predictor.model.sam_prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"):
+        assert k in sch, k
+
+
+def test_synthetic_inputs_are_deterministic():
+    a, b = synth.smooth_image_u8(seed=3), synth.smooth_image_u8(seed=3)
+    assert a.dtype == np.uint8 and a.shape == (1008, 1008, 3) and np.array_equal(a, b)
+    x = synth.normalise_to_chw_f32(a)
+    assert x.shape == (3, 1008, 1008) and x.dtype == np.float32 and -1.0 <= x.min() and x.max() <= 1.0
+    p1, p2 = synth.prompts(4, seed=2), synth.prompts(4, seed=2)
+    assert all(np.array_equal(u, v) for u, v in zip(p1, p2))
+
+
+def test_product_path_fails_loudly_without_hip_device():
+    """No CPU fallback: on a box without a GPU building the model must raise, not degrade."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(Exception) as ei:
+        model_builder.build_efficientsam3_image_model(device="cuda", enable_inst_interactivity=True,
+                                                      backbone_type="efficientvit", model_name="b1")
+    assert not isinstance(ei.value, NotImplementedError)
+    with pytest.raises(RuntimeError):
+        model_builder.build_efficientsam3_image_model(device="cpu")
