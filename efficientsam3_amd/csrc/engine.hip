@@ -843,7 +843,6 @@ int E::precompute_pe() {
 
 // Prompt encoder + MaskDecoder.forward (sam1_task_predictor.py:385-421, mask_decoder.py:107-242)
 int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
-  if (pr->mask_input_dev) { esam3_set_error("mask_input prompts are not supported by this build yet"); return -1; }
   arena.top = 0;
   const int Bp = pr->n_prompts, Np = pr->n_points;
   const int pad = Np > 0 ? 1 : 0;  // _embed_points appends a pad point (prompt_encoder.py:84-88)
@@ -881,6 +880,7 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
       std::vector<float> cb(DM);
       for (int i = 0; i < DM; ++i) cb[i] = nm->d[i] + nk->d[i];
       fvec_raw("src_cbias", cb);
+      fvec_raw("src_cbias_nomask", nm->d);  // with a mask prompt the dense embedding replaces no_mask_embed
     } else {
       ot = it->second;
     }
@@ -896,10 +896,24 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
   // ---- src = image_embed[img] + no_mem_embed + dense(no_mask) ------------------------------
   void* keys = allocb((size_t)Bp * P * DM * esz);
   if (!ok(keys)) return -1;
+  void* dense = nullptr;
+  if (pr->mask_input_dev) {  // PromptEncoder._embed_masks (prompt_encoder.py:131-134)
+    dense = allocb((size_t)Bp * P * DM * esz);
+    if (!ok(dense)) return -1;
+    const std::string mp = PE + "mask_downscaling.";
+    const float* w[10] = {fvec(mp + "0.weight"), fvec(mp + "0.bias"), fvec(mp + "1.weight"), fvec(mp + "1.bias"),
+                          fvec(mp + "3.weight"), fvec(mp + "3.bias"), fvec(mp + "4.weight"), fvec(mp + "4.bias"),
+                          fvec(mp + "6.weight"), fvec(mp + "6.bias")};
+    for (const float* q : w) if (!q) return -1;
+    if (!dry)
+      CK(prof_launch("mask_embed", 0.0, 0.0, [&]() {
+        return esam3_launch_mask_embed(dtype, pr->mask_input_dev, w, dense, Bp, 4 * EMB, EMB, st);
+      }));
+  }
   if (!dry)
     CK(prof_launch("gather_add", (double)Bp * P * DM, 2.0 * (double)Bp * P * DM * (double)esz, [&]() {
-      return esam3_launch_gather_add(dtype, pr->sam2_fpn_dev[2], pr->prompt_image_dev, fbufs["src_cbias"], nullptr,
-                                     keys, Bp, P, DM, st);
+      return esam3_launch_gather_add(dtype, pr->sam2_fpn_dev[2], pr->prompt_image_dev,
+                                     fbufs[dense ? "src_cbias_nomask" : "src_cbias"], dense, keys, Bp, P, DM, st);
     }));
 
   // scratch
@@ -1154,6 +1168,14 @@ int esam3_postprocess_masks(esam3_engine* e, const float* low_res, int n, int oh
 int esam3_clamp_f32(esam3_engine* e, float* x, int64_t n, float lo, float hi, void* stream) {
   (void)e;
   return esam3_launch_clamp(x, n, lo, hi, (hipStream_t)stream);
+}
+
+int esam3_preprocess_resize_u8(const uint8_t* in, int H, int W, float* out, int out_h, int out_w, void* stream) {
+  if (!in || !out || H <= 0 || W <= 0 || out_h <= 0 || out_w <= 0) {
+    esam3_set_error("esam3_preprocess_resize_u8: bad argument");
+    return -1;
+  }
+  return esam3_launch_resize_aa_u8(in, H, W, out, out_h, out_w, (hipStream_t)stream);
 }
 
 int esam3_preprocess_u8(const uint8_t* in, float* out, int B, int H, int W, void* stream) {

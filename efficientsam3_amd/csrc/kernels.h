@@ -63,6 +63,9 @@ int esam3_launch_build_tokens(int dtype, const float* out_tokens /*[6][256]*/,
                               void* tokens, int Bp, int Np, int pad, float img_size, hipStream_t s);
 
 // masks[bp][k][p] = sum_c hyper[bp][k][c] * up[bp][p][c]   (k < 4, c < 32), fp32 out.
+// w = {conv0.w, conv0.b, ln1.w, ln1.b, conv3.w, conv3.b, ln4.w, ln4.b, conv6.w, conv6.b} (device fp32)
+int esam3_launch_mask_embed(int dtype, const float* mask, const float* const* w, void* out, int Bp, int in_size,
+                            int emb_size, hipStream_t s);
 int esam3_launch_mask_product(int dtype, const void* hyper, int ld_h, const void* up, float* masks,
                               int Bp, int64_t P, int C, hipStream_t s);
 
@@ -95,6 +98,7 @@ int esam3_launch_nhwc_to_nchw_f32(int dtype, const void* in, float* out, int B, 
                                   hipStream_t s);
 // uint8 HWC -> fp32 NCHW, x/255 then (x-0.5)/0.5
 int esam3_launch_preprocess_u8(const uint8_t* in, float* out, int B, int H, int W, hipStream_t s);
+int esam3_launch_resize_aa_u8(const uint8_t* in, int H, int W, float* out, int OH, int OW, hipStream_t s);
 // zero the 1-pixel border of a [B][Hp][Wp][C] tensor (Hp = H+2, Wp = W+2)
 int esam3_launch_zero_border(int dtype, void* x, int B, int Hp, int Wp, int C, hipStream_t s);
 // fused MBConv (mbconv_fused.hip): returns LDS bytes needed, 0 if the shape is unsupported

@@ -619,6 +619,62 @@ __global__ void preprocess_u8_kernel(const uint8_t* __restrict__ in, float* __re
   }
 }
 
+// P1: uint8 HWC image of any size -> antialiased bilinear resize to (OH, OW) -> round to uint8
+// -> x/255 -> (x-0.5)/0.5, fp32 CHW.  The reference runs torchvision v2.Resize on a uint8 device
+// tensor (sam3_image_processor.py:24-31,57-58), which resizes in fp32 with the triangle filter of
+// torch's upsample_bilinear2d_aa (support = max(scale,1), taps normalised to sum 1), rounds half
+// to even and casts back to uint8.  One thread per output pixel; tap weights are recomputed per
+// thread (a 1024->1008 resize has 3x3 taps).
+__device__ __forceinline__ void aa_span(int i, int in_size, float scale, float support, int& lo, int& n,
+                                        float& lo_m_center) {
+  const float center = scale * ((float)i + 0.5f);
+  lo = max((int)(center - support + 0.5f), 0);
+  n = min((int)(center + support + 0.5f), in_size) - lo;
+  lo_m_center = (float)lo - center;
+}
+__device__ __forceinline__ float aa_tap(int j, float lo_m_center, float invscale) {
+  const float x = fabsf(((float)j + lo_m_center + 0.5f) * invscale);
+  return x < 1.f ? 1.f - x : 0.f;
+}
+__global__ __launch_bounds__(256) void resize_aa_u8_kernel(const uint8_t* __restrict__ in, int H, int W,
+                                                           float* __restrict__ out, int OH, int OW) {
+#pragma clang fp contract(off)  // separate multiply and add like the upstream kernel: results land on
+                                // .5 rounding ties often enough (uint8 inputs) for an fma to show
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y;
+  if (ox >= OW) return;
+  const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+  const float sup_y = sy >= 1.f ? sy : 1.f, sup_x = sx >= 1.f ? sx : 1.f;
+  const float inv_y = sy >= 1.f ? 1.f / sy : 1.f, inv_x = sx >= 1.f ? 1.f / sx : 1.f;
+  int y0, ny, x0, nx;
+  float ym, xm;
+  aa_span(oy, H, sy, sup_y, y0, ny, ym);
+  aa_span(ox, W, sx, sup_x, x0, nx, xm);
+  float ty = 0.f, tx = 0.f;
+  for (int j = 0; j < ny; ++j) ty += aa_tap(j, ym, inv_y);
+  for (int j = 0; j < nx; ++j) tx += aa_tap(j, xm, inv_x);
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int jy = 0; jy < ny; ++jy) {
+    float wy = aa_tap(jy, ym, inv_y);
+    if (ty != 0.f) wy /= ty;
+    const uint8_t* row = in + ((int64_t)(y0 + jy) * W + x0) * 3;
+    float r[3] = {0.f, 0.f, 0.f};
+    for (int jx = 0; jx < nx; ++jx) {
+      float wx = aa_tap(jx, xm, inv_x);
+      if (tx != 0.f) wx /= tx;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) r[c] += (float)row[jx * 3 + c] * wx;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] += r[c] * wy;
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float q = fminf(fmaxf(rintf(acc[c]), 0.f), 255.f);  // back to uint8 (round half to even)
+    const float x = q / 255.0f;
+    out[((int64_t)c * OH + oy) * OW + ox] = (x - 0.5f) / 0.5f;
+  }
+}
+
 // border pixels of [B][Hp][Wp][C]: rows 0 and Hp-1, columns 0 and Wp-1; 16 bytes per thread
 __global__ void zero_border_kernel(char* __restrict__ x, int B, int Hp, int Wp, int row_bytes) {
   const int per_img = 2 * Wp + 2 * (Hp - 2);  // border pixels per image
@@ -654,6 +710,13 @@ int esam3_launch_zero_border(int dtype, void* x, int B, int Hp, int Wp, int C, h
 int esam3_launch_preprocess_u8(const uint8_t* in, float* out, int B, int H, int W, hipStream_t s) {
   const int64_t HW = (int64_t)H * W, total = HW * B;
   hipLaunchKernelGGL(preprocess_u8_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, in, out, HW, total);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_resize_aa_u8(const uint8_t* in, int H, int W, float* out, int OH, int OW, hipStream_t s) {
+  hipLaunchKernelGGL(resize_aa_u8_kernel, dim3(blocks_for(OW, 256), (unsigned)OH), dim3(256), 0, s, in, H, W, out,
+                     OH, OW);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -190,6 +190,98 @@ __global__ void build_tokens_kernel(const float* __restrict__ out_tokens, const 
 }
 
 // ------------------------------------------------------------------------------------
+// PromptEncoder._embed_masks (sam/prompt_encoder.py:51-59,131-134): mask_downscaling =
+// Conv k2s2 1->4, LayerNorm2d, GELU, Conv k2s2 4->16, LayerNorm2d, GELU, Conv 1x1 16->256 on a
+// [Bp,1,288,288] fp32 mask -> dense prompt embedding [Bp][72*72][256].  A workgroup serves 64
+// output pixels: 64 threads reduce their 4x4 input patch to the 16-vector, then all 256 threads
+// (one per output channel, its 16 weights in registers) expand it.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void mask_embed_kernel(const float* __restrict__ mask, const float* __restrict__ w0,
+                                                         const float* __restrict__ b0, const float* __restrict__ g1,
+                                                         const float* __restrict__ be1, const float* __restrict__ w3,
+                                                         const float* __restrict__ b3, const float* __restrict__ g4,
+                                                         const float* __restrict__ be4, const float* __restrict__ w6,
+                                                         const float* __restrict__ b6, T* __restrict__ out, int IN, int E) {
+  __shared__ float h[64][17];
+  const int64_t bp = blockIdx.y;
+  const int P = E * E;
+  const int p0 = blockIdx.x * 64;
+  if (threadIdx.x < 64) {
+    const int p = p0 + threadIdx.x;
+    float v16[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v16[i] = 0.f;
+    if (p < P) {
+      const int Y = p / E, X = p - Y * E;
+      const float* m = mask + (bp * IN + 4 * Y) * (int64_t)IN + 4 * X;
+      float c1[2][2][4];  // conv1 + LN + GELU at the 2x2 positions feeding this pixel
+#pragma unroll
+      for (int qy = 0; qy < 2; ++qy)
+#pragma unroll
+        for (int qx = 0; qx < 2; ++qx) {
+          float a[4], mean = 0.f;
+#pragma unroll
+          for (int co = 0; co < 4; ++co) {
+            float acc = b0[co];
+#pragma unroll
+            for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+              for (int kx = 0; kx < 2; ++kx)
+                acc = fmaf(w0[co * 4 + ky * 2 + kx], m[(2 * qy + ky) * IN + 2 * qx + kx], acc);
+            a[co] = acc;
+            mean += acc;
+          }
+          mean *= 0.25f;
+          float var = 0.f;
+#pragma unroll
+          for (int co = 0; co < 4; ++co) var += (a[co] - mean) * (a[co] - mean);
+          const float inv = 1.f / sqrtf(var * 0.25f + 1e-6f);
+#pragma unroll
+          for (int co = 0; co < 4; ++co) c1[qy][qx][co] = gelu_erf(g1[co] * ((a[co] - mean) * inv) + be1[co]);
+        }
+      float mean = 0.f;
+#pragma unroll
+      for (int co = 0; co < 16; ++co) {
+        float acc = b3[co];
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+          for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 2; ++kx) acc = fmaf(w3[((co * 4 + ci) * 2 + ky) * 2 + kx], c1[ky][kx][ci], acc);
+        v16[co] = acc;
+        mean += acc;
+      }
+      mean *= (1.f / 16.f);
+      float var = 0.f;
+#pragma unroll
+      for (int co = 0; co < 16; ++co) var += (v16[co] - mean) * (v16[co] - mean);
+      const float inv = 1.f / sqrtf(var * (1.f / 16.f) + 1e-6f);
+#pragma unroll
+      for (int co = 0; co < 16; ++co) v16[co] = gelu_erf(g4[co] * ((v16[co] - mean) * inv) + be4[co]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) h[threadIdx.x][i] = v16[i];
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  float w[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) w[k] = w6[c * 16 + k];
+  const float bias = b6[c];
+  const int n = min(64, P - p0);
+  for (int j = 0; j < n; ++j) {
+    float acc = bias;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = fmaf(w[k], h[j][k], acc);
+    out[(bp * P + p0 + j) * 256 + c] = from_f32<T>(acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // masks[bp][k][p] = sum_c hyper[bp][k][c] * up[bp][p][c]   (mask_decoder.py:230-231)
 // ------------------------------------------------------------------------------------
 template <typename T, int C>
@@ -497,6 +589,16 @@ int esam3_launch_build_tokens(int dtype, const float* out_tokens, const float* c
   DISPATCH_T(dtype, hipLaunchKernelGGL(build_tokens_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0,
                                        s, out_tokens, coords, labels, gauss, point_emb, not_a_point,
                                        (T*)tokens, Bp, Np, pad, img_size));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_mask_embed(int dtype, const float* mask, const float* const* w, void* out, int Bp, int in_size,
+                            int emb_size, hipStream_t s) {
+  if (in_size != 4 * emb_size) { esam3_set_error("mask_embed: %d != 4*%d", in_size, emb_size); return -1; }
+  dim3 grid(blocks_for((int64_t)emb_size * emb_size, 64), (unsigned)Bp);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(mask_embed_kernel<T>, grid, dim3(256), 0, s, mask, w[0], w[1], w[2], w[3], w[4],
+                                       w[5], w[6], w[7], w[8], w[9], (T*)out, in_size, emb_size));
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

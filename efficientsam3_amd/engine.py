@@ -90,6 +90,16 @@ class HipEngine:
                    "esam3_preprocess_u8")
         return out
 
+    def preprocess_resize_u8(self, img_hwc_u8: torch.Tensor, out_chw: torch.Tensor) -> torch.Tensor:
+        """uint8 HWC image of any size -> out_chw [3,R,R] fp32 (antialiased resize + normalise)."""
+        assert img_hwc_u8.dtype == torch.uint8 and img_hwc_u8.dim() == 3 and img_hwc_u8.shape[-1] == 3
+        assert img_hwc_u8.is_cuda and img_hwc_u8.is_contiguous() and out_chw.is_contiguous()
+        assert out_chw.dtype == torch.float32 and out_chw.dim() == 3 and out_chw.shape[0] == 3
+        h, w = img_hwc_u8.shape[:2]
+        _lib.check(self.lib.esam3_preprocess_resize_u8(_ptr(img_hwc_u8), h, w, _ptr(out_chw), out_chw.shape[1],
+                                                       out_chw.shape[2], _stream()), "esam3_preprocess_resize_u8")
+        return out_chw
+
     def encode(self, img_nchw: torch.Tensor, want_sam3: bool = True, want_sam2: bool = True,
                want_trunk: bool = False, want_stages: bool = False) -> dict:
         """img_nchw: [B,3,1008,1008] fp32 normalised, on this engine's device."""
@@ -129,10 +139,19 @@ class HipEngine:
 
     # ---- prompt decode -----------------------------------------------------------------------
     def decode(self, sam2_fpn: Sequence[torch.Tensor], prompt_image: torch.Tensor, coords: torch.Tensor,
-               labels: torch.Tensor, multimask_output: bool, want_obj: bool = False):
-        """coords [Bp,Np,2] fp32 network pixels, labels [Bp,Np] int32, prompt_image [Bp] int32 (device).
+               labels: torch.Tensor, multimask_output: bool, want_obj: bool = False,
+               mask_input: Optional[torch.Tensor] = None):
+        """coords [Bp,Np,2] fp32 network pixels (or None: no point/box prompt), labels [Bp,Np] int32,
+        prompt_image [Bp] int32, mask_input optional [Bp,288,288] fp32 low-res logits (all on device).
         Returns (low_res [Bp,C,288,288] fp32 unclamped, iou [Bp,C] fp32[, obj [Bp]])."""
-        bp, npts = coords.shape[0], coords.shape[1]
+        bp = prompt_image.shape[0]
+        npts = 0 if coords is None else coords.shape[1]
+        if coords is not None:
+            assert coords.shape[0] == bp and coords.dtype == torch.float32 and coords.is_contiguous()
+            assert labels.shape == coords.shape[:2] and labels.dtype == torch.int32 and labels.is_contiguous()
+        if mask_input is not None:
+            assert mask_input.shape == (bp, LOW_RES, LOW_RES) and mask_input.dtype == torch.float32
+            assert mask_input.is_cuda and mask_input.is_contiguous()
         c = 3 if multimask_output else 1
         low = torch.empty((bp, c, LOW_RES, LOW_RES), dtype=torch.float32, device=self.device)
         iou = torch.empty((bp, c), dtype=torch.float32, device=self.device)
@@ -146,7 +165,7 @@ class HipEngine:
         pr.coords_dev = coords.data_ptr() if npts > 0 else None
         pr.labels_dev = labels.data_ptr() if npts > 0 else None
         pr.n_points = npts
-        pr.mask_input_dev = None
+        pr.mask_input_dev = mask_input.data_ptr() if mask_input is not None else None
         pr.multimask_output = int(bool(multimask_output))
         od = _lib.DecodeOut(low_res_dev=low.data_ptr(), iou_dev=iou.data_ptr(),
                             obj_score_dev=obj.data_ptr() if obj is not None else None)

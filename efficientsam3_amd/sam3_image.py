@@ -217,13 +217,36 @@ class Sam3Image:
                 coords, labels = bx, bl
         return coords, labels
 
-    def _decode(self, sam2_nhwc: Sequence[torch.Tensor], coords: np.ndarray, labels: np.ndarray,
-                prompt_image: np.ndarray, multimask_output: bool):
+    def _decode(self, sam2_nhwc: Sequence[torch.Tensor], coords: Optional[np.ndarray], labels: Optional[np.ndarray],
+                prompt_image: np.ndarray, multimask_output: bool, mask_input: Optional[np.ndarray] = None):
         dev = self.device
-        c = torch.from_numpy(np.ascontiguousarray(coords, dtype=np.float32)).to(dev)
-        l = torch.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)).to(dev)
+        c = l = m = None
+        if coords is not None:
+            c = torch.from_numpy(np.ascontiguousarray(coords, dtype=np.float32)).to(dev)
+            l = torch.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)).to(dev)
+        if mask_input is not None:
+            m = torch.from_numpy(np.ascontiguousarray(mask_input, dtype=np.float32)).to(dev)
         pi = torch.from_numpy(np.ascontiguousarray(prompt_image, dtype=np.int32)).to(dev)
-        return self.engine.decode(sam2_nhwc, pi, c, l, multimask_output)
+        return self.engine.decode(sam2_nhwc, pi, c, l, multimask_output, mask_input=m)
+
+    @staticmethod
+    def _prep_mask_input(mask_input, bp: Optional[int]) -> Tuple[Optional[np.ndarray], int]:
+        """mask_input [1,288,288] (or [Bp,1,288,288], sam1_task_predictor.py:327-333) -> [Bp,288,288].
+        Without point/box prompts the batch is the mask's own (1 for the documented [1,H,W] form)."""
+        if mask_input is None:
+            return None, (1 if bp is None else bp)
+        m = np.asarray(mask_input, dtype=np.float32)
+        if m.ndim == 3:
+            m = m[None]
+        assert m.ndim == 4 and m.shape[1] == 1 and m.shape[-2:] == (LOW_RES, LOW_RES), \
+            f"mask_input must be [1,{LOW_RES},{LOW_RES}] low-res logits, got {m.shape}"
+        m = m[:, 0]
+        if bp is None:
+            bp = m.shape[0]
+        if m.shape[0] == 1 and bp > 1:  # one mask shared by all prompt sets (broadcast in mask_decoder.py:196-197)
+            m = np.repeat(m, bp, axis=0)
+        assert m.shape[0] == bp, f"mask_input batch {m.shape[0]} != number of prompt sets {bp}"
+        return np.ascontiguousarray(m), bp
 
     def _check_state(self, inference_state):
         if self.inst_interactive_predictor is None:
@@ -240,14 +263,10 @@ class Sam3Image:
         (masks [C,H,W] float32 0/1 or logits, iou [C], low_res [C,288,288]); K boxes keep a
         leading K dimension."""
         sam2 = self._check_state(inference_state)
-        if mask_input is not None:
-            raise NotImplementedError("mask_input prompts are not supported by this build yet")
         h, w = inference_state["original_height"], inference_state["original_width"]
         coords, labels = self._prep_prompts(point_coords, point_labels, box, normalize_coords, (h, w))
-        if coords is None:
-            raise NotImplementedError("predict_inst without point or box prompts is not supported yet")
-        bp = coords.shape[0]
-        low, iou = self._decode(sam2, coords, labels, np.zeros((bp,), np.int32), multimask_output)
+        mask, bp = self._prep_mask_input(mask_input, None if coords is None else coords.shape[0])
+        low, iou = self._decode(sam2, coords, labels, np.zeros((bp,), np.int32), multimask_output, mask)
         masks = self.engine.postprocess(low, (h, w), return_logits)
         self.engine.clamp_(low, -32.0, 32.0)
         masks_np = masks.squeeze(0).float().cpu().numpy()
@@ -260,8 +279,6 @@ class Sam3Image:
         prompt layout are decoded in ONE engine call instead of a Python loop with a D2H sync per
         image.  Returns three lists (masks, ious, low_res), one entry per image."""
         sam2 = self._check_state(inference_state)
-        if mask_input_batch is not None:
-            raise NotImplementedError("mask_input prompts are not supported by this build yet")
         hs, ws = inference_state["original_heights"], inference_state["original_widths"]
         n_img = sam2[2].shape[0]
         assert n_img == len(hs) == len(ws), \
@@ -272,21 +289,22 @@ class Sam3Image:
             pl = point_labels_batch[i] if point_labels_batch is not None else None
             bx = box_batch[i] if box_batch is not None else None
             c, l = self._prep_prompts(pc, pl, bx, normalize_coords, (hs[i], ws[i]))
-            if c is None:
-                raise NotImplementedError("predict_inst_batch needs a point or box prompt per image")
-            per.append((c, l))
-        # group images by prompt layout (Bp_i, Np)
-        groups: Dict[Tuple[int, int], List[int]] = {}
-        for i, (c, _) in enumerate(per):
-            groups.setdefault((c.shape[0], c.shape[1]), []).append(i)
+            mi = mask_input_batch[i] if mask_input_batch is not None else None
+            m, bpi = self._prep_mask_input(mi, None if c is None else c.shape[0])
+            per.append((c, l, m, bpi))
+        # group images by prompt layout (Bp_i, Np, has mask)
+        groups: Dict[Tuple[int, int, bool], List[int]] = {}
+        for i, (c, _, m, bpi) in enumerate(per):
+            groups.setdefault((bpi, 0 if c is None else c.shape[1], m is not None), []).append(i)
         masks_out: List[Optional[np.ndarray]] = [None] * n_img
         iou_out: List[Optional[np.ndarray]] = [None] * n_img
         low_out: List[Optional[np.ndarray]] = [None] * n_img
-        for (bpi, _), idxs in groups.items():
-            coords = np.concatenate([per[i][0] for i in idxs], axis=0)
-            labels = np.concatenate([per[i][1] for i in idxs], axis=0)
+        for (bpi, npts, has_mask), idxs in groups.items():
+            coords = np.concatenate([per[i][0] for i in idxs], axis=0) if npts else None
+            labels = np.concatenate([per[i][1] for i in idxs], axis=0) if npts else None
+            mask = np.concatenate([per[i][2] for i in idxs], axis=0) if has_mask else None
             pimg = np.repeat(np.asarray(idxs, dtype=np.int32), bpi)
-            low, iou = self._decode(sam2, coords, labels, pimg, multimask_output)
+            low, iou = self._decode(sam2, coords, labels, pimg, multimask_output, mask)
             # post-process per distinct original size
             by_size: Dict[Tuple[int, int], List[int]] = {}
             for j, i in enumerate(idxs):

@@ -50,14 +50,24 @@ class Sam3Processor:
         return t.contiguous(), int(height), int(width)
 
     def _preprocess(self, hwc_u8_list: List[torch.Tensor]) -> torch.Tensor:
+        """The reference's transform (uint8 -> Resize(1008) -> float/255 -> Normalize(.5,.5)) on
+        the device; images already at the network resolution skip the resize exactly as
+        torchvision's Resize does."""
+        r = self.resolution
         for t in hwc_u8_list:
-            if tuple(t.shape[:2]) != (self.resolution, self.resolution):
-                raise NotImplementedError(
-                    f"input of size {tuple(t.shape[:2])}: the uint8 antialiased resize to "
-                    f"{self.resolution}x{self.resolution} (torchvision v2.Resize) is not built yet; "
-                    "pass images already at the network resolution")
-        batch = torch.stack([t.to(self.device) for t in hwc_u8_list], dim=0)
-        return self.model.engine.preprocess_u8(batch)
+            if t.dim() != 3 or t.shape[-1] != 3:
+                raise ValueError(f"expected an RGB image, got shape {tuple(t.shape)}")
+        if all(tuple(t.shape[:2]) == (r, r) for t in hwc_u8_list):
+            batch = torch.stack([t.to(self.device) for t in hwc_u8_list], dim=0)
+            return self.model.engine.preprocess_u8(batch)
+        out = torch.empty((len(hwc_u8_list), 3, r, r), dtype=torch.float32, device=self.device)
+        for i, t in enumerate(hwc_u8_list):
+            t = t.to(self.device).contiguous()
+            if tuple(t.shape[:2]) == (r, r):
+                out[i] = self.model.engine.preprocess_u8(t[None])[0]
+            else:
+                self.model.engine.preprocess_resize_u8(t, out[i])
+        return out
 
     # ---- reference API ---------------------------------------------------------------------------
     @torch.inference_mode()

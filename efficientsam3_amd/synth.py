@@ -65,3 +65,15 @@ def prompts(batch: int, seed: int = 2, size: int = NET_RES):
     y1 = np.minimum(y0 + bh, size - 1)
     boxes = np.stack([x0, y0, x1, y1], axis=1).astype(np.float32)
     return pts, labels, boxes
+
+
+def mask_logits(seed: int = 4, size: int = 288) -> np.ndarray:
+    """[1,size,size] fp32 low-res mask logits for mask_input prompts: two soft blobs in [-6, 6]."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.arange(size, dtype=np.float64), np.arange(size, dtype=np.float64), indexing="ij")
+    out = np.full((size, size), -6.0)
+    for _ in range(2):
+        cx, cy = rng.uniform(0.25 * size, 0.75 * size, size=2)
+        r = rng.uniform(0.08 * size, 0.2 * size)
+        out = np.maximum(out, 6.0 - 12.0 * np.clip(np.hypot(xx - cx, yy - cy) / (2 * r), 0.0, 1.0))
+    return out[None].astype(np.float32)

@@ -99,6 +99,12 @@ int esam3_clamp_f32(esam3_engine* e, float* x_dev, int64_t n, float lo, float hi
  * uint8 HWC [B][H][W][3] -> fp32 NCHW [B][3][H][W], x/255 then (x-0.5)/0.5 */
 int esam3_preprocess_u8(const uint8_t* img_hwc_u8_dev, float* out_nchw_f32_dev, int B, int H, int W,
                         void* hip_stream);
+/* Sam3Processor.transform for an image of any size (sam3_image_processor.py:24-31,57-58:
+ * v2.Resize on a uint8 device tensor = fp32 antialiased bilinear (triangle filter, support
+ * max(scale,1)), round half to even, back to uint8; then /255 and (x-0.5)/0.5):
+ * uint8 HWC [H][W][3] -> fp32 CHW [3][out_h][out_w] */
+int esam3_preprocess_resize_u8(const uint8_t* img_hwc_u8_dev, int H, int W, float* out_chw_f32_dev,
+                               int out_h, int out_w, void* hip_stream);
 
 /* Per-launch timing with HIP events on the launch stream (bench.py roofline leg): enable,
  * run encode/decode, then fetch a JSON report (syncs the device, clears the records). */

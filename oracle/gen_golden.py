@@ -73,15 +73,54 @@ CASES = [
     dict(name="point_logits_orig480x640", hw=(480, 640),
          kw=dict(point_coords=[[320.0, 240.0]], point_labels=[1], multimask_output=False,
                  return_logits=True)),
+    # mask prompts (PromptEncoder._embed_masks) and the prompt-free call; "mask_input" names the
+    # seed of synth.mask_logits
+    dict(name="point_mask_input", hw=(1008, 1008),
+         kw=dict(point_coords=[[400.0, 520.0]], point_labels=[1], mask_input=4, multimask_output=False)),
+    dict(name="mask_input_only", hw=(1008, 1008), kw=dict(mask_input=5, multimask_output=True)),
+    dict(name="no_prompt", hw=(1008, 1008), kw=dict(multimask_output=True)),
+]
+
+# images that are NOT at the network resolution: Sam3Processor.transform resizes them (through the
+# torchvision shim, oracle/shims/torchvision/transforms/v2 -- that boundary is "parity unpinned")
+RESIZE_CASES = [
+    dict(name="resize_1024_point_box", size=(1024, 1024), seed=11,
+         kw=dict(point_coords=[[500.0, 520.0]], point_labels=[1], box=[200.0, 220.0, 800.0, 840.0],
+                 multimask_output=False)),
+    dict(name="resize_600x800_point", size=(600, 800), seed=12,
+         kw=dict(point_coords=[[420.0, 300.0]], point_labels=[1], multimask_output=True)),
 ]
 
 
 def np_kw(kw):
     out = {}
     for k, v in kw.items():
-        out[k] = np.asarray(v, dtype=np.float32 if k != "point_labels" else np.int32) \
-            if isinstance(v, list) else v
+        if k == "mask_input":
+            out[k] = synth.mask_logits(seed=v)
+        else:
+            out[k] = np.asarray(v, dtype=np.float32 if k != "point_labels" else np.int32) \
+                if isinstance(v, list) else v
     return out
+
+
+def compare_and_pack(masks_r, iou_r, low_r, masks_o, iou_o, low_o, return_logits):
+    e_low, e_iou = maxerr(low_r, low_o), maxerr(iou_r, iou_o)
+    e_mask = maxerr(masks_r, masks_o) if return_logits else float((masks_r != masks_o).mean())
+    inter = np.logical_and(masks_r > 0, masks_o > 0).sum()
+    union = np.logical_or(masks_r > 0, masks_o > 0).sum()
+    miou = float(inter / max(union, 1))
+    out = {"low_res": low_r.astype(np.float32), "iou": iou_r.astype(np.float32),
+           "mask_shape": np.asarray(masks_r.shape, dtype=np.int64)}
+    if return_logits:
+        out["mask_logits_sample"] = masks_r.reshape(-1)[::97].astype(np.float32)
+    out["mask_bits"] = np.packbits((masks_r > 0).reshape(-1))
+    return {"low_res": e_low, "iou": e_iou, "mask": e_mask, "mask_iou": miou}, out
+
+
+def resized_smooth_image(size, seed):
+    """HWC uint8 image of an arbitrary (h, w): a crop of a larger seeded smooth image."""
+    h, w = size
+    return np.ascontiguousarray(synth.smooth_image_u8(seed=seed, size=max(h, w))[:h, :w])
 
 
 def main():
@@ -169,32 +208,38 @@ def main():
             with torch.inference_mode():
                 masks_r, iou_r, low_r = model.predict_inst(state, **kw)
                 masks_o, iou_o, low_o = ref_model.predict_inst(sd, ostate, **kw)
-            e_low, e_iou = maxerr(low_r, low_o), maxerr(iou_r, iou_o)
-            if kw.get("return_logits"):
-                e_mask = maxerr(masks_r, masks_o)
-                inter = np.logical_and(masks_r > 0, masks_o > 0).sum()
-                union = np.logical_or(masks_r > 0, masks_o > 0).sum()
-            else:
-                e_mask = float((masks_r != masks_o).mean())
-                inter = np.logical_and(masks_r > 0, masks_o > 0).sum()
-                union = np.logical_or(masks_r > 0, masks_o > 0).sum()
-            miou = float(inter / max(union, 1))
-            manifest["oracle_vs_reference_maxabs"][f"case/{case['name']}"] = {
-                "low_res": e_low, "iou": e_iou, "mask": e_mask, "mask_iou": miou}
+            errs, out = compare_and_pack(masks_r, iou_r, low_r, masks_o, iou_o, low_o, kw.get("return_logits"))
+            manifest["oracle_vs_reference_maxabs"][f"case/{case['name']}"] = errs
             print(f"  case {case['name']:28s} low_res shape {low_r.shape} range "
-                  f"[{low_r.min():.2f},{low_r.max():.2f}] fg {float((masks_r > 0).mean()):.3f} "
-                  f"oracle-ref: low {e_low:.2e} iou {e_iou:.2e} mask {e_mask:.2e} IoU {miou:.6f}")
-            out = {"low_res": low_r.astype(np.float32), "iou": iou_r.astype(np.float32),
-                   "mask_shape": np.asarray(masks_r.shape, dtype=np.int64)}
-            if kw.get("return_logits"):
-                out["mask_logits_sample"] = masks_r.reshape(-1)[::97].astype(np.float32)
-            out["mask_bits"] = np.packbits((masks_r > 0).reshape(-1))
+                  f"[{low_r.min():.2f},{low_r.max():.2f}] fg {float((masks_r > 0).mean()):.3f} oracle-ref: {errs}")
             np.savez_compressed(os.path.join(GOLD, f"case_{case['name']}.npz"), **out)
             manifest["cases"][case["name"]] = {
                 "hw": [h, w],
                 "kw": {k: (v.tolist() if isinstance(v, np.ndarray) else v)
-                       for k, v in kw.items()},
+                       for k, v in case["kw"].items()},
             }
+
+    # ---- inputs that need the processor's resize ---------------------------------------
+    for case in RESIZE_CASES:
+        img = resized_smooth_image(case["size"], case["seed"])
+        chw_u8 = torch.from_numpy(np.ascontiguousarray(np.moveaxis(img, -1, 0)))
+        kw = np_kw(case["kw"])
+        with torch.inference_mode():
+            x_ref = proc.transform(chw_u8)                      # reference pipeline (shimmed torchvision)
+            x_or = ref_model.processor_transform(chw_u8)        # oracle restatement
+            state = proc.set_image(chw_u8)
+            ostate = ref_model.set_image(sd, x_or[None], tuple(case["size"]), "b1")
+            masks_r, iou_r, low_r = model.predict_inst(state, **kw)
+            masks_o, iou_o, low_o = ref_model.predict_inst(sd, ostate, **kw)
+        assert (state["original_height"], state["original_width"]) == tuple(case["size"])
+        errs, out = compare_and_pack(masks_r, iou_r, low_r, masks_o, iou_o, low_o, False)
+        errs["input"] = maxerr(x_ref, x_or)
+        out["input_sample"] = sample(x_ref)
+        manifest["oracle_vs_reference_maxabs"][f"case/{case['name']}"] = errs
+        print(f"  case {case['name']:28s} low_res shape {low_r.shape} oracle-ref: {errs}")
+        np.savez_compressed(os.path.join(GOLD, f"case_{case['name']}.npz"), **out)
+        manifest["cases"][case["name"]] = {"hw": list(case["size"]), "kw": case["kw"],
+                                           "image": {"kind": "smooth_crop", "seed": case["seed"]}}
 
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

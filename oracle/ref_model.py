@@ -433,6 +433,26 @@ def normalise_image_u8(img_chw_u8: torch.Tensor) -> torch.Tensor:
     return (x - 0.5) / 0.5
 
 
+def resize_u8_antialias(img_chw_u8: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    """torchvision v2.Resize on a uint8 tensor the way the reference uses it
+    (sam3_image_processor.py:27,57-58; torchvision is absent, so this restates the upstream tensor
+    kernel: same size -> identity; otherwise fp32 bilinear with antialias=True,
+    align_corners=False, round half to even, clamp, back to uint8).  PARITY UNPINNED: the
+    reference holds no fixture for this boundary."""
+    if tuple(img_chw_u8.shape[-2:]) == tuple(size):
+        return img_chw_u8
+    y = F.interpolate(img_chw_u8[None].to(torch.float32), size=tuple(size), mode="bilinear",
+                      align_corners=False, antialias=True)[0]
+    return y.round().clamp(0, 255).to(torch.uint8)
+
+
+def processor_transform(img_chw_u8: torch.Tensor) -> torch.Tensor:
+    """Sam3Processor.transform (sam3_image_processor.py:24-31): uint8 -> Resize(1008,1008) ->
+    float/255 -> Normalize(0.5, 0.5).  -> [3,1008,1008] fp32."""
+    assert img_chw_u8.dtype == torch.uint8 and img_chw_u8.dim() == 3
+    return normalise_image_u8(resize_u8_antialias(img_chw_u8, (IMG, IMG)))
+
+
 def set_image(sd: SD, img: torch.Tensor, orig_hw: Tuple[int, int], model_name: str = "b1",
               taps: Optional[dict] = None) -> dict:
     """img: [B,3,1008,1008] fp32 normalised (B=1 for set_image)."""

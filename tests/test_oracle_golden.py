@@ -10,6 +10,7 @@ import torch
 
 from efficientsam3_amd import synth
 from oracle import ref_model
+from tests import util as U
 
 SAMPLE = 4096
 
@@ -69,11 +70,17 @@ def test_oracle_cases_vs_golden(oracle_state, state_dict, golden_dir, manifest):
     st, _ = oracle_state
     for name, case in manifest["cases"].items():
         g = np.load(os.path.join(golden_dir, f"case_{name}.npz"))
-        st["original_height"], st["original_width"] = case["hw"]
-        kw = {k: (np.asarray(v, dtype=np.int32 if k == "point_labels" else np.float32)
-                  if isinstance(v, list) else v) for k, v in case["kw"].items()}
+        kw = U.case_kwargs(case)
+        own = U.case_image_chw_u8(case)
         with torch.inference_mode():
-            masks, iou, low = ref_model.predict_inst(state_dict, st, **kw)
+            if own is None:
+                st["original_height"], st["original_width"] = case["hw"]
+                cst = st
+            else:  # image that goes through the processor's antialiased resize
+                x = ref_model.processor_transform(own)
+                assert float(np.abs(_sample(x) - g["input_sample"]).max()) == 0.0, name
+                cst = ref_model.set_image(state_dict, x[None], tuple(case["hw"]), "b1")
+            masks, iou, low = ref_model.predict_inst(state_dict, cst, **kw)
         assert list(masks.shape) == list(g["mask_shape"])
         assert float(np.abs(low - g["low_res"]).max()) <= 1e-4, name
         assert float(np.abs(iou - g["iou"]).max()) <= 1e-5, name

@@ -49,3 +49,30 @@ def assert_close(got: torch.Tensor, ref: torch.Tensor, mode: str, what: str = ""
     bad = diff > bound
     assert not bad.any(), (f"{what} [{mode}]: {int(bad.sum())}/{bad.numel()} elements out of tolerance; "
                            f"max abs err {float(diff.max()):.3e}, ref max {float(ref.abs().max()):.3e}")
+
+
+# ---- golden prompt cases (tests/golden/manifest.json, written by oracle/gen_golden.py) ----------
+def case_kwargs(case):
+    """manifest 'kw' -> predict_inst keyword arguments ("mask_input" is a synth.mask_logits seed)."""
+    from efficientsam3_amd import synth
+    kw = {}
+    for k, v in case["kw"].items():
+        if k == "mask_input":
+            kw[k] = synth.mask_logits(seed=v)
+        elif isinstance(v, list):
+            kw[k] = np.asarray(v, dtype=np.int32 if k == "point_labels" else np.float32)
+        else:
+            kw[k] = v
+    return kw
+
+
+def case_image_chw_u8(case):
+    """None for cases on the shared 1008x1008 image 0; else the case's own CHW uint8 image."""
+    from efficientsam3_amd import synth
+    spec = case.get("image")
+    if spec is None:
+        return None
+    assert spec["kind"] == "smooth_crop"
+    h, w = case["hw"]
+    img = np.ascontiguousarray(synth.smooth_image_u8(seed=spec["seed"], size=max(h, w))[:h, :w])
+    return torch.from_numpy(np.ascontiguousarray(np.moveaxis(img, -1, 0)))
