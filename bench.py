@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backbone", default="efficientvit", help="student family (the headline metric is efficientvit/b1)")
+    ap.add_argument("--model", default="b1")
     ap.add_argument("--no-fuse", action="store_true",
                     help="run the reference's layer list without composing ConvT->1x1 / 3x3->conv_s0,s1")
     ap.add_argument("--sam2-only", action="store_true",
@@ -94,9 +96,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     esdist.init_process_group("nccl", dev)
 
-    sd = schema.synthetic_state_dict("efficientvit", "b1", seed=0)
+    sd = schema.synthetic_state_dict(args.backbone, args.model, seed=0)
     model = build_efficientsam3_image_model(device=dev, enable_inst_interactivity=True,
-                                            backbone_type="efficientvit", model_name="b1",
+                                            backbone_type=args.backbone, model_name=args.model,
                                             dtype=args.dtype, state_dict=sd, dual_neck=not args.sam2_only,
                                             fuse_linear_chains=not args.no_fuse)
     eng = model.engine
@@ -178,15 +180,16 @@ def main():
             t_ = p_["tag"]
             key = ("neck" if ".convs." in t_ or ".sam2_convs." in t_ or "conv_s0" in t_ or "conv_s1" in t_
                    else "head" if ".head." in t_
-                   else "backbone" if "trunk.model.backbone" in t_ or t_.startswith(("dwconv", "stem", "lite_mla", "grouped_pw", "resize", "mbconv_fused"))
+                   else "backbone" if "trunk.model.backbone" in t_ or t_.startswith(("dwconv", "stem", "lite_mla", "grouped_pw", "resize", "mbconv_fused", "squeeze_excite"))
                    else "decode+post")
             stage_ms[key] = stage_ms.get(key, 0.0) + p_["ms"] / args.steps
         out = {
-            "metric": "images/sec encode+decode @1024^2 (EV-M bf16)", "value": round(value, 2), "unit": "images/s",
+            "metric": "images/sec encode+decode @1024^2 (EV-M bf16)" if (args.backbone, args.model) == ("efficientvit", "b1")
+            else f"images/sec encode+decode @1024^2 ({args.backbone}-{args.model} {args.dtype})", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic (seeded images at the network's native 1008x1008, seeded realistic random-init weights)",
-            "config": {"workload": "EV-M (EfficientViT-B1) set_image_batch + predict_inst(point+box) per image, "
+            "config": {"workload": ("EV-M (EfficientViT-B1)" if args.backbone == "efficientvit" else f"{args.backbone}-{args.model}") + " set_image_batch + predict_inst(point+box) per image, "
                                    "batch=32 per GPU, full dual-neck graph" + (" [sam2-only variant]" if args.sam2_only else ""),
                        "global_batch": world * B, "resolution": 1008, "prompts_per_image": 1,
                        "parallelism": f"dp{world} (image shards, RCCL gather of uint8 masks)" if world > 1 else "single GPU",

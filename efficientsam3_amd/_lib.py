@@ -65,6 +65,8 @@ SIGNATURES = {
     "esam3_preprocess_resize_u8": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "esam3_op_linear": (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "esam3_op_conv2d": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "esam3_op_conv3x3_s2": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "esam3_op_squeeze_excite": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "esam3_op_conv3x3_padded": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_conv_transpose2x2": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_mbconv_fused": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -103,6 +103,8 @@ struct esam3_engine {
   size_t esz = 2;
   std::vector<int> widths, depths;
   int dim = 16;
+  struct RvBlock { int c, se, stride; };
+  std::vector<RvBlock> rv_cfg;  // RepViT block table (repvit.py:291-506)
   std::unordered_map<std::string, HostTensor> raw;
   std::unordered_map<std::string, PackedGemm> gemms;
   std::unordered_map<std::string, PackedDw> dws;
@@ -402,8 +404,9 @@ struct esam3_engine {
   // ---------------- launch helpers ----------------
   int gemm(const PackedGemm* g, const void* A, int lda, int64_t M, int H, int W, void* out, int ldc,
            int act, const void* res = nullptr, int ldr = 0, int res_after_act = 1, int res_mod = 0,
-           const int* res_bidx = nullptr, int in_pad = 0, int out_pad = 0) {
+           const int* res_bidx = nullptr, int in_pad = 0, int out_pad = 0, int stride = 1) {
     if (!g) return -1;
+    if (stride != 1 && (g->ksize != 3 || in_pad || out_pad)) { esam3_set_error("strided conv: only plain 3x3"); return -1; }
     if (in_pad && g->ksize != 3) { esam3_set_error("padded input given to a %dx%d conv", g->ksize, g->ksize); return -1; }
     if (dry) return 0;
     GemmParams p{};
@@ -418,6 +421,7 @@ struct esam3_engine {
     p.res_bidx = res_bidx;
     p.in_pad = in_pad;
     p.out_pad = out_pad;
+    p.stride = stride;
     const double uniq_in = (double)M * g->cin * (g->ksize == 3 ? 1 : 1);
     const double bytes = (uniq_in + (double)g->N * g->K + (double)M * g->N + (res ? (double)M * g->N : 0.0)) * (double)esz;
     return prof_launch(g->tag, 2.0 * (double)M * g->N * g->K, bytes, [&]() { return esam3_launch_gemm(dtype, p, st); });
@@ -493,6 +497,13 @@ struct esam3_engine {
   int mbconv(const std::string& p, const T4& x, int stride, bool residual, T4* y, const T4* dst = nullptr);
   int evit_block(const std::string& p, const T4& x, T4* y);
   int backbone(const float* img, int B, const esam3_image_features* out, T4* feat);
+  int stem(const std::string& wname, const std::string& bn, int cout, int act, const float* img, int B, T4* y);
+  int conv_bn(const std::string& p, const T4& x, int stride, int act, T4* y, const T4* res = nullptr, const T4* dst = nullptr);
+  int squeeze_excite(const std::string& p, T4& x);
+  PackedDw* pk_repvggdw(const std::string& q);
+  int repvit_block(const std::string& p, const T4& x, bool use_se, int stride, T4* y);
+  int backbone_repvit(const float* img, int B, const esam3_image_features* out, T4* feat);
+  int tap(const esam3_image_features* out, int i, const T4& t);
   int neck(const std::string& which, const T4& trunk, void* const outs[3], bool sam2);
   int encode(const float* img, int B, const esam3_image_features* out);
   int decode(const esam3_prompts* pr, const esam3_decode_out* out);
@@ -613,40 +624,164 @@ int E::evit_block(const std::string& p, const T4& x, T4* y) {
 }
 
 // EfficientViTBackbone.forward -> stage_final (backbone.py:150-156)
-int E::backbone(const float* img, int B, const esam3_image_features* out, T4* feat) {
-  auto tap = [&](int i, const T4& t) -> int {
-    if (out && out->stages_dev[i] && !dry)
-      HIP_CHECK_RET(hipMemcpyAsync(out->stages_dev[i], t.p, (size_t)t.rows() * t.C * esz,
-                                   hipMemcpyDeviceToDevice, st));
-    return 0;
-  };
-  // E0 stem: 3x3 s2 conv + BN + Hardswish, straight from the NCHW fp32 input
-  T4 x = alloc4(B, IMG / 2, IMG / 2, widths[0]);
-  if (!ok(x.p)) return -1;
-  {
-    const std::string p = EVBB + "input_stem.op_list.0";
-    const std::string key = p + ".stem_packed";
-    float *sw = nullptr, *sb = nullptr;
-    auto it = fbufs.find(key);
-    if (it == fbufs.end()) {
-      const HostTensor* w = need(p + ".conv.weight");
-      if (!w) return -1;
-      std::vector<float> scale, shift;
-      if (!bn_fold(p + ".norm", widths[0], scale, shift)) return -1;
-      std::vector<float> pk(27 * (size_t)widths[0]);
-      for (int co = 0; co < widths[0]; ++co)
-        for (int c = 0; c < 3; ++c)
-          for (int t = 0; t < 9; ++t)
-            pk[(size_t)(t * 3 + c) * widths[0] + co] = w->d[((size_t)co * 3 + c) * 9 + t] * scale[co];
-      sw = fvec_raw(key, pk);
-      sb = fvec_raw(key + ".bias", shift);
-    } else {
-      sw = it->second;
-      sb = fbufs[key + ".bias"];
-    }
-    if (!sw || !sb) return -1;
-    if (!dry) CK(prof_launch("stem", 0.0, 0.0, [&]() { return esam3_launch_stem(dtype, img, sw, sb, x.p, B, IMG, IMG, widths[0], ACT_HSWISH, st); }));
+int E::tap(const esam3_image_features* out, int i, const T4& t) {
+  if (out && out->stages_dev[i] && !dry)
+    HIP_CHECK_RET(hipMemcpyAsync(out->stages_dev[i], t.p, (size_t)t.rows() * t.C * esz, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+// 3x3 stride-2 pad-1 conv from the NCHW fp32 image (Cin = 3) + folded BN + activation -> NHWC
+int E::stem(const std::string& wname, const std::string& bn, int cout, int act, const float* img, int B, T4* y) {
+  *y = alloc4(B, IMG / 2, IMG / 2, cout);
+  if (!ok(y->p)) return -1;
+  const std::string key = wname + "#stem_packed";
+  float *sw = nullptr, *sb = nullptr;
+  auto it = fbufs.find(key);
+  if (it == fbufs.end()) {
+    const HostTensor* w = need(wname);
+    if (!w) return -1;
+    if ((int)w->shape[0] != cout || w->shape[1] != 3 || w->shape[2] != 3) { esam3_set_error("stem %s: unexpected shape", wname.c_str()); return -1; }
+    std::vector<float> scale, shift;
+    if (!bn_fold(bn, cout, scale, shift)) return -1;
+    std::vector<float> pk(27 * (size_t)cout);
+    for (int co = 0; co < cout; ++co)
+      for (int c = 0; c < 3; ++c)
+        for (int t = 0; t < 9; ++t)
+          pk[(size_t)(t * 3 + c) * cout + co] = w->d[((size_t)co * 3 + c) * 9 + t] * scale[co];
+    sw = fvec_raw(key, pk);
+    sb = fvec_raw(key + ".bias", shift);
+  } else {
+    sw = it->second;
+    sb = fbufs[key + ".bias"];
   }
+  if (!sw || !sb) return -1;
+  if (!dry) CK(prof_launch("stem", 0.0, 0.0, [&]() { return esam3_launch_stem(dtype, img, sw, sb, y->p, B, IMG, IMG, cout, act, st); }));
+  return 0;
+}
+
+// Conv2d_BN (repvit.py:29-37, tiny_vit.py:38-64): bias-free 1x1 / 3x3 conv `<p>.c` + BatchNorm `<p>.bn`
+int E::conv_bn(const std::string& p, const T4& x, int stride, int act, T4* y, const T4* res, const T4* dst) {
+  PackedGemm* g = pk_conv(p + ".c.weight", "", p + ".bn");
+  if (!g) return -1;
+  if (g->cin != x.C) { esam3_set_error("conv_bn %s: Cin %d != %d", p.c_str(), g->cin, x.C); return -1; }
+  if (dst) *y = *dst;
+  else *y = alloc4(x.B, (x.H + stride - 1) / stride, (x.W + stride - 1) / stride, g->N);
+  if (!ok(y->p)) return -1;
+  return gemm(g, x.p, x.ld, y->rows(), x.H, x.W, y->p, y->ld, act, res ? res->p : nullptr, res ? res->ld : 0, 1, 0,
+              nullptr, x.pad, 0, stride);
+}
+
+// timm SqueezeExcite, in place on x (`p` ends with '.')
+int E::squeeze_excite(const std::string& p, T4& x) {
+  const HostTensor* w1 = need(p + "fc1.weight");
+  if (!w1) return -1;
+  const int R = (int)w1->shape[0];
+  float *d1 = fvec(p + "fc1.weight"), *b1 = fvec(p + "fc1.bias"), *d2 = fvec(p + "fc2.weight"), *b2 = fvec(p + "fc2.bias");
+  if (!d1 || !b1 || !d2 || !b2) return -1;
+  const size_t mk = arena.mark();
+  float* sums = (float*)allocb(sizeof(float) * (size_t)x.B * x.C);
+  float* gate = (float*)allocb(sizeof(float) * (size_t)x.B * x.C);
+  if (!ok(sums) || !ok(gate)) return -1;
+  int rc = 0;
+  if (!dry)
+    rc = prof_launch("squeeze_excite", 0.0, 3.0 * (double)x.rows() * x.C * (double)esz, [&]() {
+      return esam3_launch_squeeze_excite(dtype, x.p, x.ld, sums, gate, d1, b1, d2, b2, x.B, x.H * x.W, x.C, R, st);
+    });
+  arena.release(mk);
+  return rc;
+}
+
+// RepVGGDW (repvit.py:84-123): bn(dw3x3_bn(x) + dw1x1(x) + x) is ONE depthwise 3x3 with bias -- the
+// reference's own fuse() algebra, evaluated in fp64 at load time.
+PackedDw* E::pk_repvggdw(const std::string& q) {
+  const std::string key = q + "#fused";
+  if (!find(key + ".weight")) {
+    const HostTensor *w = need(q + "conv.c.weight"), *w1 = need(q + "conv1.weight"), *b1 = need(q + "conv1.bias");
+    if (!w || !w1 || !b1) return nullptr;
+    const int C = (int)w->shape[0];
+    std::vector<float> s1, t1, s2, t2;
+    if (!bn_fold(q + "conv.bn", C, s1, t1) || !bn_fold(q + "bn", C, s2, t2)) return nullptr;
+    HostTensor fw, fb;
+    fw.shape = {C, 1, 3, 3};
+    fw.d.resize((size_t)C * 9);
+    fb.shape = {C};
+    fb.d.resize(C);
+    for (int c = 0; c < C; ++c) {
+      for (int t = 0; t < 9; ++t) {
+        double v = (double)w->d[(size_t)c * 9 + t] * s1[c];
+        if (t == 4) v += (double)w1->d[c] + 1.0;  // 1x1 branch and identity sit on the centre tap
+        fw.d[(size_t)c * 9 + t] = (float)(v * s2[c]);
+      }
+      // bn(y) = y*s2 + t2 with y's bias = t1 + b1
+      fb.d[c] = (float)(((double)t1[c] + b1->d[c]) * s2[c] + t2[c]);
+    }
+    raw[key + ".weight"] = std::move(fw);
+    raw[key + ".bias"] = std::move(fb);
+  }
+  return pk_dw(key + ".weight", key + ".bias", "");
+}
+
+// RepViTBlock (repvit.py:125-161): token mixer (RepVGGDW [+SE] | dw3x3 s2 + 1x1) then
+// Residual(1x1 C->2C, GELU, 1x1 2C->C) with the shortcut fused into the last GEMM's epilogue.
+int E::repvit_block(const std::string& p, const T4& x, bool use_se, int stride, T4* y) {
+  const HostTensor* ow = need(p + "channel_mixer.m.2.c.weight");
+  if (!ow) return -1;
+  const T4 dst = alloc4(x.B, (x.H + stride - 1) / stride, (x.W + stride - 1) / stride, (int)ow->shape[0]);
+  if (!ok(dst.p)) return -1;
+  const size_t mk = arena.mark();  // everything below is scratch of this block
+  T4 tm;
+  auto dw_launch = [&](PackedDw* d, const T4& in, int s_, T4* o) -> int {
+    if (!d) return -1;
+    *o = alloc4(in.B, (in.H + s_ - 1) / s_, (in.W + s_ - 1) / s_, in.C);
+    if (!ok(o->p)) return -1;
+    if (dry) return 0;
+    const double px_in = (double)in.rows() * in.C, px_out = (double)o->rows() * o->C;
+    return prof_launch("dwconv3s" + std::to_string(s_), 18.0 * px_out, (px_in + px_out) * (double)esz, [&]() {
+      return esam3_launch_dwconv(dtype, in.p, in.ld, d->w, d->bias, o->p, o->ld, in.B, in.H, in.W, in.C, 3, s_, ACT_NONE, st);
+    });
+  };
+  if (stride == 2) {
+    if (use_se) { esam3_set_error("RepViT: SE in a stride-2 block is not supported"); return -1; }
+    T4 d;
+    CK(dw_launch(pk_dw(p + "token_mixer.0.c.weight", "", p + "token_mixer.0.bn"), x, 2, &d));
+    CK(conv_bn(p + "token_mixer.2", d, 1, ACT_NONE, &tm));
+  } else {
+    CK(dw_launch(pk_repvggdw(p + "token_mixer.0."), x, 1, &tm));
+    if (use_se) CK(squeeze_excite(p + "token_mixer.1.", tm));
+  }
+  T4 h;
+  CK(conv_bn(p + "channel_mixer.m.0", tm, 1, ACT_GELU, &h));
+  CK(conv_bn(p + "channel_mixer.m.2", h, 1, ACT_NONE, y, &tm, &dst));
+  arena.release(mk);
+  return 0;
+}
+
+// RepViTTrunkWrapper.forward (model_builder.py:862-865): patch embed (2x Conv3x3 s2 + BN, GELU
+// between) then every block of model.features.
+int E::backbone_repvit(const float* img, int B, const esam3_image_features* out, T4* feat) {
+  const std::string p = EVBB + "features.";
+  const int c0 = rv_cfg[0].c;
+  T4 s1, x;
+  CK(stem(p + "0.0.c.weight", p + "0.0.bn", c0 / 2, ACT_GELU, img, B, &s1));
+  CK(conv_bn(p + "0.2", s1, 2, ACT_NONE, &x));
+  int stage = 0;
+  for (size_t i = 0; i < rv_cfg.size(); ++i) {
+    if (rv_cfg[i].stride == 2) CK(tap(out, stage++, x));
+    T4 y;
+    CK(repvit_block(p + std::to_string(i + 1) + ".", x, rv_cfg[i].se != 0, rv_cfg[i].stride, &y));
+    x = y;
+  }
+  CK(tap(out, stage, x));
+  *feat = x;
+  return 0;
+}
+
+int E::backbone(const float* img, int B, const esam3_image_features* out, T4* feat) {
+  if (cfg.backbone == ESAM3_BACKBONE_REPVIT) return backbone_repvit(img, B, out, feat);
+  auto tap = [&](int i, const T4& t) -> int { return this->tap(out, i, t); };
+  // E0 stem: 3x3 s2 conv + BN + Hardswish, straight from the NCHW fp32 input
+  T4 x;
+  CK(stem(EVBB + "input_stem.op_list.0.conv.weight", EVBB + "input_stem.op_list.0.norm", widths[0], ACT_HSWISH, img, B, &x));
   for (int i = 0; i < depths[0]; ++i) {  // Residual(DSConv)  ops.py:273-312
     const std::string p = EVBB + "input_stem.op_list." + std::to_string(i + 1) + ".main.";
     T4 y = alloc4(x.B, x.H, x.W, x.C);
@@ -1057,12 +1192,27 @@ int esam3_create(const esam3_config* cfg, esam3_engine** out) {
   }
   if (cfg->device < 0 || cfg->device >= ndev) { esam3_set_error("bad device ordinal %d", cfg->device); return -1; }
   HIP_CHECK_RET(hipSetDevice(cfg->device));
-  if (cfg->backbone != ESAM3_BACKBONE_EFFICIENTVIT) { esam3_set_error("unsupported backbone %d", cfg->backbone); return -1; }
+  if (cfg->backbone != ESAM3_BACKBONE_EFFICIENTVIT && cfg->backbone != ESAM3_BACKBONE_REPVIT) {
+    esam3_set_error("unsupported backbone %d", cfg->backbone);
+    return -1;
+  }
   esam3_engine* e = new esam3_engine();
   e->cfg = *cfg;
   e->dtype = cfg->dtype == ESAM3_F32 ? 0 : 1;
   e->esz = e->dtype == 0 ? 4 : 2;
   const std::string mn(cfg->model_name);
+  if (cfg->backbone == ESAM3_BACKBONE_REPVIT) {
+    // (channels, SE, stride) per block: repvit.py:320-350 (m0_9), :386-416 (m1_1)
+    auto stage = [&](int c, int n_s1, bool first_stage, int tail_plain) {
+      if (!first_stage) e->rv_cfg.push_back({c, 0, 2});
+      for (int i = 0; i < n_s1; ++i) e->rv_cfg.push_back({c, (i % 2 == 0 && i < n_s1 - tail_plain) ? 1 : 0, 1});
+    };
+    if (mn == "m1.1" || mn == "m1_1") { stage(64, 3, true, 1); stage(128, 3, false, 1); stage(256, 13, false, 1); stage(512, 2, false, 0); }
+    else if (mn == "m0.9" || mn == "m0_9") { stage(48, 3, true, 1); stage(96, 3, false, 1); stage(192, 15, false, 1); stage(384, 2, false, 0); }
+    else { esam3_set_error("unknown RepViT model '%s'", mn.c_str()); delete e; return -1; }
+    *out = e;
+    return 0;
+  }
   if (mn == "b0") { e->widths = {8, 16, 32, 64, 128}; e->depths = {1, 2, 2, 2, 2}; e->dim = 16; }
   else if (mn == "b1") { e->widths = {16, 32, 64, 128, 256}; e->depths = {1, 2, 3, 3, 4}; e->dim = 16; }
   else if (mn == "b2") { e->widths = {24, 48, 96, 192, 384}; e->depths = {1, 3, 4, 4, 6}; e->dim = 32; }

@@ -116,6 +116,7 @@ struct GemmParams {
   int korder;         // ksize 3: 0 -> k = tap*Cin + c ; 1 -> k = (c/BKE)*9*BKE + tap*BKE + c%BKE
                       // (channel-chunk major: the 9 taps of one 128-byte channel chunk are
                       //  consecutive K tiles, so shifted re-reads of the same pixels hit in L2)
+  int stride;         // ksize 3 only: 0/1 -> stride 1; 2 -> H, W are the INPUT dims, M = B*ceil(H/2)*ceil(W/2)
   int debug;          // development switches (ESAM3_GEMM_DEBUG): 1 skip epilogue, 2 skip DMA, 4 skip MFMA
 };
 

@@ -78,7 +78,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(GemmParams p) {
 
   int64_t a_off[A_ITERS];         // element offset of the window origin, or -1
   int a_oh[A_ITERS], a_ow[A_ITERS];
-  const int HW = p.H * p.W;
+  const int cs = p.stride > 1 ? p.stride : 1;                    // conv stride (3x3 only)
+  const int OWo = (p.W + cs - 1) / cs, HWo = ((p.H + cs - 1) / cs) * OWo;  // output grid
   const int Wp = p.W + 2 * p.in_pad;  // row pitch (pixels) of the input
 #pragma unroll
   for (int i = 0; i < A_ITERS; ++i) {
@@ -87,14 +88,15 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_gemm_kernel(GemmParams p) {
     a_ow[i] = 0;
     if (m < p.M) {
       if (p.ksize == 3) {
-        const unsigned b = (unsigned)m / (unsigned)HW;  // launcher guarantees M < 2^31
-        const unsigned rem = (unsigned)m - b * (unsigned)HW;
-        a_oh[i] = (int)(rem / (unsigned)p.W);
-        a_ow[i] = (int)rem - a_oh[i] * p.W;
+        const unsigned b = (unsigned)m / (unsigned)HWo;  // launcher guarantees M < 2^31
+        const unsigned rem = (unsigned)m - b * (unsigned)HWo;
+        const int oh = (int)(rem / (unsigned)OWo);
+        a_oh[i] = oh * cs;                       // input coordinates of the window centre
+        a_ow[i] = ((int)rem - oh * OWo) * cs;
         if (p.in_pad)  // origin = top-left pixel of the 3x3 window in the padded buffer
           a_off[i] = ((int64_t)(b * (unsigned)(p.H + 2) + a_oh[i]) * Wp + a_ow[i]) * p.lda;
         else           // origin = centre pixel
-          a_off[i] = m * (int64_t)p.lda;
+          a_off[i] = ((int64_t)(b * (unsigned)p.H + a_oh[i]) * p.W + a_ow[i]) * p.lda;
       } else {
         a_off[i] = m * (int64_t)p.lda;
       }
@@ -743,6 +745,7 @@ template <typename T>
 bool use_256(const GemmParams& p) {
   constexpr int BKE = 128 / (int)sizeof(T);
   if (p.M >= (int64_t)1 << 31) return false;
+  if (p.stride > 1) return false;
   if (p.N < 192 || p.N % 32 != 0 || p.M < 256 || p.K % BKE != 0 || p.K != p.Kp) return false;
   if (p.out_mode == OUT_CONVT2X2 && p.convt_cout % 32 != 0) return false;
   if ((p.ldc * (int)sizeof(T)) % 16 != 0 || (p.res && (p.ldr * (int)sizeof(T)) % 8 != 0)) return false;

@@ -98,6 +98,10 @@ int esam3_launch_nhwc_to_nchw_f32(int dtype, const void* in, float* out, int B, 
                                   hipStream_t s);
 // uint8 HWC -> fp32 NCHW, x/255 then (x-0.5)/0.5
 int esam3_launch_preprocess_u8(const uint8_t* in, float* out, int B, int H, int W, hipStream_t s);
+// in-place squeeze-excite on x [B][HW][C]; sums/gate: [B][C] fp32 scratch; w1 [R][C], w2 [C][R] (device fp32)
+int esam3_launch_squeeze_excite(int dtype, void* x, int ld, float* sums, float* gate, const float* w1,
+                                const float* b1, const float* w2, const float* b2, int B, int HW, int C, int R,
+                                hipStream_t s);
 int esam3_launch_resize_aa_u8(const uint8_t* in, int H, int W, float* out, int OH, int OW, hipStream_t s);
 // zero the 1-pixel border of a [B][Hp][Wp][C] tensor (Hp = H+2, Wp = W+2)
 int esam3_launch_zero_border(int dtype, void* x, int B, int Hp, int Wp, int C, hipStream_t s);

@@ -487,6 +487,82 @@ __global__ __launch_bounds__(256) void mla_apply_kernel(const T* __restrict__ ms
 }
 
 // ------------------------------------------------------------------------------------
+// Squeeze-Excite (timm SqueezeExcite as used by RepViT, repvit.py:136,150):
+//   gate[b][c] = sigmoid(W2 . relu(W1 . mean_hw(x[b]) + b1) + b2);  x *= gate
+// three small kernels: per-channel sums (atomics over pixel splits), the two tiny FCs (one
+// workgroup per image), and the in-place scaling.  fp32 statistics regardless of T.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void se_pool_kernel(const T* __restrict__ x, int ld, float* __restrict__ sums,
+                                                      int HW, int C, int splits) {
+  extern __shared__ float red[];  // [C]
+  const int CG = C / VEC;
+  const int b = blockIdx.x / splits, sp = blockIdx.x - b * splits;
+  for (int i = threadIdx.x; i < C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const int lanes = 256 / CG;  // pixel lanes (launcher guarantees CG <= 256)
+  const int pl = threadIdx.x / CG, cg = threadIdx.x - pl * CG;
+  if (pl < lanes) {
+    const int per = (HW + splits - 1) / splits;
+    const int p0 = sp * per, p1 = min(HW, p0 + per);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int p = p0 + pl; p < p1; p += lanes) {
+      float v[VEC];
+      Vec8<T>::load(x + ((int64_t)b * HW + p) * ld + cg * VEC, v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) atomicAdd(&red[cg * VEC + e], acc[e]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) unsafeAtomicAdd(sums + (int64_t)b * C + i, red[i]);
+}
+
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ sums, const float* __restrict__ w1,
+                                                    const float* __restrict__ b1, const float* __restrict__ w2,
+                                                    const float* __restrict__ b2, float* __restrict__ gate, int C,
+                                                    int R, float inv_hw) {
+  extern __shared__ float sm[];  // mean[C] | hidden[R]
+  float* mean = sm;
+  float* hid = sm + C;
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < C; i += 256) mean[i] = sums[(int64_t)b * C + i] * inv_hw;
+  __syncthreads();
+  for (int r = threadIdx.x; r < R; r += 256) {
+    float a = b1[r];
+    for (int c = 0; c < C; ++c) a = fmaf(w1[(int64_t)r * C + c], mean[c], a);
+    hid[r] = a > 0.f ? a : 0.f;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = b2[c];
+    for (int r = 0; r < R; ++r) a = fmaf(w2[(int64_t)c * R + r], hid[r], a);
+    gate[(int64_t)b * C + c] = 1.f / (1.f + expf(-a));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void se_scale_kernel(T* __restrict__ x, int ld, const float* __restrict__ gate,
+                                                       int HW, int C, int64_t total) {
+  const int CG = C / VEC;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // (b, pixel, channel group)
+  if (i >= total) return;
+  const int cg = (int)(i % CG);
+  const int64_t bp = i / CG;
+  const int64_t b = bp / HW;
+  float v[VEC];
+  T* px = x + bp * ld + cg * VEC;
+  Vec8<T>::load(px, v);
+  const float* g = gate + b * C + cg * VEC;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) v[e] *= g[e];
+  Vec8<T>::store(px, v);
+}
+
+// ------------------------------------------------------------------------------------
 // bilinear resize, align_corners=False (model_builder.py:779-786)
 // ------------------------------------------------------------------------------------
 template <typename T>
@@ -829,6 +905,24 @@ int esam3_launch_lite_mla(int dtype, const void* ms, int ld, void* out, int ld_o
   }
   esam3_set_error("lite_mla: dim=%d unsupported", dim);
   return -1;
+}
+
+int esam3_launch_squeeze_excite(int dtype, void* x, int ld, float* sums, float* gate, const float* w1,
+                                const float* b1, const float* w2, const float* b2, int B, int HW, int C, int R,
+                                hipStream_t s) {
+  if (C % VEC || C / VEC > 256 || C + R > 12288) { esam3_set_error("squeeze_excite: C=%d R=%d", C, R); return -1; }
+  HIP_CHECK_RET(hipMemsetAsync(sums, 0, sizeof(float) * (size_t)B * C, s));
+  int splits = 1;
+  while (B * splits < 1024 && HW / (splits * 2) >= 64) splits *= 2;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(se_pool_kernel<T>, dim3((unsigned)(B * splits)), dim3(256), sizeof(float) * C, s,
+                                       (const T*)x, ld, sums, HW, C, splits));
+  hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)B), dim3(256), sizeof(float) * (C + R), s, sums, w1, b1, w2, b2, gate,
+                     C, R, 1.0f / (float)HW);
+  const int64_t total = (int64_t)B * HW * (C / VEC);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(se_scale_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (T*)x, ld,
+                                       gate, HW, C, total));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
 }
 
 int esam3_launch_resize_bilinear(int dtype, const void* in, void* out, int B, int IH, int IW, int OH,

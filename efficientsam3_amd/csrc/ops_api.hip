@@ -85,6 +85,44 @@ int esam3_op_conv2d(int dtype, const void* x, const float* w, const float* bias,
   return 0;
 }
 
+int esam3_op_conv3x3_s2(int dtype, const void* x, const float* w, const float* bias, void* out, int B, int H, int W,
+                        int Cin, int Cout, int act, void* stream) {
+  Tmp t;
+  const int esz = dtype == 0 ? 4 : 2;
+  const int K = Cin * 9;
+  const int Kp = esam3_gemm_pad_k(K, esz), Np = esam3_gemm_pad_n(Cout);
+  std::vector<float> pk((size_t)Np * Kp, 0.f);
+  for (int n = 0; n < Cout; ++n)
+    for (int c = 0; c < Cin; ++c)
+      for (int tp = 0; tp < 9; ++tp) pk[(size_t)n * Kp + esam3_conv_k_index(Cin, 3, esz, tp, c)] = w[((size_t)n * Cin + c) * 9 + tp];
+  GemmParams p{};
+  p.A = x; p.Wt = t.upT(dtype, pk); p.bias = bias ? (float*)t.up(bias, (size_t)Cout * 4) : nullptr;
+  if (!p.Wt || (bias && !p.bias)) return fail("op_conv3x3_s2");
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  p.out = out; p.M = (int64_t)B * OH * OW; p.N = Cout; p.K = K; p.Kp = Kp; p.H = H; p.W = W;
+  p.Cin = Cin; p.ksize = 3; p.lda = Cin; p.ldc = Cout; p.ldr = Cout; p.act = act; p.res_after_act = 1;
+  p.korder = esam3_conv_korder(Cin, 3, esz);
+  p.stride = 2;
+  if (esam3_launch_gemm(dtype, p, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int esam3_op_squeeze_excite(int dtype, void* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                            int B, int HW, int C, int R, void* stream) {
+  Tmp t;
+  float* d1 = (float*)t.up(w1, (size_t)R * C * 4);
+  float* e1 = (float*)t.up(b1, (size_t)R * 4);
+  float* d2 = (float*)t.up(w2, (size_t)R * C * 4);
+  float* e2 = (float*)t.up(b2, (size_t)C * 4);
+  float* sums = (float*)t.raw((size_t)B * C * 4);
+  float* gate = (float*)t.raw((size_t)B * C * 4);
+  if (!d1 || !e1 || !d2 || !e2 || !sums || !gate) return fail("op_squeeze_excite");
+  if (esam3_launch_squeeze_excite(dtype, x, C, sums, gate, d1, e1, d2, e2, B, HW, C, R, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
 int esam3_op_conv3x3_padded(int dtype, const void* x_padded, const float* w, const float* bias, void* out, int B,
                             int H, int W, int Cin, int Cout, int act, int out_pad, void* stream) {
   Tmp t;

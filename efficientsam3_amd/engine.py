@@ -26,6 +26,19 @@ def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+BACKBONES = {"efficientvit": 0, "repvit": 1}  # ESAM3_BACKBONE_*
+
+
+def stage_shapes(backbone_type: str, model_name: str):
+    """(channels, spatial sizes) of the backbone's stage-boundary taps at 1008x1008 input."""
+    if backbone_type == "efficientvit":
+        return ({"b0": [8, 16, 32, 64, 128], "b1": [16, 32, 64, 128, 256],
+                 "b2": [24, 48, 96, 192, 384]}[model_name], [504, 252, 126, 63, 32])
+    if backbone_type == "repvit":
+        return ({"m0.9": [48, 96, 192, 384], "m1.1": [64, 128, 256, 512]}[model_name], [252, 126, 63, 32])
+    raise NotImplementedError(backbone_type)
+
+
 class HipEngine:
     """One engine per (device, activation dtype)."""
 
@@ -34,8 +47,9 @@ class HipEngine:
                  interactive: bool = True, fuse_linear_chains: bool = True):
         if not torch.cuda.is_available():
             raise _lib.Esam3Error("no HIP device visible: the EfficientSAM3 engine has no CPU path")
-        if backbone_type != "efficientvit":
+        if backbone_type not in BACKBONES:
             raise NotImplementedError(f"backbone_type={backbone_type!r} is not built yet")
+        model_name = model_name.replace("_", ".") if backbone_type == "repvit" else model_name
         self.lib = _lib.load()
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
@@ -47,7 +61,8 @@ class HipEngine:
         self.torch_dtype = torch.float32 if self.esam_dtype == _lib.ESAM3_F32 else torch.bfloat16
         self.interactive = interactive
         self.model_name = model_name
-        cfg = _lib.Config(dtype=self.esam_dtype, backbone=0, model_name=model_name.encode(),
+        self.backbone_type = backbone_type
+        cfg = _lib.Config(dtype=self.esam_dtype, backbone=BACKBONES[backbone_type], model_name=model_name.encode(),
                           device=self.dev_index, interactive=int(interactive),
                           fuse_linear_chains=int(fuse_linear_chains))
         h = C.c_void_p()
@@ -126,9 +141,7 @@ class HipEngine:
             out["trunk"] = buf(72, 1024)
             feats.trunk_dev = out["trunk"].data_ptr()
         if want_stages:
-            widths = {"b0": [8, 16, 32, 64, 128], "b1": [16, 32, 64, 128, 256],
-                      "b2": [24, 48, 96, 192, 384]}[self.model_name]
-            sizes = [504, 252, 126, 63, 32]
+            widths, sizes = stage_shapes(self.backbone_type, self.model_name)
             out["stages"] = [torch.empty((b, s, s, c), dtype=dt, device=dev) for s, c in zip(sizes, widths)]
             for i, t in enumerate(out["stages"]):
                 feats.stages_dev[i] = t.data_ptr()

@@ -42,6 +42,19 @@ EFFICIENTVIT_CFG = {
     "b2": ([24, 48, 96, 192, 384], [1, 3, 4, 4, 6], 32),
 }
 
+# RepViT: (k, t, c, use_se, use_hs, stride) per block (repvit.py:291-384,430-506)
+REPVIT_CFG = {
+    # explicit tables (k, t, c, SE, HS, s), repvit.py:320-350 (m0_9), :386-416 (m1_1), :470-506 (m2_3)
+    "m0.9": [(3, 2, 48, 1, 0, 1), (3, 2, 48, 0, 0, 1), (3, 2, 48, 0, 0, 1), (3, 2, 96, 0, 0, 2),
+             (3, 2, 96, 1, 0, 1), (3, 2, 96, 0, 0, 1), (3, 2, 96, 0, 0, 1), (3, 2, 192, 0, 1, 2)]
+            + [(3, 2, 192, 1 - (i % 2), 1, 1) for i in range(14)] + [(3, 2, 192, 0, 1, 1), (3, 2, 384, 0, 1, 2),
+                                                                      (3, 2, 384, 1, 1, 1), (3, 2, 384, 0, 1, 1)],
+    "m1.1": [(3, 2, 64, 1, 0, 1), (3, 2, 64, 0, 0, 1), (3, 2, 64, 0, 0, 1), (3, 2, 128, 0, 0, 2),
+             (3, 2, 128, 1, 0, 1), (3, 2, 128, 0, 0, 1), (3, 2, 128, 0, 0, 1), (3, 2, 256, 0, 1, 2)]
+            + [(3, 2, 256, 1 - (i % 2), 1, 1) for i in range(12)] + [(3, 2, 256, 0, 1, 1), (3, 2, 512, 0, 1, 2),
+                                                                      (3, 2, 512, 1, 1, 1), (3, 2, 512, 0, 1, 1)],
+}
+
 EMBED_DIM = 1024  # ImageStudentEncoder embed_dim (model_builder.py:913-919)
 D_MODEL = 256
 
@@ -128,6 +141,66 @@ def efficientvit_schema(model_name: str = "b1") -> _Schema:
             s.conv_layer(m + "inverted_conv", cin, mid, 1, bias=True, norm=False)
             s.conv_layer(m + "depth_conv", mid, mid, 3, groups=mid, bias=True, norm=False)
             s.conv_layer(m + "point_conv", mid, cin, 1)
+    return s
+
+
+def make_divisible(v, divisor=8, min_value=None, round_limit=0.9):
+    """timm.layers.make_divisible (SqueezeExcite uses round_limit=0.0)."""
+    min_value = min_value or divisor
+    new_v = max(min_value, int(v + divisor / 2) // divisor * divisor)
+    if new_v < round_limit * v:
+        new_v += divisor
+    return new_v
+
+
+def repvit_out_channels(model_name: str) -> int:
+    return REPVIT_CFG[model_name][-1][2]
+
+
+def repvit_schema(model_name: str = "m1.1") -> _Schema:
+    """RepViT feature trunk (repvit.py:29-47,84-161,232-252; classifier stripped by the builder,
+    model_builder.py:845-860).  Keys: <trunk>.backbone.model.features.{i}..."""
+    cfgs = REPVIT_CFG[model_name]
+    s = _Schema()
+    p = EV_BB + "features."
+
+    def conv_bn(name, cin, cout, k, groups=1):
+        s.conv(name + ".c", cout, cin, k, groups=groups)
+        s.bn(name + ".bn", cout)
+
+    c0 = cfgs[0][2]
+    conv_bn(p + "0.0", 3, c0 // 2, 3)
+    conv_bn(p + "0.2", c0 // 2, c0, 3)
+    cin = c0
+    for i, (k, t, c, use_se, use_hs, stride) in enumerate(cfgs, start=1):
+        q = p + f"{i}."
+        if stride == 2:
+            conv_bn(q + "token_mixer.0", cin, cin, k, groups=cin)
+            if use_se:
+                raise NotImplementedError("SE in a stride-2 RepViT block")
+            conv_bn(q + "token_mixer.2", cin, c, 1)
+        else:
+            assert cin == c
+            conv_bn(q + "token_mixer.0.conv", c, c, 3, groups=c)
+            s[q + "token_mixer.0.conv1.weight"] = ((c, 1, 1, 1), "dw1")
+            s[q + "token_mixer.0.conv1.bias"] = ((c,), "bias")
+            s[q + "token_mixer.0.bn.weight"] = ((c,), "bn_w_repdw")
+            s[q + "token_mixer.0.bn.bias"] = ((c,), "bn_b")
+            s[q + "token_mixer.0.bn.running_mean"] = ((c,), "bn_m")
+            s[q + "token_mixer.0.bn.running_var"] = ((c,), "bn_v")
+            s[q + "token_mixer.0.bn.num_batches_tracked"] = ((), "bn_n")
+            if use_se:
+                rd = make_divisible(c * 0.25, 8, round_limit=0.0)
+                s.conv(q + "token_mixer.1.fc1", rd, c, 1, bias=True)
+                s[q + "token_mixer.1.fc2.weight"] = ((c, rd, 1, 1), "conv")
+                s[q + "token_mixer.1.fc2.bias"] = ((c,), "se_bias")
+        conv_bn(q + "channel_mixer.m.0", c, 2 * c, 1)
+        s.conv(q + "channel_mixer.m.2.c", c, 2 * c, 1)
+        for suffix, kind in (("weight", "bn_w_res"), ("bias", "bn_b"), ("running_mean", "bn_m"),
+                             ("running_var", "bn_v")):
+            s[q + "channel_mixer.m.2.bn." + suffix] = ((c,), kind)
+        s[q + "channel_mixer.m.2.bn.num_batches_tracked"] = ((), "bn_n")
+        cin = c
     return s
 
 
@@ -219,12 +292,17 @@ def sam_heads_schema() -> _Schema:
 def image_path_schema(backbone_type: str = "efficientvit", model_name: str = "b1",
                       enable_inst_interactivity: bool = True) -> _Schema:
     """All tensors read by set_image + predict_inst for a student model."""
-    if backbone_type != "efficientvit":
-        raise NotImplementedError(
-            f"backbone_type={backbone_type!r}: only the EfficientViT family is built so far")
     s = _Schema()
-    s.update(efficientvit_schema(model_name))
-    s.update(student_head_schema(EFFICIENTVIT_CFG[model_name][0][-1]))
+    if backbone_type == "efficientvit":
+        s.update(efficientvit_schema(model_name))
+        s.update(student_head_schema(EFFICIENTVIT_CFG[model_name][0][-1]))
+    elif backbone_type == "repvit":
+        model_name = model_name.replace("_", ".")
+        s.update(repvit_schema(model_name))
+        s.update(student_head_schema(repvit_out_channels(model_name)))
+    else:
+        raise NotImplementedError(
+            f"backbone_type={backbone_type!r}: EfficientViT and RepViT students are built so far")
     s.update(neck_schema("convs"))
     if enable_inst_interactivity:
         s.update(neck_schema("sam2_convs"))
@@ -239,7 +317,8 @@ def image_path_schema(backbone_type: str = "efficientvit", model_name: str = "b1
 # Hardswish / GELU / ReLU get ~2/fan_in, linear layers 1/fan_in.  BatchNorms that close a
 # residual branch get a small gamma (as trained networks have) so that residual stacks do
 # not blow the activation scale up.
-_ACT_FOLLOWS = ("inverted_conv.conv", "depth_conv.conv", "input_stem.op_list.0.conv",
+_ACT_FOLLOWS = ("inverted_conv.conv", "depth_conv.conv", "input_stem.op_list.0.conv", "features.0.0.c",
+                "channel_mixer.m.0.c", "token_mixer.1.fc1",
                 "dconv_2x2_0", "output_upscaling.0", "output_upscaling.3", "mask_downscaling.0",
                 "mask_downscaling.3")
 
@@ -294,6 +373,14 @@ def init_state_dict(schema: _Schema, seed: int = 0) -> "OrderedDict[str, torch.T
             t = randn(shape) * 0.1
         elif kind == "bn_w":
             t = rand(shape, 0.25, 0.6) if _is_residual_branch_end(name) else rand(shape, 0.7, 1.3)
+        elif kind == "dw1":      # RepVGGDW's per-channel 1x1 branch next to the identity
+            t = randn(shape) * 0.3
+        elif kind == "bn_w_repdw":  # BN over (dw3x3 + dw1x1 + identity): ~2x the input variance comes in
+            t = rand(shape, 0.45, 0.72)
+        elif kind == "bn_w_res":    # last BN of a residual branch in a 24-block stack
+            t = rand(shape, 0.1, 0.25)
+        elif kind == "se_bias":     # gates mostly open, as in trained networks
+            t = randn(shape) * 0.3 + 2.0
         elif kind == "bn_b":
             t = randn(shape) * 0.1
         elif kind == "bn_m":

@@ -33,12 +33,12 @@ extern "C" {
 typedef struct esam3_engine esam3_engine;
 
 enum { ESAM3_F32 = 0, ESAM3_BF16 = 1 };
-enum { ESAM3_BACKBONE_EFFICIENTVIT = 0 };
+enum { ESAM3_BACKBONE_EFFICIENTVIT = 0, ESAM3_BACKBONE_REPVIT = 1 };
 
 typedef struct esam3_config {
   int dtype;            /* ESAM3_F32 (validation) or ESAM3_BF16 (throughput) activations */
   int backbone;         /* ESAM3_BACKBONE_* */
-  char model_name[16];  /* "b0" | "b1" | "b2" */
+  char model_name[16];  /* EfficientViT "b0" | "b1" | "b2"; RepViT "m0.9" | "m1.1" */
   int device;           /* HIP device ordinal */
   int interactive;      /* 1: sam2 neck + SAM heads are present (enable_inst_interactivity) */
   int fuse_linear_chains; /* 1: compose ConvT->1x1 and 3x3->conv_s0/s1 weight chains at finalize
@@ -49,7 +49,7 @@ typedef struct esam3_config {
  *   sam3_fpn: [B,288,288,256] [B,144,144,256] [B,72,72,256]   (all NULL -> sam3 neck not run)
  *   sam2_fpn: [B,288,288,32]  [B,144,144,64]  [B,72,72,256]   (after conv_s0 / conv_s1)
  *   trunk:    [B,72,72,1024]  ImageStudentEncoder output
- *   stages:   backbone stage0..stage4 outputs (validation taps) */
+ *   stages:   backbone stage outputs (validation taps): EfficientViT stage0..4, RepViT stage0..3 */
 typedef struct esam3_image_features {
   void* sam3_fpn_dev[3];
   void* sam2_fpn_dev[3];
@@ -129,6 +129,14 @@ int esam3_op_conv2d(int dtype, const void* x_dev, const float* w_host, const flo
 int esam3_op_conv3x3_padded(int dtype, const void* x_padded_dev, const float* w_host,
                             const float* bias_host, void* out_dev, int B, int H, int W, int Cin,
                             int Cout, int act, int out_pad, void* hip_stream);
+/* 3x3 stride-2 pad-1 conv, NHWC [B][H][W][Cin] -> [B][ceil(H/2)][ceil(W/2)][Cout]
+ * (RepViT / TinyViT patch embedding, repvit.py:241-242) */
+int esam3_op_conv3x3_s2(int dtype, const void* x_dev, const float* w_host, const float* bias_host,
+                        void* out_dev, int B, int H, int W, int Cin, int Cout, int act, void* hip_stream);
+/* timm SqueezeExcite in place on x [B][HW][C] (repvit.py:136,150): w1 [R][C], w2 [C][R] host fp32 */
+int esam3_op_squeeze_excite(int dtype, void* x_dev, const float* w1_host, const float* b1_host,
+                            const float* w2_host, const float* b2_host, int B, int HW, int C, int R,
+                            void* hip_stream);
 /* ConvTranspose2d k2 s2, NHWC; w_host is the PyTorch [Cin][Cout][2][2] fp32 weight */
 int esam3_op_conv_transpose2x2(int dtype, const void* x_dev, const float* w_host,
                                const float* bias_host, const void* res_dev, void* out_dev, int B,

@@ -4,7 +4,11 @@ REAL reference and generate the golden fixtures under ``tests/golden/``.
 Runs only in the build container, where ``/root/reference`` exists:
 
     PYTHONDONTWRITEBYTECODE=1 CUDA_VISIBLE_DEVICES="" HIP_VISIBLE_DEVICES="" \
-    PYTHONPATH=oracle/shims:/root/reference/sam3:. python oracle/gen_golden.py
+    PYTHONPATH=oracle/shims:/root/reference/sam3:. python oracle/gen_golden.py \
+        [--backbone efficientvit|repvit|tinyvit --model b1|m1.1|11m]
+
+The default (EfficientViT-B1) writes tests/golden/; other students write a reduced fixture set
+(one image, three prompt cases -- the decoder is shared) to tests/golden/<backbone>_<model>/.
 
 What it does
   1. builds the reference EV-M model (``build_efficientsam3_image_model``, CPU, fp32,
@@ -123,7 +127,38 @@ def resized_smooth_image(size, seed):
     return np.ascontiguousarray(synth.smooth_image_u8(seed=seed, size=max(h, w))[:h, :w])
 
 
+OTHER_STUDENT_CASES = ("point_multimask", "point_box_single", "two_boxes_batched")
+
+
+def reference_stage_taps(backbone_type, bb, x):
+    """Stage-boundary tensors of the REAL reference backbone (same names as the oracle's taps)."""
+    if backbone_type == "efficientvit":
+        out = bb.model(x)
+        return {f"stage{i}": out[f"stage{i}"] for i in range(5)}
+    if backbone_type == "repvit":  # features[] list; a stage ends before each stride-2 block
+        taps, stage = {}, 0
+        for i, f in enumerate(bb.model.features):
+            if i > 0 and getattr(f, "identity", True) is False:
+                taps[f"stage{stage}"] = x
+                stage += 1
+            x = f(x)
+        taps[f"stage{stage}"] = x
+        return taps
+    raise NotImplementedError(backbone_type)
+
+
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backbone", default="efficientvit")
+    ap.add_argument("--model", default="b1")
+    args = ap.parse_args()
+    global GOLD, CASES, RESIZE_CASES
+    default = (args.backbone, args.model) == ("efficientvit", "b1")
+    if not default:
+        GOLD = os.path.join(GOLD, f"{args.backbone}_{args.model}")
+        CASES = [c for c in CASES if c["name"] in OTHER_STUDENT_CASES]
+        RESIZE_CASES = []
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 8)
     os.makedirs(GOLD, exist_ok=True)
@@ -133,9 +168,9 @@ def main():
     t0 = time.time()
     model = build_efficientsam3_image_model(
         device="cpu", checkpoint_path=None, load_from_HF=False, enable_inst_interactivity=True,
-        backbone_type="efficientvit", model_name="b1", text_encoder_type="MobileCLIP-S0",
+        backbone_type=args.backbone, model_name=args.model, text_encoder_type="MobileCLIP-S0",
         text_encoder_context_length=16)
-    sd = schema.synthetic_state_dict("efficientvit", "b1", seed=0)
+    sd = schema.synthetic_state_dict(args.backbone, args.model, seed=0)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected[:5]
     print(f"reference built+loaded in {time.time() - t0:.1f}s; schema keys {len(sd)}; "
@@ -147,11 +182,13 @@ def main():
     for k, v in sd.items():
         digest.update(k.encode())
         digest.update(np.ascontiguousarray(v.numpy()).tobytes())
-    manifest = {"weights_sha256": digest.hexdigest(), "weights_seed": 0, "model": "efficientvit-b1", "cases": {}, "stages": {},
+    manifest = {"weights_sha256": digest.hexdigest(), "weights_seed": 0, "model": f"{args.backbone}-{args.model}",
+                "cases": {}, "stages": {},
                 "oracle_vs_reference_maxabs": {}}
 
     # ---- image 0: smooth synthetic, image 1: noise -------------------------------
-    imgs_u8 = [synth.smooth_image_u8(seed=1), synth.noise_image_u8(seed=3)]
+    imgs_u8 = [synth.smooth_image_u8(seed=1), synth.noise_image_u8(seed=3)][: 2 if default else 1]
+    bb = model.backbone.vision_backbone.trunk.model.backbone  # the family's TrunkWrapper
     for ii, img_u8 in enumerate(imgs_u8):
         chw_u8 = torch.from_numpy(np.ascontiguousarray(np.moveaxis(img_u8, -1, 0)))
         x = ref_model.normalise_image_u8(chw_u8)[None]
@@ -160,12 +197,12 @@ def main():
         # reference stage tensors
         with torch.inference_mode():
             t1 = time.time()
-            stages_ref = model.backbone.vision_backbone.trunk.model.backbone.model(x)
+            stages_ref = reference_stage_taps(args.backbone, bb, x)
             trunk_ref = model.backbone.vision_backbone.trunk(x)[0]
             state = proc.set_image(chw_u8)
             t_set = time.time() - t1
         bo = state["backbone_out"]
-        ref_t = {f"stage{i}": stages_ref[f"stage{i}"] for i in range(5)}
+        ref_t = dict(stages_ref)
         ref_t["trunk"] = trunk_ref
         for i in range(3):
             ref_t[f"sam3_fpn{i}"] = bo["backbone_fpn"][i]
@@ -176,10 +213,10 @@ def main():
         taps = {}
         with torch.inference_mode():
             t1 = time.time()
-            ostate = ref_model.set_image(sd, x, (1008, 1008), "b1", taps)
+            ostate = ref_model.set_image(sd, x, (1008, 1008), args.model, taps)
             t_or = time.time() - t1
         obo = ostate["backbone_out"]
-        or_t = {f"stage{i}": taps[f"stage{i}"] for i in range(5)}
+        or_t = {k: taps[k] for k in stages_ref}
         or_t["trunk"] = taps["trunk"]
         for i in range(3):
             or_t[f"sam3_fpn{i}"] = obo["backbone_fpn"][i]
@@ -228,7 +265,7 @@ def main():
             x_ref = proc.transform(chw_u8)                      # reference pipeline (shimmed torchvision)
             x_or = ref_model.processor_transform(chw_u8)        # oracle restatement
             state = proc.set_image(chw_u8)
-            ostate = ref_model.set_image(sd, x_or[None], tuple(case["size"]), "b1")
+            ostate = ref_model.set_image(sd, x_or[None], tuple(case["size"]), args.model)
             masks_r, iou_r, low_r = model.predict_inst(state, **kw)
             masks_o, iou_o, low_o = ref_model.predict_inst(sd, ostate, **kw)
         assert (state["original_height"], state["original_width"]) == tuple(case["size"])

@@ -138,6 +138,87 @@ def efficientvit_backbone(sd: SD, x: torch.Tensor, model_name: str = "b1",
     return x
 
 
+# --------------------------------------------------------------------------
+# RepViT (backbones/repvit.py)
+# --------------------------------------------------------------------------
+def _conv_bn(sd: SD, p: str, x: torch.Tensor, stride: int = 1, padding: int = 0,
+             groups: int = 1) -> torch.Tensor:
+    """Conv2d_BN (repvit.py:29-37): bias-free conv followed by BatchNorm2d (eval)."""
+    x = F.conv2d(x, sd[p + ".c.weight"], None, stride, padding, 1, groups)
+    return F.batch_norm(x, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"],
+                        sd[p + ".bn.weight"], sd[p + ".bn.bias"], False, 0.0, BN_EPS)
+
+
+def squeeze_excite(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """timm.layers.SqueezeExcite (timm >= 1.0.17, not vendored in the reference): global mean ->
+    1x1 fc1 -> ReLU -> 1x1 fc2 -> sigmoid gate (used at repvit.py:136,150)."""
+    g = x.mean((2, 3), keepdim=True)
+    g = F.relu(F.conv2d(g, sd[p + "fc1.weight"], sd[p + "fc1.bias"]))
+    g = F.conv2d(g, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
+    return x * torch.sigmoid(g)
+
+
+def repvit_block(sd: SD, p: str, x: torch.Tensor, cfg) -> torch.Tensor:
+    """RepViTBlock.forward (repvit.py:125-161), un-fused (training-time) parameterisation."""
+    k, _t, _c, use_se, _use_hs, stride = cfg
+    cin = x.shape[1]
+    if stride == 2:
+        x = _conv_bn(sd, p + "token_mixer.0", x, 2, (k - 1) // 2, groups=cin)
+        if use_se:
+            x = squeeze_excite(sd, p + "token_mixer.1.", x)
+        x = _conv_bn(sd, p + "token_mixer.2", x)
+    else:
+        q = p + "token_mixer.0."  # RepVGGDW (repvit.py:84-93)
+        y = (_conv_bn(sd, q + "conv", x, 1, 1, groups=cin)
+             + F.conv2d(x, sd[q + "conv1.weight"], sd[q + "conv1.bias"], groups=cin)) + x
+        x = F.batch_norm(y, sd[q + "bn.running_mean"], sd[q + "bn.running_var"], sd[q + "bn.weight"],
+                         sd[q + "bn.bias"], False, 0.0, BN_EPS)
+        if use_se:
+            x = squeeze_excite(sd, p + "token_mixer.1.", x)
+    m = F.gelu(_conv_bn(sd, p + "channel_mixer.m.0", x))
+    return x + _conv_bn(sd, p + "channel_mixer.m.2", m)
+
+
+def repvit_backbone(sd: SD, x: torch.Tensor, model_name: str = "m1.1",
+                    taps: Optional[dict] = None) -> torch.Tensor:
+    """RepViTTrunkWrapper.forward: all of model.features (model_builder.py:862-865, repvit.py:232-252)."""
+    from efficientsam3_amd.schema import REPVIT_CFG
+    cfgs = REPVIT_CFG[model_name.replace("_", ".")]
+    p = EV_BB + "features."
+    x = F.gelu(_conv_bn(sd, p + "0.0", x, 2, 1))
+    x = _conv_bn(sd, p + "0.2", x, 2, 1)
+    stage = 0
+    for i, cfg in enumerate(cfgs, start=1):
+        if cfg[5] == 2:
+            if taps is not None:
+                taps[f"stage{stage}"] = x
+            stage += 1
+        x = repvit_block(sd, p + f"{i}.", x, cfg)
+    if taps is not None:
+        taps[f"stage{stage}"] = x
+    return x
+
+
+def backbone_family(model_name: str) -> str:
+    """The reference's model names are disjoint across families (model_builder.py:807-890)."""
+    if model_name in EV_CFG:
+        return "efficientvit"
+    if model_name.startswith("m"):
+        return "repvit"
+    if model_name.endswith("m"):
+        return "tinyvit"
+    raise ValueError(model_name)
+
+
+def student_backbone(sd: SD, x: torch.Tensor, model_name: str, taps: Optional[dict] = None) -> torch.Tensor:
+    fam = backbone_family(model_name)
+    if fam == "efficientvit":
+        return efficientvit_backbone(sd, x, model_name, taps)
+    if fam == "repvit":
+        return repvit_backbone(sd, x, model_name, taps)
+    raise NotImplementedError(fam)
+
+
 def student_head(sd: SD, x: torch.Tensor) -> torch.Tensor:
     """ImageStudentEncoder.head + bilinear to 72x72 (model_builder.py:764-787)."""
     p = TRUNK + "head."
@@ -193,7 +274,7 @@ def forward_image(sd: SD, img: torch.Tensor, model_name: str = "b1",
     """SAM3VLBackbone.forward_image + the conv_s0/conv_s1 projection that
     Sam3Processor.set_image applies in place (vl_combiner.py:81-124,
     sam3_image_processor.py:62-75).  ``img``: [B,3,1008,1008] fp32 normalised."""
-    feat = efficientvit_backbone(sd, img, model_name, taps)
+    feat = student_backbone(sd, img, model_name, taps)
     if taps is not None:
         taps["stage_final"] = feat
     emb = student_head(sd, feat)

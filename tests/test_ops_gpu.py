@@ -77,6 +77,44 @@ def test_conv2d(mode, B, H, W, Cin, Cout, ks, act, res):
 
 
 @pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act", [
+    (2, 24, 24, 32, 64, None),   # RepViT / TinyViT patch-embed shape
+    (1, 17, 13, 16, 32, "gelu"),  # odd sizes: ceil(H/2) outputs, bottom/right windows clipped
+    (2, 10, 12, 64, 128, None), (1, 8, 8, 24, 48, None),
+])
+def test_conv3x3_stride2(mode, B, H, W, Cin, Cout, act):
+    d, tdt = U.DT[mode]
+    x = _rand(B, Cin, H, W, seed=1)
+    w = _rand(Cout, Cin, 3, 3, seed=2) / (Cin * 9) ** 0.5
+    b = _rand(Cout, seed=3) * 0.1
+    ref = F.conv2d(_q(x, mode), _q(w, mode), b, stride=2, padding=1)
+    ref = F.gelu(ref) if act == "gelu" else ref
+    x_d = U.to_dev_nhwc(x, tdt)
+    out = torch.empty((B, (H + 1) // 2, (W + 1) // 2, Cout), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_conv3x3_s2(d, U.P(x_d), U.H(U.np32(w)), U.H(U.np32(b)), U.P(out), B, H, W, Cin, Cout,
+                                        U.ACT[act], None), "op_conv3x3_s2")
+    U.assert_close(U.from_dev_nhwc(out), ref, mode, f"conv3x3 s2 {Cin}->{Cout}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("B,H,W,C,R", [(2, 63, 63, 256, 64), (3, 20, 31, 64, 16), (1, 32, 32, 512, 128), (2, 7, 5, 48, 16)])
+def test_squeeze_excite(mode, B, H, W, C, R):
+    d, tdt = U.DT[mode]
+    x = _rand(B, C, H, W, seed=1)
+    w1, b1 = _rand(R, C, seed=2) / C ** 0.5, _rand(R, seed=3) * 0.1
+    w2, b2 = _rand(C, R, seed=4) / R ** 0.5, _rand(C, seed=5) * 0.5
+    xq = _q(x, mode)
+    g = xq.mean((2, 3), keepdim=True)
+    g = F.relu(F.conv2d(g, w1[:, :, None, None], b1))
+    g = torch.sigmoid(F.conv2d(g, w2[:, :, None, None], b2))
+    ref = xq * g
+    x_d = U.to_dev_nhwc(x, tdt)
+    U.check(U.lib().esam3_op_squeeze_excite(d, U.P(x_d), U.H(U.np32(w1)), U.H(U.np32(b1)), U.H(U.np32(w2)),
+                                            U.H(U.np32(b2)), B, H * W, C, R, None), "op_squeeze_excite")
+    U.assert_close(U.from_dev_nhwc(x_d), ref, mode, f"squeeze-excite C={C}")
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout,out_pad", [
     (2, 24, 24, 256, 256, 0),   # 256x256 LDS-DMA kernel, M = 1152 (ragged last tile)
     (1, 16, 16, 1024, 1024, 0),  # head.3 shape (16x16 patch tiles)

@@ -1,0 +1,89 @@
+"""GPU parity of the other student backbones (RepViT-M1.1; the neck, SAM heads and
+post-processing are shared with EfficientViT) against fixtures produced by the REAL reference
+(tests/golden/<backbone>_<model>/, oracle/gen_golden.py --backbone ... --model ...).
+Tolerances as in test_e2e_gpu.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from efficientsam3_amd import Sam3Processor, build_efficientsam3_image_model, schema, synth  # noqa: E402
+from tests import util as U  # noqa: E402
+
+STUDENTS = [("repvit", "m1.1")]
+SAMPLE = 4096
+
+
+def _sample(t: torch.Tensor) -> np.ndarray:
+    flat = t.detach().float().cpu().contiguous().reshape(-1)
+    step = max(1, flat.numel() // SAMPLE)
+    return flat[::step][:SAMPLE].numpy()
+
+
+def _iou(a, b):
+    a, b = a > 0, b > 0
+    u = np.logical_or(a, b).sum()
+    return 1.0 if u == 0 else float(np.logical_and(a, b).sum() / u)
+
+
+@pytest.fixture(scope="module", params=STUDENTS, ids=lambda s: f"{s[0]}-{s[1]}")
+def student(request, golden_dir):
+    bt, mn = request.param
+    gdir = os.path.join(golden_dir, f"{bt}_{mn}")
+    with open(os.path.join(gdir, "manifest.json")) as f:
+        manifest = json.load(f)
+    sd = schema.synthetic_state_dict(bt, mn, seed=0)
+    models = {mode: build_efficientsam3_image_model(device="cuda", enable_inst_interactivity=True, backbone_type=bt,
+                                                    model_name=mn, dtype=mode, state_dict=sd)
+              for mode in ("f32", "bf16")}
+    return dict(bt=bt, mn=mn, gdir=gdir, manifest=manifest, models=models)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_student_stages_vs_golden(student, mode):
+    model = student["models"][mode]
+    gold = np.load(os.path.join(student["gdir"], "stages_img0.npz"))
+    img = synth.smooth_image_u8(seed=1)
+    x = model.engine.preprocess_u8(torch.from_numpy(img)[None].to("cuda"))
+    out = model.engine.encode(x, want_sam3=True, want_sam2=True, want_trunk=True, want_stages=True)
+    got = {f"stage{i}": t.permute(0, 3, 1, 2) for i, t in enumerate(out["stages"])}
+    got["trunk"] = out["trunk"].permute(0, 3, 1, 2)
+    for i in range(3):
+        got[f"sam3_fpn{i}"] = out["sam3_fpn"][i].permute(0, 3, 1, 2)
+        got[f"sam2_fpn{i}"] = out["sam2_fpn"][i].permute(0, 3, 1, 2)
+    assert all(f"stage{i}" in gold for i in range(len(out["stages"])))
+    atol = 1e-3 if mode == "f32" else 0.15
+    report = {k: float(np.abs(_sample(v) - gold[k]).max()) for k, v in got.items()}
+    bad = {k: e for k, e in report.items() if not (e <= atol)}
+    assert not bad, f"[{mode}] stage max-abs-err over {atol}: {bad}; all: {report}"
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_student_predict_inst_vs_golden(student, mode):
+    model = student["models"][mode]
+    proc = Sam3Processor(model)
+    img = synth.smooth_image_u8(seed=1)
+    state = proc.set_image(torch.from_numpy(np.ascontiguousarray(np.moveaxis(img, -1, 0))))
+    # bf16: same logit envelope as EfficientViT (<= 0.35 on a +-15 range); the mask-IoU floor is lower
+    # because these random-weight masks have long, speckled zero crossings (two_boxes_batched: 0.953)
+    lim = dict(f32=(1e-3, 1e-3, 0.999), bf16=(0.35, 0.03, 0.93))[mode]
+    failures = []
+    for name, case in student["manifest"]["cases"].items():
+        g = np.load(os.path.join(student["gdir"], f"case_{name}.npz"))
+        state["original_height"], state["original_width"] = case["hw"]
+        masks, iou, low = model.predict_inst(state, **U.case_kwargs(case))
+        assert list(masks.shape) == list(g["mask_shape"]) and low.shape == g["low_res"].shape
+        e_low = float(np.abs(low - g["low_res"]).max())
+        e_iou = float(np.abs(iou - g["iou"]).max())
+        ref_bits = np.unpackbits(g["mask_bits"])[: masks.size].reshape(masks.shape).astype(bool)
+        miou = _iou(masks, ref_bits)
+        print(f"[{student['bt']} {mode}] {name}: low_res err {e_low:.3e} iou err {e_iou:.3e} mask IoU {miou:.6f}")
+        for what, v, ok in (("low_res", e_low, e_low <= lim[0]), ("iou", e_iou, e_iou <= lim[1]),
+                            ("mask_iou", miou, miou >= lim[2])):
+            if not ok:
+                failures.append((name, what, v))
+    assert not failures, failures
