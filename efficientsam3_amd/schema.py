@@ -55,6 +55,13 @@ REPVIT_CFG = {
                                                                       (3, 2, 512, 1, 1, 1), (3, 2, 512, 0, 1, 1)],
 }
 
+TINYVIT_CFG = {
+    # name: (embed_dims, depths, num_heads, window_sizes)   tiny_vit.py:641-679; mlp_ratio 4, MBConv expand 4
+    "5m": ([64, 128, 160, 320], [2, 2, 6, 2], [2, 4, 5, 10], [7, 7, 14, 7]),
+    "11m": ([64, 128, 256, 448], [2, 2, 6, 2], [2, 4, 8, 14], [7, 7, 14, 7]),
+    "21m": ([96, 192, 384, 576], [2, 2, 6, 2], [3, 6, 12, 18], [7, 7, 14, 7]),
+}
+
 EMBED_DIM = 1024  # ImageStudentEncoder embed_dim (model_builder.py:913-919)
 D_MODEL = 256
 
@@ -204,6 +211,55 @@ def repvit_schema(model_name: str = "m1.1") -> _Schema:
     return s
 
 
+def tinyvit_schema(model_name: str = "11m") -> _Schema:
+    """TinyViT trunk built with img_size=1008, num_classes=0 (tiny_vit.py:67-154,196-386,453-536;
+    model_builder.py:869-905).  Keys: <trunk>.backbone.model.{patch_embed,layers.N}...  The
+    non-persistent attention_bias_idxs buffers are not part of the state dict."""
+    dims, depths, heads, windows = TINYVIT_CFG[model_name]
+    s = _Schema()
+    p = EV_BB
+
+    def conv_bn(name, cin, cout, k, groups=1, res_end=False):
+        s.conv(name + ".c", cout, cin, k, groups=groups)
+        if res_end:
+            for suffix, kind in (("weight", "bn_w_res"), ("bias", "bn_b"), ("running_mean", "bn_m"),
+                                 ("running_var", "bn_v")):
+                s[name + ".bn." + suffix] = ((cout,), kind)
+            s[name + ".bn.num_batches_tracked"] = ((), "bn_n")
+        else:
+            s.bn(name + ".bn", cout)
+
+    conv_bn(p + "patch_embed.seq.0", 3, dims[0] // 2, 3)
+    conv_bn(p + "patch_embed.seq.2", dims[0] // 2, dims[0], 3)
+    for li, (dim, depth) in enumerate(zip(dims, depths)):
+        q = p + f"layers.{li}."
+        for bi in range(depth):
+            b = q + f"blocks.{bi}."
+            if li == 0:  # MBConv
+                hid = int(dim * 4.0)
+                conv_bn(b + "conv1", dim, hid, 1)
+                conv_bn(b + "conv2", hid, hid, 3, groups=hid)
+                conv_bn(b + "conv3", hid, dim, 1, res_end=True)
+            else:        # TinyViTBlock
+                ws = windows[li]
+                s.ln(b + "attn.norm", dim)
+                s.linear(b + "attn.qkv", 3 * dim, dim)
+                s[b + "attn.proj.weight"] = ((dim, dim), "linear_res")
+                s[b + "attn.proj.bias"] = ((dim,), "bias")
+                s[b + "attn.attention_biases"] = ((heads[li], ws * ws), "attn_bias")
+                conv_bn(b + "local_conv", dim, dim, 3, groups=dim)
+                s.ln(b + "mlp.norm", dim)
+                s.linear(b + "mlp.fc1", 4 * dim, dim)
+                s[b + "mlp.fc2.weight"] = ((dim, 4 * dim), "linear_res")
+                s[b + "mlp.fc2.bias"] = ((dim,), "bias")
+        if li < len(dims) - 1:
+            out = dims[li + 1]
+            conv_bn(q + "downsample.conv1", dim, out, 1)
+            conv_bn(q + "downsample.conv2", out, out, 3, groups=out)
+            conv_bn(q + "downsample.conv3", out, out, 1)
+    return s
+
+
 def student_head_schema(c_backbone: int) -> _Schema:
     """ImageStudentEncoder.head (model_builder.py:770-775)."""
     s = _Schema()
@@ -300,9 +356,11 @@ def image_path_schema(backbone_type: str = "efficientvit", model_name: str = "b1
         model_name = model_name.replace("_", ".")
         s.update(repvit_schema(model_name))
         s.update(student_head_schema(repvit_out_channels(model_name)))
+    elif backbone_type == "tinyvit":
+        s.update(tinyvit_schema(model_name))
+        s.update(student_head_schema(TINYVIT_CFG[model_name][0][-1]))
     else:
-        raise NotImplementedError(
-            f"backbone_type={backbone_type!r}: EfficientViT and RepViT students are built so far")
+        raise NotImplementedError(f"backbone_type={backbone_type!r}")
     s.update(neck_schema("convs"))
     if enable_inst_interactivity:
         s.update(neck_schema("sam2_convs"))
@@ -318,7 +376,7 @@ def image_path_schema(backbone_type: str = "efficientvit", model_name: str = "b1
 # residual branch get a small gamma (as trained networks have) so that residual stacks do
 # not blow the activation scale up.
 _ACT_FOLLOWS = ("inverted_conv.conv", "depth_conv.conv", "input_stem.op_list.0.conv", "features.0.0.c",
-                "channel_mixer.m.0.c", "token_mixer.1.fc1",
+                "channel_mixer.m.0.c", "token_mixer.1.fc1", "patch_embed.seq.0.c", "conv1.c", "conv2.c",
                 "dconv_2x2_0", "output_upscaling.0", "output_upscaling.3", "mask_downscaling.0",
                 "mask_downscaling.3")
 
@@ -332,7 +390,7 @@ def _conv_gain(name: str) -> float:
 
 
 def _linear_gain(name: str) -> float:
-    if "mlp.lin1" in name or ".layers.0." in name or ".layers.1." in name:
+    if "mlp.lin1" in name or ".layers.0." in name or ".layers.1." in name or "mlp.fc1" in name:
         return 2.0  # followed by ReLU
     return 1.0
 
@@ -369,6 +427,10 @@ def init_state_dict(schema: _Schema, seed: int = 0) -> "OrderedDict[str, torch.T
             t = randn(shape) * math.sqrt(_conv_gain(name) / shape[0])
         elif kind == "linear":
             t = randn(shape) * math.sqrt(_linear_gain(name) / shape[1])
+        elif kind == "linear_res":  # last linear of a transformer residual branch
+            t = randn(shape) * math.sqrt(0.03 / shape[1])
+        elif kind == "attn_bias":   # TinyViT relative-offset attention biases
+            t = randn(shape) * 0.5
         elif kind == "bias":
             t = randn(shape) * 0.1
         elif kind == "bn_w":

@@ -144,6 +144,16 @@ def reference_stage_taps(backbone_type, bb, x):
             x = f(x)
         taps[f"stage{stage}"] = x
         return taps
+    if backbone_type == "tinyvit":  # stage0 = patch embed; stage k = output of layers[k-1] as NCHW
+        m = bb.model
+        x = m.patch_embed(x)
+        taps = {"stage0": x}
+        for li, layer in enumerate(m.layers):
+            x = layer(x)
+            b, l, c = x.shape
+            side = int(l ** 0.5)
+            taps[f"stage{li + 1}"] = x.view(b, side, side, c).permute(0, 3, 1, 2).contiguous()
+        return taps
     raise NotImplementedError(backbone_type)
 
 
@@ -173,6 +183,10 @@ def main():
     sd = schema.synthetic_state_dict(args.backbone, args.model, seed=0)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected[:5]
+    # the builder loads a checkpoint BEFORE it switches to eval (model_builder.py:1040-1052); do the
+    # same here: TinyViT's Attention caches `ab` from attention_biases inside train(False)
+    # (tiny_vit.py:257-263) and would otherwise keep the biases of the random initialisation
+    model.eval()
     print(f"reference built+loaded in {time.time() - t0:.1f}s; schema keys {len(sd)}; "
           f"reference keys not in hot-path schema: {len(missing)}")
     proc = Sam3Processor(model, device="cpu")

@@ -199,6 +199,100 @@ def repvit_backbone(sd: SD, x: torch.Tensor, model_name: str = "m1.1",
     return x
 
 
+# --------------------------------------------------------------------------
+# TinyViT (backbones/tiny_vit.py), built with img_size=1008, num_classes=0
+# --------------------------------------------------------------------------
+def _tv_mbconv(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """MBConv.forward (tiny_vit.py:87-125): the GELU comes AFTER the shortcut add."""
+    y = F.gelu(_conv_bn(sd, p + "conv1", x))
+    y = F.gelu(_conv_bn(sd, p + "conv2", y, 1, 1, groups=y.shape[1]))
+    y = _conv_bn(sd, p + "conv3", y)
+    return F.gelu(y + x)
+
+
+def _tv_patch_merging(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """PatchMerging.forward on NCHW (tiny_vit.py:128-154): 1x1, GELU, dw3x3 s2, GELU, 1x1."""
+    x = F.gelu(_conv_bn(sd, p + "conv1", x))
+    x = F.gelu(_conv_bn(sd, p + "conv2", x, 2, 1, groups=x.shape[1]))
+    return _conv_bn(sd, p + "conv3", x)
+
+
+def _tv_attention_bias_idxs(ws: int) -> torch.Tensor:
+    """Attention.__init__ (tiny_vit.py:240-255): index of the (|dy|, |dx|) offset in order of first
+    appearance, which for the row-major point list is dy * ws + dx."""
+    ys, xs = torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")
+    pts = torch.stack([ys.reshape(-1), xs.reshape(-1)], 1)
+    d = (pts[:, None, :] - pts[None, :, :]).abs()
+    return d[..., 0] * ws + d[..., 1]
+
+
+def _tv_attention(sd: SD, p: str, x: torch.Tensor, heads: int, ws: int) -> torch.Tensor:
+    """Attention.forward (tiny_vit.py:265-293) on windows x [Bw, N, C]; attn_ratio = 1."""
+    bw, n, c = x.shape
+    kd = c // heads
+    x = F.layer_norm(x, (c,), sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-5)
+    qkv = F.linear(x, sd[p + "qkv.weight"], sd[p + "qkv.bias"]).view(bw, n, heads, 3 * kd)
+    q, k, v = qkv.split([kd, kd, kd], dim=3)
+    q, k, v = q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)
+    bias = sd[p + "attention_biases"][:, _tv_attention_bias_idxs(ws)]
+    attn = (q @ k.transpose(-2, -1)) * (kd ** -0.5) + bias
+    attn = attn.softmax(dim=-1)
+    x = (attn @ v).transpose(1, 2).reshape(bw, n, c)
+    return F.linear(x, sd[p + "proj.weight"], sd[p + "proj.bias"])
+
+
+def _tv_block(sd: SD, p: str, x: torch.Tensor, hw: int, heads: int, ws: int) -> torch.Tensor:
+    """TinyViTBlock.forward (tiny_vit.py:339-380) on tokens [B, hw*hw, C]."""
+    b, l, c = x.shape
+    res = x
+    y = x.view(b, hw, hw, c)
+    pad = (ws - hw % ws) % ws
+    if pad:
+        y = F.pad(y, (0, 0, 0, pad, 0, pad))  # zero rows/cols BEFORE the attention's LayerNorm
+    ph = hw + pad
+    nw = ph // ws
+    y = y.view(b, nw, ws, nw, ws, c).transpose(2, 3).reshape(b * nw * nw, ws * ws, c)
+    y = _tv_attention(sd, p + "attn.", y, heads, ws)
+    y = y.view(b, nw, nw, ws, ws, c).transpose(2, 3).reshape(b, ph, ph, c)
+    if pad:
+        y = y[:, :hw, :hw].contiguous()
+    x = res + y.view(b, l, c)
+    x = x.transpose(1, 2).reshape(b, c, hw, hw)
+    x = _conv_bn(sd, p + "local_conv", x, 1, 1, groups=c)
+    x = x.view(b, c, l).transpose(1, 2)
+    m = F.layer_norm(x, (c,), sd[p + "mlp.norm.weight"], sd[p + "mlp.norm.bias"], 1e-5)
+    m = F.gelu(F.linear(m, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+    return x + F.linear(m, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+
+
+def tinyvit_backbone(sd: SD, x: torch.Tensor, model_name: str = "11m",
+                     taps: Optional[dict] = None) -> torch.Tensor:
+    """TinyViTTrunkWrapper.forward (model_builder.py:883-896): patch_embed, layers, tokens -> NCHW."""
+    from efficientsam3_amd.schema import TINYVIT_CFG
+    dims, depths, heads, windows = TINYVIT_CFG[model_name]
+    p = EV_BB
+    x = F.gelu(_conv_bn(sd, p + "patch_embed.seq.0", x, 2, 1))
+    x = _conv_bn(sd, p + "patch_embed.seq.2", x, 2, 1)
+    if taps is not None:
+        taps["stage0"] = x
+    for bi in range(depths[0]):
+        x = _tv_mbconv(sd, p + f"layers.0.blocks.{bi}.", x)
+    x = _tv_patch_merging(sd, p + "layers.0.downsample.", x)
+    if taps is not None:
+        taps["stage1"] = x
+    for li in range(1, len(dims)):
+        b, c, hw, _ = x.shape
+        t = x.flatten(2).transpose(1, 2)
+        for bi in range(depths[li]):
+            t = _tv_block(sd, p + f"layers.{li}.blocks.{bi}.", t, hw, heads[li], windows[li])
+        x = t.view(b, hw, hw, c).permute(0, 3, 1, 2)
+        if li < len(dims) - 1:
+            x = _tv_patch_merging(sd, p + f"layers.{li}.downsample.", x)
+        if taps is not None:
+            taps[f"stage{li + 1}"] = x.contiguous()
+    return x.contiguous()
+
+
 def backbone_family(model_name: str) -> str:
     """The reference's model names are disjoint across families (model_builder.py:807-890)."""
     if model_name in EV_CFG:
@@ -216,7 +310,7 @@ def student_backbone(sd: SD, x: torch.Tensor, model_name: str, taps: Optional[di
         return efficientvit_backbone(sd, x, model_name, taps)
     if fam == "repvit":
         return repvit_backbone(sd, x, model_name, taps)
-    raise NotImplementedError(fam)
+    return tinyvit_backbone(sd, x, model_name, taps)
 
 
 def student_head(sd: SD, x: torch.Tensor) -> torch.Tensor:
