@@ -105,6 +105,7 @@ struct esam3_engine {
   int dim = 16;
   struct RvBlock { int c, se, stride; };
   std::vector<RvBlock> rv_cfg;  // RepViT block table (repvit.py:291-506)
+  std::vector<int> tv_dims, tv_depths, tv_heads, tv_windows;  // TinyViT (tiny_vit.py:656-690)
   std::unordered_map<std::string, HostTensor> raw;
   std::unordered_map<std::string, PackedGemm> gemms;
   std::unordered_map<std::string, PackedDw> dws;
@@ -498,12 +499,19 @@ struct esam3_engine {
   int evit_block(const std::string& p, const T4& x, T4* y);
   int backbone(const float* img, int B, const esam3_image_features* out, T4* feat);
   int stem(const std::string& wname, const std::string& bn, int cout, int act, const float* img, int B, T4* y);
-  int conv_bn(const std::string& p, const T4& x, int stride, int act, T4* y, const T4* res = nullptr, const T4* dst = nullptr);
+  int conv_bn(const std::string& p, const T4& x, int stride, int act, T4* y, const T4* res = nullptr, const T4* dst = nullptr,
+              int res_after_act = 1);
   int squeeze_excite(const std::string& p, T4& x);
   PackedDw* pk_repvggdw(const std::string& q);
   int repvit_block(const std::string& p, const T4& x, bool use_se, int stride, T4* y);
   int backbone_repvit(const float* img, int B, const esam3_image_features* out, T4* feat);
   int tap(const esam3_image_features* out, int i, const T4& t);
+  int dw_launch(PackedDw* d, const T4& in, int stride, int act, T4* o);
+  int dw_bn(const std::string& p, const T4& x, int stride, int act, T4* y);
+  int tv_mbconv(const std::string& p, const T4& x, T4* y);
+  int tv_patch_merging(const std::string& p, const T4& x, T4* y);
+  int tv_block(const std::string& p, const T4& x, int heads, int ws, T4* y);
+  int backbone_tinyvit(const float* img, int B, const esam3_image_features* out, T4* feat);
   int neck(const std::string& which, const T4& trunk, void* const outs[3], bool sam2);
   int encode(const float* img, int B, const esam3_image_features* out);
   int decode(const esam3_prompts* pr, const esam3_decode_out* out);
@@ -660,15 +668,34 @@ int E::stem(const std::string& wname, const std::string& bn, int cout, int act, 
 }
 
 // Conv2d_BN (repvit.py:29-37, tiny_vit.py:38-64): bias-free 1x1 / 3x3 conv `<p>.c` + BatchNorm `<p>.bn`
-int E::conv_bn(const std::string& p, const T4& x, int stride, int act, T4* y, const T4* res, const T4* dst) {
+int E::conv_bn(const std::string& p, const T4& x, int stride, int act, T4* y, const T4* res, const T4* dst,
+               int res_after_act) {
   PackedGemm* g = pk_conv(p + ".c.weight", "", p + ".bn");
   if (!g) return -1;
   if (g->cin != x.C) { esam3_set_error("conv_bn %s: Cin %d != %d", p.c_str(), g->cin, x.C); return -1; }
   if (dst) *y = *dst;
   else *y = alloc4(x.B, (x.H + stride - 1) / stride, (x.W + stride - 1) / stride, g->N);
   if (!ok(y->p)) return -1;
-  return gemm(g, x.p, x.ld, y->rows(), x.H, x.W, y->p, y->ld, act, res ? res->p : nullptr, res ? res->ld : 0, 1, 0,
-              nullptr, x.pad, 0, stride);
+  return gemm(g, x.p, x.ld, y->rows(), x.H, x.W, y->p, y->ld, act, res ? res->p : nullptr, res ? res->ld : 0,
+              res_after_act, 0, nullptr, x.pad, 0, stride);
+}
+
+int E::dw_launch(PackedDw* d, const T4& in, int s_, int act, T4* o) {
+  if (!d) return -1;
+  if (d->C != in.C) { esam3_set_error("depthwise conv: C %d != %d", d->C, in.C); return -1; }
+  *o = alloc4(in.B, (in.H + s_ - 1) / s_, (in.W + s_ - 1) / s_, in.C);
+  if (!ok(o->p)) return -1;
+  if (dry) return 0;
+  const double px_in = (double)in.rows() * in.C, px_out = (double)o->rows() * o->C;
+  return prof_launch("dwconv" + std::to_string(d->ks) + "s" + std::to_string(s_), 2.0 * d->ks * d->ks * px_out,
+                     (px_in + px_out) * (double)esz, [&]() {
+                       return esam3_launch_dwconv(dtype, in.p, in.ld, d->w, d->bias, o->p, o->ld, in.B, in.H, in.W, in.C,
+                                                  d->ks, s_, act, st);
+                     });
+}
+// depthwise Conv2d_BN `<p>.c` + `<p>.bn`
+int E::dw_bn(const std::string& p, const T4& x, int stride, int act, T4* y) {
+  return dw_launch(pk_dw(p + ".c.weight", "", p + ".bn"), x, stride, act, y);
 }
 
 // timm SqueezeExcite, in place on x (`p` ends with '.')
@@ -730,23 +757,13 @@ int E::repvit_block(const std::string& p, const T4& x, bool use_se, int stride, 
   if (!ok(dst.p)) return -1;
   const size_t mk = arena.mark();  // everything below is scratch of this block
   T4 tm;
-  auto dw_launch = [&](PackedDw* d, const T4& in, int s_, T4* o) -> int {
-    if (!d) return -1;
-    *o = alloc4(in.B, (in.H + s_ - 1) / s_, (in.W + s_ - 1) / s_, in.C);
-    if (!ok(o->p)) return -1;
-    if (dry) return 0;
-    const double px_in = (double)in.rows() * in.C, px_out = (double)o->rows() * o->C;
-    return prof_launch("dwconv3s" + std::to_string(s_), 18.0 * px_out, (px_in + px_out) * (double)esz, [&]() {
-      return esam3_launch_dwconv(dtype, in.p, in.ld, d->w, d->bias, o->p, o->ld, in.B, in.H, in.W, in.C, 3, s_, ACT_NONE, st);
-    });
-  };
   if (stride == 2) {
     if (use_se) { esam3_set_error("RepViT: SE in a stride-2 block is not supported"); return -1; }
     T4 d;
-    CK(dw_launch(pk_dw(p + "token_mixer.0.c.weight", "", p + "token_mixer.0.bn"), x, 2, &d));
+    CK(dw_bn(p + "token_mixer.0", x, 2, ACT_NONE, &d));
     CK(conv_bn(p + "token_mixer.2", d, 1, ACT_NONE, &tm));
   } else {
-    CK(dw_launch(pk_repvggdw(p + "token_mixer.0."), x, 1, &tm));
+    CK(dw_launch(pk_repvggdw(p + "token_mixer.0."), x, 1, ACT_NONE, &tm));
     if (use_se) CK(squeeze_excite(p + "token_mixer.1.", tm));
   }
   T4 h;
@@ -776,8 +793,119 @@ int E::backbone_repvit(const float* img, int B, const esam3_image_features* out,
   return 0;
 }
 
+// TinyViT MBConv (tiny_vit.py:87-125): 1x1 + BN, GELU, dw3x3 + BN, GELU, 1x1 + BN, + shortcut, GELU
+int E::tv_mbconv(const std::string& p, const T4& x, T4* y) {
+  const T4 dst = alloc4(x.B, x.H, x.W, x.C);
+  if (!ok(dst.p)) return -1;
+  const size_t mk = arena.mark();
+  T4 a, d;
+  CK(conv_bn(p + "conv1", x, 1, ACT_GELU, &a));
+  CK(dw_bn(p + "conv2", a, 1, ACT_GELU, &d));
+  CK(conv_bn(p + "conv3", d, 1, ACT_GELU, y, &x, &dst, /*res_after_act=*/0));
+  arena.release(mk);
+  return 0;
+}
+
+// PatchMerging (tiny_vit.py:128-154): 1x1 + BN, GELU, dw3x3 s2 + BN, GELU, 1x1 + BN
+int E::tv_patch_merging(const std::string& p, const T4& x, T4* y) {
+  const HostTensor* w = need(p + "conv3.c.weight");
+  if (!w) return -1;
+  const T4 dst = alloc4(x.B, (x.H + 1) / 2, (x.W + 1) / 2, (int)w->shape[0]);
+  if (!ok(dst.p)) return -1;
+  const size_t mk = arena.mark();
+  T4 a, d;
+  CK(conv_bn(p + "conv1", x, 1, ACT_GELU, &a));
+  CK(dw_bn(p + "conv2", a, 2, ACT_GELU, &d));
+  CK(conv_bn(p + "conv3", d, 1, ACT_NONE, y, nullptr, &dst));
+  arena.release(mk);
+  return 0;
+}
+
+// TinyViTBlock (tiny_vit.py:339-380) on NHWC tokens: x + proj(window_attention(qkv(LN(x)))), dw3x3 + BN
+// local conv, x + fc2(GELU(fc1(LN(x)))).  The window partition (with its zero padding) is index
+// arithmetic inside the attention kernel; padded positions use the constant qkv(LN(0)).
+int E::tv_block(const std::string& p, const T4& x, int heads, int ws, T4* y) {
+  const int C = x.C;
+  if (C != heads * 32) { esam3_set_error("TinyViT block %s: head dim %d != 32", p.c_str(), C / heads); return -1; }
+  const T4 dst = alloc4(x.B, x.H, x.W, C);
+  if (!ok(dst.p)) return -1;
+  const size_t mk = arena.mark();
+  const int64_t rows = x.rows();
+  // constant qkv of a padded token: W_qkv . LN(0) + b = W_qkv . ln_bias + b   (fp64 on the host)
+  const std::string padkey = p + "attn.qkv#pad";
+  void* pad_qkv = nullptr;
+  {
+    auto it = tbufs.find(padkey);
+    if (it == tbufs.end()) {
+      const HostTensor *w = need(p + "attn.qkv.weight"), *b = need(p + "attn.qkv.bias"), *lb = need(p + "attn.norm.bias");
+      if (!w || !b || !lb) return -1;
+      std::vector<float> v(3 * (size_t)C);
+      for (int o = 0; o < 3 * C; ++o) {
+        double a = b->d[o];
+        for (int c = 0; c < C; ++c) a += (double)w->d[(size_t)o * C + c] * lb->d[c];
+        v[o] = (float)a;
+      }
+      pad_qkv = upload_T(v);
+      if (!pad_qkv) return -1;
+      tbufs[padkey] = pad_qkv;
+    } else {
+      pad_qkv = it->second;
+    }
+  }
+  float* bias = fvec(p + "attn.attention_biases");
+  if (!bias) return -1;
+  void* ln1 = allocb((size_t)rows * C * esz);
+  void* qkv = allocb((size_t)rows * 3 * C * esz);
+  void* att = allocb((size_t)rows * C * esz);
+  T4 x1 = alloc4(x.B, x.H, x.W, C);
+  if (!ok(ln1) || !ok(qkv) || !ok(att) || !ok(x1.p)) return -1;
+  CK(layernorm(p + "attn.norm", x.p, ln1, rows, C, 1e-5f));
+  CK(linear(p + "attn.qkv", ln1, C, rows, qkv, 3 * C, ACT_NONE));
+  if (!dry)
+    CK(prof_launch("window_attn" + std::to_string(ws), 4.0 * (double)rows * ws * ws * C, 5.0 * (double)rows * C * (double)esz, [&]() {
+      return esam3_launch_window_attn(dtype, qkv, 3 * C, pad_qkv, bias, att, C, x.B, x.H, x.W, heads, ws, st);
+    }));
+  CK(linear(p + "attn.proj", att, C, rows, x1.p, C, ACT_NONE, x.p, x.ld));
+  T4 x2;
+  CK(dw_bn(p + "local_conv", x1, 1, ACT_NONE, &x2));
+  void* hid = allocb((size_t)rows * 4 * C * esz);
+  if (!ok(hid)) return -1;
+  CK(layernorm(p + "mlp.norm", x2.p, ln1, rows, C, 1e-5f));
+  CK(linear(p + "mlp.fc1", ln1, C, rows, hid, 4 * C, ACT_GELU));
+  CK(linear(p + "mlp.fc2", hid, 4 * C, rows, dst.p, C, ACT_NONE, x2.p, x2.ld));
+  *y = dst;
+  arena.release(mk);
+  return 0;
+}
+
+// TinyViTTrunkWrapper.forward (model_builder.py:883-896): patch_embed, ConvLayer, 3 BasicLayers
+int E::backbone_tinyvit(const float* img, int B, const esam3_image_features* out, T4* feat) {
+  const std::string p = EVBB;
+  T4 s1, x, y;
+  CK(stem(p + "patch_embed.seq.0.c.weight", p + "patch_embed.seq.0.bn", tv_dims[0] / 2, ACT_GELU, img, B, &s1));
+  CK(conv_bn(p + "patch_embed.seq.2", s1, 2, ACT_NONE, &x));
+  CK(tap(out, 0, x));
+  for (size_t li = 0; li < tv_dims.size(); ++li) {
+    const std::string q = p + "layers." + std::to_string(li) + ".";
+    for (int bi = 0; bi < tv_depths[li]; ++bi) {
+      const std::string bp = q + "blocks." + std::to_string(bi) + ".";
+      if (li == 0) CK(tv_mbconv(bp, x, &y));
+      else CK(tv_block(bp, x, tv_heads[li], tv_windows[li], &y));
+      x = y;
+    }
+    if (li + 1 < tv_dims.size()) {
+      CK(tv_patch_merging(q + "downsample.", x, &y));
+      x = y;
+    }
+    CK(tap(out, (int)li + 1, x));
+  }
+  *feat = x;
+  return 0;
+}
+
 int E::backbone(const float* img, int B, const esam3_image_features* out, T4* feat) {
   if (cfg.backbone == ESAM3_BACKBONE_REPVIT) return backbone_repvit(img, B, out, feat);
+  if (cfg.backbone == ESAM3_BACKBONE_TINYVIT) return backbone_tinyvit(img, B, out, feat);
   auto tap = [&](int i, const T4& t) -> int { return this->tap(out, i, t); };
   // E0 stem: 3x3 s2 conv + BN + Hardswish, straight from the NCHW fp32 input
   T4 x;
@@ -1192,7 +1320,8 @@ int esam3_create(const esam3_config* cfg, esam3_engine** out) {
   }
   if (cfg->device < 0 || cfg->device >= ndev) { esam3_set_error("bad device ordinal %d", cfg->device); return -1; }
   HIP_CHECK_RET(hipSetDevice(cfg->device));
-  if (cfg->backbone != ESAM3_BACKBONE_EFFICIENTVIT && cfg->backbone != ESAM3_BACKBONE_REPVIT) {
+  if (cfg->backbone != ESAM3_BACKBONE_EFFICIENTVIT && cfg->backbone != ESAM3_BACKBONE_REPVIT &&
+      cfg->backbone != ESAM3_BACKBONE_TINYVIT) {
     esam3_set_error("unsupported backbone %d", cfg->backbone);
     return -1;
   }
@@ -1201,6 +1330,16 @@ int esam3_create(const esam3_config* cfg, esam3_engine** out) {
   e->dtype = cfg->dtype == ESAM3_F32 ? 0 : 1;
   e->esz = e->dtype == 0 ? 4 : 2;
   const std::string mn(cfg->model_name);
+  if (cfg->backbone == ESAM3_BACKBONE_TINYVIT) {
+    e->tv_depths = {2, 2, 6, 2};
+    e->tv_windows = {7, 7, 14, 7};
+    if (mn == "5m") { e->tv_dims = {64, 128, 160, 320}; e->tv_heads = {2, 4, 5, 10}; }
+    else if (mn == "11m") { e->tv_dims = {64, 128, 256, 448}; e->tv_heads = {2, 4, 8, 14}; }
+    else if (mn == "21m") { e->tv_dims = {96, 192, 384, 576}; e->tv_heads = {3, 6, 12, 18}; }
+    else { esam3_set_error("unknown TinyViT model '%s'", mn.c_str()); delete e; return -1; }
+    *out = e;
+    return 0;
+  }
   if (cfg->backbone == ESAM3_BACKBONE_REPVIT) {
     // (channels, SE, stride) per block: repvit.py:320-350 (m0_9), :386-416 (m1_1)
     auto stage = [&](int c, int n_s1, bool first_stage, int tail_plain) {

@@ -98,6 +98,10 @@ int esam3_launch_nhwc_to_nchw_f32(int dtype, const void* in, float* out, int B, 
                                   hipStream_t s);
 // uint8 HWC -> fp32 NCHW, x/255 then (x-0.5)/0.5
 int esam3_launch_preprocess_u8(const uint8_t* in, float* out, int B, int H, int W, hipStream_t s);
+// TinyViT window attention, head dim 32: qkv [B][H][W][heads*96] (q|k|v per head), pad_qkv [heads*96] (T),
+// bias [heads][ws*ws] fp32 indexed by |dy|*ws+|dx|; out [B][H][W][heads*32]
+int esam3_launch_window_attn(int dtype, const void* qkv, int ld, const void* pad_qkv, const float* bias, void* out,
+                             int ldo, int B, int H, int W, int heads, int ws, hipStream_t s);
 // in-place squeeze-excite on x [B][HW][C]; sums/gate: [B][C] fp32 scratch; w1 [R][C], w2 [C][R] (device fp32)
 int esam3_launch_squeeze_excite(int dtype, void* x, int ld, float* sums, float* gate, const float* w1,
                                 const float* b1, const float* w2, const float* b2, int B, int HW, int C, int R,

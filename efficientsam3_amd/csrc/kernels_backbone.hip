@@ -563,6 +563,134 @@ __global__ __launch_bounds__(256) void se_scale_kernel(T* __restrict__ x, int ld
 }
 
 // ------------------------------------------------------------------------------------
+// TinyViT window attention (tiny_vit.py:265-293,339-372): tokens [B][H][W][heads*(q32|k32|v32)]
+// are partitioned into WS x WS windows (the map is zero-padded up to a multiple of WS BEFORE the
+// attention's LayerNorm, so a padded position carries the constant qkv(LayerNorm(0)) = `pad_qkv`
+// and takes part as a key/value); out = softmax(q k^T / sqrt(32) + bias[h][|dy|*WS+|dx|]) v.
+// One (window, head) pair per thread group: K and V of the pair sit in LDS as fp32, every thread
+// owns QB queries and runs an online softmax over the N = WS*WS keys (LDS reads are broadcasts).
+// ------------------------------------------------------------------------------------
+template <typename T, int WS, int QB, int PAIRS>
+__global__ __launch_bounds__(PAIRS * ((WS * WS + QB - 1) / QB)) void window_attn_kernel(
+    const T* __restrict__ qkv, int ld, const T* __restrict__ pad_qkv, const float* __restrict__ bias,
+    T* __restrict__ out, int ldo, int H, int W, int heads, int nwx, int nwy, int total_pairs) {
+  constexpr int N = WS * WS, HD = 32, TPP = (N + QB - 1) / QB;
+  constexpr int PAIR_FLOATS = 2 * N * HD + N;
+  extern __shared__ float smem[];
+  const int pl = threadIdx.x / TPP, tl = threadIdx.x - pl * TPP;
+  const int pair = blockIdx.x * PAIRS + pl;
+  const bool pvalid = pair < total_pairs;
+  float* sk = smem + pl * PAIR_FLOATS;
+  float* sv = sk + N * HD;
+  float* sb = sv + N * HD;
+  int h = 0, wx = 0, wy = 0, b = 0;
+  if (pvalid) {
+    h = pair % heads;
+    const int win = pair / heads;
+    wx = win % nwx;
+    wy = (win / nwx) % nwy;
+    b = win / (nwx * nwy);
+    for (int i = tl; i < N * (HD / VEC); i += TPP) {
+      const int j = i / (HD / VEC), c = i - j * (HD / VEC);
+      const int y = wy * WS + j / WS, x = wx * WS + j % WS;
+      const T* src = (y < H && x < W) ? qkv + ((int64_t)(b * H + y) * W + x) * ld + h * 3 * HD : pad_qkv + h * 3 * HD;
+      float kk[VEC], vv[VEC];
+      Vec8<T>::load(src + HD + c * VEC, kk);
+      Vec8<T>::load(src + 2 * HD + c * VEC, vv);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        sk[j * HD + c * VEC + e] = kk[e];
+        sv[j * HD + c * VEC + e] = vv[e];
+      }
+    }
+    for (int i = tl; i < N; i += TPP) sb[i] = bias[h * N + i];
+  }
+  __syncthreads();
+  if (!pvalid) return;
+  float q[QB][HD], acc[QB][HD], mx[QB], sum[QB];
+  int qy[QB], qx[QB];
+  bool qok[QB];
+#pragma unroll
+  for (int r = 0; r < QB; ++r) {
+    const int qi = tl * QB + r;
+    qy[r] = qi / WS;
+    qx[r] = qi - qy[r] * WS;
+    const int y = wy * WS + qy[r], x = wx * WS + qx[r];
+    qok[r] = qi < N && y < H && x < W;
+    mx[r] = -INFINITY;
+    sum[r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { acc[r][d] = 0.f; q[r][d] = 0.f; }
+    if (qok[r]) {
+      const T* src = qkv + ((int64_t)(b * H + y) * W + x) * ld + h * 3 * HD;
+#pragma unroll
+      for (int c = 0; c < HD / VEC; ++c) Vec8<T>::load(src + c * VEC, q[r] + c * VEC);
+    }
+  }
+  const float scale = 0.17677669529663687f;  // 32^-0.5
+  int jy = 0, jx = 0;
+  for (int j = 0; j < N; ++j) {
+    const float4* kr = reinterpret_cast<const float4*>(sk + j * HD);
+    float s[QB];
+#pragma unroll
+    for (int r = 0; r < QB; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+      const float4 k4 = kr[c];
+#pragma unroll
+      for (int r = 0; r < QB; ++r) {
+        s[r] = fmaf(q[r][4 * c], k4.x, s[r]);
+        s[r] = fmaf(q[r][4 * c + 1], k4.y, s[r]);
+        s[r] = fmaf(q[r][4 * c + 2], k4.z, s[r]);
+        s[r] = fmaf(q[r][4 * c + 3], k4.w, s[r]);
+      }
+    }
+    float p[QB];
+#pragma unroll
+    for (int r = 0; r < QB; ++r) {
+      const int dy = qy[r] > jy ? qy[r] - jy : jy - qy[r], dx = qx[r] > jx ? qx[r] - jx : jx - qx[r];
+      const float sc = s[r] * scale + sb[(dy * WS + dx) % N];
+      if (sc > mx[r]) {  // new running maximum: rescale what has been accumulated
+        const float f = __expf(mx[r] - sc);
+        sum[r] *= f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[r][d] *= f;
+        mx[r] = sc;
+      }
+      p[r] = __expf(sc - mx[r]);
+      sum[r] += p[r];
+    }
+    const float4* vr = reinterpret_cast<const float4*>(sv + j * HD);
+#pragma unroll
+    for (int c = 0; c < HD / 4; ++c) {
+      const float4 v4 = vr[c];
+#pragma unroll
+      for (int r = 0; r < QB; ++r) {
+        acc[r][4 * c] = fmaf(p[r], v4.x, acc[r][4 * c]);
+        acc[r][4 * c + 1] = fmaf(p[r], v4.y, acc[r][4 * c + 1]);
+        acc[r][4 * c + 2] = fmaf(p[r], v4.z, acc[r][4 * c + 2]);
+        acc[r][4 * c + 3] = fmaf(p[r], v4.w, acc[r][4 * c + 3]);
+      }
+    }
+    if (++jx == WS) { jx = 0; ++jy; }
+  }
+#pragma unroll
+  for (int r = 0; r < QB; ++r) {
+    if (!qok[r]) continue;
+    const int y = wy * WS + qy[r], x = wx * WS + qx[r];
+    const float inv = 1.f / sum[r];
+    T* dst = out + ((int64_t)(b * H + y) * W + x) * ldo + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD / VEC; ++c) {
+      float o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = acc[r][c * VEC + e] * inv;
+      Vec8<T>::store(dst + c * VEC, o);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // bilinear resize, align_corners=False (model_builder.py:779-786)
 // ------------------------------------------------------------------------------------
 template <typename T>
@@ -904,6 +1032,38 @@ int esam3_launch_lite_mla(int dtype, const void* ms, int ld, void* out, int ld_o
                       : lite_mla_t<bf16_t, 32>(ms, ld, out, ld_out, kv, B, N, groups, s);
   }
   esam3_set_error("lite_mla: dim=%d unsupported", dim);
+  return -1;
+}
+
+template <typename T, int WS, int QB, int PAIRS>
+static int launch_window_attn(const void* qkv, int ld, const void* pad_qkv, const float* bias, void* out, int ldo, int B,
+                              int H, int W, int heads, hipStream_t s) {
+  constexpr int N = WS * WS, TPP = (N + QB - 1) / QB;
+  constexpr size_t lds = sizeof(float) * PAIRS * (2 * N * 32 + N);
+  auto kern = window_attn_kernel<T, WS, QB, PAIRS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+    attr_set = true;
+  }
+  const int nwx = (W + WS - 1) / WS, nwy = (H + WS - 1) / WS;
+  const int total = B * nwx * nwy * heads;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((total + PAIRS - 1) / PAIRS)), dim3(PAIRS * TPP), lds, s, (const T*)qkv, ld,
+                     (const T*)pad_qkv, bias, (T*)out, ldo, H, W, heads, nwx, nwy, total);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_window_attn(int dtype, const void* qkv, int ld, const void* pad_qkv, const float* bias, void* out,
+                             int ldo, int B, int H, int W, int heads, int ws, hipStream_t s) {
+  if (ws == 7)
+    return dtype == 0 ? launch_window_attn<float, 7, 2, 4>(qkv, ld, pad_qkv, bias, out, ldo, B, H, W, heads, s)
+                      : launch_window_attn<bf16_t, 7, 2, 4>(qkv, ld, pad_qkv, bias, out, ldo, B, H, W, heads, s);
+  if (ws == 14)
+    return dtype == 0 ? launch_window_attn<float, 14, 2, 1>(qkv, ld, pad_qkv, bias, out, ldo, B, H, W, heads, s)
+                      : launch_window_attn<bf16_t, 14, 2, 1>(qkv, ld, pad_qkv, bias, out, ldo, B, H, W, heads, s);
+  esam3_set_error("window_attn: window size %d unsupported", ws);
   return -1;
 }
 

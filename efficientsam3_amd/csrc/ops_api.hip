@@ -108,6 +108,19 @@ int esam3_op_conv3x3_s2(int dtype, const void* x, const float* w, const float* b
   return 0;
 }
 
+int esam3_op_window_attention(int dtype, const void* qkv, const float* pad_qkv, const float* bias, void* out, int B,
+                              int H, int W, int heads, int ws, void* stream) {
+  Tmp t;
+  const int C = heads * 32;
+  std::vector<float> pv(pad_qkv, pad_qkv + 3 * (size_t)C);
+  void* pd = t.upT(dtype, pv);
+  float* bd = (float*)t.up(bias, (size_t)heads * ws * ws * 4);
+  if (!pd || !bd) return fail("op_window_attention");
+  if (esam3_launch_window_attn(dtype, qkv, 3 * C, pd, bd, out, C, B, H, W, heads, ws, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
 int esam3_op_squeeze_excite(int dtype, void* x, const float* w1, const float* b1, const float* w2, const float* b2,
                             int B, int HW, int C, int R, void* stream) {
   Tmp t;

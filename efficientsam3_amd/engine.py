@@ -26,7 +26,7 @@ def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-BACKBONES = {"efficientvit": 0, "repvit": 1}  # ESAM3_BACKBONE_*
+BACKBONES = {"efficientvit": 0, "repvit": 1, "tinyvit": 2}  # ESAM3_BACKBONE_*
 
 
 def stage_shapes(backbone_type: str, model_name: str):
@@ -36,6 +36,9 @@ def stage_shapes(backbone_type: str, model_name: str):
                  "b2": [24, 48, 96, 192, 384]}[model_name], [504, 252, 126, 63, 32])
     if backbone_type == "repvit":
         return ({"m0.9": [48, 96, 192, 384], "m1.1": [64, 128, 256, 512]}[model_name], [252, 126, 63, 32])
+    if backbone_type == "tinyvit":
+        d = {"5m": [64, 128, 160, 320], "11m": [64, 128, 256, 448], "21m": [96, 192, 384, 576]}[model_name]
+        return ([d[0], d[1], d[2], d[3], d[3]], [252, 126, 63, 32, 32])
     raise NotImplementedError(backbone_type)
 
 

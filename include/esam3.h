@@ -33,12 +33,12 @@ extern "C" {
 typedef struct esam3_engine esam3_engine;
 
 enum { ESAM3_F32 = 0, ESAM3_BF16 = 1 };
-enum { ESAM3_BACKBONE_EFFICIENTVIT = 0, ESAM3_BACKBONE_REPVIT = 1 };
+enum { ESAM3_BACKBONE_EFFICIENTVIT = 0, ESAM3_BACKBONE_REPVIT = 1, ESAM3_BACKBONE_TINYVIT = 2 };
 
 typedef struct esam3_config {
   int dtype;            /* ESAM3_F32 (validation) or ESAM3_BF16 (throughput) activations */
   int backbone;         /* ESAM3_BACKBONE_* */
-  char model_name[16];  /* EfficientViT "b0" | "b1" | "b2"; RepViT "m0.9" | "m1.1" */
+  char model_name[16];  /* EfficientViT "b0" | "b1" | "b2"; RepViT "m0.9" | "m1.1"; TinyViT "5m" | "11m" | "21m" */
   int device;           /* HIP device ordinal */
   int interactive;      /* 1: sam2 neck + SAM heads are present (enable_inst_interactivity) */
   int fuse_linear_chains; /* 1: compose ConvT->1x1 and 3x3->conv_s0/s1 weight chains at finalize
@@ -49,7 +49,8 @@ typedef struct esam3_config {
  *   sam3_fpn: [B,288,288,256] [B,144,144,256] [B,72,72,256]   (all NULL -> sam3 neck not run)
  *   sam2_fpn: [B,288,288,32]  [B,144,144,64]  [B,72,72,256]   (after conv_s0 / conv_s1)
  *   trunk:    [B,72,72,1024]  ImageStudentEncoder output
- *   stages:   backbone stage outputs (validation taps): EfficientViT stage0..4, RepViT stage0..3 */
+ *   stages:   backbone stage outputs (validation taps): EfficientViT stage0..4, RepViT stage0..3,
+ *             TinyViT patch embed + the 4 layer outputs */
 typedef struct esam3_image_features {
   void* sam3_fpn_dev[3];
   void* sam2_fpn_dev[3];
@@ -133,6 +134,12 @@ int esam3_op_conv3x3_padded(int dtype, const void* x_padded_dev, const float* w_
  * (RepViT / TinyViT patch embedding, repvit.py:241-242) */
 int esam3_op_conv3x3_s2(int dtype, const void* x_dev, const float* w_host, const float* bias_host,
                         void* out_dev, int B, int H, int W, int Cin, int Cout, int act, void* hip_stream);
+/* TinyViT window attention, head dim 32 (tiny_vit.py:265-293,339-372): qkv [B][H][W][heads*96]
+ * (q|k|v per head); positions of the zero-padded border use pad_qkv [heads*96]; bias [heads][ws*ws]
+ * indexed by |dy|*ws+|dx|; out [B][H][W][heads*32]; ws in {7, 14} */
+int esam3_op_window_attention(int dtype, const void* qkv_dev, const float* pad_qkv_host,
+                              const float* bias_host, void* out_dev, int B, int H, int W, int heads,
+                              int ws, void* hip_stream);
 /* timm SqueezeExcite in place on x [B][HW][C] (repvit.py:136,150): w1 [R][C], w2 [C][R] host fp32 */
 int esam3_op_squeeze_excite(int dtype, void* x_dev, const float* w1_host, const float* b1_host,
                             const float* w2_host, const float* b2_host, int B, int HW, int C, int R,

@@ -97,6 +97,36 @@ def test_conv3x3_stride2(mode, B, H, W, Cin, Cout, act):
 
 
 @pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("B,H,W,heads,ws", [(2, 14, 14, 4, 7), (1, 18, 18, 2, 14), (2, 32, 32, 14, 7), (1, 63, 63, 8, 14),
+                                            (3, 7, 7, 2, 7)])
+def test_window_attention(mode, B, H, W, heads, ws):
+    """TinyViT window attention incl. the zero-padded border windows whose padded tokens act as
+    keys with the constant qkv(LayerNorm(0))."""
+    d, tdt = U.DT[mode]
+    C = heads * 32
+    qkv = _q(_rand(B, H, W, 3 * C, seed=1), mode)
+    pad_qkv = _q(_rand(3 * C, seed=2), mode)
+    bias = _rand(heads, ws * ws, seed=3) * 0.5
+    pad = (ws - H % ws) % ws
+    full = pad_qkv.expand(B, H + pad, W + pad, 3 * C).clone()
+    full[:, :H, :W] = qkv
+    nw = (H + pad) // ws
+    win = full.view(B, nw, ws, nw, ws, 3 * C).transpose(2, 3).reshape(B * nw * nw, ws * ws, heads, 96)
+    q, k, v = [t.permute(0, 2, 1, 3) for t in win.split([32, 32, 32], dim=3)]
+    ys, xs = torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")
+    pts = torch.stack([ys.reshape(-1), xs.reshape(-1)], 1)
+    dd = (pts[:, None] - pts[None]).abs()
+    attn = (q @ k.transpose(-2, -1)) * 32 ** -0.5 + bias[:, dd[..., 0] * ws + dd[..., 1]]
+    o = (attn.softmax(-1) @ v).transpose(1, 2).reshape(B * nw * nw, ws * ws, C)
+    ref = o.view(B, nw, nw, ws, ws, C).transpose(2, 3).reshape(B, H + pad, W + pad, C)[:, :H, :W]
+    x_d = qkv.to(tdt).to("cuda").contiguous()
+    out = torch.empty((B, H, W, C), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_window_attention(d, U.P(x_d), U.H(U.np32(pad_qkv)), U.H(U.np32(bias)), U.P(out), B, H, W,
+                                              heads, ws, None), "op_window_attention")
+    U.assert_close(out.float().cpu(), ref, mode, f"window attention ws={ws} heads={heads}")
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("B,H,W,C,R", [(2, 63, 63, 256, 64), (3, 20, 31, 64, 16), (1, 32, 32, 512, 128), (2, 7, 5, 48, 16)])
 def test_squeeze_excite(mode, B, H, W, C, R):
     d, tdt = U.DT[mode]
