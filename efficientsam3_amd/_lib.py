@@ -61,6 +61,7 @@ SIGNATURES = {
     "esam3_profile_report": (_I, [_P, C.c_char_p, _L]),
     "esam3_workspace_bytes": (_L, [_P]),
     "esam3_elem_size": (_I, [_P]),
+    "esam3_encode_text": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "esam3_preprocess_u8": (_I, [_P, _P, _I, _I, _I, _P]),
     "esam3_preprocess_resize_u8": (_I, [_P, _I, _I, _P, _I, _I, _P]),
     "esam3_op_linear": (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),

@@ -49,6 +49,7 @@ constexpr float BN_EPS = 1e-5f;
 const std::string TRUNK = "backbone.vision_backbone.trunk.model.";
 const std::string EVBB = TRUNK + "backbone.model.";
 const std::string NECK = "backbone.vision_backbone.";
+const std::string TEXTP = "backbone.language_backbone.";
 const std::string SAM = "inst_interactive_predictor.model.";
 const std::string MD = SAM + "sam_mask_decoder.";
 const std::string PE = SAM + "sam_prompt_encoder.";
@@ -516,6 +517,8 @@ struct esam3_engine {
   int encode(const float* img, int B, const esam3_image_features* out);
   int decode(const esam3_prompts* pr, const esam3_decode_out* out);
   int precompute_pe();
+  int text_repmixer(const std::string& p, void* x, int B, int S, int D, void* out);
+  int encode_text(const int64_t* tokens, int B, int S, float* memory_sbd, float* embeds_sbd);
   int ensure_arena(size_t need);
 };
 
@@ -1056,6 +1059,123 @@ int E::encode(const float* img, int B, const esam3_image_features* out) {
   return 0;
 }
 
+// RepMixerBlock (mobile_clip.py:647-702) with every BatchNorm branch and layer scale folded at load
+// (the reference's own reparameterize() algebra, mobile_clip.py:131-196,600-640, in fp64):
+//   token mixer  x + ls*(BN_s(x) + BN_c(dw(x)) - BN_n(x))  ==  one depthwise 1x11 conv with bias
+//   ConvFFN      x + ls2 * fc2(GELU(fc1(BN(dw(x)))))        ==  dw 1x11 + bias, GEMM+GELU, GEMM(+res) with ls2 in fc2
+int E::text_repmixer(const std::string& p, void* x, int B, int S, int D, void* out) {
+  const std::string kt = p + "#tm", kc = p + "#cf";
+  if (!find(kt + ".w")) {
+    const std::string t = p + "token_mixer.";
+    const HostTensor *cw = need(t + "mixer.rbr_conv.0.conv.weight"), *ls = need(t + "layer_scale"),
+                     *fw = need(p + "convffn.conv.conv.weight"), *ls2 = need(p + "layer_scale"),
+                     *w2 = need(p + "convffn.fc2.weight"), *b2 = need(p + "convffn.fc2.bias");
+    if (!cw || !ls || !fw || !ls2 || !w2 || !b2) return -1;
+    const int KW = (int)cw->shape[3];
+    std::vector<float> ss, st_, cs, ct, ns, nt, fs, ft;
+    if (!bn_fold(t + "mixer.rbr_skip", D, ss, st_) || !bn_fold(t + "mixer.rbr_conv.0.bn", D, cs, ct) ||
+        !bn_fold(t + "norm.rbr_skip", D, ns, nt) || !bn_fold(p + "convffn.conv.bn", D, fs, ft))
+      return -1;
+    HostTensor tw, tb, fw2, fb2, gw, gb;
+    tw.shape = {KW, D}; tw.d.resize((size_t)KW * D);
+    tb.shape = {D}; tb.d.resize(D);
+    fw2.shape = {KW, D}; fw2.d.resize((size_t)KW * D);
+    fb2.shape = {D}; fb2.d.resize(D);
+    for (int c = 0; c < D; ++c) {
+      for (int k = 0; k < KW; ++k) {
+        double mix = (double)cw->d[(size_t)c * KW + k] * cs[c];
+        double v = (double)ls->d[c] * mix;
+        if (k == KW / 2) v = 1.0 + (double)ls->d[c] * (mix + (double)ss[c] - (double)ns[c]);
+        tw.d[(size_t)k * D + c] = (float)v;
+        fw2.d[(size_t)k * D + c] = (float)((double)fw->d[(size_t)c * KW + k] * fs[c]);
+      }
+      tb.d[c] = (float)((double)ls->d[c] * ((double)st_[c] + ct[c] - nt[c]));
+      fb2.d[c] = ft[c];
+    }
+    const int Hd = (int)w2->shape[1];
+    gw.shape = {D, Hd}; gw.d.resize((size_t)D * Hd);
+    gb.shape = {D}; gb.d.resize(D);
+    for (int c = 0; c < D; ++c) {
+      for (int k = 0; k < Hd; ++k) gw.d[(size_t)c * Hd + k] = (float)((double)w2->d[(size_t)c * Hd + k] * ls2->d[c]);
+      gb.d[c] = (float)((double)b2->d[c] * ls2->d[c]);
+    }
+    raw[kt + ".w"] = std::move(tw); raw[kt + ".b"] = std::move(tb);
+    raw[kc + ".w"] = std::move(fw2); raw[kc + ".b"] = std::move(fb2);
+    raw[p + "convffn.fc2#ls.weight"] = std::move(gw); raw[p + "convffn.fc2#ls.bias"] = std::move(gb);
+  }
+  const int KW = (int)raw[kt + ".w"].shape[0];
+  float *tw = fvec(kt + ".w"), *tb = fvec(kt + ".b"), *fw = fvec(kc + ".w"), *fb = fvec(kc + ".b");
+  PackedGemm* g1 = pk_conv(p + "convffn.fc1.weight", p + "convffn.fc1.bias", "");
+  PackedGemm* g2 = pk_conv_like_linear(p + "convffn.fc2#ls.weight", p + "convffn.fc2#ls.bias");
+  if (!tw || !tb || !fw || !fb || !g1 || !g2) return -1;
+  const int64_t rows = (int64_t)B * S;
+  const size_t mk = arena.mark();
+  void* tm = allocb((size_t)rows * D * esz);
+  void* cf = allocb((size_t)rows * D * esz);
+  void* hid = allocb((size_t)rows * g1->N * esz);
+  if (!ok(tm) || !ok(cf) || !ok(hid)) return -1;
+  if (!dry) {
+    CK(prof_launch("seq_dwconv", 0.0, 0.0, [&]() { return esam3_launch_seq_dwconv(dtype, x, tw, tb, tm, B, S, D, KW, st); }));
+    CK(prof_launch("seq_dwconv", 0.0, 0.0, [&]() { return esam3_launch_seq_dwconv(dtype, tm, fw, fb, cf, B, S, D, KW, st); }));
+  }
+  CK(gemm(g1, cf, D, rows, 1, 1, hid, g1->N, ACT_GELU));
+  CK(gemm(g2, hid, g1->N, rows, 1, 1, out, D, ACT_NONE, tm, D));
+  arena.release(mk);
+  return 0;
+}
+
+// TextStudentEncoder.forward after tokenisation (text_encoder_student.py:40-58) for the MobileCLIP-S0
+// ("mct") text transformer: embeddings, RepMixerBlock, N x pre-norm transformer layers, RepMixerBlock,
+// final LayerNorm, projector.  Outputs fp32 [S][B][256] (language_features) and [S][B][512]
+// (language_embeds), the reference's sequence-first layouts.
+int E::encode_text(const int64_t* tokens, int B, int S, float* memory_sbd, float* embeds_sbd) {
+  arena.top = 0;
+  const std::string e = TEXTP + "encoder.";
+  const HostTensor *tab = need(e + "embedding_layer.weight"), *pos = need(e + "positional_embedding.pos_embed.pos_embed");
+  if (!tab || !pos) return -1;
+  const int D = (int)tab->shape[1], vocab = (int)tab->shape[0];
+  const int pos_len = (int)pos->shape[2];
+  if (S > pos_len) { esam3_set_error("encode_text: sequence length %d exceeds the positional table (%d)", S, pos_len); return -1; }
+  int n_layers = 0;
+  while (find(e + "transformer." + std::to_string(n_layers + 1) + ".pre_norm_mha.0.weight")) ++n_layers;
+  const HostTensor* qw = need(e + "transformer.1.pre_norm_mha.1.qkv_proj.weight");
+  if (!qw || n_layers == 0) { esam3_set_error("encode_text: no transformer layers in the state dict"); return -1; }
+  const int heads = D / 64;
+  float *dtab = fvec(e + "embedding_layer.weight"), *dpos = fvec(e + "positional_embedding.pos_embed.pos_embed");
+  if (!dtab || !dpos) return -1;
+  const int64_t rows = (int64_t)B * S;
+  void* x = allocb((size_t)rows * D * esz);
+  void* y = allocb((size_t)rows * D * esz);
+  void* ln = allocb((size_t)rows * D * esz);
+  void* qkv = allocb((size_t)rows * 3 * D * esz);
+  void* att = allocb((size_t)rows * D * esz);
+  void* hid = allocb((size_t)rows * 4 * D * esz);
+  if (!ok(x) || !ok(y) || !ok(ln) || !ok(qkv) || !ok(att) || !ok(hid)) return -1;
+  if (!dry)
+    CK(prof_launch("text_embed", 0.0, 0.0, [&]() { return esam3_launch_text_embed(dtype, tokens, dtab, dpos, x, embeds_sbd, B, S, D, vocab, st); }));
+  CK(text_repmixer(e + "transformer.0.", x, B, S, D, y));
+  std::swap(x, y);
+  for (int i = 1; i <= n_layers; ++i) {
+    const std::string q = e + "transformer." + std::to_string(i) + ".";
+    CK(layernorm(q + "pre_norm_mha.0", x, ln, rows, D, 1e-5f));
+    CK(linear(q + "pre_norm_mha.1.qkv_proj", ln, D, rows, qkv, 3 * D, ACT_NONE));
+    if (!dry) CK(prof_launch("text_attn", 0.0, 0.0, [&]() { return esam3_launch_text_attn(dtype, qkv, att, B, S, heads, 64, st); }));
+    CK(linear(q + "pre_norm_mha.1.out_proj", att, D, rows, y, D, ACT_NONE, x, D));
+    CK(layernorm(q + "pre_norm_ffn.0", y, ln, rows, D, 1e-5f));
+    CK(linear(q + "pre_norm_ffn.1", ln, D, rows, hid, 4 * D, ACT_GELU));
+    CK(linear(q + "pre_norm_ffn.4", hid, 4 * D, rows, x, D, ACT_NONE, y, D));
+  }
+  CK(text_repmixer(e + "transformer." + std::to_string(n_layers + 1) + ".", x, B, S, D, y));
+  CK(layernorm(e + "final_layer_norm", y, ln, rows, D, 1e-5f));
+  PackedGemm* gp = pk_linear(TEXTP + "projector");
+  if (!gp) return -1;
+  void* mem = allocb((size_t)rows * gp->N * esz);
+  if (!ok(mem)) return -1;
+  CK(gemm(gp, ln, D, rows, 1, 1, mem, gp->N, ACT_NONE));
+  if (!dry) CK(prof_launch("bsc_to_sbc", 0.0, 0.0, [&]() { return esam3_launch_bsc_to_sbc_f32(dtype, mem, memory_sbd, B, S, gp->N, st); }));
+  return 0;
+}
+
 // PositionEmbeddingRandom on the 72x72 grid (prompt_encoder.py:223-234) and its projections
 // through the k_proj / q_proj weights of the image-side cross attentions, so that
 // proj(keys + pe) = proj(keys) + PEproj is a residual in the GEMM epilogue.
@@ -1431,6 +1551,13 @@ int esam3_decode(esam3_engine* e, const esam3_prompts* pr, const esam3_decode_ou
   }
   if (pr->n_points > 0 && (!pr->coords_dev || !pr->labels_dev)) { esam3_set_error("esam3_decode: null coords/labels"); return -1; }
   return run_sized(e, stream, [&]() { return e->decode(pr, out); });
+}
+
+int esam3_encode_text(esam3_engine* e, const int64_t* tokens, int B, int S, float* memory, float* embeds, void* stream) {
+  if (!e || !tokens || !memory || B <= 0 || S <= 0) { esam3_set_error("esam3_encode_text: bad argument"); return -1; }
+  if (!e->finalized) { esam3_set_error("esam3_finalize has not been called"); return -1; }
+  if (!e->find(TEXTP + "projector.weight")) { esam3_set_error("esam3_encode_text: no text-encoder weights were loaded"); return -1; }
+  return run_sized(e, stream, [&]() { return e->encode_text(tokens, B, S, memory, embeds); });
 }
 
 int esam3_postprocess_masks(esam3_engine* e, const float* low_res, int n, int oh, int ow, float max_hole_area,

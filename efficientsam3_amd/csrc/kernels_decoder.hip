@@ -190,6 +190,84 @@ __global__ void build_tokens_kernel(const float* __restrict__ out_tokens, const 
 }
 
 // ------------------------------------------------------------------------------------
+// MobileCLIP-S0 text encoder helpers (backbones/mobile_clip.py).  The sequence is 16..77 tokens
+// long, so these are latency-sized kernels: rows = B*S tokens of 512 channels.
+// ------------------------------------------------------------------------------------
+// forward_embedding (mobile_clip.py:815-823): x[b][s] = table[token] + pos[s]; also the fp32
+// [S][B][D] copy the reference returns as language_embeds (text_encoder_student.py:58).
+template <typename T>
+__global__ void text_embed_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ table,
+                                  const float* __restrict__ pos, T* __restrict__ x, float* __restrict__ embeds_sbd,
+                                  int B, int S, int D, int vocab) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * S * D) return;
+  const int d = (int)(i % D);
+  const int64_t bs = i / D;
+  const int s_ = (int)(bs % S), b = (int)(bs / S);
+  int64_t tok = tokens[bs];
+  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+  const float v = table[tok * D + d] + pos[(int64_t)s_ * D + d];
+  x[i] = from_f32<T>(v);
+  if (embeds_sbd) embeds_sbd[((int64_t)s_ * B + b) * D + d] = v;
+}
+
+// depthwise 1 x KW conv along the sequence with zero padding KW/2 (RepMixer / ConvFFN,
+// mobile_clip.py:499-640 after folding their BatchNorm branches): w [KW][D] fp32, bias [D] or null
+template <typename T>
+__global__ void seq_dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                  T* __restrict__ out, int B, int S, int D, int KW) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * S * D) return;
+  const int d = (int)(i % D);
+  const int64_t bs = i / D;
+  const int s_ = (int)(bs % S);
+  const int64_t b = bs / S;
+  float acc = bias ? bias[d] : 0.f;
+  for (int t = 0; t < KW; ++t) {
+    const int sj = s_ + t - KW / 2;
+    if (sj >= 0 && sj < S) acc = fmaf(w[t * D + d], to_f32<T>(x[(b * S + sj) * D + d]), acc);
+  }
+  out[i] = from_f32<T>(acc);
+}
+
+// MultiHeadAttention (mobile_clip.py:354-425): qkv rows [3][heads][64]; softmax in fp32 over all
+// S keys (no padding mask is passed by the student encoder).  One wavefront per (b, head, query):
+// lane = channel of the 64-wide head.
+template <typename T>
+__global__ __launch_bounds__(64) void text_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int S, int heads) {
+  const int i = blockIdx.x % S;
+  const int h = (blockIdx.x / S) % heads;
+  const int64_t b = blockIdx.x / (S * heads);
+  const int D = heads * 64, lane = threadIdx.x;
+  const T* base = qkv + b * S * 3 * (int64_t)D;
+  const float q = to_f32<T>(base[(int64_t)i * 3 * D + h * 64 + lane]) * 0.125f;  // 64^-0.5
+  float m = -INFINITY, l = 0.f, acc = 0.f;
+  for (int j = 0; j < S; ++j) {
+    float sc = q * to_f32<T>(base[(int64_t)j * 3 * D + D + h * 64 + lane]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o, 64);
+    const float v = to_f32<T>(base[(int64_t)j * 3 * D + 2 * D + h * 64 + lane]);
+    const float mn = fmaxf(m, sc);
+    const float f = __expf(m - mn), p = __expf(sc - mn);
+    l = l * f + p;
+    acc = acc * f + p * v;
+    m = mn;
+  }
+  out[(b * S + i) * (int64_t)D + h * 64 + lane] = from_f32<T>(acc / l);
+}
+
+// [B][S][C] T -> [S][B][C] fp32 (language_features layout, text_encoder_student.py:58)
+template <typename T>
+__global__ void bsc_to_sbc_f32_kernel(const T* __restrict__ x, float* __restrict__ out, int B, int S, int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * S * C) return;
+  const int c = (int)(i % C);
+  const int64_t bs = i / C;
+  const int s_ = (int)(bs % S), b = (int)(bs / S);
+  out[((int64_t)s_ * B + b) * C + c] = to_f32<T>(x[i]);
+}
+
+// ------------------------------------------------------------------------------------
 // PromptEncoder._embed_masks (sam/prompt_encoder.py:51-59,131-134): mask_downscaling =
 // Conv k2s2 1->4, LayerNorm2d, GELU, Conv k2s2 4->16, LayerNorm2d, GELU, Conv 1x1 16->256 on a
 // [Bp,1,288,288] fp32 mask -> dense prompt embedding [Bp][72*72][256].  A workgroup serves 64
@@ -589,6 +667,37 @@ int esam3_launch_build_tokens(int dtype, const float* out_tokens, const float* c
   DISPATCH_T(dtype, hipLaunchKernelGGL(build_tokens_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0,
                                        s, out_tokens, coords, labels, gauss, point_emb, not_a_point,
                                        (T*)tokens, Bp, Np, pad, img_size));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_text_embed(int dtype, const int64_t* tokens, const float* table, const float* pos, void* x,
+                            float* embeds_sbd, int B, int S, int D, int vocab, hipStream_t s) {
+  const int64_t total = (int64_t)B * S * D;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(text_embed_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, tokens, table,
+                                       pos, (T*)x, embeds_sbd, B, S, D, vocab));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int esam3_launch_seq_dwconv(int dtype, const void* x, const float* w, const float* bias, void* out, int B, int S, int D,
+                            int KW, hipStream_t s) {
+  const int64_t total = (int64_t)B * S * D;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(seq_dwconv_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (const T*)x, w,
+                                       bias, (T*)out, B, S, D, KW));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int esam3_launch_text_attn(int dtype, const void* qkv, void* out, int B, int S, int heads, int hd, hipStream_t s) {
+  if (hd != 64) { esam3_set_error("text_attn: head dim %d unsupported", hd); return -1; }
+  DISPATCH_T(dtype, hipLaunchKernelGGL(text_attn_kernel<T>, dim3((unsigned)(B * heads * S)), dim3(64), 0, s, (const T*)qkv,
+                                       (T*)out, S, heads));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int esam3_launch_bsc_to_sbc_f32(int dtype, const void* x, float* out, int B, int S, int C, hipStream_t s) {
+  const int64_t total = (int64_t)B * S * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(bsc_to_sbc_f32_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s,
+                                       (const T*)x, out, B, S, C));
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -153,6 +153,18 @@ class HipEngine:
                        "esam3_encode_image")
         return out
 
+    # ---- text encoder ------------------------------------------------------------------------
+    def encode_text(self, tokens: torch.Tensor):
+        """tokens int64 [B,S] -> (memory fp32 [S,B,256], embeds fp32 [S,B,512]) on this device."""
+        tokens = tokens.to(self.device, torch.int64).contiguous()
+        b, s = tokens.shape
+        mem = torch.empty((s, b, 256), dtype=torch.float32, device=self.device)
+        emb = torch.empty((s, b, 512), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.dev_index):
+            _lib.check(self.lib.esam3_encode_text(self.handle, _ptr(tokens), b, s, _ptr(mem), _ptr(emb), _stream()),
+                       "esam3_encode_text")
+        return mem, emb
+
     # ---- prompt decode -----------------------------------------------------------------------
     def decode(self, sam2_fpn: Sequence[torch.Tensor], prompt_image: torch.Tensor, coords: torch.Tensor,
                labels: torch.Tensor, multimask_output: bool, want_obj: bool = False,

@@ -64,8 +64,10 @@ def build_efficientsam3_image_model(
     """Build an EfficientSAM3 image model whose encode/decode run as HIP kernels on MI355X.
 
     Reference arguments keep their meaning.  ``compile`` is accepted and ignored (there is no
-    tracing compiler; the engine *is* the compiled graph).  ``text_encoder_type`` /
-    ``enable_segmentation`` configure the text-grounding path, which this build does not run yet.
+    tracing compiler; the engine *is* the compiled graph).  ``text_encoder_type="MobileCLIP-S0"`` adds
+    the student text encoder (``model.backbone.language_backbone`` / ``forward_text``; ``bpe_path`` is
+    the reference's merge table); ``enable_segmentation`` configures the PCS grounding head, which
+    this build does not run yet.
     ``dtype``: "bf16" (throughput) or "f32" (validation: exact-f32 MFMA).
     ``fuse_linear_chains``: compose the neck's ConvT->1x1 and 3x3->conv_s0/s1 weight chains at
     load time (exact algebra, same outputs, fewer FLOPs); False runs the reference's layer list.
@@ -75,7 +77,9 @@ def build_efficientsam3_image_model(
     if str(device).startswith("cpu"):
         raise RuntimeError("EfficientSAM3-AMD has no CPU path; pass a HIP device (device='cuda')")
     model = Sam3Image(backbone_type, model_name, bool(enable_inst_interactivity), dtype=dtype,
-                      device=device, dual_neck=dual_neck, fuse_linear_chains=fuse_linear_chains)
+                      device=device, dual_neck=dual_neck, fuse_linear_chains=fuse_linear_chains,
+                      text_encoder_type=text_encoder_type, text_encoder_context_length=text_encoder_context_length,
+                      bpe_path=bpe_path)
     if state_dict is None and checkpoint_path is not None:
         with open(checkpoint_path, "rb") as f:
             ckpt = torch.load(f, map_location="cpu", weights_only=True)
@@ -83,6 +87,9 @@ def build_efficientsam3_image_model(
     if state_dict is None:
         state_dict = schema.synthetic_state_dict(backbone_type, model_name, seed=synthetic_seed,
                                                  enable_inst_interactivity=bool(enable_inst_interactivity))
+        if text_encoder_type is not None:
+            state_dict.update(schema.synthetic_text_state_dict(text_encoder_type, text_encoder_context_length,
+                                                               seed=synthetic_seed))
     model.load_state_dict(state_dict, strict=False)
     return model
 

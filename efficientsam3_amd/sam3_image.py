@@ -17,6 +17,8 @@ import math
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -66,8 +68,39 @@ class _VisionBackbone:
         self.trunk = _Trunk(owner)
 
 
+class _TextStudentEncoder:
+    """Stand-in for TextStudentEncoder (text_encoder_student.py:9-58): tokenizer on the host, the
+    MobileCLIP-S0 transformer on the HIP engine.  ``__call__(text, input_boxes, device)`` ->
+    (mask [B,S] bool True = padding, memory [S,B,256], embeds [S,B,512])."""
+
+    def __init__(self, owner: "Sam3Image", context_length: int, bpe_path=None):
+        self._o = owner
+        self.context_length = context_length
+        self._bpe_path = bpe_path if bpe_path is not None else os.environ.get("ESAM3_BPE_PATH")
+        self._tokenizer = None
+
+    @property
+    def tokenizer(self):
+        if self._tokenizer is None:
+            from .tokenizer import ClipBpeTokenizer
+            self._tokenizer = ClipBpeTokenizer(self._bpe_path, context_length=self.context_length)
+        return self._tokenizer
+
+    def set_context_length(self, context_length: int):
+        """The positional table is sliced per call; only lengths up to the loaded table are valid."""
+        self.context_length = context_length
+
+    def encode_tokens(self, tokenized: torch.Tensor):
+        mem, emb = self._o.engine.encode_text(tokenized)
+        return (tokenized.to(mem.device) == 0), mem, emb
+
+    def __call__(self, text, input_boxes=None, device=None):
+        tokenized = torch.from_numpy(self.tokenizer(text, context_length=self.context_length))
+        return self.encode_tokens(tokenized)
+
+
 class _VLBackbone:
-    """Stand-in for SAM3VLBackbone (image half)."""
+    """Stand-in for SAM3VLBackbone (vl_combiner.py:20-180)."""
 
     def __init__(self, owner: "Sam3Image"):
         self._o = owner
@@ -79,7 +112,20 @@ class _VLBackbone:
         return self._o._forward_image(samples)
 
     def forward_text(self, captions, input_boxes=None, additional_text=None, device=None):
-        raise NotImplementedError("the text encoder is not part of this build yet (SURVEY.md §8 row T0-T4)")
+        """_forward_text_no_ack_ckpt (vl_combiner.py:136-180)."""
+        if self.language_backbone is None:
+            raise NotImplementedError("model was built without text_encoder_type='MobileCLIP-S0'")
+        texts = list(captions) + (list(additional_text) if additional_text is not None else [])
+        mask, memory, embeds = self.language_backbone(texts, input_boxes, device=device)
+        out = {}
+        if additional_text is not None:
+            out["additional_text_features"] = memory[:, -len(additional_text):]
+            out["additional_text_mask"] = mask[-len(additional_text):]
+        n = len(captions)
+        out["language_features"] = memory[:, :n]
+        out["language_mask"] = mask[:n]
+        out["language_embeds"] = embeds[:, :n]
+        return out
 
 
 class _InteractivePredictorInfo:
@@ -96,7 +142,8 @@ class Sam3Image:
 
     def __init__(self, backbone_type: str, model_name: str, enable_inst_interactivity: bool,
                  dtype: str = "bf16", device=None, dual_neck: bool = True,
-                 fuse_linear_chains: bool = True):
+                 fuse_linear_chains: bool = True, text_encoder_type: Optional[str] = None,
+                 text_encoder_context_length: int = 77, bpe_path=None):
         self.backbone_type = backbone_type
         self.model_name = model_name
         self.dual_neck = dual_neck
@@ -107,6 +154,11 @@ class Sam3Image:
         self.backbone = _VLBackbone(self)
         self.inst_interactive_predictor = _InteractivePredictorInfo() if enable_inst_interactivity else None
         self._schema = schema.image_path_schema(backbone_type, model_name, enable_inst_interactivity)
+        self.text_encoder_type = text_encoder_type
+        if text_encoder_type is not None:
+            if text_encoder_type not in schema.TEXT_ENCODER_CFG:
+                raise NotImplementedError(f"text_encoder_type={text_encoder_type!r}: only MobileCLIP-S0 is built")
+            self.backbone.language_backbone = _TextStudentEncoder(self, text_encoder_context_length, bpe_path)
         self._sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         self._pos_cache: Dict[Tuple[int, int], torch.Tensor] = {}
         self.training = False
@@ -134,6 +186,12 @@ class Sam3Image:
         ignored like ``strict=False`` does upstream (model_builder.py:584-630)."""
         if self.engine.finalized:
             raise RuntimeError("weights are already packed on the device; build a new model to reload")
+        if self.text_encoder_type is not None:
+            # checkpoints carry the 77-row positional table (the reference truncates it after loading,
+            # model_builder.py:1035-1047); take whatever length the state dict holds
+            pk = schema.TEXT + "encoder.positional_embedding.pos_embed.pos_embed"
+            rows = int(sd[pk].shape[2]) if pk in sd else self.backbone.language_backbone.context_length
+            self._schema.update(schema.text_encoder_schema(self.text_encoder_type, rows))
         missing = [k for k, (shape, kind) in self._schema.items() if k not in sd and kind != "bn_n"]
         unexpected = [k for k in sd if k not in self._schema]
         if strict and (missing or unexpected):

@@ -345,6 +345,64 @@ def sam_heads_schema() -> _Schema:
     return s
 
 
+TEXT = "backbone.language_backbone."
+TEXT_ENCODER_CFG = {
+    # name: (dim, n_transformer_layers, heads, variant)   model_builder.py:499-560
+    "MobileCLIP-S0": (512, 4, 8, "mct"),
+}
+
+
+def text_encoder_schema(kind: str = "MobileCLIP-S0", context_length: int = 16) -> _Schema:
+    """TextStudentEncoder (text_encoder_student.py:9-58) around MobileCLIPTextTransformer
+    (mobile_clip.py:709-901): token + learned positional embeddings, RepMixerBlock, N x
+    TransformerEncoder, RepMixerBlock ("mct" variant), final LayerNorm, projector 512 -> 256.
+    ``context_length`` is the length of the positional table in the state dict (the reference
+    builds at 77 and truncates to the requested length after loading, model_builder.py:1035-1047)."""
+    dim, n_layers, heads, variant = TEXT_ENCODER_CFG[kind]
+    if variant != "mct":
+        raise NotImplementedError(variant)
+    s = _Schema()
+    e = TEXT + "encoder."
+    s[e + "projection_layer"] = ((dim, dim), "embed")  # present in the reference, unused by this path
+    s[e + "embedding_layer.weight"] = ((49408, dim), "embed")
+    s[e + "positional_embedding.pos_embed.pos_embed"] = ((1, 1, context_length, dim), "embed")
+
+    def bn(name):
+        s.bn(name, dim)
+
+    def repmixer(q):
+        s[q + "layer_scale"] = ((dim, 1, 1), "layer_scale")
+        s[q + "token_mixer.layer_scale"] = ((dim, 1, 1), "layer_scale")
+        bn(q + "token_mixer.norm.rbr_skip")
+        bn(q + "token_mixer.mixer.rbr_skip")
+        s[q + "token_mixer.mixer.rbr_conv.0.conv.weight"] = ((dim, 1, 1, 11), "dw")
+        bn(q + "token_mixer.mixer.rbr_conv.0.bn")
+        s[q + "convffn.conv.conv.weight"] = ((dim, 1, 1, 11), "dw")
+        bn(q + "convffn.conv.bn")
+        s.conv(q + "convffn.fc1", 4 * dim, dim, 1, bias=True)
+        s.conv(q + "convffn.fc2", dim, 4 * dim, 1, bias=True)
+
+    repmixer(e + "transformer.0.")
+    for i in range(1, n_layers + 1):
+        q = e + f"transformer.{i}."
+        s.ln(q + "pre_norm_mha.0", dim)
+        s.linear(q + "pre_norm_mha.1.qkv_proj", 3 * dim, dim)
+        s[q + "pre_norm_mha.1.out_proj.weight"] = ((dim, dim), "linear_res")
+        s[q + "pre_norm_mha.1.out_proj.bias"] = ((dim,), "bias")
+        s.ln(q + "pre_norm_ffn.0", dim)
+        s.linear(q + "pre_norm_ffn.1", 4 * dim, dim)
+        s[q + "pre_norm_ffn.4.weight"] = ((dim, 4 * dim), "linear_res")
+        s[q + "pre_norm_ffn.4.bias"] = ((dim,), "bias")
+    repmixer(e + f"transformer.{n_layers + 1}.")
+    s.ln(e + "final_layer_norm", dim)
+    s.linear(TEXT + "projector", D_MODEL, dim)
+    return s
+
+
+def synthetic_text_state_dict(kind: str = "MobileCLIP-S0", context_length: int = 16, seed: int = 0):
+    return init_state_dict(text_encoder_schema(kind, context_length), seed)
+
+
 def image_path_schema(backbone_type: str = "efficientvit", model_name: str = "b1",
                       enable_inst_interactivity: bool = True) -> _Schema:
     """All tensors read by set_image + predict_inst for a student model."""
@@ -376,7 +434,7 @@ def image_path_schema(backbone_type: str = "efficientvit", model_name: str = "b1
 # residual branch get a small gamma (as trained networks have) so that residual stacks do
 # not blow the activation scale up.
 _ACT_FOLLOWS = ("inverted_conv.conv", "depth_conv.conv", "input_stem.op_list.0.conv", "features.0.0.c",
-                "channel_mixer.m.0.c", "token_mixer.1.fc1", "patch_embed.seq.0.c", "conv1.c", "conv2.c",
+                "channel_mixer.m.0.c", "token_mixer.1.fc1", "patch_embed.seq.0.c", "conv1.c", "conv2.c", "convffn.fc1",
                 "dconv_2x2_0", "output_upscaling.0", "output_upscaling.3", "mask_downscaling.0",
                 "mask_downscaling.3")
 
@@ -390,7 +448,8 @@ def _conv_gain(name: str) -> float:
 
 
 def _linear_gain(name: str) -> float:
-    if "mlp.lin1" in name or ".layers.0." in name or ".layers.1." in name or "mlp.fc1" in name:
+    if "mlp.lin1" in name or ".layers.0." in name or ".layers.1." in name or "mlp.fc1" in name \
+            or "pre_norm_ffn.1." in name:
         return 2.0  # followed by ReLU
     return 1.0
 
@@ -429,6 +488,8 @@ def init_state_dict(schema: _Schema, seed: int = 0) -> "OrderedDict[str, torch.T
             t = randn(shape) * math.sqrt(_linear_gain(name) / shape[1])
         elif kind == "linear_res":  # last linear of a transformer residual branch
             t = randn(shape) * math.sqrt(0.03 / shape[1])
+        elif kind == "layer_scale":  # MobileCLIP RepMixer layer scales (trained values are O(0.1))
+            t = rand(shape, 0.1, 0.5)
         elif kind == "attn_bias":   # TinyViT relative-offset attention biases
             t = randn(shape) * 0.5
         elif kind == "bias":

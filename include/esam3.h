@@ -89,6 +89,12 @@ int esam3_encode_image(esam3_engine* e, const float* img_nchw_f32_dev, int B,
                        const esam3_image_features* out, void* hip_stream);
 int esam3_decode(esam3_engine* e, const esam3_prompts* prompts, const esam3_decode_out* out,
                  void* hip_stream);
+/* TextStudentEncoder.forward after tokenisation (text_encoder_student.py:40-58; MobileCLIP-S0 weights
+ * under "backbone.language_backbone."): tokens int64 [B][S] (device) ->
+ * memory fp32 [S][B][256] (language_features), embeds fp32 [S][B][512] (language_embeds, may be NULL).
+ * The padding mask is tokens == 0 and stays on the host side. */
+int esam3_encode_text(esam3_engine* e, const int64_t* tokens_dev, int B, int S, float* memory_sbd_dev,
+                      float* embeds_sbd_dev, void* hip_stream);
 /* low_res: [n][288][288] fp32 -> masks at (out_h, out_w); either output may be NULL */
 int esam3_postprocess_masks(esam3_engine* e, const float* low_res_dev, int n_masks, int out_h,
                             int out_w, float max_hole_area, float mask_threshold,

@@ -690,3 +690,70 @@ def predict_inst(sd: SD, state: dict, point_coords=None, point_labels=None, box=
         masks = masks > 0.0
     return (masks.squeeze(0).float().numpy(), iou.squeeze(0).float().numpy(),
             low_res.squeeze(0).float().numpy())
+
+
+# --------------------------------------------------------------------------
+# MobileCLIP-S0 student text encoder (text_encoder_student.py, backbones/mobile_clip.py)
+# --------------------------------------------------------------------------
+TEXT = "backbone.language_backbone."
+
+
+def _bn2d(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"],
+                        False, 0.0, BN_EPS)
+
+
+def _repmixer_block(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """RepMixerBlock.forward (mobile_clip.py:647-702) on [B, S, D], training-time branches:
+    token mixer x + ls*(mixer(x) - norm(x)) with mixer = BN(x) + BN(dw1x11(x)), norm = BN(x)
+    (MobileOneBlock, mobile_clip.py:49-160; the (1,11) kernel disables the scale branch), then
+    x + ls * ConvFFN(x) (dw1x11 + BN, 1x1 -> GELU -> 1x1; mobile_clip.py:499-548)."""
+    x = x.permute(0, 2, 1).unsqueeze(2)  # [B, D, 1, S]
+    d = x.shape[1]
+    t = p + "token_mixer."
+    mixer = _bn2d(sd, t + "mixer.rbr_skip", x) + _bn2d(
+        sd, t + "mixer.rbr_conv.0.bn", F.conv2d(x, sd[t + "mixer.rbr_conv.0.conv.weight"], None, 1, (0, 5), 1, d))
+    norm = _bn2d(sd, t + "norm.rbr_skip", x)
+    x = x + sd[t + "layer_scale"] * (mixer - norm)
+    c = p + "convffn."
+    y = _bn2d(sd, c + "conv.bn", F.conv2d(x, sd[c + "conv.conv.weight"], None, 1, (0, 5), 1, d))
+    y = F.gelu(F.conv2d(y, sd[c + "fc1.weight"], sd[c + "fc1.bias"]))
+    y = F.conv2d(y, sd[c + "fc2.weight"], sd[c + "fc2.bias"])
+    x = x + sd[p + "layer_scale"] * y
+    return x.squeeze(2).permute(0, 2, 1)
+
+
+def _text_transformer_layer(sd: SD, p: str, x: torch.Tensor, heads: int) -> torch.Tensor:
+    """TransformerEncoder.forward (mobile_clip.py:427-491): pre-norm MHA over ALL positions (the
+    student passes no key-padding mask, text_encoder_student.py:48-50; S0 is non-causal) and
+    pre-norm FFN."""
+    b, s_len, d = x.shape
+    y = F.layer_norm(x, (d,), sd[p + "pre_norm_mha.0.weight"], sd[p + "pre_norm_mha.0.bias"], 1e-5)
+    a = p + "pre_norm_mha.1."
+    qkv = F.linear(y, sd[a + "qkv_proj.weight"], sd[a + "qkv_proj.bias"]).reshape(b, s_len, 3, heads, -1)
+    qkv = qkv.transpose(1, 3).contiguous()  # [B, heads, 3, S, hd]
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    attn = torch.matmul(q * (q.shape[-1] ** -0.5), k.transpose(-1, -2)).float().softmax(-1)
+    o = torch.matmul(attn, v).transpose(1, 2).reshape(b, s_len, -1)
+    x = F.linear(o, sd[a + "out_proj.weight"], sd[a + "out_proj.bias"]) + x
+    y = F.layer_norm(x, (d,), sd[p + "pre_norm_ffn.0.weight"], sd[p + "pre_norm_ffn.0.bias"], 1e-5)
+    y = F.gelu(F.linear(y, sd[p + "pre_norm_ffn.1.weight"], sd[p + "pre_norm_ffn.1.bias"]))
+    return x + F.linear(y, sd[p + "pre_norm_ffn.4.weight"], sd[p + "pre_norm_ffn.4.bias"])
+
+
+def text_encoder_student(sd: SD, tokens: torch.Tensor, n_layers: int = 4, heads: int = 8):
+    """TextStudentEncoder.forward after tokenisation (text_encoder_student.py:40-58):
+    tokens int64 [B, S] -> (mask [B,S] True = padding, memory [S,B,256], embeds [S,B,512]).
+    embed_scale is computed by the reference but never applied (mobile_clip.py:743,815-823)."""
+    e = TEXT + "encoder."
+    s_len = tokens.shape[1]
+    emb = F.embedding(tokens, sd[e + "embedding_layer.weight"])
+    emb = emb + sd[e + "positional_embedding.pos_embed.pos_embed"][0, 0, :s_len][None]
+    x = _repmixer_block(sd, e + "transformer.0.", emb)
+    for i in range(1, n_layers + 1):
+        x = _text_transformer_layer(sd, e + f"transformer.{i}.", x, heads)
+    x = _repmixer_block(sd, e + f"transformer.{n_layers + 1}.", x)
+    d = x.shape[-1]
+    x = F.layer_norm(x, (d,), sd[e + "final_layer_norm.weight"], sd[e + "final_layer_norm.bias"], 1e-5)
+    mem = F.linear(x, sd[TEXT + "projector.weight"], sd[TEXT + "projector.bias"])
+    return tokens == 0, mem.transpose(0, 1), emb.transpose(0, 1)
