@@ -58,6 +58,7 @@ SIGNATURES = {
     "esam3_postprocess_masks": (_I, [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P]),
     "esam3_clamp_f32": (_I, [_P, _P, _L, _F, _F, _P]),
     "esam3_profile_enable": (_I, [_P, _I]),
+    "esam3_profile_tag": (_I, [_P, C.c_char_p]),
     "esam3_profile_report": (_I, [_P, C.c_char_p, _L]),
     "esam3_workspace_bytes": (_L, [_P]),
     "esam3_elem_size": (_I, [_P]),

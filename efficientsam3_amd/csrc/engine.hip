@@ -118,10 +118,26 @@ struct esam3_engine {
   bool dry = false;  // allocate + pack only, launch nothing
   hipStream_t st = nullptr;
 
-  // ---------------- optional per-launch profiler (HIP events on the launch stream) --------
   struct ProfRec { std::string tag; hipEvent_t a, b; double flops, bytes; const char* kernel; };
-  bool prof = false;
   std::vector<ProfRec> recs;
+  // bench.py's live roofline leg: the GEMM launches whose tag equals `watch_tag` (esam3_profile_tag)
+  // are bracketed by HIP events on the launch stream while everything else runs un-instrumented.
+  std::string watch_tag;  // empty: nothing watched
+  int timed_gemm(const std::string& tag, double flops, double bytes, const GemmParams& p, hipStream_t s) {
+    ProfRec r{tag, nullptr, nullptr, flops, bytes, nullptr};
+    esam3_take_last_gemm_kernel();
+    HIP_CHECK_RET(hipEventCreate(&r.a));
+    HIP_CHECK_RET(hipEventCreate(&r.b));
+    HIP_CHECK_RET(hipEventRecord(r.a, s));
+    const int rc = esam3_launch_gemm(dtype, p, s);
+    HIP_CHECK_RET(hipEventRecord(r.b, s));
+    r.kernel = esam3_take_last_gemm_kernel();
+    recs.push_back(r);
+    return rc;
+  }
+
+  // ---------------- optional per-launch profiler (HIP events on the launch stream) --------
+  bool prof = false;
   int prof_launch(const std::string& tag, double flops, double bytes, const std::function<int()>& fn) {
     if (!prof) return fn();
     ProfRec r{tag, nullptr, nullptr, flops, bytes, nullptr};
@@ -426,7 +442,9 @@ struct esam3_engine {
     p.stride = stride;
     const double uniq_in = (double)M * g->cin * (g->ksize == 3 ? 1 : 1);
     const double bytes = (uniq_in + (double)g->N * g->K + (double)M * g->N + (res ? (double)M * g->N : 0.0)) * (double)esz;
-    return prof_launch(g->tag, 2.0 * (double)M * g->N * g->K, bytes, [&]() { return esam3_launch_gemm(dtype, p, st); });
+    const double flops = 2.0 * (double)M * g->N * g->K;
+    if (!prof && !watch_tag.empty() && g->tag == watch_tag) return timed_gemm(g->tag, flops, bytes, p, st);
+    return prof_launch(g->tag, flops, bytes, [&]() { return esam3_launch_gemm(dtype, p, st); });
   }
   // 1x1 / 3x3 conv on an NHWC view -> new tensor (or into `dst` if given)
   int conv(const std::string& prefix, bool convlayer, const T4& x, int act, T4* y, const T4* res = nullptr,
@@ -613,7 +631,7 @@ int E::evit_block(const std::string& p, const T4& x, T4* y) {
       CK(gemm(gbd, agg.p, agg.ld, ms.rows(), 1, 1, (char*)ms.p + (size_t)total3 * esz, ms.ld, ACT_NONE));
     }
     T4 att = alloc4(x.B, x.H, x.W, 2 * heads * dim);
-    float* kv = (float*)allocb(sizeof(float) * (size_t)x.B * 2 * heads * (dim + 1) * dim);
+    float* kv = (float*)allocb(sizeof(float) * (size_t)esam3_lite_mla_scratch_floats(x.B, x.H * x.W, 2 * heads, dim));
     if (!ok(att.p) || !ok(kv)) return -1;
     if (!dry)
       CK(prof_launch("lite_mla", 4.0 * (double)ms.rows() * 2 * heads * (dim + 1) * dim,
@@ -709,7 +727,7 @@ int E::squeeze_excite(const std::string& p, T4& x) {
   float *d1 = fvec(p + "fc1.weight"), *b1 = fvec(p + "fc1.bias"), *d2 = fvec(p + "fc2.weight"), *b2 = fvec(p + "fc2.bias");
   if (!d1 || !b1 || !d2 || !b2) return -1;
   const size_t mk = arena.mark();
-  float* sums = (float*)allocb(sizeof(float) * (size_t)x.B * x.C);
+  float* sums = (float*)allocb(sizeof(float) * (size_t)esam3_squeeze_excite_scratch_floats(x.B, x.H * x.W, x.C));
   float* gate = (float*)allocb(sizeof(float) * (size_t)x.B * x.C);
   if (!ok(sums) || !ok(gate)) return -1;
   int rc = 0;
@@ -1483,6 +1501,7 @@ int esam3_create(const esam3_config* cfg, esam3_engine** out) {
 void esam3_destroy(esam3_engine* e) {
   if (!e) return;
   hipDeviceSynchronize();
+
   for (void* p : e->owned) hipFree(p);
   if (e->arena.base) hipFree(e->arena.base);
   delete e;
@@ -1604,6 +1623,14 @@ int esam3_profile_enable(esam3_engine* e, int on) {
   for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   e->recs.clear();
   e->prof = on != 0;
+  return 0;
+}
+
+int esam3_profile_tag(esam3_engine* e, const char* tag) {
+  if (!e) return -1;
+  e->watch_tag = tag ? tag : "";
+  for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  e->recs.clear();
   return 0;
 }
 

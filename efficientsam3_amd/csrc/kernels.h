@@ -29,6 +29,8 @@ int esam3_launch_grouped_pw(int dtype, const void* in, int ld_in, const float* w
 
 // LiteMLA ReLU linear attention (ops.py:584-621).  ms: [B][N][ld] with `groups` groups of
 // (q|k|v) x dim channels; kv: fp32 scratch [B][groups][dim+1][dim]; out: [B][N][ld_out].
+// kv: fp32 scratch of esam3_lite_mla_scratch_floats() elements
+int64_t esam3_lite_mla_scratch_floats(int B, int N, int groups, int dim);
 int esam3_launch_lite_mla(int dtype, const void* ms, int ld, void* out, int ld_out, float* kv,
                           int B, int N, int groups, int dim, hipStream_t s);
 
@@ -110,7 +112,8 @@ int esam3_launch_preprocess_u8(const uint8_t* in, float* out, int B, int H, int 
 // bias [heads][ws*ws] fp32 indexed by |dy|*ws+|dx|; out [B][H][W][heads*32]
 int esam3_launch_window_attn(int dtype, const void* qkv, int ld, const void* pad_qkv, const float* bias, void* out,
                              int ldo, int B, int H, int W, int heads, int ws, hipStream_t s);
-// in-place squeeze-excite on x [B][HW][C]; sums/gate: [B][C] fp32 scratch; w1 [R][C], w2 [C][R] (device fp32)
+// in-place squeeze-excite on x [B][HW][C]; sums: esam3_squeeze_excite_scratch_floats() fp32, gate: [B][C] fp32; w1 [R][C], w2 [C][R] (device fp32)
+int64_t esam3_squeeze_excite_scratch_floats(int B, int HW, int C);
 int esam3_launch_squeeze_excite(int dtype, void* x, int ld, float* sums, float* gate, const float* w1,
                                 const float* b1, const float* w2, const float* b2, int B, int HW, int C, int R,
                                 hipStream_t s);

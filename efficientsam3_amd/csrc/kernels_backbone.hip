@@ -366,17 +366,18 @@ template <> __device__ inline void load4<float>(const float* p, float* v) {
 
 // kv reduction with every accumulator in registers: block = (image, token split), thread =
 // (token lane, group, part) where a part owns 4 of the DIM v-rows of its group's (DIM+1) x DIM
-// matrix.  A token's row of `ms` is read by groups*DIM/4 adjacent threads, i.e. fully coalesced;
-// the token lanes are merged through LDS atomics and the splits through global atomics.
+// matrix.  A token's row of `ms` is read by groups*DIM/4 adjacent threads, i.e. fully coalesced.
+// The reduction is DETERMINISTIC: token lanes are summed in lane order through LDS, the splits are
+// written as partials and summed in split order by mla_kv_sum_kernel (no floating-point atomics,
+// so repeated runs give bit-identical results).
 template <typename T, int DIM>
-__global__ __launch_bounds__(256) void mla_kv_kernel(const T* __restrict__ ms, int ld, float* __restrict__ kv,
+__global__ __launch_bounds__(256) void mla_kv_kernel(const T* __restrict__ ms, int ld, float* __restrict__ partial,
                                                      int N, int groups, int n_split) {
   constexpr int P = DIM / 4;
   constexpr int PAIRS = (DIM + 1) * DIM;
-  extern __shared__ float skv[];  // [groups][PAIRS]
-  for (int i = threadIdx.x; i < groups * PAIRS; i += 256) skv[i] = 0.f;
-  __syncthreads();
+  extern __shared__ float skv[];  // [TL][groups][PAIRS]
   const int tpt = groups * P, TL = 256 / tpt;
+  const int GP = groups * PAIRS;
   const int split = blockIdx.x % n_split;
   const int64_t b = blockIdx.x / n_split;
   const int tl = threadIdx.x / tpt, r = threadIdx.x - tl * tpt;
@@ -407,22 +408,35 @@ __global__ __launch_bounds__(256) void mla_kv_kernel(const T* __restrict__ ms, i
         for (int i = 0; i < 4; ++i) acc[i][j] = fmaf(v[i], k[j], acc[i][j]);
       }
     }
-    float* o = skv + g * PAIRS;
+    float* o = skv + (size_t)tl * GP + g * PAIRS;  // every element of this lane's slice has one writer
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < DIM; ++j) atomicAdd(&o[(4 * part + i) * DIM + j], acc[i][j]);
+      for (int j = 0; j < DIM; ++j) o[(4 * part + i) * DIM + j] = acc[i][j];
     if (part == 0) {
 #pragma unroll
-      for (int j = 0; j < DIM; ++j) atomicAdd(&o[DIM * DIM + j], ksum[j]);
+      for (int j = 0; j < DIM; ++j) o[DIM * DIM + j] = ksum[j];
     }
   }
   __syncthreads();
-  float* out = kv + b * groups * (int64_t)PAIRS;
-  for (int i = threadIdx.x; i < groups * PAIRS; i += 256) {
-    if (n_split == 1) out[i] = skv[i];
-    else unsafeAtomicAdd(out + i, skv[i]);
+  float* out = partial + (b * n_split + split) * (int64_t)GP;
+  for (int i = threadIdx.x; i < GP; i += 256) {
+    float a = skv[i];
+    for (int t = 1; t < TL; ++t) a += skv[(size_t)t * GP + i];
+    out[i] = a;
   }
+}
+
+__global__ void mla_kv_sum_kernel(const float* __restrict__ partial, float* __restrict__ kv, int GP, int n_split,
+                                  int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, element)
+  if (i >= total) return;
+  const int64_t b = i / GP;
+  const int e = (int)(i - b * GP);
+  const float* p = partial + b * n_split * (int64_t)GP + e;
+  float a = p[0];
+  for (int sp = 1; sp < n_split; ++sp) a += p[(int64_t)sp * GP];
+  kv[i] = a;
 }
 
 // out = (kv . relu(q)) / den.  kv sits in LDS as [pair/4][group][4] so that the 16-lane groups of
@@ -493,13 +507,11 @@ __global__ __launch_bounds__(256) void mla_apply_kernel(const T* __restrict__ ms
 // workgroup per image), and the in-place scaling.  fp32 statistics regardless of T.
 // ------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void se_pool_kernel(const T* __restrict__ x, int ld, float* __restrict__ sums,
+__global__ __launch_bounds__(256) void se_pool_kernel(const T* __restrict__ x, int ld, float* __restrict__ partial,
                                                       int HW, int C, int splits) {
-  extern __shared__ float red[];  // [C]
+  extern __shared__ float red[];  // [lanes][C]; deterministic: lanes are summed in order, no atomics
   const int CG = C / VEC;
   const int b = blockIdx.x / splits, sp = blockIdx.x - b * splits;
-  for (int i = threadIdx.x; i < C; i += 256) red[i] = 0.f;
-  __syncthreads();
   const int lanes = 256 / CG;  // pixel lanes (launcher guarantees CG <= 256)
   const int pl = threadIdx.x / CG, cg = threadIdx.x - pl * CG;
   if (pl < lanes) {
@@ -515,21 +527,29 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const T* __restrict__ x, i
       for (int e = 0; e < VEC; ++e) acc[e] += v[e];
     }
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) atomicAdd(&red[cg * VEC + e], acc[e]);
+    for (int e = 0; e < VEC; ++e) red[pl * C + cg * VEC + e] = acc[e];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) unsafeAtomicAdd(sums + (int64_t)b * C + i, red[i]);
+  for (int i = threadIdx.x; i < C; i += 256) {
+    float a = red[i];
+    for (int l = 1; l < lanes; ++l) a += red[l * C + i];
+    partial[((int64_t)b * splits + sp) * C + i] = a;
+  }
 }
 
-__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ sums, const float* __restrict__ w1,
-                                                    const float* __restrict__ b1, const float* __restrict__ w2,
-                                                    const float* __restrict__ b2, float* __restrict__ gate, int C,
-                                                    int R, float inv_hw) {
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ partial, int splits,
+                                                    const float* __restrict__ w1, const float* __restrict__ b1,
+                                                    const float* __restrict__ w2, const float* __restrict__ b2,
+                                                    float* __restrict__ gate, int C, int R, float inv_hw) {
   extern __shared__ float sm[];  // mean[C] | hidden[R]
   float* mean = sm;
   float* hid = sm + C;
   const int b = blockIdx.x;
-  for (int i = threadIdx.x; i < C; i += 256) mean[i] = sums[(int64_t)b * C + i] * inv_hw;
+  for (int i = threadIdx.x; i < C; i += 256) {
+    float a = 0.f;
+    for (int sp = 0; sp < splits; ++sp) a += partial[((int64_t)b * splits + sp) * C + i];
+    mean[i] = a * inv_hw;
+  }
   __syncthreads();
   for (int r = threadIdx.x; r < R; r += 256) {
     float a = b1[r];
@@ -990,6 +1010,22 @@ int esam3_launch_grouped_pw(int dtype, const void* in, int ld_in, const float* w
   return 0;
 }
 
+// token splits of the kv reduction for (B, N, threads-per-token)
+static int mla_splits(int B, int N, int tpt) {
+  const int TL = 256 / tpt;
+  int n_split = 1;
+  while ((int64_t)B * n_split < 1024 && N / (n_split * 2) >= 16 * TL) n_split *= 2;
+  return n_split;
+}
+
+// fp32 scratch needed by esam3_launch_lite_mla: final kv [B][groups][PAIRS] + per-split partials
+int64_t esam3_lite_mla_scratch_floats(int B, int N, int groups, int dim) {
+  const int64_t gp = (int64_t)groups * (dim + 1) * dim;
+  const int tpt = groups * (dim / 4);
+  const int n_split = tpt <= 256 ? mla_splits(B, N, tpt) : 1;
+  return (int64_t)B * gp * (1 + n_split);
+}
+
 template <typename T, int DIM>
 static int lite_mla_t(const void* ms, int ld, void* out, int ld_out, float* kv, int B, int N,
                       int groups, hipStream_t s) {
@@ -997,15 +1033,24 @@ static int lite_mla_t(const void* ms, int ld, void* out, int ld_out, float* kv, 
   if (groups > 256) { esam3_set_error("lite_mla: groups=%d too large", groups); return -1; }
   const size_t lds = sizeof(float) * (size_t)groups * PAIRS;
   const int tpt = groups * (DIM / 4);
-  int n_split = 1;
-  if (tpt <= 256 && lds <= 64 * 1024) {
-    const int TL = 256 / tpt;
-    while ((int64_t)B * n_split < 1024 && N / (n_split * 2) >= 16 * TL) n_split *= 2;
-    if (n_split > 1)
-      HIP_CHECK_RET(hipMemsetAsync(kv, 0, sizeof(float) * (size_t)B * groups * PAIRS, s));
-    hipLaunchKernelGGL((mla_kv_kernel<T, DIM>), dim3((unsigned)(B * n_split)), dim3(256), lds, s,
-                       (const T*)ms, ld, kv, N, groups, n_split);
-  } else {
+  const size_t lds_kv = tpt <= 256 ? lds * (256 / tpt) : 0;
+  if (tpt <= 256 && lds_kv <= 160 * 1024 - 1024) {
+    const int n_split = mla_splits(B, N, tpt);
+    float* partial = kv + (size_t)B * groups * PAIRS;
+    auto kern = mla_kv_kernel<T, DIM>;
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024 - 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(B * n_split)), dim3(256), lds_kv, s, (const T*)ms, ld, partial, N, groups,
+                       n_split);
+    const int64_t total = (int64_t)B * groups * PAIRS;
+    hipLaunchKernelGGL(mla_kv_sum_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, s, partial, kv, groups * PAIRS,
+                       n_split, total);
+  } else {  // unusual head counts: generic kernel (global fp32 atomics, order-dependent rounding)
+    int n_split = 1;
     while ((int64_t)B * groups * n_split < 512 && N / (n_split * 2) >= 256) n_split *= 2;
     if (n_split > 1)
       HIP_CHECK_RET(hipMemsetAsync(kv, 0, sizeof(float) * (size_t)B * groups * PAIRS, s));
@@ -1067,17 +1112,24 @@ int esam3_launch_window_attn(int dtype, const void* qkv, int ld, const void* pad
   return -1;
 }
 
+static int se_splits(int B, int HW) {
+  int splits = 1;
+  while (B * splits < 1024 && HW / (splits * 2) >= 64) splits *= 2;
+  return splits;
+}
+// fp32 scratch of esam3_launch_squeeze_excite: per-split channel sums [B][splits][C]
+int64_t esam3_squeeze_excite_scratch_floats(int B, int HW, int C) { return (int64_t)B * se_splits(B, HW) * C; }
+
 int esam3_launch_squeeze_excite(int dtype, void* x, int ld, float* sums, float* gate, const float* w1,
                                 const float* b1, const float* w2, const float* b2, int B, int HW, int C, int R,
                                 hipStream_t s) {
   if (C % VEC || C / VEC > 256 || C + R > 12288) { esam3_set_error("squeeze_excite: C=%d R=%d", C, R); return -1; }
-  HIP_CHECK_RET(hipMemsetAsync(sums, 0, sizeof(float) * (size_t)B * C, s));
-  int splits = 1;
-  while (B * splits < 1024 && HW / (splits * 2) >= 64) splits *= 2;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(se_pool_kernel<T>, dim3((unsigned)(B * splits)), dim3(256), sizeof(float) * C, s,
-                                       (const T*)x, ld, sums, HW, C, splits));
-  hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)B), dim3(256), sizeof(float) * (C + R), s, sums, w1, b1, w2, b2, gate,
-                     C, R, 1.0f / (float)HW);
+  const int splits = se_splits(B, HW);
+  const int lanes = 256 / (C / VEC);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(se_pool_kernel<T>, dim3((unsigned)(B * splits)), dim3(256),
+                                       sizeof(float) * (size_t)lanes * C, s, (const T*)x, ld, sums, HW, C, splits));
+  hipLaunchKernelGGL(se_fc_kernel, dim3((unsigned)B), dim3(256), sizeof(float) * (C + R), s, sums, splits, w1, b1, w2, b2,
+                     gate, C, R, 1.0f / (float)HW);
   const int64_t total = (int64_t)B * HW * (C / VEC);
   DISPATCH_T(dtype, hipLaunchKernelGGL(se_scale_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (T*)x, ld,
                                        gate, HW, C, total));

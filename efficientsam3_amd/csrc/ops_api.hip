@@ -128,7 +128,7 @@ int esam3_op_squeeze_excite(int dtype, void* x, const float* w1, const float* b1
   float* e1 = (float*)t.up(b1, (size_t)R * 4);
   float* d2 = (float*)t.up(w2, (size_t)R * C * 4);
   float* e2 = (float*)t.up(b2, (size_t)C * 4);
-  float* sums = (float*)t.raw((size_t)B * C * 4);
+  float* sums = (float*)t.raw((size_t)esam3_squeeze_excite_scratch_floats(B, HW, C) * 4);
   float* gate = (float*)t.raw((size_t)B * C * 4);
   if (!d1 || !e1 || !d2 || !e2 || !sums || !gate) return fail("op_squeeze_excite");
   if (esam3_launch_squeeze_excite(dtype, x, C, sums, gate, d1, e1, d2, e2, B, HW, C, R, (hipStream_t)stream)) return -1;
@@ -241,7 +241,7 @@ int esam3_op_stem(int dtype, const float* img, const float* w, const float* bias
 
 int esam3_op_lite_mla(int dtype, const void* ms, void* out, int B, int N, int groups, int dim, void* stream) {
   Tmp t;
-  float* kv = (float*)t.raw(sizeof(float) * (size_t)B * groups * (dim + 1) * dim);
+  float* kv = (float*)t.raw(sizeof(float) * (size_t)esam3_lite_mla_scratch_floats(B, N, groups, dim));
   if (!kv) return fail("op_lite_mla");
   if (esam3_launch_lite_mla(dtype, ms, groups * 3 * dim, out, groups * dim, kv, B, N, groups, dim,
                             (hipStream_t)stream))

@@ -119,33 +119,40 @@ class HipEngine:
         return out_chw
 
     def encode(self, img_nchw: torch.Tensor, want_sam3: bool = True, want_sam2: bool = True,
-               want_trunk: bool = False, want_stages: bool = False) -> dict:
-        """img_nchw: [B,3,1008,1008] fp32 normalised, on this engine's device."""
+               want_trunk: bool = False, want_stages: bool = False, out: Optional[dict] = None) -> dict:
+        """img_nchw: [B,3,1008,1008] fp32 normalised, on this engine's device.  ``out``: a dict
+        returned by an earlier call with the same arguments -- its buffers are reused instead of
+        allocating new ones."""
         assert img_nchw.is_cuda and img_nchw.dtype == torch.float32
         assert tuple(img_nchw.shape[1:]) == (3, NET_RES, NET_RES), img_nchw.shape
         img_nchw = img_nchw.contiguous()
         b = img_nchw.shape[0]
         dt, dev = self.torch_dtype, self.device
         feats = _lib.ImageFeatures()
-        out: dict = {}
+        reuse = out if out is not None else {}
+        out = {}
 
-        def buf(h, c):
+        def buf(key, i, h, c):
+            old = reuse.get(key)
+            old = old[i] if isinstance(old, list) else old
+            if old is not None and tuple(old.shape) == (b, h, h, c) and old.dtype == dt:
+                return old
             return torch.empty((b, h, h, c), dtype=dt, device=dev)
 
         if want_sam3:
-            out["sam3_fpn"] = [buf(288, 256), buf(144, 256), buf(72, 256)]
+            out["sam3_fpn"] = [buf("sam3_fpn", i, h, c) for i, (h, c) in enumerate(((288, 256), (144, 256), (72, 256)))]
             for i, t in enumerate(out["sam3_fpn"]):
                 feats.sam3_fpn_dev[i] = t.data_ptr()
         if want_sam2:
-            out["sam2_fpn"] = [buf(288, 32), buf(144, 64), buf(72, 256)]
+            out["sam2_fpn"] = [buf("sam2_fpn", i, h, c) for i, (h, c) in enumerate(((288, 32), (144, 64), (72, 256)))]
             for i, t in enumerate(out["sam2_fpn"]):
                 feats.sam2_fpn_dev[i] = t.data_ptr()
         if want_trunk:
-            out["trunk"] = buf(72, 1024)
+            out["trunk"] = buf("trunk", 0, 72, 1024)
             feats.trunk_dev = out["trunk"].data_ptr()
         if want_stages:
             widths, sizes = stage_shapes(self.backbone_type, self.model_name)
-            out["stages"] = [torch.empty((b, s, s, c), dtype=dt, device=dev) for s, c in zip(sizes, widths)]
+            out["stages"] = [buf("stages", i, s, c) for i, (s, c) in enumerate(zip(sizes, widths))]
             for i, t in enumerate(out["stages"]):
                 feats.stages_dev[i] = t.data_ptr()
         with torch.cuda.device(self.dev_index):
@@ -168,7 +175,7 @@ class HipEngine:
     # ---- prompt decode -----------------------------------------------------------------------
     def decode(self, sam2_fpn: Sequence[torch.Tensor], prompt_image: torch.Tensor, coords: torch.Tensor,
                labels: torch.Tensor, multimask_output: bool, want_obj: bool = False,
-               mask_input: Optional[torch.Tensor] = None):
+               mask_input: Optional[torch.Tensor] = None, out: Optional[tuple] = None):
         """coords [Bp,Np,2] fp32 network pixels (or None: no point/box prompt), labels [Bp,Np] int32,
         prompt_image [Bp] int32, mask_input optional [Bp,288,288] fp32 low-res logits (all on device).
         Returns (low_res [Bp,C,288,288] fp32 unclamped, iou [Bp,C] fp32[, obj [Bp]])."""
@@ -181,8 +188,11 @@ class HipEngine:
             assert mask_input.shape == (bp, LOW_RES, LOW_RES) and mask_input.dtype == torch.float32
             assert mask_input.is_cuda and mask_input.is_contiguous()
         c = 3 if multimask_output else 1
-        low = torch.empty((bp, c, LOW_RES, LOW_RES), dtype=torch.float32, device=self.device)
-        iou = torch.empty((bp, c), dtype=torch.float32, device=self.device)
+        if out is not None and tuple(out[0].shape) == (bp, c, LOW_RES, LOW_RES):
+            low, iou = out[0], out[1]  # reuse the buffers of an earlier call
+        else:
+            low = torch.empty((bp, c, LOW_RES, LOW_RES), dtype=torch.float32, device=self.device)
+            iou = torch.empty((bp, c), dtype=torch.float32, device=self.device)
         obj = torch.empty((bp,), dtype=torch.float32, device=self.device) if want_obj else None
         pr = _lib.Prompts()
         for i in range(3):
@@ -202,18 +212,17 @@ class HipEngine:
         return (low, iou, obj) if want_obj else (low, iou)
 
     def postprocess(self, low_res: torch.Tensor, orig_hw: Tuple[int, int], return_logits: bool,
-                    max_hole_area: float = 256.0, mask_threshold: float = 0.0) -> torch.Tensor:
+                    max_hole_area: float = 256.0, mask_threshold: float = 0.0,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """low_res [..., 288, 288] fp32 -> masks [..., H, W]: uint8 0/1, or fp32 logits."""
         lead = low_res.shape[:-2]
         n = int(np.prod(lead)) if len(lead) else 1
         h, w = int(orig_hw[0]), int(orig_hw[1])
         low_res = low_res.contiguous()
-        if return_logits:
-            out = torch.empty((*lead, h, w), dtype=torch.float32, device=self.device)
-            u8, f32 = None, out
-        else:
-            out = torch.empty((*lead, h, w), dtype=torch.uint8, device=self.device)
-            u8, f32 = out, None
+        want = torch.float32 if return_logits else torch.uint8
+        if out is None or tuple(out.shape) != (*lead, h, w) or out.dtype != want:
+            out = torch.empty((*lead, h, w), dtype=want, device=self.device)
+        u8, f32 = (None, out) if return_logits else (out, None)
         with torch.cuda.device(self.dev_index):
             _lib.check(self.lib.esam3_postprocess_masks(self.handle, _ptr(low_res), n, h, w, float(max_hole_area),
                                                         float(mask_threshold), _ptr(u8), _ptr(f32), _stream()),
@@ -226,6 +235,10 @@ class HipEngine:
 
     def profile_enable(self, on: bool = True):
         _lib.check(self.lib.esam3_profile_enable(self.handle, int(on)), "esam3_profile_enable")
+
+    def profile_tag(self, tag: Optional[str]):
+        """Time only the GEMM launches with this tag (HIP events); everything else runs un-instrumented."""
+        _lib.check(self.lib.esam3_profile_tag(self.handle, tag.encode() if tag else None), "esam3_profile_tag")
 
     def profile_report(self) -> list:
         """Per-tag HIP-event timings recorded since profile_enable(True): list of dicts

@@ -117,6 +117,10 @@ int esam3_preprocess_resize_u8(const uint8_t* img_hwc_u8_dev, int H, int W, floa
  * run encode/decode, then fetch a JSON report (syncs the device, clears the records). */
 int esam3_profile_enable(esam3_engine* e, int on);
 int esam3_profile_report(esam3_engine* e, char* json_buf, int64_t buf_size);
+/* Time only the GEMM launches whose tag (= weight name, as listed by esam3_profile_report) equals
+ * `tag`, with HIP events on the launch stream; every other launch runs un-instrumented (bench.py's
+ * live roofline leg).  NULL or "" stops watching.  Clears the collected records. */
+int esam3_profile_tag(esam3_engine* e, const char* tag);
 
 /* bytes of engine workspace currently reserved, and size of one activation element */
 int64_t esam3_workspace_bytes(const esam3_engine* e);
