@@ -403,6 +403,37 @@ def synthetic_text_state_dict(kind: str = "MobileCLIP-S0", context_length: int =
     return init_state_dict(text_encoder_schema(kind, context_length), seed)
 
 
+VIT_TRUNK = NECK + "trunk."
+VIT_CFG = dict(embed_dim=1024, depth=32, heads=16, mlp_hidden=4736, patch=14, pretrain_grid=24, window=24,
+               global_blocks=(7, 15, 23, 31))  # _create_vit_backbone, model_builder.py:70-97
+
+
+def vit_schema() -> _Schema:
+    """ViT-H teacher trunk (vitdet.py:616-859 as configured by model_builder.py:70-97): patch embed
+    14x14 s14 without bias, abs-pos table of the 336-px pre-training grid (24x24 + cls), ln_pre, 32
+    blocks (LN, qkv, proj, LN, Mlp 1024->4736->1024).  The complex ``freqs_cis`` buffers are derived
+    constants and not part of this schema."""
+    c = VIT_CFG
+    d = c["embed_dim"]
+    s = _Schema()
+    p = VIT_TRUNK
+    s[p + "pos_embed"] = ((1, c["pretrain_grid"] ** 2 + 1, d), "pos_small")
+    s.conv(p + "patch_embed.proj", d, 3, c["patch"])
+    s[p + "ln_pre.weight"] = ((d,), "ln_w_small")  # keeps the residual stream (and the mask logits) O(1)
+    s[p + "ln_pre.bias"] = ((d,), "ln_b")
+    for i in range(c["depth"]):
+        q = p + f"blocks.{i}."
+        s.ln(q + "norm1", d)
+        s.linear(q + "attn.qkv", 3 * d, d)
+        s[q + "attn.proj.weight"] = ((d, d), "linear_res")
+        s[q + "attn.proj.bias"] = ((d,), "bias")
+        s.ln(q + "norm2", d)
+        s.linear(q + "mlp.fc1", c["mlp_hidden"], d)
+        s[q + "mlp.fc2.weight"] = ((d, c["mlp_hidden"]), "linear_res")
+        s[q + "mlp.fc2.bias"] = ((d,), "bias")
+    return s
+
+
 def image_path_schema(backbone_type: str = "efficientvit", model_name: str = "b1",
                       enable_inst_interactivity: bool = True) -> _Schema:
     """All tensors read by set_image + predict_inst for a student model."""
@@ -417,6 +448,8 @@ def image_path_schema(backbone_type: str = "efficientvit", model_name: str = "b1
     elif backbone_type == "tinyvit":
         s.update(tinyvit_schema(model_name))
         s.update(student_head_schema(TINYVIT_CFG[model_name][0][-1]))
+    elif backbone_type == "sam3":  # ViT-H teacher (build_sam3_image_model): no student head
+        s.update(vit_schema())
     else:
         raise NotImplementedError(f"backbone_type={backbone_type!r}")
     s.update(neck_schema("convs"))
@@ -488,6 +521,10 @@ def init_state_dict(schema: _Schema, seed: int = 0) -> "OrderedDict[str, torch.T
             t = randn(shape) * math.sqrt(_linear_gain(name) / shape[1])
         elif kind == "linear_res":  # last linear of a transformer residual branch
             t = randn(shape) * math.sqrt(0.03 / shape[1])
+        elif kind == "ln_w_small":
+            t = rand(shape, 0.3, 0.5)
+        elif kind == "pos_small":   # absolute position table
+            t = randn(shape) * 0.2
         elif kind == "layer_scale":  # MobileCLIP RepMixer layer scales (trained values are O(0.1))
             t = rand(shape, 0.1, 0.5)
         elif kind == "attn_bias":   # TinyViT relative-offset attention biases

@@ -154,6 +154,18 @@ def reference_stage_taps(backbone_type, bb, x):
             side = int(l ** 0.5)
             taps[f"stage{li + 1}"] = x.view(b, side, side, c).permute(0, 3, 1, 2).contiguous()
         return taps
+    if backbone_type == "sam3":  # ViT-H: ln_pre output and the outputs of the four global-attention blocks
+        from sam3.model.vitdet import get_abs_pos
+        x = bb.patch_embed(x)
+        h, w = x.shape[1], x.shape[2]
+        x = bb.ln_pre(x + get_abs_pos(bb.pos_embed, bb.pretrain_use_cls_token, (h, w), bb.retain_cls_token,
+                                      tiling=bb.tile_abs_pos))
+        taps = {"stage0": x.permute(0, 3, 1, 2)}
+        for i, blk in enumerate(bb.blocks):
+            x = blk(x)
+            if i in bb.full_attn_ids:
+                taps[f"stage{1 + bb.full_attn_ids.index(i)}"] = x.permute(0, 3, 1, 2)
+        return taps
     raise NotImplementedError(backbone_type)
 
 
@@ -172,14 +184,18 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 8)
     os.makedirs(GOLD, exist_ok=True)
-    from sam3 import build_efficientsam3_image_model  # the REAL reference
+    from sam3 import build_efficientsam3_image_model, build_sam3_image_model  # the REAL reference
     from sam3.model.sam3_image_processor import Sam3Processor
 
     t0 = time.time()
-    model = build_efficientsam3_image_model(
-        device="cpu", checkpoint_path=None, load_from_HF=False, enable_inst_interactivity=True,
-        backbone_type=args.backbone, model_name=args.model, text_encoder_type="MobileCLIP-S0",
-        text_encoder_context_length=16)
+    if args.backbone == "sam3":  # ViT-H teacher
+        model = build_sam3_image_model(device="cpu", checkpoint_path=None, load_from_HF=False,
+                                       enable_inst_interactivity=True, enable_text_encoder=False)
+    else:
+        model = build_efficientsam3_image_model(
+            device="cpu", checkpoint_path=None, load_from_HF=False, enable_inst_interactivity=True,
+            backbone_type=args.backbone, model_name=args.model, text_encoder_type="MobileCLIP-S0",
+            text_encoder_context_length=16)
     sd = schema.synthetic_state_dict(args.backbone, args.model, seed=0)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected[:5]
@@ -202,7 +218,8 @@ def main():
 
     # ---- image 0: smooth synthetic, image 1: noise -------------------------------
     imgs_u8 = [synth.smooth_image_u8(seed=1), synth.noise_image_u8(seed=3)][: 2 if default else 1]
-    bb = model.backbone.vision_backbone.trunk.model.backbone  # the family's TrunkWrapper
+    trunk = model.backbone.vision_backbone.trunk
+    bb = trunk if args.backbone == "sam3" else trunk.model.backbone  # the family's TrunkWrapper
     for ii, img_u8 in enumerate(imgs_u8):
         chw_u8 = torch.from_numpy(np.ascontiguousarray(np.moveaxis(img_u8, -1, 0)))
         x = ref_model.normalise_image_u8(chw_u8)[None]

@@ -293,8 +293,80 @@ def tinyvit_backbone(sd: SD, x: torch.Tensor, model_name: str = "11m",
     return x.contiguous()
 
 
+# --------------------------------------------------------------------------
+# ViT-H teacher trunk (model/vitdet.py as configured by model_builder.py:70-97)
+# --------------------------------------------------------------------------
+VIT_TRUNK = NECK + "trunk."
+
+
+def _vit_rope_table(end: int, scale: float, head_dim: int = 64, theta: float = 10000.0):
+    """compute_axial_cis (vitdet.py:41-57): angles [end*end, head_dim/2]; the first half of the
+    complex pairs rotates with x, the second half with y."""
+    f = 1.0 / (theta ** (torch.arange(0, head_dim, 4)[: head_dim // 4].float() / head_dim))
+    t = torch.arange(end * end, dtype=torch.float32)
+    tx = (t % end).float() * scale
+    ty = torch.div(t, end, rounding_mode="floor").float() * scale
+    return torch.cat([torch.outer(tx, f), torch.outer(ty, f)], dim=-1)
+
+
+def _vit_apply_rope(x: torch.Tensor, ang: torch.Tensor) -> torch.Tensor:
+    """apply_rotary_enc (vitdet.py:68-90): (x[2i] + i x[2i+1]) * exp(i ang[i]), fp32."""
+    xr = x.float().reshape(*x.shape[:-1], -1, 2)
+    c, s_ = torch.cos(ang), torch.sin(ang)
+    out = torch.stack([xr[..., 0] * c - xr[..., 1] * s_, xr[..., 0] * s_ + xr[..., 1] * c], dim=-1)
+    return out.flatten(-2).type_as(x)
+
+
+def _vit_attention(sd: SD, p: str, x: torch.Tensor, heads: int, ang: torch.Tensor) -> torch.Tensor:
+    """Attention.forward (vitdet.py:466-515) on [B', H, W, C] windows (or the full map)."""
+    b, h, w, c = x.shape
+    l = h * w
+    qkv = F.linear(x, sd[p + "qkv.weight"], sd[p + "qkv.bias"]).reshape(b, l, 3, heads, -1)
+    q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)
+    q, k = _vit_apply_rope(q, ang), _vit_apply_rope(k, ang)
+    o = F.scaled_dot_product_attention(q, k, v)
+    o = o.view(b, heads, h, w, -1).permute(0, 2, 3, 1, 4).reshape(b, h, w, -1)
+    return F.linear(o, sd[p + "proj.weight"], sd[p + "proj.bias"])
+
+
+def vit_backbone(sd: SD, img: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+    """ViT.forward (vitdet.py:796-839): -> [B, 1024, 72, 72]."""
+    from efficientsam3_amd.schema import VIT_CFG as C
+    p = VIT_TRUNK
+    d, heads, ws, g0 = C["embed_dim"], C["heads"], C["window"], C["pretrain_grid"]
+    x = F.conv2d(img, sd[p + "patch_embed.proj.weight"], None, stride=C["patch"]).permute(0, 2, 3, 1)
+    b, h, w, _ = x.shape
+    pos = sd[p + "pos_embed"][:, 1:].reshape(1, g0, g0, d).permute(0, 3, 1, 2)  # drop cls, tile (get_abs_pos)
+    pos = pos.tile([1, 1, h // g0 + 1, w // g0 + 1])[:, :, :h, :w].permute(0, 2, 3, 1)
+    x = x + pos
+    x = F.layer_norm(x, (d,), sd[p + "ln_pre.weight"], sd[p + "ln_pre.bias"], 1e-5)
+    if taps is not None:
+        taps["stage0"] = x.permute(0, 3, 1, 2)
+    ang_win = _vit_rope_table(ws, 1.0)            # window blocks: rope over the 24x24 window
+    ang_glob = _vit_rope_table(h, ws / h)         # global blocks: interpolated to the 24-px pre-training extent
+    for i in range(C["depth"]):
+        q = p + f"blocks.{i}."
+        y = F.layer_norm(x, (d,), sd[q + "norm1.weight"], sd[q + "norm1.bias"], 1e-5)
+        if i in C["global_blocks"]:
+            y = _vit_attention(sd, q + "attn.", y, heads, ang_glob)
+        else:
+            nw = h // ws
+            y = y.view(b, nw, ws, nw, ws, d).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws, ws, d)
+            y = _vit_attention(sd, q + "attn.", y, heads, ang_win)
+            y = y.view(b, nw, nw, ws, ws, d).permute(0, 1, 3, 2, 4, 5).reshape(b, h, w, d)
+        x = x + y
+        y = F.layer_norm(x, (d,), sd[q + "norm2.weight"], sd[q + "norm2.bias"], 1e-5)
+        y = F.gelu(F.linear(y, sd[q + "mlp.fc1.weight"], sd[q + "mlp.fc1.bias"]))
+        x = x + F.linear(y, sd[q + "mlp.fc2.weight"], sd[q + "mlp.fc2.bias"])
+        if taps is not None and i in C["global_blocks"]:
+            taps[f"stage{1 + C['global_blocks'].index(i)}"] = x.permute(0, 3, 1, 2)
+    return x.permute(0, 3, 1, 2)
+
+
 def backbone_family(model_name: str) -> str:
     """The reference's model names are disjoint across families (model_builder.py:807-890)."""
+    if model_name in ("sam3", "vit_h"):
+        return "sam3"
     if model_name in EV_CFG:
         return "efficientvit"
     if model_name.startswith("m"):
@@ -368,10 +440,13 @@ def forward_image(sd: SD, img: torch.Tensor, model_name: str = "b1",
     """SAM3VLBackbone.forward_image + the conv_s0/conv_s1 projection that
     Sam3Processor.set_image applies in place (vl_combiner.py:81-124,
     sam3_image_processor.py:62-75).  ``img``: [B,3,1008,1008] fp32 normalised."""
-    feat = student_backbone(sd, img, model_name, taps)
-    if taps is not None:
-        taps["stage_final"] = feat
-    emb = student_head(sd, feat)
+    if backbone_family(model_name) == "sam3":  # ViT-H teacher: the trunk output feeds the neck directly
+        emb = vit_backbone(sd, img, taps)
+    else:
+        feat = student_backbone(sd, img, model_name, taps)
+        if taps is not None:
+            taps["stage_final"] = feat
+        emb = student_head(sd, feat)
     if taps is not None:
         taps["trunk"] = emb
     sam3 = fpn_neck(sd, "convs", emb)
