@@ -86,7 +86,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from efficientsam3_amd import build_efficientsam3_image_model, schema, synth
+    from efficientsam3_amd import build_efficientsam3_image_model, build_sam3_image_model, schema, synth
     from efficientsam3_amd import dist as esdist
 
     rank, local_rank, world = esdist.env_ranks()
@@ -97,10 +97,14 @@ def main():
     esdist.init_process_group("nccl", dev)
 
     sd = schema.synthetic_state_dict(args.backbone, args.model, seed=0)
-    model = build_efficientsam3_image_model(device=dev, enable_inst_interactivity=True,
-                                            backbone_type=args.backbone, model_name=args.model,
-                                            dtype=args.dtype, state_dict=sd, dual_neck=not args.sam2_only,
-                                            fuse_linear_chains=not args.no_fuse)
+    if args.backbone == "sam3":  # ViT-H teacher (not the headline configuration)
+        model = build_sam3_image_model(device=dev, enable_inst_interactivity=True, dtype=args.dtype, state_dict=sd,
+                                       dual_neck=not args.sam2_only, fuse_linear_chains=not args.no_fuse)
+    else:
+        model = build_efficientsam3_image_model(device=dev, enable_inst_interactivity=True,
+                                                backbone_type=args.backbone, model_name=args.model,
+                                                dtype=args.dtype, state_dict=sd, dual_neck=not args.sam2_only,
+                                                fuse_linear_chains=not args.no_fuse)
     eng = model.engine
     B = args.batch
     # synthetic batch, resident in HBM before the timed region: 4 distinct images tiled to B
@@ -196,7 +200,9 @@ def main():
             t_ = p_["tag"]
             key = ("neck" if ".convs." in t_ or ".sam2_convs." in t_ or "conv_s0" in t_ or "conv_s1" in t_
                    else "head" if ".head." in t_
-                   else "backbone" if "trunk.model.backbone" in t_ or t_.startswith(("dwconv", "stem", "lite_mla", "grouped_pw", "resize", "mbconv_fused", "squeeze_excite"))
+                   else "backbone" if "trunk.model.backbone" in t_ or "vision_backbone.trunk." in t_ and ".head." not in t_
+                   or t_.startswith(("dwconv", "stem", "lite_mla", "grouped_pw", "resize", "mbconv_fused", "squeeze_excite",
+                                     "window_attn", "vit_", "patchify"))
                    else "decode+post")
             stage_ms[key] = stage_ms.get(key, 0.0) + p_["ms"]
         out = {

@@ -531,6 +531,8 @@ struct esam3_engine {
   int tv_patch_merging(const std::string& p, const T4& x, T4* y);
   int tv_block(const std::string& p, const T4& x, int heads, int ws, T4* y);
   int backbone_tinyvit(const float* img, int B, const esam3_image_features* out, T4* feat);
+  float* vit_rope_table(int end, float scale);
+  int backbone_vit(const float* img, int B, const esam3_image_features* out, T4* feat);
   int neck(const std::string& which, const T4& trunk, void* const outs[3], bool sam2);
   int encode(const float* img, int B, const esam3_image_features* out);
   int decode(const esam3_prompts* pr, const esam3_decode_out* out);
@@ -924,7 +926,102 @@ int E::backbone_tinyvit(const float* img, int B, const esam3_image_features* out
   return 0;
 }
 
+// compute_axial_cis (vitdet.py:41-57) as an interleaved (cos, sin) fp32 table [end*end][32]
+float* E::vit_rope_table(int end, float scale) {
+  const std::string key = "vit_rope#" + std::to_string(end) + "#" + std::to_string(scale);
+  auto it = fbufs.find(key);
+  if (it != fbufs.end()) return it->second;
+  const int hd = 64, nf = hd / 4;
+  std::vector<float> freq(nf);
+  for (int i = 0; i < nf; ++i) freq[i] = 1.0f / std::pow(10000.0f, (float)(4 * i) / (float)hd);
+  std::vector<float> cs((size_t)end * end * 2 * nf * 2);
+  for (int t = 0; t < end * end; ++t) {
+    const float tx = (float)(t % end) * scale, ty = (float)(t / end) * scale;
+    for (int i = 0; i < 2 * nf; ++i) {
+      const float ang = (i < nf ? tx * freq[i] : ty * freq[i - nf]);
+      cs[((size_t)t * 2 * nf + i) * 2] = std::cos(ang);
+      cs[((size_t)t * 2 * nf + i) * 2 + 1] = std::sin(ang);
+    }
+  }
+  return fvec_raw(key, cs);
+}
+
+// ViT.forward of the SAM3 teacher (vitdet.py:796-839 with the configuration of model_builder.py:70-97):
+// 14x14 patch embedding as a GEMM (+ the tiled absolute position table as a batch-broadcast residual),
+// ln_pre, 32 pre-norm blocks: 24x24-window attention (global in blocks 7/15/23/31) with axial RoPE,
+// Mlp 1024 -> 4736 -> 1024.  Tokens stay [B][72][72][1024]; window partition is index arithmetic.
+int E::backbone_vit(const float* img, int B, const esam3_image_features* out, T4* feat) {
+  const std::string p = NECK + "trunk.";
+  const int D = 1024, heads = 16, P = 14, G = IMG / P, ws = 24, G0 = 24, depth = 32;
+  const int64_t rows = (int64_t)B * G * G;
+  const HostTensor* pw = need(p + "patch_embed.proj.weight");
+  const HostTensor* pe = need(p + "pos_embed");
+  if (!pw || !pe) return -1;
+  const int K = 3 * P * P, ldk = (K + 7) / 8 * 8;
+  if (!find(p + "patch_embed.proj#flat.weight")) {
+    HostTensor f = *pw;  // [D][3][P][P] is already [D][K] row-major
+    f.shape = {D, K};
+    raw[p + "patch_embed.proj#flat.weight"] = std::move(f);
+  }
+  PackedGemm* gpe = pk_conv_like_linear(p + "patch_embed.proj#flat.weight", "");
+  if (!gpe) return -1;
+  void* pos_full = nullptr;  // get_abs_pos(tiling=True): drop cls, tile the G0 x G0 table over G x G
+  {
+    auto it = tbufs.find("vit_pos_full");
+    if (it == tbufs.end()) {
+      std::vector<float> v((size_t)G * G * D);
+      for (int y = 0; y < G; ++y)
+        for (int x = 0; x < G; ++x)
+          memcpy(&v[((size_t)y * G + x) * D], &pe->d[((size_t)1 + (y % G0) * G0 + (x % G0)) * D], sizeof(float) * D);
+      pos_full = upload_T(v);
+      if (!pos_full) return -1;
+      tbufs["vit_pos_full"] = pos_full;
+    } else {
+      pos_full = it->second;
+    }
+  }
+  float* rope_win = vit_rope_table(ws, 1.0f);
+  float* rope_glob = vit_rope_table(G, (float)ws / (float)G);  // rope_interp: scaled to the window extent
+  if (!rope_win || !rope_glob) return -1;
+
+  T4 x = alloc4(B, G, G, D), y = alloc4(B, G, G, D);
+  void* ln = allocb((size_t)rows * D * esz);
+  void* qkv = allocb((size_t)rows * 3 * D * esz);   // also holds the patch rows and the attention output
+  void* hid = allocb((size_t)rows * 4736 * esz);
+  if (!ok(x.p) || !ok(y.p) || !ok(ln) || !ok(qkv) || !ok(hid)) return -1;
+  if (!dry) CK(prof_launch("patchify", 0.0, 0.0, [&]() { return esam3_launch_patchify(dtype, img, qkv, B, IMG, P, ldk, st); }));
+  CK(gemm(gpe, qkv, ldk, rows, 1, 1, y.p, D, ACT_NONE, pos_full, D, 1, G * G));
+  CK(layernorm(p + "ln_pre", y.p, x.p, rows, D, 1e-5f));
+  CK(tap(out, 0, x));
+  int stage = 1;
+  for (int i = 0; i < depth; ++i) {
+    const std::string q = p + "blocks." + std::to_string(i) + ".";
+    const bool global = (i % 8) == 7;
+    CK(layernorm(q + "norm1", x.p, ln, rows, D, 1e-5f));
+    CK(linear(q + "attn.qkv", ln, D, rows, qkv, 3 * D, ACT_NONE));
+    if (!dry) {
+      CK(prof_launch("vit_rope", 0.0, 4.0 * (double)rows * D * (double)esz, [&]() {
+        return esam3_launch_vit_rope(dtype, qkv, global ? rope_glob : rope_win, rows, G, G, global ? G : ws, heads, st);
+      }));
+      const double keys = global ? (double)G * G : (double)ws * ws;
+      CK(prof_launch(global ? "vit_attn_global" : "vit_attn_window", 4.0 * (double)rows * keys * D,
+                     4.0 * (double)rows * D * (double)esz, [&]() {
+                       return esam3_launch_attn_window(dtype, qkv, 3 * D, 0, D, 2 * D, ln, D, B, G, G, global ? G : ws,
+                                                       heads, 64, st);
+                     }));
+    }
+    CK(linear(q + "attn.proj", ln, D, rows, y.p, D, ACT_NONE, x.p, D));
+    CK(layernorm(q + "norm2", y.p, ln, rows, D, 1e-5f));
+    CK(linear(q + "mlp.fc1", ln, D, rows, hid, 4736, ACT_GELU));
+    CK(linear(q + "mlp.fc2", hid, 4736, rows, x.p, D, ACT_NONE, y.p, D));
+    if (global) CK(tap(out, stage++, x));
+  }
+  *feat = x;
+  return 0;
+}
+
 int E::backbone(const float* img, int B, const esam3_image_features* out, T4* feat) {
+  if (cfg.backbone == ESAM3_BACKBONE_VIT) return backbone_vit(img, B, out, feat);
   if (cfg.backbone == ESAM3_BACKBONE_REPVIT) return backbone_repvit(img, B, out, feat);
   if (cfg.backbone == ESAM3_BACKBONE_TINYVIT) return backbone_tinyvit(img, B, out, feat);
   auto tap = [&](int i, const T4& t) -> int { return this->tap(out, i, t); };
@@ -1050,6 +1147,10 @@ int E::encode(const float* img, int B, const esam3_image_features* out) {
   arena.top = 0;
   T4 feat;
   CK(backbone(img, B, out, &feat));
+  T4 trunk;
+  if (cfg.backbone == ESAM3_BACKBONE_VIT) {
+    trunk = feat;  // the teacher's ViT output is the neck input (necks.py:100-125), no student head
+  } else {
   // head: 1x1 (no bias) + BN + GELU, 3x3 + bias, bilinear 32 -> 72
   T4 h1, h2;
   {
@@ -1059,11 +1160,12 @@ int E::encode(const float* img, int B, const esam3_image_features* out) {
     CK(gemm(g, feat.p, feat.ld, feat.rows(), feat.H, feat.W, h1.p, h1.ld, ACT_GELU, nullptr, 0, 1, 0, nullptr, 0, 1));
   }
   CK(conv(TRUNK + "head.3", false, h1, ACT_NONE, &h2));
-  T4 trunk = h2;
+  trunk = h2;
   if (h2.H != EMB || h2.W != EMB) {
     trunk = alloc4(B, EMB, EMB, h2.C);
     if (!ok(trunk.p)) return -1;
     if (!dry) CK(prof_launch("resize_bilinear", 0.0, 0.0, [&]() { return esam3_launch_resize_bilinear(dtype, h2.p, trunk.p, B, h2.H, h2.W, EMB, EMB, h2.C, st); }));
+  }
   }
   if (out->trunk_dev && !dry)
     HIP_CHECK_RET(hipMemcpyAsync(out->trunk_dev, trunk.p, (size_t)trunk.rows() * trunk.C * esz,
@@ -1459,7 +1561,7 @@ int esam3_create(const esam3_config* cfg, esam3_engine** out) {
   if (cfg->device < 0 || cfg->device >= ndev) { esam3_set_error("bad device ordinal %d", cfg->device); return -1; }
   HIP_CHECK_RET(hipSetDevice(cfg->device));
   if (cfg->backbone != ESAM3_BACKBONE_EFFICIENTVIT && cfg->backbone != ESAM3_BACKBONE_REPVIT &&
-      cfg->backbone != ESAM3_BACKBONE_TINYVIT) {
+      cfg->backbone != ESAM3_BACKBONE_TINYVIT && cfg->backbone != ESAM3_BACKBONE_VIT) {
     esam3_set_error("unsupported backbone %d", cfg->backbone);
     return -1;
   }
@@ -1468,6 +1570,10 @@ int esam3_create(const esam3_config* cfg, esam3_engine** out) {
   e->dtype = cfg->dtype == ESAM3_F32 ? 0 : 1;
   e->esz = e->dtype == 0 ? 4 : 2;
   const std::string mn(cfg->model_name);
+  if (cfg->backbone == ESAM3_BACKBONE_VIT) {  // one configuration: the ViT-H of _create_vit_backbone
+    *out = e;
+    return 0;
+  }
   if (cfg->backbone == ESAM3_BACKBONE_TINYVIT) {
     e->tv_depths = {2, 2, 6, 2};
     e->tv_windows = {7, 7, 14, 7};

@@ -501,6 +501,148 @@ __global__ __launch_bounds__(256) void mla_apply_kernel(const T* __restrict__ ms
 }
 
 // ------------------------------------------------------------------------------------
+// ViT-H teacher helpers (model/vitdet.py)
+// ------------------------------------------------------------------------------------
+// PatchEmbed (vitdet.py:312-337): Conv2d(3, D, k=P, s=P, bias=False) as a GEMM over patch rows.
+// img NCHW fp32 -> A [B*G*G][ldk] with k = (c*P + ky)*P + kx (the conv weight's own order), the
+// ldk - 3*P*P padding columns are zeroed.
+template <typename T>
+__global__ void patchify_kernel(const float* __restrict__ img, T* __restrict__ a, int B, int S, int P, int G, int ldk) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * G * G * ldk;
+  if (i >= total) return;
+  const int k = (int)(i % ldk);
+  const int64_t m = i / ldk;
+  const int px = (int)(m % G), py = (int)((m / G) % G);
+  const int64_t b = m / ((int64_t)G * G);
+  float v = 0.f;
+  if (k < 3 * P * P) {
+    const int c = k / (P * P), r = k - c * P * P;
+    const int ky = r / P, kx = r - ky * P;
+    v = img[((b * 3 + c) * S + (py * P + ky)) * (int64_t)S + px * P + kx];
+  }
+  a[i] = from_f32<T>(v);
+}
+
+// 2-D axial RoPE on q and k in place (vitdet.py:41-90,421-457): qkv rows [3][heads][64]; the pair
+// (x[2i], x[2i+1]) of every head is rotated by angle table[pos][i] (cos | sin, fp32), where pos is
+// the token's index inside its ws x ws attention window (the whole map for global blocks).
+template <typename T>
+__global__ void vit_rope_kernel(T* __restrict__ qkv, const float* __restrict__ cs, int64_t rows, int H, int W, int ws,
+                                int heads) {
+  const int half = 32;  // complex pairs per 64-wide head
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (row, q|k, head, pair)
+  const int64_t total = rows * 2 * heads * half;
+  if (i >= total) return;
+  const int pr = (int)(i % half);
+  const int h = (int)((i / half) % heads);
+  const int which = (int)((i / ((int64_t)half * heads)) % 2);
+  const int64_t row = i / ((int64_t)half * heads * 2);
+  const int x = (int)(row % W), y = (int)((row / W) % H);
+  const int pos = (y % ws) * ws + (x % ws);
+  const float c = cs[((int64_t)pos * half + pr) * 2], s_ = cs[((int64_t)pos * half + pr) * 2 + 1];
+  T* p = qkv + row * 3 * (int64_t)heads * 64 + (int64_t)which * heads * 64 + h * 64 + 2 * pr;
+  const float a = to_f32<T>(p[0]), b = to_f32<T>(p[1]);
+  p[0] = from_f32<T>(a * c - b * s_);
+  p[1] = from_f32<T>(a * s_ + b * c);
+}
+
+// Softmax attention over ws x ws windows of an [B][H][W] token map (ws = H = W: global), head dim HD.
+// q/k/v live in one row-major buffer (row stride ld; q at q_off + h*HD, k at k_off + h*HD, ...).
+// One query per thread with q and the output accumulator in registers; keys and values stream
+// through LDS in chunks of KC (fp32, broadcast reads), online softmax in fp32.
+template <typename T, int HD, int KC>
+__global__ __launch_bounds__(256) void attn_window_kernel(const T* __restrict__ qkv, int ld, int q_off, int k_off, int v_off,
+                                                          T* __restrict__ out, int ldo, int H, int W, int ws, int heads,
+                                                          float scale) {
+  __shared__ float sk[KC][HD];
+  __shared__ float sv[KC][HD];
+  const int N = ws * ws;
+  const int nwx = W / ws, nwy = H / ws;
+  const int h = blockIdx.y;
+  const int win = blockIdx.z % (nwx * nwy);
+  const int64_t b = blockIdx.z / (nwx * nwy);
+  const int wy = win / nwx, wx = win - wy * nwx;
+  auto row_of = [&](int i) -> int64_t {  // token i of this window -> row of the token map
+    const int y = wy * ws + i / ws, x = wx * ws + i % ws;
+    return (b * H + y) * (int64_t)W + x;
+  };
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = qi < N;
+  float q[HD], acc[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) { q[d] = 0.f; acc[d] = 0.f; }
+  if (valid) {
+    const T* src = qkv + row_of(qi) * ld + q_off + h * HD;
+#pragma unroll
+    for (int c = 0; c < HD / VEC; ++c) Vec8<T>::load(src + c * VEC, q + c * VEC);
+#pragma unroll
+    for (int d = 0; d < HD; ++d) q[d] *= scale;
+  }
+  float mx = -INFINITY, sum = 0.f;
+  for (int j0 = 0; j0 < N; j0 += KC) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < KC * (HD / VEC); i += 256) {
+      const int j = i / (HD / VEC), c = i - j * (HD / VEC);
+      float kk[VEC], vv[VEC];
+      if (j0 + j < N) {
+        const T* src = qkv + row_of(j0 + j) * ld + h * HD + c * VEC;
+        Vec8<T>::load(src + k_off, kk);
+        Vec8<T>::load(src + v_off, vv);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { kk[e] = 0.f; vv[e] = 0.f; }
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { sk[j][c * VEC + e] = kk[e]; sv[j][c * VEC + e] = vv[e]; }
+    }
+    __syncthreads();
+    const int jn = min(KC, N - j0);
+    for (int j = 0; j < jn; ++j) {
+      const float4* kr = reinterpret_cast<const float4*>(sk[j]);
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < HD / 4; c += 2) {
+        const float4 a = kr[c], bq = kr[c + 1];
+        s0 = fmaf(q[4 * c], a.x, s0); s0 = fmaf(q[4 * c + 1], a.y, s0);
+        s0 = fmaf(q[4 * c + 2], a.z, s0); s0 = fmaf(q[4 * c + 3], a.w, s0);
+        s1 = fmaf(q[4 * c + 4], bq.x, s1); s1 = fmaf(q[4 * c + 5], bq.y, s1);
+        s1 = fmaf(q[4 * c + 6], bq.z, s1); s1 = fmaf(q[4 * c + 7], bq.w, s1);
+      }
+      const float sc = s0 + s1;
+      if (sc > mx) {
+        const float f = __expf(mx - sc);
+        sum *= f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] *= f;
+        mx = sc;
+      }
+      const float p = __expf(sc - mx);
+      sum += p;
+      const float4* vr = reinterpret_cast<const float4*>(sv[j]);
+#pragma unroll
+      for (int c = 0; c < HD / 4; ++c) {
+        const float4 v4 = vr[c];
+        acc[4 * c] = fmaf(p, v4.x, acc[4 * c]);
+        acc[4 * c + 1] = fmaf(p, v4.y, acc[4 * c + 1]);
+        acc[4 * c + 2] = fmaf(p, v4.z, acc[4 * c + 2]);
+        acc[4 * c + 3] = fmaf(p, v4.w, acc[4 * c + 3]);
+      }
+    }
+  }
+  if (!valid) return;
+  const float inv = 1.f / sum;
+  T* dst = out + row_of(qi) * ldo + h * HD;
+#pragma unroll
+  for (int c = 0; c < HD / VEC; ++c) {
+    float o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = acc[c * VEC + e] * inv;
+    Vec8<T>::store(dst + c * VEC, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // Squeeze-Excite (timm SqueezeExcite as used by RepViT, repvit.py:136,150):
 //   gate[b][c] = sigmoid(W2 . relu(W1 . mean_hw(x[b]) + b1) + b2);  x *= gate
 // three small kernels: per-channel sums (atomics over pixel splits), the two tiny FCs (one
@@ -1119,6 +1261,33 @@ static int se_splits(int B, int HW) {
 }
 // fp32 scratch of esam3_launch_squeeze_excite: per-split channel sums [B][splits][C]
 int64_t esam3_squeeze_excite_scratch_floats(int B, int HW, int C) { return (int64_t)B * se_splits(B, HW) * C; }
+
+int esam3_launch_patchify(int dtype, const float* img, void* a, int B, int S, int P, int ldk, hipStream_t s) {
+  const int G = S / P;
+  const int64_t total = (int64_t)B * G * G * ldk;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(patchify_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, img, (T*)a, B, S, P,
+                                       G, ldk));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int esam3_launch_vit_rope(int dtype, void* qkv, const float* cos_sin, int64_t rows, int H, int W, int ws, int heads,
+                          hipStream_t s) {
+  const int64_t total = rows * 2 * heads * 32;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(vit_rope_kernel<T>, dim3(blocks_for(total, 256)), dim3(256), 0, s, (T*)qkv, cos_sin,
+                                       rows, H, W, ws, heads));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int esam3_launch_attn_window(int dtype, const void* qkv, int ld, int q_off, int k_off, int v_off, void* out, int ldo, int B,
+                             int H, int W, int ws, int heads, int hd, hipStream_t s) {
+  if (hd != 64 || H % ws || W % ws) { esam3_set_error("attn_window: hd=%d ws=%d H=%d W=%d unsupported", hd, ws, H, W); return -1; }
+  const int N = ws * ws;
+  dim3 grid(blocks_for(N, 256), (unsigned)heads, (unsigned)(B * (H / ws) * (W / ws)));
+  DISPATCH_T(dtype, hipLaunchKernelGGL((attn_window_kernel<T, 64, 32>), grid, dim3(256), 0, s, (const T*)qkv, ld, q_off,
+                                       k_off, v_off, (T*)out, ldo, H, W, ws, heads, 0.125f));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
 
 int esam3_launch_squeeze_excite(int dtype, void* x, int ld, float* sums, float* gate, const float* w1,
                                 const float* b1, const float* w2, const float* b2, int B, int HW, int C, int R,

@@ -26,7 +26,7 @@ def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-BACKBONES = {"efficientvit": 0, "repvit": 1, "tinyvit": 2}  # ESAM3_BACKBONE_*
+BACKBONES = {"efficientvit": 0, "repvit": 1, "tinyvit": 2, "sam3": 3}  # ESAM3_BACKBONE_*
 
 
 def stage_shapes(backbone_type: str, model_name: str):
@@ -39,6 +39,8 @@ def stage_shapes(backbone_type: str, model_name: str):
     if backbone_type == "tinyvit":
         d = {"5m": [64, 128, 160, 320], "11m": [64, 128, 256, 448], "21m": [96, 192, 384, 576]}[model_name]
         return ([d[0], d[1], d[2], d[3], d[3]], [252, 126, 63, 32, 32])
+    if backbone_type == "sam3":  # ViT-H teacher: ln_pre output + the four global-attention block outputs
+        return ([1024] * 5, [72] * 5)
     raise NotImplementedError(backbone_type)
 
 

@@ -94,7 +94,46 @@ def build_efficientsam3_image_model(
     return model
 
 
-def build_sam3_image_model(*args, **kwargs):
-    raise NotImplementedError(
-        "build_sam3_image_model (ViT-H teacher + LiteText) is a later row of SURVEY.md §8; "
-        "only the student EfficientViT path is built so far")
+def build_sam3_image_model(
+    bpe_path=None,
+    device="cuda",
+    eval_mode=True,
+    checkpoint_path=None,
+    load_from_HF=False,
+    enable_segmentation=True,
+    enable_inst_interactivity=False,
+    compile=False,
+    enable_text_encoder=True,
+    enable_vision_encoder=True,
+    text_encoder_type=None,
+    text_encoder_context_length=77,
+    *,
+    dtype: str = "bf16",
+    state_dict: Optional[Dict[str, torch.Tensor]] = None,
+    synthetic_seed: int = 0,
+    dual_neck: bool = True,
+    fuse_linear_chains: bool = True,
+) -> Sam3Image:
+    """``build_sam3_image_model`` (model_builder.py:643-750): the ViT-H teacher trunk + the same dual neck and
+    SAM heads as the students.  The image path (set_image / predict_inst) runs on the HIP engine; the 354 M
+    teacher text encoder and the PCS grounding head are not built (``text_encoder_type="MobileCLIP-S0"`` gives
+    the LiteText student encoder)."""
+    if str(device).startswith("cpu"):
+        raise RuntimeError("EfficientSAM3-AMD has no CPU path; pass a HIP device (device='cuda')")
+    if not enable_vision_encoder:
+        raise NotImplementedError("enable_vision_encoder=False")
+    model = Sam3Image("sam3", "vit_h", bool(enable_inst_interactivity), dtype=dtype, device=device, dual_neck=dual_neck,
+                      fuse_linear_chains=fuse_linear_chains, text_encoder_type=text_encoder_type,
+                      text_encoder_context_length=text_encoder_context_length, bpe_path=bpe_path)
+    if state_dict is None and checkpoint_path is not None:
+        with open(checkpoint_path, "rb") as f:
+            ckpt = torch.load(f, map_location="cpu", weights_only=True)
+        state_dict = _clean_checkpoint_keys(ckpt, bool(enable_inst_interactivity))
+    if state_dict is None:
+        state_dict = schema.synthetic_state_dict("sam3", "vit_h", seed=synthetic_seed,
+                                                 enable_inst_interactivity=bool(enable_inst_interactivity))
+        if text_encoder_type is not None:
+            state_dict.update(schema.synthetic_text_state_dict(text_encoder_type, text_encoder_context_length,
+                                                               seed=synthetic_seed))
+    model.load_state_dict(state_dict, strict=False)
+    return model

@@ -33,12 +33,13 @@ extern "C" {
 typedef struct esam3_engine esam3_engine;
 
 enum { ESAM3_F32 = 0, ESAM3_BF16 = 1 };
-enum { ESAM3_BACKBONE_EFFICIENTVIT = 0, ESAM3_BACKBONE_REPVIT = 1, ESAM3_BACKBONE_TINYVIT = 2 };
+enum { ESAM3_BACKBONE_EFFICIENTVIT = 0, ESAM3_BACKBONE_REPVIT = 1, ESAM3_BACKBONE_TINYVIT = 2,
+       ESAM3_BACKBONE_VIT = 3 /* ViT-H teacher of build_sam3_image_model (model_builder.py:70-97) */ };
 
 typedef struct esam3_config {
   int dtype;            /* ESAM3_F32 (validation) or ESAM3_BF16 (throughput) activations */
   int backbone;         /* ESAM3_BACKBONE_* */
-  char model_name[16];  /* EfficientViT "b0" | "b1" | "b2"; RepViT "m0.9" | "m1.1"; TinyViT "5m" | "11m" | "21m" */
+  char model_name[16];  /* EfficientViT "b0" | "b1" | "b2"; RepViT "m0.9" | "m1.1"; TinyViT "5m" | "11m" | "21m"; ViT "vit_h" */
   int device;           /* HIP device ordinal */
   int interactive;      /* 1: sam2 neck + SAM heads are present (enable_inst_interactivity) */
   int fuse_linear_chains; /* 1: compose ConvT->1x1 and 3x3->conv_s0/s1 weight chains at finalize
@@ -50,7 +51,7 @@ typedef struct esam3_config {
  *   sam2_fpn: [B,288,288,32]  [B,144,144,64]  [B,72,72,256]   (after conv_s0 / conv_s1)
  *   trunk:    [B,72,72,1024]  ImageStudentEncoder output
  *   stages:   backbone stage outputs (validation taps): EfficientViT stage0..4, RepViT stage0..3,
- *             TinyViT patch embed + the 4 layer outputs */
+ *             TinyViT patch embed + the 4 layer outputs, ViT-H ln_pre + the 4 global-block outputs */
 typedef struct esam3_image_features {
   void* sam3_fpn_dev[3];
   void* sam2_fpn_dev[3];

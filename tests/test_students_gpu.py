@@ -1,5 +1,5 @@
 """GPU parity of the other student backbones (RepViT-M1.1 and TinyViT-11M; the neck, SAM heads and
-post-processing are shared with EfficientViT) against fixtures produced by the REAL reference
+post-processing are shared with EfficientViT) and of the ViT-H teacher (build_sam3_image_model) against fixtures produced by the REAL reference
 (tests/golden/<backbone>_<model>/, oracle/gen_golden.py --backbone ... --model ...).
 Tolerances as in test_e2e_gpu.py."""
 import json
@@ -11,10 +11,11 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from efficientsam3_amd import Sam3Processor, build_efficientsam3_image_model, schema, synth  # noqa: E402
+from efficientsam3_amd import (Sam3Processor, build_efficientsam3_image_model, build_sam3_image_model,  # noqa: E402
+                               schema, synth)
 from tests import util as U  # noqa: E402
 
-STUDENTS = [("repvit", "m1.1"), ("tinyvit", "11m")]
+STUDENTS = [("repvit", "m1.1"), ("tinyvit", "11m"), ("sam3", "vit_h")]  # the last one is the ViT-H teacher
 SAMPLE = 4096
 
 
@@ -37,9 +38,13 @@ def student(request, golden_dir):
     with open(os.path.join(gdir, "manifest.json")) as f:
         manifest = json.load(f)
     sd = schema.synthetic_state_dict(bt, mn, seed=0)
-    models = {mode: build_efficientsam3_image_model(device="cuda", enable_inst_interactivity=True, backbone_type=bt,
-                                                    model_name=mn, dtype=mode, state_dict=sd)
-              for mode in ("f32", "bf16")}
+    if bt == "sam3":
+        models = {mode: build_sam3_image_model(device="cuda", enable_inst_interactivity=True, dtype=mode, state_dict=sd)
+                  for mode in ("f32", "bf16")}
+    else:
+        models = {mode: build_efficientsam3_image_model(device="cuda", enable_inst_interactivity=True, backbone_type=bt,
+                                                        model_name=mn, dtype=mode, state_dict=sd)
+                  for mode in ("f32", "bf16")}
     return dict(bt=bt, mn=mn, gdir=gdir, manifest=manifest, models=models)
 
 
