@@ -5,6 +5,8 @@
 
 namespace {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // 16-byte register value
+
 constexpr int VEC = 8;  // channels per thread for vectorised NHWC kernels
 
 // Workgroups are dispatched round-robin over the 8 XCDs (linear id % 8), each with a private
@@ -640,6 +642,161 @@ __global__ __launch_bounds__(256) void attn_window_kernel(const T* __restrict__ 
     for (int e = 0; e < VEC; ++e) o[e] = acc[c * VEC + e] * inv;
     Vec8<T>::store(dst + c * VEC, o);
   }
+}
+
+// MFMA flash attention for the bf16 engine, head dim 64, N = ws*ws a multiple of 64 (ViT-H: 576-token
+// windows and the 5184-token global blocks).  Workgroup = 128 queries (4 wavefronts x 32) of one
+// (image, window, head); keys/values stream through LDS in tiles of 64.
+//   S^T[key][query] = K Q^T      v_mfma_f32_32x32x16_bf16 with A = K rows (from LDS), B = Q (registers)
+//   online softmax per query = per lane column (lane & 31), fp32, exp2 with log2(e) folded into the scale;
+//                     the two half-waves hold different keys of the same query and merge with one swap
+//   O^T[d][query]  += V^T P      A = V^T rows (V is transposed while it is staged into LDS), B = P:
+//                     the C layout of S^T is exactly the B-operand layout once the k slots of a 16-key
+//                     step are read as keys {4g..4g+3, 8+4g..8+4g+3}, so P never leaves its registers;
+//                     the V^T fragments are fetched with the same key permutation (two 8-byte reads).
+__global__ __launch_bounds__(256) void attn_mfma64_kernel(const bf16_t* __restrict__ qkv, int ld, int q_off, int k_off,
+                                                          int v_off, bf16_t* __restrict__ out, int ldo, int H, int W,
+                                                          int ws, int heads, float scale_log2e) {
+  constexpr int HD = 64, KT = 64, VP = 136;  // V^T row pitch in bytes: 34 dwords -> conflict-free b64 reads
+  __shared__ __attribute__((aligned(16))) char sK[KT * 128];
+  __shared__ __attribute__((aligned(16))) char sVt[HD * VP];
+  const int N = ws * ws;
+  const int nwx = W / ws, nwy = H / ws;
+  const int h = blockIdx.y;
+  const int win = blockIdx.z % (nwx * nwy);
+  const int64_t b = blockIdx.z / (nwx * nwy);
+  const int wy = win / nwx, wx = win - wy * nwx;
+  auto row_of = [&](int i) -> int64_t {
+    const int y = wy * ws + i / ws, x = wx * ws + i % ws;
+    return (b * H + y) * (int64_t)W + x;
+  };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
+  const int qi = blockIdx.x * 128 + wave * 32 + l31;
+  const bool valid = qi < N;
+  // Q fragments (B operand): 8 channels d = 16 s + 8 g .. +7 of this lane's query, s = 0..3
+  u32x4 qf[4];
+  {
+    const bf16_t* src = qkv + row_of(valid ? qi : N - 1) * ld + q_off + h * HD;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) qf[s_] = *reinterpret_cast<const u32x4*>(src + s_ * 16 + g * 8);
+  }
+  f32x16_v o[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;  // lsum: this half-wave's share of the softmax denominator
+
+  for (int j0 = 0; j0 < N; j0 += KT) {
+    __syncthreads();  // the previous tile has been consumed
+    if (wave >= 2) {  // K tile [key][64 d], 128-byte rows, 16-byte slots XOR-swizzled by (key >> 1) & 7
+      const int t = tid - 128;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = t + 128 * i, key = c >> 3, slot = c & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(qkv + row_of(j0 + key) * ld + k_off + h * HD + slot * 8);
+        *reinterpret_cast<u32x4*>(sK + key * 128 + ((slot ^ ((key >> 1) & 7)) << 4)) = v;
+      }
+    } else {  // V^T tile [d][64 keys]: a thread transposes an (8 d) x (4 keys) patch in registers
+      const int dch = tid & 7, kq = tid >> 3;  // kq 0..15
+      u32x4 u[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        u[i] = *reinterpret_cast<const u32x4*>(qkv + row_of(j0 + kq * 4 + i) * ld + v_off + h * HD + dch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {  // channel d = dch*8 + e: its values for the 4 keys, 8 bytes
+        const int w_ = e >> 1;
+        uint32_t a0, a1;
+        if (e & 1) {
+          a0 = (u[0][w_] >> 16) | (u[1][w_] & 0xffff0000u);
+          a1 = (u[2][w_] >> 16) | (u[3][w_] & 0xffff0000u);
+        } else {
+          a0 = (u[0][w_] & 0xffffu) | (u[1][w_] << 16);
+          a1 = (u[2][w_] & 0xffffu) | (u[3][w_] << 16);
+        }
+        *reinterpret_cast<uint2*>(sVt + (dch * 8 + e) * VP + kq * 8) = make_uint2(a0, a1);
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T for the two 32-key blocks --------------------------------------------
+    f32x16_v sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+      const int key = kb * 32 + l31;
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + key * 128 + (((s_ * 2 + g) ^ ((key >> 1) & 7)) << 4));
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, kf),
+                                                           __builtin_bit_cast(bf16x8_v, qf[s_]), sacc[kb], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (base 2) --------------------------------------------------------------
+    float mt = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sacc[kb][r] *= scale_log2e;
+        mt = fmaxf(mt, sacc[kb][r]);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    m = mn;
+    lsum *= alpha;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    u32x4 pf[2][2];  // P as B-operand fragments: [key block][16-key step]
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = __builtin_amdgcn_exp2f(sacc[kb][r] - mn);
+        lsum += pv[r];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        pf[kb][s2].x = pack_bf16x2(pv[8 * s2 + 0], pv[8 * s2 + 1]);
+        pf[kb][s2].y = pack_bf16x2(pv[8 * s2 + 2], pv[8 * s2 + 3]);
+        pf[kb][s2].z = pack_bf16x2(pv[8 * s2 + 4], pv[8 * s2 + 5]);
+        pf[kb][s2].w = pack_bf16x2(pv[8 * s2 + 6], pv[8 * s2 + 7]);
+      }
+    }
+    // ---- O^T += V^T P ---------------------------------------------------------------------------
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const char* vrow = sVt + (db * 32 + l31) * VP;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int koff = (kb * 32 + 16 * s2 + 4 * g) * 2;  // keys 16 s2 + 4g .. +3, then + 8
+          const uint2 lo = *reinterpret_cast<const uint2*>(vrow + koff);
+          const uint2 hi = *reinterpret_cast<const uint2*>(vrow + koff + 16);
+          const u32x4 vf = {lo.x, lo.y, hi.x, hi.y};
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, vf),
+                                                          __builtin_bit_cast(bf16x8_v, pf[kb][s2]), o[db], 0, 0, 0);
+        }
+    }
+  }
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (!valid) return;
+  const float inv = 1.f / lsum;
+  bf16_t* dst = out + row_of(qi) * ldo + h * HD;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {  // registers 4 q4 .. 4 q4 + 3 are channels db*32 + 8 q4 + 4 g + {0..3}
+      const uint2 w_ = make_uint2(pack_bf16x2(o[db][4 * q4] * inv, o[db][4 * q4 + 1] * inv),
+                                  pack_bf16x2(o[db][4 * q4 + 2] * inv, o[db][4 * q4 + 3] * inv));
+      *reinterpret_cast<uint2*>(dst + db * 32 + 8 * q4 + 4 * g) = w_;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1282,6 +1439,14 @@ int esam3_launch_attn_window(int dtype, const void* qkv, int ld, int q_off, int 
                              int H, int W, int ws, int heads, int hd, hipStream_t s) {
   if (hd != 64 || H % ws || W % ws) { esam3_set_error("attn_window: hd=%d ws=%d H=%d W=%d unsupported", hd, ws, H, W); return -1; }
   const int N = ws * ws;
+  static const bool no_mfma = getenv("ESAM3_ATTN_VALU") != nullptr;
+  if (dtype == 1 && N % 64 == 0 && !no_mfma && ld % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && ldo % 4 == 0) {
+    dim3 grid(blocks_for(N, 128), (unsigned)heads, (unsigned)(B * (H / ws) * (W / ws)));
+    hipLaunchKernelGGL(attn_mfma64_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, ld, q_off, k_off, v_off,
+                       (bf16_t*)out, ldo, H, W, ws, heads, 0.125f * 1.4426950408889634f);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
   dim3 grid(blocks_for(N, 256), (unsigned)heads, (unsigned)(B * (H / ws) * (W / ws)));
   DISPATCH_T(dtype, hipLaunchKernelGGL((attn_window_kernel<T, 64, 32>), grid, dim3(256), 0, s, (const T*)qkv, ld, q_off,
                                        k_off, v_off, (T*)out, ldo, H, W, ws, heads, 0.125f));

@@ -121,6 +121,23 @@ int esam3_op_window_attention(int dtype, const void* qkv, const float* pad_qkv, 
   return 0;
 }
 
+int esam3_op_attn_window(int dtype, const void* qkv, void* out, int B, int H, int W, int ws, int heads, void* stream) {
+  const int D = heads * 64;
+  if (esam3_launch_attn_window(dtype, qkv, 3 * D, 0, D, 2 * D, out, D, B, H, W, ws, heads, 64, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int esam3_op_vit_rope(int dtype, void* qkv, const float* cos_sin, int64_t rows, int H, int W, int ws, int heads,
+                      void* stream) {
+  Tmp t;
+  float* cs = (float*)t.up(cos_sin, (size_t)ws * ws * 32 * 2 * 4);
+  if (!cs) return fail("op_vit_rope");
+  if (esam3_launch_vit_rope(dtype, qkv, cs, rows, H, W, ws, heads, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
 int esam3_op_squeeze_excite(int dtype, void* x, const float* w1, const float* b1, const float* w2, const float* b2,
                             int B, int HW, int C, int R, void* stream) {
   Tmp t;

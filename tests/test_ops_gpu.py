@@ -127,6 +127,47 @@ def test_window_attention(mode, B, H, W, heads, ws):
 
 
 @pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("B,H,W,ws,heads", [(1, 24, 24, 24, 2), (2, 48, 48, 24, 3), (1, 16, 16, 16, 1), (1, 72, 72, 72, 2),
+                                            (2, 16, 16, 8, 2), (1, 10, 10, 5, 1)])
+def test_vit_attention_window(mode, B, H, W, ws, heads):
+    """ViT-H softmax attention over ws x ws windows (ws = H: global).  bf16 with ws*ws % 64 == 0 runs the MFMA
+    flash-attention kernel (P is rounded to bf16 before P.V, like the reference's bf16 SDPA); the other cases
+    run the fp32 VALU kernel."""
+    d, tdt = U.DT[mode]
+    D = heads * 64
+    qkv = _q(_rand(B, H, W, 3 * D, seed=1), mode)
+    nw = H // ws
+    t = qkv.view(B, nw, ws, nw, ws, 3, heads, 64).permute(5, 0, 1, 3, 6, 2, 4, 7).reshape(3, B * nw * nw, heads, ws * ws, 64)
+    o = F.scaled_dot_product_attention(t[0], t[1], t[2])  # [Bw, heads, N, 64]
+    ref = o.view(B, nw, nw, heads, ws, ws, 64).permute(0, 1, 4, 2, 5, 3, 6).reshape(B, H, W, D)
+    x_d = qkv.to(tdt).to("cuda").contiguous()
+    out = torch.empty((B, H, W, D), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_attn_window(d, U.P(x_d), U.P(out), B, H, W, ws, heads, None), "op_attn_window")
+    U.assert_close(out.float().cpu(), ref, mode, f"vit attention ws={ws} heads={heads}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_vit_rope(mode):
+    d, tdt = U.DT[mode]
+    B, H, W, ws, heads = 2, 12, 12, 6, 2
+    D = heads * 64
+    qkv = _q(_rand(B, H, W, 3 * D, seed=1), mode)
+    ang = torch.rand(ws * ws, 32, generator=torch.Generator().manual_seed(2)) * 6.0
+    cs = torch.stack([torch.cos(ang), torch.sin(ang)], dim=-1).contiguous()
+    ref = qkv.clone().view(B, H, W, 3, heads, 32, 2)
+    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    pos = (ys % ws) * ws + (xs % ws)
+    c, s_ = torch.cos(ang)[pos][None, :, :, None], torch.sin(ang)[pos][None, :, :, None]
+    for which in (0, 1):
+        a, b = ref[:, :, :, which, :, :, 0].clone(), ref[:, :, :, which, :, :, 1].clone()
+        ref[:, :, :, which, :, :, 0] = a * c - b * s_
+        ref[:, :, :, which, :, :, 1] = a * s_ + b * c
+    x_d = qkv.to(tdt).to("cuda").contiguous()
+    U.check(U.lib().esam3_op_vit_rope(d, U.P(x_d), U.H(U.np32(cs)), B * H * W, H, W, ws, heads, None), "op_vit_rope")
+    U.assert_close(x_d.float().cpu().view(B, H, W, 3, heads, 32, 2), _q(ref, mode) if mode == "bf16" else ref, mode, "vit rope")
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("B,H,W,C,R", [(2, 63, 63, 256, 64), (3, 20, 31, 64, 16), (1, 32, 32, 512, 128), (2, 7, 5, 48, 16)])
 def test_squeeze_excite(mode, B, H, W, C, R):
     d, tdt = U.DT[mode]
