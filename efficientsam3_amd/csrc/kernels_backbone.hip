@@ -799,6 +799,157 @@ __global__ __launch_bounds__(256) void attn_mfma64_kernel(const bf16_t* __restri
     }
 }
 
+// The same scheme for TinyViT's windows (bf16, head dim 32; tiny_vit.py:265-293,339-372): WS x WS windows over
+// a map that is zero-padded to a multiple of WS before the attention's LayerNorm (padded positions
+// carry the constant `pad_qkv`), additive bias[h][|dy|*WS+|dx|], qkv rows [heads][q32|k32|v32].
+// N = WS*WS is not a multiple of the 64-key tile: the surplus keys of the last tile are masked.
+template <int WS, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_mfma32_win_kernel(const bf16_t* __restrict__ qkv, int ld,
+                                                                  const bf16_t* __restrict__ pad_qkv,
+                                                                  const float* __restrict__ bias, bf16_t* __restrict__ out,
+                                                                  int ldo, int H, int W, int heads, int nwx, int nwy) {
+  constexpr int HD = 32, KT = 64, VP = 136, N = WS * WS, NT = NW * 64;
+  constexpr float LOG2E = 1.4426950408889634f;
+  __shared__ __attribute__((aligned(16))) char sK[KT * 64];    // [key][32 d] bf16, 64-byte rows, slots ^ (key>>2)&3
+  __shared__ __attribute__((aligned(16))) char sVt[HD * VP];  // [d][64 keys]
+  __shared__ float sb[N];                                      // bias row of this head, pre-scaled by log2(e)
+  const int h = blockIdx.y;
+  const int win = blockIdx.z % (nwx * nwy);
+  const int64_t b = blockIdx.z / (nwx * nwy);
+  const int wy = win / nwx, wx = win - wy * nwx;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
+  // token i of the window -> its qkv row for head h (the constant row for zero-padded positions)
+  auto tok = [&](int i) -> const bf16_t* {
+    const int y = wy * WS + i / WS, x = wx * WS + i % WS;
+    return (y < H && x < W) ? qkv + ((b * H + y) * (int64_t)W + x) * ld + h * 96 : pad_qkv + h * 96;
+  };
+  for (int i = tid; i < N; i += NT) sb[i] = bias[h * N + i] * LOG2E;
+  const int qi = blockIdx.x * (NW * 32) + wave * 32 + l31;
+  const int qc = qi < N ? qi : N - 1;
+  const int qy = qc / WS, qx = qc - qy * WS;
+  const bool valid = qi < N && wy * WS + qy < H && wx * WS + qx < W;
+  u32x4 qf[2];
+  {
+    const bf16_t* src = tok(qc);
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) qf[s_] = *reinterpret_cast<const u32x4*>(src + s_ * 16 + g * 8);
+  }
+  f32x16_v o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+  const float scale_log2e = 0.17677669529663687f * LOG2E;  // 32^-0.5 * log2(e)
+
+  for (int j0 = 0; j0 < N; j0 += KT) {
+    __syncthreads();
+    for (int c = tid; c < KT * 4; c += NT) {  // K tile: 4 slots of 16 bytes per key
+      const int key = c >> 2, slot = c & 3;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (j0 + key < N) v = *reinterpret_cast<const u32x4*>(tok(j0 + key) + 32 + slot * 8);
+      *reinterpret_cast<u32x4*>(sK + key * 64 + ((slot ^ ((key >> 2) & 3)) << 4)) = v;
+    }
+    for (int c = tid; c < 64; c += NT) {  // V^T tile: (8 d) x (4 keys) patches
+      const int dch = c & 3, kq = c >> 2;
+      u32x4 u[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int key = j0 + kq * 4 + i;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        u[i] = key < N ? *reinterpret_cast<const u32x4*>(tok(key) + 64 + dch * 8) : z;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int w_ = e >> 1;
+        uint32_t a0, a1;
+        if (e & 1) {
+          a0 = (u[0][w_] >> 16) | (u[1][w_] & 0xffff0000u);
+          a1 = (u[2][w_] >> 16) | (u[3][w_] & 0xffff0000u);
+        } else {
+          a0 = (u[0][w_] & 0xffffu) | (u[1][w_] << 16);
+          a1 = (u[2][w_] & 0xffffu) | (u[3][w_] << 16);
+        }
+        *reinterpret_cast<uint2*>(sVt + (dch * 8 + e) * VP + kq * 8) = make_uint2(a0, a1);
+      }
+    }
+    __syncthreads();
+
+    f32x16_v sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+      const int key = kb * 32 + l31;
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + key * 64 + (((s_ * 2 + g) ^ ((key >> 2) & 3)) << 4));
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, kf),
+                                                           __builtin_bit_cast(bf16x8_v, qf[s_]), sacc[kb], 0, 0, 0);
+      }
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kj = j0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;  // this register's key
+        float sc = -INFINITY;
+        if (kj < N) {
+          const int ky = kj / WS, kx = kj - ky * WS;
+          const int dy = qy > ky ? qy - ky : ky - qy, dx = qx > kx ? qx - kx : kx - qx;
+          sc = fmaf(sacc[kb][r], scale_log2e, sb[dy * WS + dx]);
+        }
+        sacc[kb][r] = sc;
+        mt = fmaxf(mt, sc);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    m = mn;
+    lsum *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+    u32x4 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = __builtin_amdgcn_exp2f(sacc[kb][r] - mn);
+        lsum += pv[r];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        pf[kb][s2].x = pack_bf16x2(pv[8 * s2 + 0], pv[8 * s2 + 1]);
+        pf[kb][s2].y = pack_bf16x2(pv[8 * s2 + 2], pv[8 * s2 + 3]);
+        pf[kb][s2].z = pack_bf16x2(pv[8 * s2 + 4], pv[8 * s2 + 5]);
+        pf[kb][s2].w = pack_bf16x2(pv[8 * s2 + 6], pv[8 * s2 + 7]);
+      }
+    }
+    const char* vrow = sVt + l31 * VP;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int koff = (kb * 32 + 16 * s2 + 4 * g) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vrow + koff);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vrow + koff + 16);
+        const u32x4 vf = {lo.x, lo.y, hi.x, hi.y};
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, vf),
+                                                    __builtin_bit_cast(bf16x8_v, pf[kb][s2]), o, 0, 0, 0);
+      }
+  }
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (!valid) return;
+  const float inv = 1.f / lsum;
+  bf16_t* dst = out + ((b * H + wy * WS + qy) * (int64_t)W + wx * WS + qx) * ldo + h * HD;
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    const uint2 w_ = make_uint2(pack_bf16x2(o[4 * q4] * inv, o[4 * q4 + 1] * inv),
+                                pack_bf16x2(o[4 * q4 + 2] * inv, o[4 * q4 + 3] * inv));
+    *reinterpret_cast<uint2*>(dst + 8 * q4 + 4 * g) = w_;
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // Squeeze-Excite (timm SqueezeExcite as used by RepViT, repvit.py:136,150):
 //   gate[b][c] = sigmoid(W2 . relu(W1 . mean_hw(x[b]) + b1) + b2);  x *= gate
@@ -1401,6 +1552,19 @@ static int launch_window_attn(const void* qkv, int ld, const void* pad_qkv, cons
 
 int esam3_launch_window_attn(int dtype, const void* qkv, int ld, const void* pad_qkv, const float* bias, void* out,
                              int ldo, int B, int H, int W, int heads, int ws, hipStream_t s) {
+  static const bool no_mfma = getenv("ESAM3_ATTN_VALU") != nullptr;
+  if (dtype == 1 && !no_mfma && ld % 8 == 0 && ldo % 4 == 0 && (ws == 7 || ws == 14)) {
+    const int nwx = (W + ws - 1) / ws, nwy = (H + ws - 1) / ws;
+    const unsigned gz = (unsigned)(B * nwx * nwy);
+    if (ws == 7)
+      hipLaunchKernelGGL((attn_mfma32_win_kernel<7, 2>), dim3(1, (unsigned)heads, gz), dim3(128), 0, s, (const bf16_t*)qkv, ld,
+                         (const bf16_t*)pad_qkv, bias, (bf16_t*)out, ldo, H, W, heads, nwx, nwy);
+    else
+      hipLaunchKernelGGL((attn_mfma32_win_kernel<14, 4>), dim3(2, (unsigned)heads, gz), dim3(256), 0, s, (const bf16_t*)qkv,
+                         ld, (const bf16_t*)pad_qkv, bias, (bf16_t*)out, ldo, H, W, heads, nwx, nwy);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
   if (ws == 7)
     return dtype == 0 ? launch_window_attn<float, 7, 2, 4>(qkv, ld, pad_qkv, bias, out, ldo, B, H, W, heads, s)
                       : launch_window_attn<bf16_t, 7, 2, 4>(qkv, ld, pad_qkv, bias, out, ldo, B, H, W, heads, s);
