@@ -94,3 +94,30 @@ def test_product_path_fails_loudly_without_hip_device():
     assert not isinstance(ei.value, NotImplementedError)
     with pytest.raises(RuntimeError):
         model_builder.build_efficientsam3_image_model(device="cpu")
+
+
+def test_sam3_import_facade():
+    """<repo>/compat on PYTHONPATH gives the reference's import surface."""
+    import importlib
+    import os
+    import sys
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "compat")
+    saved = {k: v for k, v in sys.modules.items() if k == "sam3" or k.startswith("sam3.")}
+    for k in saved:
+        del sys.modules[k]
+    sys.path.insert(0, compat)
+    try:
+        sam3 = importlib.import_module("sam3")
+        proc = importlib.import_module("sam3.model.sam3_image_processor")
+        dev = importlib.import_module("sam3.device")
+        mb = importlib.import_module("sam3.model_builder")
+        import efficientsam3_amd
+        assert sam3.build_efficientsam3_image_model is efficientsam3_amd.build_efficientsam3_image_model
+        assert mb.build_sam3_image_model is efficientsam3_amd.build_sam3_image_model
+        assert proc.Sam3Processor is efficientsam3_amd.Sam3Processor
+        assert callable(dev.get_device)
+    finally:
+        sys.path.remove(compat)
+        for k in [k for k in sys.modules if k == "sam3" or k.startswith("sam3.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
