@@ -56,15 +56,15 @@ template <> struct Vec8<float> {
 
 // ------------------------------------------------------------------------------------
 // E0 stem: 3x3 stride-2 pad-1 conv, Cin = 3, NCHW fp32 in -> NHWC T out
-// (efficientvit/backbone.py:48-56).  One thread per output pixel, Cout <= 32.
+// (efficientvit/backbone.py:48-56; RepViT / TinyViT patch embedding).  Cout <= 64.
 // ------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                    const float* __restrict__ bias, T* __restrict__ out, int B,
                                                    int H, int W, int Cout, int act, unsigned gx, unsigned gy) {
   // thread = (output pixel, 8-channel group); weights [27][Cout] + bias in LDS
-  __shared__ float sw[27 * 32];
-  __shared__ float sb[32];
+  __shared__ float sw[27 * 64];
+  __shared__ float sb[64];
   for (int i = threadIdx.x; i < 27 * Cout; i += blockDim.x) sw[i] = w[i];
   for (int i = threadIdx.x; i < Cout; i += blockDim.x) sb[i] = bias ? bias[i] : 0.f;
   __syncthreads();
@@ -1403,7 +1403,7 @@ int esam3_launch_resize_aa_u8(const uint8_t* in, int H, int W, float* out, int O
 
 int esam3_launch_stem(int dtype, const float* img, const float* w, const float* bias, void* out,
                       int B, int H, int W, int Cout, int act, hipStream_t s) {
-  if (Cout > 32 || Cout % VEC) { esam3_set_error("stem: Cout=%d unsupported", Cout); return -1; }
+  if (Cout > 64 || Cout % VEC) { esam3_set_error("stem: Cout=%d unsupported", Cout); return -1; }
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   const unsigned gx = blocks_for((int64_t)OW * (Cout / VEC), 256), gy = (unsigned)(B * OH);
   DISPATCH_T(dtype, hipLaunchKernelGGL(stem_kernel<T>, dim3(gx * gy), dim3(256), 0, s, img, w, bias, (T*)out, B,

@@ -96,3 +96,38 @@ def test_student_predict_inst_vs_golden(student, mode):
             if not ok:
                 failures.append((name, what, v))
     assert not failures, failures
+
+
+@pytest.mark.parametrize("bt,mn", [("efficientvit", "b0"), ("efficientvit", "b2"), ("repvit", "m0.9"),
+                                   ("tinyvit", "5m"), ("tinyvit", "21m")])
+def test_other_sizes_vs_oracle_live(bt, mn):
+    """The S / L sizes of every student family (eval/eval_coco.py:158-162 aliases) against the oracle run
+    live on CPU (the oracle itself is pinned to the reference on the M sizes): f32 trunk embedding and one
+    point-prompt decode within 1e-3; the bf16 engine must agree with its own f32 twin within the bf16 envelope."""
+    from oracle import ref_model
+    sd = schema.synthetic_state_dict(bt, mn, seed=0)
+    img = synth.smooth_image_u8(seed=1)
+    x = torch.from_numpy(synth.normalise_to_chw_f32(img))[None]
+    taps = {}
+    with torch.inference_mode():
+        ost = ref_model.set_image(sd, x, (1008, 1008), mn, taps)
+        m_o, iou_o, low_o = ref_model.predict_inst(sd, ost, point_coords=np.array([[400.0, 520.0]], np.float32),
+                                                   point_labels=np.array([1]), multimask_output=True)
+    lows = {}
+    for mode in ("f32", "bf16"):
+        model = build_efficientsam3_image_model(device="cuda", enable_inst_interactivity=True, backbone_type=bt,
+                                                model_name=mn, dtype=mode, state_dict=sd)
+        out = model.engine.encode(x.to("cuda"), want_sam3=False, want_sam2=True, want_trunk=True)
+        trunk = out["trunk"].permute(0, 3, 1, 2).float().cpu()
+        state = Sam3Processor(model).set_image_tensor_batch(x.to("cuda"))
+        state["original_height"], state["original_width"] = 1008, 1008
+        masks, iou, low = model.predict_inst(state, point_coords=np.array([[400.0, 520.0]], np.float32),
+                                             point_labels=np.array([1]), multimask_output=True)
+        lows[mode] = low
+        if mode == "f32":
+            assert float((trunk - taps["trunk"]).abs().max()) <= 1e-3, (bt, mn)
+            assert float(np.abs(low - low_o).max()) <= 1e-3 and float(np.abs(iou - iou_o).max()) <= 1e-3
+            assert _iou(masks, m_o) >= 0.999
+        del model
+    rng = float(low_o.max() - low_o.min())
+    assert float(np.abs(lows["bf16"] - lows["f32"]).max()) <= max(0.35, 0.03 * rng)
