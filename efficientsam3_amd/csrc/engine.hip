@@ -1000,14 +1000,11 @@ int E::backbone_vit(const float* img, int B, const esam3_image_features* out, T4
     CK(layernorm(q + "norm1", x.p, ln, rows, D, 1e-5f));
     CK(linear(q + "attn.qkv", ln, D, rows, qkv, 3 * D, ACT_NONE));
     if (!dry) {
-      CK(prof_launch("vit_rope", 0.0, 4.0 * (double)rows * D * (double)esz, [&]() {
-        return esam3_launch_vit_rope(dtype, qkv, global ? rope_glob : rope_win, rows, G, G, global ? G : ws, heads, st);
-      }));
       const double keys = global ? (double)G * G : (double)ws * ws;
       CK(prof_launch(global ? "vit_attn_global" : "vit_attn_window", 4.0 * (double)rows * keys * D,
                      4.0 * (double)rows * D * (double)esz, [&]() {
                        return esam3_launch_attn_window(dtype, qkv, 3 * D, 0, D, 2 * D, ln, D, B, G, G, global ? G : ws,
-                                                       heads, 64, st);
+                                                       heads, 64, global ? rope_glob : rope_win, st);
                      }));
     }
     CK(linear(q + "attn.proj", ln, D, rows, y.p, D, ACT_NONE, x.p, D));

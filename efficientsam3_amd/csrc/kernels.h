@@ -113,8 +113,10 @@ int esam3_launch_preprocess_u8(const uint8_t* in, float* out, int B, int H, int 
 int esam3_launch_patchify(int dtype, const float* img_nchw, void* a, int B, int S, int P, int ldk, hipStream_t s);
 int esam3_launch_vit_rope(int dtype, void* qkv, const float* cos_sin /*[ws*ws][32][2]*/, int64_t rows, int H, int W, int ws,
                           int heads, hipStream_t s);
-int esam3_launch_attn_window(int dtype, const void* qkv, int ld, int q_off, int k_off, int v_off, void* out, int ldo, int B,
-                             int H, int W, int ws, int heads, int hd, hipStream_t s);
+// rope: optional [ws*ws][32][2] (cos, sin) table applied to q and k (on the fly in the bf16 MFMA kernel, as an
+// in-place pass over qkv before the fp32 kernel)
+int esam3_launch_attn_window(int dtype, void* qkv, int ld, int q_off, int k_off, int v_off, void* out, int ldo, int B,
+                             int H, int W, int ws, int heads, int hd, const float* rope, hipStream_t s);
 // TinyViT window attention, head dim 32: qkv [B][H][W][heads*96] (q|k|v per head), pad_qkv [heads*96] (T),
 // bias [heads][ws*ws] fp32 indexed by |dy|*ws+|dx|; out [B][H][W][heads*32]
 int esam3_launch_window_attn(int dtype, const void* qkv, int ld, const void* pad_qkv, const float* bias, void* out,

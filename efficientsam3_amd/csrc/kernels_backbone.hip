@@ -656,8 +656,21 @@ __global__ __launch_bounds__(256) void attn_window_kernel(const T* __restrict__ 
 //                     the V^T fragments are fetched with the same key permutation (two 8-byte reads).
 __global__ __launch_bounds__(256) void attn_mfma64_kernel(const bf16_t* __restrict__ qkv, int ld, int q_off, int k_off,
                                                           int v_off, bf16_t* __restrict__ out, int ldo, int H, int W,
-                                                          int ws, int heads, float scale_log2e) {
+                                                          int ws, int heads, float scale_log2e,
+                                                          const float* __restrict__ rope) {
   constexpr int HD = 64, KT = 64, VP = 136;  // V^T row pitch in bytes: 34 dwords -> conflict-free b64 reads
+  // optional 2-D axial RoPE (vitdet.py:68-90) applied to q and k on their way in: rope[token][pair] =
+  // (cos, sin) fp32, pairs (x[2i], x[2i+1]); rotated in fp32 and rounded back to bf16 like the reference
+  auto rotate8 = [&](u32x4 v, const float* cs /* 4 pairs x (cos, sin) */) -> u32x4 {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = __uint_as_float(v[i] << 16), b_ = __uint_as_float(v[i] & 0xffff0000u);
+      const float c = cs[2 * i], s_ = cs[2 * i + 1];
+      r[i] = pack_bf16x2(a * c - b_ * s_, a * s_ + b_ * c);
+    }
+    return r;
+  };
   __shared__ __attribute__((aligned(16))) char sK[KT * 128];
   __shared__ __attribute__((aligned(16))) char sVt[HD * VP];
   const int N = ws * ws;
@@ -678,7 +691,10 @@ __global__ __launch_bounds__(256) void attn_mfma64_kernel(const bf16_t* __restri
   {
     const bf16_t* src = qkv + row_of(valid ? qi : N - 1) * ld + q_off + h * HD;
 #pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_) qf[s_] = *reinterpret_cast<const u32x4*>(src + s_ * 16 + g * 8);
+    for (int s_ = 0; s_ < 4; ++s_) {
+      qf[s_] = *reinterpret_cast<const u32x4*>(src + s_ * 16 + g * 8);
+      if (rope) qf[s_] = rotate8(qf[s_], rope + ((int64_t)(valid ? qi : N - 1) * 32 + s_ * 8 + g * 4) * 2);
+    }
   }
   f32x16_v o[2];
 #pragma unroll
@@ -694,7 +710,8 @@ __global__ __launch_bounds__(256) void attn_mfma64_kernel(const bf16_t* __restri
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = t + 128 * i, key = c >> 3, slot = c & 7;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(qkv + row_of(j0 + key) * ld + k_off + h * HD + slot * 8);
+        u32x4 v = *reinterpret_cast<const u32x4*>(qkv + row_of(j0 + key) * ld + k_off + h * HD + slot * 8);
+        if (rope) v = rotate8(v, rope + ((int64_t)(j0 + key) * 32 + slot * 4) * 2);
         *reinterpret_cast<u32x4*>(sK + key * 128 + ((slot ^ ((key >> 1) & 7)) << 4)) = v;
       }
     } else {  // V^T tile [d][64 keys]: a thread transposes an (8 d) x (4 keys) patch in registers
@@ -1599,17 +1616,21 @@ int esam3_launch_vit_rope(int dtype, void* qkv, const float* cos_sin, int64_t ro
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-int esam3_launch_attn_window(int dtype, const void* qkv, int ld, int q_off, int k_off, int v_off, void* out, int ldo, int B,
-                             int H, int W, int ws, int heads, int hd, hipStream_t s) {
+int esam3_launch_attn_window(int dtype, void* qkv, int ld, int q_off, int k_off, int v_off, void* out, int ldo, int B,
+                             int H, int W, int ws, int heads, int hd, const float* rope, hipStream_t s) {
   if (hd != 64 || H % ws || W % ws) { esam3_set_error("attn_window: hd=%d ws=%d H=%d W=%d unsupported", hd, ws, H, W); return -1; }
   const int N = ws * ws;
   static const bool no_mfma = getenv("ESAM3_ATTN_VALU") != nullptr;
   if (dtype == 1 && N % 64 == 0 && !no_mfma && ld % 8 == 0 && q_off % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0 && ldo % 4 == 0) {
     dim3 grid(blocks_for(N, 128), (unsigned)heads, (unsigned)(B * (H / ws) * (W / ws)));
     hipLaunchKernelGGL(attn_mfma64_kernel, grid, dim3(256), 0, s, (const bf16_t*)qkv, ld, q_off, k_off, v_off,
-                       (bf16_t*)out, ldo, H, W, ws, heads, 0.125f * 1.4426950408889634f);
+                       (bf16_t*)out, ldo, H, W, ws, heads, 0.125f * 1.4426950408889634f, rope);  // RoPE on the fly
     HIP_CHECK_RET(hipGetLastError());
     return 0;
+  }
+  if (rope) {  // the VALU kernel reads rotated q / k: rotate in place first (needs the ViT row layout)
+    if (q_off != 0 || k_off != heads * hd || ld != 3 * heads * hd) { esam3_set_error("attn_window: rope needs the [3][heads][hd] row layout"); return -1; }
+    if (esam3_launch_vit_rope(dtype, qkv, rope, (int64_t)B * H * W, H, W, ws, heads, s)) return -1;
   }
   dim3 grid(blocks_for(N, 256), (unsigned)heads, (unsigned)(B * (H / ws) * (W / ws)));
   DISPATCH_T(dtype, hipLaunchKernelGGL((attn_window_kernel<T, 64, 32>), grid, dim3(256), 0, s, (const T*)qkv, ld, q_off,

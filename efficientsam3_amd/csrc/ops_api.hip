@@ -121,9 +121,16 @@ int esam3_op_window_attention(int dtype, const void* qkv, const float* pad_qkv, 
   return 0;
 }
 
-int esam3_op_attn_window(int dtype, const void* qkv, void* out, int B, int H, int W, int ws, int heads, void* stream) {
+int esam3_op_attn_window(int dtype, void* qkv, const float* cos_sin, void* out, int B, int H, int W, int ws, int heads,
+                         void* stream) {
+  Tmp t;
   const int D = heads * 64;
-  if (esam3_launch_attn_window(dtype, qkv, 3 * D, 0, D, 2 * D, out, D, B, H, W, ws, heads, 64, (hipStream_t)stream)) return -1;
+  float* cs = nullptr;
+  if (cos_sin) {
+    cs = (float*)t.up(cos_sin, (size_t)ws * ws * 32 * 2 * 4);
+    if (!cs) return fail("op_attn_window");
+  }
+  if (esam3_launch_attn_window(dtype, qkv, 3 * D, 0, D, 2 * D, out, D, B, H, W, ws, heads, 64, cs, (hipStream_t)stream)) return -1;
   HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }

@@ -152,9 +152,10 @@ int esam3_op_window_attention(int dtype, const void* qkv_dev, const float* pad_q
                               const float* bias_host, void* out_dev, int B, int H, int W, int heads,
                               int ws, void* hip_stream);
 /* ViT-H attention (vitdet.py:466-515): qkv [B][H][W][3][heads][64]; softmax(q k^T / 8) v over ws x ws
- * windows (ws = H = W: global attention); out [B][H][W][heads*64].  bf16 runs on MFMA when ws*ws % 64 == 0 */
-int esam3_op_attn_window(int dtype, const void* qkv_dev, void* out_dev, int B, int H, int W, int ws,
-                         int heads, void* hip_stream);
+ * windows (ws = H = W: global attention); out [B][H][W][heads*64].  bf16 runs on MFMA when ws*ws % 64 == 0.
+ * With a RoPE table [ws*ws][32][2] q and k are rotated first (on the fly on MFMA; in place in qkv otherwise) */
+int esam3_op_attn_window(int dtype, void* qkv_dev, const float* rope_cos_sin_host /* or NULL */, void* out_dev,
+                         int B, int H, int W, int ws, int heads, void* hip_stream);
 /* 2-D axial RoPE in place on the q and k parts of qkv (vitdet.py:41-90): cos_sin_host [ws*ws][32][2] */
 int esam3_op_vit_rope(int dtype, void* qkv_dev, const float* cos_sin_host, int64_t rows, int H, int W, int ws,
                       int heads, void* hip_stream);

@@ -129,7 +129,8 @@ def test_window_attention(mode, B, H, W, heads, ws):
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("B,H,W,ws,heads", [(1, 24, 24, 24, 2), (2, 48, 48, 24, 3), (1, 16, 16, 16, 1), (1, 72, 72, 72, 2),
                                             (2, 16, 16, 8, 2), (1, 10, 10, 5, 1)])
-def test_vit_attention_window(mode, B, H, W, ws, heads):
+@pytest.mark.parametrize("rope", [False, True])
+def test_vit_attention_window(mode, B, H, W, ws, heads, rope):
     """ViT-H softmax attention over ws x ws windows (ws = H: global).  bf16 with ws*ws % 64 == 0 runs the MFMA
     flash-attention kernel (P is rounded to bf16 before P.V, like the reference's bf16 SDPA); the other cases
     run the fp32 VALU kernel."""
@@ -138,11 +139,20 @@ def test_vit_attention_window(mode, B, H, W, ws, heads):
     qkv = _q(_rand(B, H, W, 3 * D, seed=1), mode)
     nw = H // ws
     t = qkv.view(B, nw, ws, nw, ws, 3, heads, 64).permute(5, 0, 1, 3, 6, 2, 4, 7).reshape(3, B * nw * nw, heads, ws * ws, 64)
+    cs = None
+    if rope:  # rotate q and k of every window token by its (cos, sin) row; bf16: rounded back like the engine
+        ang = torch.rand(ws * ws, 32, generator=torch.Generator().manual_seed(7)) * 6.0
+        cs = torch.stack([torch.cos(ang), torch.sin(ang)], dim=-1).contiguous()
+        def rot(u):
+            a, b = u[..., 0::2], u[..., 1::2]
+            return _q(torch.stack([a * cs[:, :, 0] - b * cs[:, :, 1], a * cs[:, :, 1] + b * cs[:, :, 0]], dim=-1).flatten(-2), mode)
+        t = torch.stack([rot(t[0]), rot(t[1]), t[2]])
     o = F.scaled_dot_product_attention(t[0], t[1], t[2])  # [Bw, heads, N, 64]
     ref = o.view(B, nw, nw, heads, ws, ws, 64).permute(0, 1, 4, 2, 5, 3, 6).reshape(B, H, W, D)
     x_d = qkv.to(tdt).to("cuda").contiguous()
     out = torch.empty((B, H, W, D), dtype=tdt, device="cuda")
-    U.check(U.lib().esam3_op_attn_window(d, U.P(x_d), U.P(out), B, H, W, ws, heads, None), "op_attn_window")
+    U.check(U.lib().esam3_op_attn_window(d, U.P(x_d), U.H(U.np32(cs)) if rope else None, U.P(out), B, H, W, ws, heads,
+                                         None), "op_attn_window")
     U.assert_close(out.float().cpu(), ref, mode, f"vit attention ws={ws} heads={heads}")
 
 
