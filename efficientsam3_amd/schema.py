@@ -434,6 +434,97 @@ def vit_schema() -> _Schema:
     return s
 
 
+def pcs_schema() -> _Schema:
+    """Text-grounding (PCS) detector of Sam3Image (model_builder.py:116-300): geometry encoder, fusion
+    encoder (6 layers), DETR decoder (6 layers, 200 queries, box RPB, presence token), segmentation head,
+    dot-product scoring.  Key layout = the reference's module tree."""
+    s = _Schema()
+    d, ff = D_MODEL, 2048
+
+    def mha(p):
+        s[p + "in_proj_weight"] = ((3 * d, d), "linear")
+        s[p + "in_proj_bias"] = ((3 * d,), "bias")
+        s[p + "out_proj.weight"] = ((d, d), "linear_res")
+        s[p + "out_proj.bias"] = ((d,), "bias")
+
+    def mlp(p, dims):
+        for i in range(len(dims) - 1):
+            s.linear(p + f"layers.{i}", dims[i + 1], dims[i])
+
+    def enc_layer(p):
+        mha(p + "self_attn.")
+        mha(p + "cross_attn_image.")
+        s.linear(p + "linear1", ff, d)
+        s[p + "linear2.weight"] = ((d, ff), "linear_res")
+        s[p + "linear2.bias"] = ((d,), "bias")
+        for n in ("norm1", "norm2", "norm3"):
+            s.ln(p + n, d)
+
+    g = "geometry_encoder."
+    s[g + "label_embed.weight"] = ((2, d), "embed")
+    s[g + "cls_embed.weight"] = ((1, d), "embed")
+    s.linear(g + "points_direct_project", d, 2)
+    s.linear(g + "points_pool_project", d, d)
+    s.linear(g + "points_pos_enc_project", d, d)
+    s.linear(g + "boxes_direct_project", d, 4)
+    s.conv(g + "boxes_pool_project", d, d, 7, bias=True)
+    s.linear(g + "boxes_pos_enc_project", d, d + 2)
+    s.linear(g + "final_proj", d, d)
+    s.ln(g + "norm", d)
+    s.ln(g + "img_pre_norm", d)
+    for i in range(3):
+        enc_layer(g + f"encode.{i}.")
+    s.ln(g + "encode_norm", d)
+
+    for i in range(6):
+        enc_layer(f"transformer.encoder.layers.{i}.")
+    t = "transformer.decoder."
+    for i in range(6):
+        q = t + f"layers.{i}."
+        mha(q + "cross_attn.")
+        s.ln(q + "norm1", d)
+        mha(q + "ca_text.")
+        s.ln(q + "catext_norm", d)
+        mha(q + "self_attn.")
+        s.ln(q + "norm2", d)
+        s.linear(q + "linear1", ff, d)
+        s[q + "linear2.weight"] = ((d, ff), "linear_res")
+        s[q + "linear2.bias"] = ((d,), "bias")
+        s.ln(q + "norm3", d)
+    s.ln(t + "norm", d)
+    mlp(t + "bbox_embed.", [d, d, d, 4])
+    s[t + "query_embed.weight"] = ((200, d), "embed")
+    s[t + "reference_points.weight"] = ((200, 4), "gauss")
+    mlp(t + "boxRPB_embed_x.", [2, d, 8])
+    mlp(t + "boxRPB_embed_y.", [2, d, 8])
+    s[t + "presence_token.weight"] = ((1, d), "embed")
+    mlp(t + "presence_token_head.", [d, d, d, 1])
+    s.ln(t + "presence_token_out_norm", d)
+    mlp(t + "ref_point_head.", [2 * d, d, d])
+
+    h = "segmentation_head."
+    for i in range(3):
+        s.conv(h + f"pixel_decoder.conv_layers.{i}", d, d, 3, bias=True)
+        s.ln(h + f"pixel_decoder.norms.{i}", d)
+    mlp(h + "mask_predictor.mask_embed.", [d, d, d, d])
+    mha(h + "cross_attend_prompt.")
+    s.ln(h + "cross_attn_norm", d)
+    s.conv(h + "semantic_seg_head", 1, d, 1, bias=True)
+    s.conv(h + "instance_seg_head", d, d, 1, bias=True)
+
+    p = "dot_prod_scoring."
+    s.linear(p + "prompt_mlp.layers.0", ff, d)
+    s.linear(p + "prompt_mlp.layers.1", d, ff)
+    s.ln(p + "prompt_mlp.out_norm", d)
+    s.linear(p + "prompt_proj", d, d)
+    s.linear(p + "hs_proj", d, d)
+    return s
+
+
+def synthetic_pcs_state_dict(seed: int = 0):
+    return init_state_dict(pcs_schema(), seed)
+
+
 def image_path_schema(backbone_type: str = "efficientvit", model_name: str = "b1",
                       enable_inst_interactivity: bool = True) -> _Schema:
     """All tensors read by set_image + predict_inst for a student model."""
