@@ -29,6 +29,16 @@ class ImageFeatures(C.Structure):
                 ("trunk_dev", C.c_void_p), ("stages_dev", C.c_void_p * 5)]
 
 
+class GroundIn(C.Structure):
+    _fields_ = [("sam3_fpn_dev", C.c_void_p * 3), ("n_images", C.c_int), ("language_features_dev", C.c_void_p),
+                ("language_mask_dev", C.c_void_p), ("n_tokens", C.c_int)]
+
+
+class GroundOut(C.Structure):
+    _fields_ = [("pred_logits_dev", C.c_void_p), ("pred_boxes_dev", C.c_void_p), ("presence_logit_dev", C.c_void_p),
+                ("pred_masks_dev", C.c_void_p), ("semantic_seg_dev", C.c_void_p)]
+
+
 class Prompts(C.Structure):
     _fields_ = [("sam2_fpn_dev", C.c_void_p * 3), ("n_images", C.c_int), ("n_prompts", C.c_int),
                 ("prompt_image_dev", C.c_void_p), ("coords_dev", C.c_void_p),
@@ -62,6 +72,7 @@ SIGNATURES = {
     "esam3_profile_report": (_I, [_P, C.c_char_p, _L]),
     "esam3_workspace_bytes": (_L, [_P]),
     "esam3_elem_size": (_I, [_P]),
+    "esam3_ground": (_I, [_P, _P, _P, _P]),
     "esam3_encode_text": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "esam3_preprocess_u8": (_I, [_P, _P, _I, _I, _I, _P]),
     "esam3_preprocess_resize_u8": (_I, [_P, _I, _I, _P, _I, _I, _P]),

@@ -537,6 +537,13 @@ struct esam3_engine {
   int encode(const float* img, int B, const esam3_image_features* out);
   int decode(const esam3_prompts* pr, const esam3_decode_out* out);
   int precompute_pe();
+  // ---- PCS text-grounding detector -------------------------------------------------------------
+  bool pcs_ready = false;
+  PackedGemm* pk_rows(const std::string& wname, const std::string& bname, int row0, int nrows, const std::string& key,
+                      int zero_from = -1);
+  void* pcs_pos_table(const std::string& key, PackedGemm* g);
+  int pcs_prepare();
+  int ground(const esam3_ground_in* in, const esam3_ground_out* out);
   int text_repmixer(const std::string& p, void* x, int B, int S, int D, void* out);
   int encode_text(const int64_t* tokens, int B, int S, float* memory_sbd, float* embeds_sbd);
   int ensure_arena(size_t need);
@@ -1293,6 +1300,375 @@ int E::encode_text(const int64_t* tokens, int B, int S, float* memory_sbd, float
   return 0;
 }
 
+// =======================================================================================
+// PCS text-grounding detector: Sam3Image.forward_grounding (sam3_image.py:442-493) for the prompt that
+// Sam3Processor.set_text_prompt issues (one text per image + the dummy geometric prompt).  Every tensor is
+// token-major [B][L][256]; image tokens are the NHWC 72x72 level of the sam3 neck as it is.
+// =======================================================================================
+// rows [row0, row0+nrows) of a [R][K] weight (+ bias) as their own packed GEMM; rows >= zero_from are zeroed
+PackedGemm* E::pk_rows(const std::string& wname, const std::string& bname, int row0, int nrows, const std::string& key,
+                       int zero_from) {
+  auto it = gemms.find(key + ".weight");
+  if (it != gemms.end()) return &it->second;
+  const HostTensor* w = need(wname);
+  if (!w) return nullptr;
+  const int K = (int)w->shape[1];
+  HostTensor sw;
+  sw.shape = {nrows, K};
+  sw.d.assign(w->d.begin() + (size_t)row0 * K, w->d.begin() + (size_t)(row0 + nrows) * K);
+  if (zero_from >= 0) std::fill(sw.d.begin() + (size_t)zero_from * K, sw.d.end(), 0.f);
+  raw[key + ".weight"] = std::move(sw);
+  if (!bname.empty()) {
+    const HostTensor* b = need(bname);
+    if (!b) return nullptr;
+    HostTensor sb;
+    sb.shape = {nrows};
+    sb.d.assign(b->d.begin() + row0, b->d.begin() + row0 + nrows);
+    raw[key + ".bias"] = std::move(sb);
+  }
+  return pk_conv_like_linear(key + ".weight", bname.empty() ? "" : key + ".bias");
+}
+
+// pos72 . W^T (no bias) as a persistent [5184][N] table: (x + pos) W^T = x W^T + table, added as a
+// batch-broadcast residual in the GEMM epilogue
+void* E::pcs_pos_table(const std::string& key, PackedGemm* g) {
+  auto it = tbufs.find(key);
+  if (it != tbufs.end()) return it->second;
+  if (!g) return nullptr;
+  void* o = nullptr;
+  if (hipMalloc(&o, (size_t)EMB * EMB * g->N * esz) != hipSuccess) { esam3_set_error("hipMalloc failed (%s)", key.c_str()); return nullptr; }
+  owned.push_back(o);
+  const bool was_dry = dry;
+  dry = false;
+  const int rc = gemm(g, tbufs["pcs_pos72"], DM, (int64_t)EMB * EMB, 1, 1, o, g->N, ACT_NONE);
+  dry = was_dry;
+  if (rc) return nullptr;
+  tbufs[key] = o;
+  return o;
+}
+
+// one-time constants: the sine position encoding of the 72x72 level (position_encoding.py:92-127), its
+// projections through every attention that adds it to queries / keys, and the geometry encoder's CLS token
+int E::pcs_prepare() {
+  if (pcs_ready) return 0;
+  if (!find("transformer.decoder.query_embed.weight")) { esam3_set_error("esam3_ground: no PCS detector weights were loaded"); return -1; }
+  {
+    std::vector<float> pos((size_t)EMB * EMB * DM);
+    const int half = DM / 2;
+    const float eps = 1e-6f, scale = 6.283185307179586f;
+    std::vector<float> dim_t(half);
+    for (int i = 0; i < half; ++i) dim_t[i] = std::pow(10000.0f, (float)(2 * (i / 2)) / (float)half);
+    for (int y = 0; y < EMB; ++y)
+      for (int x = 0; x < EMB; ++x) {
+        const float ye = (float)(y + 1) / ((float)EMB + eps) * scale, xe = (float)(x + 1) / ((float)EMB + eps) * scale;
+        float* o = &pos[((size_t)y * EMB + x) * DM];
+        for (int i = 0; i < half; ++i) {
+          const float py = ye / dim_t[i], px = xe / dim_t[i];
+          o[i] = (i % 2 == 0) ? std::sin(py) : std::cos(py);          // channels [0,128): y
+          o[half + i] = (i % 2 == 0) ? std::sin(px) : std::cos(px);   // channels [128,256): x
+        }
+      }
+    void* d = upload_T(pos);
+    if (!d) return -1;
+    tbufs["pcs_pos72"] = d;
+  }
+  // geometry encoder: x0 = norm(final_proj(cls)) is a constant of the weights
+  {
+    const std::string g = "geometry_encoder.";
+    const HostTensor *cls = need(g + "cls_embed.weight"), *w = need(g + "final_proj.weight"), *b = need(g + "final_proj.bias"),
+                     *nw = need(g + "norm.weight"), *nb = need(g + "norm.bias");
+    if (!cls || !w || !b || !nw || !nb) return -1;
+    std::vector<double> y(DM);
+    double mean = 0;
+    for (int o = 0; o < DM; ++o) {
+      double a = b->d[o];
+      for (int c = 0; c < DM; ++c) a += (double)w->d[(size_t)o * DM + c] * cls->d[c];
+      y[o] = a; mean += a;
+    }
+    mean /= DM;
+    double var = 0;
+    for (int o = 0; o < DM; ++o) var += (y[o] - mean) * (y[o] - mean);
+    var /= DM;
+    std::vector<float> x0(DM);
+    for (int o = 0; o < DM; ++o) x0[o] = (float)((y[o] - mean) / std::sqrt(var + 1e-5) * nw->d[o] + nb->d[o]);
+    if (!fvec_raw("pcs_geo_x0", x0)) return -1;
+    std::vector<float> zero(DM, 0.f);
+    if (!fvec_raw("pcs_zero_row", zero)) return -1;
+  }
+  const bool was_dry = dry;
+  for (int i = 0; i < 3; ++i) {  // geometry layers: keys = Wk (img + pos)
+    const std::string p = "geometry_encoder.encode." + std::to_string(i) + ".cross_attn_image.";
+    if (!pcs_pos_table(p + "#posk", pk_rows(p + "in_proj_weight", "", DM, DM, p + "#posk_w"))) return -1;
+  }
+  for (int i = 0; i < 6; ++i) {
+    const std::string e = "transformer.encoder.layers." + std::to_string(i) + ".self_attn.";
+    // fused [q|k|v] projection of LN(x): the position encoding enters q and k only
+    if (!pcs_pos_table(e + "#posqkv", pk_rows(e + "in_proj_weight", "", 0, 3 * DM, e + "#posqkv_w", 2 * DM))) return -1;
+    const std::string d = "transformer.decoder.layers." + std::to_string(i) + ".cross_attn.";
+    if (!pcs_pos_table(d + "#posk", pk_rows(d + "in_proj_weight", "", DM, DM, d + "#posk_w"))) return -1;
+  }
+  dry = was_dry;
+  HIP_CHECK_RET(hipStreamSynchronize(st));
+  pcs_ready = true;
+  return 0;
+}
+
+int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
+  arena.top = 0;
+  const int B = in->n_images, S = in->n_tokens, Sp = S + 1, Q = 200, QR = Q + 1, HEADS = 8, FF = 2048;
+  const int64_t P = (int64_t)EMB * EMB;
+  const void* img = in->sam3_fpn_dev[2];
+  const void* pos = tbufs["pcs_pos72"];
+  auto L = [&](const std::string& w, const std::string& b, int r0, int n, const std::string& key) { return pk_rows(w, b, r0, n, key); };
+  auto lin = [&](PackedGemm* g, const void* A, int lda, int64_t M, void* o, int ldc, int act, const void* res = nullptr,
+                 int ldr = 0, int res_mod = 0) -> int { return gemm(g, A, lda, M, 1, 1, o, ldc, act, res, ldr, 1, res_mod); };
+  auto attn = [&](const void* q, int ldq, int qo, const void* kv, int ldk, int ko, int vo, void* o, int Nq, int Nk,
+                  const uint8_t* mask, const float* by = nullptr, const float* bx = nullptr, int q0 = 0) -> int {
+    if (dry) return 0;
+    return prof_launch("pcs_attn", 4.0 * (double)B * Nq * Nk * DM, 0.0, [&]() {
+      return esam3_launch_mha_core(dtype, q, ldq, qo, kv, ldk, ko, vo, o, DM, B, Nq, Nk, HEADS, mask, by, bx, EMB, EMB, q0, st);
+    });
+  };
+  auto addk = [&](const void* a, const void* b, void* o, int64_t n) -> int { return dry ? 0 : esam3_launch_add(dtype, a, b, o, n, st); };
+  auto LN = [&](const std::string& name, const void* x, void* o, int64_t rows) -> int { return layernorm(name, x, o, rows, DM, 1e-5f); };
+
+  // ---- prompt = [text tokens ; geometry CLS] ------------------------------------------------------
+  void* prompt = allocb((size_t)B * Sp * DM * esz);
+  uint8_t* pmask = (uint8_t*)allocb((size_t)B * Sp);
+  if (!ok(prompt) || !ok(pmask)) return -1;
+  if (!dry) CK(esam3_launch_pcs_prompt(dtype, in->language_features_dev, in->language_mask_dev, prompt, pmask, B, S, 1, DM, st));
+
+  // scratch shared by all stages (image-sized)
+  void* t2 = allocb((size_t)B * P * DM * esz);        // LayerNorm output / attention output
+  void* qkv = allocb((size_t)B * P * 3 * DM * esz);   // projections of image tokens
+  void* hid = allocb((size_t)B * P * FF * esz);       // FFN hidden
+  void* mem = allocb((size_t)B * P * DM * esz);       // encoder state -> memory
+  void* pkv = allocb((size_t)B * Sp * 2 * DM * esz);  // k|v of the prompt tokens
+  if (!ok(t2) || !ok(qkv) || !ok(hid) || !ok(mem) || !ok(pkv)) return -1;
+
+  // ---- geometry encoder on the dummy prompt: the CLS token through 3 layers (geometry_encoders.py:819-853)
+  {
+    const std::string g = "geometry_encoder.";
+    void* x = allocb((size_t)B * DM * esz);
+    void* a = allocb((size_t)B * DM * esz);
+    void* b_ = allocb((size_t)B * DM * esz);
+    void* h2 = allocb((size_t)B * FF * esz);
+    if (!ok(x) || !ok(a) || !ok(b_) || !ok(h2)) return -1;
+    if (!dry) CK(esam3_launch_bcast_rows(dtype, fbufs["pcs_geo_x0"], 1, x, 1, 0, B, DM, st));
+    for (int i = 0; i < 3; ++i) {
+      const std::string p = g + "encode." + std::to_string(i) + ".";
+      // self-attention over a single token: softmax over one key = 1 -> out_proj(v_proj(LN(x)))
+      CK(LN(p + "norm1", x, a, B));
+      CK(lin(L(p + "self_attn.in_proj_weight", p + "self_attn.in_proj_bias", 2 * DM, DM, p + "self_attn.#v"), a, DM, B, b_, DM, ACT_NONE));
+      CK(lin(pk_linear(p + "self_attn.out_proj"), b_, DM, B, x, DM, ACT_NONE, x, DM));
+      // cross-attention to the image tokens, keys carry the position encoding
+      CK(LN(p + "norm2", x, a, B));
+      const std::string c = p + "cross_attn_image.";
+      CK(lin(L(c + "in_proj_weight", c + "in_proj_bias", 0, DM, c + "#q"), a, DM, B, b_, DM, ACT_NONE));
+      CK(lin(L(c + "in_proj_weight", c + "in_proj_bias", DM, DM, c + "#k"), img, DM, B * P, qkv, 2 * DM, ACT_NONE, tbufs[c + "#posk"], DM, (int)P));
+      CK(lin(L(c + "in_proj_weight", c + "in_proj_bias", 2 * DM, DM, c + "#v"), img, DM, B * P, (char*)qkv + DM * esz, 2 * DM, ACT_NONE));
+      CK(attn(b_, DM, 0, qkv, 2 * DM, 0, DM, a, 1, (int)P, nullptr));
+      CK(lin(pk_linear(c + "out_proj"), a, DM, B, x, DM, ACT_NONE, x, DM));
+      CK(LN(p + "norm3", x, a, B));
+      CK(lin(pk_linear(p + "linear1"), a, DM, B, h2, FF, ACT_RELU));
+      CK(lin(pk_linear(p + "linear2"), h2, FF, B, x, DM, ACT_NONE, x, DM));
+    }
+    CK(LN(g + "encode_norm", x, a, B));
+    if (!dry) CK(esam3_launch_copy_rows(dtype, a, 1, prompt, Sp, S, B, DM, st));
+  }
+
+  // ---- fusion encoder (encoder.py:139-201,513-577): 6 pre-norm layers over the 5184 image tokens -------
+  if (!dry) HIP_CHECK_RET(hipMemcpyAsync(mem, img, (size_t)B * P * DM * esz, hipMemcpyDeviceToDevice, st));
+  for (int i = 0; i < 6; ++i) {
+    const std::string p = "transformer.encoder.layers." + std::to_string(i) + ".";
+    const std::string sa = p + "self_attn.", ca = p + "cross_attn_image.";
+    CK(LN(p + "norm1", mem, t2, B * P));
+    CK(lin(L(sa + "in_proj_weight", sa + "in_proj_bias", 0, 3 * DM, sa + "#qkv"), t2, DM, B * P, qkv, 3 * DM, ACT_NONE,
+           tbufs[sa + "#posqkv"], 3 * DM, (int)P));
+    CK(attn(qkv, 3 * DM, 0, qkv, 3 * DM, DM, 2 * DM, t2, (int)P, (int)P, nullptr));
+    CK(lin(pk_linear(sa + "out_proj"), t2, DM, B * P, mem, DM, ACT_NONE, mem, DM));
+    CK(LN(p + "norm2", mem, t2, B * P));
+    CK(lin(L(ca + "in_proj_weight", ca + "in_proj_bias", 0, DM, ca + "#q"), t2, DM, B * P, qkv, DM, ACT_NONE));
+    CK(lin(L(ca + "in_proj_weight", ca + "in_proj_bias", DM, 2 * DM, ca + "#kv"), prompt, DM, B * Sp, pkv, 2 * DM, ACT_NONE));
+    CK(attn(qkv, DM, 0, pkv, 2 * DM, 0, DM, t2, (int)P, Sp, pmask));
+    CK(lin(pk_linear(ca + "out_proj"), t2, DM, B * P, mem, DM, ACT_NONE, mem, DM));
+    CK(LN(p + "norm3", mem, t2, B * P));
+    CK(lin(pk_linear(p + "linear1"), t2, DM, B * P, hid, FF, ACT_RELU));
+    CK(lin(pk_linear(p + "linear2"), hid, FF, B * P, mem, DM, ACT_NONE, mem, DM));
+  }
+
+  // ---- decoder (decoder.py:33-191,417-618): [presence ; 200 queries] per image, post-norm layers, box refinement
+  const std::string t = "transformer.decoder.";
+  const int64_t R = (int64_t)B * QR;
+  void* x = allocb((size_t)R * DM * esz);      // rows: presence token, then the queries
+  void* xp = allocb((size_t)R * DM * esz);     // x + query_pos
+  void* qpos = allocb((size_t)R * DM * esz);
+  void* sine = allocb((size_t)R * 2 * DM * esz);
+  void* da = allocb((size_t)R * DM * esz);
+  void* dq = allocb((size_t)R * 3 * DM * esz);
+  void* dh = allocb((size_t)R * FF * esz);
+  void* hs = allocb((size_t)R * DM * esz);
+  float* ref = (float*)allocb(sizeof(float) * (size_t)R * 4);
+  float* by = (float*)allocb(sizeof(float) * (size_t)R * EMB * HEADS);
+  float* bx = (float*)allocb(sizeof(float) * (size_t)R * EMB * HEADS);
+  void* mkv = allocb((size_t)B * P * 2 * DM * esz);  // [k (with position) | v] of the memory
+  if (!ok(x) || !ok(xp) || !ok(qpos) || !ok(sine) || !ok(da) || !ok(dq) || !ok(dh) || !ok(hs) || !ok(ref) || !ok(by) || !ok(bx) || !ok(mkv))
+    return -1;
+  {
+    float* qe = fvec(t + "query_embed.weight");
+    float* pt = fvec(t + "presence_token.weight");
+    if (!qe || !pt) return -1;
+    auto it = fbufs.find("pcs_ref0");
+    if (it == fbufs.end()) {  // sigmoid(reference_points) with a dummy row for the presence token
+      const HostTensor* rp = need(t + "reference_points.weight");
+      if (!rp) return -1;
+      std::vector<float> r0((size_t)QR * 4, 0.5f);
+      for (int i = 0; i < Q * 4; ++i) r0[4 + i] = 1.f / (1.f + std::exp(-rp->d[i]));
+      if (!fvec_raw("pcs_ref0", r0)) return -1;
+    }
+    if (!dry) {
+      CK(esam3_launch_bcast_rows(dtype, pt, 1, x, QR, 0, B, DM, st));
+      CK(esam3_launch_bcast_rows(dtype, qe, Q, x, QR, 1, B, DM, st));
+      CK(esam3_launch_bcast_rows(0, fbufs["pcs_ref0"], QR, ref, QR, 0, B, 4, st));
+    }
+  }
+  const float* rpbx[4] = {fvec(t + "boxRPB_embed_x.layers.0.weight"), fvec(t + "boxRPB_embed_x.layers.0.bias"),
+                          fvec(t + "boxRPB_embed_x.layers.1.weight"), fvec(t + "boxRPB_embed_x.layers.1.bias")};
+  const float* rpby[4] = {fvec(t + "boxRPB_embed_y.layers.0.weight"), fvec(t + "boxRPB_embed_y.layers.0.bias"),
+                          fvec(t + "boxRPB_embed_y.layers.1.weight"), fvec(t + "boxRPB_embed_y.layers.1.bias")};
+  for (int k = 0; k < 4; ++k) if (!rpbx[k] || !rpby[k]) return -1;
+  void* ph = allocb((size_t)B * DM * esz);
+  float* presence_logits = out->presence_logit_dev;
+  for (int i = 0; i < 6; ++i) {
+    const std::string p = t + "layers." + std::to_string(i) + ".";
+    // conditional query position: MLP(sine(reference box)); zero for the presence token
+    if (!dry) CK(esam3_launch_box_sine(dtype, ref, sine, R, QR, st));
+    CK(lin(pk_linear(t + "ref_point_head.layers.0"), sine, 2 * DM, R, da, DM, ACT_RELU));
+    CK(lin(pk_linear(t + "ref_point_head.layers.1"), da, DM, R, qpos, DM, ACT_NONE));
+    if (!dry) {
+      CK(esam3_launch_bcast_rows(dtype, fbufs["pcs_zero_row"], 1, qpos, QR, 0, B, DM, st));
+      CK(prof_launch("pcs_rpb", 0.0, 0.0, [&]() { return esam3_launch_rpb_mlp(ref, rpbx, rpby, by, bx, R, EMB, EMB, HEADS, st); }));
+    }
+    // self-attention among presence + queries: q = k = x + pos, v = x
+    const std::string sa = p + "self_attn.", ct = p + "ca_text.", ci = p + "cross_attn.";
+    CK(addk(x, qpos, xp, R * DM));
+    CK(lin(L(sa + "in_proj_weight", sa + "in_proj_bias", 0, 2 * DM, sa + "#qk"), xp, DM, R, dq, 3 * DM, ACT_NONE));
+    CK(lin(L(sa + "in_proj_weight", sa + "in_proj_bias", 2 * DM, DM, sa + "#v"), x, DM, R, (char*)dq + 2 * DM * esz, 3 * DM, ACT_NONE));
+    CK(attn(dq, 3 * DM, 0, dq, 3 * DM, DM, 2 * DM, da, QR, QR, nullptr));
+    CK(lin(pk_linear(sa + "out_proj"), da, DM, R, x, DM, ACT_NONE, x, DM));
+    CK(LN(p + "norm2", x, x, R));
+    // cross-attention to the prompt tokens
+    CK(addk(x, qpos, xp, R * DM));
+    CK(lin(L(ct + "in_proj_weight", ct + "in_proj_bias", 0, DM, ct + "#q"), xp, DM, R, dq, DM, ACT_NONE));
+    CK(lin(L(ct + "in_proj_weight", ct + "in_proj_bias", DM, 2 * DM, ct + "#kv"), prompt, DM, B * Sp, pkv, 2 * DM, ACT_NONE));
+    CK(attn(dq, DM, 0, pkv, 2 * DM, 0, DM, da, QR, Sp, pmask));
+    CK(lin(pk_linear(ct + "out_proj"), da, DM, R, x, DM, ACT_NONE, x, DM));
+    CK(LN(p + "catext_norm", x, x, R));
+    // cross-attention to the image memory with the box-relative position bias (none for the presence token)
+    CK(addk(x, qpos, xp, R * DM));
+    CK(lin(L(ci + "in_proj_weight", ci + "in_proj_bias", 0, DM, ci + "#q"), xp, DM, R, dq, DM, ACT_NONE));
+    CK(lin(L(ci + "in_proj_weight", ci + "in_proj_bias", DM, DM, ci + "#k"), mem, DM, B * P, mkv, 2 * DM, ACT_NONE, tbufs[ci + "#posk"], DM, (int)P));
+    CK(lin(L(ci + "in_proj_weight", ci + "in_proj_bias", 2 * DM, DM, ci + "#v"), mem, DM, B * P, (char*)mkv + DM * esz, 2 * DM, ACT_NONE));
+    CK(attn(dq, DM, 0, mkv, 2 * DM, 0, DM, da, QR, (int)P, nullptr, by, bx, 1));
+    CK(lin(pk_linear(ci + "out_proj"), da, DM, R, x, DM, ACT_NONE, x, DM));
+    CK(LN(p + "norm1", x, x, R));
+    CK(lin(pk_linear(p + "linear1"), x, DM, R, dh, FF, ACT_RELU));
+    CK(lin(pk_linear(p + "linear2"), dh, FF, R, x, DM, ACT_NONE, x, DM));
+    CK(LN(p + "norm3", x, x, R));
+    // box refinement from the normed queries (the update after the last layer IS pred_boxes)
+    CK(LN(t + "norm", x, hs, R));
+    CK(lin(pk_linear(t + "bbox_embed.layers.0"), hs, DM, R, da, DM, ACT_RELU));
+    CK(lin(pk_linear(t + "bbox_embed.layers.1"), da, DM, R, dq, DM, ACT_RELU));
+    CK(lin(pk_linear(t + "bbox_embed.layers.2"), dq, DM, R, da, 8, ACT_NONE));
+    if (!dry) CK(esam3_launch_box_refine(dtype, da, 8, ref, R, st));
+  }
+  // presence logit of the last layer: MLP(LN(presence token)) (row 0 of every image)
+  {
+    void* pr = allocb((size_t)R * DM * esz);
+    void* p2 = allocb((size_t)R * DM * esz);
+    if (!ok(pr) || !ok(p2)) return -1;
+    CK(LN(t + "presence_token_out_norm", x, pr, R));
+    CK(lin(pk_linear(t + "presence_token_head.layers.0"), pr, DM, R, p2, DM, ACT_RELU));
+    CK(lin(pk_linear(t + "presence_token_head.layers.1"), p2, DM, R, pr, DM, ACT_RELU));
+    CK(lin(pk_linear(t + "presence_token_head.layers.2"), pr, DM, R, p2, 8, ACT_NONE));
+    if (!dry) CK(esam3_launch_strided_to_f32(dtype, p2, 8 * QR, presence_logits, B, st));
+  }
+  if (!dry)  // rows 1..200 of every image: the boxes after the last refinement = pred_boxes (cxcywh in [0,1])
+    HIP_CHECK_RET(hipMemcpy2DAsync(out->pred_boxes_dev, (size_t)Q * 16, ref + 4, (size_t)QR * 16, (size_t)Q * 16, B,
+                                   hipMemcpyDeviceToDevice, st));
+
+  // ---- dot-product scoring (model_misc.py:37-91) ---------------------------------------------------------
+  {
+    const std::string d = "dot_prod_scoring.";
+    void* pm = allocb((size_t)B * Sp * FF * esz);
+    void* p1 = allocb((size_t)B * Sp * DM * esz);
+    void* pool = allocb((size_t)B * DM * esz);
+    void* hp = allocb((size_t)R * DM * esz);
+    if (!ok(pm) || !ok(p1) || !ok(pool) || !ok(hp)) return -1;
+    CK(lin(pk_linear(d + "prompt_mlp.layers.0"), prompt, DM, B * Sp, pm, FF, ACT_RELU));
+    CK(lin(pk_linear(d + "prompt_mlp.layers.1"), pm, FF, B * Sp, p1, DM, ACT_NONE, prompt, DM));
+    CK(LN(d + "prompt_mlp.out_norm", p1, p1, B * Sp));
+    if (!dry) CK(esam3_launch_masked_mean(dtype, p1, pmask, pool, B, Sp, DM, st));
+    CK(lin(pk_linear(d + "prompt_proj"), pool, DM, B, ph, DM, ACT_NONE));
+    CK(lin(pk_linear(d + "hs_proj"), hs, DM, R, hp, DM, ACT_NONE));
+    if (!dry) CK(esam3_launch_dot_score(dtype, hp, QR, 1, Q, ph, out->pred_logits_dev, B, DM, 1.0f / 16.0f, 12.0f, st));
+  }
+
+  // ---- segmentation head (maskformer_segmentation.py:172-323) ------------------------------------------------
+  {
+    const std::string h = "segmentation_head.";
+    const std::string ca = h + "cross_attend_prompt.";
+    CK(LN(h + "cross_attn_norm", mem, t2, B * P));
+    CK(lin(L(ca + "in_proj_weight", ca + "in_proj_bias", 0, DM, ca + "#q"), t2, DM, B * P, qkv, DM, ACT_NONE));
+    CK(lin(L(ca + "in_proj_weight", ca + "in_proj_bias", DM, 2 * DM, ca + "#kv"), prompt, DM, B * Sp, pkv, 2 * DM, ACT_NONE));
+    CK(attn(qkv, DM, 0, pkv, 2 * DM, 0, DM, t2, (int)P, Sp, pmask));
+    CK(lin(pk_linear(ca + "out_proj"), t2, DM, B * P, mem, DM, ACT_NONE, mem, DM));
+    // pixel decoder: 72 -> 144 -> 288, fine + nearest(coarse), 3x3 conv, GroupNorm(8), ReLU
+    float* gn = (float*)allocb(sizeof(float) * (size_t)esam3_groupnorm_scratch_floats(B, 8));
+    if (!ok(gn)) return -1;
+    T4 prev;
+    prev.p = mem; prev.B = B; prev.H = EMB; prev.W = EMB; prev.C = DM; prev.ld = DM;
+    for (int li = 0; li < 2; ++li) {
+      const void* fine = in->sam3_fpn_dev[1 - li];
+      T4 u, c;
+      if (alloc4_padded(B, 2 * prev.H, 2 * prev.W, DM, &u)) return -1;
+      if (!dry) CK(prof_launch("pcs_upsample_add", 0.0, 0.0, [&]() { return esam3_launch_upsample_add(dtype, fine, prev.p, u.p, B, prev.H, prev.W, DM, st); }));
+      CK(conv(h + "pixel_decoder.conv_layers." + std::to_string(li), false, u, ACT_NONE, &c));
+      float* gw = fvec(h + "pixel_decoder.norms." + std::to_string(li) + ".weight");
+      float* gb = fvec(h + "pixel_decoder.norms." + std::to_string(li) + ".bias");
+      if (!gw || !gb) return -1;
+      if (!dry) CK(prof_launch("pcs_groupnorm", 0.0, 0.0, [&]() { return esam3_launch_groupnorm_relu(dtype, c.p, gn, gw, gb, B, c.H * c.W, DM, 8, 1e-5f, st); }));
+      prev = c;
+    }
+    const int64_t PX = (int64_t)prev.H * prev.W;  // 288 * 288
+    T4 inst;
+    CK(conv(h + "instance_seg_head", false, prev, ACT_NONE, &inst));
+    if (out->semantic_seg_dev) {
+      T4 sem;
+      CK(conv(h + "semantic_seg_head", false, prev, ACT_NONE, &sem));
+      if (!dry) CK(esam3_launch_cast_to_f32(dtype, sem.p, out->semantic_seg_dev, (int64_t)B * PX, st));
+    }
+    // mask embedding of the last layer's queries, then masks[b][q][pixel] = <embed[b][q], inst[b][pixel]>:
+    // a GEMM per image whose "weight" operand is that image's pixel embedding
+    void* me1 = allocb((size_t)R * DM * esz);
+    void* me2 = allocb((size_t)R * DM * esz);
+    void* mt = allocb((size_t)Q * PX * esz);
+    if (!ok(me1) || !ok(me2) || !ok(mt)) return -1;
+    CK(lin(pk_linear(h + "mask_predictor.mask_embed.layers.0"), hs, DM, R, me1, DM, ACT_RELU));
+    CK(lin(pk_linear(h + "mask_predictor.mask_embed.layers.1"), me1, DM, R, me2, DM, ACT_RELU));
+    CK(lin(pk_linear(h + "mask_predictor.mask_embed.layers.2"), me2, DM, R, me1, DM, ACT_NONE));
+    for (int b = 0; b < B; ++b) {
+      PackedGemm g;
+      g.w = (char*)inst.p + (size_t)b * PX * DM * esz;
+      g.N = (int)PX; g.Np = (int)PX; g.K = DM; g.Kp = DM; g.cin = DM; g.ksize = 1;
+      g.tag = "segmentation_head.mask_einsum";
+      CK(gemm(&g, (char*)me1 + ((size_t)b * QR + 1) * DM * esz, DM, Q, 1, 1, mt, (int)PX, ACT_NONE));
+      if (!dry) CK(esam3_launch_cast_to_f32(dtype, mt, out->pred_masks_dev + (size_t)b * Q * PX, (int64_t)Q * PX, st));
+    }
+  }
+  return 0;
+}
+
 // PositionEmbeddingRandom on the 72x72 grid (prompt_encoder.py:223-234) and its projections
 // through the k_proj / q_proj weights of the image-side cross attentions, so that
 // proj(keys + pe) = proj(keys) + PEproj is a residual in the GEMM epilogue.
@@ -1680,6 +2056,20 @@ int esam3_encode_text(esam3_engine* e, const int64_t* tokens, int B, int S, floa
   if (!e->finalized) { esam3_set_error("esam3_finalize has not been called"); return -1; }
   if (!e->find(TEXTP + "projector.weight")) { esam3_set_error("esam3_encode_text: no text-encoder weights were loaded"); return -1; }
   return run_sized(e, stream, [&]() { return e->encode_text(tokens, B, S, memory, embeds); });
+}
+
+int esam3_ground(esam3_engine* e, const esam3_ground_in* in, const esam3_ground_out* out, void* stream) {
+  if (!e || !in || !out) { esam3_set_error("esam3_ground: null argument"); return -1; }
+  if (!e->finalized) { esam3_set_error("esam3_finalize has not been called"); return -1; }
+  if (in->n_images <= 0 || in->n_tokens <= 0 || !in->sam3_fpn_dev[0] || !in->sam3_fpn_dev[1] || !in->sam3_fpn_dev[2] ||
+      !in->language_features_dev || !in->language_mask_dev || !out->pred_logits_dev || !out->pred_boxes_dev ||
+      !out->presence_logit_dev || !out->pred_masks_dev) {
+    esam3_set_error("esam3_ground: bad input/output description");
+    return -1;
+  }
+  e->st = (hipStream_t)stream;
+  CK(e->pcs_prepare());
+  return run_sized(e, stream, [&]() { return e->ground(in, out); });
 }
 
 int esam3_postprocess_masks(esam3_engine* e, const float* low_res, int n, int oh, int ow, float max_hole_area,

@@ -135,3 +135,26 @@ int esam3_launch_mbconv_fused(int dtype, const void* x, void* out, const void* w
                               const float* wd, const float* bd, const void* w2, int Kp2, const float* b2, int B,
                               int H, int W, int Cin, int Cmid, int Cout, int stride, int residual,
                               hipStream_t stream);
+
+// ---- PCS text-grounding detector (kernels_pcs.hip) ---------------------------------------------------------
+int esam3_launch_mha_core(int dtype, const void* q, int ldq, int q_off, const void* kv, int ldk, int k_off, int v_off,
+                          void* out, int ldo, int B, int Nq, int Nk, int heads, const uint8_t* key_mask,
+                          const float* bias_y, const float* bias_x, int Hk, int Wk, int bias_q0, hipStream_t s);
+int esam3_launch_pcs_prompt(int dtype, const float* lang, const uint8_t* lmask, void* prompt, uint8_t* pmask, int B, int S,
+                            int extra, int C, hipStream_t s);
+int esam3_launch_copy_rows(int dtype, const void* src, int n_src, void* dst, int n_dst, int dst_row0, int B, int C,
+                           hipStream_t s);
+int esam3_launch_bcast_rows(int dtype, const float* src, int n, void* dst, int n_dst, int dst_row0, int B, int C,
+                            hipStream_t s);
+int esam3_launch_box_sine(int dtype, const float* boxes, void* out, int64_t rows, int rows_per_img, hipStream_t s);
+int esam3_launch_rpb_mlp(const float* boxes, const float* const* wx /*w1,b1,w2,b2*/, const float* const* wy, float* out_y,
+                         float* out_x, int64_t nq_total, int H, int W, int heads, hipStream_t s);
+int esam3_launch_box_refine(int dtype, const void* delta, int ld, float* ref, int64_t rows, hipStream_t s);
+int esam3_launch_masked_mean(int dtype, const void* x, const uint8_t* mask, void* out, int B, int S, int C, hipStream_t s);
+int esam3_launch_dot_score(int dtype, const void* hs, int rows_per_img, int row0, int nq, const void* pp, float* out, int B,
+                           int C, float scale, float clampv, hipStream_t s);
+int esam3_launch_upsample_add(int dtype, const void* fine, const void* coarse, void* out_padded, int B, int h, int w, int C,
+                              hipStream_t s);
+int64_t esam3_groupnorm_scratch_floats(int B, int groups);
+int esam3_launch_groupnorm_relu(int dtype, void* x, float* partial, const float* gamma, const float* beta, int B, int HW,
+                                int C, int groups, float eps, hipStream_t s);

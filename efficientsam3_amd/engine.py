@@ -174,6 +174,40 @@ class HipEngine:
                        "esam3_encode_text")
         return mem, emb
 
+    # ---- PCS text grounding ----------------------------------------------------------------------
+    def ground(self, sam3_fpn: Sequence[torch.Tensor], language_features: torch.Tensor,
+               language_mask: torch.Tensor, want_semantic: bool = False) -> dict:
+        """sam3_fpn: the three NHWC levels of B images (encode()'s "sam3_fpn"); language_features
+        [S,B,256] fp32 and language_mask [B,S] bool (True = padding), one text per image.
+        -> pred_logits [B,200,1], pred_boxes [B,200,4] (cxcywh in [0,1]), presence_logit_dec [B,1],
+        pred_masks [B,200,288,288] fp32 logits (the reference's forward_grounding outputs)."""
+        b = sam3_fpn[2].shape[0]
+        s = language_features.shape[0]
+        lf = language_features.to(self.device, torch.float32).contiguous()
+        lm = language_mask.to(self.device).to(torch.uint8).contiguous()
+        assert tuple(lf.shape) == (s, b, 256) and tuple(lm.shape) == (b, s)
+        dev = self.device
+        logits = torch.empty((b, 200, 1), dtype=torch.float32, device=dev)
+        boxes = torch.empty((b, 200, 4), dtype=torch.float32, device=dev)
+        presence = torch.empty((b, 1), dtype=torch.float32, device=dev)
+        masks = torch.empty((b, 200, LOW_RES, LOW_RES), dtype=torch.float32, device=dev)
+        sem = torch.empty((b, 1, LOW_RES, LOW_RES), dtype=torch.float32, device=dev) if want_semantic else None
+        gi = _lib.GroundIn()
+        for i in range(3):
+            assert sam3_fpn[i].is_contiguous() and sam3_fpn[i].dtype == self.torch_dtype
+            gi.sam3_fpn_dev[i] = sam3_fpn[i].data_ptr()
+        gi.n_images, gi.n_tokens = b, s
+        gi.language_features_dev, gi.language_mask_dev = lf.data_ptr(), lm.data_ptr()
+        go = _lib.GroundOut(pred_logits_dev=logits.data_ptr(), pred_boxes_dev=boxes.data_ptr(),
+                            presence_logit_dev=presence.data_ptr(), pred_masks_dev=masks.data_ptr(),
+                            semantic_seg_dev=sem.data_ptr() if sem is not None else None)
+        with torch.cuda.device(self.dev_index):
+            _lib.check(self.lib.esam3_ground(self.handle, C.byref(gi), C.byref(go), _stream()), "esam3_ground")
+        out = {"pred_logits": logits, "pred_boxes": boxes, "presence_logit_dec": presence, "pred_masks": masks}
+        if sem is not None:
+            out["semantic_seg"] = sem
+        return out
+
     # ---- prompt decode -----------------------------------------------------------------------
     def decode(self, sam2_fpn: Sequence[torch.Tensor], prompt_image: torch.Tensor, coords: torch.Tensor,
                labels: torch.Tensor, multimask_output: bool, want_obj: bool = False,

@@ -159,6 +159,7 @@ class Sam3Image:
             if text_encoder_type not in schema.TEXT_ENCODER_CFG:
                 raise NotImplementedError(f"text_encoder_type={text_encoder_type!r}: only MobileCLIP-S0 is built")
             self.backbone.language_backbone = _TextStudentEncoder(self, text_encoder_context_length, bpe_path)
+            self._schema.update(schema.pcs_schema())  # the grounding detector the text prompts feed
         self._sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         self._pos_cache: Dict[Tuple[int, int], torch.Tensor] = {}
         self.training = False
@@ -235,7 +236,8 @@ class Sam3Image:
         if self.dual_neck:
             fpn = [_nchw_view(t) for t in out["sam3_fpn"]]
             res.update(vision_features=fpn[-1], backbone_fpn=fpn,
-                       vision_pos_enc=[self._pos(b, t.shape[-2], t.shape[-1]) for t in fpn])
+                       vision_pos_enc=[self._pos(b, t.shape[-2], t.shape[-1]) for t in fpn],
+                       _esam3_nhwc_sam3=out["sam3_fpn"])
         if interactive:
             fpn2 = [_nchw_view(t) for t in out["sam2_fpn"]]
             res["sam2_backbone_out"] = {
@@ -381,9 +383,28 @@ class Sam3Image:
                 iou_out[i] = iou_np[j].squeeze(0) if bpi == 1 else iou_np[j]
         return masks_out, iou_out, low_out
 
-    # ---- text / grounding path: SURVEY.md §8 marks it "next" ------------------------------------
-    def forward_grounding(self, *a, **k):
-        raise NotImplementedError("the PCS text-grounding detector is not part of this build yet")
+    # ---- PCS text grounding (sam3_image.py:442-493) -------------------------------------------------
+    def forward_grounding(self, backbone_out, find_input=None, find_target=None, geometric_prompt=None):
+        """Sam3Image.forward_grounding for what Sam3Processor.set_text_prompt passes: the image features of
+        set_image, the text features of forward_text (one text, broadcast to every image) and the dummy
+        geometric prompt.  Box / point geometric prompts are not built."""
+        if self.text_encoder_type is None:
+            raise NotImplementedError("model was built without text_encoder_type='MobileCLIP-S0'")
+        if geometric_prompt is not None and getattr(geometric_prompt, "n_prompts", 0) != 0:
+            raise NotImplementedError("box / point geometric prompts of the PCS detector are not built yet")
+        if "language_features" not in backbone_out:
+            raise ValueError("forward_text has not been run for this state")
+        fpn = backbone_out.get("_esam3_nhwc_sam3")
+        if fpn is None:
+            raise RuntimeError("the sam3 neck features are missing (model built with dual_neck=False?)")
+        b = fpn[2].shape[0]
+        lf, lm = backbone_out["language_features"], backbone_out["language_mask"]
+        if lf.shape[1] == 1 and b > 1:
+            lf, lm = lf.expand(-1, b, -1), lm.expand(b, -1)
+        return self.engine.ground(fpn, lf, lm)
 
-    def _get_dummy_prompt(self, *a, **k):
-        raise NotImplementedError("the PCS text-grounding detector is not part of this build yet")
+    def _get_dummy_prompt(self, num_prompts: int = 1):
+        """Stand-in for the empty geometric Prompt (sam3_image.py:522-528): no boxes, no points."""
+        class _DummyPrompt:
+            n_prompts = 0
+        return _DummyPrompt()

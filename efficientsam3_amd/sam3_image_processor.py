@@ -111,20 +111,65 @@ class Sam3Processor:
         state["backbone_out"] = self.model.backbone.forward_image(images_nchw_f32)
         return state
 
+    @torch.inference_mode()
     def set_text_prompt(self, prompt: str, state: Dict):
+        """Sets the text prompt and runs the grounding detector (sam3_image_processor.py:115-131)."""
         if "backbone_out" not in state:
             raise ValueError("You must call set_image before set_text_prompt")
-        raise NotImplementedError("text prompts (PCS detector) are not part of this build yet")
+        text_outputs = self.model.backbone.forward_text([prompt], device=self.device)
+        state["backbone_out"].update(text_outputs)  # erases the previous text prompt if any
+        if "geometric_prompt" not in state:
+            state["geometric_prompt"] = self.model._get_dummy_prompt()
+        return self._forward_grounding(state)
 
     def add_geometric_prompt(self, box, label, state):
         if "backbone_out" not in state:
-            raise ValueError("You must call set_image before set_text_prompt")
-        raise NotImplementedError("geometric PCS prompts are not part of this build yet")
+            raise ValueError("You must call set_image before add_geometric_prompt")
+        raise NotImplementedError("box prompts of the PCS detector (geometry encoder with roi_align) are not built yet")
+
+    def add_point_prompt(self, point, label, state):
+        if "backbone_out" not in state:
+            raise ValueError("You must call set_image before add_point_prompt")
+        raise NotImplementedError("point prompts of the PCS detector are not built yet")
+
+    @torch.inference_mode()
+    def _forward_grounding(self, state: Dict):
+        """sam3_image_processor.py:219-259: scores = sigmoid(logits) * sigmoid(presence), keep > threshold,
+        boxes to XYXY pixels, masks bilinearly upsampled to the original size and passed through a sigmoid."""
+        out = self.model.forward_grounding(backbone_out=state["backbone_out"], find_input=None, find_target=None,
+                                           geometric_prompt=state["geometric_prompt"])
+        probs = (out["pred_logits"].sigmoid() * out["presence_logit_dec"].sigmoid().unsqueeze(1)).squeeze(-1)
+        keep = probs > self.confidence_threshold
+        scores = probs[keep]
+        cxcywh = out["pred_boxes"][keep]
+        cx, cy, w, h = cxcywh.unbind(-1)
+        boxes = torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+        img_h, img_w = state["original_height"], state["original_width"]
+        boxes = boxes * torch.tensor([img_w, img_h, img_w, img_h], dtype=torch.float32, device=boxes.device)[None]
+        low = out["pred_masks"][keep].contiguous()  # [K, 288, 288]
+        if low.shape[0] > 0:
+            logits = self.model.engine.postprocess(low[:, None], (img_h, img_w), return_logits=True, max_hole_area=0.0)
+            logits = torch.sigmoid_(logits)
+        else:
+            logits = torch.empty((0, 1, img_h, img_w), dtype=torch.float32, device=low.device)
+        state["masks_logits"] = logits
+        state["masks"] = logits > 0.5
+        state["boxes"] = boxes
+        state["scores"] = scores
+        return state
 
     def reset_all_prompts(self, state):
+        """Removes all the prompts and results (sam3_image_processor.py:190-206)."""
+        if "backbone_out" in state:
+            for k in ("language_features", "language_mask", "language_embeds"):
+                state["backbone_out"].pop(k, None)
         for k in ("geometric_prompt", "boxes", "masks", "masks_logits", "scores"):
             state.pop(k, None)
 
+    @torch.inference_mode()
     def set_confidence_threshold(self, threshold: float, state=None):
+        """sam3_image_processor.py:208-217: filtering again means running the heads again."""
         self.confidence_threshold = threshold
+        if state is not None and "boxes" in state:
+            return self._forward_grounding(state)
         return state

@@ -96,6 +96,25 @@ int esam3_decode(esam3_engine* e, const esam3_prompts* prompts, const esam3_deco
  * The padding mask is tokens == 0 and stays on the host side. */
 int esam3_encode_text(esam3_engine* e, const int64_t* tokens_dev, int B, int S, float* memory_sbd_dev,
                       float* embeds_sbd_dev, void* hip_stream);
+/* PCS text-grounding detector: Sam3Image.forward_grounding (sam3_image.py:442-493) for one text prompt per
+ * image and the dummy geometric prompt, i.e. what Sam3Processor.set_text_prompt runs
+ * (sam3_image_processor.py:115-131,219-226).  Weights: "geometry_encoder.*", "transformer.*",
+ * "segmentation_head.*", "dot_prod_scoring.*". */
+typedef struct esam3_ground_in {
+  const void* sam3_fpn_dev[3];          /* sam3 neck levels of n_images images, as written by esam3_encode_image */
+  int n_images;
+  const float* language_features_dev;   /* [S][n_images][256] fp32 (esam3_encode_text layout) */
+  const uint8_t* language_mask_dev;     /* [n_images][S], 1 = padding token */
+  int n_tokens;                         /* S */
+} esam3_ground_in;
+typedef struct esam3_ground_out {
+  float* pred_logits_dev;     /* [n_images][200] */
+  float* pred_boxes_dev;      /* [n_images][200][4] cx, cy, w, h in [0, 1] */
+  float* presence_logit_dev;  /* [n_images] */
+  float* pred_masks_dev;      /* [n_images][200][288][288] fp32 logits */
+  float* semantic_seg_dev;    /* [n_images][288][288] fp32 logits, may be NULL */
+} esam3_ground_out;
+int esam3_ground(esam3_engine* e, const esam3_ground_in* in, const esam3_ground_out* out, void* hip_stream);
 /* low_res: [n][288][288] fp32 -> masks at (out_h, out_w); either output may be NULL */
 int esam3_postprocess_masks(esam3_engine* e, const float* low_res_dev, int n_masks, int out_h,
                             int out_w, float max_hole_area, float mask_threshold,

@@ -62,3 +62,44 @@ def test_pcs_oracle_pinned_and_reproduces_golden(pcs_gold, pcs_sd):
             assert float(np.abs(post["boxes"].numpy() - g[f"{pi}_boxes"]).max()) <= 1e-2  # pixels
             bits = np.unpackbits(g[f"{pi}_mask_bits"])[: post["masks"].numel()].reshape(post["masks"].shape).astype(bool)
             assert float((post["masks"].numpy() != bits).mean()) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_pcs_engine_vs_golden(pcs_gold, pcs_sd, mode):
+    """The HIP engine's grounding path (esam3_ground) on the engine's own EV-M features and the REFERENCE's text
+    features vs the reference's outputs.  f32: logits / boxes within 1e-4, mask logits within 2e-3 on a -21..63
+    range, identical detections after thresholding.  bf16: inside the bf16 envelope of the same quantities."""
+    from efficientsam3_amd import Sam3Processor, build_efficientsam3_image_model
+    man, g = pcs_gold
+    model = build_efficientsam3_image_model(device="cuda", enable_inst_interactivity=False, backbone_type="efficientvit",
+                                            model_name="b1", dtype=mode, state_dict=pcs_sd, text_encoder_type="MobileCLIP-S0",
+                                            text_encoder_context_length=16)
+    proc = Sam3Processor(model, confidence_threshold=man["confidence_threshold"])
+    img = synth.smooth_image_u8(seed=1)
+    state = proc.set_image(torch.from_numpy(np.ascontiguousarray(np.moveaxis(img, -1, 0))))
+    lim = dict(f32=dict(logits=1e-4, boxes=1e-4, presence=1e-4, masks=2e-3), bf16=dict(logits=0.08, boxes=0.06, presence=0.08, masks=2.5))[mode]
+    for pi in range(len(man["prompts"])):
+        state["backbone_out"]["language_features"] = torch.from_numpy(g[f"{pi}_language_features"]).to("cuda")
+        state["backbone_out"]["language_mask"] = torch.from_numpy(g[f"{pi}_language_mask"]).to("cuda")
+        out = model.forward_grounding(state["backbone_out"], geometric_prompt=model._get_dummy_prompt())
+        e = dict(logits=float(np.abs(out["pred_logits"].cpu().numpy() - g[f"{pi}_pred_logits"]).max()),
+                 boxes=float(np.abs(out["pred_boxes"].cpu().numpy() - g[f"{pi}_pred_boxes"]).max()),
+                 presence=float(np.abs(out["presence_logit_dec"].cpu().numpy() - g[f"{pi}_presence_logit_dec"]).max()),
+                 masks=float(np.abs(_sample(out["pred_masks"]) - g[f"{pi}_pred_masks_sample"]).max()))
+        print(f"[pcs {mode}] prompt {pi}: {e}")
+        for k, v in e.items():
+            assert v <= lim[k], (k, v, lim[k])
+        state["geometric_prompt"] = model._get_dummy_prompt()
+        st = proc._forward_grounding(state)
+        n_ref = g[f"{pi}_scores"].size
+        if mode == "f32":
+            assert st["scores"].numel() == n_ref
+            assert float(np.abs(st["scores"].cpu().numpy() - g[f"{pi}_scores"]).max()) <= 1e-4
+            assert float(np.abs(st["boxes"].cpu().numpy() - g[f"{pi}_boxes"]).max()) <= 1.0  # pixels
+            bits = np.unpackbits(g[f"{pi}_mask_bits"])[: st["masks"].numel()].reshape(tuple(st["masks"].shape)).astype(bool)
+            assert float((st["masks"].cpu().numpy() != bits).mean()) <= 1e-4
+        else:
+            assert abs(st["scores"].numel() - n_ref) <= max(4, n_ref // 10)
+        assert st["masks"].dtype == torch.bool and st["masks"].shape[1:] == (1, 1008, 1008)
+        assert st["masks_logits"].shape == st["masks"].shape and st["boxes"].shape == (st["scores"].numel(), 4)
