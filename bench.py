@@ -74,6 +74,10 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="interactive", choices=["interactive", "text"],
+                    help="interactive: set_image_batch + predict_inst (headline, BASELINE configs[1]); text: image encoder + "
+                         "MobileCLIP-S0 text encoder + PCS grounding detector, one text prompt per image (configs[3] with "
+                         "--backbone sam3 --model vit_h --batch 8)")
     ap.add_argument("--backbone", default="efficientvit", help="student family (the headline metric is efficientvit/b1)")
     ap.add_argument("--model", default="b1")
     ap.add_argument("--no-fuse", action="store_true",
@@ -96,15 +100,21 @@ def main():
     dev = torch.device("cuda", local_rank)
     esdist.init_process_group("nccl", dev)
 
-    sd = schema.synthetic_state_dict(args.backbone, args.model, seed=0)
+    text = args.workload == "text"
+    sd = schema.synthetic_state_dict(args.backbone, args.model, seed=0, enable_inst_interactivity=not text)
+    tkw = {}
+    if text:
+        sd.update(schema.synthetic_text_state_dict("MobileCLIP-S0", 16, seed=0))
+        sd.update(schema.synthetic_pcs_state_dict(seed=0))
+        tkw = dict(text_encoder_type="MobileCLIP-S0", text_encoder_context_length=16)
     if args.backbone == "sam3":  # ViT-H teacher (not the headline configuration)
-        model = build_sam3_image_model(device=dev, enable_inst_interactivity=True, dtype=args.dtype, state_dict=sd,
-                                       dual_neck=not args.sam2_only, fuse_linear_chains=not args.no_fuse)
+        model = build_sam3_image_model(device=dev, enable_inst_interactivity=not text, dtype=args.dtype, state_dict=sd,
+                                       dual_neck=not args.sam2_only, fuse_linear_chains=not args.no_fuse, **tkw)
     else:
-        model = build_efficientsam3_image_model(device=dev, enable_inst_interactivity=True,
+        model = build_efficientsam3_image_model(device=dev, enable_inst_interactivity=not text,
                                                 backbone_type=args.backbone, model_name=args.model,
                                                 dtype=args.dtype, state_dict=sd, dual_neck=not args.sam2_only,
-                                                fuse_linear_chains=not args.no_fuse)
+                                                fuse_linear_chains=not args.no_fuse, **tkw)
     eng = model.engine
     B = args.batch
     # synthetic batch, resident in HBM before the timed region: 4 distinct images tiled to B
@@ -119,8 +129,23 @@ def main():
     l_d = torch.from_numpy(labs).to(dev)
     pi_d = torch.arange(B, dtype=torch.int32, device=dev)
     bufs = {"enc": None, "dec": None, "post": None}
+    # text workload: one 16-token prompt per image (seeded synthetic token ids: <sot>, 1-4 word ids, <eot>, padding)
+    rng = np.random.default_rng(5 + rank)
+    tok = np.zeros((B, 16), dtype=np.int64)
+    for i in range(B):
+        n = int(rng.integers(1, 5))
+        tok[i, 0], tok[i, 1:1 + n], tok[i, 1 + n] = 49406, rng.integers(300, 40000, size=n), 49407
+    tok_d = torch.from_numpy(tok).to(dev)
+
+    def step_text():
+        bufs["enc"] = out = eng.encode(x, want_sam3=True, want_sam2=False, out=bufs["enc"])
+        mem_t, _ = eng.encode_text(tok_d)
+        g = eng.ground(out["sam3_fpn"], mem_t, tok_d == 0)
+        return g["pred_masks"], g["pred_logits"]
 
     def step():
+        if text:
+            return step_text()
         # fixed output buffers, nothing is allocated inside the timed region
         bufs["enc"] = out = eng.encode(x, want_sam3=not args.sam2_only, want_sam2=True, out=bufs["enc"])
         bufs["dec"] = low, iou = eng.decode(out["sam2_fpn"], pi_d, c_d, l_d, multimask_output=False, out=bufs["dec"])
@@ -160,7 +185,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    fg = float(masks.float().mean().item())
+    fg = float((masks > 0).float().mean().item()) if text else float(masks.float().mean().item())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -200,19 +225,24 @@ def main():
             t_ = p_["tag"]
             key = ("neck" if ".convs." in t_ or ".sam2_convs." in t_ or "conv_s0" in t_ or "conv_s1" in t_
                    else "head" if ".head." in t_
+                   else "grounding" if t_.startswith(("pcs_", "transformer.", "geometry_encoder.", "segmentation_head.", "dot_prod_scoring."))
+                   else "text" if "language_backbone" in t_ or t_.startswith(("text_", "seq_dwconv", "bsc_to_sbc"))
                    else "backbone" if "trunk.model.backbone" in t_ or "vision_backbone.trunk." in t_ and ".head." not in t_
                    or t_.startswith(("dwconv", "stem", "lite_mla", "grouped_pw", "resize", "mbconv_fused", "squeeze_excite",
                                      "window_attn", "vit_", "patchify"))
                    else "decode+post")
             stage_ms[key] = stage_ms.get(key, 0.0) + p_["ms"]
         out = {
-            "metric": "images/sec encode+decode @1024^2 (EV-M bf16)" if (args.backbone, args.model) == ("efficientvit", "b1")
-            else f"images/sec encode+decode @1024^2 ({args.backbone}-{args.model} {args.dtype})", "value": round(value, 2), "unit": "images/s",
+            "metric": "images/sec encode+decode @1024^2 (EV-M bf16)" if (args.backbone, args.model, text) == ("efficientvit", "b1", False)
+            else (f"images/sec text-prompted encode+ground @1024^2 ({args.backbone}-{args.model} + MobileCLIP-S0-16 {args.dtype})" if text
+                  else f"images/sec encode+decode @1024^2 ({args.backbone}-{args.model} {args.dtype})"), "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic (seeded images at the network's native 1008x1008, seeded realistic random-init weights)",
-            "config": {"workload": ("EV-M (EfficientViT-B1)" if args.backbone == "efficientvit" else f"{args.backbone}-{args.model}") + " set_image_batch + predict_inst(point+box) per image, "
-                                   "batch=32 per GPU, full dual-neck graph" + (" [sam2-only variant]" if args.sam2_only else ""),
+            "config": {"workload": ("EV-M (EfficientViT-B1)" if args.backbone == "efficientvit" else f"{args.backbone}-{args.model}") + (" image encoder + text encoder + PCS grounding detector (200 queries -> logits, boxes, "
+                                                       "288x288 mask logits), one text prompt per image, " if text else
+                                                       " set_image_batch + predict_inst(point+box) per image, ")
+                                   + f"batch={B} per GPU, " + ("sam3 neck" if text else "full dual-neck graph") + (" [sam2-only variant]" if args.sam2_only else ""),
                        "global_batch": world * B, "resolution": 1008, "prompts_per_image": 1,
                        "parallelism": f"dp{world} (image shards, RCCL gather of uint8 masks)" if world > 1 else "single GPU",
                        "graph": ("reference layer list" if args.no_fuse else

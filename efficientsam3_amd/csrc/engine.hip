@@ -1425,6 +1425,14 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
   auto attn = [&](const void* q, int ldq, int qo, const void* kv, int ldk, int ko, int vo, void* o, int Nq, int Nk,
                   const uint8_t* mask, const float* by = nullptr, const float* bx = nullptr, int q0 = 0) -> int {
     if (dry) return 0;
+    if (dtype == 1 && !mask && !by && Nq >= 1024) {  // big plain attention (fusion encoder self-attention): MFMA
+      int rc = 1;
+      CK(prof_launch("pcs_attn_mfma", 4.0 * (double)B * Nq * Nk * DM, 0.0, [&]() {
+        rc = esam3_launch_attn_mfma32(q, ldq, qo, kv, ldk, ko, vo, o, DM, B, Nq, Nk, HEADS, st);
+        return rc < 0 ? -1 : 0;
+      }));
+      if (rc == 0) return 0;
+    }
     return prof_launch("pcs_attn", 4.0 * (double)B * Nq * Nk * DM, 0.0, [&]() {
       return esam3_launch_mha_core(dtype, q, ldq, qo, kv, ldk, ko, vo, o, DM, B, Nq, Nk, HEADS, mask, by, bx, EMB, EMB, q0, st);
     });

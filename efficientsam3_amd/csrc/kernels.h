@@ -136,6 +136,9 @@ int esam3_launch_mbconv_fused(int dtype, const void* x, void* out, const void* w
                               int H, int W, int Cin, int Cmid, int Cout, int stride, int residual,
                               hipStream_t stream);
 
+// bf16 MFMA flash attention, heads x 32, no mask / bias (returns 1 when the shape is not eligible)
+int esam3_launch_attn_mfma32(const void* q, int ldq, int q_off, const void* kv, int ldk, int k_off, int v_off, void* out,
+                             int ldo, int B, int Nq, int Nk, int heads, hipStream_t s);
 // ---- PCS text-grounding detector (kernels_pcs.hip) ---------------------------------------------------------
 int esam3_launch_mha_core(int dtype, const void* q, int ldq, int q_off, const void* kv, int ldk, int k_off, int v_off,
                           void* out, int ldo, int B, int Nq, int Nk, int heads, const uint8_t* key_mask,

@@ -816,6 +816,130 @@ __global__ __launch_bounds__(256) void attn_mfma64_kernel(const bf16_t* __restri
     }
 }
 
+// Head dim 32, plain token sequences (PCS fusion encoder: 8 heads x 32 over the 5184 image tokens): same
+// scheme as attn_mfma64_kernel with two K steps for S^T and one 32-channel block of O^T.  Nq and Nk are
+// multiples of 64 / any (queries past Nq are clamped and not stored).
+__global__ __launch_bounds__(256) void attn_mfma32_kernel(const bf16_t* __restrict__ q, int ldq, int q_off,
+                                                          const bf16_t* __restrict__ kv, int ldk, int k_off, int v_off,
+                                                          bf16_t* __restrict__ out, int ldo, int Nq, int Nk,
+                                                          float scale_log2e) {
+  constexpr int HD = 32, KT = 64, VP = 136;
+  __shared__ __attribute__((aligned(16))) char sK[KT * 64];
+  __shared__ __attribute__((aligned(16))) char sVt[HD * VP];
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
+  const int qi = blockIdx.x * 128 + wave * 32 + l31;
+  const bool valid = qi < Nq;
+  u32x4 qf[2];
+  {
+    const bf16_t* src = q + (b * Nq + (valid ? qi : Nq - 1)) * (int64_t)ldq + q_off + h * HD;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) qf[s_] = *reinterpret_cast<const u32x4*>(src + s_ * 16 + g * 8);
+  }
+  f32x16_v o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+  const bf16_t* kbase = kv + b * Nk * (int64_t)ldk + h * HD;
+  for (int j0 = 0; j0 < Nk; j0 += KT) {
+    __syncthreads();
+    {  // K tile: 64 keys x 4 slots of 16 bytes = 256 chunks, one per thread
+      const int key = tid >> 2, slot = tid & 3;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(kbase + (int64_t)(j0 + key) * ldk + k_off + slot * 8);
+      *reinterpret_cast<u32x4*>(sK + key * 64 + ((slot ^ ((key >> 2) & 3)) << 4)) = v;
+    }
+    if (tid < 64) {  // V^T tile: (8 d) x (4 keys) patches
+      const int dch = tid & 3, kq = tid >> 2;
+      u32x4 u[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        u[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)(j0 + kq * 4 + i) * ldk + v_off + dch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int w_ = e >> 1;
+        uint32_t a0, a1;
+        if (e & 1) {
+          a0 = (u[0][w_] >> 16) | (u[1][w_] & 0xffff0000u);
+          a1 = (u[2][w_] >> 16) | (u[3][w_] & 0xffff0000u);
+        } else {
+          a0 = (u[0][w_] & 0xffffu) | (u[1][w_] << 16);
+          a1 = (u[2][w_] & 0xffffu) | (u[3][w_] << 16);
+        }
+        *reinterpret_cast<uint2*>(sVt + (dch * 8 + e) * VP + kq * 8) = make_uint2(a0, a1);
+      }
+    }
+    __syncthreads();
+    f32x16_v sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+      const int key = kb * 32 + l31;
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + key * 64 + (((s_ * 2 + g) ^ ((key >> 2) & 3)) << 4));
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, kf),
+                                                           __builtin_bit_cast(bf16x8_v, qf[s_]), sacc[kb], 0, 0, 0);
+      }
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sacc[kb][r] *= scale_log2e;
+        mt = fmaxf(mt, sacc[kb][r]);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
+    m = mn;
+    lsum *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+    u32x4 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = __builtin_amdgcn_exp2f(sacc[kb][r] - mn);
+        lsum += pv[r];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        pf[kb][s2].x = pack_bf16x2(pv[8 * s2 + 0], pv[8 * s2 + 1]);
+        pf[kb][s2].y = pack_bf16x2(pv[8 * s2 + 2], pv[8 * s2 + 3]);
+        pf[kb][s2].z = pack_bf16x2(pv[8 * s2 + 4], pv[8 * s2 + 5]);
+        pf[kb][s2].w = pack_bf16x2(pv[8 * s2 + 6], pv[8 * s2 + 7]);
+      }
+    }
+    const char* vrow = sVt + l31 * VP;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int koff = (kb * 32 + 16 * s2 + 4 * g) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vrow + koff);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vrow + koff + 16);
+        const u32x4 vf = {lo.x, lo.y, hi.x, hi.y};
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, vf),
+                                                    __builtin_bit_cast(bf16x8_v, pf[kb][s2]), o, 0, 0, 0);
+      }
+  }
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (!valid) return;
+  const float inv = 1.f / lsum;
+  bf16_t* dst = out + (b * Nq + qi) * (int64_t)ldo + h * HD;
+#pragma unroll
+  for (int q4 = 0; q4 < 4; ++q4) {
+    const uint2 w_ = make_uint2(pack_bf16x2(o[4 * q4] * inv, o[4 * q4 + 1] * inv),
+                                pack_bf16x2(o[4 * q4 + 2] * inv, o[4 * q4 + 3] * inv));
+    *reinterpret_cast<uint2*>(dst + 8 * q4 + 4 * g) = w_;
+  }
+}
+
 // The same scheme for TinyViT's windows (bf16, head dim 32; tiny_vit.py:265-293,339-372): WS x WS windows over
 // a map that is zero-padded to a multiple of WS before the attention's LayerNorm (padded positions
 // carry the constant `pad_qkv`), additive bias[h][|dy|*WS+|dx|], qkv rows [heads][q32|k32|v32].
@@ -1563,6 +1687,19 @@ static int launch_window_attn(const void* qkv, int ld, const void* pad_qkv, cons
   const int total = B * nwx * nwy * heads;
   hipLaunchKernelGGL(kern, dim3((unsigned)((total + PAIRS - 1) / PAIRS)), dim3(PAIRS * TPP), lds, s, (const T*)qkv, ld,
                      (const T*)pad_qkv, bias, (T*)out, ldo, H, W, heads, nwx, nwy, total);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// plain (unmasked, unbiased) softmax attention, heads x 32, bf16, Nk % 64 == 0: the MFMA kernel; returns 1 if
+// the shape is not eligible (the caller then uses the generic fp32 core)
+int esam3_launch_attn_mfma32(const void* q, int ldq, int q_off, const void* kv, int ldk, int k_off, int v_off, void* out,
+                             int ldo, int B, int Nq, int Nk, int heads, hipStream_t s) {
+  static const bool no_mfma = getenv("ESAM3_ATTN_VALU") != nullptr;
+  if (no_mfma || Nk % 64 || Nq < 64 || ldq % 8 || ldk % 8 || q_off % 8 || k_off % 8 || v_off % 8 || ldo % 4) return 1;
+  dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)heads, (unsigned)B);
+  hipLaunchKernelGGL(attn_mfma32_kernel, grid, dim3(256), 0, s, (const bf16_t*)q, ldq, q_off, (const bf16_t*)kv, ldk, k_off,
+                     v_off, (bf16_t*)out, ldo, Nq, Nk, 0.17677669529663687f * 1.4426950408889634f);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
