@@ -81,6 +81,7 @@ SIGNATURES = {
     "esam3_op_conv3x3_s2": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_window_attention": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "esam3_op_attn_window": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "esam3_op_mha": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "esam3_op_vit_rope": (_I, [_I, _P, _P, _L, _I, _I, _I, _I, _P]),
     "esam3_op_squeeze_excite": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "esam3_op_conv3x3_padded": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -1433,6 +1433,14 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
       }));
       if (rc == 0) return 0;
     }
+    if (dtype == 1 && Nq <= 1024 && Nk >= 128) {  // few queries x many keys (decoder / geometry cross-attention)
+      int rc = 1;
+      CK(prof_launch("pcs_attn_splitk", 4.0 * (double)B * Nq * Nk * DM, 0.0, [&]() {
+        rc = esam3_launch_attn_mfma32_splitk(q, ldq, qo, kv, ldk, ko, vo, o, DM, B, Nq, Nk, HEADS, mask, by, bx, EMB, EMB, q0, st);
+        return rc < 0 ? -1 : 0;
+      }));
+      if (rc == 0) return 0;
+    }
     return prof_launch("pcs_attn", 4.0 * (double)B * Nq * Nk * DM, 0.0, [&]() {
       return esam3_launch_mha_core(dtype, q, ldq, qo, kv, ldk, ko, vo, o, DM, B, Nq, Nk, HEADS, mask, by, bx, EMB, EMB, q0, st);
     });
@@ -1555,7 +1563,7 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
     CK(lin(pk_linear(t + "ref_point_head.layers.1"), da, DM, R, qpos, DM, ACT_NONE));
     if (!dry) {
       CK(esam3_launch_bcast_rows(dtype, fbufs["pcs_zero_row"], 1, qpos, QR, 0, B, DM, st));
-      CK(prof_launch("pcs_rpb", 0.0, 0.0, [&]() { return esam3_launch_rpb_mlp(ref, rpbx, rpby, by, bx, R, EMB, EMB, HEADS, st); }));
+      CK(prof_launch("pcs_rpb", 0.0, 0.0, [&]() { return esam3_launch_rpb_mlp(ref, rpbx, rpby, by, bx, R, QR, EMB, EMB, HEADS, st); }));
     }
     // self-attention among presence + queries: q = k = x + pos, v = x
     const std::string sa = p + "self_attn.", ct = p + "ca_text.", ci = p + "cross_attn.";

@@ -139,6 +139,11 @@ int esam3_launch_mbconv_fused(int dtype, const void* x, void* out, const void* w
 // bf16 MFMA flash attention, heads x 32, no mask / bias (returns 1 when the shape is not eligible)
 int esam3_launch_attn_mfma32(const void* q, int ldq, int q_off, const void* kv, int ldk, int k_off, int v_off, void* out,
                              int ldo, int B, int Nq, int Nk, int heads, hipStream_t s);
+// the same for FEW queries against many keys (Nq <= ~1k): 32 queries per block, the four waves split the key
+// tiles and merge (m, l, O) through LDS; optional key mask [B][Nk] and separable bias (layout of mha_core)
+int esam3_launch_attn_mfma32_splitk(const void* q, int ldq, int q_off, const void* kv, int ldk, int k_off, int v_off,
+                                    void* out, int ldo, int B, int Nq, int Nk, int heads, const uint8_t* key_mask,
+                                    const float* bias_y, const float* bias_x, int Hk, int Wk, int bias_q0, hipStream_t s);
 // ---- PCS text-grounding detector (kernels_pcs.hip) ---------------------------------------------------------
 int esam3_launch_mha_core(int dtype, const void* q, int ldq, int q_off, const void* kv, int ldk, int k_off, int v_off,
                           void* out, int ldo, int B, int Nq, int Nk, int heads, const uint8_t* key_mask,
@@ -151,7 +156,7 @@ int esam3_launch_bcast_rows(int dtype, const float* src, int n, void* dst, int n
                             hipStream_t s);
 int esam3_launch_box_sine(int dtype, const float* boxes, void* out, int64_t rows, int rows_per_img, hipStream_t s);
 int esam3_launch_rpb_mlp(const float* boxes, const float* const* wx /*w1,b1,w2,b2*/, const float* const* wy, float* out_y,
-                         float* out_x, int64_t nq_total, int H, int W, int heads, hipStream_t s);
+                         float* out_x, int64_t nq_total, int nq_img, int H, int W, int heads, hipStream_t s);
 int esam3_launch_box_refine(int dtype, const void* delta, int ld, float* ref, int64_t rows, hipStream_t s);
 int esam3_launch_masked_mean(int dtype, const void* x, const uint8_t* mask, void* out, int B, int S, int C, hipStream_t s);
 int esam3_launch_dot_score(int dtype, const void* hs, int rows_per_img, int row0, int nq, const void* pp, float* out, int B,

@@ -940,6 +940,186 @@ __global__ __launch_bounds__(256) void attn_mfma32_kernel(const bf16_t* __restri
   }
 }
 
+// Few queries x many keys (PCS decoder image cross-attention: 201 x 5184 with the box-relative bias; geometry
+// CLS: 1 x 5184): one block = 32 queries of one (image, head); its four waves take the 64-key tiles round robin
+// (each with its own K / V^T staging area), then the partial (m, l, O) are merged through LDS.
+// key_mask [B][Nk] (1 = ignore) or null; bias_y [B][heads][Nq][Hk], bias_x [B][heads][Nq][Wk] (Wk % 4 == 0) or null.
+__global__ __launch_bounds__(256) void attn_mfma32_splitk_kernel(const bf16_t* __restrict__ q, int ldq, int q_off,
+                                                                 const bf16_t* __restrict__ kv, int ldk, int k_off, int v_off,
+                                                                 bf16_t* __restrict__ out, int ldo, int Nq, int Nk, int heads,
+                                                                 const uint8_t* __restrict__ key_mask,
+                                                                 const float* __restrict__ bias_y,
+                                                                 const float* __restrict__ bias_x, int Hk, int Wk, int bias_q0,
+                                                                 float scale_log2e) {
+  constexpr int HD = 32, KT = 64, VP = 136, NWV = 4;
+  constexpr float LOG2E = 1.4426950408889634f;
+  __shared__ __attribute__((aligned(16))) char sK_all[NWV][KT * 64];
+  __shared__ __attribute__((aligned(16))) char sVt_all[NWV][HD * VP];
+  __shared__ float s_m[NWV][32], s_l[NWV][32];
+  __shared__ float s_o[NWV][HD][33];
+  const int h = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
+  char* sK = sK_all[wave];
+  char* sVt = sVt_all[wave];
+  const int qi = blockIdx.x * 32 + l31;
+  const bool valid = qi < Nq;
+  const int qc = valid ? qi : Nq - 1;
+  u32x4 qf[2];
+  {
+    const bf16_t* src = q + (b * Nq + qc) * (int64_t)ldq + q_off + h * HD;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) qf[s_] = *reinterpret_cast<const u32x4*>(src + s_ * 16 + g * 8);
+  }
+  const bool biased = bias_y != nullptr && qc >= bias_q0;
+  const float* by = bias_y ? bias_y + ((b * heads + h) * Nq + qc) * (int64_t)Hk : nullptr;
+  const float* bx = bias_x ? bias_x + ((b * heads + h) * Nq + qc) * (int64_t)Wk : nullptr;
+  const uint8_t* km = key_mask ? key_mask + b * Nk : nullptr;
+  f32x16_v o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m = -INFINITY, lsum = 0.f;
+  const bf16_t* kbase = kv + b * Nk * (int64_t)ldk + h * HD;
+  const int ntiles = (Nk + KT - 1) / KT;
+  for (int t = wave; t < ntiles; t += NWV) {   // wave-private tiles: LDS traffic of one wave is in order
+    const int j0 = t * KT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = lane + 64 * i, key = idx >> 2, slot = idx & 3;
+      const int kj = min(j0 + key, Nk - 1);
+      const u32x4 v = *reinterpret_cast<const u32x4*>(kbase + (int64_t)kj * ldk + k_off + slot * 8);
+      *reinterpret_cast<u32x4*>(sK + key * 64 + ((slot ^ ((key >> 2) & 3)) << 4)) = v;
+    }
+    {
+      const int dch = lane & 3, kq = lane >> 2;
+      u32x4 u[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        u[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)min(j0 + kq * 4 + i, Nk - 1) * ldk + v_off + dch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int w_ = e >> 1;
+        uint32_t a0, a1;
+        if (e & 1) {
+          a0 = (u[0][w_] >> 16) | (u[1][w_] & 0xffff0000u);
+          a1 = (u[2][w_] >> 16) | (u[3][w_] & 0xffff0000u);
+        } else {
+          a0 = (u[0][w_] & 0xffffu) | (u[1][w_] << 16);
+          a1 = (u[2][w_] & 0xffffu) | (u[3][w_] << 16);
+        }
+        *reinterpret_cast<uint2*>(sVt + (dch * 8 + e) * VP + kq * 8) = make_uint2(a0, a1);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x16_v sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+      const int key = kb * 32 + l31;
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const u32x4 kf = *reinterpret_cast<const u32x4*>(sK + key * 64 + (((s_ * 2 + g) ^ ((key >> 2) & 3)) << 4));
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, kf),
+                                                           __builtin_bit_cast(bf16x8_v, qf[s_]), sacc[kb], 0, 0, 0);
+      }
+    }
+    const bool edge = km != nullptr || j0 + KT > Nk;
+    float mt = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int jg = j0 + kb * 32 + 8 * q4 + 4 * g;  // keys jg .. jg+3 = accumulator rows 4*q4 .. 4*q4+3
+        float add[4] = {0.f, 0.f, 0.f, 0.f};
+        if (biased) {
+          const int jc = min(jg, Nk - 4);
+          const int ky = jc / Wk, kx = jc - ky * Wk;
+          const float yv = by[ky];
+          const float4 xv = *reinterpret_cast<const float4*>(bx + kx);
+          add[0] = (yv + xv.x) * LOG2E; add[1] = (yv + xv.y) * LOG2E;
+          add[2] = (yv + xv.z) * LOG2E; add[3] = (yv + xv.w) * LOG2E;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float sc = fmaf(sacc[kb][4 * q4 + e], scale_log2e, add[e]);
+          if (edge) {
+            const int j = jg + e;
+            if (j >= Nk || (km && km[j])) sc = -INFINITY;
+          }
+          sacc[kb][4 * q4 + e] = sc;
+          mt = fmaxf(mt, sc);
+        }
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m, mt);
+    const float mref = mn == -INFINITY ? 0.f : mn;   // a fully masked prefix keeps everything at zero
+    const float alpha = __builtin_amdgcn_exp2f(m - mref);
+    m = mn;
+    lsum *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+    u32x4 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        pv[r] = __builtin_amdgcn_exp2f(sacc[kb][r] - mref);
+        lsum += pv[r];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        pf[kb][s2].x = pack_bf16x2(pv[8 * s2 + 0], pv[8 * s2 + 1]);
+        pf[kb][s2].y = pack_bf16x2(pv[8 * s2 + 2], pv[8 * s2 + 3]);
+        pf[kb][s2].z = pack_bf16x2(pv[8 * s2 + 4], pv[8 * s2 + 5]);
+        pf[kb][s2].w = pack_bf16x2(pv[8 * s2 + 6], pv[8 * s2 + 7]);
+      }
+    }
+    const char* vrow = sVt + l31 * VP;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int koff = (kb * 32 + 16 * s2 + 4 * g) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vrow + koff);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vrow + koff + 16);
+        const u32x4 vf = {lo.x, lo.y, hi.x, hi.y};
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, vf),
+                                                    __builtin_bit_cast(bf16x8_v, pf[kb][s2]), o, 0, 0, 0);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (g == 0) { s_m[wave][l31] = m; s_l[wave][l31] = lsum; }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_o[wave][(r & 3) + 8 * (r >> 2) + 4 * g][l31] = o[r];
+  __syncthreads();
+  {  // merge: thread -> (query, 4 channels)
+    const int qq = tid & 31, dg = tid >> 5;
+    const int qo_ = blockIdx.x * 32 + qq;
+    if (qo_ >= Nq) return;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w_ = 0; w_ < NWV; ++w_) M = fmaxf(M, s_m[w_][qq]);
+    float L = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w_ = 0; w_ < NWV; ++w_) {
+      const float mw = s_m[w_][qq];
+      const float f = mw == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(mw - M);
+      L = fmaf(s_l[w_][qq], f, L);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaf(s_o[w_][dg * 4 + e][qq], f, acc[e]);
+    }
+    const float inv = 1.f / L;
+    bf16_t* dst = out + (b * Nq + qo_) * (int64_t)ldo + h * HD + dg * 4;
+    *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(acc[0] * inv, acc[1] * inv), pack_bf16x2(acc[2] * inv, acc[3] * inv));
+  }
+}
+
 // The same scheme for TinyViT's windows (bf16, head dim 32; tiny_vit.py:265-293,339-372): WS x WS windows over
 // a map that is zero-padded to a multiple of WS before the attention's LayerNorm (padded positions
 // carry the constant `pad_qkv`), additive bias[h][|dy|*WS+|dx|], qkv rows [heads][q32|k32|v32].
@@ -1700,6 +1880,20 @@ int esam3_launch_attn_mfma32(const void* q, int ldq, int q_off, const void* kv, 
   dim3 grid((unsigned)((Nq + 127) / 128), (unsigned)heads, (unsigned)B);
   hipLaunchKernelGGL(attn_mfma32_kernel, grid, dim3(256), 0, s, (const bf16_t*)q, ldq, q_off, (const bf16_t*)kv, ldk, k_off,
                      v_off, (bf16_t*)out, ldo, Nq, Nk, 0.17677669529663687f * 1.4426950408889634f);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_attn_mfma32_splitk(const void* q, int ldq, int q_off, const void* kv, int ldk, int k_off, int v_off,
+                                    void* out, int ldo, int B, int Nq, int Nk, int heads, const uint8_t* key_mask,
+                                    const float* bias_y, const float* bias_x, int Hk, int Wk, int bias_q0, hipStream_t s) {
+  static const bool no_mfma = getenv("ESAM3_ATTN_VALU") != nullptr;
+  if (no_mfma || Nk < 4 || ldq % 8 || ldk % 8 || q_off % 8 || k_off % 8 || v_off % 8 || ldo % 4) return 1;
+  if (bias_y && (Wk % 4 || Nk != Hk * Wk || Nk % 4)) return 1;
+  dim3 grid((unsigned)((Nq + 31) / 32), (unsigned)heads, (unsigned)B);
+  hipLaunchKernelGGL(attn_mfma32_splitk_kernel, grid, dim3(256), 0, s, (const bf16_t*)q, ldq, q_off, (const bf16_t*)kv, ldk,
+                     k_off, v_off, (bf16_t*)out, ldo, Nq, Nk, heads, key_mask, bias_y, bias_x, Hk, Wk, bias_q0,
+                     0.17677669529663687f * 1.4426950408889634f);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -42,7 +42,7 @@ template <> struct Vec8<float> {
 // nn.MultiheadAttention core (after the input projections): heads x 32, softmax in fp32.
 //   q rows [B*Nq][ldq] (+q_off), k / v rows [B*Nk][ldk] (+k_off / +v_off), head h at +h*32;
 //   key_mask [B][Nk] (1 = ignore) or null; optional separable additive bias for image keys j = y*Wk + x:
-//   bias_y [B][Nq][Hk][heads] + bias_x [B][Nq][Wk][heads] (decoder.py:333-415; rows with q < bias_q0 get none).
+//   bias_y [B][heads][Nq][Hk] + bias_x [B][heads][Nq][Wk] (decoder.py:333-415; rows with q < bias_q0 get none).
 // One query per thread; keys / values stream through LDS in chunks of KC (broadcast reads).
 // ------------------------------------------------------------------------------------
 template <typename T, int KC>
@@ -70,8 +70,8 @@ __global__ __launch_bounds__(128) void mha_core_kernel(const T* __restrict__ q, 
     for (int d = 0; d < HD; ++d) qr[d] *= 0.17677669529663687f;  // 32^-0.5
   }
   const bool biased = bias_y != nullptr && valid && qi >= bias_q0;
-  const float* by = biased ? bias_y + ((b * Nq + qi) * (int64_t)Hk) * heads + h : nullptr;
-  const float* bx = biased ? bias_x + ((b * Nq + qi) * (int64_t)Wk) * heads + h : nullptr;
+  const float* by = biased ? bias_y + ((b * heads + h) * Nq + qi) * (int64_t)Hk : nullptr;
+  const float* bx = biased ? bias_x + ((b * heads + h) * Nq + qi) * (int64_t)Wk : nullptr;
   float mx = -INFINITY, sum = 0.f;
   for (int j0 = 0; j0 < Nk; j0 += KC) {
     __syncthreads();
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(128) void mha_core_kernel(const T* __restrict__ q, 
       float sc = s0 + s1;
       if (biased) {
         const int kj = j0 + j, ky = kj / Wk, kx = kj - ky * Wk;
-        sc += by[ky * heads] + bx[kx * heads];
+        sc += by[ky] + bx[kx];
       }
       if (sc > mx) {
         const float f = __expf(mx - sc);
@@ -202,13 +202,13 @@ __global__ void box_sine_kernel(const float* __restrict__ boxes, T* __restrict__
 }
 
 // boxRPB "log" features -> MLP(2 -> 256 -> heads) (decoder.py:333-415): one thread per (b, q, coordinate index, axis);
-// out_y [B][Q][H][heads], out_x [B][Q][W][heads] fp32.  w1 [256][2], b1 [256], w2 [heads][256], b2 [heads].
+// out_y [B][heads][Q][H], out_x [B][heads][Q][W] fp32 (Q = nq_img query rows per image).  w1 [256][2], b1 [256], w2 [heads][256], b2 [heads].
 __global__ __launch_bounds__(256) void rpb_mlp_kernel(const float* __restrict__ boxes, const float* __restrict__ w1x,
                                                       const float* __restrict__ b1x, const float* __restrict__ w2x,
                                                       const float* __restrict__ b2x, const float* __restrict__ w1y,
                                                       const float* __restrict__ b1y, const float* __restrict__ w2y,
                                                       const float* __restrict__ b2y, float* __restrict__ out_y,
-                                                      float* __restrict__ out_x, int64_t nq_total, int H, int W, int heads) {
+                                                      float* __restrict__ out_x, int64_t nq_total, int nq_img, int H, int W, int heads) {
   extern __shared__ float sw[];  // per axis: w1 [256][2] | b1 [256] | w2 [heads][256] | b2 [heads]
   const int per = 256 * 2 + 256 + heads * 256 + heads;
   for (int i = threadIdx.x; i < 2 * per; i += 256) {
@@ -243,8 +243,10 @@ __global__ __launch_bounds__(256) void rpb_mlp_kernel(const float* __restrict__ 
     hdn = hdn > 0.f ? hdn : 0.f;
     for (int hh = 0; hh < heads; ++hh) o[hh] = fmaf(w[768 + hh * 256 + k], hdn, o[hh]);
   }
-  float* dst = ax ? out_y + (qrow * H + ci) * heads : out_x + (qrow * W + ci) * heads;
-  for (int hh = 0; hh < heads; ++hh) dst[hh] = o[hh];
+  const int64_t bimg = qrow / nq_img, qi = qrow - bimg * nq_img;
+  const int len = ax ? H : W;
+  float* dst = (ax ? out_y : out_x) + ((bimg * heads) * nq_img + qi) * len + ci;
+  for (int hh = 0; hh < heads; ++hh) dst[(int64_t)hh * nq_img * len] = o[hh];
 }
 
 // box refinement (decoder.py:560-581): ref <- sigmoid(delta + inverse_sigmoid(ref)), delta rows [rows][ld] (T)
@@ -423,10 +425,10 @@ int esam3_launch_box_sine(int dtype, const float* boxes, void* out, int64_t rows
   return 0;
 }
 int esam3_launch_rpb_mlp(const float* boxes, const float* const* wx, const float* const* wy, float* out_y, float* out_x,
-                         int64_t nq_total, int H, int W, int heads, hipStream_t s) {
+                         int64_t nq_total, int nq_img, int H, int W, int heads, hipStream_t s) {
   const size_t lds = sizeof(float) * 2 * (size_t)(256 * 2 + 256 + heads * 256 + heads);
   hipLaunchKernelGGL(rpb_mlp_kernel, dim3(blocks_for(nq_total * (H + W), 256)), dim3(256), lds, s, boxes, wx[0], wx[1],
-                     wx[2], wx[3], wy[0], wy[1], wy[2], wy[3], out_y, out_x, nq_total, H, W, heads);
+                     wx[2], wx[3], wy[0], wy[1], wy[2], wy[3], out_y, out_x, nq_total, nq_img, H, W, heads);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -135,6 +135,26 @@ int esam3_op_attn_window(int dtype, void* qkv, const float* cos_sin, void* out, 
   return 0;
 }
 
+int esam3_op_mha(int dtype, int path, const void* q, const void* k, const void* v, void* out, int B, int Nq, int Nk, int heads,
+                 const uint8_t* key_mask, const float* bias_y, const float* bias_x, int Hk, int Wk, int bias_q0, void* stream) {
+  const int D = heads * 32;
+  hipStream_t s = (hipStream_t)stream;
+  // k and v are separate [B*Nk][D] buffers: address v relative to k (element offset) like the engine's packed kv rows
+  const size_t es = dtype == 0 ? 4 : 2;
+  const int64_t voff = ((const char*)v - (const char*)k) / (int64_t)es;
+  if (voff < INT32_MIN || voff > INT32_MAX) { esam3_set_error("op_mha: k and v too far apart"); return -1; }
+  int rc;
+  if (path == 1) rc = bias_y || key_mask ? 1 : esam3_launch_attn_mfma32(q, D, 0, k, D, 0, (int)voff, out, D, B, Nq, Nk, heads, s);
+  else if (path == 2) rc = esam3_launch_attn_mfma32_splitk(q, D, 0, k, D, 0, (int)voff, out, D, B, Nq, Nk, heads, key_mask, bias_y,
+                                                          bias_x, Hk, Wk, bias_q0, s);
+  else rc = esam3_launch_mha_core(dtype, q, D, 0, k, D, 0, (int)voff, out, D, B, Nq, Nk, heads, key_mask, bias_y, bias_x, Hk, Wk,
+                                  bias_q0, s);
+  if (rc > 0) { esam3_set_error("op_mha: path %d does not take this shape", path); return -1; }
+  if (rc) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize(s));
+  return 0;
+}
+
 int esam3_op_vit_rope(int dtype, void* qkv, const float* cos_sin, int64_t rows, int H, int W, int ws, int heads,
                       void* stream) {
   Tmp t;

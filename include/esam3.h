@@ -175,6 +175,15 @@ int esam3_op_window_attention(int dtype, const void* qkv_dev, const float* pad_q
  * With a RoPE table [ws*ws][32][2] q and k are rotated first (on the fly on MFMA; in place in qkv otherwise) */
 int esam3_op_attn_window(int dtype, void* qkv_dev, const float* rope_cos_sin_host /* or NULL */, void* out_dev,
                          int B, int H, int W, int ws, int heads, void* hip_stream);
+/* nn.MultiheadAttention core after the input projections, heads x 32 (the PCS encoder / decoder attentions,
+ * sam3/model/encoder.py:60-130, decoder.py:120-200): q [B*Nq][heads*32], k / v [B*Nk][heads*32] in one allocation
+ * (v within 2^31 elements of k), key_mask [B][Nk] (1 = ignore) or NULL, separable box-relative bias
+ * bias_y [B][heads][Nq][Hk] + bias_x [B][heads][Nq][Wk] fp32 or NULL (decoder.py:333-415; query rows < bias_q0 get
+ * none).  path 0: fp32-accumulate VALU kernel (any dtype); 1: bf16 MFMA flash kernel (no mask / bias, Nk % 64 == 0,
+ * Nq >= 64); 2: bf16 MFMA kernel for few queries (keys split over the waves of a block).  All device pointers. */
+int esam3_op_mha(int dtype, int path, const void* q_dev, const void* k_dev, const void* v_dev, void* out_dev, int B, int Nq,
+                 int Nk, int heads, const uint8_t* key_mask_dev, const float* bias_y_dev, const float* bias_x_dev, int Hk,
+                 int Wk, int bias_q0, void* hip_stream);
 /* 2-D axial RoPE in place on the q and k parts of qkv (vitdet.py:41-90): cos_sin_host [ws*ws][32][2] */
 int esam3_op_vit_rope(int dtype, void* qkv_dev, const float* cos_sin_host, int64_t rows, int H, int W, int ws,
                       int heads, void* hip_stream);

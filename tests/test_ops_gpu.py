@@ -458,3 +458,44 @@ def test_upsample_masks():
         assert float((got - ref).abs().max()) < 2e-5
         mism = (u_d.cpu().bool() != (ref > 0)) & ((ref.abs() > 1e-5))
         assert not mism.any()
+
+
+@pytest.mark.parametrize("path,mode,B,Nq,Hk,Wk,masked,biased", [
+    (0, "f32", 2, 37, 6, 8, False, True),      # VALU core, bias (decoder image cross-attention)
+    (0, "f32", 2, 37, 1, 19, True, False),     # VALU core, key mask (text cross-attention)
+    (0, "bf16", 2, 150, 6, 8, False, True),
+    (1, "bf16", 2, 320, 8, 32, False, False),  # MFMA flash kernel (fusion-encoder self-attention)
+    (1, "bf16", 1, 200, 8, 16, False, False),  # query remainder
+    (2, "bf16", 2, 201, 12, 24, False, True),  # split-K MFMA: bias + presence row without bias
+    (2, "bf16", 2, 1, 9, 16, False, False),    # one query (geometry CLS)
+    (2, "bf16", 2, 45, 1, 139, True, False),   # key remainder + key mask
+    (2, "bf16", 1, 33, 10, 20, True, True),
+])
+def test_mha_core(path, mode, B, Nq, Hk, Wk, masked, biased):
+    """nn.MultiheadAttention core (8 heads x 32) of the PCS encoder / decoder on its three kernels against torch
+    SDPA with the additive mask built the way the reference does (decoder.py:333-415 bias, key padding mask)."""
+    d, tdt = U.DT[mode]
+    heads, Nk, D = 8, Hk * Wk, 256
+    q = _q(_rand(B, Nq, D, seed=1), mode)
+    kv = _q(_rand(2, B, Nk, D, seed=2), mode)
+    by = _rand(B, heads, Nq, Hk, seed=3) * 2.0
+    bx = _rand(B, heads, Nq, Wk, seed=4) * 2.0
+    km = torch.zeros(B, Nk, dtype=torch.bool)
+    if masked:
+        km = torch.rand(B, Nk, generator=torch.Generator().manual_seed(5)) < 0.3
+        km[:, 0] = False
+    add = torch.zeros(B, heads, Nq, Nk)
+    if biased:
+        add = (by[..., :, None] + bx[..., None, :]).reshape(B, heads, Nq, Nk).clone()
+        add[:, :, 0] = 0.0                                           # bias_q0 = 1: the presence token row
+    add = add.masked_fill(km[:, None, None, :], float("-inf"))
+    sp = lambda t, n: t.view(B, n, heads, 32).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q, Nq), sp(kv[0], Nk), sp(kv[1], Nk), attn_mask=add)
+    ref = ref.transpose(1, 2).reshape(B, Nq, D)
+    q_d, kv_d = q.to(tdt).cuda().contiguous(), kv.to(tdt).cuda().contiguous()
+    by_d, bx_d, km_d = by.cuda().contiguous(), bx.cuda().contiguous(), km.to(torch.uint8).cuda().contiguous()
+    out = torch.empty((B, Nq, D), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_mha(d, path, U.P(q_d), U.P(kv_d[0]), U.P(kv_d[1]), U.P(out), B, Nq, Nk, heads,
+                                 U.P(km_d) if masked else None, U.P(by_d) if biased else None,
+                                 U.P(bx_d) if biased else None, Hk, Wk, 1 if biased else 0, None), "op_mha")
+    U.assert_close(out.float().cpu(), ref, mode, f"mha path={path} Nq={Nq} Nk={Nk}")
