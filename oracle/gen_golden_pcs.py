@@ -103,6 +103,51 @@ def main():
             arrays[f"{pi}_scores"] = state["scores"].numpy()
             arrays[f"{pi}_boxes"] = state["boxes"].numpy()
             arrays[f"{pi}_mask_bits"] = np.packbits(state["masks"].numpy().reshape(-1))
+        # ---- geometric prompts (add_geometric_prompt / add_point_prompt, sam3_image_processor.py:130-190) ----
+        def geo_of(state):
+            gp = state["geometric_prompt"]
+            b = 1
+            pts = gp.point_embeddings if gp.point_embeddings is not None else torch.zeros(0, b, 2)
+            bxs = gp.box_embeddings if gp.box_embeddings is not None else torch.zeros(0, b, 4)
+            pl = gp.point_labels if gp.point_labels is not None else torch.zeros(0, b, dtype=torch.long)
+            bl = gp.box_labels if gp.box_labels is not None else torch.zeros(0, b, dtype=torch.long)
+            pm = gp.point_mask if gp.point_mask is not None else torch.zeros(b, pts.shape[0], dtype=torch.bool)
+            bm = gp.box_mask if gp.box_mask is not None else torch.zeros(b, bxs.shape[0], dtype=torch.bool)
+            return {"points": pts.transpose(0, 1).float(), "point_labels": pl.transpose(0, 1).long(), "point_mask": pm.bool(),
+                    "boxes": bxs.transpose(0, 1).float(), "box_labels": bl.transpose(0, 1).long(), "box_mask": bm.bool()}
+
+        def record(name, state):
+            out_r = captured["out"]
+            geo = geo_of(state)
+            out_o = ref_pcs.forward_grounding(sd, bo["backbone_fpn"], bo["vision_pos_enc"][-1], bo["language_features"],
+                                              bo["language_mask"], None, geo)
+            errs = {k: float((out_r[k] - out_o[k]).abs().max()) for k in
+                    ("pred_logits", "pred_boxes", "presence_logit_dec", "pred_masks", "semantic_seg")}
+            print(name, errs, {k: tuple(v.shape) for k, v in geo.items()})
+            manifest["cases"][name] = {"oracle_vs_reference_maxabs": errs}
+            for k, v in geo.items():
+                arrays[f"{name}_{k}"] = v.numpy()
+            arrays[f"{name}_language_features"] = bo["language_features"].numpy()
+            arrays[f"{name}_language_mask"] = bo["language_mask"].numpy()
+            arrays[f"{name}_pred_logits"] = out_r["pred_logits"].numpy()
+            arrays[f"{name}_pred_boxes"] = out_r["pred_boxes"].numpy()
+            arrays[f"{name}_presence_logit_dec"] = out_r["presence_logit_dec"].numpy()
+            arrays[f"{name}_pred_masks_sample"] = sample(out_r["pred_masks"])
+            arrays[f"{name}_scores"] = state["scores"].numpy()
+            arrays[f"{name}_boxes"] = state["boxes"].numpy()
+            arrays[f"{name}_mask_bits"] = np.packbits(state["masks"].numpy().reshape(-1))
+
+        proc.reset_all_prompts(state)
+        state = proc.set_text_prompt("dog", state)
+        state = proc.add_geometric_prompt([0.45, 0.5, 0.3, 0.4], True, state)
+        record("geo_text_box", state)
+        proc.reset_all_prompts(state)
+        state = proc.add_point_prompt([300.0, 420.0], 1, state)          # no text: the reference encodes "visual"
+        state = proc.add_geometric_prompt([0.6, 0.4, 0.2, 0.25], False, state)
+        state = proc.add_point_prompt([700.5, 200.0], 0, state)
+        state = proc.add_geometric_prompt([0.25, 0.7, 0.45, 0.5], True, state)
+        record("geo_visual_mixed", state)
+    manifest["geometric_cases"] = ["geo_text_box", "geo_visual_mixed"]
     np.savez_compressed(os.path.join(GOLD, "pcs_cases.npz"), **arrays)
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

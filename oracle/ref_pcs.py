@@ -89,6 +89,117 @@ def geometry_dummy(sd: SD, img_feat: torch.Tensor, img_pos: torch.Tensor):
     return _ln(sd, g + "encode_norm", x), torch.zeros((b, 1), dtype=torch.bool)
 
 
+def concat_padded(seq1, mask1, seq2, mask2):
+    """concat_padded_sequences (geometry_encoders.py:22-79), batch-first: [B, L1, C] + [B, L2, C] right-padded
+    sequences -> one right-padded [B, L1+L2, C]; masks True = padding."""
+    b, l1, c = seq1.shape
+    l2 = seq2.shape[1]
+    n1, n2 = (~mask1).sum(-1), (~mask2).sum(-1)
+    out = torch.zeros((b, l1 + l2, c), dtype=seq2.dtype)
+    out[:, :l1] = seq1
+    for i in range(b):
+        out[i, int(n1[i]):int(n1[i]) + l2] = seq2[i]
+    mask = torch.arange(l1 + l2)[None, :] >= (n1 + n2)[:, None]
+    return out, mask
+
+
+def roi_align_7(feat: torch.Tensor, boxes_xyxy: torch.Tensor, out: int = 7) -> torch.Tensor:
+    """torchvision.ops.roi_align(feat, boxes, 7) with its defaults spatial_scale=1, sampling_ratio=-1 (adaptive:
+    ceil(roi / 7) samples per bin and axis), aligned=False (roi sides clamped to >= 1) - torchvision is a
+    third-party dependency absent from /root/reference; this follows its published CPU kernel
+    (roi_align_kernel.cpp).  feat [B, C, H, W]; boxes_xyxy [B, Nb, 4] in feature pixels -> [B, Nb, C, 7, 7]."""
+    b, c, h, w = feat.shape
+    nb = boxes_xyxy.shape[1]
+    res = torch.zeros((b, nb, c, out, out), dtype=feat.dtype)
+
+    def axis(start, size, n, grid):
+        # sample coordinates of the `grid` points of each of the `out` bins, then the two taps and weights
+        bins = torch.arange(out, dtype=torch.float32)[:, None]
+        g = torch.arange(grid, dtype=torch.float32)[None, :]
+        t = start + bins * (size / out) + (g + 0.5) * (size / out) / grid      # [out, grid]
+        valid = (t >= -1.0) & (t <= n)
+        t = t.clamp(min=0.0)
+        lo = t.floor().long()
+        top = lo >= n - 1
+        lo = torch.where(top, torch.full_like(lo, n - 1), lo)
+        hi = torch.where(top, lo, lo + 1)
+        t = torch.where(top, lo.float(), t)
+        fr = t - lo.float()
+        return lo, hi, fr, valid
+
+    for i in range(b):
+        for j in range(nb):
+            x1, y1, x2, y2 = [float(v) for v in boxes_xyxy[i, j]]
+            rw, rh = max(x2 - x1, 1.0), max(y2 - y1, 1.0)
+            gh, gw = int(math.ceil(rh / out)), int(math.ceil(rw / out))
+            ylo, yhi, yf, yv = axis(y1, rh, h, gh)
+            xlo, xhi, xf, xv = axis(x1, rw, w, gw)
+            f = feat[i]
+            acc = torch.zeros((c, out, out), dtype=feat.dtype)
+            for a in range(gh):
+                for e in range(gw):
+                    yl, yh_, fy = ylo[:, a], yhi[:, a], yf[:, a]
+                    xl, xh_, fx = xlo[:, e], xhi[:, e], xf[:, e]
+                    v = ((1 - fy)[None, :, None] * (1 - fx)[None, None, :] * f[:, yl][:, :, xl]
+                         + (1 - fy)[None, :, None] * fx[None, None, :] * f[:, yl][:, :, xh_]
+                         + fy[None, :, None] * (1 - fx)[None, None, :] * f[:, yh_][:, :, xl]
+                         + fy[None, :, None] * fx[None, None, :] * f[:, yh_][:, :, xh_])
+                    ok = (yv[:, a][:, None] & xv[:, e][None, :]).float()
+                    acc = acc + v * ok[None]
+            res[i, j] = acc / max(gh * gw, 1)
+    return res
+
+
+def encode_xy(x: torch.Tensor, y: torch.Tensor):
+    """PositionEmbeddingSine._encode_xy (position_encoding.py:53-70), num_pos_feats 128, scale 2*pi."""
+    dim_t = torch.arange(128, dtype=torch.float32)
+    dim_t = 10000 ** (2 * (dim_t // 2) / 128)
+
+    def enc(v):
+        pos = (v * (2 * math.pi))[..., None] / dim_t
+        return torch.stack((pos[..., 0::2].sin(), pos[..., 1::2].cos()), dim=-1).flatten(-2)
+
+    return enc(x), enc(y)
+
+
+def geometry_encoder(sd: SD, img_feat, img_pos, h: int, w: int, points, point_labels, point_mask, boxes, box_labels,
+                     box_mask):
+    """SequenceGeometryEncoder.forward (geometry_encoders.py:732-853) as model_builder.py:270-285 configures it
+    (direct + pooled + position projections for points and boxes, CLS token, final_proj + norm, 3 layers):
+    points [B, Np, 2] normalised xy, boxes [B, Nb, 4] normalised cxcywh, labels [B, N] {0,1}, masks [B, N] True = pad;
+    img_feat / img_pos [B, HW, 256]  ->  ([B, Np+Nb+1, 256], mask)."""
+    g = "geometry_encoder."
+    b = img_feat.shape[0]
+    nchw = _ln(sd, g + "img_pre_norm", img_feat).transpose(1, 2).reshape(b, D, h, w)
+    # points (:600-643): direct projection + bilinear sample of the normalised feature map + sine encoding
+    pe = _lin(sd, g + "points_direct_project", points)
+    if points.shape[1] > 0:
+        grid = (points * 2 - 1).unsqueeze(2)                        # [B, Np, 1, 2]
+        samp = F.grid_sample(nchw, grid, align_corners=False)       # [B, C, Np, 1]
+        pe = pe + _lin(sd, g + "points_pool_project", samp.squeeze(-1).transpose(1, 2))
+    ex, ey = encode_xy(points[..., 0], points[..., 1])
+    pe = pe + _lin(sd, g + "points_pos_enc_project", torch.cat([ex, ey], -1))
+    pe = pe + sd[g + "label_embed.weight"][point_labels.long()]
+    # boxes (:645-695): direct projection + 7x7 roi_align through a 7x7 conv + sine encoding of (cy, cx, h, w)
+    be = _lin(sd, g + "boxes_direct_project", boxes)
+    if boxes.shape[1] > 0:
+        roi = roi_align_7(nchw, box_cxcywh_to_xyxy(boxes) * torch.tensor([w, h, w, h], dtype=torch.float32))
+        pooled = F.conv2d(roi.flatten(0, 1), sd[g + "boxes_pool_project.weight"], sd[g + "boxes_pool_project.bias"])
+        be = be + pooled.view(b, boxes.shape[1], D)
+    ex, ey = encode_xy(boxes[..., 0], boxes[..., 1])
+    enc = torch.cat([ey, ex, boxes[..., 3:4], boxes[..., 2:3]], -1)
+    be = be + _lin(sd, g + "boxes_pos_enc_project", enc)
+    be = be + sd[g + "label_embed.weight"][box_labels.long()]
+    x, mask = concat_padded(pe, point_mask, be, box_mask)
+    cls = sd[g + "cls_embed.weight"].view(1, 1, D).repeat(b, 1, 1)
+    x, mask = concat_padded(x, mask, cls, torch.zeros((b, 1), dtype=torch.bool))
+    x = _ln(sd, g + "norm", _lin(sd, g + "final_proj", x))
+    zero = torch.zeros_like(x)
+    for i in range(3):
+        x = encoder_layer(sd, g + f"encode.{i}.", x, img_feat, None, zero, img_pos, False, True, tgt_kpm=mask)
+    return _ln(sd, g + "encode_norm", x), mask
+
+
 def fusion_encoder(sd: SD, img_feat, img_pos, prompt, prompt_mask) -> torch.Tensor:
     """TransformerEncoderFusion (add_pooled_text_to_img_feat=False): 6 pre-norm layers, self-attention over
     the image tokens with the position encoding on q and k, cross-attention to the prompt tokens."""
@@ -207,15 +318,20 @@ def segmentation_head(sd: SD, fpn, enc_out, prompt, prompt_mask, queries):
 
 
 def forward_grounding(sd: SD, backbone_fpn, pos72: torch.Tensor, language_features: torch.Tensor,
-                      language_mask: torch.Tensor, taps: Optional[dict] = None) -> dict:
+                      language_mask: torch.Tensor, taps: Optional[dict] = None, geo: Optional[dict] = None) -> dict:
     """backbone_fpn: the sam3 neck's three NCHW levels for the B images; pos72 [B,256,72,72] sine position
-    encoding of the last level; language_features [S, B, 256] / language_mask [B, S] (one text per image)."""
+    encoding of the last level; language_features [S, B, 256] / language_mask [B, S] (one text per image);
+    geo: optional geometric prompt {points, point_labels, point_mask, boxes, box_labels, box_mask} (batch-first)."""
     feat = backbone_fpn[-1]
     b, _, h, w = feat.shape
     img = feat.flatten(2).transpose(1, 2)
     pos = pos72.flatten(2).transpose(1, 2)
     txt = language_features.transpose(0, 1)
-    geo, geo_mask = geometry_dummy(sd, img, pos)
+    if geo is None:
+        geo, geo_mask = geometry_dummy(sd, img, pos)
+    else:
+        geo, geo_mask = geometry_encoder(sd, img, pos, h, w, geo["points"], geo["point_labels"], geo["point_mask"],
+                                         geo["boxes"], geo["box_labels"], geo["box_mask"])
     prompt = torch.cat([txt, geo], dim=1)
     prompt_mask = torch.cat([language_mask, geo_mask], dim=1)
     memory = fusion_encoder(sd, img, pos, prompt, prompt_mask)
