@@ -31,7 +31,11 @@ class ImageFeatures(C.Structure):
 
 class GroundIn(C.Structure):
     _fields_ = [("sam3_fpn_dev", C.c_void_p * 3), ("n_images", C.c_int), ("language_features_dev", C.c_void_p),
-                ("language_mask_dev", C.c_void_p), ("n_tokens", C.c_int)]
+                ("language_mask_dev", C.c_void_p), ("n_tokens", C.c_int),
+                ("n_points", C.c_int), ("points_dev", C.c_void_p), ("point_labels_dev", C.c_void_p),
+                ("point_mask_dev", C.c_void_p),
+                ("n_boxes", C.c_int), ("boxes_dev", C.c_void_p), ("box_labels_dev", C.c_void_p),
+                ("box_mask_dev", C.c_void_p)]
 
 
 class GroundOut(C.Structure):

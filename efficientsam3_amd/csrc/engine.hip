@@ -543,6 +543,7 @@ struct esam3_engine {
                       int zero_from = -1);
   void* pcs_pos_table(const std::string& key, PackedGemm* g);
   int pcs_prepare();
+  bool pcs_geo_pack();
   int ground(const esam3_ground_in* in, const esam3_ground_out* out);
   int text_repmixer(const std::string& p, void* x, int B, int S, int D, void* out);
   int encode_text(const int64_t* tokens, int B, int S, float* memory_sbd, float* embeds_sbd);
@@ -1413,9 +1414,46 @@ int E::pcs_prepare() {
   return 0;
 }
 
+// weights of the geometric-prompt token assembly (only needed when a point / box prompt arrives): summed biases of
+// the projections that land on a point / box token, the 7x7 conv as a [256][49*256] tap-major linear, and the
+// 258-wide box sine projection zero padded to 264 columns
+bool E::pcs_geo_pack() {
+  if (fbufs.count("pcs_geo_b_pt")) return true;
+  const std::string g = "geometry_encoder.";
+  const HostTensor *b1 = need(g + "points_direct_project.bias"), *b2 = need(g + "points_pool_project.bias"),
+                   *b3 = need(g + "points_pos_enc_project.bias"), *c1 = need(g + "boxes_direct_project.bias"),
+                   *c2 = need(g + "boxes_pool_project.bias"), *c3 = need(g + "boxes_pos_enc_project.bias"),
+                   *wc = need(g + "boxes_pool_project.weight"), *wp = need(g + "boxes_pos_enc_project.weight");
+  if (!b1 || !b2 || !b3 || !c1 || !c2 || !c3 || !wc || !wp) return false;
+  std::vector<float> bp(DM), bb(DM);
+  for (int c = 0; c < DM; ++c) {
+    bp[c] = (float)((double)b1->d[c] + b2->d[c] + b3->d[c]);
+    bb[c] = (float)((double)c1->d[c] + c2->d[c] + c3->d[c]);
+  }
+  HostTensor flat;
+  flat.shape = {DM, 49 * DM};
+  flat.d.resize((size_t)DM * 49 * DM);
+  for (int n = 0; n < DM; ++n)
+    for (int c = 0; c < DM; ++c)
+      for (int t = 0; t < 49; ++t) flat.d[((size_t)n * 49 + t) * DM + c] = wc->d[((size_t)n * DM + c) * 49 + t];
+  raw[g + "boxes_pool_project#flat.weight"] = std::move(flat);
+  HostTensor pad;
+  pad.shape = {DM, 264};
+  pad.d.assign((size_t)DM * 264, 0.f);
+  for (int n = 0; n < DM; ++n)
+    for (int k = 0; k < DM + 2; ++k) pad.d[(size_t)n * 264 + k] = wp->d[(size_t)n * (DM + 2) + k];
+  raw[g + "boxes_pos_enc_project#pad.weight"] = std::move(pad);
+  if (!pk_conv_like_linear(g + "boxes_pool_project#flat.weight", "") || !pk_conv_like_linear(g + "boxes_pos_enc_project#pad.weight", "") ||
+      !pk_conv_like_linear(g + "points_pool_project.weight", "") || !pk_conv_like_linear(g + "points_pos_enc_project.weight", "") ||
+      !fvec(g + "points_direct_project.weight") || !fvec(g + "boxes_direct_project.weight") || !fvec(g + "label_embed.weight") ||
+      !fvec(g + "cls_embed.weight"))
+    return false;
+  return fvec_raw("pcs_geo_b_pt", bp) && fvec_raw("pcs_geo_b_bx", bb);
+}
+
 int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
   arena.top = 0;
-  const int B = in->n_images, S = in->n_tokens, Sp = S + 1, Q = 200, QR = Q + 1, HEADS = 8, FF = 2048;
+  const int B = in->n_images, S = in->n_tokens, Np = in->n_points, Nb = in->n_boxes, Lg = Np + Nb + 1, Sp = S + Lg, Q = 200, QR = Q + 1, HEADS = 8, FF = 2048;
   const int64_t P = (int64_t)EMB * EMB;
   const void* img = in->sam3_fpn_dev[2];
   const void* pos = tbufs["pcs_pos72"];
@@ -1448,11 +1486,11 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
   auto addk = [&](const void* a, const void* b, void* o, int64_t n) -> int { return dry ? 0 : esam3_launch_add(dtype, a, b, o, n, st); };
   auto LN = [&](const std::string& name, const void* x, void* o, int64_t rows) -> int { return layernorm(name, x, o, rows, DM, 1e-5f); };
 
-  // ---- prompt = [text tokens ; geometry CLS] ------------------------------------------------------
+  // ---- prompt = [text tokens ; geometry tokens] ------------------------------------------------------
   void* prompt = allocb((size_t)B * Sp * DM * esz);
   uint8_t* pmask = (uint8_t*)allocb((size_t)B * Sp);
   if (!ok(prompt) || !ok(pmask)) return -1;
-  if (!dry) CK(esam3_launch_pcs_prompt(dtype, in->language_features_dev, in->language_mask_dev, prompt, pmask, B, S, 1, DM, st));
+  if (!dry) CK(esam3_launch_pcs_prompt(dtype, in->language_features_dev, in->language_mask_dev, prompt, pmask, B, S, Lg, DM, st));
 
   // scratch shared by all stages (image-sized)
   void* t2 = allocb((size_t)B * P * DM * esz);        // LayerNorm output / attention output
@@ -1462,35 +1500,74 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
   void* pkv = allocb((size_t)B * Sp * 2 * DM * esz);  // k|v of the prompt tokens
   if (!ok(t2) || !ok(qkv) || !ok(hid) || !ok(mem) || !ok(pkv)) return -1;
 
-  // ---- geometry encoder on the dummy prompt: the CLS token through 3 layers (geometry_encoders.py:819-853)
+  // ---- geometry encoder (geometry_encoders.py:732-853): [points ; boxes ; CLS] through 3 layers ---------
   {
     const std::string g = "geometry_encoder.";
-    void* x = allocb((size_t)B * DM * esz);
-    void* a = allocb((size_t)B * DM * esz);
-    void* b_ = allocb((size_t)B * DM * esz);
-    void* h2 = allocb((size_t)B * FF * esz);
-    if (!ok(x) || !ok(a) || !ok(b_) || !ok(h2)) return -1;
-    if (!dry) CK(esam3_launch_bcast_rows(dtype, fbufs["pcs_geo_x0"], 1, x, 1, 0, B, DM, st));
+    const int64_t R = (int64_t)B * Lg;
+    void* x = allocb((size_t)R * DM * esz);
+    void* a = allocb((size_t)R * DM * esz);
+    void* b_ = allocb((size_t)R * 3 * DM * esz);
+    void* h2 = allocb((size_t)R * FF * esz);
+    uint8_t* geo_mask = (uint8_t*)allocb((size_t)R);
+    if (!ok(x) || !ok(a) || !ok(b_) || !ok(h2) || !ok(geo_mask)) return -1;
+    if (Lg == 1) {
+      if (!dry) CK(esam3_launch_bcast_rows(dtype, fbufs["pcs_geo_x0"], 1, x, 1, 0, B, DM, st));
+    } else {
+      // token assembly: direct projections / label embeddings in one kernel, the pooled-feature and sine
+      // projections as bias-free GEMMs summed onto it, then final_proj + norm
+      void* a_samp = allocb((size_t)R * DM * esz);
+      void* a_encp = allocb((size_t)R * DM * esz);
+      void* a_roi = allocb((size_t)R * 49 * DM * esz);
+      void* a_encb = allocb((size_t)R * 264 * esz);
+      if (!ok(a_samp) || !ok(a_encp) || !ok(a_roi) || !ok(a_encb)) return -1;
+      CK(LN(g + "img_pre_norm", img, t2, B * P));
+      if (!pcs_geo_pack()) return -1;
+      if (!dry)
+        CK(prof_launch("pcs_geo_tokens", 0.0, 0.0, [&]() {
+          return esam3_launch_geo_tokens(dtype, in->points_dev, in->point_labels_dev, in->point_mask_dev, Np, in->boxes_dev,
+                                         in->box_labels_dev, in->box_mask_dev, Nb, t2, EMB, EMB,
+                                         fvec(g + "points_direct_project.weight"), fbufs["pcs_geo_b_pt"],
+                                         fvec(g + "boxes_direct_project.weight"), fbufs["pcs_geo_b_bx"],
+                                         fvec(g + "label_embed.weight"), fvec(g + "cls_embed.weight"), x, a_samp, a_encp, a_roi,
+                                         a_encb, pmask, Sp, S, geo_mask, B, st);
+        }));
+      if (Np > 0) {
+        CK(lin(pk_conv_like_linear(g + "points_pool_project.weight", ""), a_samp, DM, R, x, DM, ACT_NONE, x, DM));
+        CK(lin(pk_conv_like_linear(g + "points_pos_enc_project.weight", ""), a_encp, DM, R, x, DM, ACT_NONE, x, DM));
+      }
+      if (Nb > 0) {
+        CK(lin(pk_conv_like_linear(g + "boxes_pool_project#flat.weight", ""), a_roi, 49 * DM, R, x, DM, ACT_NONE, x, DM));
+        CK(lin(pk_conv_like_linear(g + "boxes_pos_enc_project#pad.weight", ""), a_encb, 264, R, x, DM, ACT_NONE, x, DM));
+      }
+      CK(lin(pk_linear(g + "final_proj"), x, DM, R, a, DM, ACT_NONE));
+      CK(LN(g + "norm", a, x, R));
+    }
     for (int i = 0; i < 3; ++i) {
       const std::string p = g + "encode." + std::to_string(i) + ".";
-      // self-attention over a single token: softmax over one key = 1 -> out_proj(v_proj(LN(x)))
-      CK(LN(p + "norm1", x, a, B));
-      CK(lin(L(p + "self_attn.in_proj_weight", p + "self_attn.in_proj_bias", 2 * DM, DM, p + "self_attn.#v"), a, DM, B, b_, DM, ACT_NONE));
-      CK(lin(pk_linear(p + "self_attn.out_proj"), b_, DM, B, x, DM, ACT_NONE, x, DM));
+      CK(LN(p + "norm1", x, a, R));
+      if (Lg == 1) {
+        // self-attention over a single token: softmax over one key = 1 -> out_proj(v_proj(LN(x)))
+        CK(lin(L(p + "self_attn.in_proj_weight", p + "self_attn.in_proj_bias", 2 * DM, DM, p + "self_attn.#v"), a, DM, R, b_, DM, ACT_NONE));
+        CK(lin(pk_linear(p + "self_attn.out_proj"), b_, DM, R, x, DM, ACT_NONE, x, DM));
+      } else {
+        CK(lin(L(p + "self_attn.in_proj_weight", p + "self_attn.in_proj_bias", 0, 3 * DM, p + "self_attn.#qkv"), a, DM, R, b_, 3 * DM, ACT_NONE));
+        CK(attn(b_, 3 * DM, 0, b_, 3 * DM, DM, 2 * DM, a, Lg, Lg, geo_mask));
+        CK(lin(pk_linear(p + "self_attn.out_proj"), a, DM, R, x, DM, ACT_NONE, x, DM));
+      }
       // cross-attention to the image tokens, keys carry the position encoding
-      CK(LN(p + "norm2", x, a, B));
+      CK(LN(p + "norm2", x, a, R));
       const std::string c = p + "cross_attn_image.";
-      CK(lin(L(c + "in_proj_weight", c + "in_proj_bias", 0, DM, c + "#q"), a, DM, B, b_, DM, ACT_NONE));
+      CK(lin(L(c + "in_proj_weight", c + "in_proj_bias", 0, DM, c + "#q"), a, DM, R, b_, DM, ACT_NONE));
       CK(lin(L(c + "in_proj_weight", c + "in_proj_bias", DM, DM, c + "#k"), img, DM, B * P, qkv, 2 * DM, ACT_NONE, tbufs[c + "#posk"], DM, (int)P));
       CK(lin(L(c + "in_proj_weight", c + "in_proj_bias", 2 * DM, DM, c + "#v"), img, DM, B * P, (char*)qkv + DM * esz, 2 * DM, ACT_NONE));
-      CK(attn(b_, DM, 0, qkv, 2 * DM, 0, DM, a, 1, (int)P, nullptr));
-      CK(lin(pk_linear(c + "out_proj"), a, DM, B, x, DM, ACT_NONE, x, DM));
-      CK(LN(p + "norm3", x, a, B));
-      CK(lin(pk_linear(p + "linear1"), a, DM, B, h2, FF, ACT_RELU));
-      CK(lin(pk_linear(p + "linear2"), h2, FF, B, x, DM, ACT_NONE, x, DM));
+      CK(attn(b_, DM, 0, qkv, 2 * DM, 0, DM, a, Lg, (int)P, nullptr));
+      CK(lin(pk_linear(c + "out_proj"), a, DM, R, x, DM, ACT_NONE, x, DM));
+      CK(LN(p + "norm3", x, a, R));
+      CK(lin(pk_linear(p + "linear1"), a, DM, R, h2, FF, ACT_RELU));
+      CK(lin(pk_linear(p + "linear2"), h2, FF, R, x, DM, ACT_NONE, x, DM));
     }
-    CK(LN(g + "encode_norm", x, a, B));
-    if (!dry) CK(esam3_launch_copy_rows(dtype, a, 1, prompt, Sp, S, B, DM, st));
+    CK(LN(g + "encode_norm", x, a, R));
+    if (!dry) CK(esam3_launch_copy_rows(dtype, a, Lg, prompt, Sp, S, B, DM, st));
   }
 
   // ---- fusion encoder (encoder.py:139-201,513-577): 6 pre-norm layers over the 5184 image tokens -------
@@ -2081,6 +2158,11 @@ int esam3_ground(esam3_engine* e, const esam3_ground_in* in, const esam3_ground_
       !in->language_features_dev || !in->language_mask_dev || !out->pred_logits_dev || !out->pred_boxes_dev ||
       !out->presence_logit_dev || !out->pred_masks_dev) {
     esam3_set_error("esam3_ground: bad input/output description");
+    return -1;
+  }
+  if (in->n_points < 0 || in->n_boxes < 0 || (in->n_points > 0 && (!in->points_dev || !in->point_labels_dev)) ||
+      (in->n_boxes > 0 && (!in->boxes_dev || !in->box_labels_dev)) || in->n_points + in->n_boxes > 64) {
+    esam3_set_error("esam3_ground: bad geometric prompt (n_points=%d n_boxes=%d, at most 64 in total)", in->n_points, in->n_boxes);
     return -1;
   }
   e->st = (hipStream_t)stream;

@@ -155,6 +155,11 @@ int esam3_launch_copy_rows(int dtype, const void* src, int n_src, void* dst, int
 int esam3_launch_bcast_rows(int dtype, const float* src, int n, void* dst, int n_dst, int dst_row0, int B, int C,
                             hipStream_t s);
 int esam3_launch_box_sine(int dtype, const float* boxes, void* out, int64_t rows, int rows_per_img, hipStream_t s);
+int esam3_launch_geo_tokens(int dtype, const float* points, const int32_t* plabels, const uint8_t* pmask, int Np,
+                            const float* boxes, const int32_t* blabels, const uint8_t* bmask, int Nb, const void* imgn, int H,
+                            int W, const float* w_pd, const float* b_pt, const float* w_bd, const float* b_bx,
+                            const float* label_embed, const float* cls, void* x0, void* a_samp, void* a_encp, void* a_roi,
+                            void* a_encb, uint8_t* gmask, int ld_mask, int mask_off, uint8_t* gmask_dense, int B, hipStream_t s);
 int esam3_launch_rpb_mlp(const float* boxes, const float* const* wx /*w1,b1,w2,b2*/, const float* const* wy, float* out_y,
                          float* out_x, int64_t nq_total, int nq_img, int H, int W, int heads, hipStream_t s);
 int esam3_launch_box_refine(int dtype, const void* delta, int ld, float* ref, int64_t rows, hipStream_t s);

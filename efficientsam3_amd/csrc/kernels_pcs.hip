@@ -201,6 +201,105 @@ __global__ void box_sine_kernel(const float* __restrict__ boxes, T* __restrict__
   dst[1] = from_f32<T>(cosf(a));
 }
 
+// SequenceGeometryEncoder token assembly (geometry_encoders.py:600-695,790-815): one workgroup per (token slot,
+// image), one thread per channel.  Slot order per image: its valid points, its valid boxes, the CLS token, padding.
+//   x0 [B][Lg][256]      direct projections + all Linear biases + label embedding (or cls_embed); 0 for padding
+//   a_samp [B][Lg][256]  bilinear grid_sample of the pre-normed image features at the point (zero padding,
+//                        align_corners=False);  a_encp [B][Lg][256] = [sine(x) | sine(y)]
+//   a_roi [B][Lg][49][256]  roi_align 7x7 (torchvision defaults: scale 1, adaptive sampling, aligned=False) of the
+//                        box in feature pixels;  a_encb [B][Lg][264] = [sine(cy) | sine(cx) | h | w | 0...]
+// The four A matrices are multiplied by the pool / pos-enc projection weights (GEMMs without bias) and summed
+// into x0 by the caller; rows of the other kinds stay zero.  gmask [B][ld_mask] (+mask_off) and gmask_dense
+// [B][Lg]: 1 = padding.
+template <typename T>
+__global__ __launch_bounds__(256) void geo_tokens_kernel(
+    const float* __restrict__ points, const int32_t* __restrict__ plabels, const uint8_t* __restrict__ pmask, int Np,
+    const float* __restrict__ boxes, const int32_t* __restrict__ blabels, const uint8_t* __restrict__ bmask, int Nb,
+    const T* __restrict__ imgn, int H, int W, const float* __restrict__ w_pd, const float* __restrict__ b_pt,
+    const float* __restrict__ w_bd, const float* __restrict__ b_bx, const float* __restrict__ label_embed,
+    const float* __restrict__ cls, T* __restrict__ x0, T* __restrict__ a_samp, T* __restrict__ a_encp,
+    T* __restrict__ a_roi, T* __restrict__ a_encb, uint8_t* __restrict__ gmask, int ld_mask, int mask_off,
+    uint8_t* __restrict__ gmask_dense) {
+  constexpr int C = 256;
+  const int t = blockIdx.x, b = blockIdx.y, c = threadIdx.x, Lg = Np + Nb + 1;
+  int np = 0, nb = 0;
+  for (int i = 0; i < Np; ++i) np += pmask ? (pmask[b * Np + i] == 0) : 1;
+  for (int i = 0; i < Nb; ++i) nb += bmask ? (bmask[b * Nb + i] == 0) : 1;
+  const int64_t row = (int64_t)b * Lg + t;
+  float xv = 0.f, sv = 0.f, ev = 0.f;
+  const bool is_pt = t < np, is_box = !is_pt && t < np + nb, is_cls = t == np + nb;
+  if (c == 0) {
+    gmask[(int64_t)b * ld_mask + mask_off + t] = t > np + nb;
+    gmask_dense[(int64_t)b * Lg + t] = t > np + nb;
+  }
+  const T* fimg = imgn + (int64_t)b * H * W * C;
+  const float dim_t = powf(10000.f, (float)(2 * ((c & 127) >> 1)) / 128.f);
+  if (is_pt) {
+    const float px = points[((int64_t)b * Np + t) * 2], py = points[((int64_t)b * Np + t) * 2 + 1];
+    xv = fmaf(w_pd[c * 2], px, fmaf(w_pd[c * 2 + 1], py, b_pt[c])) + label_embed[plabels[b * Np + t] * C + c];
+    const float ix = px * (float)W - 0.5f, iy = py * (float)H - 0.5f;
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0i = (int)fx0, y0i = (int)fy0;
+    const float lx = ix - fx0, ly = iy - fy0;
+    auto tap = [&](int yy, int xx) -> float {
+      return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? to_f32<T>(fimg[((int64_t)yy * W + xx) * C + c]) : 0.f;
+    };
+    sv = tap(y0i, x0i) * (1.f - ly) * (1.f - lx) + tap(y0i, x0i + 1) * (1.f - ly) * lx + tap(y0i + 1, x0i) * ly * (1.f - lx) +
+         tap(y0i + 1, x0i + 1) * ly * lx;
+    const float v = (c < 128 ? px : py) * 6.283185307179586f / dim_t;
+    ev = (c & 1) ? cosf(v) : sinf(v);
+  } else if (is_box) {
+    const int j = t - np;
+    const float* bx = boxes + ((int64_t)b * Nb + j) * 4;
+    const float cx = bx[0], cy = bx[1], bw = bx[2], bh = bx[3];
+    xv = fmaf(w_bd[c * 4], cx, fmaf(w_bd[c * 4 + 1], cy, fmaf(w_bd[c * 4 + 2], bw, fmaf(w_bd[c * 4 + 3], bh, b_bx[c])))) +
+         label_embed[blabels[b * Nb + j] * C + c];
+    const float v = (c < 128 ? cy : cx) * 6.283185307179586f / dim_t;
+    a_encb[row * 264 + c] = from_f32<T>((c & 1) ? cosf(v) : sinf(v));
+    if (c < 8) a_encb[row * 264 + 256 + c] = from_f32<T>(c == 0 ? bh : (c == 1 ? bw : 0.f));
+    // roi_align: box corners in feature pixels, sides clamped to >= 1, ceil(side / 7) samples per bin and axis
+    const float x1 = (cx - 0.5f * bw) * (float)W, y1 = (cy - 0.5f * bh) * (float)H;
+    const float x2 = (cx + 0.5f * bw) * (float)W, y2 = (cy + 0.5f * bh) * (float)H;
+    const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+    const float bin_h = rh / 7.f, bin_w = rw / 7.f;
+    const int gh = (int)ceilf(rh / 7.f), gw = (int)ceilf(rw / 7.f);
+    const float inv = 1.f / (float)max(gh * gw, 1);
+    for (int phh = 0; phh < 7; ++phh)
+      for (int pww = 0; pww < 7; ++pww) {
+        float acc = 0.f;
+        for (int iy = 0; iy < gh; ++iy) {
+          float y = y1 + (float)phh * bin_h + ((float)iy + 0.5f) * bin_h / (float)gh;
+          if (y < -1.f || y > (float)H) continue;
+          y = fmaxf(y, 0.f);
+          int yl = (int)y, yh;
+          if (yl >= H - 1) { yl = yh = H - 1; y = (float)yl; } else yh = yl + 1;
+          const float ly = y - (float)yl, hy = 1.f - ly;
+          for (int ixx = 0; ixx < gw; ++ixx) {
+            float x = x1 + (float)pww * bin_w + ((float)ixx + 0.5f) * bin_w / (float)gw;
+            if (x < -1.f || x > (float)W) continue;
+            x = fmaxf(x, 0.f);
+            int xl = (int)x, xh;
+            if (xl >= W - 1) { xl = xh = W - 1; x = (float)xl; } else xh = xl + 1;
+            const float lx = x - (float)xl, hx = 1.f - lx;
+            acc += hy * hx * to_f32<T>(fimg[((int64_t)yl * W + xl) * C + c]) + hy * lx * to_f32<T>(fimg[((int64_t)yl * W + xh) * C + c]) +
+                   ly * hx * to_f32<T>(fimg[((int64_t)yh * W + xl) * C + c]) + ly * lx * to_f32<T>(fimg[((int64_t)yh * W + xh) * C + c]);
+          }
+        }
+        a_roi[(row * 49 + phh * 7 + pww) * C + c] = from_f32<T>(acc * inv);
+      }
+  } else if (is_cls) {
+    xv = cls[c];
+  }
+  x0[row * C + c] = from_f32<T>(xv);
+  a_samp[row * C + c] = from_f32<T>(sv);
+  a_encp[row * C + c] = from_f32<T>(ev);
+  if (!is_box) {
+    a_encb[row * 264 + c] = from_f32<T>(0.f);
+    if (c < 8) a_encb[row * 264 + 256 + c] = from_f32<T>(0.f);
+    for (int k = 0; k < 49; ++k) a_roi[(row * 49 + k) * C + c] = from_f32<T>(0.f);
+  }
+}
+
 // boxRPB "log" features -> MLP(2 -> 256 -> heads) (decoder.py:333-415): one thread per (b, q, coordinate index, axis);
 // out_y [B][heads][Q][H], out_x [B][heads][Q][W] fp32 (Q = nq_img query rows per image).  w1 [256][2], b1 [256], w2 [heads][256], b2 [heads].
 __global__ __launch_bounds__(256) void rpb_mlp_kernel(const float* __restrict__ boxes, const float* __restrict__ w1x,
@@ -421,6 +520,18 @@ int esam3_launch_bcast_rows(int dtype, const float* src, int n, void* dst, int n
 int esam3_launch_box_sine(int dtype, const float* boxes, void* out, int64_t rows, int rows_per_img, hipStream_t s) {
   DISPATCH_T(dtype, hipLaunchKernelGGL(box_sine_kernel<T>, dim3(blocks_for(rows * 256, 256)), dim3(256), 0, s, boxes,
                                        (T*)out, rows, rows_per_img));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int esam3_launch_geo_tokens(int dtype, const float* points, const int32_t* plabels, const uint8_t* pmask, int Np,
+                            const float* boxes, const int32_t* blabels, const uint8_t* bmask, int Nb, const void* imgn, int H,
+                            int W, const float* w_pd, const float* b_pt, const float* w_bd, const float* b_bx,
+                            const float* label_embed, const float* cls, void* x0, void* a_samp, void* a_encp, void* a_roi,
+                            void* a_encb, uint8_t* gmask, int ld_mask, int mask_off, uint8_t* gmask_dense, int B, hipStream_t s) {
+  dim3 grid((unsigned)(Np + Nb + 1), (unsigned)B);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(geo_tokens_kernel<T>, grid, dim3(256), 0, s, points, plabels, pmask, Np, boxes, blabels,
+                                       bmask, Nb, (const T*)imgn, H, W, w_pd, b_pt, w_bd, b_bx, label_embed, cls, (T*)x0,
+                                       (T*)a_samp, (T*)a_encp, (T*)a_roi, (T*)a_encb, gmask, ld_mask, mask_off, gmask_dense));
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

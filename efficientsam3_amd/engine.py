@@ -176,9 +176,11 @@ class HipEngine:
 
     # ---- PCS text grounding ----------------------------------------------------------------------
     def ground(self, sam3_fpn: Sequence[torch.Tensor], language_features: torch.Tensor,
-               language_mask: torch.Tensor, want_semantic: bool = False) -> dict:
+               language_mask: torch.Tensor, want_semantic: bool = False, geo: Optional[dict] = None) -> dict:
         """sam3_fpn: the three NHWC levels of B images (encode()'s "sam3_fpn"); language_features
-        [S,B,256] fp32 and language_mask [B,S] bool (True = padding), one text per image.
+        [S,B,256] fp32 and language_mask [B,S] bool (True = padding), one text per image; geo: optional
+        geometric prompt {points [B,Np,2], point_labels [B,Np], point_mask [B,Np], boxes [B,Nb,4] cxcywh,
+        box_labels, box_mask} (normalised coordinates, masks True = padding, right-padded).
         -> pred_logits [B,200,1], pred_boxes [B,200,4] (cxcywh in [0,1]), presence_logit_dec [B,1],
         pred_masks [B,200,288,288] fp32 logits (the reference's forward_grounding outputs)."""
         b = sam3_fpn[2].shape[0]
@@ -198,6 +200,22 @@ class HipEngine:
             gi.sam3_fpn_dev[i] = sam3_fpn[i].data_ptr()
         gi.n_images, gi.n_tokens = b, s
         gi.language_features_dev, gi.language_mask_dev = lf.data_ptr(), lm.data_ptr()
+        keep = []
+        if geo is not None:
+            for kind, width in (("point", 2), ("box", 4)):
+                xs = geo[kind + "s" if kind == "point" else "boxes"].to(dev, torch.float32).contiguous()
+                n = xs.shape[1]
+                assert tuple(xs.shape) == (b, n, width)
+                if n == 0:
+                    continue
+                lab = geo[kind + "_labels"].to(dev).to(torch.int32).contiguous()
+                msk = geo[kind + "_mask"].to(dev).to(torch.uint8).contiguous()
+                assert tuple(lab.shape) == (b, n) and tuple(msk.shape) == (b, n)
+                keep += [xs, lab, msk]
+                if kind == "point":
+                    gi.n_points, gi.points_dev, gi.point_labels_dev, gi.point_mask_dev = n, xs.data_ptr(), lab.data_ptr(), msk.data_ptr()
+                else:
+                    gi.n_boxes, gi.boxes_dev, gi.box_labels_dev, gi.box_mask_dev = n, xs.data_ptr(), lab.data_ptr(), msk.data_ptr()
         go = _lib.GroundOut(pred_logits_dev=logits.data_ptr(), pred_boxes_dev=boxes.data_ptr(),
                             presence_logit_dev=presence.data_ptr(), pred_masks_dev=masks.data_ptr(),
                             semantic_seg_dev=sem.data_ptr() if sem is not None else None)

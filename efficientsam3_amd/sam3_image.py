@@ -385,13 +385,11 @@ class Sam3Image:
 
     # ---- PCS text grounding (sam3_image.py:442-493) -------------------------------------------------
     def forward_grounding(self, backbone_out, find_input=None, find_target=None, geometric_prompt=None):
-        """Sam3Image.forward_grounding for what Sam3Processor.set_text_prompt passes: the image features of
-        set_image, the text features of forward_text (one text, broadcast to every image) and the dummy
-        geometric prompt.  Box / point geometric prompts are not built."""
+        """Sam3Image.forward_grounding for what Sam3Processor.set_text_prompt / add_geometric_prompt /
+        add_point_prompt pass: the image features of set_image, the text features of forward_text (one text,
+        broadcast to every image) and the geometric prompt (a ``geometry_prompt.Prompt``; empty = dummy)."""
         if self.text_encoder_type is None:
             raise NotImplementedError("model was built without text_encoder_type='MobileCLIP-S0'")
-        if geometric_prompt is not None and getattr(geometric_prompt, "n_prompts", 0) != 0:
-            raise NotImplementedError("box / point geometric prompts of the PCS detector are not built yet")
         if "language_features" not in backbone_out:
             raise ValueError("forward_text has not been run for this state")
         fpn = backbone_out.get("_esam3_nhwc_sam3")
@@ -401,10 +399,15 @@ class Sam3Image:
         lf, lm = backbone_out["language_features"], backbone_out["language_mask"]
         if lf.shape[1] == 1 and b > 1:
             lf, lm = lf.expand(-1, b, -1), lm.expand(b, -1)
-        return self.engine.ground(fpn, lf, lm)
+        geo = None
+        if geometric_prompt is not None and geometric_prompt.n_prompts > 0:
+            geo = geometric_prompt.batch_first()
+            if geo["points"].shape[0] == 1 and b > 1:
+                geo = {k: v.expand(b, *v.shape[1:]) for k, v in geo.items()}
+        return self.engine.ground(fpn, lf, lm, geo=geo)
 
     def _get_dummy_prompt(self, num_prompts: int = 1):
-        """Stand-in for the empty geometric Prompt (sam3_image.py:522-528): no boxes, no points."""
-        class _DummyPrompt:
-            n_prompts = 0
-        return _DummyPrompt()
+        """The empty geometric Prompt (sam3_image.py:522-528): no boxes, no points."""
+        from .geometry_prompt import Prompt
+        return Prompt(box_embeddings=torch.zeros(0, num_prompts, 4, device=self.device),
+                      box_mask=torch.zeros(num_prompts, 0, dtype=torch.bool, device=self.device))

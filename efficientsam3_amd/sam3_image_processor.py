@@ -122,15 +122,39 @@ class Sam3Processor:
             state["geometric_prompt"] = self.model._get_dummy_prompt()
         return self._forward_grounding(state)
 
+    def _ensure_text(self, state):
+        """Without a text prompt the reference encodes the word "visual" so that the detector relies on the
+        geometric prompt alone (sam3_image_processor.py:140-146,166-172)."""
+        if "language_features" not in state["backbone_out"]:
+            state["backbone_out"].update(self.model.backbone.forward_text(["visual"], device=self.device))
+        if "geometric_prompt" not in state:
+            state["geometric_prompt"] = self.model._get_dummy_prompt()
+
+    @torch.inference_mode()
     def add_geometric_prompt(self, box, label, state):
+        """Adds a box prompt ([cx, cy, w, h] normalised to [0, 1]; label True = positive) and reruns the
+        detector (sam3_image_processor.py:130-158)."""
         if "backbone_out" not in state:
             raise ValueError("You must call set_image before add_geometric_prompt")
-        raise NotImplementedError("box prompts of the PCS detector (geometry encoder with roi_align) are not built yet")
+        self._ensure_text(state)
+        boxes = torch.tensor(box, device=self.device, dtype=torch.float32).view(1, 1, 4)
+        labels = torch.tensor([label], device=self.device, dtype=torch.bool).view(1, 1)
+        state["geometric_prompt"].append_boxes(boxes, labels)
+        return self._forward_grounding(state)
 
+    @torch.inference_mode()
     def add_point_prompt(self, point, label, state):
+        """Adds a point prompt ([x, y] in pixels of the original image; label 1 = foreground, 0 = background)
+        and reruns the detector (sam3_image_processor.py:160-190)."""
         if "backbone_out" not in state:
             raise ValueError("You must call set_image before add_point_prompt")
-        raise NotImplementedError("point prompts of the PCS detector are not built yet")
+        self._ensure_text(state)
+        x_norm = point[0] / state["original_width"]
+        y_norm = point[1] / state["original_height"]
+        points = torch.tensor([[x_norm, y_norm]], device=self.device, dtype=torch.float32).view(1, 1, 2)
+        labels = torch.tensor([label], device=self.device, dtype=torch.bool).view(1, 1)
+        state["geometric_prompt"].append_points(points, labels)
+        return self._forward_grounding(state)
 
     @torch.inference_mode()
     def _forward_grounding(self, state: Dict):

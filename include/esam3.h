@@ -96,9 +96,10 @@ int esam3_decode(esam3_engine* e, const esam3_prompts* prompts, const esam3_deco
  * The padding mask is tokens == 0 and stays on the host side. */
 int esam3_encode_text(esam3_engine* e, const int64_t* tokens_dev, int B, int S, float* memory_sbd_dev,
                       float* embeds_sbd_dev, void* hip_stream);
-/* PCS text-grounding detector: Sam3Image.forward_grounding (sam3_image.py:442-493) for one text prompt per
- * image and the dummy geometric prompt, i.e. what Sam3Processor.set_text_prompt runs
- * (sam3_image_processor.py:115-131,219-226).  Weights: "geometry_encoder.*", "transformer.*",
+/* PCS grounding detector: Sam3Image.forward_grounding (sam3_image.py:442-493) for one text prompt per image plus
+ * an optional geometric prompt (points / boxes; none = the dummy prompt), i.e. what Sam3Processor.set_text_prompt,
+ * add_geometric_prompt and add_point_prompt run (sam3_image_processor.py:115-190,219-226; geometry encoder
+ * geometry_encoders.py:600-695,732-853).  Weights: "geometry_encoder.*", "transformer.*",
  * "segmentation_head.*", "dot_prod_scoring.*". */
 typedef struct esam3_ground_in {
   const void* sam3_fpn_dev[3];          /* sam3 neck levels of n_images images, as written by esam3_encode_image */
@@ -106,6 +107,15 @@ typedef struct esam3_ground_in {
   const float* language_features_dev;   /* [S][n_images][256] fp32 (esam3_encode_text layout) */
   const uint8_t* language_mask_dev;     /* [n_images][S], 1 = padding token */
   int n_tokens;                         /* S */
+  /* geometric prompt; per image the valid entries come first (right-padded), masks may be NULL = all valid */
+  int n_points;                         /* Np = max points per image, 0 = none */
+  const float* points_dev;              /* [n_images][Np][2] x, y normalised to [0, 1] */
+  const int32_t* point_labels_dev;      /* [n_images][Np] 1 = positive, 0 = negative */
+  const uint8_t* point_mask_dev;        /* [n_images][Np] 1 = padding */
+  int n_boxes;                          /* Nb = max boxes per image, 0 = none */
+  const float* boxes_dev;               /* [n_images][Nb][4] cx, cy, w, h normalised to [0, 1] */
+  const int32_t* box_labels_dev;        /* [n_images][Nb] 1 = positive, 0 = negative */
+  const uint8_t* box_mask_dev;          /* [n_images][Nb] 1 = padding */
 } esam3_ground_in;
 typedef struct esam3_ground_out {
   float* pred_logits_dev;     /* [n_images][200] */

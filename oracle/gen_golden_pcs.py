@@ -126,7 +126,7 @@ def main():
             print(name, errs, {k: tuple(v.shape) for k, v in geo.items()})
             manifest["cases"][name] = {"oracle_vs_reference_maxabs": errs}
             for k, v in geo.items():
-                arrays[f"{name}_{k}"] = v.numpy()
+                arrays[f"{name}_in_{k}"] = v.numpy()
             arrays[f"{name}_language_features"] = bo["language_features"].numpy()
             arrays[f"{name}_language_mask"] = bo["language_mask"].numpy()
             arrays[f"{name}_pred_logits"] = out_r["pred_logits"].numpy()
