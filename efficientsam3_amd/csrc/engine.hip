@@ -2051,12 +2051,13 @@ int esam3_create(const esam3_config* cfg, esam3_engine** out) {
     return 0;
   }
   if (cfg->backbone == ESAM3_BACKBONE_REPVIT) {
-    // (channels, SE, stride) per block: repvit.py:320-350 (m0_9), :386-416 (m1_1)
+    // (channels, SE, stride) per block: repvit.py:320-350 (m0_9), :386-416 (m1_1), :446-506 (m2_3)
     auto stage = [&](int c, int n_s1, bool first_stage, int tail_plain) {
       if (!first_stage) e->rv_cfg.push_back({c, 0, 2});
       for (int i = 0; i < n_s1; ++i) e->rv_cfg.push_back({c, (i % 2 == 0 && i < n_s1 - tail_plain) ? 1 : 0, 1});
     };
     if (mn == "m1.1" || mn == "m1_1") { stage(64, 3, true, 1); stage(128, 3, false, 1); stage(256, 13, false, 1); stage(512, 2, false, 0); }
+    else if (mn == "m2.3" || mn == "m2_3") { stage(80, 7, true, 1); stage(160, 7, false, 1); stage(320, 35, false, 1); stage(640, 2, false, 0); }
     else if (mn == "m0.9" || mn == "m0_9") { stage(48, 3, true, 1); stage(96, 3, false, 1); stage(192, 15, false, 1); stage(384, 2, false, 0); }
     else { esam3_set_error("unknown RepViT model '%s'", mn.c_str()); delete e; return -1; }
     *out = e;

@@ -53,6 +53,10 @@ REPVIT_CFG = {
              (3, 2, 128, 1, 0, 1), (3, 2, 128, 0, 0, 1), (3, 2, 128, 0, 0, 1), (3, 2, 256, 0, 1, 2)]
             + [(3, 2, 256, 1 - (i % 2), 1, 1) for i in range(12)] + [(3, 2, 256, 0, 1, 1), (3, 2, 512, 0, 1, 2),
                                                                       (3, 2, 512, 1, 1, 1), (3, 2, 512, 0, 1, 1)],
+    "m2.3": [(3, 2, 80, 1 - (i % 2) if i < 6 else 0, 0, 1) for i in range(7)] + [(3, 2, 160, 0, 0, 2)]
+            + [(3, 2, 160, 1 - (i % 2) if i < 6 else 0, 0, 1) for i in range(7)] + [(3, 2, 320, 0, 1, 2)]
+            + [(3, 2, 320, 1 - (i % 2), 1, 1) for i in range(34)] + [(3, 2, 320, 0, 1, 1), (3, 2, 640, 0, 1, 2),
+                                                                      (3, 2, 640, 1, 1, 1), (3, 2, 640, 0, 1, 1)],
 }
 
 TINYVIT_CFG = {

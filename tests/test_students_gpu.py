@@ -15,7 +15,7 @@ from efficientsam3_amd import (Sam3Processor, build_efficientsam3_image_model, b
                                schema, synth)
 from tests import util as U  # noqa: E402
 
-STUDENTS = [("repvit", "m1.1"), ("tinyvit", "11m"), ("sam3", "vit_h")]  # the last one is the ViT-H teacher
+STUDENTS = [("repvit", "m1.1"), ("repvit", "m2.3"), ("tinyvit", "11m"), ("sam3", "vit_h")]  # the last one is the ViT-H teacher
 SAMPLE = 4096
 
 
