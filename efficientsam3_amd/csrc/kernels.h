@@ -171,3 +171,6 @@ int esam3_launch_upsample_add(int dtype, const void* fine, const void* coarse, v
 int64_t esam3_groupnorm_scratch_floats(int B, int groups);
 int esam3_launch_groupnorm_relu(int dtype, void* x, float* partial, const float* gamma, const float* beta, int B, int HW,
                                 int C, int groups, float eps, hipStream_t s);
+// ---- COCO RLE of binary masks (kernels_rle.hip)
+int esam3_launch_rle_encode(const uint8_t* masks, int n, int H, int W, uint32_t* counts, int64_t capacity, int32_t* offsets,
+                            void* scratch, hipStream_t s);

@@ -406,3 +406,63 @@ extern "C" int esam3_bench_gemm(int dtype, int B, int H, int W, int Cin, int N, 
   *avg_ms = ms / iters;
   return 0;
 }
+
+
+// ---- COCO run-length encoding (eval writers: eval_efficientsam3_all_subsets.py:124-135, masks_ops.py:161-230) ----
+int esam3_rle_encode(const uint8_t* masks_dev, int n, int H, int W, uint32_t* counts_dev, int64_t capacity,
+                     int32_t* offsets_dev, void* scratch_dev, int64_t scratch_bytes, void* stream) {
+  if (!masks_dev || !counts_dev || !offsets_dev || !scratch_dev || n <= 0 || H <= 0 || W <= 0 || capacity <= 0) {
+    esam3_set_error("esam3_rle_encode: bad argument");
+    return -1;
+  }
+  if (scratch_bytes < esam3_rle_scratch_bytes(n, H, W, capacity)) {
+    esam3_set_error("esam3_rle_encode: scratch of %lld bytes, need %lld", (long long)scratch_bytes,
+                    (long long)esam3_rle_scratch_bytes(n, H, W, capacity));
+    return -1;
+  }
+  return esam3_launch_rle_encode(masks_dev, n, H, W, counts_dev, capacity, offsets_dev, scratch_dev, (hipStream_t)stream);
+}
+
+// cocoapi's compressed string form of the counts (maskApi.c rleToString / rleFrString: every count after the third is
+// stored as the difference to the count two places before; 5 payload bits per character with a continuation bit,
+// sign-extended, + 48).  Host code, no device work.  Returns the string length (without a terminator) or -1.
+int64_t esam3_rle_to_string(const uint32_t* counts_host, int64_t n_counts, char* out, int64_t capacity) {
+  if (!counts_host || !out || n_counts < 0) { esam3_set_error("esam3_rle_to_string: bad argument"); return -1; }
+  int64_t p = 0;
+  for (int64_t i = 0; i < n_counts; ++i) {
+    long long x = (long long)counts_host[i];
+    if (i > 2) x -= (long long)counts_host[i - 2];
+    bool more = true;
+    while (more) {
+      char c = (char)(x & 0x1f);
+      x >>= 5;
+      more = (c & 0x10) ? x != -1 : x != 0;
+      if (more) c |= 0x20;
+      c += 48;
+      if (p >= capacity) { esam3_set_error("esam3_rle_to_string: output buffer too small"); return -1; }
+      out[p++] = c;
+    }
+  }
+  return p;
+}
+int64_t esam3_rle_from_string(const char* s, int64_t len, uint32_t* counts_host, int64_t capacity) {
+  if (!s || !counts_host || len < 0) { esam3_set_error("esam3_rle_from_string: bad argument"); return -1; }
+  int64_t m = 0, p = 0;
+  while (p < len) {
+    long long x = 0;
+    int k = 0;
+    bool more = true;
+    while (more) {
+      if (p >= len) { esam3_set_error("esam3_rle_from_string: truncated string"); return -1; }
+      const long long c = (long long)s[p] - 48;
+      x |= (c & 0x1f) << (5 * k);
+      more = (c & 0x20) != 0;
+      ++p; ++k;
+      if (!more && (c & 0x10)) x |= -1LL << (5 * k);
+    }
+    if (m > 2) x += (long long)counts_host[m - 2];
+    if (m >= capacity) { esam3_set_error("esam3_rle_from_string: output buffer too small"); return -1; }
+    counts_host[m++] = (uint32_t)x;
+  }
+  return m;
+}

@@ -77,3 +77,35 @@ def mask_logits(seed: int = 4, size: int = 288) -> np.ndarray:
         r = rng.uniform(0.08 * size, 0.2 * size)
         out = np.maximum(out, 6.0 - 12.0 * np.clip(np.hypot(xx - cx, yy - cy) / (2 * r), 0.0, 1.0))
     return out[None].astype(np.float32)
+
+
+def rle_test_masks() -> dict:
+    """Seeded binary masks for the RLE path: name -> uint8 [N, H, W] (non-zero = foreground; some use 255 / 2 as
+    the foreground value).  Blob masks at the sizes the pipeline produces plus the edge cases: empty, full,
+    checkerboard (the maximum number of runs), single pixels, 1x1, sizes that are no multiple of any tile."""
+    rng = np.random.default_rng(11)
+
+    def blobs(n, h, w, seed):
+        r = np.random.default_rng(seed)
+        ys, xs = np.mgrid[0:h, 0:w].astype(np.float32)
+        out = []
+        for _ in range(n):
+            f = np.zeros((h, w), np.float32)
+            for _ in range(6):
+                fy, fx = r.uniform(0.5, 4.0, 2)
+                f += np.sin(2 * np.pi * (fy * ys / h + r.uniform()) ) * np.cos(2 * np.pi * (fx * xs / w + r.uniform()))
+            out.append(((f > 0.8) * 255).astype(np.uint8))
+        return np.stack(out)
+
+    tiny = np.zeros((7, 5, 7), np.uint8)
+    tiny[1] = 1
+    tiny[2] = (np.add.outer(np.arange(5), np.arange(7)) % 2) * 2
+    tiny[3, 0, 0] = 1
+    tiny[4, -1, -1] = 255
+    tiny[5, :, ::2] = 1
+    tiny[6, ::2, :] = 1
+    one = np.zeros((2, 1, 1), np.uint8)
+    one[1] = 1
+    noise = (rng.random((3, 37, 53)) < np.array([0.5, 0.05, 0.95])[:, None, None]).astype(np.uint8)
+    return {"tiny_5x7": tiny, "single_1x1": one, "noise_37x53": noise, "blobs_600x800": blobs(2, 600, 800, 3),
+            "blobs_1008": blobs(2, 1008, 1008, 4), "checker_64x4097": ((np.add.outer(np.arange(64), np.arange(4097)) % 2)[None]).astype(np.uint8)}

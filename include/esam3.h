@@ -143,6 +143,21 @@ int esam3_preprocess_u8(const uint8_t* img_hwc_u8_dev, float* out_nchw_f32_dev, 
 int esam3_preprocess_resize_u8(const uint8_t* img_hwc_u8_dev, int H, int W, float* out_chw_f32_dev,
                                int out_h, int out_w, void* hip_stream);
 
+/* COCO run-length encoding of binary masks, the mask -> RLE step of the evaluation writers
+ * (scripts/eval/gold/eval_efficientsam3_all_subsets.py:124-135 through pycocotools.mask.encode;
+ * sam3/sam3/train/masks_ops.py:161-230 rle_encode): masks u8 [n][H][W] (non-zero = foreground) -> run lengths in
+ * column-major order (zeros, ones, zeros, ...; the first is 0 when a mask starts with a one) of all masks back to
+ * back in counts_dev [capacity] and offsets_dev [n+1] (mask i owns counts[offsets[i] .. offsets[i+1])).  No hidden
+ * sync: when offsets[n] > capacity the counts are truncated and the caller retries with a larger buffer.
+ * scratch_dev: esam3_rle_scratch_bytes(n, H, W, capacity) bytes. */
+int64_t esam3_rle_scratch_bytes(int n, int H, int W, int64_t capacity);
+int esam3_rle_encode(const uint8_t* masks_dev, int n, int H, int W, uint32_t* counts_dev, int64_t capacity,
+                     int32_t* offsets_dev, void* scratch_dev, int64_t scratch_bytes, void* hip_stream);
+/* cocoapi's compressed "counts" string (maskApi.c rleToString / rleFrString; what pycocotools returns as bytes):
+ * host buffers, returns the number of characters / counts written, -1 on error */
+int64_t esam3_rle_to_string(const uint32_t* counts_host, int64_t n_counts, char* out, int64_t capacity);
+int64_t esam3_rle_from_string(const char* s, int64_t len, uint32_t* counts_host, int64_t capacity);
+
 /* Per-launch timing with HIP events on the launch stream (bench.py roofline leg): enable,
  * run encode/decode, then fetch a JSON report (syncs the device, clears the records). */
 int esam3_profile_enable(esam3_engine* e, int on);
