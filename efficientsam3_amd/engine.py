@@ -35,7 +35,7 @@ def stage_shapes(backbone_type: str, model_name: str):
         return ({"b0": [8, 16, 32, 64, 128], "b1": [16, 32, 64, 128, 256],
                  "b2": [24, 48, 96, 192, 384]}[model_name], [504, 252, 126, 63, 32])
     if backbone_type == "repvit":
-        return ({"m0.9": [48, 96, 192, 384], "m1.1": [64, 128, 256, 512]}[model_name], [252, 126, 63, 32])
+        return ({"m0.9": [48, 96, 192, 384], "m1.1": [64, 128, 256, 512], "m2.3": [80, 160, 320, 640]}[model_name], [252, 126, 63, 32])
     if backbone_type == "tinyvit":
         d = {"5m": [64, 128, 160, 320], "11m": [64, 128, 256, 448], "21m": [96, 192, 384, 576]}[model_name]
         return ([d[0], d[1], d[2], d[3], d[3]], [252, 126, 63, 32, 32])

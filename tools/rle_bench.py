@@ -4,8 +4,12 @@ six-kernel pipeline.  Algorithmic bytes = n*H*W mask bytes in + 4 bytes per run 
     python tools/rle_bench.py            # on an MI355X
 """
 import json
+import os
+import sys
 
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from efficientsam3_amd import _lib, synth
 
