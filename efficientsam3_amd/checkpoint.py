@@ -1,0 +1,105 @@
+"""Checkpoint ingestion: the interchange formats the reference's converters and loader define
+(checkpoints are the interchange format).
+
+* ``extract_state_dict``      — what ``_load_state_dict`` accepts (stage1/convert_*_weights_stage1.py:35-47):
+  a module, ``{"model": ...}``, ``{"state_dict": ...}`` or a plain tensor dict.
+* ``normalize_image_student_key`` / ``normalize_text_student_key`` — the prefix rules of the stage-1 student
+  checkpoints (``module.``, ``student_trunk.``, already-merged prefixes; convert_both_encoders_weights_stage1.py:8-27).
+* ``merge_student_checkpoints`` — convert_both_encoders_weights_stage1.py:106-152 /
+  convert_image_encoder_weights_stage1.py:93-150 / convert_text_encoder_weights_stage1.py: students under
+  ``detector.backbone.vision_backbone.trunk.model.`` / ``detector.backbone.language_backbone.``, the teacher's
+  tensors kept except the two subtrees the students replace.
+* ``clean_checkpoint_keys``  — ``_load_checkpoint`` (sam3/sam3/model_builder.py:584-630): strip ``detector.``,
+  drop the ``student_trunk.`` wrapper, map ``tracker.*`` to ``inst_interactive_predictor.model.*``.
+
+Host-side only (dict manipulation); the tensors then cross the C ABI through ``esam3_load_weight``."""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Optional
+
+import torch
+
+IMAGE_TARGET_PREFIX = "detector.backbone.vision_backbone.trunk.model."
+TEXT_TARGET_PREFIX = "detector.backbone.language_backbone."
+IMAGE_REPLACE_PREFIX = "detector.backbone.vision_backbone.trunk."
+TEXT_REPLACE_PREFIX = "detector.backbone.language_backbone."
+
+
+def _strip(key: str, prefix: str) -> str:
+    return key[len(prefix):] if key.startswith(prefix) else key
+
+
+def extract_state_dict(obj) -> Dict[str, torch.Tensor]:
+    if hasattr(obj, "state_dict"):
+        return obj.state_dict()
+    if isinstance(obj, dict):
+        for key in ("model", "state_dict"):
+            if key in obj and isinstance(obj[key], dict):
+                return obj[key]
+        if all(isinstance(v, torch.Tensor) for v in obj.values()):
+            return obj
+    raise ValueError("Unable to extract a state_dict from the checkpoint object")
+
+
+def load_state_dict_file(path: str) -> Dict[str, torch.Tensor]:
+    with open(path, "rb") as f:
+        return extract_state_dict(torch.load(f, map_location="cpu", weights_only=True))
+
+
+def normalize_image_student_key(key: str) -> str:
+    for p in ("module.", "student_trunk.", "detector.backbone.vision_backbone.trunk.model.",
+              "detector.backbone.vision_backbone.trunk.", "backbone.vision_backbone.trunk.model.",
+              "backbone.vision_backbone.trunk."):
+        key = _strip(key, p)
+    return key
+
+
+def normalize_text_student_key(key: str) -> str:
+    for p in ("module.", "detector.backbone.language_backbone.", "backbone.language_backbone."):
+        key = _strip(key, p)
+    return key
+
+
+def merge_student_checkpoints(teacher_sd: Dict[str, torch.Tensor], image_sd: Optional[Dict[str, torch.Tensor]] = None,
+                              text_sd: Optional[Dict[str, torch.Tensor]] = None,
+                              skip_teacher_prefixes: Iterable[str] = (), text_context_length: Optional[int] = None,
+                              text_pos_embed_table_size: Optional[int] = None) -> dict:
+    """-> {"model": merged[, "meta": {...}]} exactly as the converters save it."""
+    merged: Dict[str, torch.Tensor] = {}
+    replace = []
+    if image_sd is not None:
+        for k, v in image_sd.items():
+            merged[IMAGE_TARGET_PREFIX + normalize_image_student_key(k)] = v
+        replace.append(IMAGE_REPLACE_PREFIX)
+    if text_sd is not None:
+        for k, v in text_sd.items():
+            merged[TEXT_TARGET_PREFIX + normalize_text_student_key(k)] = v
+        replace.append(TEXT_REPLACE_PREFIX)
+    skip = [p.strip(".") + "." for p in skip_teacher_prefixes if p]
+    for k, v in teacher_sd.items():
+        if any(k.startswith(p) for p in replace) or any(k.startswith(p) for p in skip):
+            continue
+        merged[k] = v
+    payload = {"model": merged}
+    if text_context_length is not None or text_pos_embed_table_size is not None:
+        payload["meta"] = {"text_context_length": text_context_length,
+                           "text_pos_embed_table_size": text_pos_embed_table_size}
+    return payload
+
+
+def clean_checkpoint_keys(ckpt: dict, interactive: bool) -> Dict[str, torch.Tensor]:
+    if "model" in ckpt and isinstance(ckpt["model"], dict):
+        ckpt = ckpt["model"]
+    out = {}
+    for k, v in ckpt.items():
+        nk = k
+        if nk.startswith("detector."):
+            nk = nk.replace("detector.", "")
+        if "student_trunk." in nk:
+            nk = nk.replace("student_trunk.", "")
+        out[nk] = v
+    if interactive:
+        for k, v in ckpt.items():
+            if "tracker" in k:
+                out[k.replace("tracker.", "inst_interactive_predictor.model.")] = v
+    return out

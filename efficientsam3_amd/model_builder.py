@@ -21,23 +21,9 @@ SIZE_ALIASES = {
 
 
 def _clean_checkpoint_keys(ckpt: Dict[str, torch.Tensor], interactive: bool) -> Dict[str, torch.Tensor]:
-    """Key remap rules of _load_checkpoint (model_builder.py:584-630): strip ``detector.`` and
-    ``student_trunk.``; ``tracker.*`` -> ``inst_interactive_predictor.model.*``."""
-    if "model" in ckpt and isinstance(ckpt["model"], dict):
-        ckpt = ckpt["model"]
-    out = {}
-    for k, v in ckpt.items():
-        nk = k
-        if nk.startswith("detector."):
-            nk = nk.replace("detector.", "")
-        if "student_trunk." in nk:
-            nk = nk.replace("student_trunk.", "")
-        out[nk] = v
-    if interactive:
-        for k, v in ckpt.items():
-            if "tracker" in k:
-                out[k.replace("tracker.", "inst_interactive_predictor.model.")] = v
-    return out
+    """Key remap rules of _load_checkpoint (model_builder.py:584-630), see checkpoint.clean_checkpoint_keys."""
+    from .checkpoint import clean_checkpoint_keys
+    return clean_checkpoint_keys(ckpt, interactive)
 
 
 def build_efficientsam3_image_model(

@@ -121,3 +121,44 @@ def test_sam3_import_facade():
         for k in [k for k in sys.modules if k == "sam3" or k.startswith("sam3.")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_checkpoint_merge_and_clean_round_trip(tmp_path):
+    """The stage-1 converters' merge format (convert_both_encoders_weights_stage1.py:106-152) followed by the
+    loader's key rules (model_builder.py:584-630) gives back the model's own key names; a checkpoint written that
+    way loads through ``checkpoint_path`` parsing."""
+    from efficientsam3_amd import checkpoint as ck
+    full = schema.synthetic_state_dict("efficientvit", "b0", seed=0, enable_inst_interactivity=True)
+    full.update(schema.synthetic_text_state_dict("MobileCLIP-S0", 16, seed=0))
+    img_p, txt_p = "backbone.vision_backbone.trunk.model.", "backbone.language_backbone."
+    image_sd = {"module.student_trunk." + k[len(img_p):]: v for k, v in full.items() if k.startswith(img_p)}
+    text_sd = {"module." + k[len(txt_p):]: v for k, v in full.items() if k.startswith(txt_p)}
+    assert image_sd and text_sd
+    inter_p = "inst_interactive_predictor.model."
+    teacher = {}
+    for k, v in full.items():
+        if k.startswith(inter_p):
+            teacher["tracker." + k[len(inter_p):]] = v
+        elif k.startswith(img_p) or k.startswith(txt_p):
+            continue
+        else:
+            teacher["detector." + k] = v
+    teacher["detector.backbone.vision_backbone.trunk.blocks.0.attn.qkv.weight"] = torch.zeros(1)   # ViT-H: replaced
+    teacher["detector.backbone.language_backbone.encoder.transformer.resblocks.0.ln_1.weight"] = torch.zeros(1)
+    payload = ck.merge_student_checkpoints(teacher, image_sd, text_sd, text_context_length=16)
+    assert payload["meta"]["text_context_length"] == 16
+    assert not any("blocks.0.attn.qkv" in k or "resblocks" in k for k in payload["model"])
+    assert all(k.startswith(("detector.", "tracker.")) for k in payload["model"])
+    path = tmp_path / "merged.pth"
+    torch.save(payload, path)
+    sd = ck.clean_checkpoint_keys({"model": ck.load_state_dict_file(str(path))}, interactive=True)
+    missing = [k for k in full if k not in sd]
+    assert not missing, missing[:5]
+    assert all(torch.equal(sd[k], full[k]) for k in full)
+    # the single-encoder converters: only one subtree replaced
+    only_img = ck.merge_student_checkpoints(teacher, image_sd=image_sd)["model"]
+    assert "detector.backbone.language_backbone.encoder.transformer.resblocks.0.ln_1.weight" in only_img
+    assert ck.normalize_image_student_key("detector.backbone.vision_backbone.trunk.model.backbone.x") == "backbone.x"
+    assert ck.extract_state_dict({"state_dict": {"a": torch.zeros(1)}}).keys() == {"a"}
+    with pytest.raises(ValueError):
+        ck.extract_state_dict({"a": 1})
