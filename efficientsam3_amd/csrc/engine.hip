@@ -539,6 +539,7 @@ struct esam3_engine {
   int precompute_pe();
   // ---- PCS text-grounding detector -------------------------------------------------------------
   bool pcs_ready = false;
+  bool text_causal = false;  // MobileCLIP-B masks its text self-attention causally (esam3_set_text_causal)
   PackedGemm* pk_rows(const std::string& wname, const std::string& bname, int row0, int nrows, const std::string& key,
                       int zero_from = -1);
   void* pcs_pos_table(const std::string& key, PackedGemm* g);
@@ -1261,10 +1262,15 @@ int E::encode_text(const int64_t* tokens, int B, int S, float* memory_sbd, float
   const int D = (int)tab->shape[1], vocab = (int)tab->shape[0];
   const int pos_len = (int)pos->shape[2];
   if (S > pos_len) { esam3_set_error("encode_text: sequence length %d exceeds the positional table (%d)", S, pos_len); return -1; }
+  // "mct" (MobileCLIP-S0): transformer.0 and transformer.N+1 are RepMixer blocks around N encoder layers;
+  // "base" (the other students, model_builder.py:525-546): transformer.0 .. N-1 are all encoder layers
+  const bool mct = !find(e + "transformer.0.pre_norm_mha.0.weight");
+  const int first = mct ? 1 : 0;
   int n_layers = 0;
-  while (find(e + "transformer." + std::to_string(n_layers + 1) + ".pre_norm_mha.0.weight")) ++n_layers;
-  const HostTensor* qw = need(e + "transformer.1.pre_norm_mha.1.qkv_proj.weight");
+  while (find(e + "transformer." + std::to_string(n_layers + first) + ".pre_norm_mha.0.weight")) ++n_layers;
+  const HostTensor* qw = need(e + "transformer." + std::to_string(first) + ".pre_norm_mha.1.qkv_proj.weight");
   if (!qw || n_layers == 0) { esam3_set_error("encode_text: no transformer layers in the state dict"); return -1; }
+  if (D % 64) { esam3_set_error("encode_text: model dim %d is not a multiple of the 64-wide heads", D); return -1; }
   const int heads = D / 64;
   float *dtab = fvec(e + "embedding_layer.weight"), *dpos = fvec(e + "positional_embedding.pos_embed.pos_embed");
   if (!dtab || !dpos) return -1;
@@ -1278,19 +1284,25 @@ int E::encode_text(const int64_t* tokens, int B, int S, float* memory_sbd, float
   if (!ok(x) || !ok(y) || !ok(ln) || !ok(qkv) || !ok(att) || !ok(hid)) return -1;
   if (!dry)
     CK(prof_launch("text_embed", 0.0, 0.0, [&]() { return esam3_launch_text_embed(dtype, tokens, dtab, dpos, x, embeds_sbd, B, S, D, vocab, st); }));
-  CK(text_repmixer(e + "transformer.0.", x, B, S, D, y));
-  std::swap(x, y);
-  for (int i = 1; i <= n_layers; ++i) {
+  if (mct) {
+    CK(text_repmixer(e + "transformer.0.", x, B, S, D, y));
+    std::swap(x, y);
+  }
+  for (int i = first; i < n_layers + first; ++i) {
     const std::string q = e + "transformer." + std::to_string(i) + ".";
     CK(layernorm(q + "pre_norm_mha.0", x, ln, rows, D, 1e-5f));
     CK(linear(q + "pre_norm_mha.1.qkv_proj", ln, D, rows, qkv, 3 * D, ACT_NONE));
-    if (!dry) CK(prof_launch("text_attn", 0.0, 0.0, [&]() { return esam3_launch_text_attn(dtype, qkv, att, B, S, heads, 64, st); }));
+    if (!dry) CK(prof_launch("text_attn", 0.0, 0.0, [&]() { return esam3_launch_text_attn(dtype, qkv, att, B, S, heads, 64, text_causal ? 1 : 0, st); }));
     CK(linear(q + "pre_norm_mha.1.out_proj", att, D, rows, y, D, ACT_NONE, x, D));
     CK(layernorm(q + "pre_norm_ffn.0", y, ln, rows, D, 1e-5f));
     CK(linear(q + "pre_norm_ffn.1", ln, D, rows, hid, 4 * D, ACT_GELU));
     CK(linear(q + "pre_norm_ffn.4", hid, 4 * D, rows, x, D, ACT_NONE, y, D));
   }
-  CK(text_repmixer(e + "transformer." + std::to_string(n_layers + 1) + ".", x, B, S, D, y));
+  if (mct) {
+    CK(text_repmixer(e + "transformer." + std::to_string(n_layers + 1) + ".", x, B, S, D, y));
+  } else {
+    std::swap(x, y);
+  }
   CK(layernorm(e + "final_layer_norm", y, ln, rows, D, 1e-5f));
   PackedGemm* gp = pk_linear(TEXTP + "projector");
   if (!gp) return -1;
@@ -2215,6 +2227,12 @@ int esam3_profile_enable(esam3_engine* e, int on) {
   for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
   e->recs.clear();
   e->prof = on != 0;
+  return 0;
+}
+
+int esam3_set_text_causal(esam3_engine* e, int causal_masking) {
+  if (!e) { esam3_set_error("esam3_set_text_causal: null engine"); return -1; }
+  e->text_causal = causal_masking != 0;
   return 0;
 }
 

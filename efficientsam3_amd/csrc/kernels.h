@@ -71,7 +71,7 @@ int esam3_launch_text_embed(int dtype, const int64_t* tokens, const float* table
 int esam3_launch_seq_dwconv(int dtype, const void* x, const float* w /*[KW][D]*/, const float* bias, void* out, int B,
                             int S, int D, int KW, hipStream_t s);
 int esam3_launch_text_attn(int dtype, const void* qkv /*[B*S][3*heads*hd]*/, void* out, int B, int S, int heads, int hd,
-                           hipStream_t s);
+                           int causal, hipStream_t s);
 int esam3_launch_bsc_to_sbc_f32(int dtype, const void* x, float* out, int B, int S, int C, hipStream_t s);
 // w = {conv0.w, conv0.b, ln1.w, ln1.b, conv3.w, conv3.b, ln4.w, ln4.b, conv6.w, conv6.b} (device fp32)
 int esam3_launch_mask_embed(int dtype, const float* mask, const float* const* w, void* out, int Bp, int in_size,

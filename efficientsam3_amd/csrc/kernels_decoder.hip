@@ -231,10 +231,12 @@ __global__ void seq_dwconv_kernel(const T* __restrict__ x, const float* __restri
 }
 
 // MultiHeadAttention (mobile_clip.py:354-425): qkv rows [3][heads][64]; softmax in fp32 over all
-// S keys (no padding mask is passed by the student encoder).  One wavefront per (b, head, query):
-// lane = channel of the 64-wide head.
+// S keys (no padding mask is passed by the student encoder), or over keys <= query when the model masks
+// causally (MobileCLIP-B, mobile_clip.py:826-832).  One wavefront per (b, head, query): lane = channel of the
+// 64-wide head.
 template <typename T>
-__global__ __launch_bounds__(64) void text_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int S, int heads) {
+__global__ __launch_bounds__(64) void text_attn_kernel(const T* __restrict__ qkv, T* __restrict__ out, int S, int heads,
+                                                       int causal) {
   const int i = blockIdx.x % S;
   const int h = (blockIdx.x / S) % heads;
   const int64_t b = blockIdx.x / (S * heads);
@@ -242,7 +244,8 @@ __global__ __launch_bounds__(64) void text_attn_kernel(const T* __restrict__ qkv
   const T* base = qkv + b * S * 3 * (int64_t)D;
   const float q = to_f32<T>(base[(int64_t)i * 3 * D + h * 64 + lane]) * 0.125f;  // 64^-0.5
   float m = -INFINITY, l = 0.f, acc = 0.f;
-  for (int j = 0; j < S; ++j) {
+  const int jn = causal ? i + 1 : S;
+  for (int j = 0; j < jn; ++j) {
     float sc = q * to_f32<T>(base[(int64_t)j * 3 * D + D + h * 64 + lane]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sc += __shfl_xor(sc, o, 64);
@@ -687,10 +690,10 @@ int esam3_launch_seq_dwconv(int dtype, const void* x, const float* w, const floa
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
-int esam3_launch_text_attn(int dtype, const void* qkv, void* out, int B, int S, int heads, int hd, hipStream_t s) {
+int esam3_launch_text_attn(int dtype, const void* qkv, void* out, int B, int S, int heads, int hd, int causal, hipStream_t s) {
   if (hd != 64) { esam3_set_error("text_attn: head dim %d unsupported", hd); return -1; }
   DISPATCH_T(dtype, hipLaunchKernelGGL(text_attn_kernel<T>, dim3((unsigned)(B * heads * S)), dim3(64), 0, s, (const T*)qkv,
-                                       (T*)out, S, heads));
+                                       (T*)out, S, heads, causal));
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -163,12 +163,16 @@ class HipEngine:
         return out
 
     # ---- text encoder ------------------------------------------------------------------------
-    def encode_text(self, tokens: torch.Tensor):
-        """tokens int64 [B,S] -> (memory fp32 [S,B,256], embeds fp32 [S,B,512]) on this device."""
+    def set_text_causal(self, causal: bool) -> None:
+        """cfg["causal_masking"] of the text student (only MobileCLIP-B, model_builder.py:532-539)."""
+        _lib.check(self.lib.esam3_set_text_causal(self.handle, 1 if causal else 0), "esam3_set_text_causal")
+
+    def encode_text(self, tokens: torch.Tensor, dim: int = 512):
+        """tokens int64 [B,S] -> (memory fp32 [S,B,256], embeds fp32 [S,B,dim]) on this device."""
         tokens = tokens.to(self.device, torch.int64).contiguous()
         b, s = tokens.shape
         mem = torch.empty((s, b, 256), dtype=torch.float32, device=self.device)
-        emb = torch.empty((s, b, 512), dtype=torch.float32, device=self.device)
+        emb = torch.empty((s, b, dim), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.dev_index):
             _lib.check(self.lib.esam3_encode_text(self.handle, _ptr(tokens), b, s, _ptr(mem), _ptr(emb), _stream()),
                        "esam3_encode_text")

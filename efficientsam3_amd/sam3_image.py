@@ -70,8 +70,9 @@ class _VisionBackbone:
 
 class _TextStudentEncoder:
     """Stand-in for TextStudentEncoder (text_encoder_student.py:9-58): tokenizer on the host, the
-    MobileCLIP-S0 transformer on the HIP engine.  ``__call__(text, input_boxes, device)`` ->
-    (mask [B,S] bool True = padding, memory [S,B,256], embeds [S,B,512])."""
+    MobileCLIP student transformer (S0 "mct", or the 12-layer "base" students) on the HIP engine.
+    ``__call__(text, input_boxes, device)`` -> (mask [B,S] bool True = padding, memory [S,B,256],
+    embeds [S,B,dim])."""
 
     def __init__(self, owner: "Sam3Image", context_length: int, bpe_path=None):
         self._o = owner
@@ -91,7 +92,7 @@ class _TextStudentEncoder:
         self.context_length = context_length
 
     def encode_tokens(self, tokenized: torch.Tensor):
-        mem, emb = self._o.engine.encode_text(tokenized)
+        mem, emb = self._o.engine.encode_text(tokenized, dim=schema.TEXT_ENCODER_CFG[self._o.text_encoder_type][0])
         return (tokenized.to(mem.device) == 0), mem, emb
 
     def __call__(self, text, input_boxes=None, device=None):
@@ -157,7 +158,9 @@ class Sam3Image:
         self.text_encoder_type = text_encoder_type
         if text_encoder_type is not None:
             if text_encoder_type not in schema.TEXT_ENCODER_CFG:
-                raise NotImplementedError(f"text_encoder_type={text_encoder_type!r}: only MobileCLIP-S0 is built")
+                raise NotImplementedError(f"text_encoder_type={text_encoder_type!r}: known students are "
+                                          f"{sorted(schema.TEXT_ENCODER_CFG)}")
+            self.engine.set_text_causal(schema.TEXT_ENCODER_CFG[text_encoder_type][4])
             self.backbone.language_backbone = _TextStudentEncoder(self, text_encoder_context_length, bpe_path)
             self._schema.update(schema.pcs_schema())  # the grounding detector the text prompts feed
         self._sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()

@@ -351,8 +351,15 @@ def sam_heads_schema() -> _Schema:
 
 TEXT = "backbone.language_backbone."
 TEXT_ENCODER_CFG = {
-    # name: (dim, n_transformer_layers, heads, variant)   model_builder.py:499-560
-    "MobileCLIP-S0": (512, 4, 8, "mct"),
+    # name: (dim, n_transformer_layers, heads, variant, causal_masking)   model_builder.py:499-560
+    "MobileCLIP-S0": (512, 4, 8, "mct", False),
+    "MobileCLIP-S1": (512, 12, 8, "base", False),
+    "MobileCLIP2-S0": (512, 12, 8, "base", False),
+    "MobileCLIP2-S2": (512, 12, 8, "base", False),
+    "MobileCLIP-B": (512, 12, 8, "base", True),
+    "MobileCLIP2-S3": (768, 12, 12, "base", False),
+    "MobileCLIP2-S4": (768, 12, 12, "base", False),
+    "MobileCLIP2-L": (768, 12, 12, "base", False),
 }
 
 
@@ -362,9 +369,8 @@ def text_encoder_schema(kind: str = "MobileCLIP-S0", context_length: int = 16) -
     TransformerEncoder, RepMixerBlock ("mct" variant), final LayerNorm, projector 512 -> 256.
     ``context_length`` is the length of the positional table in the state dict (the reference
     builds at 77 and truncates to the requested length after loading, model_builder.py:1035-1047)."""
-    dim, n_layers, heads, variant = TEXT_ENCODER_CFG[kind]
-    if variant != "mct":
-        raise NotImplementedError(variant)
+    dim, n_layers, heads, variant, _causal = TEXT_ENCODER_CFG[kind]
+    first = 1 if variant == "mct" else 0   # "base": transformer.0 .. transformer.N-1 are all TransformerEncoder layers
     s = _Schema()
     e = TEXT + "encoder."
     s[e + "projection_layer"] = ((dim, dim), "embed")  # present in the reference, unused by this path
@@ -386,8 +392,9 @@ def text_encoder_schema(kind: str = "MobileCLIP-S0", context_length: int = 16) -
         s.conv(q + "convffn.fc1", 4 * dim, dim, 1, bias=True)
         s.conv(q + "convffn.fc2", dim, 4 * dim, 1, bias=True)
 
-    repmixer(e + "transformer.0.")
-    for i in range(1, n_layers + 1):
+    if variant == "mct":
+        repmixer(e + "transformer.0.")
+    for i in range(first, n_layers + first):
         q = e + f"transformer.{i}."
         s.ln(q + "pre_norm_mha.0", dim)
         s.linear(q + "pre_norm_mha.1.qkv_proj", 3 * dim, dim)
@@ -397,7 +404,8 @@ def text_encoder_schema(kind: str = "MobileCLIP-S0", context_length: int = 16) -
         s.linear(q + "pre_norm_ffn.1", 4 * dim, dim)
         s[q + "pre_norm_ffn.4.weight"] = ((dim, 4 * dim), "linear_res")
         s[q + "pre_norm_ffn.4.bias"] = ((dim,), "bias")
-    repmixer(e + f"transformer.{n_layers + 1}.")
+    if variant == "mct":
+        repmixer(e + f"transformer.{n_layers + 1}.")
     s.ln(e + "final_layer_norm", dim)
     s.linear(TEXT + "projector", D_MODEL, dim)
     return s

@@ -92,10 +92,15 @@ int esam3_decode(esam3_engine* e, const esam3_prompts* prompts, const esam3_deco
                  void* hip_stream);
 /* TextStudentEncoder.forward after tokenisation (text_encoder_student.py:40-58; MobileCLIP-S0 weights
  * under "backbone.language_backbone."): tokens int64 [B][S] (device) ->
- * memory fp32 [S][B][256] (language_features), embeds fp32 [S][B][512] (language_embeds, may be NULL).
+ * memory fp32 [S][B][256] (language_features), embeds fp32 [S][B][dim] (language_embeds, dim = 512 or 768,
+ * may be NULL).
  * The padding mask is tokens == 0 and stays on the host side. */
 int esam3_encode_text(esam3_engine* e, const int64_t* tokens_dev, int B, int S, float* memory_sbd_dev,
                       float* embeds_sbd_dev, void* hip_stream);
+/* cfg["causal_masking"] of the text student (model_builder.py:532-539: only MobileCLIP-B sets it): the text
+ * self-attention then sees keys <= query (mobile_clip.py:826-846).  The variant ("mct" with RepMixer blocks or
+ * "base"), depth and width are read from the state dict. */
+int esam3_set_text_causal(esam3_engine* e, int causal_masking);
 /* PCS grounding detector: Sam3Image.forward_grounding (sam3_image.py:442-493) for one text prompt per image plus
  * an optional geometric prompt (points / boxes; none = the dummy prompt), i.e. what Sam3Processor.set_text_prompt,
  * add_geometric_prompt and add_point_prompt run (sam3_image_processor.py:115-190,219-226; geometry encoder

@@ -798,7 +798,7 @@ def _repmixer_block(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     return x.squeeze(2).permute(0, 2, 1)
 
 
-def _text_transformer_layer(sd: SD, p: str, x: torch.Tensor, heads: int) -> torch.Tensor:
+def _text_transformer_layer(sd: SD, p: str, x: torch.Tensor, heads: int, causal: bool = False) -> torch.Tensor:
     """TransformerEncoder.forward (mobile_clip.py:427-491): pre-norm MHA over ALL positions (the
     student passes no key-padding mask, text_encoder_student.py:48-50; S0 is non-causal) and
     pre-norm FFN."""
@@ -808,7 +808,10 @@ def _text_transformer_layer(sd: SD, p: str, x: torch.Tensor, heads: int) -> torc
     qkv = F.linear(y, sd[a + "qkv_proj.weight"], sd[a + "qkv_proj.bias"]).reshape(b, s_len, 3, heads, -1)
     qkv = qkv.transpose(1, 3).contiguous()  # [B, heads, 3, S, hd]
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-    attn = torch.matmul(q * (q.shape[-1] ** -0.5), k.transpose(-1, -2)).float().softmax(-1)
+    attn = torch.matmul(q * (q.shape[-1] ** -0.5), k.transpose(-1, -2))
+    if causal:  # build_attention_mask (mobile_clip.py:826-832): -inf above the diagonal
+        attn = attn + torch.full((s_len, s_len), float("-inf")).triu_(1)
+    attn = attn.float().softmax(-1)
     o = torch.matmul(attn, v).transpose(1, 2).reshape(b, s_len, -1)
     x = F.linear(o, sd[a + "out_proj.weight"], sd[a + "out_proj.bias"]) + x
     y = F.layer_norm(x, (d,), sd[p + "pre_norm_ffn.0.weight"], sd[p + "pre_norm_ffn.0.bias"], 1e-5)
@@ -816,18 +819,26 @@ def _text_transformer_layer(sd: SD, p: str, x: torch.Tensor, heads: int) -> torc
     return x + F.linear(y, sd[p + "pre_norm_ffn.4.weight"], sd[p + "pre_norm_ffn.4.bias"])
 
 
-def text_encoder_student(sd: SD, tokens: torch.Tensor, n_layers: int = 4, heads: int = 8):
+def text_encoder_student(sd: SD, tokens: torch.Tensor, n_layers: int = 4, heads: int = 8, variant: str = "mct",
+                         causal: bool = False):
     """TextStudentEncoder.forward after tokenisation (text_encoder_student.py:40-58):
-    tokens int64 [B, S] -> (mask [B,S] True = padding, memory [S,B,256], embeds [S,B,512]).
-    embed_scale is computed by the reference but never applied (mobile_clip.py:743,815-823)."""
+    tokens int64 [B, S] -> (mask [B,S] True = padding, memory [S,B,256], embeds [S,B,dim]).
+    embed_scale is computed by the reference but never applied (mobile_clip.py:743,815-823).
+    variant "mct" (MobileCLIP-S0): RepMixerBlock, n_layers x TransformerEncoder, RepMixerBlock; "base" (the
+    other students, model_builder.py:525-546): n_layers x TransformerEncoder, causal for MobileCLIP-B."""
     e = TEXT + "encoder."
     s_len = tokens.shape[1]
     emb = F.embedding(tokens, sd[e + "embedding_layer.weight"])
     emb = emb + sd[e + "positional_embedding.pos_embed.pos_embed"][0, 0, :s_len][None]
-    x = _repmixer_block(sd, e + "transformer.0.", emb)
-    for i in range(1, n_layers + 1):
-        x = _text_transformer_layer(sd, e + f"transformer.{i}.", x, heads)
-    x = _repmixer_block(sd, e + f"transformer.{n_layers + 1}.", x)
+    if variant == "mct":
+        x = _repmixer_block(sd, e + "transformer.0.", emb)
+        for i in range(1, n_layers + 1):
+            x = _text_transformer_layer(sd, e + f"transformer.{i}.", x, heads, causal)
+        x = _repmixer_block(sd, e + f"transformer.{n_layers + 1}.", x)
+    else:
+        x = emb
+        for i in range(n_layers):
+            x = _text_transformer_layer(sd, e + f"transformer.{i}.", x, heads, causal)
     d = x.shape[-1]
     x = F.layer_norm(x, (d,), sd[e + "final_layer_norm.weight"], sd[e + "final_layer_norm.bias"], 1e-5)
     mem = F.linear(x, sd[TEXT + "projector.weight"], sd[TEXT + "projector.bias"])

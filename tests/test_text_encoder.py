@@ -99,3 +99,61 @@ def test_text_encoder_engine_vs_golden(text_gold, text_sd, mode):
         lb._bpe_path = bpe
         out = model.backbone.forward_text(man["prompts"][:4])
         assert tuple(out["language_features"].shape) == (16, 4, 256)
+
+
+# ---- the 12-layer "base" students (MobileCLIP-S1 / -B / MobileCLIP2-*; model_builder.py:525-546) ----
+VARIANTS = ["MobileCLIP-S1", "MobileCLIP-B", "MobileCLIP2-L"]
+
+
+@pytest.fixture(scope="module")
+def variants_gold(golden_dir):
+    d = os.path.join(golden_dir, "text_variants")
+    with open(os.path.join(d, "manifest.json")) as f:
+        man = json.load(f)
+    return man, np.load(os.path.join(d, "text_variants.npz"))
+
+
+def test_text_variants_oracle_reproduces_golden(variants_gold):
+    from oracle import ref_model
+    man, g = variants_gold
+    assert man["kinds"] == VARIANTS
+    ids = torch.from_numpy(g["ids"])
+    for kind in VARIANTS:
+        assert man["cases"][kind]["oracle_vs_reference_maxabs"]["memory"] <= 1e-5
+        dim, n_layers, heads, variant, causal = schema.TEXT_ENCODER_CFG[kind]
+        sd = schema.synthetic_text_state_dict(kind, man["context_length"], seed=0)
+        with torch.inference_mode():
+            _, mem, emb = ref_model.text_encoder_student(sd, ids, n_layers, heads, variant, causal)
+        assert tuple(emb.shape) == (16, ids.shape[0], dim)
+        assert float(np.abs(mem.numpy() - g[kind + "_memory"]).max()) <= 1e-5
+        assert float(np.abs(emb.numpy()[:, :, ::8] - g[kind + "_embeds_sample"]).max()) <= 1e-6
+    # same seeded weights, only the causal mask differs: the fixtures must tell the two apart
+    assert float(np.abs(g["MobileCLIP-S1_memory"] - g["MobileCLIP-B_memory"]).max()) > 0.05
+    # the aliases share their configuration
+    assert schema.TEXT_ENCODER_CFG["MobileCLIP2-S0"] == schema.TEXT_ENCODER_CFG["MobileCLIP-S1"]
+    assert schema.TEXT_ENCODER_CFG["MobileCLIP2-S4"] == schema.TEXT_ENCODER_CFG["MobileCLIP2-L"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", VARIANTS)
+def test_text_variants_engine_vs_golden(variants_gold, kind):
+    """esam3_encode_text on the "base" students (12 encoder layers, no RepMixer blocks; width 512 or 768; causal
+    self-attention for MobileCLIP-B) vs the reference's outputs.  Tolerances as for MobileCLIP-S0."""
+    from efficientsam3_amd import build_efficientsam3_image_model
+    man, g = variants_gold
+    ids = torch.from_numpy(g["ids"])
+    dim = schema.TEXT_ENCODER_CFG[kind][0]
+    for mode, tol in (("f32", 1e-3), ("bf16", 0.15)):
+        sd = schema.synthetic_state_dict("efficientvit", "b0", seed=0, enable_inst_interactivity=False)
+        sd.update(schema.synthetic_text_state_dict(kind, man["context_length"], seed=0))
+        model = build_efficientsam3_image_model(device="cuda", enable_inst_interactivity=False, backbone_type="efficientvit",
+                                                model_name="b0", dtype=mode, state_dict=sd, text_encoder_type=kind,
+                                                text_encoder_context_length=man["context_length"])
+        mask, mem, emb = model.backbone.language_backbone.encode_tokens(ids)
+        assert tuple(mem.shape) == g[kind + "_memory"].shape and tuple(emb.shape) == (16, ids.shape[0], dim)
+        assert np.array_equal(mask.cpu().numpy(), g["ids"] == 0)
+        assert float(np.abs(emb.cpu().numpy()[:, :, ::8] - g[kind + "_embeds_sample"]).max()) <= 1e-6
+        err = float(np.abs(mem.cpu().numpy() - g[kind + "_memory"]).max())
+        print(f"[{kind} {mode}] language_features max-abs-err {err:.3e}")
+        assert err <= tol, (kind, mode, err)
+        del model
