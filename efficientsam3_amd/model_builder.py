@@ -76,6 +76,7 @@ def build_efficientsam3_image_model(
         if text_encoder_type is not None:
             state_dict.update(schema.synthetic_text_state_dict(text_encoder_type, text_encoder_context_length,
                                                                seed=synthetic_seed))
+            state_dict.update(schema.synthetic_pcs_state_dict(seed=synthetic_seed))
     model.load_state_dict(state_dict, strict=False)
     return model
 
@@ -121,5 +122,6 @@ def build_sam3_image_model(
         if text_encoder_type is not None:
             state_dict.update(schema.synthetic_text_state_dict(text_encoder_type, text_encoder_context_length,
                                                                seed=synthetic_seed))
+            state_dict.update(schema.synthetic_pcs_state_dict(seed=synthetic_seed))
     model.load_state_dict(state_dict, strict=False)
     return model

@@ -196,6 +196,14 @@ class Sam3Image:
             pk = schema.TEXT + "encoder.positional_embedding.pos_embed.pos_embed"
             rows = int(sd[pk].shape[2]) if pk in sd else self.backbone.language_backbone.context_length
             self._schema.update(schema.text_encoder_schema(self.text_encoder_type, rows))
+        if self.text_encoder_type is not None:
+            # a checkpoint may carry the text student without the grounding detector (stage-1 text checkpoints):
+            # the text path still works, forward_grounding then fails loudly
+            pcs_keys = [k for k in schema.pcs_schema() if k in self._schema]
+            self._has_detector = all(k in sd for k in pcs_keys)
+            if not self._has_detector:
+                for k in pcs_keys:
+                    del self._schema[k]
         missing = [k for k, (shape, kind) in self._schema.items() if k not in sd and kind != "bn_n"]
         unexpected = [k for k in sd if k not in self._schema]
         if strict and (missing or unexpected):
@@ -393,6 +401,9 @@ class Sam3Image:
         broadcast to every image) and the geometric prompt (a ``geometry_prompt.Prompt``; empty = dummy)."""
         if self.text_encoder_type is None:
             raise NotImplementedError("model was built without text_encoder_type='MobileCLIP-S0'")
+        if not getattr(self, "_has_detector", False):
+            raise RuntimeError("the loaded state dict has no grounding-detector weights (geometry_encoder.*, "
+                               "transformer.*, segmentation_head.*, dot_prod_scoring.*)")
         if "language_features" not in backbone_out:
             raise ValueError("forward_text has not been run for this state")
         fpn = backbone_out.get("_esam3_nhwc_sam3")

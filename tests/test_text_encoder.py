@@ -81,6 +81,8 @@ def test_text_encoder_engine_vs_golden(text_gold, text_sd, mode):
                                             model_name="b0", dtype=mode, state_dict=sd, text_encoder_type="MobileCLIP-S0",
                                             text_encoder_context_length=man["context_length"])
     lb = model.backbone.language_backbone
+    with pytest.raises(RuntimeError, match="grounding-detector"):   # this state dict has no detector weights
+        model.forward_grounding({"language_features": None})
     ids = torch.from_numpy(g["ids_ctx16"])
     mask, mem, emb = lb.encode_tokens(ids)
     assert tuple(mem.shape) == g["memory"].shape and tuple(emb.shape) == g["embeds"].shape
