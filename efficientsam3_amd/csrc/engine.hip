@@ -120,7 +120,7 @@ struct esam3_engine {
 
   struct ProfRec { std::string tag; hipEvent_t a, b; double flops, bytes; const char* kernel; };
   std::vector<ProfRec> recs;
-  // bench.py's live roofline leg: the GEMM launches whose tag equals `watch_tag` (esam3_profile_tag)
+  // bench.py's live roofline leg: the launches whose tag equals `watch_tag` (esam3_profile_tag)
   // are bracketed by HIP events on the launch stream while everything else runs un-instrumented.
   std::string watch_tag;  // empty: nothing watched
   int timed_gemm(const std::string& tag, double flops, double bytes, const GemmParams& p, hipStream_t s) {
@@ -139,7 +139,7 @@ struct esam3_engine {
   // ---------------- optional per-launch profiler (HIP events on the launch stream) --------
   bool prof = false;
   int prof_launch(const std::string& tag, double flops, double bytes, const std::function<int()>& fn) {
-    if (!prof) return fn();
+    if (!prof && (watch_tag.empty() || tag != watch_tag)) return fn();  // watched tag: timed like a watched GEMM
     ProfRec r{tag, nullptr, nullptr, flops, bytes, nullptr};
     esam3_take_last_gemm_kernel();
     HIP_CHECK_RET(hipEventCreate(&r.a));

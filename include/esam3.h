@@ -167,7 +167,7 @@ int64_t esam3_rle_from_string(const char* s, int64_t len, uint32_t* counts_host,
  * run encode/decode, then fetch a JSON report (syncs the device, clears the records). */
 int esam3_profile_enable(esam3_engine* e, int on);
 int esam3_profile_report(esam3_engine* e, char* json_buf, int64_t buf_size);
-/* Time only the GEMM launches whose tag (= weight name, as listed by esam3_profile_report) equals
+/* Time only the launches whose tag (= weight name or kernel tag, as listed by esam3_profile_report) equals
  * `tag`, with HIP events on the launch stream; every other launch runs un-instrumented (bench.py's
  * live roofline leg).  NULL or "" stops watching.  Clears the collected records. */
 int esam3_profile_tag(esam3_engine* e, const char* tag);
