@@ -1,0 +1,145 @@
+// Stage-1 distillation loss, forward (stage1/train_image_encoder_stage1.py:271-307): masked MSE and
+// masked cosine loss between the student embedding and the teacher embedding, both [B][HW][C] token-major (NHWC).
+// HBM-bound: each embedding is read exactly once; fixed-order reductions (no atomics).
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/esam3.h"
+#include "esam3_common.h"
+#include "kernels.h"
+
+namespace {
+
+template <int DT> struct Elem;  // 0 f32, 1 bf16, 2 f16
+template <> struct Elem<0> {
+  using type = float;
+  static __device__ inline void load8(const float* p, float* v) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+};
+template <> struct Elem<1> {
+  using type = uint16_t;
+  static __device__ inline void load8(const uint16_t* p, float* v) {
+    const uint4 q = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+};
+template <> struct Elem<2> {
+  using type = __half;
+  static __device__ inline void load8(const __half* p, float* v) {
+    const uint4 q = *reinterpret_cast<const uint4*>(p);
+    const __half2* h = reinterpret_cast<const __half2*>(&q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float2 f = __half22float2(h[i]);
+      v[2 * i] = f.x;
+      v[2 * i + 1] = f.y;
+    }
+  }
+};
+
+// one wavefront per pixel: sum_c (p - t)^2 and 1 - cos(p, t) (F.cosine_similarity: each norm clamped at 1e-8)
+template <int DP, int DTT>
+__global__ __launch_bounds__(256) void distill_pixel_kernel(const typename Elem<DP>::type* __restrict__ preds,
+                                                            const typename Elem<DTT>::type* __restrict__ teacher,
+                                                            float* __restrict__ px, int64_t n_pix, int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= n_pix) return;
+  const auto* p = preds + pix * C;
+  const auto* t = teacher + pix * C;
+  float sq = 0.f, dot = 0.f, np_ = 0.f, nt = 0.f;
+  for (int c0 = lane * 8; c0 < C; c0 += 512) {
+    float a[8], b[8];
+    Elem<DP>::load8(p + c0, a);
+    Elem<DTT>::load8(t + c0, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float d = a[e] - b[e];
+      sq = fmaf(d, d, sq);
+      dot = fmaf(a[e], b[e], dot);
+      np_ = fmaf(a[e], a[e], np_);
+      nt = fmaf(b[e], b[e], nt);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sq += __shfl_xor(sq, o, 64);
+    dot += __shfl_xor(dot, o, 64);
+    np_ += __shfl_xor(np_, o, 64);
+    nt += __shfl_xor(nt, o, 64);
+  }
+  if (lane == 0) {
+    px[pix * 2] = sq;
+    px[pix * 2 + 1] = 1.f - dot / (fmaxf(sqrtf(np_), 1e-8f) * fmaxf(sqrtf(nt), 1e-8f));
+  }
+}
+
+// per image: masked sums over its HW pixels in a fixed order -> out[b] = {mse_b, cos_b} (each divided by
+// max(#valid, 1), masked_mse / masked_cosine_loss before their batch mean)
+__global__ __launch_bounds__(256) void distill_reduce_kernel(const float* __restrict__ px, const uint8_t* __restrict__ valid,
+                                                             int HW, float* __restrict__ out) {
+  __shared__ float s0[256], s1[256], s2[256];
+  const int b = blockIdx.x;
+  float a0 = 0.f, a1 = 0.f, n = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    if (valid[(int64_t)b * HW + i]) {
+      a0 += px[((int64_t)b * HW + i) * 2];
+      a1 += px[((int64_t)b * HW + i) * 2 + 1];
+      n += 1.f;
+    }
+  }
+  s0[threadIdx.x] = a0; s1[threadIdx.x] = a1; s2[threadIdx.x] = n;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      s0[threadIdx.x] += s0[threadIdx.x + o];
+      s1[threadIdx.x] += s1[threadIdx.x + o];
+      s2[threadIdx.x] += s2[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float d = fmaxf(s2[0], 1.f);
+    out[b * 2] = s0[0] / d;
+    out[b * 2 + 1] = s1[0] / d;
+  }
+}
+
+template <int DP>
+int launch_pixel(int teacher_dtype, const void* preds, const void* teacher, float* px, int64_t n_pix, int C, hipStream_t s) {
+  const dim3 grid((unsigned)((n_pix + 3) / 4));
+  using P = typename Elem<DP>::type;
+  if (teacher_dtype == 0) hipLaunchKernelGGL((distill_pixel_kernel<DP, 0>), grid, dim3(256), 0, s, (const P*)preds, (const float*)teacher, px, n_pix, C);
+  else if (teacher_dtype == 1) hipLaunchKernelGGL((distill_pixel_kernel<DP, 1>), grid, dim3(256), 0, s, (const P*)preds, (const uint16_t*)teacher, px, n_pix, C);
+  else hipLaunchKernelGGL((distill_pixel_kernel<DP, 2>), grid, dim3(256), 0, s, (const P*)preds, (const __half*)teacher, px, n_pix, C);
+  return 0;
+}
+
+}  // namespace
+
+int esam3_distill_loss(int preds_dtype, const void* preds_dev, int teacher_dtype, const void* teacher_dev,
+                       const uint8_t* valid_dev, int B, int HW, int C, float* per_image_dev, float* scratch_dev,
+                       void* stream) {
+  if (!preds_dev || !teacher_dev || !valid_dev || !per_image_dev || !scratch_dev || B <= 0 || HW <= 0 || C <= 0 || C % 8 ||
+      preds_dtype < 0 || preds_dtype > 1 || teacher_dtype < 0 || teacher_dtype > 2) {
+    esam3_set_error("esam3_distill_loss: bad argument (B=%d HW=%d C=%d dtypes %d/%d; C must be a multiple of 8)", B, HW, C,
+                    preds_dtype, teacher_dtype);
+    return -1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n_pix = (int64_t)B * HW;
+  if (preds_dtype == 0) launch_pixel<0>(teacher_dtype, preds_dev, teacher_dev, scratch_dev, n_pix, C, s);
+  else launch_pixel<1>(teacher_dtype, preds_dev, teacher_dev, scratch_dev, n_pix, C, s);
+  hipLaunchKernelGGL(distill_reduce_kernel, dim3((unsigned)B), dim3(256), 0, s, scratch_dev, valid_dev, HW, per_image_dev);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

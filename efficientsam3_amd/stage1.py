@@ -1,0 +1,63 @@
+"""Stage-1 image distillation, forward pieces on the device: the loss between a student embedding
+and the saved teacher embedding (stage1/train_image_encoder_stage1.py:271-307) and the teacher-embedding payload
+(stage1/save_embedding_image_stage1.py:92-96: int32 augmentation seed ‖ fp16 [C, H, W]).  The trunks that produce the
+embeddings are the engine's encoders (``engine.encode(..., want_trunk=True)``); the backward pass is not built."""
+from __future__ import annotations
+
+from typing import Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}
+
+
+def valid_mask(img_size: int, sizes_before_pad: Sequence[Tuple[int, int]], target_hw: Tuple[int, int]) -> np.ndarray:
+    """build_valid_mask in closed form: the indicator of the (h, w) rectangle is separable, so its bilinear resize
+    (align_corners=False, no antialias) is the product of two 1-D resizes -> uint8 [B, H*W] (1 = valid)."""
+    def axis(n_valid: int, n_out: int) -> np.ndarray:
+        scale = img_size / n_out
+        src = np.maximum((np.arange(n_out, dtype=np.float32) + 0.5) * np.float32(scale) - 0.5, 0.0).astype(np.float32)
+        i0 = np.minimum(np.floor(src).astype(np.int64), img_size - 1)
+        i1 = np.minimum(i0 + 1, img_size - 1)
+        lam = (src - i0).astype(np.float32)
+        return (1.0 - lam) * (i0 < n_valid) + lam * (i1 < n_valid)
+    th, tw = target_hw
+    out = np.zeros((len(sizes_before_pad), th * tw), np.uint8)
+    for i, (h, w) in enumerate(sizes_before_pad):
+        out[i] = (np.outer(axis(h, th), axis(w, tw)).astype(np.float32) > 0.5).reshape(-1)
+    return out
+
+
+def distill_loss(preds: torch.Tensor, teacher: torch.Tensor, valid: torch.Tensor):
+    """preds [B, HW, C] fp32 / bf16 and teacher [B, HW, C] fp32 / bf16 / fp16 (token-major, on the GPU),
+    valid uint8 [B, HW] -> (masked_mse, masked_cosine_loss, per_image [B, 2])."""
+    assert preds.is_cuda and teacher.is_cuda and valid.is_cuda
+    assert preds.dim() == 3 and preds.shape == teacher.shape and preds.dtype in (torch.float32, torch.bfloat16)
+    assert teacher.dtype in _DT and valid.dtype == torch.uint8 and tuple(valid.shape) == tuple(preds.shape[:2])
+    b, hw, c = preds.shape
+    preds, teacher, valid = preds.contiguous(), teacher.contiguous(), valid.contiguous()
+    per = torch.empty((b, 2), dtype=torch.float32, device=preds.device)
+    scratch = torch.empty((b * hw * 2,), dtype=torch.float32, device=preds.device)
+    lib = _lib.load()
+    with torch.cuda.device(preds.device):
+        _lib.check(lib.esam3_distill_loss(_DT[preds.dtype], preds.data_ptr(), _DT[teacher.dtype], teacher.data_ptr(),
+                                          valid.data_ptr(), b, hw, c, per.data_ptr(), scratch.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "esam3_distill_loss")
+    m = per.mean(dim=0)
+    return m[0], m[1], per
+
+
+def pack_embedding(seed: int, embedding_chw: np.ndarray) -> bytes:
+    return np.int32(seed).tobytes() + np.ascontiguousarray(embedding_chw, dtype=np.float16).tobytes()
+
+
+def unpack_embedding(payload: bytes, shape_chw: Tuple[int, int, int]):
+    """-> (seed, fp16 [C, H, W]) as dataset_wrapper.py:50-62 parses it."""
+    seed = int(np.frombuffer(payload[:4], dtype=np.int32)[0])
+    n = int(np.prod(shape_chw))
+    if len(payload) < 4 + 2 * n:
+        raise ValueError(f"payload of {len(payload)} bytes is too short for an embedding of shape {shape_chw}")
+    return seed, np.frombuffer(payload[4:4 + 2 * n], dtype=np.float16).copy().reshape(shape_chw)

@@ -109,3 +109,19 @@ def rle_test_masks() -> dict:
     noise = (rng.random((3, 37, 53)) < np.array([0.5, 0.05, 0.95])[:, None, None]).astype(np.uint8)
     return {"tiny_5x7": tiny, "single_1x1": one, "noise_37x53": noise, "blobs_600x800": blobs(2, 600, 800, 3),
             "blobs_1008": blobs(2, 1008, 1008, 4), "checker_64x4097": ((np.add.outer(np.arange(64), np.arange(4097)) % 2)[None]).astype(np.uint8)}
+
+
+def stage1_cases() -> dict:
+    """Seeded cases for the stage-1 distillation loss: name -> (B, C, HW side, image size, [(h, w) before padding])."""
+    return {"small": (3, 64, 9, 126, [(126, 126), (70, 126), (5, 3)]),
+            "full": (2, 1024, 72, 1008, [(1008, 1008), (756, 1001)])}
+
+
+def stage1_embeddings(name: str):
+    """(student preds, teacher) fp32 [B, C, H, W]; the teacher is stored as fp16 by the reference, so its values are
+    fp16-representable; the student is the teacher plus noise (cosine similarity around 0.9)."""
+    b, c, hw, _, _ = stage1_cases()[name]
+    rng = np.random.default_rng(21 if name == "small" else 22)
+    teacher = rng.standard_normal((b, c, hw, hw)).astype(np.float16).astype(np.float32)
+    preds = (teacher + 0.4 * rng.standard_normal((b, c, hw, hw))).astype(np.float32)
+    return preds, teacher

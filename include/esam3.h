@@ -163,6 +163,16 @@ int esam3_rle_encode(const uint8_t* masks_dev, int n, int H, int W, uint32_t* co
 int64_t esam3_rle_to_string(const uint32_t* counts_host, int64_t n_counts, char* out, int64_t capacity);
 int64_t esam3_rle_from_string(const char* s, int64_t len, uint32_t* counts_host, int64_t capacity);
 
+/* Stage-1 distillation loss, forward (stage1/train_image_encoder_stage1.py:271-307 masked_mse and
+ * masked_cosine_loss): student embedding preds and teacher embedding, both token-major [B][HW][C] (NHWC; C % 8 == 0;
+ * dtype 0 = fp32, 1 = bf16, teacher also 2 = fp16 as stored by save_embedding_image_stage1.py:92-96), valid [B][HW]
+ * u8 from build_valid_mask.  per_image_dev [B][2] = {sum_valid sum_c (p-t)^2 / max(#valid,1),
+ * sum_valid (1 - cos(p,t)) / max(#valid,1)}; the losses are the means of the two columns.
+ * scratch_dev: B*HW*2 floats. */
+int esam3_distill_loss(int preds_dtype, const void* preds_dev, int teacher_dtype, const void* teacher_dev,
+                       const uint8_t* valid_dev, int B, int HW, int C, float* per_image_dev, float* scratch_dev,
+                       void* hip_stream);
+
 /* Per-launch timing with HIP events on the launch stream (bench.py roofline leg): enable,
  * run encode/decode, then fetch a JSON report (syncs the device, clears the records). */
 int esam3_profile_enable(esam3_engine* e, int on);

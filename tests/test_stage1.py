@@ -1,0 +1,74 @@
+"""Stage-1 distillation forward pieces: loss + teacher-embedding payload.
+
+CPU: the oracle reproduces the values the reference's own functions gave (tests/golden/stage1, written by
+oracle/gen_golden_stage1.py); the product's closed-form valid mask equals the oracle's interpolate-based one; the
+payload codec round-trips.  GPU: esam3_distill_loss vs the fixtures."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from efficientsam3_amd import stage1, synth
+
+
+@pytest.fixture(scope="module")
+def stage1_gold(golden_dir):
+    with open(os.path.join(golden_dir, "stage1", "manifest.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_oracle_loss_matches_reference_values(stage1_gold):
+    from oracle import ref_stage1
+    for name, (b, c, hw, img, sizes) in synth.stage1_cases().items():
+        preds, teacher = synth.stage1_embeddings(name)
+        m = ref_stage1.build_valid_mask(img, sizes, (hw, hw))
+        assert [int(v) for v in m.sum(dim=(1, 2, 3))] == stage1_gold[name]["valid_pixels"]
+        p, t = torch.from_numpy(preds), torch.from_numpy(teacher)
+        assert float(ref_stage1.masked_mse(p, t, m)) == pytest.approx(stage1_gold[name]["mse"], rel=1e-6)
+        assert float(ref_stage1.masked_cosine_loss(p, t, m)) == pytest.approx(stage1_gold[name]["cosine"], rel=1e-6)
+
+
+def test_valid_mask_closed_form_equals_interpolate():
+    from oracle import ref_stage1
+    rng = np.random.default_rng(0)
+    for img, hw in ((1008, 72), (126, 9), (1024, 64), (100, 7), (64, 64), (50, 72)):
+        sizes = [(img, img), (1, 1), (img // 2, img), (img, img // 3)] + [tuple(int(v) for v in rng.integers(1, img + 1, 2)) for _ in range(8)]
+        want = ref_stage1.build_valid_mask(img, sizes, (hw, hw)).numpy().reshape(len(sizes), -1).astype(np.uint8)
+        got = stage1.valid_mask(img, sizes, (hw, hw))
+        assert np.array_equal(got, want), (img, hw)
+
+
+def test_embedding_payload_round_trip():
+    from oracle import ref_stage1
+    emb = np.random.default_rng(1).standard_normal((8, 3, 5)).astype(np.float32)
+    blob = stage1.pack_embedding(123456789, emb)
+    assert blob == ref_stage1.pack_embedding(123456789, emb) and len(blob) == 4 + 2 * emb.size
+    seed, back = stage1.unpack_embedding(blob, emb.shape)
+    seed_o, back_o = ref_stage1.unpack_embedding(blob, emb.shape)
+    assert seed == seed_o == 123456789 and back.dtype == np.float16
+    assert np.array_equal(back, back_o) and np.array_equal(back, emb.astype(np.float16))
+    with pytest.raises(ValueError):
+        stage1.unpack_embedding(blob[:-2], emb.shape)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small", "full"])
+def test_distill_loss_kernel_vs_reference_values(stage1_gold, name):
+    b, c, hw, img, sizes = synth.stage1_cases()[name]
+    preds, teacher = synth.stage1_embeddings(name)
+    valid = torch.from_numpy(stage1.valid_mask(img, sizes, (hw, hw))).cuda()
+    p = torch.from_numpy(preds).permute(0, 2, 3, 1).reshape(b, hw * hw, c).contiguous().cuda()
+    t = torch.from_numpy(teacher).permute(0, 2, 3, 1).reshape(b, hw * hw, c).contiguous().cuda()
+    g = stage1_gold[name]
+    for tdt in (torch.float32, torch.float16):          # the teacher values are fp16-representable: same result
+        mse, cos, per = stage1.distill_loss(p, t.to(tdt), valid)
+        assert float(mse) == pytest.approx(g["mse"], rel=2e-5) and float(cos) == pytest.approx(g["cosine"], rel=2e-5)
+        assert per.shape == (b, 2)
+        if name == "small":
+            assert float(per[2].abs().max()) == 0.0      # an image without valid pixels contributes zero
+    mse, cos, _ = stage1.distill_loss(p.to(torch.bfloat16), t.to(torch.bfloat16), valid)   # bf16 inputs: rounding only
+    assert float(mse) == pytest.approx(g["mse"], rel=2e-2) and float(cos) == pytest.approx(g["cosine"], rel=5e-2)
+    a = stage1.distill_loss(p, t, valid)[2]
+    assert torch.equal(a, stage1.distill_loss(p, t, valid)[2])   # fixed-order reductions: bit-identical repeats
