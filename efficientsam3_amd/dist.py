@@ -82,3 +82,49 @@ def run_sharded(process: Callable[[Sequence], torch.Tensor], items: Sequence, ds
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     a, b = shard_bounds(len(items), rank, world)
     return gather_to_root(process(items[a:b]), n_items=len(items), dst=dst, group=group)
+
+
+# ---- detector outputs of a chunk of video frames: the reference's only GPU-to-GPU tensor collective ----------
+def all_gather_tensor(x: torch.Tensor, async_op: bool = False, group=None):
+    """``Sam3ImageOnVideoMultiGPU._gather_tensor`` (sam3/sam3/model/sam3_image.py:869-883): every rank receives every
+    rank's ``x`` -> (list of world_size tensors, work handle or None).  The input is made contiguous first (the
+    reference notes that NCCL/RCCL all_gather needs it)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [x], None
+    x = x.contiguous()
+    outs = [torch.empty_like(x) for _ in range(dist.get_world_size(group))]
+    handle = dist.all_gather(outs, x, async_op=async_op, group=group)
+    return outs, handle
+
+
+def local_frame_index(frame_idx_begin: int, frame_idx_end: int, rank: int) -> int:
+    """Round-robin frame of a chunk that this rank runs the detector on (sam3_image.py:808-809); ranks past the end
+    of the chunk repeat its last frame."""
+    return min(frame_idx_begin + rank, frame_idx_end - 1)
+
+
+def gather_detector_chunk(out_local: dict, frame_idx_begin: int, num_frames: int, sam2_fpn: Optional[Sequence[torch.Tensor]] = None,
+                          vision_pos_enc=None, async_op: bool = True, group=None) -> dict:
+    """``_build_multigpu_buffer_next_chunk`` after the detector ran (sam3_image.py:836-867): all-gather the
+    detector outputs of this rank's frame (``pred_logits``, ``pred_boxes``, ``pred_boxes_xyxy``, ``pred_masks``) and,
+    when given, the three SAM2 FPN levels cast to bf16; returns {frame_idx: {key: (tensor_of_that_frame, handle)}}
+    for the frames ``frame_idx_begin + rank`` that exist.  Call ``handle.wait()`` before reading (``async_op``)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    keys = ("pred_logits", "pred_boxes", "pred_boxes_xyxy", "pred_masks")
+    gathered = {k: all_gather_tensor(out_local[k], async_op, group) for k in keys if k in out_local}
+    fpn = None
+    if sam2_fpn is not None:
+        assert len(sam2_fpn) == 3, "the SAM2 backbone always has 3 levels"
+        fpn = [all_gather_tensor(x.to(torch.bfloat16), async_op, group) for x in sam2_fpn]
+    buf = {}
+    for r in range(world):
+        f = frame_idx_begin + r
+        if f >= num_frames:
+            continue
+        fb = {k: (v[r], h) for k, (v, h) in gathered.items()}
+        if fpn is not None:
+            for i, (v, h) in enumerate(fpn):
+                fb[f"tracker_backbone_fpn_{i}"] = (v[r], h)
+            fb["tracker_backbone_pos_enc"] = (vision_pos_enc, None)
+        buf[f] = fb
+    return buf

@@ -86,3 +86,68 @@ def test_single_process_is_passthrough():
     x = _fake_masks(range(3))
     assert esdist.gather_to_root(x) is x
     assert torch.equal(esdist.run_sharded(_fake_masks, list(range(3))), x)
+
+
+def _detector_out(frame):
+    g = torch.Generator().manual_seed(77 + frame)
+    return {"pred_logits": torch.randn((1, 6, 1), generator=g), "pred_boxes": torch.rand((1, 6, 4), generator=g),
+            "pred_boxes_xyxy": torch.rand((1, 6, 4), generator=g), "pred_masks": torch.randn((1, 6, 8, 8), generator=g),
+            "extra_key_not_gathered": torch.zeros(1)}
+
+
+def _fpn(frame):
+    g = torch.Generator().manual_seed(900 + frame)
+    return [torch.randn((1, c, s, s), generator=g) for c, s in ((4, 8), (8, 4), (16, 2))]
+
+
+def _chunk_worker(rank, world, port, begin, num_frames, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    esdist.init_process_group("gloo")
+    try:
+        end = min(begin + world, num_frames)
+        mine = esdist.local_frame_index(begin, end, rank)
+        # non-contiguous input on purpose: the helper must make it contiguous
+        out_local = {k: (v.transpose(-1, -2).contiguous().transpose(-1, -2) if v.dim() == 4 else v)
+                     for k, v in _detector_out(mine).items()}
+        buf = esdist.gather_detector_chunk(out_local, begin, num_frames, sam2_fpn=_fpn(mine), vision_pos_enc="pos",
+                                           async_op=True)
+        res = {}
+        for f, fb in buf.items():
+            for k, (t, h) in fb.items():
+                if h is not None:
+                    h.wait()
+            res[f] = {k: (t.float().numpy() if torch.is_tensor(t) else t) for k, (t, h) in fb.items()}
+        q.put((rank, mine, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("begin,num_frames", [(0, 7), (6, 7)])
+def test_detector_chunk_all_gather(begin, num_frames):
+    """Sam3ImageOnVideoMultiGPU's chunk exchange (sam3_image.py:792-883) on gloo: every rank ends with the detector
+    outputs and bf16 SAM2 features of every frame of the chunk; frames past the end of the video are dropped."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, world, port, begin, num_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    frames = [f for f in range(begin, begin + world) if f < num_frames]
+    for rank, mine, res in results:
+        assert mine == min(begin + rank, min(begin + world, num_frames) - 1)
+        assert sorted(res) == frames
+        for f in frames:
+            want = _detector_out(f)
+            assert set(res[f]) == {"pred_logits", "pred_boxes", "pred_boxes_xyxy", "pred_masks", "tracker_backbone_fpn_0",
+                                   "tracker_backbone_fpn_1", "tracker_backbone_fpn_2", "tracker_backbone_pos_enc"}
+            for k in ("pred_logits", "pred_boxes", "pred_boxes_xyxy", "pred_masks"):
+                np.testing.assert_array_equal(res[f][k], want[k].numpy())
+            for i, x in enumerate(_fpn(f)):
+                np.testing.assert_array_equal(res[f][f"tracker_backbone_fpn_{i}"], x.to(torch.bfloat16).float().numpy())
+            assert res[f]["tracker_backbone_pos_enc"] == "pos"
