@@ -2085,10 +2085,10 @@ int esam3_create(const esam3_config* cfg, esam3_engine** out) {
 
 void esam3_destroy(esam3_engine* e) {
   if (!e) return;
-  hipDeviceSynchronize();
+  (void)hipDeviceSynchronize();
 
-  for (void* p : e->owned) hipFree(p);
-  if (e->arena.base) hipFree(e->arena.base);
+  for (void* p : e->owned) (void)hipFree(p);
+  if (e->arena.base) (void)hipFree(e->arena.base);
   delete e;
 }
 
@@ -2224,7 +2224,7 @@ int esam3_preprocess_u8(const uint8_t* in, float* out, int B, int H, int W, void
 
 int esam3_profile_enable(esam3_engine* e, int on) {
   if (!e) return -1;
-  for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  for (auto& r : e->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   e->recs.clear();
   e->prof = on != 0;
   return 0;
@@ -2239,7 +2239,7 @@ int esam3_set_text_causal(esam3_engine* e, int causal_masking) {
 int esam3_profile_tag(esam3_engine* e, const char* tag) {
   if (!e) return -1;
   e->watch_tag = tag ? tag : "";
-  for (auto& r : e->recs) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+  for (auto& r : e->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   e->recs.clear();
   return 0;
 }
@@ -2256,7 +2256,7 @@ int esam3_profile_report(esam3_engine* e, char* buf, int64_t buf_size) {
     HIP_CHECK_RET(hipEventElapsedTime(&ms, r.a, r.b));
     Agg& a = agg[r.tag];
     a.ms += ms; a.n += 1; a.flops = r.flops; a.bytes = r.bytes; a.kernel = r.kernel;
-    hipEventDestroy(r.a); hipEventDestroy(r.b);
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
   e->recs.clear();
   std::vector<std::pair<std::string, Agg>> v(agg.begin(), agg.end());

@@ -13,7 +13,7 @@ namespace {
 struct Tmp {  // scoped device allocations
   std::vector<void*> ptrs;
   ~Tmp() {
-    for (void* p : ptrs) hipFree(p);
+    for (void* p : ptrs) (void)hipFree(p);
   }
   void* up(const void* src, size_t bytes) {
     void* p = nullptr;
@@ -386,7 +386,7 @@ extern "C" int esam3_bench_gemm(int dtype, int B, int H, int W, int Cin, int N, 
   if (!w || !a || !o || !chunk) return fail("bench_gemm");
   for (size_t off = 0; off < a_elems; off += ha.size()) {
     const size_t n = std::min(ha.size(), a_elems - off);
-    hipMemcpy((char*)a + off * esz, chunk, n * esz, hipMemcpyDeviceToDevice);
+    (void)hipMemcpy((char*)a + off * esz, chunk, n * esz, hipMemcpyDeviceToDevice);
   }
   GemmParams p{};
   p.A = a; p.Wt = w; p.out = o; p.M = M; p.N = N; p.K = K; p.Kp = Kp; p.H = H; p.W = W; p.Cin = Cin;
@@ -394,15 +394,15 @@ extern "C" int esam3_bench_gemm(int dtype, int B, int H, int W, int Cin, int N, 
   p.korder = esam3_conv_korder(Cin, ksize, esz);
   if (convt) { p.out_mode = OUT_CONVT2X2; p.convt_cout = N / 4; }
   hipEvent_t e0, e1;
-  hipEventCreate(&e0); hipEventCreate(&e1);
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) if (esam3_launch_gemm(dtype, p, nullptr)) return -1;
-  hipEventRecord(e0, nullptr);
+  (void)hipEventRecord(e0, nullptr);
   for (int i = 0; i < iters; ++i) if (esam3_launch_gemm(dtype, p, nullptr)) return -1;
-  hipEventRecord(e1, nullptr);
+  (void)hipEventRecord(e1, nullptr);
   HIP_CHECK_RET(hipDeviceSynchronize());
   float ms = 0.f;
-  hipEventElapsedTime(&ms, e0, e1);
-  hipEventDestroy(e0); hipEventDestroy(e1);
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   *avg_ms = ms / iters;
   return 0;
 }
