@@ -17,6 +17,15 @@
  *   esam3_postprocess_masks
  *       <- SAM2Transforms.postprocess_masks (sam3/sam3/model/utils/sam1_utils.py:77-119) and
  *          the `> mask_threshold` of sam1_task_predictor.py:423-428.
+ *   esam3_encode_text (+ esam3_set_text_causal)
+ *       <- TextStudentEncoder.forward after tokenisation (sam3/sam3/model/text_encoder_student.py:40-58).
+ *   esam3_ground
+ *       <- Sam3Image.forward_grounding (sam3/sam3/model/sam3_image.py:442-493): geometry encoder, fusion
+ *          encoder, DETR decoder, scoring, mask head.
+ *   esam3_rle_encode / esam3_rle_to_string / esam3_rle_from_string
+ *       <- the evaluation writers' mask -> COCO RLE step (sam3/sam3/train/masks_ops.py:161-250).
+ *   esam3_distill_loss
+ *       <- masked_mse / masked_cosine_loss of stage-1 distillation (stage1/train_image_encoder_stage1.py:271-307).
  *
  * Conventions: every pointer named *_dev is device memory owned by the caller; tensors are
  * NHWC (channels innermost) in the engine's activation dtype unless stated; all functions

@@ -41,3 +41,21 @@ def test_create_fails_loudly_without_gpu():
     from efficientsam3_amd import build_efficientsam3_image_model
     with pytest.raises(Exception):
         build_efficientsam3_image_model(enable_inst_interactivity=True, model_name="b1")
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/esam3.h must compile as C99 (no C++ in the signatures) and the library must
+    link from a C translation unit."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "t.c"
+    src.write_text('#include "esam3.h"\n'
+                   "int probe(void) { esam3_config c; esam3_ground_in g; esam3_ground_out o; (void)c; (void)g; (void)o;\n"
+                   "  return esam3_last_error() == 0 && esam3_rle_scratch_bytes(1, 8, 8, 16) > 0; }\n")
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-c", str(src), "-o",
+                        str(tmp_path / "t.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

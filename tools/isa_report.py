@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""Static report on the compiled kernels of one .hip file (no GPU needed): VGPR / SGPR / LDS use, spills, and for
+every kernel the instruction mix of its hottest loop (the innermost loop with the most MFMAs, else the most VMEM).
+
+    python tools/isa_report.py efficientsam3_amd/csrc/gemm_conv.hip [--match gemm256] [--out profiles/x.txt]
+"""
+import argparse
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def demangle(names):
+    try:
+        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True)
+        return out.stdout.split("\n")[:len(names)]
+    except Exception:
+        return names
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("source")
+    ap.add_argument("--match", default="")
+    ap.add_argument("--out")
+    args = ap.parse_args()
+    src = os.path.abspath(args.source)
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "k.s")
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
+               "-x", "hip", src, "-I", os.path.dirname(src), "-o", asm]
+        subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+        text = open(asm).read()
+    meta = {}
+    for blk in re.split(r"\n  - \.agpr_count:", text)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        if not name:
+            continue
+        get = lambda k: (re.search(r"\." + k + r":\s+(\d+)", blk) or [None, "?"])[1]
+        meta[name.group(1)] = {k: get(k) for k in ("vgpr_count", "vgpr_spill_count", "sgpr_count", "sgpr_spill_count",
+                                                   "group_segment_fixed_size", "private_segment_fixed_size")}
+    lines = text.split("\n")
+    starts = [(i, l[:-1].split(":")[0]) for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
+    rows = []
+    names = [n for _, n in starts]
+    pretty = dict(zip(names, demangle(names)))
+    for idx, (i0, name) in enumerate(starts):
+        if args.match and args.match not in pretty.get(name, name):
+            continue
+        i1 = starts[idx + 1][0] if idx + 1 < len(starts) else len(lines)
+        body = lines[i0:i1]
+        # loops: a backward branch to a label defined earlier
+        labels = {l.split(":")[0]: j for j, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
+        best = None
+        for j, l in enumerate(body):
+            m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)
+            if m and m.group(1) in labels and labels[m.group(1)] < j:
+                seg = body[labels[m.group(1)]:j + 1]
+                cnt = lambda pat: sum(1 for s in seg if re.search(pat, s))
+                mix = {"mfma": cnt(r"\bv_mfma"), "ds_read": cnt(r"\bds_read"), "ds_write": cnt(r"\bds_write"),
+                       "lds_dma": cnt(r"global_load_lds|buffer_load.*lds"), "vmem_ld": cnt(r"\b(global|buffer)_load(?!.*lds)"),
+                       "vmem_st": cnt(r"\b(global|buffer)_store"), "barrier": cnt(r"\bs_barrier"), "waitcnt": cnt(r"\bs_waitcnt"),
+                       "valu": cnt(r"^\s+v_(?!mfma)"), "salu": cnt(r"^\s+s_(?!waitcnt|barrier|cbranch|nop)"), "insts": len([s for s in seg if re.match(r"^\s+[a-z]", s)])}
+                key = (mix["mfma"], mix["vmem_ld"] + mix["lds_dma"], -mix["insts"])
+                if best is None or key > best[0]:
+                    best = (key, mix)
+        rows.append((pretty.get(name, name), meta.get(name, {}), best[1] if best else {}))
+    out = []
+    for name, m, mix in rows:
+        out.append(name)
+        out.append("  regs: " + ", ".join(f"{k}={v}" for k, v in m.items()))
+        if mix:
+            out.append("  hottest loop: " + ", ".join(f"{k}={v}" for k, v in mix.items()))
+    report = "\n".join(out)
+    print(report)
+    if args.out:
+        with open(args.out, "w") as f:
+            f.write(f"# tools/isa_report.py {os.path.relpath(src, ROOT)} --match {args.match}\n" + report + "\n")
+
+
+if __name__ == "__main__":
+    sys.exit(main())
