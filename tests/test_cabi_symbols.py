@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from efficientsam3_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
