@@ -61,3 +61,21 @@ def unpack_embedding(payload: bytes, shape_chw: Tuple[int, int, int]):
     if len(payload) < 4 + 2 * n:
         raise ValueError(f"payload of {len(payload)} bytes is too short for an embedding of shape {shape_chw}")
     return seed, np.frombuffer(payload[4:4 + 2 * n], dtype=np.float16).copy().reshape(shape_chw)
+
+
+def paired_forward(teacher, student, images: torch.Tensor, sizes_before_pad: Sequence[Tuple[int, int]]):
+    """BASELINE config 5, forward half: the ViT-H teacher trunk and a student trunk on the same normalised images
+    [B, 3, 1008, 1008], then the distillation loss between the two [B, 1024, 72, 72] embeddings
+    (stage1/model.py:237 ``model.backbone.vision_backbone.trunk(x)`` on both sides,
+    stage1/train_image_encoder_stage1.py:196-212).  ``teacher`` / ``student`` are models built by
+    ``build_sam3_image_model`` / ``build_efficientsam3_image_model`` on the same device.
+    -> dict(mse, cosine, per_image [B, 2], teacher [B, 5184, 1024], student [B, 5184, 1024])."""
+    x = images.to(student.device, torch.float32).contiguous()
+    t = teacher.engine.encode(x, want_sam3=False, want_sam2=False, want_trunk=True)["trunk"]
+    s = student.engine.encode(x, want_sam3=False, want_sam2=False, want_trunk=True)["trunk"]
+    b, h, w, c = s.shape
+    assert tuple(t.shape) == (b, h, w, c), (t.shape, s.shape)
+    valid = torch.from_numpy(valid_mask(x.shape[-1], sizes_before_pad, (h, w))).to(x.device)
+    tt, ss = t.reshape(b, h * w, c), s.reshape(b, h * w, c)
+    mse, cos, per = distill_loss(ss, tt, valid)
+    return {"mse": mse, "cosine": cos, "per_image": per, "teacher": tt, "student": ss, "valid": valid}

@@ -72,3 +72,29 @@ def test_distill_loss_kernel_vs_reference_values(stage1_gold, name):
     assert float(mse) == pytest.approx(g["mse"], rel=2e-2) and float(cos) == pytest.approx(g["cosine"], rel=5e-2)
     a = stage1.distill_loss(p, t, valid)[2]
     assert torch.equal(a, stage1.distill_loss(p, t, valid)[2])   # fixed-order reductions: bit-identical repeats
+
+
+@pytest.mark.gpu
+def test_paired_forward_composes_trunks_and_loss():
+    """BASELINE config 5 (forward): ViT-H teacher trunk + EV-M student trunk on the same images, then the loss.  The
+    trunks have their own parity tests (test_students_gpu.py, test_e2e_gpu.py); here the composition is checked:
+    the device loss equals the oracle's loss evaluated on the very tensors the two engines produced."""
+    from efficientsam3_amd import build_efficientsam3_image_model, build_sam3_image_model, schema
+    from oracle import ref_stage1
+    teacher = build_sam3_image_model(device="cuda", enable_inst_interactivity=False, dtype="bf16",
+                                     state_dict=schema.synthetic_state_dict("sam3", "vit_h", seed=0, enable_inst_interactivity=False))
+    student = build_efficientsam3_image_model(device="cuda", enable_inst_interactivity=False, backbone_type="efficientvit",
+                                              model_name="b1", dtype="bf16",
+                                              state_dict=schema.synthetic_state_dict("efficientvit", "b1", seed=0,
+                                                                                     enable_inst_interactivity=False))
+    x = torch.from_numpy(np.stack([synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=s)) for s in (1, 3)]))
+    sizes = [(1008, 1008), (700, 900)]
+    out = stage1.paired_forward(teacher, student, x, sizes)
+    assert tuple(out["teacher"].shape) == (2, 5184, 1024) == tuple(out["student"].shape)
+    nchw = lambda t: t.float().cpu().reshape(2, 72, 72, 1024).permute(0, 3, 1, 2)
+    m = ref_stage1.build_valid_mask(1008, sizes, (72, 72))
+    assert np.array_equal(out["valid"].cpu().numpy().reshape(2, 1, 72, 72), m.numpy().astype(np.uint8))
+    mse = float(ref_stage1.masked_mse(nchw(out["student"]), nchw(out["teacher"]), m))
+    cos = float(ref_stage1.masked_cosine_loss(nchw(out["student"]), nchw(out["teacher"]), m))
+    assert float(out["mse"]) == pytest.approx(mse, rel=1e-4) and float(out["cosine"]) == pytest.approx(cos, rel=1e-4)
+    assert 0.0 < float(out["cosine"]) < 2.0 and float(out["mse"]) > 0.0
