@@ -209,3 +209,33 @@ def test_pcs_engine_geometric_prompts_vs_golden(pcs_gold, pcs_sd, mode):
         assert float(np.abs(state["boxes"].cpu().numpy() - g[f"{name}_boxes"]).max()) <= 1.0
     else:
         assert abs(state["scores"].numel() - n_ref) <= max(4, n_ref // 10)
+
+
+@pytest.mark.gpu
+def test_config4_batch_8_is_image_independent():
+    """BASELINE config 4 at its full size (ViT-H + MobileCLIP-S0-16 + detector, bf16, batch 8): four distinct
+    (image, text) pairs tiled twice; both copies must give bit-identical logits, boxes, presence and mask logits."""
+    from efficientsam3_amd import build_sam3_image_model
+    sd = schema.synthetic_state_dict("sam3", "vit_h", seed=0, enable_inst_interactivity=False)
+    sd.update(schema.synthetic_text_state_dict("MobileCLIP-S0", 16, seed=0))
+    sd.update(schema.synthetic_pcs_state_dict(seed=0))
+    model = build_sam3_image_model(device="cuda", enable_inst_interactivity=False, dtype="bf16", state_dict=sd,
+                                   text_encoder_type="MobileCLIP-S0", text_encoder_context_length=16)
+    eng = model.engine
+    base = [synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=1)), synth.normalise_to_chw_f32(synth.noise_image_u8(seed=2)),
+            synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=3)), synth.normalise_to_chw_f32(synth.noise_image_u8(seed=4))]
+    x = torch.from_numpy(np.stack([base[i % 4] for i in range(8)])).to("cuda")
+    rng = np.random.default_rng(5)
+    tok = np.zeros((8, 16), dtype=np.int64)
+    for i in range(4):
+        n = int(rng.integers(1, 5))
+        tok[i, 0], tok[i, 1:1 + n], tok[i, 1 + n] = 49406, rng.integers(300, 40000, size=n), 49407
+    tok[4:] = tok[:4]
+    tok_d = torch.from_numpy(tok).to("cuda")
+    out = eng.encode(x, want_sam3=True, want_sam2=False)
+    mem, _ = eng.encode_text(tok_d)
+    g = eng.ground(out["sam3_fpn"], mem, tok_d == 0)
+    for k in ("pred_logits", "pred_boxes", "presence_logit_dec", "pred_masks"):
+        assert torch.equal(g[k][:4], g[k][4:]), k
+        assert torch.isfinite(g[k]).all(), k
+    assert g["pred_masks"].shape == (8, 200, 288, 288) and float(g["pred_boxes"].min()) >= 0.0 and float(g["pred_boxes"].max()) <= 1.0

@@ -131,3 +131,25 @@ def test_other_sizes_vs_oracle_live(bt, mn):
         del model
     rng = float(low_o.max() - low_o.min())
     assert float(np.abs(lows["bf16"] - lows["f32"]).max()) <= max(0.35, 0.03 * rng)
+
+
+def test_tinyvit_full_shard_32_is_image_independent():
+    """BASELINE config 3 at the size one GPU sees (TV-M bf16, a 32-image shard of the 256-image batch): copies of
+    an image inside the shard produce bit-identical embeddings and masks (padded-window attention, bias tables and
+    every reduction are order-fixed)."""
+    sd = schema.synthetic_state_dict("tinyvit", "11m", seed=0)
+    model = build_efficientsam3_image_model(device="cuda", enable_inst_interactivity=True, backbone_type="tinyvit",
+                                            model_name="11m", dtype="bf16", state_dict=sd)
+    eng = model.engine
+    base = [synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=1)), synth.normalise_to_chw_f32(synth.noise_image_u8(seed=2)),
+            synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=3)), synth.normalise_to_chw_f32(synth.noise_image_u8(seed=4))]
+    x = torch.from_numpy(np.stack([base[i % 4] for i in range(32)])).to("cuda")
+    pts, labels, boxes = synth.prompts(4, seed=2)
+    c4, l4 = model._prep_prompts(pts, labels, boxes, True, (1008, 1008))
+    out = eng.encode(x, want_sam3=False, want_sam2=True, want_trunk=True)
+    low, iou = eng.decode(out["sam2_fpn"], torch.arange(32, dtype=torch.int32, device="cuda"),
+                          torch.from_numpy(np.concatenate([c4] * 8)).to("cuda"), torch.from_numpy(np.concatenate([l4] * 8)).to("cuda"),
+                          multimask_output=False)
+    for i in range(4, 32):
+        assert torch.equal(out["trunk"][i], out["trunk"][i % 4]) and torch.equal(low[i], low[i % 4]) and torch.equal(iou[i], iou[i % 4]), i
+    assert torch.isfinite(low).all() and float(low.std()) > 0.1
