@@ -174,12 +174,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--backbone", default="efficientvit")
     ap.add_argument("--model", default="b1")
+    ap.add_argument("--light", action="store_true", help="S / L sizes: one image, one prompt case (small fixtures)")
     args = ap.parse_args()
     global GOLD, CASES, RESIZE_CASES
     default = (args.backbone, args.model) == ("efficientvit", "b1")
     if not default:
         GOLD = os.path.join(GOLD, f"{args.backbone}_{args.model}")
-        CASES = [c for c in CASES if c["name"] in OTHER_STUDENT_CASES]
+        CASES = [c for c in CASES if c["name"] in (("point_box_single",) if args.light else OTHER_STUDENT_CASES)]
         RESIZE_CASES = []
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 8)
@@ -220,7 +221,7 @@ def main():
     imgs_u8 = [synth.smooth_image_u8(seed=1), synth.noise_image_u8(seed=3)][: 2 if default else 1]
     trunk = model.backbone.vision_backbone.trunk
     bb = trunk if args.backbone == "sam3" else trunk.model.backbone  # the family's TrunkWrapper
-    for ii, img_u8 in enumerate(imgs_u8):
+    for ii, img_u8 in enumerate(imgs_u8[:1] if args.light else imgs_u8):
         chw_u8 = torch.from_numpy(np.ascontiguousarray(np.moveaxis(img_u8, -1, 0)))
         x = ref_model.normalise_image_u8(chw_u8)[None]
         assert np.array_equal(x[0].numpy(), synth.normalise_to_chw_f32(img_u8))
