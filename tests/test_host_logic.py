@@ -162,3 +162,31 @@ def test_checkpoint_merge_and_clean_round_trip(tmp_path):
     assert ck.extract_state_dict({"state_dict": {"a": torch.zeros(1)}}).keys() == {"a"}
     with pytest.raises(ValueError):
         ck.extract_state_dict({"a": 1})
+
+
+def test_box_ops_match_the_reference_formulas():
+    """sam3.model.box_ops of the facade: the six format conversions are mutually inverse and agree with the reference's
+    definitions (box_ops.py:11-45) on hand-computed values; pairwise IoU on a known pair."""
+    import os
+    import sys
+    from efficientsam3_amd import box_ops as bo
+    b = torch.tensor([[10.0, 20.0, 30.0, 40.0], [0.25, 0.5, 0.5, 0.25]])          # XYWH
+    assert torch.equal(bo.box_xywh_to_xyxy(b), torch.tensor([[10.0, 20.0, 40.0, 60.0], [0.25, 0.5, 0.75, 0.75]]))
+    assert torch.equal(bo.box_xywh_to_cxcywh(b), torch.tensor([[25.0, 40.0, 30.0, 40.0], [0.5, 0.625, 0.5, 0.25]]))
+    g = torch.rand((3, 5, 4), generator=torch.Generator().manual_seed(0)) + 0.1
+    for f, inv in ((bo.box_xywh_to_xyxy, bo.box_xyxy_to_xywh), (bo.box_xywh_to_cxcywh, bo.box_cxcywh_to_xywh),
+                   (bo.box_cxcywh_to_xyxy, bo.box_xyxy_to_cxcywh)):
+        assert torch.allclose(inv(f(g)), g, atol=1e-6)
+    iou, union = bo.box_iou(torch.tensor([[0.0, 0.0, 2.0, 2.0]]), torch.tensor([[1.0, 1.0, 3.0, 3.0], [5.0, 5.0, 6.0, 6.0]]))
+    assert torch.allclose(iou, torch.tensor([[1.0 / 7.0, 0.0]])) and torch.allclose(union, torch.tensor([[7.0, 5.0]]))
+    compat = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "compat")
+    sys.path.insert(0, compat)
+    try:
+        for m in [k for k in sys.modules if k == "sam3" or k.startswith("sam3.")]:
+            del sys.modules[m]
+        from sam3.model.box_ops import box_xywh_to_cxcywh
+        assert box_xywh_to_cxcywh is bo.box_xywh_to_cxcywh
+    finally:
+        sys.path.remove(compat)
+        for m in [k for k in sys.modules if k == "sam3" or k.startswith("sam3.")]:
+            del sys.modules[m]
