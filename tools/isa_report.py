@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def demangle(names):
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True)
+        out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True)
         return out.stdout.split("\n")[:len(names)]
     except Exception:
         return names
