@@ -159,3 +159,41 @@ def test_text_variants_engine_vs_golden(variants_gold, kind):
         print(f"[{kind} {mode}] language_features max-abs-err {err:.3e}")
         assert err <= tol, (kind, mode, err)
         del model
+
+
+def test_tokenizer_equals_reference_on_random_text():
+    """Property check of row T0 where the reference is present (the build container): for random unicode / ASCII /
+    punctuation-heavy strings the product tokenizer emits exactly the reference tokenizer's ids
+    (sam3/sam3/model/tokenizer_ve.py:128-253).  Skipped on machines without /root/reference."""
+    import sys
+    ref_root = "/root/reference/sam3"
+    bpe = "/root/reference/sam3/assets/bpe_simple_vocab_16e6.txt.gz"
+    if not (os.path.isdir(ref_root) and os.path.exists(bpe)):
+        pytest.skip("the reference is not present on this machine")
+    from hypothesis import given, settings, strategies as st
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    added = [os.path.join(repo, "oracle", "shims"), ref_root]
+    sys.path[:0] = added
+    try:
+        for m in [k for k in sys.modules if k == "sam3" or k.startswith("sam3.")]:
+            del sys.modules[m]
+        from sam3.model.tokenizer_ve import SimpleTokenizer
+        ref = SimpleTokenizer(bpe_path=bpe)
+    finally:
+        for p_ in added:
+            sys.path.remove(p_)
+        for m in [k for k in sys.modules if k == "sam3" or k.startswith("sam3.")]:
+            del sys.modules[m]
+    from efficientsam3_amd.tokenizer import ClipBpeTokenizer
+    mine = ClipBpeTokenizer(bpe)
+    alphabet = st.one_of(st.characters(min_codepoint=32, max_codepoint=126), st.characters(min_codepoint=0xA0, max_codepoint=0x2FFF),
+                         st.sampled_from(list(" \t\n'\".,!?-_&<>;#@$%0123456789")))
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(st.text(alphabet=alphabet, min_size=0, max_size=60), min_size=1, max_size=4), st.sampled_from([16, 32, 77]))
+    def check(texts, ctx):
+        want = ref(texts, context_length=ctx).numpy()
+        got = mine(texts, context_length=ctx)
+        assert np.array_equal(got, want), (texts, ctx)
+
+    check()
