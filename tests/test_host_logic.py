@@ -190,3 +190,80 @@ def test_box_ops_match_the_reference_formulas():
         sys.path.remove(compat)
         for m in [k for k in sys.modules if k == "sam3" or k.startswith("sam3.")]:
             del sys.modules[m]
+
+
+def _with_reference():
+    """Context for importing the REAL reference where it exists (the build container); None elsewhere."""
+    import contextlib
+    import os
+    import sys
+    ref_root = "/root/reference/sam3"
+    if not os.path.isdir(ref_root):
+        return None
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    added = [os.path.join(repo, "oracle", "shims"), ref_root]
+
+    @contextlib.contextmanager
+    def ctx():
+        purge = lambda: [sys.modules.pop(k) for k in list(sys.modules) if k == "sam3" or k.startswith("sam3.")]
+        purge()
+        sys.path[:0] = added
+        try:
+            yield
+        finally:
+            for p_ in added:
+                sys.path.remove(p_)
+            purge()
+    return ctx()
+
+
+def test_prompt_coordinates_match_reference_transforms():
+    """Row P2: Sam3Image._prep_prompts == SAM2Transforms.transform_coords / transform_boxes
+    (sam3/sam3/model/utils/sam1_utils.py:47-75) for random points, boxes and original sizes."""
+    ctx = _with_reference()
+    if ctx is None:
+        pytest.skip("the reference is not present on this machine")
+    from efficientsam3_amd.sam3_image import Sam3Image
+    with ctx:
+        from sam3.model.utils.sam1_utils import SAM2Transforms
+        tr = SAM2Transforms(resolution=1008, mask_threshold=0.0, max_hole_area=0.0, max_sprinkle_area=0.0)
+        rng = np.random.default_rng(0)
+        for _ in range(25):
+            h, w = int(rng.integers(50, 3000)), int(rng.integers(50, 3000))
+            n = int(rng.integers(1, 6))
+            pts = (rng.random((n, 2)) * [w, h]).astype(np.float32)
+            lab = rng.integers(0, 2, n).astype(np.int32)
+            box = np.sort(rng.random((2, 2)) * [w, h], axis=0).reshape(4).astype(np.float32)
+            want_pts = tr.transform_coords(torch.from_numpy(pts)[None], normalize=True, orig_hw=(h, w))[0].numpy()
+            want_box = tr.transform_boxes(torch.from_numpy(box)[None], normalize=True, orig_hw=(h, w)).reshape(-1, 2, 2)[0].numpy()
+            coords, labels = Sam3Image._prep_prompts(pts, lab, box, True, (h, w))
+            # the box corners come first with labels 2 / 3 (sam1_task_predictor.py:385-396), then the points
+            assert coords.shape == (1, 2 + n, 2) and labels.tolist() == [[2, 3] + lab.tolist()]
+            np.testing.assert_allclose(coords[0, :2], want_box, rtol=1e-6, atol=1e-4)
+            np.testing.assert_allclose(coords[0, 2:], want_pts, rtol=1e-6, atol=1e-4)
+
+
+def test_geometry_prompt_matches_reference_prompt_class():
+    """geometry_prompt.Prompt == the reference's Prompt (geometry_encoders.py:82-400) for random append sequences with
+    per-image padding: same embeddings, labels and masks after every step."""
+    ctx = _with_reference()
+    if ctx is None:
+        pytest.skip("the reference is not present on this machine")
+    from efficientsam3_amd.geometry_prompt import Prompt as Mine
+    with ctx:
+        from sam3.model.geometry_encoders import Prompt as Ref
+        rng = np.random.default_rng(1)
+        for trial in range(10):
+            b = int(rng.integers(1, 4))
+            kw = dict(box_embeddings=torch.zeros(0, b, 4), box_mask=torch.zeros(b, 0, dtype=torch.bool))
+            mine, ref = Mine(**kw), Ref(**kw)
+            for step in range(int(rng.integers(1, 6))):
+                boxes = torch.from_numpy(rng.random((1, b, 4)).astype(np.float32))
+                labels = torch.from_numpy(rng.integers(0, 2, (1, b))).bool()
+                mask = torch.from_numpy(rng.random((b, 1)) < 0.35)
+                mine.append_boxes(boxes, labels, mask=mask.clone())
+                ref.append_boxes(boxes.clone(), labels.clone(), mask=mask.clone())
+                valid = ~ref.box_mask
+                assert torch.equal(mine.box_mask, ref.box_mask), (trial, step)
+                assert torch.equal(mine.box_embeddings.transpose(0, 1)[valid], ref.box_embeddings.transpose(0, 1)[valid])
+                assert torch.equal(mine.box_labels.transpose(0, 1)[valid].long(), ref.box_labels.transpose(0, 1)[valid].long())
