@@ -117,7 +117,6 @@ struct GemmParams {
                       // (channel-chunk major: the 9 taps of one 128-byte channel chunk are
                       //  consecutive K tiles, so shifted re-reads of the same pixels hit in L2)
   int stride;         // ksize 3 only: 0/1 -> stride 1; 2 -> H, W are the INPUT dims, M = B*ceil(H/2)*ceil(W/2)
-  int debug;          // development switches (ESAM3_GEMM_DEBUG): 1 skip epilogue, 2 skip DMA, 4 skip MFMA
 };
 
 // ---- error handling ---------------------------------------------------------------

@@ -1,0 +1,473 @@
+// gemm256p_kernel: bf16 256x256x64 implicit GEMM for gfx950, phase-interleaved schedule.
+//
+// Serves the same layers as gemm256_kernel<bf16> in gemm_conv.hip (neck 3x3 / 1x1 / ConvT-k2s2 convs of
+// model/necks.py:42-92, the head 3x3 of model_builder.py:770-775, the ViT-H Linears of model/vitdet.py:339-515)
+// with the same operand convention (weights = MFMA A operand, pixels = B operand; a lane owns 4 consecutive
+// channels of one pixel).  What differs is the schedule of the main loop and the epilogue:
+//
+//  * The eight wavefronts form two groups (wm = 0 / 1, one wave of each group per SIMD) that run half a phase
+//    apart: while one group issues its 8 MFMAs of a phase, the other issues its ds_reads and LDS-DMA pieces.
+//    A K tile (64 deep) is four phases, one 64-pixel x 32-channel quadrant of the wave's 128 x 64 block each:
+//        phase 1: read B0 (4 x ds_read_b128) + A0 (8)   MFMA acc[0..1][0]      stage A1 of K tile t+1
+//        phase 2: read B1 (4)                           MFMA acc[0..1][1]      stage B0 of K tile t+2
+//        phase 3: read A1 (8, into A0's registers)      MFMA acc[2..3][1]      stage A0 of K tile t+2
+//        phase 4: -                                     MFMA acc[2..3][0]      stage B1 of K tile t+2, vmcnt(6)
+//    "A0/A1" = the rows every wave reads in phase 1 / 3 (its upper / lower 64 pixels), "B0/B1" = its first /
+//    second 32 channels: the LDS image of a K tile is four 16 KB half tiles laid out by *reader*, so that a half
+//    tile is dead for the whole workgroup one phase after it was read and can be re-staged while the rest of the
+//    buffer is still in use.  One half tile (2 LDS-DMA pieces per wave) is staged per phase; three half tiles
+//    stay in flight across the barriers behind the counted vmcnt(6) of phase 4.
+//  * The staging stream is decoupled from the output tile: it runs ahead across the end of the K loop into the
+//    next output tile of the persistent workgroup, so the DMA of the next tile's first two K tiles is already
+//    in flight when the epilogue starts.
+//  * Epilogue: bias / activation / residual in the accumulator layout, packed bf16 transposed through a
+//    wave-private 4 KB LDS strip so that every global store instruction writes 8 complete 128-byte lines
+//    (the accumulator layout itself gives 32 partial lines per instruction).
+//
+// Hazards (DMA write -> ds_read, ds_read -> DMA overwrite) are ordered by counted waits followed by a barrier
+// that every reader / writer passes; the derivation is in DESIGN.md ("gemm256p: phase schedule").
+#include "gemm_common.h"
+
+namespace {
+
+// One LDS-DMA piece: 64 lanes x 16 B from (scalar base + per-lane 32-bit byte offset) to LDS [m0 .. m0+1024).
+// Inline assembly on purpose: the compiler's wait-count pass must not see these (it would fence every following
+// ds_read with vmcnt(0)).  s_nop 3: five wait states between a VALU-written SGPR base and the VMEM that reads it.
+__device__ __forceinline__ void dma_piece(const void* base, uint32_t voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr)
+               : "memory");
+}
+
+template <int ACT>
+__global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
+  typedef bf16_t T;
+  constexpr int BKE = 64;                  // K elements per tile (128 bytes)
+  constexpr uint32_t HALF = 16384u;        // one half tile: 128 rows x 128 B
+  constexpr uint32_t BUF = 65536u;         // A0 | A1 | B0 | B1
+  constexpr uint32_t EPI = 131072u;        // 8 x 4 KB epilogue strips
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tiles_n = (p.N + 255) / 256;
+  const unsigned tiles_m = (unsigned)((p.M + 255) / 256);
+  const unsigned nblk = tiles_m * (unsigned)tiles_n;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // wave block: pixels [wm*128,+128) x channels [wn*64,+64)
+  const int l31 = lane & 31, g = lane >> 5;
+
+  const T* __restrict__ gA = reinterpret_cast<const T*>(p.A);
+  const T* __restrict__ gW = reinterpret_cast<const T*>(p.Wt);
+  T* __restrict__ gO = reinterpret_cast<T*>(p.out);
+  const T* __restrict__ gR = reinterpret_cast<const T*>(p.res);
+  const int HW = p.H * p.W;
+  const int Wp = p.W + 2 * p.in_pad;
+  const int P = p.out_pad;
+  const bool convt = p.out_mode == OUT_CONVT2X2;
+  const int nk = p.K / BKE;
+  const unsigned M32 = (unsigned)p.M;
+
+  // 3x3 convs: a 256-row tile is a 16x16 pixel patch when the image tiles evenly, else 256 consecutive pixels
+  const bool patch = p.ksize == 3 && (p.H % 16 == 0) && (p.W % 16 == 0);
+  const unsigned tiles_x = patch ? p.W / 16 : 1, tiles_img = patch ? (p.H / 16) * tiles_x : 1;
+  auto row_to_m = [&](unsigned m0, int row) -> unsigned {
+    if (!patch) return m0 + (unsigned)row;
+    const unsigned t = m0 >> 8;
+    const unsigned b = t / tiles_img;
+    const unsigned ti = t - b * tiles_img;
+    const unsigned ty = ti / tiles_x, tx = ti - ty * tiles_x;
+    return b * (unsigned)HW + (ty * 16 + ((unsigned)row >> 4)) * (unsigned)p.W + tx * 16 + ((unsigned)row & 15);
+  };
+  auto a_row_off = [&](unsigned m) -> int64_t {  // element offset of pixel / token row m in A
+    if (p.ksize == 3) {
+      const unsigned b = m / (unsigned)HW;
+      const unsigned rem = m - b * (unsigned)HW;
+      const unsigned oh = rem / (unsigned)p.W, ow = rem - oh * (unsigned)p.W;
+      return ((int64_t)(b * (unsigned)(p.H + 2) + oh) * Wp + ow) * p.lda;  // in_pad is required for ksize 3
+    }
+    return (int64_t)m * p.lda;
+  };
+
+  // ---- persistent workgroups, XCD-contiguous logical tile order (as gemm256_kernel) ----------------------
+  const unsigned nwg = gridDim.x;
+  const unsigned xcd = blockIdx.x % 8, wg_in_xcd = blockIdx.x / 8;
+  const unsigned wgs_this_xcd = nwg / 8 + (xcd < nwg % 8 ? 1 : 0);
+  const unsigned q_ = nblk / 8, r_ = nblk % 8;
+  const unsigned xcd_first = xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_;
+  const unsigned xcd_count = q_ + (xcd < r_ ? 1 : 0);
+  if (wg_in_xcd >= xcd_count) return;
+  auto tile_of = [&](unsigned w, unsigned& m0, int& n0) {
+    const unsigned lt = xcd_first + wg_in_xcd + w * wgs_this_xcd;
+    m0 = (lt / (unsigned)tiles_n) * 256u;
+    n0 = (int)(lt % (unsigned)tiles_n) * 256;
+  };
+  auto tile_exists = [&](unsigned w) -> bool { return wg_in_xcd + w * wgs_this_xcd < xcd_count; };
+
+  // ---- staging stream -------------------------------------------------------------------------------------
+  // Wave w fills physical rows [16w, 16w+16) of every half tile, 8 rows (1 KB) per piece; lane -> (row = 8j +
+  // lane/8, physical 16-byte slot = lane%8); the logical slot it fetches is physical ^ ((row>>1)&7).
+  // Physical row pr of half h holds:  A: tile row (pr>>6)*128 + h*64 + (pr&63)   B: channel (pr>>5)*64 + h*32 + (pr&31)
+  uint32_t a_off[2][2], b_off[2][2];  // byte offsets from the wave-uniform bases below
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pr = wave * 16 + j * 8 + (lane >> 3);
+      const int lslot = (lane & 7) ^ ((pr >> 1) & 7);
+      const int ch = (pr >> 5) * 64 + h * 32 + (pr & 31);
+      b_off[h][j] = (uint32_t)(((int64_t)ch * p.Kp + lslot * 8) * 2);
+    }
+  auto set_a_off = [&](unsigned m0, int64_t tileA) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int pr = wave * 16 + j * 8 + (lane >> 3);
+        const int lslot = (lane & 7) ^ ((pr >> 1) & 7);
+        const int row = (pr >> 6) * 128 + h * 64 + (pr & 63);
+        unsigned m = row_to_m(m0, row);
+        if (m >= M32) m = M32 - 1;  // rows past M are computed but never stored
+        a_off[h][j] = (uint32_t)((a_row_off(m) - tileA + lslot * 8) * 2);
+      }
+  };
+  // tiles whose per-lane offsets differ from the generic full tile: ragged last M tile, 3x3 without patch tiling
+  const bool a_off_varies = (p.ksize == 3 && !patch) || (M32 % 256u) != 0;
+
+  unsigned s_w = 0;            // stream: ordinal of the output tile being staged
+  int s_kt = 0, s_tap = 0, s_chunk = 0;
+  uint32_t s_par = 0;          // stream: LDS buffer of the K tile being staged
+  bool s_ok = true;            // stream not exhausted
+  int64_t s_tileA = 0, s_tileB = 0;
+  const T* sA = gA;
+  const T* sB = gW;
+  auto stream_bases = [&]() {
+    int64_t koff = (int64_t)s_kt * BKE;
+    if (p.ksize == 3) {  // K order: channel chunk major, 9 taps per chunk (korder 1)
+      const int kh = (s_tap * 11) >> 5, kw = s_tap - kh * 3;
+      koff = ((int64_t)kh * Wp + kw) * p.lda + s_chunk * BKE;
+    }
+    sA = gA + s_tileA + koff;
+    sB = gW + s_tileB + (int64_t)s_kt * BKE;
+  };
+  auto stream_open = [&](unsigned w, bool first) {
+    unsigned m0;
+    int n0;
+    tile_of(w, m0, n0);
+    s_tileA = a_row_off(row_to_m(m0, 0));
+    s_tileB = (int64_t)n0 * p.Kp;
+    if (first || a_off_varies) set_a_off(m0, s_tileA);
+  };
+  auto stream_advance = [&]() {
+    if (!s_ok) return;
+    ++s_kt;
+    if (++s_tap == 9) { s_tap = 0; ++s_chunk; }
+    if (s_kt == nk) {
+      s_kt = 0; s_tap = 0; s_chunk = 0;
+      ++s_w;
+      if (!tile_exists(s_w)) { s_ok = false; return; }
+      stream_open(s_w, false);
+    }
+    s_par ^= 1u;
+    stream_bases();
+  };
+  auto stream_advance_in_tile = [&]() {  // s_ok and s_kt + 1 < nk are known
+    ++s_kt;
+    if (++s_tap == 9) { s_tap = 0; ++s_chunk; }
+    s_par ^= 1u;
+    stream_bases();
+  };
+#define ESAM3_STAGE(HSEL)                                                              \
+  do {                                                                                 \
+    if (s_ok) {                                                                        \
+      const uint32_t dst_ = lds0 + s_par * BUF + (HSEL) * HALF + (uint32_t)wave * 2048u; \
+      if ((HSEL) < 2) {                                                                \
+        dma_piece(sA, a_off[(HSEL) & 1][0], dst_);                                     \
+        dma_piece(sA, a_off[(HSEL) & 1][1], dst_ + 1024u);                             \
+      } else {                                                                         \
+        dma_piece(sB, b_off[(HSEL) & 1][0], dst_);                                     \
+        dma_piece(sB, b_off[(HSEL) & 1][1], dst_ + 1024u);                             \
+      }                                                                                \
+    }                                                                                  \
+  } while (0)
+  // half selectors: 0 = A0, 1 = A1, 2 = B0, 3 = B1 (also the order of the half tiles inside a buffer)
+
+  // ---- fragment read addresses (per lane, without the buffer base) ---------------------------------------
+  uint32_t rdA[4], rdB[4];
+#pragma unroll
+  for (int ck = 0; ck < 4; ++ck) {
+    rdA[ck] = (uint32_t)((wm * 64 + l31) * 128 + swz(l31, ck * 2 + g));
+    rdB[ck] = (uint32_t)(2 * HALF + (wn * 32 + l31) * 128 + swz(l31, ck * 2 + g));
+  }
+
+  // ---- prologue: K tiles 0 and 1 (minus its A1) of the first output tile ----------------------------------
+  stream_open(0, true);
+  stream_bases();
+  ESAM3_STAGE(2); ESAM3_STAGE(0); ESAM3_STAGE(3); ESAM3_STAGE(1);
+  stream_advance();
+  ESAM3_STAGE(2); ESAM3_STAGE(0); ESAM3_STAGE(3);
+  if (s_ok) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  uint32_t c_par = 0;  // compute: LDS buffer of the current K tile
+  char* const epi = smem + EPI + wave * 4096;
+
+  for (unsigned w = 0;; ++w) {
+    unsigned m0;
+    int n0;
+    tile_of(w, m0, n0);
+    const bool has_next = tile_exists(w + 1);
+
+    f32x16_v acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
+
+#define ESAM3_LDS16(OFF) (*reinterpret_cast<const u32x4*>(lbuf + (OFF)))
+// The MFMA builtins are pure values to the compiler: without the two register pins it sinks them below the
+// closing barrier (and below the next phase's ds_reads).  s_setprio sits outside the pins for the same reason.
+#define ESAM3_MFMA8(FW, I0, J)                                                       \
+  do {                                                                               \
+    __builtin_amdgcn_s_barrier();                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                   \
+    asm volatile("" : "+v"(acc[(I0)][(J)]), "+v"(acc[(I0) + 1][(J)]));               \
+    _Pragma("unroll") for (int ck = 0; ck < 4; ++ck) {                               \
+      MmaOps<T>::mma(FW[ck], fa[0][ck], acc[(I0)][(J)]);                             \
+      MmaOps<T>::mma(FW[ck], fa[1][ck], acc[(I0) + 1][(J)]);                         \
+    }                                                                                \
+    asm volatile("" : "+v"(acc[(I0)][(J)]), "+v"(acc[(I0) + 1][(J)]));               \
+    __builtin_amdgcn_s_setprio(0);                                                   \
+    __builtin_amdgcn_s_barrier();                                                    \
+  } while (0)
+// One K tile = four phases.  ADVANCE moves the staging stream to the K tile two ahead of the one being computed.
+#define ESAM3_KTILE(ADVANCE)                                                         \
+  do {                                                                               \
+    const char* lbuf = smem + c_par * BUF;                                           \
+    /* ---- phase 1: B0 + A0 -> acc[0..1][0]; stage A1 of K tile t+1 ---- */         \
+    _Pragma("unroll") for (int ck = 0; ck < 4; ++ck) fb0[ck] = ESAM3_LDS16(rdB[ck]); \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    _Pragma("unroll") for (int ck = 0; ck < 4; ++ck) {                               \
+      fa[0][ck] = ESAM3_LDS16(rdA[ck]);                                              \
+      fa[1][ck] = ESAM3_LDS16(rdA[ck] + 4096u);                                      \
+    }                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    ESAM3_STAGE(1);                                                                  \
+    /* the B0 reads (issued first) have returned: the other group may re-stage B0 in the next interval */ \
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                               \
+    ESAM3_MFMA8(fb0, 0, 0);                                                          \
+    /* ---- phase 2: B1 -> acc[0..1][1]; stage B0 of K tile t+2 ---- */              \
+    _Pragma("unroll") for (int ck = 0; ck < 4; ++ck) fb1[ck] = ESAM3_LDS16(rdB[ck] + HALF); \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    ADVANCE;                                                                         \
+    ESAM3_STAGE(2);                                                                  \
+    ESAM3_MFMA8(fb1, 0, 1);                                                          \
+    /* ---- phase 3: A1 (into A0's registers) -> acc[2..3][1]; stage A0 of K tile t+2 ---- */ \
+    _Pragma("unroll") for (int ck = 0; ck < 4; ++ck) {                               \
+      fa[0][ck] = ESAM3_LDS16(rdA[ck] + HALF);                                       \
+      fa[1][ck] = ESAM3_LDS16(rdA[ck] + HALF + 4096u);                               \
+    }                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                               \
+    ESAM3_STAGE(0);                                                                  \
+    ESAM3_MFMA8(fb1, 2, 1);                                                          \
+    /* ---- phase 4: no reads -> acc[2..3][0]; stage B1 of K tile t+2; K tile t+1 has landed ---- */ \
+    ESAM3_STAGE(3);                                                                  \
+    if (s_ok) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                       \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            \
+    ESAM3_MFMA8(fb0, 2, 0);                                                          \
+    c_par ^= 1u;                                                                     \
+  } while (0)
+
+    u32x4 fa[2][4], fb0[4], fb1[4];
+    // steady state: the stream stays inside this output tile (K tile kt+2 exists)
+    for (int kt = 0; kt < nk - 2; ++kt) ESAM3_KTILE(stream_advance_in_tile());
+    // last two K tiles: the stream crosses into the next output tile (or ends)
+    ESAM3_KTILE(stream_advance());
+    ESAM3_KTILE(stream_advance());
+#undef ESAM3_KTILE
+#undef ESAM3_MFMA8
+#undef ESAM3_LDS16
+    if (wm == 0) __builtin_amdgcn_s_barrier();  // both groups leave the K loop behind the same barrier
+
+    // =========================== epilogue ===========================
+    const int nbw = n0 + wn * 64;  // first channel of this wave's 64-channel block (wave-uniform)
+    if (nbw < p.N) {
+      // channel-direction part of the addresses (a 64-channel block never straddles a ConvT tap: Cout % 64 == 0)
+      int64_t ocol = nbw, rcol = nbw;
+      int bias_n = nbw;
+      if (convt) {
+        const int tap = nbw / p.convt_cout, co = nbw - tap * p.convt_cout;
+        const int OWp = 2 * p.W + 2 * P;
+        ocol = ((int64_t)(tap >> 1) * OWp + (tap & 1)) * p.ldc + co;
+        rcol = ((int64_t)(tap >> 1) * (2 * p.W) + (tap & 1)) * p.ldr + co;
+        bias_n = co;
+      }
+      // residual rows in the accumulator layout (lane's own pixel l31 of block i)
+      int64_t rbase[4];
+      bool rok[4];
+      if (gR) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned m = row_to_m(m0, wm * 128 + i * 32 + l31);
+          rok[i] = m < M32;
+          const unsigned mm = rok[i] ? m : 0u;
+          const unsigned b = mm / (unsigned)HW;
+          const unsigned rem = mm - b * (unsigned)HW;
+          if (convt) {
+            const unsigned h = rem / (unsigned)p.W, ww = rem - h * (unsigned)p.W;
+            const unsigned rb = p.res_bidx ? (unsigned)p.res_bidx[b] : b;
+            rbase[i] = ((int64_t)(rb * 2u * p.H + 2 * h) * (2 * p.W) + 2 * ww) * p.ldr;
+          } else {
+            unsigned rrow = mm;
+            if (p.res_mod > 0) rrow = mm % (unsigned)p.res_mod;
+            else if (p.res_bidx) rrow = (unsigned)p.res_bidx[b] * (unsigned)HW + rem;
+            rbase[i] = (int64_t)rrow * p.ldr;
+          }
+        }
+      }
+      // store side: lane -> (pixel 8k + lane/8 of the 32-pixel block, 16-byte chunk lane%8 of its 128-byte row)
+      const int sp = lane >> 3, sc = lane & 7;
+      // pixel walker for the store rows R = wm*128 + 8*s + sp, s = 0..15
+      const int omode = patch ? 0 : ((!convt && !P) ? 1 : 2);
+      unsigned pb = 0, ph = 0, pw = 0;  // omode 2: (image, row, column) of the current store row
+      int64_t tile_o = 0;               // omode 0: offset of the patch origin (+ lane part)
+      unsigned mrow = m0 + (unsigned)(wm * 128 + sp);
+      if (omode == 0) {
+        const unsigned t = m0 >> 8;
+        const unsigned b = t / tiles_img;
+        const unsigned ti = t - b * tiles_img;
+        const unsigned ty = ti / tiles_x, tx = ti - ty * tiles_x;
+        const int64_t pitch = (int64_t)(p.W + 2 * P);
+        tile_o = (((int64_t)b * (p.H + 2 * P) + ty * 16 + P + wm * 8) * pitch + tx * 16 + P + sp) * p.ldc;
+      } else if (omode == 2) {
+        pb = mrow / (unsigned)HW;
+        const unsigned rem = mrow - pb * (unsigned)HW;
+        ph = rem / (unsigned)p.W;
+        pw = rem - ph * (unsigned)p.W;
+      }
+      float4 bq[2][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          bq[j][q] = p.bias ? *reinterpret_cast<const float4*>(p.bias + bias_n + j * 32 + 8 * q + 4 * g)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float v[16], r16[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float r4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (gR && rok[i]) {
+              const uint2 u = *reinterpret_cast<const uint2*>(gR + rbase[i] + rcol + j * 32 + 8 * q + 4 * g);
+              r4[0] = __uint_as_float(u.x << 16); r4[1] = __uint_as_float(u.x & 0xffff0000u);
+              r4[2] = __uint_as_float(u.y << 16); r4[3] = __uint_as_float(u.y & 0xffff0000u);
+            }
+            const float bb[4] = {bq[j][q].x, bq[j][q].y, bq[j][q].z, bq[j][q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              r16[4 * q + e] = r4[e];
+              v[4 * q + e] = acc[i][j][4 * q + e] + bb[e] + (p.res_after_act ? 0.f : r4[e]);
+            }
+          }
+          act_apply_n<16>(v, ACT);
+          if (p.res_after_act && gR) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] += r16[e];
+          }
+#pragma unroll
+          for (int qp = 0; qp < 2; ++qp) {
+            const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]);
+            const uint32_t a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
+            const uint32_t b0 = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]);
+            const uint32_t b1 = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
+            // half-wave exchange: lanes 0-31 end with channels 16qp..16qp+7, lanes 32-63 with +8..+15
+            auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+            const int c = j * 4 + qp * 2 + g;  // 16-byte chunk of pixel l31's 128-byte row
+            *reinterpret_cast<u32x4*>(epi + l31 * 128 + ((c ^ (l31 & 7)) << 4)) = o;
+          }
+        }
+        // rows back out of the strip: 8 complete 128-byte lines per store instruction
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const u32x4 o = *reinterpret_cast<const u32x4*>(epi + (8 * k + sp) * 128 + ((sc ^ sp) << 4));
+          const int s = i * 4 + k;
+          int64_t off;
+          bool ok = true;
+          if (omode == 0) {
+            off = tile_o + ((int64_t)(s >> 1) * (p.W + 2 * P) + (s & 1) * 8) * p.ldc;
+          } else if (omode == 1) {
+            ok = mrow < M32;
+            off = (int64_t)mrow * p.ldc;
+          } else {
+            ok = mrow < M32;
+            off = convt ? ((int64_t)(pb * (unsigned)(2 * p.H + 2 * P) + 2 * ph + P) * (2 * p.W + 2 * P) + 2 * pw + P) * p.ldc
+                        : ((int64_t)(pb * (unsigned)(p.H + 2) + ph + 1) * (p.W + 2) + pw + 1) * p.ldc;
+          }
+          if (ok) *reinterpret_cast<u32x4*>(gO + off + ocol + sc * 8) = o;
+          // next store row: + 8 pixels
+          mrow += 8;
+          if (omode == 2) {
+            pw += 8;
+            while (pw >= (unsigned)p.W) { pw -= (unsigned)p.W; ++ph; }
+            while (ph >= (unsigned)p.H) { ph -= (unsigned)p.H; ++pb; }
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+  }
+#undef ESAM3_STAGE
+}
+
+}  // namespace
+
+bool esam3_gemm256p_ok(const GemmParams& p) {
+  // the caller has already checked the gemm256 conditions (use_256); what this kernel needs on top of them
+  if (p.K < 128) return false;
+  if (p.N % 64 != 0) return false;
+  if (p.out_mode == OUT_CONVT2X2 && p.convt_cout % 64 != 0) return false;
+  if (p.ksize == 3 && !p.korder) return false;
+  if ((((uintptr_t)p.out) & 15) || (((uintptr_t)p.A) & 15) || (((uintptr_t)p.Wt) & 15)) return false;
+  if (p.bias && (((uintptr_t)p.bias) & 15)) return false;
+  return true;
+}
+
+int esam3_launch_gemm256p(const GemmParams& p, hipStream_t stream) {
+  constexpr size_t lds = 163840;  // 2 x 64 KB K-tile buffers + 8 x 4 KB epilogue strips = all of a CU's LDS
+  static bool attr_set = false;
+  void (*kerns[5])(GemmParams) = {gemm256p_kernel<ACT_NONE>, gemm256p_kernel<ACT_RELU>, gemm256p_kernel<ACT_GELU>,
+                                  gemm256p_kernel<ACT_HSWISH>, gemm256p_kernel<ACT_SIGMOID>};
+  if (p.act < 0 || p.act > 4) { esam3_set_error("gemm: bad activation %d", p.act); return -1; }
+  if (!attr_set) {
+    for (auto k : kerns)
+      HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds));
+    attr_set = true;
+  }
+  const int64_t tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HIP_CHECK_RET(hipGetDevice(&dev));
+    HIP_CHECK_RET(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int64_t grid = tiles < n_cu ? tiles : n_cu;  // persistent: one workgroup per CU
+  hipLaunchKernelGGL(kerns[p.act], dim3((unsigned)grid), dim3(512), lds, stream, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}

@@ -31,6 +31,10 @@
 
 #include "gemm_common.h"
 
+// gemm256p.hip
+bool esam3_gemm256p_ok(const GemmParams& p);
+int esam3_launch_gemm256p(const GemmParams& p, hipStream_t stream);
+
 namespace {
 
 // ======================================================================================
@@ -255,12 +259,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 // ACT is a compile-time parameter: with a run-time activation switch the fully unrolled
 // epilogue carries every activation's code 128 times (28k instructions) and stalls on the
 // instruction cache.
-// V2 (ESAM3_GEMM256_V2=1, experimental, off by default): the same tile and fragment scheme with (a) the LDS-DMA pieces
-// issued by inline assembly from a scalar tile base + 32-bit per-lane byte offsets, so that the compiler's wait-count
-// pass does not fence the ds_reads behind them, (b) ONE barrier per K tile and (c) the pieces of tile kt+1 issued
-// inside the compute phase of tile kt, one after every second MFMA of the first two K chunks (ISA
-// analysis).  Parity-tested; not yet measured against V1, which is why V1 stays the default.
-template <typename T, int ACT, bool V2>
+template <typename T, int ACT>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   constexpr int BM = 256, BN = 256;
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -316,9 +315,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   // ---- DMA descriptors: wave w fills tile rows [32w, 32w+32) of A and of B, 8 rows (1 KB)
   //      per instruction; lane -> (row = 8j + lane/8, physical slot = lane%8); the logical slot
   //      it fetches is physical ^ ((row>>1)&7)  (source-side swizzle).
-  int64_t a_src[4], b_src[4];          // V1: element offsets from gA / gW
-  uint32_t a_off[4], b_off[4];         // V2: byte offsets from the scalar tile bases below
-  int64_t tileA = 0, tileB = 0;        // V2: element offset of the tile's first row / first weight row (wave-uniform)
+  int64_t a_src[4], b_src[4];          // element offsets from gA / gW
   const unsigned M32 = (unsigned)p.M;
   auto a_row_off = [&](unsigned m) -> int64_t {  // element offset of pixel / token row m in A
     if (p.ksize == 3) {
@@ -330,12 +327,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     return (int64_t)m * p.lda;
   };
   auto setup = [&](unsigned m0, int n0) {
-    if constexpr (V2) {
-      // row 0 of a tile has the smallest offset of the tile (top-left pixel of a patch / first row), so the per-lane
-      // offsets are small non-negative numbers whatever the size of the tensor
-      tileA = a_row_off(row_to_m(m0, 0));
-      tileB = (int64_t)n0 * p.Kp;
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = wave * 32 + j * 8 + (lane >> 3);
@@ -343,42 +334,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
       unsigned m = row_to_m(m0, row);
       if (m >= M32) m = M32 - 1;  // clamp: rows past M are computed but never stored
       const int64_t off = a_row_off(m);
-      if constexpr (V2) {
-        a_off[j] = (uint32_t)((off - tileA + lslot * EPC) * (int64_t)sizeof(T));
-        b_off[j] = (uint32_t)(((int64_t)row * p.Kp + lslot * EPC) * (int64_t)sizeof(T));
-      } else {
-        a_src[j] = off + lslot * EPC;
-        b_src[j] = (int64_t)(n0 + row) * p.Kp + lslot * EPC;
-      }
+      a_src[j] = off + lslot * EPC;
+      b_src[j] = (int64_t)(n0 + row) * p.Kp + lslot * EPC;
     }
   };
 
-  // V2: one LDS-DMA piece = 8 tile rows (1 KB): scalar base + per-lane 32-bit byte offset, destination in M0
-  auto piece = [&](const void* base, uint32_t voff, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory");
-  };
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  // bases of K tile KT: A shifted by the tap / channel chunk, B by KT*BKE (all wave-uniform)
-#define ESAM3_TILE_BASES(KT)                                                          \
-  int64_t koff_ = (int64_t)(KT) * BKE;                                                \
-  if (p.ksize == 3) {                                                                 \
-    int tap_, c0_;                                                                    \
-    if (p.korder) { const int ch_ = (KT) / 9; tap_ = (KT) - ch_ * 9; c0_ = ch_ * BKE; } \
-    else { const int k0_ = (KT) * BKE; tap_ = k0_ / p.Cin; c0_ = k0_ - tap_ * p.Cin; } \
-    const int kh_ = tap_ / 3, kw_ = tap_ - kh_ * 3;                                   \
-    koff_ = ((int64_t)kh_ * Wp + kw_) * p.lda + c0_;                                  \
-  }                                                                                   \
-  const T* baseA_ = gA + tileA + koff_;                                               \
-  const T* baseB_ = gW + tileB + (int64_t)(KT) * BKE;                                 \
-  const uint32_t ldsA_ = lds0 + (uint32_t)(((KT) & 1) * STAGE + wave * 32 * 128);     \
-  const uint32_t ldsB_ = ldsA_ + BM * 128;
-#define ESAM3_PIECE(J)                                                                \
-  do {                                                                                \
-    if ((J) < 4) piece(baseA_, a_off[(J)], ldsA_ + (J) * 1024);                         \
-    else piece(baseB_, b_off[(J) - 4], ldsB_ + ((J) - 4) * 1024);                       \
-  } while (0)
-
-#define ESAM3_ISSUE_TILE_V1(KT)                                                          \
+#define ESAM3_ISSUE_TILE(KT)                                                             \
   do {                                                                                \
     char* sa_ = smem + ((KT) & 1) * STAGE + wave * 32 * 128;                          \
     char* sb_ = sa_ + BM * 128;                                                       \
@@ -394,16 +355,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
         glds16(gA + a_src[j_] + koff_, sa_ + j_ * 1024);                              \
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                  \
         glds16(gW + b_src[j_] + (int64_t)(KT) * BKE, sb_ + j_ * 1024);                \
-  } while (0)
-
-#define ESAM3_ISSUE_TILE(KT)                                                          \
-  do {                                                                                \
-    if constexpr (V2) {                                                               \
-      ESAM3_TILE_BASES(KT)                                                            \
-      _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) ESAM3_PIECE(j_);                \
-    } else {                                                                          \
-      ESAM3_ISSUE_TILE_V1(KT);                                                        \
-    }                                                                                 \
   } while (0)
 
   int64_t w = 0;
@@ -428,50 +379,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if constexpr (V2) {
-      // One barrier per K tile: a wave arrives with its own pieces of tile kt landed (issued a whole tile earlier)
-      // and its ds_reads of tile kt-1 consumed by MFMAs, so afterwards every piece of tile kt is visible and the other
-      // buffer is free for the pieces of tile kt+1, which are issued between the MFMAs of K chunks 0 and 1.
-#define ESAM3_LOAD_FRAGS2(CK, BUF)                                                             \
-  do {                                                                                         \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                          \
-      const int row_ = wm * 128 + i_ * 32 + l31;                                               \
-      fa[BUF][i_] = *reinterpret_cast<const u32x4*>(la + row_ * 128 + swz(row_, (CK) * 2 + g)); \
-    }                                                                                          \
-    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                          \
-      const int row_ = wn * 64 + j_ * 32 + l31;                                                \
-      fw[BUF][j_] = *reinterpret_cast<const u32x4*>(lb + row_ * 128 + swz(row_, (CK) * 2 + g)); \
-    }                                                                                          \
-  } while (0)
-      for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const char* la = smem + (kt & 1) * STAGE;
-        const char* lb = la + BM * 128;
-        const bool more = kt + 1 < nk;
-        ESAM3_TILE_BASES(more ? kt + 1 : kt)
-        u32x4 fa[2][4], fw[2][2];
-        ESAM3_LOAD_FRAGS2(0, 0);
-#pragma unroll
-        for (int ck = 0; ck < 4; ++ck) {
-          if (ck < 3) ESAM3_LOAD_FRAGS2(ck + 1, (ck + 1) & 1);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            MmaOps<T>::mma(fw[ck & 1][0], fa[ck & 1][i], acc[i][0]);
-            MmaOps<T>::mma(fw[ck & 1][1], fa[ck & 1][i], acc[i][1]);
-            if (ck < 2 && more) ESAM3_PIECE(ck * 4 + i);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-#undef ESAM3_LOAD_FRAGS2
-      // every read of the last K tile has been consumed; nobody may still read buffer 0 when the next output
-      // tile's first K tile is DMA'd into it
-      __builtin_amdgcn_s_barrier();
-    } else {
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk && !(p.debug & 2)) {
+        if (kt + 1 < nk) {
           ESAM3_ISSUE_TILE(kt + 1);
           asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile kt landed; tile kt+1 stays in flight
         } else {
@@ -498,31 +407,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
   #pragma unroll
         for (int ck = 0; ck < 4; ++ck) {
           if (ck < 3) ESAM3_LOAD_FRAGS(ck + 1, (ck + 1) & 1);
-          if (!(p.debug & 4)) {
   #pragma unroll
-            for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
   #pragma unroll
-              for (int j = 0; j < 2; ++j) MmaOps<T>::mma(fw[ck & 1][j], fa[ck & 1][i], acc[i][j]);
-          } else {
-  #pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fa[ck & 1][i]));
-  #pragma unroll
-            for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(fw[ck & 1][j]));
-          }
+            for (int j = 0; j < 2; ++j) MmaOps<T>::mma(fw[ck & 1][j], fa[ck & 1][i], acc[i][j]);
         }
   #undef ESAM3_LOAD_FRAGS
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all ds_reads of this buffer retired
         __builtin_amdgcn_s_barrier();                      // before anybody's DMA overwrites it
       }
-  
-    }
 
     // ---- output descriptors of THIS tile (before the DMA descriptors move on) ---------------
     int64_t obase[4], rbase[4];
     bool rok[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const unsigned m = row_to_m((p.debug & 32) ? 0u : m0, wm * 128 + i * 32 + l31);
+      const unsigned m = row_to_m(m0, wm * 128 + i * 32 + l31);
       rok[i] = m < M32;
       const unsigned mm = rok[i] ? m : 0u;
       const unsigned b = mm / (unsigned)HW;
@@ -552,12 +452,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     // 8q + 4g + {0..3}.  bias / residual / activation are applied in fp32; bf16 outputs are then
     // packed and the two half-waves exchange their halves (v_permlane32_swap) so that each lane
     // stores 8 consecutive channels = 16 bytes.
-    if (p.debug & 1) {  // development: keep ALL accumulators alive, store nothing
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
-    } else {
+    {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int nb = n0 + wn * 64 + j * 32;  // first channel of this 32-wide block (wave-uniform)
@@ -616,9 +511,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
               // half-wave exchange: lanes 0-31 end with channels 16qp..16qp+7, lanes 32-63 with +8..+15
               auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
               auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-              if (p.debug & 16) {
-                asm volatile("" ::"v"(s0), "v"(s1));
-              } else if (rok[i]) {
+              if (rok[i]) {
                 u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
                 *reinterpret_cast<u32x4*>(op + 16 * qp + 8 * g) = o;
               }
@@ -636,9 +529,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmParams p) {
     if (!has_next) break;
   }
 #undef ESAM3_ISSUE_TILE
-#undef ESAM3_ISSUE_TILE_V1
-#undef ESAM3_PIECE
-#undef ESAM3_TILE_BASES
 }
 
 // ======================================================================================
@@ -814,14 +704,10 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 
 template <typename T>
 int launch_256(const GemmParams& p, hipStream_t stream) {
-  constexpr size_t lds = 2 * (size_t)(256 + 256) * 128;  // 128 KB (epilogue needs 66.5 KB)
+  constexpr size_t lds = 2 * (size_t)(256 + 256) * 128;  // 128 KB
   static bool attr_set = false;
-  static const bool v2 = getenv("ESAM3_GEMM256_V2") != nullptr && atoi(getenv("ESAM3_GEMM256_V2")) != 0;
-  void (*kerns[10])(GemmParams) = {gemm256_kernel<T, ACT_NONE, false>, gemm256_kernel<T, ACT_RELU, false>,
-                                   gemm256_kernel<T, ACT_GELU, false>, gemm256_kernel<T, ACT_HSWISH, false>,
-                                   gemm256_kernel<T, ACT_SIGMOID, false>, gemm256_kernel<T, ACT_NONE, true>,
-                                   gemm256_kernel<T, ACT_RELU, true>, gemm256_kernel<T, ACT_GELU, true>,
-                                   gemm256_kernel<T, ACT_HSWISH, true>, gemm256_kernel<T, ACT_SIGMOID, true>};
+  void (*kerns[5])(GemmParams) = {gemm256_kernel<T, ACT_NONE>, gemm256_kernel<T, ACT_RELU>, gemm256_kernel<T, ACT_GELU>,
+                                  gemm256_kernel<T, ACT_HSWISH>, gemm256_kernel<T, ACT_SIGMOID>};
   if (p.act < 0 || p.act > 4) { esam3_set_error("gemm: bad activation %d", p.act); return -1; }
   if (!attr_set) {
     for (auto k : kerns)
@@ -829,7 +715,7 @@ int launch_256(const GemmParams& p, hipStream_t stream) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  auto kern = kerns[p.act + (v2 ? 5 : 0)];
+  auto kern = kerns[p.act];
   const int64_t tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   static int n_cu = 0;
   if (!n_cu) {
@@ -861,16 +747,21 @@ bool use_256(const GemmParams& p) {
 thread_local const char* g_last_kernel = nullptr;  // name of the kernel the last launch chose (profiler)
 
 template <typename T>
-int launch_gemm_t(const GemmParams& p, hipStream_t stream, int force_small) {
+int launch_gemm_t(const GemmParams& p, hipStream_t stream) {
   constexpr bool bf = sizeof(T) == 2;
-  if (!force_small && use_256<T>(p)) {
-    static const bool v2 = getenv("ESAM3_GEMM256_V2") != nullptr && atoi(getenv("ESAM3_GEMM256_V2")) != 0;
-    g_last_kernel = bf ? (v2 ? "gemm256_kernel<bf16, V2> (256x256x64, asm LDS-DMA interleaved, one barrier per K tile)"
-                             : "gemm256_kernel<bf16> (256x256x64, 8 waves, glds double buffer, persistent)")
-                       : "gemm256_kernel<f32>";
+  if (use_256<T>(p)) {
+    if constexpr (bf) {
+      // ESAM3_GEMM256_CLASSIC=1 keeps the two-barrier kernel for A/B timing (tools/bench_gemm.py)
+      static const bool classic = getenv("ESAM3_GEMM256_CLASSIC") != nullptr && atoi(getenv("ESAM3_GEMM256_CLASSIC")) != 0;
+      if (!classic && esam3_gemm256p_ok(p)) {
+        g_last_kernel = "gemm256p_kernel<bf16> (256x256x64, 8 waves in 2 staggered groups, 4 phases per K tile, LDS-DMA)";
+        return esam3_launch_gemm256p(p, stream);
+      }
+    }
+    g_last_kernel = bf ? "gemm256_kernel<bf16> (256x256x64, 8 waves, glds double buffer, persistent)" : "gemm256_kernel<f32>";
     return launch_256<T>(p, stream);
   }
-  if (!(force_small & 2)) {
+  {
     bool done = false;
     const int rc = try_thin<T>(p, stream, &done);
     if (done) g_last_kernel = bf ? "thin_gemm_kernel<bf16> (LDS-free, weights in registers)" : "thin_gemm_kernel<f32>";
@@ -911,13 +802,6 @@ const char* esam3_take_last_gemm_kernel() {
 
 int esam3_launch_gemm(int dtype /*0 f32, 1 bf16*/, const GemmParams& p, hipStream_t stream) {
   if (p.M >= ((int64_t)1 << 31)) { esam3_set_error("gemm: M=%lld rows exceed the 32-bit pixel index", (long long)p.M); return -1; }
-  static const int force_small = getenv("ESAM3_GEMM_SMALL") ? atoi(getenv("ESAM3_GEMM_SMALL")) : 0;
-  static const int dbg = getenv("ESAM3_GEMM_DEBUG") ? atoi(getenv("ESAM3_GEMM_DEBUG")) : 0;
-  if (dbg) {
-    GemmParams q = p;
-    q.debug = dbg;
-    return dtype == 0 ? launch_gemm_t<float>(q, stream, force_small) : launch_gemm_t<bf16_t>(q, stream, force_small);
-  }
-  return dtype == 0 ? launch_gemm_t<float>(p, stream, force_small)
-                    : launch_gemm_t<bf16_t>(p, stream, force_small);
+  return dtype == 0 ? launch_gemm_t<float>(p, stream)
+                    : launch_gemm_t<bf16_t>(p, stream);
 }

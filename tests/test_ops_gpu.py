@@ -499,3 +499,59 @@ def test_mha_core(path, mode, B, Nq, Hk, Wk, masked, biased):
                                  U.P(km_d) if masked else None, U.P(by_d) if biased else None,
                                  U.P(bx_d) if biased else None, Hk, Wk, 1 if biased else 0, None), "op_mha")
     U.assert_close(out.float().cpu(), ref, mode, f"mha path={path} Nq={Nq} Nk={Nk}")
+
+
+# ---- the phase-interleaved 256x256 kernel at sizes where every workgroup walks several output tiles ---------------
+@pytest.mark.parametrize("case", ["neck_l0_3x3", "conv3x3_k576_padded_out", "linear_ragged_gelu_res", "convt_big"])
+def test_gemm256p_many_tiles(case):
+    """gemm256p_kernel (bf16) with more output tiles than CUs: the staging stream crosses output tiles, the persistent
+    loop re-uses both LDS buffers and the epilogue strips.  Two launches must agree bit for bit (no race) and match
+    the fp32 reference (necks.py:42-92 shapes, vitdet.py:585-590 MLP shape)."""
+    d, tdt = U.DT["bf16"]
+    lib = U.lib()
+    if case in ("neck_l0_3x3", "conv3x3_k576_padded_out"):
+        B, H, W, Cin, Cout, out_pad = (1, 288, 288, 256, 256, 0) if case == "neck_l0_3x3" else (3, 160, 160, 64, 256, 1)
+        x = _rand(B, Cin, H, W, seed=1)
+        w = _rand(Cout, Cin, 3, 3, seed=2) / (Cin * 9) ** 0.5
+        b = _rand(Cout, seed=3) * 0.1
+        ref = F.conv2d(_q(x, "bf16"), _q(w, "bf16"), b, padding=1)
+        xp = F.pad(x, (1, 1, 1, 1)).permute(0, 2, 3, 1).contiguous().to("cuda", tdt)
+        outs = []
+        for _ in range(2):
+            out = torch.full((B, H + 2 * out_pad, W + 2 * out_pad, Cout), 7.0, dtype=tdt, device="cuda")
+            U.check(lib.esam3_op_conv3x3_padded(d, U.P(xp), U.H(U.np32(w)), U.H(U.np32(b)), U.P(out), B, H, W, Cin,
+                                                Cout, 0, out_pad, None), "op_conv3x3_padded")
+            outs.append(out.float().cpu())
+        got = outs[0][:, 1:-1, 1:-1] if out_pad else outs[0]
+        if out_pad:
+            assert float(outs[0][:, 0].abs().max()) == 0 and float(outs[0][:, :, -1].abs().max()) == 0
+        got = got.permute(0, 3, 1, 2)
+    elif case == "linear_ragged_gelu_res":
+        M, N, K = 20000, 4736, 1024
+        a, w, b = _rand(M, K, seed=1), _rand(N, K, seed=2) / K ** 0.5, _rand(N, seed=3) * 0.1
+        r = _rand(M, N, seed=4)
+        ref = F.gelu(F.linear(_q(a, "bf16"), _q(w, "bf16"), b)) + _q(r, "bf16")
+        a_d, r_d = a.to("cuda", tdt), r.to("cuda", tdt)
+        outs = []
+        for _ in range(2):
+            out = torch.empty((M, N), dtype=tdt, device="cuda")
+            U.check(lib.esam3_op_linear(d, U.P(a_d), U.H(U.np32(w)), U.H(U.np32(b)), U.P(r_d), U.P(out), M, N, K,
+                                        U.ACT["gelu"], None), "op_linear")
+            outs.append(out.float().cpu())
+        got = outs[0]
+    else:
+        B, H, W, Cin, Cout = 4, 72, 72, 1024, 512
+        x = _rand(B, Cin, H, W, seed=1)
+        w = _rand(Cin, Cout, 2, 2, seed=2) / Cin ** 0.5
+        b = _rand(Cout, seed=3) * 0.1
+        ref = F.gelu(F.conv_transpose2d(_q(x, "bf16"), _q(w, "bf16"), b, stride=2))
+        x_d = U.to_dev_nhwc(x, tdt)
+        outs = []
+        for _ in range(2):
+            out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=tdt, device="cuda")
+            U.check(lib.esam3_op_conv_transpose2x2(d, U.P(x_d), U.H(U.np32(w)), U.H(U.np32(b)), None, U.P(out), B, H, W,
+                                                   Cin, Cout, U.ACT["gelu"], 1, None), "op_convT")
+            outs.append(out.float().cpu())
+        got = U.from_dev_nhwc(out)
+    assert torch.equal(outs[0], outs[1]), "two launches differ: race in the staging pipeline"
+    U.assert_close(got, ref, "bf16", f"gemm256p {case}")

@@ -1,4 +1,7 @@
-"""Development aid: time the implicit-GEMM kernels on the neck/head shapes (B=32)."""
+"""Development aid: time the implicit-GEMM kernels on the neck / head / ViT-H shapes.
+
+    python tools/bench_gemm.py [substring]          # ESAM3_GEMM256_CLASSIC=1 selects the two-barrier kernel (A/B)
+"""
 import ctypes as C
 import os
 import sys
@@ -15,10 +18,15 @@ SHAPES = [  # name, B, H, W, Cin, N, ksize, convt
     ("neck L1 convT' 1024->256 @72", 32, 72, 72, 1024, 1024, 1, 1),
     ("neck L2 1x1 1024->256 @72", 32, 72, 72, 1024, 256, 1, 0),
     ("sam2 L0 3x3 256->32 @288", 32, 288, 288, 256, 32, 3, 0),
+    ("ViT-H qkv 1024->3072 (B=8)", 8, 72, 72, 1024, 3072, 1, 0),
+    ("ViT-H proj 1024->1024", 8, 72, 72, 1024, 1024, 1, 0),
+    ("ViT-H fc1 1024->4736", 8, 72, 72, 1024, 4736, 1, 0),
+    ("ViT-H fc2 4736->1024", 8, 72, 72, 4736, 1024, 1, 0),
 ]
 lib = C.CDLL(_lib.LIB_PATH)
 lib.esam3_bench_gemm.argtypes = [C.c_int] * 9 + [C.POINTER(C.c_float)]
 only = sys.argv[1] if len(sys.argv) > 1 else None
+print("kernel:", "gemm256 (classic)" if os.environ.get("ESAM3_GEMM256_CLASSIC", "0") not in ("", "0") else "gemm256p", flush=True)
 for name, B, H, W, Cin, N, ks, ct in SHAPES:
     if only and only not in name:
         continue
