@@ -28,6 +28,20 @@
 // that every reader / writer passes; the derivation is in DESIGN.md ("gemm256p: phase schedule").
 #include "gemm_common.h"
 
+#ifdef ESAM3_P_TRACE  /* dev build only (tools/dev_variants.sh): cycle stamps of workgroups 0-7, waves 0 and 4 */
+__device__ unsigned long long g_trace[8 * 2 * 16 * 16];
+#define ESAM3_TRACE(PT)                                                                              \
+  do {                                                                                               \
+    if (blockIdx.x < 8 && (wave & 3) == 0 && w < 16 && lane == 0)                                    \
+      g_trace[((blockIdx.x * 2 + (wave >> 2)) * 16 + w) * 16 + (PT)] = clock64();                    \
+  } while (0)
+extern "C" int esam3_dev_read_trace(unsigned long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * n);
+}
+#else
+#define ESAM3_TRACE(PT)
+#endif
+
 namespace {
 
 // One LDS-DMA piece: 64 lanes x 16 B from (scalar base + per-lane 32-bit byte offset) to LDS [m0 .. m0+1024).
@@ -38,7 +52,7 @@ __device__ __forceinline__ void dma_piece(const void* base, uint32_t voff, uint3
                : "memory");
 }
 
-template <int ACT>
+template <int ACT, bool RES>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
   typedef bf16_t T;
   constexpr int BKE = 64;                  // K elements per tile (128 bytes)
@@ -136,7 +150,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
   // tiles whose per-lane offsets differ from the generic full tile: ragged last M tile, 3x3 without patch tiling
   const bool a_off_varies = (p.ksize == 3 && !patch) || (M32 % 256u) != 0;
 
-  unsigned s_w = 0;            // stream: ordinal of the output tile being staged
   int s_kt = 0, s_tap = 0, s_chunk = 0;
   uint32_t s_par = 0;          // stream: LDS buffer of the K tile being staged
   bool s_ok = true;            // stream not exhausted
@@ -152,13 +165,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
     sA = gA + s_tileA + koff;
     sB = gW + s_tileB + (int64_t)s_kt * BKE;
   };
-  auto stream_open = [&](unsigned w, bool first) {
-    unsigned m0;
-    int n0;
-    tile_of(w, m0, n0);
-    s_tileA = a_row_off(row_to_m(m0, 0));
-    s_tileB = (int64_t)n0 * p.Kp;
-    if (first || a_off_varies) set_a_off(m0, s_tileA);
+  // The wave-uniform bases of the NEXT output tile the stream will enter are worked out ahead of time, inside the
+  // epilogue (whose waits hide the scalar divisions), not when the stream crosses the tile boundary in the K loop.
+  int64_t nx_tileA = 0, nx_tileB = 0;
+  unsigned nx_m0 = 0;
+  bool nx_ok = false;
+  auto stream_look_ahead = [&](unsigned w) {  // tile ordinal w of this workgroup
+    nx_ok = tile_exists(w);
+    if (nx_ok) {
+      int n0;
+      tile_of(w, nx_m0, n0);
+      nx_tileA = a_row_off(row_to_m(nx_m0, 0));
+      nx_tileB = (int64_t)n0 * p.Kp;
+    }
   };
   auto stream_advance = [&]() {
     if (!s_ok) return;
@@ -166,9 +185,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
     if (++s_tap == 9) { s_tap = 0; ++s_chunk; }
     if (s_kt == nk) {
       s_kt = 0; s_tap = 0; s_chunk = 0;
-      ++s_w;
-      if (!tile_exists(s_w)) { s_ok = false; return; }
-      stream_open(s_w, false);
+      if (!nx_ok) { s_ok = false; return; }
+      s_tileA = nx_tileA;
+      s_tileB = nx_tileB;
+      if (a_off_varies) set_a_off(nx_m0, s_tileA);
     }
     s_par ^= 1u;
     stream_bases();
@@ -202,18 +222,24 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
     rdB[ck] = (uint32_t)(2 * HALF + (wn * 32 + l31) * 128 + swz(l31, ck * 2 + g));
   }
 
-  // ---- prologue: K tiles 0 and 1 (minus its A1) of the first output tile ----------------------------------
-  stream_open(0, true);
+  // ---- prologue: K tiles 0 and 1 of the first output tile ---------------------------------------------------
+  stream_look_ahead(0);
+  s_tileA = nx_tileA;
+  s_tileB = nx_tileB;
+  set_a_off(nx_m0, s_tileA);
+  stream_look_ahead(1);
   stream_bases();
   ESAM3_STAGE(2); ESAM3_STAGE(0); ESAM3_STAGE(3); ESAM3_STAGE(1);
   stream_advance();
-  ESAM3_STAGE(2); ESAM3_STAGE(0); ESAM3_STAGE(3);
-  if (s_ok) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  ESAM3_STAGE(2); ESAM3_STAGE(0); ESAM3_STAGE(3); ESAM3_STAGE(1);
+  if (s_ok) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  uint32_t c_par = 0;  // compute: LDS buffer of the current K tile
+  uint32_t c_par = 0;       // compute: LDS buffer of the current K tile
+  bool c_landed = false;    // the K tile after the current one is already known to have landed (set by the epilogue)
   char* const epi = smem + EPI + wave * 4096;
+  const int sp = lane >> 3, sc = lane & 7;  // store side: pixel 8k + sp of a 32-pixel block, 16-byte chunk sc of its row
 
   for (unsigned w = 0;; ++w) {
     unsigned m0;
@@ -229,6 +255,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    ESAM3_TRACE(0);
     if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one barrier behind group 0
 
 #define ESAM3_LDS16(OFF) (*reinterpret_cast<const u32x4*>(lbuf + (OFF)))
@@ -247,11 +274,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
     __builtin_amdgcn_s_setprio(0);                                                   \
     __builtin_amdgcn_s_barrier();                                                    \
   } while (0)
-// One K tile = four phases.  ADVANCE moves the staging stream to the K tile two ahead of the one being computed.
+// One K tile = four phases.  ADVANCE moves the staging stream to the K tile two ahead of the one being computed;
+// that K tile is staged in phases 2-4 (B0 and A1 one phase after their last read: the reads are retired by a counted
+// lgkmcnt before the phase's first barrier, so the other group's DMA cannot overtake them).
 #define ESAM3_KTILE(ADVANCE)                                                         \
   do {                                                                               \
     const char* lbuf = smem + c_par * BUF;                                           \
-    /* ---- phase 1: B0 + A0 -> acc[0..1][0]; stage A1 of K tile t+1 ---- */         \
+    /* ---- phase 1: B0 + A0 -> acc[0..1][0] ---- */                                 \
     _Pragma("unroll") for (int ck = 0; ck < 4; ++ck) fb0[ck] = ESAM3_LDS16(rdB[ck]); \
     __builtin_amdgcn_sched_barrier(0);                                               \
     _Pragma("unroll") for (int ck = 0; ck < 4; ++ck) {                               \
@@ -259,9 +288,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
       fa[1][ck] = ESAM3_LDS16(rdA[ck] + 4096u);                                      \
     }                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                               \
-    ESAM3_STAGE(1);                                                                  \
-    /* the B0 reads (issued first) have returned: the other group may re-stage B0 in the next interval */ \
-    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                               \
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); /* B0 reads (issued first) retired */ \
     ESAM3_MFMA8(fb0, 0, 0);                                                          \
     /* ---- phase 2: B1 -> acc[0..1][1]; stage B0 of K tile t+2 ---- */              \
     _Pragma("unroll") for (int ck = 0; ck < 4; ++ck) fb1[ck] = ESAM3_LDS16(rdB[ck] + HALF); \
@@ -276,10 +303,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
     }                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                               \
     ESAM3_STAGE(0);                                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* A1 reads retired: A1 is re-staged in the next phase */ \
     ESAM3_MFMA8(fb1, 2, 1);                                                          \
-    /* ---- phase 4: no reads -> acc[2..3][0]; stage B1 of K tile t+2; K tile t+1 has landed ---- */ \
+    /* ---- phase 4: no reads -> acc[2..3][0]; stage B1 + A1 of K tile t+2; K tile t+1 has landed ---- */ \
     ESAM3_STAGE(3);                                                                  \
-    if (s_ok) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                       \
+    ESAM3_STAGE(1);                                                                  \
+    if (c_landed) c_landed = false;                                                  \
+    else if (s_ok) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                  \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            \
     ESAM3_MFMA8(fb0, 2, 0);                                                          \
     c_par ^= 1u;                                                                     \
@@ -287,32 +317,54 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
 
     u32x4 fa[2][4], fb0[4], fb1[4];
     // steady state: the stream stays inside this output tile (K tile kt+2 exists)
-    for (int kt = 0; kt < nk - 2; ++kt) ESAM3_KTILE(stream_advance_in_tile());
+    for (int kt = 0; kt < nk - 2; ++kt) {
+      ESAM3_KTILE(stream_advance_in_tile());
+      if (kt == 0) ESAM3_TRACE(1);
+    }
+    ESAM3_TRACE(2);
     // last two K tiles: the stream crosses into the next output tile (or ends)
     ESAM3_KTILE(stream_advance());
     ESAM3_KTILE(stream_advance());
 #undef ESAM3_KTILE
 #undef ESAM3_MFMA8
 #undef ESAM3_LDS16
+    ESAM3_TRACE(3);
+    // the epilogue's bias values are requested first: their latency overlaps the last barrier and the address set-up
+    const int nbw = n0 + wn * 64;  // first channel of this wave's 64-channel block (wave-uniform)
+    const int bias_n = (convt ? nbw % p.convt_cout : nbw) + 4 * g;
+    float4 bq[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        bq[j][q] = (p.bias && nbw < p.N) ? *reinterpret_cast<const float4*>(p.bias + bias_n + j * 32 + 8 * q)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
     if (wm == 0) __builtin_amdgcn_s_barrier();  // both groups leave the K loop behind the same barrier
+    ESAM3_TRACE(4);
 
     // =========================== epilogue ===========================
-    const int nbw = n0 + wn * 64;  // first channel of this wave's 64-channel block (wave-uniform)
+    bool looked = false;  // stream_look_ahead(w + 2) done (it is placed between the store blocks, under their waits)
+#ifdef ESAM3_P_NOSTORE  /* ablation build (tools/dev_variants.sh): keep the accumulators alive, no epilogue (wrong results) */
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) asm volatile("" ::"v"(acc[i][j]));
+    if (false) {
+#else
     if (nbw < p.N) {
+#endif
       // channel-direction part of the addresses (a 64-channel block never straddles a ConvT tap: Cout % 64 == 0)
       int64_t ocol = nbw, rcol = nbw;
-      int bias_n = nbw;
       if (convt) {
         const int tap = nbw / p.convt_cout, co = nbw - tap * p.convt_cout;
         const int OWp = 2 * p.W + 2 * P;
         ocol = ((int64_t)(tap >> 1) * OWp + (tap & 1)) * p.ldc + co;
         rcol = ((int64_t)(tap >> 1) * (2 * p.W) + (tap & 1)) * p.ldr + co;
-        bias_n = co;
       }
       // residual rows in the accumulator layout (lane's own pixel l31 of block i)
       int64_t rbase[4];
       bool rok[4];
-      if (gR) {
+      if constexpr (RES) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const unsigned m = row_to_m(m0, wm * 128 + i * 32 + l31);
@@ -323,42 +375,57 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
           if (convt) {
             const unsigned h = rem / (unsigned)p.W, ww = rem - h * (unsigned)p.W;
             const unsigned rb = p.res_bidx ? (unsigned)p.res_bidx[b] : b;
-            rbase[i] = ((int64_t)(rb * 2u * p.H + 2 * h) * (2 * p.W) + 2 * ww) * p.ldr;
+            rbase[i] = ((int64_t)(rb * 2u * p.H + 2 * h) * (2 * p.W) + 2 * ww) * p.ldr + rcol;
           } else {
             unsigned rrow = mm;
             if (p.res_mod > 0) rrow = mm % (unsigned)p.res_mod;
             else if (p.res_bidx) rrow = (unsigned)p.res_bidx[b] * (unsigned)HW + rem;
-            rbase[i] = (int64_t)rrow * p.ldr;
+            rbase[i] = (int64_t)rrow * p.ldr + rcol;
           }
         }
       }
-      // store side: lane -> (pixel 8k + lane/8 of the 32-pixel block, 16-byte chunk lane%8 of its 128-byte row)
-      const int sp = lane >> 3, sc = lane & 7;
-      // pixel walker for the store rows R = wm*128 + 8*s + sp, s = 0..15
-      const int omode = patch ? 0 : ((!convt && !P) ? 1 : 2);
-      unsigned pb = 0, ph = 0, pw = 0;  // omode 2: (image, row, column) of the current store row
-      int64_t tile_o = 0;               // omode 0: offset of the patch origin (+ lane part)
+      // Store rows R = wm*128 + 8*s + sp, s = 0..15, walked incrementally: the element offset of the row advances by
+      // inc[s & 1] per step (patch tiles: 8 pixels to the right, then down one image row and 8 back; linear rows: 8
+      // rows).  Outputs with a border or a ConvT pixel shuffle on linear rows also carry an (image row, column)
+      // walker: when the column wraps the offset skips the border / the second output row (d1), when the row wraps
+      // it skips the border rows between images (d2).  W >= 8, so a step wraps at most once.
+      const bool walker = !patch && (convt || P);
       unsigned mrow = m0 + (unsigned)(wm * 128 + sp);
-      if (omode == 0) {
+      unsigned ph = 0, pw = 0;
+      int64_t cur, inc0, inc1, d1 = 0, d2 = 0;
+      if (patch) {
         const unsigned t = m0 >> 8;
         const unsigned b = t / tiles_img;
         const unsigned ti = t - b * tiles_img;
         const unsigned ty = ti / tiles_x, tx = ti - ty * tiles_x;
         const int64_t pitch = (int64_t)(p.W + 2 * P);
-        tile_o = (((int64_t)b * (p.H + 2 * P) + ty * 16 + P + wm * 8) * pitch + tx * 16 + P + sp) * p.ldc;
-      } else if (omode == 2) {
-        pb = mrow / (unsigned)HW;
+        cur = (((int64_t)b * (p.H + 2 * P) + ty * 16 + P + wm * 8) * pitch + tx * 16 + P + sp) * p.ldc;
+        inc0 = 8 * (int64_t)p.ldc;
+        inc1 = (pitch - 8) * p.ldc;
+      } else if (!walker) {
+        cur = (int64_t)mrow * p.ldc;
+        inc0 = inc1 = 8 * (int64_t)p.ldc;
+      } else {
+        const unsigned pb = mrow / (unsigned)HW;
         const unsigned rem = mrow - pb * (unsigned)HW;
         ph = rem / (unsigned)p.W;
         pw = rem - ph * (unsigned)p.W;
+        if (convt) {
+          const int64_t OWp = 2 * p.W + 2 * P;
+          cur = ((int64_t)(pb * (unsigned)(2 * p.H + 2 * P) + 2 * ph + P) * OWp + 2 * pw + P) * p.ldc;
+          inc0 = inc1 = 16 * (int64_t)p.ldc;
+          d1 = (2 * OWp - 2 * p.W) * p.ldc;
+          d2 = 2 * P * OWp * p.ldc;
+        } else {
+          cur = ((int64_t)(pb * (unsigned)(p.H + 2) + ph + 1) * (p.W + 2) + pw + 1) * p.ldc;
+          inc0 = inc1 = 8 * (int64_t)p.ldc;
+          d1 = 2 * (int64_t)p.ldc;
+          d2 = 2 * (int64_t)(p.W + 2) * p.ldc;
+        }
       }
-      float4 bq[2][4];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          bq[j][q] = p.bias ? *reinterpret_cast<const float4*>(p.bias + bias_n + j * 32 + 8 * q + 4 * g)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
+      cur += ocol + sc * 8;
+      bool landed_waited = false;
+      ESAM3_TRACE(5);
 
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -367,23 +434,29 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
           float v[16], r16[16];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            float r4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (gR && rok[i]) {
-              const uint2 u = *reinterpret_cast<const uint2*>(gR + rbase[i] + rcol + j * 32 + 8 * q + 4 * g);
-              r4[0] = __uint_as_float(u.x << 16); r4[1] = __uint_as_float(u.x & 0xffff0000u);
-              r4[2] = __uint_as_float(u.y << 16); r4[3] = __uint_as_float(u.y & 0xffff0000u);
-            }
             const float bb[4] = {bq[j][q].x, bq[j][q].y, bq[j][q].z, bq[j][q].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              r16[4 * q + e] = r4[e];
-              v[4 * q + e] = acc[i][j][4 * q + e] + bb[e] + (p.res_after_act ? 0.f : r4[e]);
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = acc[i][j][4 * q + e] + bb[e];
+          }
+          if constexpr (RES) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              uint2 u = make_uint2(0u, 0u);
+              if (rok[i]) u = *reinterpret_cast<const uint2*>(gR + rbase[i] + j * 32 + 8 * q + 4 * g);
+              r16[4 * q + 0] = __uint_as_float(u.x << 16); r16[4 * q + 1] = __uint_as_float(u.x & 0xffff0000u);
+              r16[4 * q + 2] = __uint_as_float(u.y << 16); r16[4 * q + 3] = __uint_as_float(u.y & 0xffff0000u);
+            }
+            if (!p.res_after_act) {
+#pragma unroll
+              for (int e = 0; e < 16; ++e) v[e] += r16[e];
             }
           }
           act_apply_n<16>(v, ACT);
-          if (p.res_after_act && gR) {
+          if constexpr (RES) {
+            if (p.res_after_act) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] += r16[e];
+              for (int e = 0; e < 16; ++e) v[e] += r16[e];
+            }
           }
 #pragma unroll
           for (int qp = 0; qp < 2; ++qp) {
@@ -399,35 +472,41 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
             *reinterpret_cast<u32x4*>(epi + l31 * 128 + ((c ^ (l31 & 7)) << 4)) = o;
           }
         }
+        if (i == 0) { asm volatile("" ::"v"(epi)); ESAM3_TRACE(6); }
+        if (i == 1 && has_next) { stream_look_ahead(w + 2); looked = true; }
+        if (!landed_waited) {
+          // Every LDS-DMA piece issued so far (the next output tile's K tiles 0 and 1) has had the last phases and
+          // this block's arithmetic to land; waiting for them HERE, before the first store, lets the next tile's
+          // first K tile skip its vmcnt wait, which would otherwise also wait for all of the stores below
+          // (vmcnt counts stores).
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          landed_waited = true;
+          ESAM3_TRACE(7);
+        }
         // rows back out of the strip: 8 complete 128-byte lines per store instruction
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const u32x4 o = *reinterpret_cast<const u32x4*>(epi + (8 * k + sp) * 128 + ((sc ^ sp) << 4));
-          const int s = i * 4 + k;
-          int64_t off;
-          bool ok = true;
-          if (omode == 0) {
-            off = tile_o + ((int64_t)(s >> 1) * (p.W + 2 * P) + (s & 1) * 8) * p.ldc;
-          } else if (omode == 1) {
-            ok = mrow < M32;
-            off = (int64_t)mrow * p.ldc;
-          } else {
-            ok = mrow < M32;
-            off = convt ? ((int64_t)(pb * (unsigned)(2 * p.H + 2 * P) + 2 * ph + P) * (2 * p.W + 2 * P) + 2 * pw + P) * p.ldc
-                        : ((int64_t)(pb * (unsigned)(p.H + 2) + ph + 1) * (p.W + 2) + pw + 1) * p.ldc;
-          }
-          if (ok) *reinterpret_cast<u32x4*>(gO + off + ocol + sc * 8) = o;
-          // next store row: + 8 pixels
+          if (mrow < M32) *reinterpret_cast<u32x4*>(gO + cur) = o;
+          // next store row
           mrow += 8;
-          if (omode == 2) {
+          cur += (k & 1) ? inc1 : inc0;
+          if (walker) {
             pw += 8;
-            while (pw >= (unsigned)p.W) { pw -= (unsigned)p.W; ++ph; }
-            while (ph >= (unsigned)p.H) { ph -= (unsigned)p.H; ++pb; }
+            const bool c1 = pw >= (unsigned)p.W;
+            pw -= c1 ? (unsigned)p.W : 0u;
+            ph += c1 ? 1u : 0u;
+            const bool c2 = ph >= (unsigned)p.H;
+            ph -= c2 ? (unsigned)p.H : 0u;
+            cur += (c1 ? d1 : 0) + (c2 ? d2 : 0);
           }
         }
+        ESAM3_TRACE(8 + i);
       }
+      c_landed = has_next;
     }
     if (!has_next) break;
+    if (!looked) stream_look_ahead(w + 2);
   }
 #undef ESAM3_STAGE
 }
@@ -440,6 +519,7 @@ bool esam3_gemm256p_ok(const GemmParams& p) {
   if (p.N % 64 != 0) return false;
   if (p.out_mode == OUT_CONVT2X2 && p.convt_cout % 64 != 0) return false;
   if (p.ksize == 3 && !p.korder) return false;
+  if ((p.out_mode == OUT_CONVT2X2 || p.out_pad) && p.W < 8) return false;  // epilogue row walker: one wrap per 8-pixel step
   if ((((uintptr_t)p.out) & 15) || (((uintptr_t)p.A) & 15) || (((uintptr_t)p.Wt) & 15)) return false;
   if (p.bias && (((uintptr_t)p.bias) & 15)) return false;
   return true;
@@ -448,8 +528,11 @@ bool esam3_gemm256p_ok(const GemmParams& p) {
 int esam3_launch_gemm256p(const GemmParams& p, hipStream_t stream) {
   constexpr size_t lds = 163840;  // 2 x 64 KB K-tile buffers + 8 x 4 KB epilogue strips = all of a CU's LDS
   static bool attr_set = false;
-  void (*kerns[5])(GemmParams) = {gemm256p_kernel<ACT_NONE>, gemm256p_kernel<ACT_RELU>, gemm256p_kernel<ACT_GELU>,
-                                  gemm256p_kernel<ACT_HSWISH>, gemm256p_kernel<ACT_SIGMOID>};
+  void (*kerns[10])(GemmParams) = {
+      gemm256p_kernel<ACT_NONE, false>, gemm256p_kernel<ACT_RELU, false>, gemm256p_kernel<ACT_GELU, false>,
+      gemm256p_kernel<ACT_HSWISH, false>, gemm256p_kernel<ACT_SIGMOID, false>,
+      gemm256p_kernel<ACT_NONE, true>, gemm256p_kernel<ACT_RELU, true>, gemm256p_kernel<ACT_GELU, true>,
+      gemm256p_kernel<ACT_HSWISH, true>, gemm256p_kernel<ACT_SIGMOID, true>};
   if (p.act < 0 || p.act > 4) { esam3_set_error("gemm: bad activation %d", p.act); return -1; }
   if (!attr_set) {
     for (auto k : kerns)
@@ -467,7 +550,7 @@ int esam3_launch_gemm256p(const GemmParams& p, hipStream_t stream) {
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const int64_t grid = tiles < n_cu ? tiles : n_cu;  // persistent: one workgroup per CU
-  hipLaunchKernelGGL(kerns[p.act], dim3((unsigned)grid), dim3(512), lds, stream, p);
+  hipLaunchKernelGGL(kerns[p.act + (p.res ? 5 : 0)], dim3((unsigned)grid), dim3(512), lds, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -380,6 +380,8 @@ extern "C" int esam3_bench_gemm(int dtype, int B, int H, int W, int Cin, int N, 
   for (auto& v : hw) v = rnd() * 0.05f;
   for (auto& v : ha) v = rnd();
   void* w = t.upT(dtype, hw);
+  std::vector<float> hb((size_t)Np, 0.01f);
+  const float* bias_dev = static_cast<const float*>(t.up(hb.data(), hb.size() * 4));
   void* a = t.raw(a_elems * esz);
   void* o = t.raw(o_elems * esz);
   void* chunk = t.upT(dtype, ha);
@@ -389,7 +391,7 @@ extern "C" int esam3_bench_gemm(int dtype, int B, int H, int W, int Cin, int N, 
     (void)hipMemcpy((char*)a + off * esz, chunk, n * esz, hipMemcpyDeviceToDevice);
   }
   GemmParams p{};
-  p.A = a; p.Wt = w; p.out = o; p.M = M; p.N = N; p.K = K; p.Kp = Kp; p.H = H; p.W = W; p.Cin = Cin;
+  p.A = a; p.Wt = w; p.bias = bias_dev; p.out = o; p.M = M; p.N = N; p.K = K; p.Kp = Kp; p.H = H; p.W = W; p.Cin = Cin;
   p.ksize = ksize; p.lda = Cin; p.ldc = convt ? N / 4 : N; p.ldr = p.ldc; p.in_pad = pad; p.res_after_act = 1;
   p.korder = esam3_conv_korder(Cin, ksize, esz);
   if (convt) { p.out_mode = OUT_CONVT2X2; p.convt_cout = N / 4; }

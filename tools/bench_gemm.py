@@ -23,14 +23,29 @@ SHAPES = [  # name, B, H, W, Cin, N, ksize, convt
     ("ViT-H fc1 1024->4736", 8, 72, 72, 1024, 4736, 1, 0),
     ("ViT-H fc2 4736->1024", 8, 72, 72, 4736, 1024, 1, 0),
 ]
-lib = C.CDLL(_lib.LIB_PATH)
+lib = C.CDLL(os.environ.get("ESAM3_DEV_LIB") or _lib.LIB_PATH)  # ESAM3_DEV_LIB: an ablation build (tools/dev_variants.sh)
 lib.esam3_bench_gemm.argtypes = [C.c_int] * 9 + [C.POINTER(C.c_float)]
 only = sys.argv[1] if len(sys.argv) > 1 else None
+print("lib:", os.environ.get("ESAM3_DEV_LIB") or "product", flush=True)
 print("kernel:", "gemm256 (classic)" if os.environ.get("ESAM3_GEMM256_CLASSIC", "0") not in ("", "0") else "gemm256p", flush=True)
 for name, B, H, W, Cin, N, ks, ct in SHAPES:
-    if only and only not in name:
+    if only and not any(o in name for o in only.split(',')):
         continue
     ms = C.c_float()
     rc = lib.esam3_bench_gemm(1, B, H, W, Cin, N, ks, ct, 10, C.byref(ms))
     fl = 2.0 * B * H * W * N * Cin * ks * ks
     print(f"{name:34s} rc={rc} {ms.value:8.3f} ms  {fl / ms.value / 1e9:8.1f} TF/s", flush=True)
+    if hasattr(lib, "esam3_dev_read_trace"):  # trace build: cycle stamps of the last launch (workgroups 0-7, waves 0 / 4)
+        n = 8 * 2 * 16 * 16
+        buf = (C.c_ulonglong * n)()
+        lib.esam3_dev_read_trace(buf, n)
+        names = ["tile start", "K tile 0 done", "steady loop done", "K loop done", "group barrier", "addr set-up",
+                 "block 0 packed (bias arrived)", "vmcnt(0) (next K tile 1 landed)", "stores 0", "stores 1", "stores 2", "stores 3"]
+        for blk in (0, 3):
+            for wv in (0, 1):
+                for tile in (1, 2):
+                    base = ((blk * 2 + wv) * 16 + tile) * 16
+                    t0 = buf[base]
+                    row = [buf[base + i] - t0 for i in range(12)]
+                    nxt = buf[base + 16] - t0
+                    print(f"  trace wg{blk} wave{wv * 4} tile{tile}: " + ", ".join(f"{nm}={v}" for nm, v in zip(names[1:], row[1:])) + f", next tile start={nxt}")
