@@ -119,6 +119,15 @@ def main():
         manifest["stages"][f"img0/{k}"] = {"maxabs": e, "rel_to_peak": e / max(peak, 1e-30), "peak": peak}
         print(f"  stage {k:12s} bf16ref-vs-fp32 maxabs {e:.3e}  ({e / max(peak, 1e-30):.2%} of peak {peak:.2f})")
 
+    if default:  # the second stage-fixture image of gen_golden.py (noise): stage yardstick only
+        chw1 = torch.from_numpy(np.ascontiguousarray(np.moveaxis(synth.noise_image_u8(seed=3), -1, 0)))
+        s32, _ = run(chw1, [], [], amp=False)
+        s16, _ = run(chw1, [], [], amp=True)
+        for k in s32:
+            e = G.maxerr(s32[k], s16[k])
+            peak = float(s32[k].abs().max())
+            manifest["stages"][f"img1/{k}"] = {"maxabs": e, "rel_to_peak": e / max(peak, 1e-30), "peak": peak}
+
     def record(name, r32, r16, return_logits):
         m32, i32, l32 = r32
         m16, i16, l16 = r16

@@ -13,6 +13,13 @@ import torch
 from efficientsam3_amd import schema, synth
 
 SAMPLE = 8192
+BF16_FACTOR = 1.5  # engine-bf16 error allowed as a multiple of the reference's own bf16 error (tests/util.py)
+# Named exception (tests/util.py BF16_EXCEPTIONS, [stream]): the 200-query decoder state and the 5184-token fusion memory
+# are residual streams the reference's autocast keeps in fp32 and the engine stores in bf16.  Measured on MI355X: class
+# logits 0.022-0.036 against 0.013 for the reference's own bf16 run (x 2.8), boxes 0.029 / 0.013, presence logit
+# 0.006-0.015 / 0.0015; the mask logits (0.68 / 1.06) are inside the 1.5 x rule.
+PCS_BF16_STREAM_FACTOR = 3.0
+PRESENCE_BF16_ULP = 2.0 ** -6  # the presence logit is ONE number per image (about -2): one bf16 ulp at that magnitude
 
 
 def _sample(t):
@@ -78,8 +85,13 @@ def test_pcs_engine_vs_golden(pcs_gold, pcs_sd, mode):
     proc = Sam3Processor(model, confidence_threshold=man["confidence_threshold"])
     img = synth.smooth_image_u8(seed=1)
     state = proc.set_image(torch.from_numpy(np.ascontiguousarray(np.moveaxis(img, -1, 0))))
-    lim = dict(f32=dict(logits=1e-4, boxes=1e-4, presence=1e-4, masks=2e-3), bf16=dict(logits=0.08, boxes=0.06, presence=0.08, masks=2.5))[mode]
+    with open(os.path.join(os.path.dirname(__file__), "golden", "pcs_ev_m", "bf16ref_manifest.json")) as f:
+        yard = json.load(f)["cases"]  # the reference's own bf16-autocast-vs-fp32 distance per output (gen_golden_pcs_bf16ref.py)
     for pi in range(len(man["prompts"])):
+        y = yard[man["prompts"][pi]]
+        lim = dict(logits=1e-4, boxes=1e-4, presence=1e-4, masks=2e-3) if mode == "f32" else \
+            dict(logits=PCS_BF16_STREAM_FACTOR * y["pred_logits"], boxes=PCS_BF16_STREAM_FACTOR * y["pred_boxes"],
+                 presence=PCS_BF16_STREAM_FACTOR * y["presence_logit_dec"] + PRESENCE_BF16_ULP, masks=BF16_FACTOR * y["pred_masks"])
         state["backbone_out"]["language_features"] = torch.from_numpy(g[f"{pi}_language_features"]).to("cuda")
         state["backbone_out"]["language_mask"] = torch.from_numpy(g[f"{pi}_language_mask"]).to("cuda")
         out = model.forward_grounding(state["backbone_out"], geometric_prompt=model._get_dummy_prompt())
@@ -87,7 +99,7 @@ def test_pcs_engine_vs_golden(pcs_gold, pcs_sd, mode):
                  boxes=float(np.abs(out["pred_boxes"].cpu().numpy() - g[f"{pi}_pred_boxes"]).max()),
                  presence=float(np.abs(out["presence_logit_dec"].cpu().numpy() - g[f"{pi}_presence_logit_dec"]).max()),
                  masks=float(np.abs(_sample(out["pred_masks"]) - g[f"{pi}_pred_masks_sample"]).max()))
-        print(f"[pcs {mode}] prompt {pi}: {e}")
+        print(f"[pcs {mode}] prompt {pi}: err {e} allowed {lim}")
         for k, v in e.items():
             assert v <= lim[k], (k, v, lim[k])
         state["geometric_prompt"] = model._get_dummy_prompt()
@@ -213,29 +225,56 @@ def test_pcs_engine_geometric_prompts_vs_golden(pcs_gold, pcs_sd, mode):
 
 @pytest.mark.gpu
 def test_config4_batch_8_is_image_independent():
-    """BASELINE config 4 at its full size (ViT-H + MobileCLIP-S0-16 + detector, bf16, batch 8): four distinct
-    (image, text) pairs tiled twice; both copies must give bit-identical logits, boxes, presence and mask logits."""
+    """BASELINE config 4 at its full size (ViT-H + MobileCLIP-S0-16 + detector, batch 8): four distinct (image, text)
+    pairs tiled twice.  Both copies must give bit-identical logits, boxes, presence and mask logits, and the four
+    distinct results must match the ORACLE (oracle/ref_model.py ViT-H + text student, oracle/ref_pcs.py detector) run
+    on CPU per pair: f32 within the f32 limits of test_pcs_engine_vs_golden, bf16 within the reference's own bf16
+    yardstick for this model (tests/golden/pcs_vit_h/bf16ref_manifest.json) under the same rule as the EV-M test."""
     from efficientsam3_amd import build_sam3_image_model
+    from oracle import ref_model, ref_pcs
     sd = schema.synthetic_state_dict("sam3", "vit_h", seed=0, enable_inst_interactivity=False)
     sd.update(schema.synthetic_text_state_dict("MobileCLIP-S0", 16, seed=0))
     sd.update(schema.synthetic_pcs_state_dict(seed=0))
-    model = build_sam3_image_model(device="cuda", enable_inst_interactivity=False, dtype="bf16", state_dict=sd,
-                                   text_encoder_type="MobileCLIP-S0", text_encoder_context_length=16)
-    eng = model.engine
     base = [synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=1)), synth.normalise_to_chw_f32(synth.noise_image_u8(seed=2)),
             synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=3)), synth.normalise_to_chw_f32(synth.noise_image_u8(seed=4))]
-    x = torch.from_numpy(np.stack([base[i % 4] for i in range(8)])).to("cuda")
     rng = np.random.default_rng(5)
     tok = np.zeros((8, 16), dtype=np.int64)
     for i in range(4):
         n = int(rng.integers(1, 5))
         tok[i, 0], tok[i, 1:1 + n], tok[i, 1 + n] = 49406, rng.integers(300, 40000, size=n), 49407
     tok[4:] = tok[:4]
-    tok_d = torch.from_numpy(tok).to("cuda")
-    out = eng.encode(x, want_sam3=True, want_sam2=False)
-    mem, _ = eng.encode_text(tok_d)
-    g = eng.ground(out["sam3_fpn"], mem, tok_d == 0)
-    for k in ("pred_logits", "pred_boxes", "presence_logit_dec", "pred_masks"):
-        assert torch.equal(g[k][:4], g[k][4:]), k
-        assert torch.isfinite(g[k]).all(), k
-    assert g["pred_masks"].shape == (8, 200, 288, 288) and float(g["pred_boxes"].min()) >= 0.0 and float(g["pred_boxes"].max()) <= 1.0
+    keys = ("pred_logits", "pred_boxes", "presence_logit_dec", "pred_masks")
+    oracle = []
+    with torch.inference_mode():
+        for i in range(4):
+            fo = ref_model.forward_image(sd, torch.from_numpy(base[i])[None], "vit_h")
+            mask, mem, _ = ref_model.text_encoder_student(sd, torch.from_numpy(tok[i:i + 1]))
+            o = ref_pcs.forward_grounding(sd, fo["backbone_fpn"], fo["vision_pos_enc"][-1], mem, mask)
+            oracle.append({k: o[k].float().numpy() for k in keys})
+    with open(os.path.join(os.path.dirname(__file__), "golden", "pcs_vit_h", "bf16ref_manifest.json")) as f:
+        yard = json.load(f)["cases"]
+    y = {k: max(c[k] for c in yard.values()) for k in keys}
+    lims = dict(f32=dict(pred_logits=1e-4, pred_boxes=1e-4, presence_logit_dec=1e-4, pred_masks=4e-3),
+                bf16=dict(pred_logits=PCS_BF16_STREAM_FACTOR * y["pred_logits"], pred_boxes=PCS_BF16_STREAM_FACTOR * y["pred_boxes"],
+                          presence_logit_dec=PCS_BF16_STREAM_FACTOR * y["presence_logit_dec"] + PRESENCE_BF16_ULP,
+                          pred_masks=PCS_BF16_STREAM_FACTOR * y["pred_masks"]))
+    for mode in ("bf16", "f32"):
+        model = build_sam3_image_model(device="cuda", enable_inst_interactivity=False, dtype=mode, state_dict=sd,
+                                       text_encoder_type="MobileCLIP-S0", text_encoder_context_length=16)
+        eng = model.engine
+        x = torch.from_numpy(np.stack([base[i % 4] for i in range(8)])).to("cuda")
+        tok_d = torch.from_numpy(tok).to("cuda")
+        out = eng.encode(x, want_sam3=True, want_sam2=False)
+        mem, _ = eng.encode_text(tok_d)
+        g = eng.ground(out["sam3_fpn"], mem, tok_d == 0)
+        for k in keys:
+            assert torch.equal(g[k][:4], g[k][4:]), (mode, k)
+            assert torch.isfinite(g[k]).all(), (mode, k)
+        assert g["pred_masks"].shape == (8, 200, 288, 288) and float(g["pred_boxes"].min()) >= 0.0 and float(g["pred_boxes"].max()) <= 1.0
+        for i in range(4):
+            e = {k: float(np.abs(g[k][i].float().cpu().numpy() - oracle[i][k][0]).max()) for k in keys}
+            print(f"[cfg4 {mode}] pair {i} vs oracle: err {e} allowed {lims[mode]}")
+            for k in keys:
+                assert e[k] <= lims[mode][k], (mode, i, k, e[k], lims[mode][k])
+        del model, eng, out, g, x
+        torch.cuda.empty_cache()
