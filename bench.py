@@ -94,8 +94,18 @@ def main():
     from efficientsam3_amd import dist as esdist
 
     rank, local_rank, world = esdist.env_ranks()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched from a bare shell (`python bench.py --gpus N`): re-exec as N ranks, one per GPU, over RCCL
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execvpe(cmd[0], cmd, env)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     esdist.init_process_group("nccl", dev)
@@ -150,12 +160,15 @@ def main():
         bufs["enc"] = out = eng.encode(x, want_sam3=not args.sam2_only, want_sam2=True, out=bufs["enc"])
         bufs["dec"] = low, iou = eng.decode(out["sam2_fpn"], pi_d, c_d, l_d, multimask_output=False, out=bufs["dec"])
         bufs["post"] = masks = eng.postprocess(low, (1008, 1008), return_logits=False, out=bufs["post"])
-        if world > 1:  # the path's only exchange step: uint8 masks of every shard -> rank 0
-            esdist.gather_to_root(masks, n_items=world * B, dst=0)
+        if world > 1:  # the path's only exchange step: uint8 masks of every shard -> rank 0, on a side stream
+            gatherer.submit(masks)
         return masks, iou
+
+    gatherer = esdist.MaskGatherer(dst=0) if world > 1 else None
 
     def sync():
         if world > 1:
+            gatherer.flush()  # the last step's gather is part of the timed work
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -269,10 +282,13 @@ def main():
             "data": "synthetic (seeded images at the network's native 1008x1008, seeded realistic random-init weights)",
             "config": {"workload": ("EV-M (EfficientViT-B1)" if args.backbone == "efficientvit" else f"{args.backbone}-{args.model}") + (" image encoder + text encoder + PCS grounding detector (200 queries -> logits, boxes, "
                                                        "288x288 mask logits), one text prompt per image, " if text else
-                                                       " set_image_batch + predict_inst(point+box) per image, ")
+                                                       " engine-level encode + decode(point+box) + postprocess per image (the kernels behind "
+                                                       "set_image_batch + predict_inst; the Python API leg is config.api_level_*), ")
                                    + f"batch={B} per GPU, " + ("sam3 neck" if text else "full dual-neck graph") + (" [sam2-only variant]" if args.sam2_only else ""),
                        "global_batch": world * B, "resolution": 1008, "prompts_per_image": 1,
-                       "parallelism": f"dp{world} (image shards, RCCL gather of uint8 masks)" if world > 1 else "single GPU",
+                       "parallelism": f"dp{world} (image shards, RCCL gather of uint8 masks on a side stream)" if world > 1 else "single GPU",
+                       "ranks_in_process_group": (dist.get_world_size() if dist.is_initialized() else 1),
+                       "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "graph": ("reference layer list" if args.no_fuse else
                                  "linear chains composed at load time (ConvT∘1x1, 3x3∘conv_s0/s1): same outputs, fewer FLOPs"),
                        "gflop_per_image_executed": round(gf_img, 1), "gflop_per_image_reference_graph": round(gf_ref, 1),

@@ -41,9 +41,69 @@ def extract_state_dict(obj) -> Dict[str, torch.Tensor]:
     raise ValueError("Unable to extract a state_dict from the checkpoint object")
 
 
-def load_state_dict_file(path: str) -> Dict[str, torch.Tensor]:
+class _OpaqueNode(dict):
+    """Stand-in for a non-tensor object pickled next to the weights (the stage-1 trainer stores its yacs ``CfgNode``
+    under ``"config"``, stage1/utils.py:287-293): a dict that accepts any construction arguments and any pickled
+    state, and runs no foreign code."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.update(state)
+
+    def __call__(self, *a, **k):  # a stubbed *function* global used by a REDUCE opcode
+        return _OpaqueNode()
+
+
+def _stubbing_pickle_module():
+    """A pickle-module look-alike for ``torch.load(pickle_module=...)`` whose Unpickler resolves only the globals on
+    torch's own weights-only allowlist (tensor / storage rebuild helpers, OrderedDict, ...) and maps EVERY other
+    global to an inert ``_OpaqueNode`` stand-in."""
+    import pickle
+    import types
+
+    from torch._weights_only_unpickler import _get_allowed_globals
+    allowed = _get_allowed_globals()
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            key = f"{module}.{name}"
+            if key in allowed:
+                return allowed[key]
+            return type(name, (_OpaqueNode,), {"__module__": module})
+
+    mod = types.ModuleType("esam3_stubbing_pickle")
+    mod.Unpickler = Unpickler
+    mod.load = lambda f, **kw: Unpickler(f, **kw).load()
+    mod.loads = pickle.loads
+    mod.dump, mod.dumps, mod.Pickler = pickle.dump, pickle.dumps, pickle.Pickler
+    mod.UnpicklingError, mod.PicklingError, mod.HIGHEST_PROTOCOL = pickle.UnpicklingError, pickle.PicklingError, pickle.HIGHEST_PROTOCOL
+    return mod
+
+
+def load_state_dict_file(path: str, trusted: bool = False) -> Dict[str, torch.Tensor]:
+    """Read a checkpoint and return its tensors (``extract_state_dict``).
+
+    1. ``torch.load(weights_only=True)`` -- plain tensor checkpoints (the converters' outputs).
+    2. Full training checkpoints carry non-tensor entries (``config`` = yacs CfgNode, optimizer / scaler state;
+       the reference's converters therefore load with ``weights_only=False``).  Instead of unpickling arbitrary
+       code, the file is read again with an Unpickler that resolves only torch's weights-only allowlist and replaces
+       every other global by an inert stand-in; only the tensors under ``model`` / ``state_dict`` are kept.
+    3. ``trusted=True`` is the explicit opt-in to a full unpickle, for files from a source the caller trusts."""
+    import pickle
+    if trusted:
+        with open(path, "rb") as f:
+            return extract_state_dict(torch.load(f, map_location="cpu", weights_only=False))
+    try:
+        with open(path, "rb") as f:
+            return extract_state_dict(torch.load(f, map_location="cpu", weights_only=True))
+    except pickle.UnpicklingError:
+        pass
     with open(path, "rb") as f:
-        return extract_state_dict(torch.load(f, map_location="cpu", weights_only=True))
+        obj = torch.load(f, map_location="cpu", weights_only=False, pickle_module=_stubbing_pickle_module())
+    return extract_state_dict(obj)
 
 
 def normalize_image_student_key(key: str) -> str:

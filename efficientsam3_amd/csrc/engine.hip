@@ -2027,6 +2027,22 @@ int E::ensure_arena(size_t need_bytes) {
 // --------------------------------------------------------------------------------------
 // C ABI
 // --------------------------------------------------------------------------------------
+namespace {
+// Selects the engine's device for the duration of a C-ABI call and gives the caller's current device back afterwards
+// (two engines on different GPUs in one process must not change each other's -- or the host framework's -- device).
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+}  // namespace
+
 extern "C" {
 
 int esam3_create(const esam3_config* cfg, esam3_engine** out) {
@@ -2037,7 +2053,8 @@ int esam3_create(const esam3_config* cfg, esam3_engine** out) {
     return -1;
   }
   if (cfg->device < 0 || cfg->device >= ndev) { esam3_set_error("bad device ordinal %d", cfg->device); return -1; }
-  HIP_CHECK_RET(hipSetDevice(cfg->device));
+  DeviceGuard guard(cfg->device);
+  if (!guard.ok) { esam3_set_error("esam3_create: hipSetDevice(%d) failed", cfg->device); return -1; }
   if (cfg->backbone != ESAM3_BACKBONE_EFFICIENTVIT && cfg->backbone != ESAM3_BACKBONE_REPVIT &&
       cfg->backbone != ESAM3_BACKBONE_TINYVIT && cfg->backbone != ESAM3_BACKBONE_VIT) {
     esam3_set_error("unsupported backbone %d", cfg->backbone);
@@ -2105,7 +2122,8 @@ int esam3_load_weight(esam3_engine* e, const char* name, const float* data, cons
 
 int esam3_finalize(esam3_engine* e) {
   if (!e) { esam3_set_error("null engine"); return -1; }
-  HIP_CHECK_RET(hipSetDevice(e->cfg.device));
+  DeviceGuard guard(e->cfg.device);
+  if (!guard.ok) { esam3_set_error("esam3_finalize: hipSetDevice(%d) failed", e->cfg.device); return -1; }
   // dry run of both graphs at B = 1: packs every weight the graphs touch
   e->dry = true;
   e->arena.dry = true;
@@ -2186,6 +2204,8 @@ int esam3_ground(esam3_engine* e, const esam3_ground_in* in, const esam3_ground_
 int esam3_postprocess_masks(esam3_engine* e, const float* low_res, int n, int oh, int ow, float max_hole_area,
                             float thr, uint8_t* masks_u8, float* masks_logits, void* stream) {
   if (!e || !low_res || n <= 0) { esam3_set_error("esam3_postprocess_masks: bad argument"); return -1; }
+  if (oh <= 0 || ow <= 0) { esam3_set_error("esam3_postprocess_masks: output size %d x %d", oh, ow); return -1; }
+  if (!masks_u8 && !masks_logits) { esam3_set_error("esam3_postprocess_masks: no output buffer given"); return -1; }
   const int LR = 4 * EMB;
   const size_t px = (size_t)n * LR * LR;
   return run_sized(e, stream, [&]() -> int {

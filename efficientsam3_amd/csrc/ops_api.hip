@@ -457,12 +457,17 @@ int64_t esam3_rle_from_string(const char* s, int64_t len, uint32_t* counts_host,
     while (more) {
       if (p >= len) { esam3_set_error("esam3_rle_from_string: truncated string"); return -1; }
       const long long c = (long long)s[p] - 48;
+      // cocoapi's alphabet is the 64 characters from '0' (48) up; a count has at most 7 groups of 5 payload bits here
+      // (32-bit counts + sign), so a longer continuation run is a malformed string, not something to shift by >= 64
+      if (c < 0 || c > 63) { esam3_set_error("esam3_rle_from_string: character %d outside the RLE alphabet", (int)s[p]); return -1; }
+      if (k > 12) { esam3_set_error("esam3_rle_from_string: more than 13 continuation characters in one count"); return -1; }
       x |= (c & 0x1f) << (5 * k);
       more = (c & 0x20) != 0;
       ++p; ++k;
-      if (!more && (c & 0x10)) x |= -1LL << (5 * k);
+      if (!more && (c & 0x10) && 5 * k < 64) x |= -1LL << (5 * k);
     }
     if (m > 2) x += (long long)counts_host[m - 2];
+    if (x < 0 || x > 0xffffffffLL) { esam3_set_error("esam3_rle_from_string: count %lld does not fit a run length", x); return -1; }
     if (m >= capacity) { esam3_set_error("esam3_rle_from_string: output buffer too small"); return -1; }
     counts_host[m++] = (uint32_t)x;
   }

@@ -74,6 +74,81 @@ def gather_to_root(local: torch.Tensor, n_items: Optional[int] = None, dst: int 
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
 
 
+class MaskGatherer:
+    """The path's only exchange step, made cheap for a steady stream of equal-sized steps (bench.py, batch eval):
+
+      * the root's receive buffers and two send buffers are allocated ONCE (the first call) and reused;
+      * the collective is issued on a SIDE stream: the compute stream only pays a device-to-device copy of the step's
+        masks into a send buffer, the gather itself overlaps with the next step's kernels (SURVEY.md §8(e));
+      * two send buffers alternate, so step k+1 can fill its buffer while step k's gather is still in flight; a buffer is
+        reused only after the gather that read it has completed.
+
+    `submit(masks)` enqueues the gather of this step; `result()` waits for the most recent gather and returns the
+    [world * n_local, ...] tensor on the root (None elsewhere).  Shards must have equal size (pad ragged shards with
+    `gather_to_root`).  On CPU tensors (gloo, the tests) the same calls run synchronously."""
+
+    def __init__(self, dst: int = 0, group=None):
+        self.dst, self.group = dst, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._send = [None, None]
+        self._recv = [None, None]      # root only: one list of world buffers per send slot
+        self._work = [None, None]
+        self._done = [None, None]      # cuda events: gather of slot finished
+        self._k = 0
+        self._stream = None
+        self.allocations = 0           # how many times buffers were (re)allocated: 1 in steady state
+
+    def _alloc(self, like: torch.Tensor):
+        self.allocations += 1
+        for i in range(2):
+            self._send[i] = torch.empty_like(like)
+            self._recv[i] = [torch.empty_like(like) for _ in range(self.world)] if self.rank == self.dst else None
+        if like.is_cuda:
+            self._stream = torch.cuda.Stream(device=like.device)
+
+    def submit(self, local: torch.Tensor) -> None:
+        if self.world == 1:
+            self._send[0] = local
+            return
+        local = local.contiguous()
+        if self._send[0] is None or self._send[0].shape != local.shape or self._send[0].dtype != local.dtype:
+            self.flush()
+            self._alloc(local)
+        i = self._k & 1
+        if self._work[i] is not None:       # the gather that last read this slot must be done before it is overwritten
+            self._wait(i)
+        self._send[i].copy_(local, non_blocking=True)
+        if local.is_cuda:
+            side = self._stream
+            side.wait_stream(torch.cuda.current_stream(local.device))
+            with torch.cuda.stream(side):
+                self._work[i] = dist.gather(self._send[i], self._recv[i], dst=self.dst, group=self.group, async_op=True)
+        else:
+            self._work[i] = dist.gather(self._send[i], self._recv[i], dst=self.dst, group=self.group, async_op=True)
+        self._k += 1
+
+    def _wait(self, i: int) -> None:
+        w = self._work[i]
+        if w is not None:
+            w.wait()                        # NCCL: makes the CURRENT stream wait for the collective; gloo: blocks
+            self._work[i] = None
+
+    def flush(self) -> None:
+        for i in range(2):
+            self._wait(i)
+
+    def result(self) -> Optional[torch.Tensor]:
+        """the gathered tensor of the most recent submit() (root) / None (other ranks)"""
+        if self.world == 1:
+            return self._send[0]
+        i = (self._k - 1) & 1
+        self._wait(i)
+        if self.rank != self.dst:
+            return None
+        return torch.cat(self._recv[i], dim=0)
+
+
 def run_sharded(process: Callable[[Sequence], torch.Tensor], items: Sequence, dst: int = 0,
                 group=None) -> Optional[torch.Tensor]:
     """process(shard_of_items) -> [n_local, ...] on every rank; the gathered result on `dst`."""

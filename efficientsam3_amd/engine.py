@@ -106,8 +106,9 @@ class HipEngine:
         img_hwc_u8 = img_hwc_u8.contiguous()
         b, h, w, _ = img_hwc_u8.shape
         out = torch.empty((b, 3, h, w), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.esam3_preprocess_u8(_ptr(img_hwc_u8), _ptr(out), b, h, w, _stream()),
-                   "esam3_preprocess_u8")
+        with torch.cuda.device(self.dev_index):  # the launch goes to THIS engine's device and its current stream
+            _lib.check(self.lib.esam3_preprocess_u8(_ptr(img_hwc_u8), _ptr(out), b, h, w, _stream()),
+                       "esam3_preprocess_u8")
         return out
 
     def preprocess_resize_u8(self, img_hwc_u8: torch.Tensor, out_chw: torch.Tensor) -> torch.Tensor:
@@ -116,8 +117,9 @@ class HipEngine:
         assert img_hwc_u8.is_cuda and img_hwc_u8.is_contiguous() and out_chw.is_contiguous()
         assert out_chw.dtype == torch.float32 and out_chw.dim() == 3 and out_chw.shape[0] == 3
         h, w = img_hwc_u8.shape[:2]
-        _lib.check(self.lib.esam3_preprocess_resize_u8(_ptr(img_hwc_u8), h, w, _ptr(out_chw), out_chw.shape[1],
-                                                       out_chw.shape[2], _stream()), "esam3_preprocess_resize_u8")
+        with torch.cuda.device(self.dev_index):
+            _lib.check(self.lib.esam3_preprocess_resize_u8(_ptr(img_hwc_u8), h, w, _ptr(out_chw), out_chw.shape[1],
+                                                           out_chw.shape[2], _stream()), "esam3_preprocess_resize_u8")
         return out_chw
 
     def encode(self, img_nchw: torch.Tensor, want_sam3: bool = True, want_sam2: bool = True,
@@ -288,7 +290,8 @@ class HipEngine:
         return out
 
     def clamp_(self, x: torch.Tensor, lo: float, hi: float) -> torch.Tensor:
-        _lib.check(self.lib.esam3_clamp_f32(self.handle, _ptr(x), x.numel(), lo, hi, _stream()), "esam3_clamp_f32")
+        with torch.cuda.device(self.dev_index):
+            _lib.check(self.lib.esam3_clamp_f32(self.handle, _ptr(x), x.numel(), lo, hi, _stream()), "esam3_clamp_f32")
         return x
 
     def profile_enable(self, on: bool = True):

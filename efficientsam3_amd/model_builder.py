@@ -26,6 +26,36 @@ def _clean_checkpoint_keys(ckpt: Dict[str, torch.Tensor], interactive: bool) -> 
     return clean_checkpoint_keys(ckpt, interactive)
 
 
+def resolve_bpe_path(bpe_path=None, required: bool = False):
+    """The CLIP BPE merge table: explicit argument, else $ESAM3_BPE_PATH, else ``assets/bpe_simple_vocab_16e6.txt.gz``
+    next to this package or next to an importable reference ``sam3`` package (the reference's own default,
+    sam3/sam3/model_builder.py:676-680).  An explicit path must exist; otherwise None is returned when nothing is found
+    (``required=False``) so that models fed with token ids can still be built."""
+    import os
+    if bpe_path is not None:
+        if not os.path.exists(bpe_path):
+            raise FileNotFoundError(f"bpe_path {bpe_path!r} does not exist (the reference ships it as "
+                                    "assets/bpe_simple_vocab_16e6.txt.gz)")
+        return bpe_path
+    cands = [os.environ.get("ESAM3_BPE_PATH"),
+             os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "bpe_simple_vocab_16e6.txt.gz")]
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("sam3")
+        for loc in (list(spec.submodule_search_locations) if spec and spec.submodule_search_locations else []):
+            cands += [os.path.join(loc, "..", "assets", "bpe_simple_vocab_16e6.txt.gz"),
+                      os.path.join(loc, "assets", "bpe_simple_vocab_16e6.txt.gz")]
+    except (ImportError, ValueError):
+        pass
+    for c in cands:
+        if c and os.path.exists(c):
+            return os.path.abspath(c)
+    if required:
+        raise FileNotFoundError("no CLIP BPE merge table found: pass bpe_path= or set ESAM3_BPE_PATH "
+                                "(the reference ships it as assets/bpe_simple_vocab_16e6.txt.gz)")
+    return None
+
+
 def build_efficientsam3_image_model(
     bpe_path=None,
     device="cuda",
@@ -50,10 +80,15 @@ def build_efficientsam3_image_model(
     """Build an EfficientSAM3 image model whose encode/decode run as HIP kernels on MI355X.
 
     Reference arguments keep their meaning.  ``compile`` is accepted and ignored (there is no
-    tracing compiler; the engine *is* the compiled graph).  ``text_encoder_type="MobileCLIP-S0"`` adds
-    the student text encoder (``model.backbone.language_backbone`` / ``forward_text``; ``bpe_path`` is
-    the reference's merge table); ``enable_segmentation`` configures the PCS grounding head, which
-    this build does not run yet.
+    tracing compiler; the engine *is* the compiled graph).  ``text_encoder_type`` (MobileCLIP-S0 / -S1 / -B,
+    MobileCLIP2-S0/S2/S3/S4/L) adds the student text encoder (``model.backbone.language_backbone`` /
+    ``forward_text``) and the PCS text-grounding detector (``Sam3Processor.set_text_prompt``,
+    ``add_geometric_prompt``); ``bpe_path`` is the CLIP merge table the reference ships as
+    ``assets/bpe_simple_vocab_16e6.txt.gz`` -- resolved here, at build time (``resolve_bpe_path``): an explicit path
+    that does not exist raises, no path at all leaves the token-id entry points (``language_backbone.encode_tokens``,
+    ``engine.encode_text``) usable and makes string prompts fail with the same message.
+    ``load_state_dict`` is stricter than the reference's ``strict=False`` load: a key the selected graph needs and the
+    checkpoint lacks raises KeyError (the reference warns and keeps the random initialisation).
     ``dtype``: "bf16" (throughput) or "f32" (validation: exact-f32 MFMA).
     ``fuse_linear_chains``: compose the neck's ConvT->1x1 and 3x3->conv_s0/s1 weight chains at
     load time (exact algebra, same outputs, fewer FLOPs); False runs the reference's layer list.
@@ -62,14 +97,15 @@ def build_efficientsam3_image_model(
         backbone_type, model_name = "efficientvit", efficientvit_model
     if str(device).startswith("cpu"):
         raise RuntimeError("EfficientSAM3-AMD has no CPU path; pass a HIP device (device='cuda')")
+    if text_encoder_type is not None:
+        bpe_path = resolve_bpe_path(bpe_path)
     model = Sam3Image(backbone_type, model_name, bool(enable_inst_interactivity), dtype=dtype,
                       device=device, dual_neck=dual_neck, fuse_linear_chains=fuse_linear_chains,
                       text_encoder_type=text_encoder_type, text_encoder_context_length=text_encoder_context_length,
                       bpe_path=bpe_path)
     if state_dict is None and checkpoint_path is not None:
-        with open(checkpoint_path, "rb") as f:
-            ckpt = torch.load(f, map_location="cpu", weights_only=True)
-        state_dict = _clean_checkpoint_keys(ckpt, bool(enable_inst_interactivity))
+        from .checkpoint import load_state_dict_file
+        state_dict = _clean_checkpoint_keys(load_state_dict_file(checkpoint_path), bool(enable_inst_interactivity))
     if state_dict is None:
         state_dict = schema.synthetic_state_dict(backbone_type, model_name, seed=synthetic_seed,
                                                  enable_inst_interactivity=bool(enable_inst_interactivity))
@@ -102,20 +138,21 @@ def build_sam3_image_model(
     fuse_linear_chains: bool = True,
 ) -> Sam3Image:
     """``build_sam3_image_model`` (model_builder.py:643-750): the ViT-H teacher trunk + the same dual neck and
-    SAM heads as the students.  The image path (set_image / predict_inst) runs on the HIP engine; the 354 M
-    teacher text encoder and the PCS grounding head are not built (``text_encoder_type="MobileCLIP-S0"`` gives
-    the LiteText student encoder)."""
+    SAM heads as the students, on the HIP engine.  With ``text_encoder_type`` (the LiteText students, e.g.
+    "MobileCLIP-S0") the text encoder and the PCS grounding detector run as well (BASELINE config 4); the 354 M
+    teacher text encoder (``text_encoder_type=None`` with ``enable_text_encoder``) is out of scope."""
     if str(device).startswith("cpu"):
         raise RuntimeError("EfficientSAM3-AMD has no CPU path; pass a HIP device (device='cuda')")
     if not enable_vision_encoder:
         raise NotImplementedError("enable_vision_encoder=False")
+    if text_encoder_type is not None:
+        bpe_path = resolve_bpe_path(bpe_path)
     model = Sam3Image("sam3", "vit_h", bool(enable_inst_interactivity), dtype=dtype, device=device, dual_neck=dual_neck,
                       fuse_linear_chains=fuse_linear_chains, text_encoder_type=text_encoder_type,
                       text_encoder_context_length=text_encoder_context_length, bpe_path=bpe_path)
     if state_dict is None and checkpoint_path is not None:
-        with open(checkpoint_path, "rb") as f:
-            ckpt = torch.load(f, map_location="cpu", weights_only=True)
-        state_dict = _clean_checkpoint_keys(ckpt, bool(enable_inst_interactivity))
+        from .checkpoint import load_state_dict_file
+        state_dict = _clean_checkpoint_keys(load_state_dict_file(checkpoint_path), bool(enable_inst_interactivity))
     if state_dict is None:
         state_dict = schema.synthetic_state_dict("sam3", "vit_h", seed=synthetic_seed,
                                                  enable_inst_interactivity=bool(enable_inst_interactivity))

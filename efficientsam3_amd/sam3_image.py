@@ -115,7 +115,7 @@ class _VLBackbone:
     def forward_text(self, captions, input_boxes=None, additional_text=None, device=None):
         """_forward_text_no_ack_ckpt (vl_combiner.py:136-180)."""
         if self.language_backbone is None:
-            raise NotImplementedError("model was built without text_encoder_type='MobileCLIP-S0'")
+            raise NotImplementedError("model was built without a text encoder (pass text_encoder_type=, e.g. 'MobileCLIP-S0')")
         texts = list(captions) + (list(additional_text) if additional_text is not None else [])
         mask, memory, embeds = self.language_backbone(texts, input_boxes, device=device)
         out = {}
@@ -400,7 +400,7 @@ class Sam3Image:
         add_point_prompt pass: the image features of set_image, the text features of forward_text (one text,
         broadcast to every image) and the geometric prompt (a ``geometry_prompt.Prompt``; empty = dummy)."""
         if self.text_encoder_type is None:
-            raise NotImplementedError("model was built without text_encoder_type='MobileCLIP-S0'")
+            raise NotImplementedError("model was built without a text encoder (pass text_encoder_type=, e.g. 'MobileCLIP-S0')")
         if not getattr(self, "_has_detector", False):
             raise RuntimeError("the loaded state dict has no grounding-detector weights (geometry_encoder.*, "
                                "transformer.*, segmentation_head.*, dot_prod_scoring.*)")

@@ -151,3 +151,83 @@ def test_detector_chunk_all_gather(begin, num_frames):
             for i, x in enumerate(_fpn(f)):
                 np.testing.assert_array_equal(res[f][f"tracker_backbone_fpn_{i}"], x.to(torch.bfloat16).float().numpy())
             assert res[f]["tracker_backbone_pos_enc"] == "pos"
+
+
+# ---- MaskGatherer: preallocated buffers, gather overlapped with the next step ------------------------------------
+def _gatherer_worker(rank, world, port, backend, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank) if backend == "nccl" else torch.device("cpu")
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+    esdist.init_process_group(backend, dev)
+    try:
+        g = esdist.MaskGatherer(dst=0)
+        outs = []
+        for step in range(4):  # four steps through the two alternating send slots
+            local = _fake_masks(range(100 * step + 3 * rank, 100 * step + 3 * rank + 3)).to(dev)
+            g.submit(local)
+            if step in (1, 3):
+                r = g.result()
+                outs.append(None if r is None else r.cpu().numpy())
+        g.flush()
+        assert g.allocations == 1, g.allocations
+        assert dist.get_world_size() == world and dist.get_backend() == backend
+        q.put((rank, outs))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_gatherer(backend):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gatherer_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[1] == [None, None]
+    for got, step in zip(results[0], (1, 3)):
+        want = torch.cat([_fake_masks(range(100 * step + 3 * r, 100 * step + 3 * r + 3)) for r in range(world)]).numpy()
+        np.testing.assert_array_equal(got, want)
+
+
+def test_mask_gatherer_gloo():
+    _run_gatherer("gloo")
+
+
+@pytest.mark.gpu
+def test_mask_gatherer_rccl():
+    """The same exchange over RCCL (backend "nccl") between two GPUs of one node; skipped on a single-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    _run_gatherer("nccl")
+
+
+def test_bench_respawns_itself_for_multi_gpu(monkeypatch):
+    """`python bench.py --gpus N` from a bare shell (no WORLD_SIZE) re-executes itself through torch.distributed.run
+    with N ranks on 127.0.0.1 instead of refusing to run."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_exec(file, argv, env):
+        seen.update(file=file, argv=argv, env=env)
+        raise SystemExit(0)
+
+    monkeypatch.setattr(os, "execvpe", fake_exec)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    a = seen["argv"]
+    assert a[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in a and "127.0.0.1" in a
+    assert a[-4:] == ["--gpus", "4", "--steps", "2"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -267,3 +267,81 @@ def test_geometry_prompt_matches_reference_prompt_class():
                 assert torch.equal(mine.box_mask, ref.box_mask), (trial, step)
                 assert torch.equal(mine.box_embeddings.transpose(0, 1)[valid], ref.box_embeddings.transpose(0, 1)[valid])
                 assert torch.equal(mine.box_labels.transpose(0, 1)[valid].long(), ref.box_labels.transpose(0, 1)[valid].long())
+
+
+def test_full_training_checkpoint_loads_without_unpickling_foreign_code(tmp_path):
+    """stage1/utils.py:287-293 saves {"model", "optimizer", "scaler", "config" (a yacs CfgNode), ...}; the reference's
+    converters load it with weights_only=False.  load_state_dict_file must ingest such a file -- the foreign classes are
+    not importable here -- WITHOUT executing pickled code, and `trusted=True` is the explicit opt-in to a full unpickle."""
+    import sys
+    import types
+
+    import torch
+
+    from efficientsam3_amd import checkpoint
+    pkg, mod = types.ModuleType("yacs_like"), types.ModuleType("yacs_like.config")
+
+    class CfgNode(dict):
+        pass
+
+    CfgNode.__module__, CfgNode.__qualname__ = "yacs_like.config", "CfgNode"
+    mod.CfgNode = CfgNode
+    sys.modules["yacs_like"], sys.modules["yacs_like.config"] = pkg, mod
+    marker = tmp_path / "executed"
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, (f"touch {marker}",))
+
+    try:
+        ck = {"model": {"student_trunk.w": torch.arange(4.0), "b": torch.ones(2, dtype=torch.bfloat16)},
+              "optimizer": {"state": {0: {"exp_avg": torch.zeros(2)}}, "param_groups": [{"lr": 1e-3}]},
+              "config": CfgNode(a=1, nested=CfgNode(c="x")), "epoch": 3, "hook": Evil()}
+        path = str(tmp_path / "ckpt_epoch_3.pth")
+        torch.save(ck, path)
+    finally:
+        del sys.modules["yacs_like"], sys.modules["yacs_like.config"]
+    sd = checkpoint.load_state_dict_file(path)
+    assert sorted(sd) == ["b", "student_trunk.w"] and torch.equal(sd["student_trunk.w"], torch.arange(4.0))
+    assert not marker.exists(), "pickled code was executed"
+    assert "yacs_like" not in sys.modules
+    plain = str(tmp_path / "plain.pth")
+    torch.save({"w": torch.zeros(3)}, plain)
+    assert list(checkpoint.load_state_dict_file(plain)) == ["w"]
+
+
+def test_bpe_path_is_resolved_at_build_time(tmp_path, monkeypatch):
+    """model_builder.resolve_bpe_path: an explicit path that does not exist raises at BUILD time (the reference fails in
+    its tokenizer constructor too, model_builder.py:676-692), $ESAM3_BPE_PATH is honoured, nothing found -> None."""
+    from efficientsam3_amd import model_builder
+    with pytest.raises(FileNotFoundError):
+        model_builder.resolve_bpe_path(str(tmp_path / "missing.txt.gz"))
+    f = tmp_path / "bpe.txt.gz"
+    f.write_bytes(b"x")
+    assert model_builder.resolve_bpe_path(str(f)) == str(f)
+    monkeypatch.setenv("ESAM3_BPE_PATH", str(f))
+    assert model_builder.resolve_bpe_path(None) == str(f)
+    monkeypatch.delenv("ESAM3_BPE_PATH")
+    got = model_builder.resolve_bpe_path(None)
+    assert got is None or got.endswith("bpe_simple_vocab_16e6.txt.gz")
+    if got is None:
+        with pytest.raises(FileNotFoundError):
+            model_builder.resolve_bpe_path(None, required=True)
+
+
+def test_rle_string_decoder_rejects_malformed_input():
+    """esam3_rle_from_string: characters outside cocoapi's alphabet and endless continuation runs are errors, not
+    undefined shifts."""
+    import ctypes as C
+
+    from efficientsam3_amd import _lib
+    lib = _lib.load()
+    lib.esam3_rle_from_string.restype = C.c_int64
+    lib.esam3_rle_from_string.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_uint32), C.c_int64]
+    buf = (C.c_uint32 * 16)()
+    good = b"52203"  # five single-character counts
+    assert lib.esam3_rle_from_string(good, len(good), buf, 16) == 5
+    assert lib.esam3_rle_from_string(b"\x10\x11", 2, buf, 16) == -1          # below '0'
+    assert lib.esam3_rle_from_string(b"o" * 20 + b"0", 21, buf, 16) == -1    # 'o' = continuation bit set, 20 times
+    assert lib.esam3_rle_from_string(b"o", 1, buf, 16) == -1                  # truncated
