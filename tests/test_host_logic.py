@@ -336,12 +336,13 @@ def test_rle_string_decoder_rejects_malformed_input():
     import ctypes as C
 
     from efficientsam3_amd import _lib
-    lib = _lib.load()
-    lib.esam3_rle_from_string.restype = C.c_int64
-    lib.esam3_rle_from_string.argtypes = [C.c_char_p, C.c_int64, C.POINTER(C.c_uint32), C.c_int64]
+    lib = _lib.load()  # signature declared in _lib.py: (void*, int64, void*, int64) -> int64
     buf = (C.c_uint32 * 16)()
-    good = b"52203"  # five single-character counts
-    assert lib.esam3_rle_from_string(good, len(good), buf, 16) == 5
-    assert lib.esam3_rle_from_string(b"\x10\x11", 2, buf, 16) == -1          # below '0'
-    assert lib.esam3_rle_from_string(b"o" * 20 + b"0", 21, buf, 16) == -1    # 'o' = continuation bit set, 20 times
-    assert lib.esam3_rle_from_string(b"o", 1, buf, 16) == -1                  # truncated
+
+    def dec(b):
+        return int(lib.esam3_rle_from_string(C.cast(C.c_char_p(b), C.c_void_p), len(b), C.cast(buf, C.c_void_p), 16))
+
+    assert dec(b"52203") == 5                 # five single-character counts
+    assert dec(b"\x10\x11") == -1             # below '0'
+    assert dec(b"o" * 20 + b"0") == -1        # 'o' = continuation bit set, 20 times
+    assert dec(b"o") == -1                    # truncated
