@@ -80,6 +80,7 @@ SIGNATURES = {
     "esam3_encode_text": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "esam3_preprocess_u8": (_I, [_P, _P, _I, _I, _I, _P]),
     "esam3_preprocess_resize_u8": (_I, [_P, _I, _I, _P, _I, _I, _P]),
+    "esam3_preprocess_resize_u8_batch": (_I, [_P, _I, _I, _I, _P, _I, _I, _P]),
     "esam3_op_linear": (_I, [_I, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "esam3_op_conv2d": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_conv3x3_s2": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

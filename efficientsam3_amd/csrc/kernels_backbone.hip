@@ -1637,6 +1637,8 @@ __global__ __launch_bounds__(256) void resize_aa_u8_kernel(const uint8_t* __rest
                                 // .5 rounding ties often enough (uint8 inputs) for an fma to show
   const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y;
   if (ox >= OW) return;
+  in += (int64_t)blockIdx.z * H * W * 3;      // image of the batch (equal sizes)
+  out += (int64_t)blockIdx.z * 3 * OH * OW;
   const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
   const float sup_y = sy >= 1.f ? sy : 1.f, sup_x = sx >= 1.f ? sx : 1.f;
   const float inv_y = sy >= 1.f ? 1.f / sy : 1.f, inv_x = sx >= 1.f ? 1.f / sx : 1.f;
@@ -1709,9 +1711,9 @@ int esam3_launch_preprocess_u8(const uint8_t* in, float* out, int B, int H, int 
   return 0;
 }
 
-int esam3_launch_resize_aa_u8(const uint8_t* in, int H, int W, float* out, int OH, int OW, hipStream_t s) {
-  hipLaunchKernelGGL(resize_aa_u8_kernel, dim3(blocks_for(OW, 256), (unsigned)OH), dim3(256), 0, s, in, H, W, out,
-                     OH, OW);
+int esam3_launch_resize_aa_u8(const uint8_t* in, int B, int H, int W, float* out, int OH, int OW, hipStream_t s) {
+  hipLaunchKernelGGL(resize_aa_u8_kernel, dim3(blocks_for(OW, 256), (unsigned)OH, (unsigned)B), dim3(256), 0, s, in, H, W,
+                     out, OH, OW);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -122,6 +122,17 @@ class HipEngine:
                                                            out_chw.shape[2], _stream()), "esam3_preprocess_resize_u8")
         return out_chw
 
+    def preprocess_resize_u8_batch(self, imgs_bhwc_u8: torch.Tensor, out_bchw: torch.Tensor) -> torch.Tensor:
+        """B uint8 HWC images of ONE size [B,H,W,3] -> out_bchw [B,3,R,R] fp32 in a single launch."""
+        assert imgs_bhwc_u8.dtype == torch.uint8 and imgs_bhwc_u8.dim() == 4 and imgs_bhwc_u8.shape[-1] == 3
+        assert imgs_bhwc_u8.is_cuda and imgs_bhwc_u8.is_contiguous() and out_bchw.is_contiguous()
+        assert out_bchw.dtype == torch.float32 and out_bchw.dim() == 4 and out_bchw.shape[:2] == (imgs_bhwc_u8.shape[0], 3)
+        b, h, w = imgs_bhwc_u8.shape[:3]
+        with torch.cuda.device(self.dev_index):
+            _lib.check(self.lib.esam3_preprocess_resize_u8_batch(_ptr(imgs_bhwc_u8), b, h, w, _ptr(out_bchw), out_bchw.shape[2],
+                                                                 out_bchw.shape[3], _stream()), "esam3_preprocess_resize_u8_batch")
+        return out_bchw
+
     def encode(self, img_nchw: torch.Tensor, want_sam3: bool = True, want_sam2: bool = True,
                want_trunk: bool = False, want_stages: bool = False, out: Optional[dict] = None) -> dict:
         """img_nchw: [B,3,1008,1008] fp32 normalised, on this engine's device.  ``out``: a dict

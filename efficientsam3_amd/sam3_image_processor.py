@@ -31,8 +31,7 @@ class Sam3Processor:
         (sam3_image_processor.py:50-57): PIL -> size; ndarray/Tensor -> shape[-2:]."""
         if _PILImage is not None and isinstance(image, _PILImage.Image):
             width, height = image.size
-            arr = np.asarray(image.convert("RGB"))
-            t = torch.from_numpy(np.ascontiguousarray(arr))
+            t = torch.from_numpy(np.array(image.convert("RGB")))  # a writable copy: PIL's buffer is read-only
         elif isinstance(image, np.ndarray):
             height, width = image.shape[-2:]  # (sic) the reference reads CHW-style dims here
             arr = image if image.ndim == 3 else image[:, :, None]
@@ -61,12 +60,19 @@ class Sam3Processor:
             batch = torch.stack([t.to(self.device) for t in hwc_u8_list], dim=0)
             return self.model.engine.preprocess_u8(batch)
         out = torch.empty((len(hwc_u8_list), 3, r, r), dtype=torch.float32, device=self.device)
+        eng = self.model.engine
+        if len({tuple(t.shape) for t in hwc_u8_list}) == 1 and hasattr(eng, "preprocess_resize_u8_batch"):
+            # one size: ONE host-to-device copy of the stacked batch and ONE resize launch
+            batch = torch.stack(hwc_u8_list, dim=0)
+            if not batch.is_cuda:
+                batch = batch.pin_memory().to(self.device, non_blocking=True)
+            return eng.preprocess_resize_u8_batch(batch.contiguous(), out)
         for i, t in enumerate(hwc_u8_list):
             t = t.to(self.device).contiguous()
             if tuple(t.shape[:2]) == (r, r):
-                out[i] = self.model.engine.preprocess_u8(t[None])[0]
+                out[i] = eng.preprocess_u8(t[None])[0]
             else:
-                self.model.engine.preprocess_resize_u8(t, out[i])
+                eng.preprocess_resize_u8(t, out[i])
         return out
 
     # ---- reference API ---------------------------------------------------------------------------

@@ -156,6 +156,10 @@ int esam3_preprocess_u8(const uint8_t* img_hwc_u8_dev, float* out_nchw_f32_dev, 
  * uint8 HWC [H][W][3] -> fp32 CHW [3][out_h][out_w] */
 int esam3_preprocess_resize_u8(const uint8_t* img_hwc_u8_dev, int H, int W, float* out_chw_f32_dev,
                                int out_h, int out_w, void* hip_stream);
+/* the same for B images of one size in ONE launch (Sam3Processor.set_image_batch, sam3_image_processor.py:86-113,
+ * applies the transform per image in a Python loop): uint8 [B][H][W][3] -> fp32 [B][3][out_h][out_w] */
+int esam3_preprocess_resize_u8_batch(const uint8_t* imgs_bhwc_u8_dev, int B, int H, int W, float* out_bchw_f32_dev,
+                                     int out_h, int out_w, void* hip_stream);
 
 /* COCO run-length encoding of binary masks, the mask -> RLE step of the evaluation writers
  * (scripts/eval/gold/eval_efficientsam3_all_subsets.py:124-135 through pycocotools.mask.encode;
