@@ -736,7 +736,13 @@ bool use_256(const GemmParams& p) {
   constexpr int BKE = 128 / (int)sizeof(T);
   if (p.M >= (int64_t)1 << 31) return false;
   if (p.stride > 1) return false;
-  if (p.N < 192 || p.N % 32 != 0 || p.M < 256 || p.K % BKE != 0 || p.K != p.Kp) return false;
+  // N >= 192 fills at least 3/4 of the tile's channel side.  A bf16 layer with 128 <= N < 192 and a long M (the mask
+  // decoder's 256 -> 128 projections of the 5184-token image side) is HBM-bound: the half-empty 256-wide tile still
+  // streams its rows through the LDS-DMA pipeline faster than the register-staged 128 x 128 kernel does.
+  const bool wide_enough = p.N >= 192 || (sizeof(T) == 2 && p.N >= 128 && p.M >= 16384);
+  // few rows (token-side GEMMs of the decoders, M = a few hundred): one or two 256-row tiles would serialise the whole
+  // K loop on one or two CUs; the 128 x BN kernel spreads them over more workgroups
+  if (!wide_enough || p.N % 32 != 0 || p.M < 1024 || p.K % BKE != 0 || p.K != p.Kp) return false;
   if (p.out_mode == OUT_CONVT2X2 && p.convt_cout % 32 != 0) return false;
   if ((p.ldc * (int)sizeof(T)) % 16 != 0 || (p.res && (p.ldr * (int)sizeof(T)) % 8 != 0)) return false;
   if (p.ksize == 3 && (!p.in_pad || p.Cin % BKE != 0)) return false;
