@@ -1907,6 +1907,11 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
   void* ik = allocb((size_t)Bp * P * 128 * esz);
   void* iv = allocb((size_t)Bp * P * 128 * esz);
   if (!ok(qin) || !ok(tq) || !ok(tk) || !ok(tv) || !ok(ta) || !ok(th) || !ok(ik) || !ok(iv)) return -1;
+  float* t2i_scratch = nullptr;  // per-chunk softmax partials of the token -> image attention
+  if (const int64_t nf = esam3_attn_scratch_floats(Bp, T, (int)P, 8, 16)) {
+    t2i_scratch = (float*)allocb((size_t)nf * sizeof(float));
+    if (!ok(t2i_scratch)) return -1;
+  }
 
   auto add = [&](const void* a, const void* b, void* o, int64_t n) -> int {
     if (dry) return 0;
@@ -1921,7 +1926,8 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
     CK(linear(ap + "q_proj", qin, DM, TR, tq, 128, ACT_NONE));
     CK(linear(ap + "k_proj", keys, DM, Bp * P, ik, 128, ACT_NONE, tbufs[ap + "k_proj#pe"], 128, (int)P));
     CK(linear(ap + "v_proj", keys, DM, Bp * P, iv, 128, ACT_NONE));
-    if (!dry) CK(prof_launch("attn", 0.0, 0.0, [&]() { return esam3_launch_attn(dtype, tq, 128, ik, 128, iv, 128, ta, 128, Bp, T, (int)P, 8, 16, st); }));
+    if (!dry) CK(prof_launch("attn_t2i", 4.0 * Bp * T * (double)P * 128, 2.0 * (double)Bp * P * 128 * (double)esz, [&]() {
+      return esam3_launch_attn(dtype, tq, 128, ik, 128, iv, 128, ta, 128, Bp, T, (int)P, 8, 16, t2i_scratch, st); }));
     CK(linear(ap + "out_proj", ta, 128, TR, queries, DM, ACT_NONE, queries, DM));
     return ln(norm, queries, TR);
   };
@@ -1934,7 +1940,7 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
     CK(linear(lp + "self_attn.q_proj", qk_in, DM, TR, tq, DM, ACT_NONE));
     CK(linear(lp + "self_attn.k_proj", qk_in, DM, TR, tk, DM, ACT_NONE));
     CK(linear(lp + "self_attn.v_proj", queries, DM, TR, tv, DM, ACT_NONE));
-    if (!dry) CK(prof_launch("attn", 0.0, 0.0, [&]() { return esam3_launch_attn(dtype, tq, DM, tk, DM, tv, DM, ta, DM, Bp, T, T, 8, 32, st); }));
+    if (!dry) CK(prof_launch("attn", 0.0, 0.0, [&]() { return esam3_launch_attn(dtype, tq, DM, tk, DM, tv, DM, ta, DM, Bp, T, T, 8, 32, nullptr, st); }));
     if (li == 0) CK(linear(lp + "self_attn.out_proj", ta, DM, TR, queries, DM, ACT_NONE));
     else CK(linear(lp + "self_attn.out_proj", ta, DM, TR, queries, DM, ACT_NONE, queries, DM));
     CK(ln(lp + "norm1", queries, TR));

@@ -48,9 +48,12 @@ int esam3_launch_gather_add(int dtype, const void* in, const int* src_img, const
                             const void* dense, void* out, int Bp, int64_t P, int C, hipStream_t s);
 
 // softmax attention, few queries vs many keys (token -> image):  q [Bq][Nq][ldq] etc.
+// `scratch`: fp32 workspace of esam3_attn_scratch_floats(...) elements (0 = the shape has no tiled variant) or null;
+// with it, <= 16 queries x 8 heads x 16 against >= 1024 keys run on the LDS-tiled kernel.
+int64_t esam3_attn_scratch_floats(int B, int Nq, int Nk, int heads, int hd);
 int esam3_launch_attn(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v,
                       int ldv, void* o, int ldo, int B, int Nq, int Nk, int heads, int hd,
-                      hipStream_t s);
+                      float* scratch, hipStream_t s);
 // softmax attention, many queries vs few keys (image -> token), Nk <= 64.
 int esam3_launch_attn_fewkeys(int dtype, const void* q, int ldq, const void* k, int ldk,
                               const void* v, int ldv, void* o, int ldo, int B, int Nq, int Nk,

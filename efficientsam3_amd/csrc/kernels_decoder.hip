@@ -628,8 +628,184 @@ int esam3_launch_gather_add(int dtype, const void* in, const int* src_img, const
   return 0;
 }
 
+namespace {
+// ------------------------------------------------------------------------------------
+// Token -> image cross attention of the two-way decoder (sam/transformer.py:165-170,226-264): <= 16 query tokens,
+// 8 heads x 16, thousands of keys.  The image-side K / V (Nk x 128 per prompt) are the only real traffic:
+//   * a workgroup owns one key chunk of one prompt; K and V tiles of TK keys go HBM -> LDS with 16-byte coalesced loads
+//     (whole 256-byte rows), once;
+//   * thread = (key parity s, token t, head h): its 16 query values sit in registers, the K / V slices of head h are
+//     LDS reads that the 16 tokens of a head share (broadcast, conflict-free: 8 heads = 8 distinct 32-byte slots);
+//   * fp32 online softmax per thread; the per-chunk (max, sum, acc[16]) partials are merged by attn_t2i_merge_kernel
+//     in a fixed order (bit-reproducible).
+// ------------------------------------------------------------------------------------
+constexpr int T2I_HEADS = 8, T2I_HD = 16, T2I_D = 128, T2I_MAXQ = 16, T2I_PART = 18;  // partial = m, l, acc[16]
+
+template <typename T> __device__ __forceinline__ void load_head16(const T* p, float (&f)[16]);
+template <> __device__ __forceinline__ void load_head16<bf16_t>(const bf16_t* p, float (&f)[16]) {
+  const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 8);
+  const uint32_t u[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f[2 * i] = __uint_as_float(u[i] << 16);
+    f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+  }
+}
+template <> __device__ __forceinline__ void load_head16<float>(const float* p, float (&f)[16]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float4 a = *reinterpret_cast<const float4*>(p + 4 * i);
+    f[4 * i] = a.x; f[4 * i + 1] = a.y; f[4 * i + 2] = a.z; f[4 * i + 3] = a.w;
+  }
+}
+
+template <typename T, int TK>
+__global__ __launch_bounds__(256) void attn_t2i_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                       float* __restrict__ part, int Nq, int Nk, int chunk_keys, int nchunks) {
+  constexpr int EPC = 16 / (int)sizeof(T);          // elements per 16-byte load
+  constexpr int SLOTS = T2I_D / EPC;                // 16-byte slots per row
+  __shared__ __attribute__((aligned(16))) T sk[TK * T2I_D];
+  __shared__ __attribute__((aligned(16))) T sv[TK * T2I_D];
+  const int chunk = blockIdx.x;
+  const int64_t b = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int sidx = tid >> 7, t = (tid >> 3) & 15, h = tid & 7;
+  const bool active = t < Nq;
+  float qv[T2I_HD];
+  {
+    const float scale = 0.25f;  // 1 / sqrt(16)
+    const T* qp = q + (b * Nq + (active ? t : 0)) * (int64_t)T2I_D + h * T2I_HD;
+#pragma unroll
+    for (int d = 0; d < T2I_HD; ++d) qv[d] = active ? to_f32<T>(qp[d]) * scale : 0.f;
+  }
+  float m = -3.0e38f, l = 0.f, acc[T2I_HD];
+#pragma unroll
+  for (int d = 0; d < T2I_HD; ++d) acc[d] = 0.f;
+  const int k0 = chunk * chunk_keys;
+  const int k1 = min(Nk, k0 + chunk_keys);
+  const T* kb = k + b * (int64_t)Nk * T2I_D;
+  const T* vb = v + b * (int64_t)Nk * T2I_D;
+  // software pipeline: the global loads of tile i+1 are in flight (in registers) while tile i is consumed from LDS
+  constexpr int LPT = TK * SLOTS / 256;  // 16-byte loads per thread per tile and operand
+  uint4 rk[LPT], rv[LPT];
+  auto fetch = [&](int j0) {
+    const int nkeys = min(TK, k1 - j0);
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) {
+      const int i = tid + u * 256;
+      const int r = i / SLOTS, sl = i - r * SLOTS;
+      rk[u] = make_uint4(0u, 0u, 0u, 0u);
+      rv[u] = rk[u];
+      if (r < nkeys) {
+        rk[u] = *reinterpret_cast<const uint4*>(kb + (int64_t)(j0 + r) * T2I_D + sl * EPC);
+        rv[u] = *reinterpret_cast<const uint4*>(vb + (int64_t)(j0 + r) * T2I_D + sl * EPC);
+      }
+    }
+  };
+  if (k0 < k1) fetch(k0);
+  for (int j0 = k0; j0 < k1; j0 += TK) {
+    const int nkeys = min(TK, k1 - j0);
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) {
+      const int i = tid + u * 256;
+      *reinterpret_cast<uint4*>(sk + i * EPC) = rk[u];  // row-major [TK][128]: slot i of the tile
+      *reinterpret_cast<uint4*>(sv + i * EPC) = rv[u];
+    }
+    __syncthreads();
+    if (j0 + TK < k1) fetch(j0 + TK);
+    if (active) {
+      for (int r = sidx; r < nkeys; r += 2) {
+        float kf[T2I_HD], vf[T2I_HD];
+        load_head16<T>(sk + r * T2I_D + h * T2I_HD, kf);  // two 16-byte (bf16) / four (f32) LDS reads
+        load_head16<T>(sv + r * T2I_D + h * T2I_HD, vf);
+        float sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < T2I_HD; ++d) sc = fmaf(qv[d], kf[d], sc);
+        if (sc > m) {  // new running maximum (rare after the first keys): rescale what has been accumulated
+          const float alpha = __expf(m - sc);
+          l *= alpha;
+#pragma unroll
+          for (int d = 0; d < T2I_HD; ++d) acc[d] *= alpha;
+          m = sc;
+        }
+        const float pe = __expf(sc - m);
+        l += pe;
+#pragma unroll
+        for (int d = 0; d < T2I_HD; ++d) acc[d] = fmaf(pe, vf[d], acc[d]);
+      }
+    }
+    __syncthreads();
+  }
+  if (active) {
+    float* pp = part + ((((b * nchunks + chunk) * 2 + sidx) * T2I_MAXQ + t) * T2I_HEADS + h) * T2I_PART;
+    pp[0] = m;
+    pp[1] = l;
+#pragma unroll
+    for (int d = 0; d < T2I_HD; ++d) pp[2 + d] = acc[d];
+  }
+}
+
+template <typename T>
+__global__ void attn_t2i_merge_kernel(const float* __restrict__ part, T* __restrict__ o, int B, int Nq, int nparts) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // (b, t, h)
+  if (i >= B * Nq * T2I_HEADS) return;
+  const int h = i % T2I_HEADS, t = (i / T2I_HEADS) % Nq;
+  const int64_t b = i / (T2I_HEADS * Nq);
+  float m = -3.0e38f, l = 0.f, acc[T2I_HD];
+#pragma unroll
+  for (int d = 0; d < T2I_HD; ++d) acc[d] = 0.f;
+  for (int pi = 0; pi < nparts; ++pi) {  // fixed order
+    const float* pp = part + (((b * nparts + pi) * T2I_MAXQ + t) * T2I_HEADS + h) * T2I_PART;
+    const float m2 = pp[0], l2 = pp[1];
+    if (l2 == 0.f) continue;  // a part that saw no key
+    const float mn = fmaxf(m, m2);
+    const float a1 = __expf(m - mn), a2 = __expf(m2 - mn);
+    l = l * a1 + l2 * a2;
+#pragma unroll
+    for (int d = 0; d < T2I_HD; ++d) acc[d] = acc[d] * a1 + pp[2 + d] * a2;
+    m = mn;
+  }
+  T* op = o + (b * Nq + t) * (int64_t)T2I_D + h * T2I_HD;
+  const float inv = 1.f / l;
+#pragma unroll
+  for (int d = 0; d < T2I_HD; ++d) op[d] = from_f32<T>(acc[d] * inv);
+}
+
+}  // namespace
+
+// chunks of keys per prompt for the token -> image kernel, and the fp32 scratch it needs
+static int t2i_chunks(int B, int Nk) {
+  int n = (2 * 256 + B - 1) / B;  // about two workgroups per CU
+  n = n < 1 ? 1 : (n > 32 ? 32 : n);
+  const int max_by_keys = (Nk + 127) / 128;
+  return n < max_by_keys ? n : max_by_keys;
+}
+int64_t esam3_attn_scratch_floats(int B, int Nq, int Nk, int heads, int hd) {
+  if (heads != T2I_HEADS || hd != T2I_HD || Nq > T2I_MAXQ || Nk < 1024) return 0;
+  return (int64_t)B * t2i_chunks(B, Nk) * 2 * T2I_MAXQ * T2I_HEADS * T2I_PART;
+}
+
 int esam3_launch_attn(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
-                      void* o, int ldo, int B, int Nq, int Nk, int heads, int hd, hipStream_t s) {
+                      void* o, int ldo, int B, int Nq, int Nk, int heads, int hd, float* scratch, hipStream_t s) {
+  if (scratch && esam3_attn_scratch_floats(B, Nq, Nk, heads, hd) > 0 && ldq == T2I_D && ldk == T2I_D && ldv == T2I_D &&
+      ldo == T2I_D && !((uintptr_t)k & 15) && !((uintptr_t)v & 15)) {
+    const int nch = t2i_chunks(B, Nk);
+    int chunk_keys = (Nk + nch - 1) / nch;
+    chunk_keys = (chunk_keys + 63) / 64 * 64;
+    dim3 grid((unsigned)nch, (unsigned)B);
+    if (dtype == 0)
+      hipLaunchKernelGGL((attn_t2i_kernel<float, 32>), grid, dim3(256), 0, s, (const float*)q, (const float*)k, (const float*)v,
+                         scratch, Nq, Nk, chunk_keys, nch);
+    else
+      hipLaunchKernelGGL((attn_t2i_kernel<bf16_t, 64>), grid, dim3(256), 0, s, (const bf16_t*)q, (const bf16_t*)k,
+                         (const bf16_t*)v, scratch, Nq, Nk, chunk_keys, nch);
+    HIP_CHECK_RET(hipGetLastError());
+    const int total = B * Nq * T2I_HEADS;
+    DISPATCH_T(dtype, hipLaunchKernelGGL((attn_t2i_merge_kernel<T>), dim3(blocks_for(total, 128)), dim3(128), 0, s, scratch,
+                                         (T*)o, B, Nq, nch * 2));
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
   dim3 grid((unsigned)(B * heads), (unsigned)((Nq + 15) / 16));
   if (hd == 16) {
     DISPATCH_T(dtype, hipLaunchKernelGGL((attn_kernel<T, 16>), grid, dim3(256), 0, s, (const T*)q, ldq,

@@ -326,10 +326,17 @@ int esam3_op_attention(int dtype, const void* q, const void* k, const void* v, v
                        int heads, int hd, int few_keys, void* stream) {
   const int D = heads * hd;
   int rc;
-  if (few_keys)
+  Tmp t;
+  if (few_keys) {
     rc = esam3_launch_attn_fewkeys(dtype, q, D, k, D, v, D, out, D, B, Nq, Nk, heads, hd, (hipStream_t)stream);
-  else
-    rc = esam3_launch_attn(dtype, q, D, k, D, v, D, out, D, B, Nq, Nk, heads, hd, (hipStream_t)stream);
+  } else {
+    float* scratch = nullptr;  // the engine hands the tiled token -> image kernel its workspace; do the same here
+    if (const int64_t nf = esam3_attn_scratch_floats(B, Nq, Nk, heads, hd)) {
+      scratch = (float*)t.raw((size_t)nf * sizeof(float));
+      if (!scratch) return fail("op_attention");
+    }
+    rc = esam3_launch_attn(dtype, q, D, k, D, v, D, out, D, B, Nq, Nk, heads, hd, scratch, (hipStream_t)stream);
+  }
   if (rc) return -1;
   HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
   return 0;
