@@ -561,13 +561,12 @@ int E::mbconv(const std::string& p, const T4& x, int stride, bool residual, T4* 
   if (dst) *y = *dst;
   else *y = alloc4(x.B, (x.H + stride - 1) / stride, (x.W + stride - 1) / stride, (int)pw->shape[0]);
   if (!ok(y->p)) return -1;
-  // the fused kernel is correct but still latency-bound (slower than the layer-by-layer path):
-  // opt-in until it wins
-  static const bool no_fused = getenv("ESAM3_FUSED_MBCONV") == nullptr;
+  // bf16: the high-resolution MBConvs (stages 1-3) run as ONE kernel, the 4x-expanded tensor never leaves the CU
+  // (mbconv_fused.hip v2); other shapes and the f32 validation mode run layer by layer
   const HostTensor* ew = need(p + "inverted_conv.conv.weight");
   if (!ew) return -1;
   const int cmid = (int)ew->shape[0];
-  if (!no_fused && esam3_mbconv_fused_lds(dtype, x.C, cmid, y->C, stride) > 0 && x.ld == x.C) {
+  if (esam3_mbconv_fused2_ok(dtype, x.C, cmid, y->C, stride) && x.ld == x.C) {
     auto pkc = [&](const std::string& q) {
       return pk_conv(q + ".conv.weight", find(q + ".conv.bias") ? q + ".conv.bias" : "",
                      find(q + ".norm.weight") ? q + ".norm" : "");

@@ -135,6 +135,8 @@ int esam3_launch_resize_aa_u8(const uint8_t* in, int B, int H, int W, float* out
 int esam3_launch_zero_border(int dtype, void* x, int B, int Hp, int Wp, int C, hipStream_t s);
 // fused MBConv (mbconv_fused.hip): returns LDS bytes needed, 0 if the shape is unsupported
 size_t esam3_mbconv_fused_lds(int dtype, int Cin, int Cmid, int Cout, int stride);
+// true when esam3_launch_mbconv_fused runs this shape on the v2 kernel (bf16, EfficientViT-B1 stage 1-3 shapes)
+bool esam3_mbconv_fused2_ok(int dtype, int Cin, int Cmid, int Cout, int stride);
 int esam3_launch_mbconv_fused(int dtype, const void* x, void* out, const void* w1, int Kp1, const float* b1,
                               const float* wd, const float* bd, const void* w2, int Kp2, const float* b2, int B,
                               int H, int W, int Cin, int Cmid, int Cout, int stride, int residual,

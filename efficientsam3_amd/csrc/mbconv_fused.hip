@@ -276,6 +276,267 @@ __global__ __launch_bounds__(256) void mbconv_fused_kernel(MbParams p) {
   }
 }
 
+// ======================================================================================
+// v2 (bf16): the same three phases per 64-channel chunk of the expanded tensor, rebuilt around the three things
+// that made v1 latency-bound:
+//   * bigger tiles: 8 x 16 output pixels for stride 1 (10 x 18 halo = 180 pixels, 1.4 x recompute of the expand),
+//     8 x 8 for stride 2 (17 x 17 halo);
+//   * no LDS copy of the input: the expand GEMM takes its pixel fragments straight from global memory in MFMA layout
+//     (16 bytes per lane), the two weight matrices likewise (they live in L1 / L2);
+//   * 16-byte LDS traffic only: the expand epilogue packs bf16 and exchanges half-waves (v_permlane32_swap) so that a lane
+//     writes 8 consecutive channels; the depthwise phase walks an output column strip with a rotating 3 x 3 window of
+//     packed cells in registers and its 9 x 8 weights in registers (2.25 - 4.5 LDS reads per output instead of 9).
+// Template: stride, Cin, Cout (the EfficientViT-B1 MBConv shapes of stages 1-3, backbone.py:91-147); Cmid % 64 == 0.
+// ======================================================================================
+template <int S, int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void mbconv_fused2_kernel(MbParams p) {
+  typedef bf16_t T;
+  constexpr int TH = 8, TW = S == 1 ? 16 : 8;          // output tile
+  constexpr int OP = TH * TW;                          // output pixels: 128 / 64
+  constexpr int HH = TH * S + (S == 1 ? 2 : 1), HW = TW * S + (S == 1 ? 2 : 1);  // halo 10 x 18 / 17 x 17
+  constexpr int HP = HH * HW;
+  constexpr int NPT = (HP + 31) / 32;                  // expand pixel tiles: 6 / 10
+  constexpr int MP = NPT * 32;
+  constexpr int KS = CIN / 16;                         // MFMA K steps of the expand GEMM
+  constexpr int NT = COUT / 32;                        // project channel tiles
+  constexpr int PT = OP / 32;                          // project pixel tiles: 4 / 2
+  constexpr int TPW = (NPT + 3) / 4;                   // expand pixel tiles per wave
+  constexpr int R = S == 1 ? 4 : 2;                    // output rows per thread in the depthwise phase
+  static_assert(CIN % 16 == 0 && COUT % 32 == 0, "shape");
+
+  __shared__ __attribute__((aligned(16))) char mid[MP * 128];   // [halo pixel][64 ch] bf16, 16-byte chunk c at c ^ (pixel & 7)
+  __shared__ __attribute__((aligned(16))) char dwo[OP * 128];   // [output pixel][64 ch] bf16, GEMM swizzle
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, g = lane >> 5;
+
+  const unsigned tpi = (unsigned)(p.tiles_x * p.tiles_y);
+  const unsigned b = blockIdx.x / tpi;
+  const unsigned ti = blockIdx.x - b * tpi;
+  const int ty = (int)(ti / (unsigned)p.tiles_x), tx = (int)(ti - ty * p.tiles_x);
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+
+  const T* __restrict__ gx = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ gw1 = reinterpret_cast<const T*>(p.w1);
+  const T* __restrict__ gw2 = reinterpret_cast<const T*>(p.w2);
+  T* __restrict__ go = reinterpret_cast<T*>(p.out);
+
+  // ---- this wave's halo pixels of the expand GEMM (pixel tiles wave, wave + 4, ...) ----
+  int64_t xoff[TPW];   // element offset of the lane's halo pixel, or -1 (outside the image / padding row of the tile)
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    const int hp = (wave + 4 * u) * 32 + l31;
+    const int hy = hp / HW, hx = hp - hy * HW;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    const bool in = (wave + 4 * u) < NPT && hp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    xoff[u] = in ? (((int64_t)b * p.H + iy) * p.W + ix) * CIN : -1;
+  }
+
+  // project accumulators: S = 1: wave w owns pixel tile w; S = 2: pixel tile w & 1, channel tiles (w >> 1), (w >> 1) + 2, ...
+  constexpr int NTW = S == 1 ? NT : (NT + 1) / 2;
+  f32x16_v accp[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[t][r] = 0.f;
+  const int ppt = S == 1 ? wave : (wave & 1);
+  const int pnt0 = S == 1 ? 0 : (wave >> 1);
+  constexpr int PNT_STEP = S == 1 ? 1 : 2;
+
+  // depthwise phase coordinates
+  const int cg = tid & 7;
+  const int dox = S == 1 ? ((tid >> 3) & 15) : ((tid >> 3) & 7);
+  const int doy0 = S == 1 ? (tid >> 7) * R : (tid >> 6) * R;
+
+  const int nchunks = p.Cmid / 64;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int c0 = ch * 64;
+    // ================= E: mid[halo px][64] = hswish(W1[c0..c0+64) . x + b1), 0 outside the image =================
+    {
+      u32x4 fw[2][KS];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          fw[jt][ks] = *reinterpret_cast<const u32x4*>(gw1 + (int64_t)(c0 + jt * 32 + l31) * p.Kp1 + (2 * ks + g) * 8);
+      float4 b1v[2][4];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b1v[jt][q] = *reinterpret_cast<const float4*>(p.b1 + c0 + jt * 32 + 8 * q + 4 * g);
+#pragma unroll
+      for (int u = 0; u < TPW; ++u) {
+        const int pt = wave + 4 * u;
+        if (pt >= NPT) continue;  // wave-uniform
+        const int hp = pt * 32 + l31;
+        const bool in = xoff[u] >= 0;
+        u32x4 fa[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          fa[ks] = u32x4{0u, 0u, 0u, 0u};
+          if (in) fa[ks] = *reinterpret_cast<const u32x4*>(gx + xoff[u] + (2 * ks + g) * 8);
+        }
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          f32x16_v acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) MmaOps<T>::mma(fw[jt][ks], fa[ks], acc);
+          float v[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float bb[4] = {b1v[jt][q].x, b1v[jt][q].y, b1v[jt][q].z, b1v[jt][q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = in ? hswish(acc[4 * q + e] + bb[e]) : 0.f;
+          }
+#pragma unroll
+          for (int qp = 0; qp < 2; ++qp) {
+            const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
+            const uint32_t c0_ = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]), c1_ = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
+            auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0_, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
+            const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};  // channels jt*32 + 16qp + 8g .. +8 of halo pixel hp
+            const int c = jt * 4 + qp * 2 + g;
+            *reinterpret_cast<u32x4*>(mid + hp * 128 + ((c ^ (hp & 7)) << 4)) = o;
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // ================= D: dwo[out px][64] = hswish(dw3x3(mid) + bd) =================
+    {
+      float wt[9][8], bs[8];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float4 w0 = *reinterpret_cast<const float4*>(p.wd + t * p.Cmid + c0 + cg * 8);
+        const float4 w1 = *reinterpret_cast<const float4*>(p.wd + t * p.Cmid + c0 + cg * 8 + 4);
+        wt[t][0] = w0.x; wt[t][1] = w0.y; wt[t][2] = w0.z; wt[t][3] = w0.w;
+        wt[t][4] = w1.x; wt[t][5] = w1.y; wt[t][6] = w1.z; wt[t][7] = w1.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bs[e] = p.bd ? p.bd[c0 + cg * 8 + e] : 0.f;
+      u32x4 win[3][3];  // rotating window: halo rows (relative) r % 3, columns dox*S .. +2, packed bf16 x 8
+      auto load_row = [&](int rel) {
+        const int hy = doy0 * S + rel;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int hp = hy * HW + dox * S + kw;
+          win[rel % 3][kw] = *reinterpret_cast<const u32x4*>(mid + hp * 128 + ((cg ^ (hp & 7)) << 4));
+        }
+      };
+#pragma unroll
+      for (int rel = 0; rel < 3 - S; ++rel) load_row(rel);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int q = 0; q < S; ++q) load_row(r * S + 3 - S + q);
+        float a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = bs[e];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const u32x4 m = win[(r * S + kh) % 3][kw];
+            const uint32_t ww[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              a[2 * e] = fmaf(__uint_as_float(ww[e] << 16), wt[kh * 3 + kw][2 * e], a[2 * e]);
+              a[2 * e + 1] = fmaf(__uint_as_float(ww[e] & 0xffff0000u), wt[kh * 3 + kw][2 * e + 1], a[2 * e + 1]);
+            }
+          }
+        u32x4 o;
+        o.x = pack_bf16x2(hswish(a[0]), hswish(a[1]));
+        o.y = pack_bf16x2(hswish(a[2]), hswish(a[3]));
+        o.z = pack_bf16x2(hswish(a[4]), hswish(a[5]));
+        o.w = pack_bf16x2(hswish(a[6]), hswish(a[7]));
+        const int op = (doy0 + r) * TW + dox;
+        *reinterpret_cast<u32x4*>(dwo + op * 128 + swz(op, cg)) = o;
+      }
+    }
+    __syncthreads();
+
+    // ================= P: acc[out px][Cout] += dwo . W2[:, c0..c0+64)^T =================
+    {
+      const int prow = ppt * 32 + l31;
+      u32x4 fd[4];
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) fd[kc] = *reinterpret_cast<const u32x4*>(dwo + prow * 128 + swz(prow, kc * 2 + g));
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const int nt = pnt0 + t * PNT_STEP;
+        if (nt >= NT) continue;  // wave-uniform
+        const T* wrow = gw2 + (int64_t)(nt * 32 + l31) * p.Kp2 + c0;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+          const u32x4 fw2 = *reinterpret_cast<const u32x4*>(wrow + (kc * 2 + g) * 8);
+          MmaOps<T>::mma(fw2, fd[kc], accp[t]);
+        }
+      }
+    }
+    // (the barrier after the next chunk's expand phase orders these dwo reads before the next depthwise phase)
+  }
+
+  // ================= out = acc + b2 (+ x): 16-byte NHWC stores =================
+  {
+    const int op = ppt * 32 + l31;
+    const int oy = oy0 + op / TW, ox = ox0 + op % TW;
+    const bool ok = oy < p.OH && ox < p.OW;
+    const int64_t opix = ((int64_t)b * p.OH + oy) * p.OW + ox;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int nt = pnt0 + t * PNT_STEP;
+      if (nt >= NT) continue;
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.b2 + nt * 32 + 8 * q + 4 * g);
+        v[4 * q + 0] = accp[t][4 * q + 0] + bb.x; v[4 * q + 1] = accp[t][4 * q + 1] + bb.y;
+        v[4 * q + 2] = accp[t][4 * q + 2] + bb.z; v[4 * q + 3] = accp[t][4 * q + 3] + bb.w;
+        if (p.residual && ok) {  // identity shortcut: the same pixel of the input (stride 1, Cin == Cout)
+          const uint2 u = *reinterpret_cast<const uint2*>(gx + opix * CIN + nt * 32 + 8 * q + 4 * g);
+          v[4 * q + 0] += __uint_as_float(u.x << 16); v[4 * q + 1] += __uint_as_float(u.x & 0xffff0000u);
+          v[4 * q + 2] += __uint_as_float(u.y << 16); v[4 * q + 3] += __uint_as_float(u.y & 0xffff0000u);
+        }
+      }
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
+        const uint32_t c0_ = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]), c1_ = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
+        auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0_, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
+        if (ok) {
+          const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+          *reinterpret_cast<u32x4*>(go + opix * COUT + nt * 32 + 16 * qp + 8 * g) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int S, int CIN, int COUT>
+int launch_mb2(MbParams p, hipStream_t stream) {
+  constexpr int TH = 8, TW = S == 1 ? 16 : 8;
+  p.tiles_x = (p.OW + TW - 1) / TW;
+  p.tiles_y = (p.OH + TH - 1) / TH;
+  const unsigned grid = (unsigned)p.B * p.tiles_x * p.tiles_y;
+  hipLaunchKernelGGL((mbconv_fused2_kernel<S, CIN, COUT>), dim3(grid), dim3(256), 0, stream, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// the shapes v2 is instantiated for (EfficientViT-B1 stages 1-3); everything else stays on v1 / layer by layer
+bool mb2_supported(int dtype, int Cin, int Cmid, int Cout, int stride, int Kp1, int Kp2) {
+  if (dtype != 1 || Cmid % 64 || Kp1 < Cin || Kp2 < Cmid) return false;
+  if (stride == 2) return (Cin == 16 && Cout == 32) || (Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 128);
+  if (stride == 1) return (Cin == 32 && Cout == 32) || (Cin == 64 && Cout == 64);
+  return false;
+}
+
 template <typename T, int S>
 int launch_mb(const MbParams& p, size_t lds, hipStream_t stream) {
   static bool attr_set = false;
@@ -292,6 +553,12 @@ int launch_mb(const MbParams& p, size_t lds, hipStream_t stream) {
 }
 
 }  // namespace
+
+// v2 (the default of the bf16 engine) covers this shape
+bool esam3_mbconv_fused2_ok(int dtype, int Cin, int Cmid, int Cout, int stride) {
+  const int kp1 = (Cin + 63) / 64 * 64, kp2 = (Cmid + 63) / 64 * 64;
+  return mb2_supported(dtype, Cin, Cmid, Cout, stride, kp1, kp2);
+}
 
 // LDS bytes the fused kernel needs (0 = configuration not supported -> caller runs layer by layer)
 size_t esam3_mbconv_fused_lds(int dtype, int Cin, int Cmid, int Cout, int stride) {
@@ -310,6 +577,17 @@ int esam3_launch_mbconv_fused(int dtype, const void* x, void* out, const void* w
                               const float* wd, const float* bd, const void* w2, int Kp2, const float* b2, int B,
                               int H, int W, int Cin, int Cmid, int Cout, int stride, int residual,
                               hipStream_t stream) {
+  if (mb2_supported(dtype, Cin, Cmid, Cout, stride, Kp1, Kp2)) {
+    MbParams q{};
+    q.x = x; q.out = out; q.w1 = w1; q.b1 = b1; q.wd = wd; q.bd = bd; q.w2 = w2; q.b2 = b2;
+    q.B = B; q.H = H; q.W = W; q.OH = (H + stride - 1) / stride; q.OW = (W + stride - 1) / stride;
+    q.Cin = Cin; q.Cmid = Cmid; q.Cout = Cout; q.Kp1 = Kp1; q.Kp2 = Kp2; q.residual = residual;
+    if (stride == 2 && Cin == 16) return launch_mb2<2, 16, 32>(q, stream);
+    if (stride == 2 && Cin == 32) return launch_mb2<2, 32, 64>(q, stream);
+    if (stride == 2) return launch_mb2<2, 64, 128>(q, stream);
+    if (Cin == 32) return launch_mb2<1, 32, 32>(q, stream);
+    return launch_mb2<1, 64, 64>(q, stream);
+  }
   const size_t lds = esam3_mbconv_fused_lds(dtype, Cin, Cmid, Cout, stride);
   if (!lds) { esam3_set_error("mbconv_fused: unsupported configuration"); return -1; }
   const int esz = dtype == 0 ? 4 : 2;

@@ -280,6 +280,9 @@ def test_dwconv(mode, B, H, W, C, ks, stride, act):
     (1, 16, 16, 128, 512, 128, 1, 1),  # EfficientViTBlock local module (stage 3)
     (1, 9, 9, 256, 1024, 256, 1, 1),   # stage 4 local module: 16 channel chunks, Cout 256
     (1, 17, 17, 24, 96, 48, 2, 0),     # EfficientViT-B2 widths (Cin not a power of two)
+    (2, 33, 50, 64, 256, 64, 1, 1),    # stages.1.op_list.1/2 shape (v2 kernel, ragged 8x16 tiles)
+    (1, 41, 23, 32, 128, 64, 2, 0),    # stages.1.op_list.0 shape (v2, stride 2, odd sizes)
+    (3, 64, 64, 16, 64, 32, 2, 0),     # several full tiles per image
 ])
 def test_mbconv_fused(mode, B, H, W, Cin, Cmid, Cout, stride, res):
     """Fused expand -> dw3x3 -> project kernel vs the three-layer PyTorch reference
