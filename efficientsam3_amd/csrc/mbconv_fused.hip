@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void mbconv_fused_kernel(MbParams p) {
 // Template: stride, Cin, Cout (the EfficientViT-B1 MBConv shapes of stages 1-3, backbone.py:91-147); Cmid % 64 == 0.
 // ======================================================================================
 template <int S, int CIN, int COUT>
-__global__ __launch_bounds__(256, 2) void mbconv_fused2_kernel(MbParams p) {
+__global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mbconv_fused2_kernel(MbParams p) {
   typedef bf16_t T;
   constexpr int TH = 8, TW = S == 1 ? 16 : 8;          // output tile
   constexpr int OP = TH * TW;                          // output pixels: 128 / 64
@@ -300,8 +300,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_fused2_kernel(MbParams p) {
   constexpr int KS = CIN / 16;                         // MFMA K steps of the expand GEMM
   constexpr int NT = COUT / 32;                        // project channel tiles
   constexpr int PT = OP / 32;                          // project pixel tiles: 4 / 2
-  constexpr int TPW = (NPT + 3) / 4;                   // expand pixel tiles per wave
-  constexpr int R = S == 1 ? 4 : 2;                    // output rows per thread in the depthwise phase
+  constexpr int R = S == 1 ? 8 : 4;                    // output rows per thread in the depthwise phase (one column strip)
   static_assert(CIN % 16 == 0 && COUT % 32 == 0, "shape");
 
   __shared__ __attribute__((aligned(16))) char mid[MP * 128];   // [halo pixel][64 ch] bf16, 16-byte chunk c at c ^ (pixel & 7)
@@ -323,14 +322,18 @@ __global__ __launch_bounds__(256, 2) void mbconv_fused2_kernel(MbParams p) {
   const T* __restrict__ gw2 = reinterpret_cast<const T*>(p.w2);
   T* __restrict__ go = reinterpret_cast<T*>(p.out);
 
-  // ---- this wave's halo pixels of the expand GEMM (pixel tiles wave, wave + 4, ...) ----
-  int64_t xoff[TPW];   // element offset of the lane's halo pixel, or -1 (outside the image / padding row of the tile)
+  // ---- expand GEMM work units: (pixel tile, 32-channel tile) pairs, unit = wave + 4u: a wave always has the same
+  //      channel tile (unit & 1 == wave & 1), so its W1 fragments are loaded once per chunk
+  constexpr int UPW = (2 * NPT + 3) / 4;  // units per wave: 3 / 5
+  const int ejt = wave & 1;
+  int64_t xoff[UPW];   // element offset of the lane's halo pixel, or -1 (outside the image / padding row of the tile)
 #pragma unroll
-  for (int u = 0; u < TPW; ++u) {
-    const int hp = (wave + 4 * u) * 32 + l31;
+  for (int u = 0; u < UPW; ++u) {
+    const int pt = (wave + 4 * u) >> 1;
+    const int hp = pt * 32 + l31;
     const int hy = hp / HW, hx = hp - hy * HW;
     const int iy = iy0 + hy, ix = ix0 + hx;
-    const bool in = (wave + 4 * u) < NPT && hp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const bool in = pt < NPT && hp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
     xoff[u] = in ? (((int64_t)b * p.H + iy) * p.W + ix) * CIN : -1;
   }
 
@@ -345,63 +348,59 @@ __global__ __launch_bounds__(256, 2) void mbconv_fused2_kernel(MbParams p) {
   const int pnt0 = S == 1 ? 0 : (wave >> 1);
   constexpr int PNT_STEP = S == 1 ? 1 : 2;
 
-  // depthwise phase coordinates
-  const int cg = tid & 7;
-  const int dox = S == 1 ? ((tid >> 3) & 15) : ((tid >> 3) & 7);
-  const int doy0 = S == 1 ? (tid >> 7) * R : (tid >> 6) * R;
+  // depthwise phase coordinates: thread = (4-channel group, output column, row group); 8-byte LDS accesses
+  const int cg = tid & 15;
+  const int dox = S == 1 ? ((tid >> 4) & 15) : ((tid >> 4) & 7);
+  const int doy0 = S == 1 ? 0 : (tid >> 7) * R;
 
   const int nchunks = p.Cmid / 64;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int c0 = ch * 64;
     // ================= E: mid[halo px][64] = hswish(W1[c0..c0+64) . x + b1), 0 outside the image =================
+    // the depthwise weights of this chunk are requested first: their latency overlaps the expand phase
+    float4 wt[9], bsv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const float4*>(p.wd + t * p.Cmid + c0 + cg * 4);
+    if (p.bd) bsv = *reinterpret_cast<const float4*>(p.bd + c0 + cg * 4);
     {
-      u32x4 fw[2][KS];
+      u32x4 fw[KS];
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
+      for (int ks = 0; ks < KS; ++ks)
+        fw[ks] = *reinterpret_cast<const u32x4*>(gw1 + (int64_t)(c0 + ejt * 32 + l31) * p.Kp1 + (2 * ks + g) * 8);
+      float4 b1v[4];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-          fw[jt][ks] = *reinterpret_cast<const u32x4*>(gw1 + (int64_t)(c0 + jt * 32 + l31) * p.Kp1 + (2 * ks + g) * 8);
-      float4 b1v[2][4];
+      for (int q = 0; q < 4; ++q) b1v[q] = *reinterpret_cast<const float4*>(p.b1 + c0 + ejt * 32 + 8 * q + 4 * g);
 #pragma unroll
-      for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) b1v[jt][q] = *reinterpret_cast<const float4*>(p.b1 + c0 + jt * 32 + 8 * q + 4 * g);
-#pragma unroll
-      for (int u = 0; u < TPW; ++u) {
-        const int pt = wave + 4 * u;
+      for (int u = 0; u < UPW; ++u) {
+        const int pt = (wave + 4 * u) >> 1;
         if (pt >= NPT) continue;  // wave-uniform
         const int hp = pt * 32 + l31;
         const bool in = xoff[u] >= 0;
-        u32x4 fa[KS];
+        f32x16_v acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          fa[ks] = u32x4{0u, 0u, 0u, 0u};
-          if (in) fa[ks] = *reinterpret_cast<const u32x4*>(gx + xoff[u] + (2 * ks + g) * 8);
+          u32x4 fa = {0u, 0u, 0u, 0u};
+          if (in) fa = *reinterpret_cast<const u32x4*>(gx + xoff[u] + (2 * ks + g) * 8);
+          MmaOps<T>::mma(fw[ks], fa, acc);
+        }
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float bb[4] = {b1v[q].x, b1v[q].y, b1v[q].z, b1v[q].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * q + e] = in ? hswish(acc[4 * q + e] + bb[e]) : 0.f;
         }
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) {
-          f32x16_v acc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) MmaOps<T>::mma(fw[jt][ks], fa[ks], acc);
-          float v[16];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float bb[4] = {b1v[jt][q].x, b1v[jt][q].y, b1v[jt][q].z, b1v[jt][q].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * q + e] = in ? hswish(acc[4 * q + e] + bb[e]) : 0.f;
-          }
-#pragma unroll
-          for (int qp = 0; qp < 2; ++qp) {
-            const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
-            const uint32_t c0_ = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]), c1_ = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
-            auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0_, false, false);
-            auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
-            const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};  // channels jt*32 + 16qp + 8g .. +8 of halo pixel hp
-            const int c = jt * 4 + qp * 2 + g;
-            *reinterpret_cast<u32x4*>(mid + hp * 128 + ((c ^ (hp & 7)) << 4)) = o;
-          }
+        for (int qp = 0; qp < 2; ++qp) {
+          const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
+          const uint32_t c0_ = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]), c1_ = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
+          auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0_, false, false);
+          auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
+          const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};  // channels ejt*32 + 16qp + 8g .. +8 of halo pixel hp
+          const int c = ejt * 4 + qp * 2 + g;
+          *reinterpret_cast<u32x4*>(mid + hp * 128 + ((c ^ (hp & 7)) << 4)) = o;
         }
       }
     }
@@ -409,23 +408,13 @@ __global__ __launch_bounds__(256, 2) void mbconv_fused2_kernel(MbParams p) {
 
     // ================= D: dwo[out px][64] = hswish(dw3x3(mid) + bd) =================
     {
-      float wt[9][8], bs[8];
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const float4 w0 = *reinterpret_cast<const float4*>(p.wd + t * p.Cmid + c0 + cg * 8);
-        const float4 w1 = *reinterpret_cast<const float4*>(p.wd + t * p.Cmid + c0 + cg * 8 + 4);
-        wt[t][0] = w0.x; wt[t][1] = w0.y; wt[t][2] = w0.z; wt[t][3] = w0.w;
-        wt[t][4] = w1.x; wt[t][5] = w1.y; wt[t][6] = w1.z; wt[t][7] = w1.w;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bs[e] = p.bd ? p.bd[c0 + cg * 8 + e] : 0.f;
-      u32x4 win[3][3];  // rotating window: halo rows (relative) r % 3, columns dox*S .. +2, packed bf16 x 8
+      uint2 win[3][3];  // rotating window: halo rows (relative) r % 3, columns dox*S .. +2, packed bf16 x 4
       auto load_row = [&](int rel) {
         const int hy = doy0 * S + rel;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           const int hp = hy * HW + dox * S + kw;
-          win[rel % 3][kw] = *reinterpret_cast<const u32x4*>(mid + hp * 128 + ((cg ^ (hp & 7)) << 4));
+          win[rel % 3][kw] = *reinterpret_cast<const uint2*>(mid + hp * 128 + (((cg >> 1) ^ (hp & 7)) << 4) + (cg & 1) * 8);
         }
       };
 #pragma unroll
@@ -434,28 +423,23 @@ __global__ __launch_bounds__(256, 2) void mbconv_fused2_kernel(MbParams p) {
       for (int r = 0; r < R; ++r) {
 #pragma unroll
         for (int q = 0; q < S; ++q) load_row(r * S + 3 - S + q);
-        float a[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = bs[e];
+        float a[4] = {bsv.x, bsv.y, bsv.z, bsv.w};
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
-            const u32x4 m = win[(r * S + kh) % 3][kw];
-            const uint32_t ww[4] = {m.x, m.y, m.z, m.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              a[2 * e] = fmaf(__uint_as_float(ww[e] << 16), wt[kh * 3 + kw][2 * e], a[2 * e]);
-              a[2 * e + 1] = fmaf(__uint_as_float(ww[e] & 0xffff0000u), wt[kh * 3 + kw][2 * e + 1], a[2 * e + 1]);
-            }
+            const uint2 m = win[(r * S + kh) % 3][kw];
+            const float4 w = wt[kh * 3 + kw];
+            a[0] = fmaf(__uint_as_float(m.x << 16), w.x, a[0]);
+            a[1] = fmaf(__uint_as_float(m.x & 0xffff0000u), w.y, a[1]);
+            a[2] = fmaf(__uint_as_float(m.y << 16), w.z, a[2]);
+            a[3] = fmaf(__uint_as_float(m.y & 0xffff0000u), w.w, a[3]);
           }
-        u32x4 o;
+        uint2 o;
         o.x = pack_bf16x2(hswish(a[0]), hswish(a[1]));
         o.y = pack_bf16x2(hswish(a[2]), hswish(a[3]));
-        o.z = pack_bf16x2(hswish(a[4]), hswish(a[5]));
-        o.w = pack_bf16x2(hswish(a[6]), hswish(a[7]));
         const int op = (doy0 + r) * TW + dox;
-        *reinterpret_cast<u32x4*>(dwo + op * 128 + swz(op, cg)) = o;
+        *reinterpret_cast<uint2*>(dwo + op * 128 + swz(op, cg >> 1) + (cg & 1) * 8) = o;
       }
     }
     __syncthreads();
