@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mbconv_fused2_kernel
   //      channel tile (unit & 1 == wave & 1), so its W1 fragments are loaded once per chunk
   constexpr int UPW = (2 * NPT + 3) / 4;  // units per wave: 3 / 5
   const int ejt = wave & 1;
-  int64_t xoff[UPW];   // element offset of the lane's halo pixel, or -1 (outside the image / padding row of the tile)
+  int xoff[UPW];       // element offset of the lane's halo pixel (< 2^31, checked by the launcher), or -1 (outside the image / padding row)
 #pragma unroll
   for (int u = 0; u < UPW; ++u) {
     const int pt = (wave + 4 * u) >> 1;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mbconv_fused2_kernel
     const int hy = hp / HW, hx = hp - hy * HW;
     const int iy = iy0 + hy, ix = ix0 + hx;
     const bool in = pt < NPT && hp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    xoff[u] = in ? (((int64_t)b * p.H + iy) * p.W + ix) * CIN : -1;
+    xoff[u] = in ? (int)(((b * (unsigned)p.H + iy) * (unsigned)p.W + ix) * (unsigned)CIN) : -1;
   }
 
   // project accumulators: S = 1: wave w owns pixel tile w; S = 2: pixel tile w & 1, channel tiles (w >> 1), (w >> 1) + 2, ...
@@ -370,42 +370,70 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mbconv_fused2_kernel
       float4 b1v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) b1v[q] = *reinterpret_cast<const float4*>(p.b1 + c0 + ejt * 32 + 8 * q + 4 * g);
+      // the pixel fragments of a GROUP of units are requested together (independent loads in flight), then consumed
+      constexpr int UG = (UPW * KS <= (CIN >= 64 ? 12 : 3)) ? UPW : 2;  // units per group, bounded by the registers the variant has
 #pragma unroll
-      for (int u = 0; u < UPW; ++u) {
-        const int pt = (wave + 4 * u) >> 1;
-        if (pt >= NPT) continue;  // wave-uniform
-        const int hp = pt * 32 + l31;
-        const bool in = xoff[u] >= 0;
-        f32x16_v acc;
+      for (int u0 = 0; u0 < UPW; u0 += UG) {
+        u32x4 fa[UG][KS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int uu = 0; uu < UG; ++uu)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          u32x4 fa = {0u, 0u, 0u, 0u};
-          if (in) fa = *reinterpret_cast<const u32x4*>(gx + xoff[u] + (2 * ks + g) * 8);
-          MmaOps<T>::mma(fw[ks], fa, acc);
-        }
-        float v[16];
+          for (int ks = 0; ks < KS; ++ks) {
+            fa[uu][ks] = u32x4{0u, 0u, 0u, 0u};
+            if (u0 + uu < UPW && xoff[u0 + uu < UPW ? u0 + uu : 0] >= 0)
+              fa[uu][ks] = *reinterpret_cast<const u32x4*>(gx + xoff[u0 + uu < UPW ? u0 + uu : 0] + (2 * ks + g) * 8);
+          }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float bb[4] = {b1v[q].x, b1v[q].y, b1v[q].z, b1v[q].w};
+        for (int uu = 0; uu < UG; ++uu) {
+          const int u = u0 + uu;
+          if (u >= UPW) continue;
+          const int pt = (wave + 4 * u) >> 1;
+          if (pt >= NPT) continue;  // wave-uniform
+          const int hp = pt * 32 + l31;
+          const bool in = xoff[u] >= 0;
+          f32x16_v acc;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[4 * q + e] = in ? hswish(acc[4 * q + e] + bb[e]) : 0.f;
-        }
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int qp = 0; qp < 2; ++qp) {
-          const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
-          const uint32_t c0_ = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]), c1_ = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
-          auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0_, false, false);
-          auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
-          const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};  // channels ejt*32 + 16qp + 8g .. +8 of halo pixel hp
-          const int c = ejt * 4 + qp * 2 + g;
-          *reinterpret_cast<u32x4*>(mid + hp * 128 + ((c ^ (hp & 7)) << 4)) = o;
+          for (int ks = 0; ks < KS; ++ks) MmaOps<T>::mma(fw[ks], fa[uu][ks], acc);
+          float v[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float bb[4] = {b1v[q].x, b1v[q].y, b1v[q].z, b1v[q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = in ? hswish(acc[4 * q + e] + bb[e]) : 0.f;
+          }
+#pragma unroll
+          for (int qp = 0; qp < 2; ++qp) {
+            const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
+            const uint32_t c0_ = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]), c1_ = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
+            auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0_, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
+            const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};  // channels ejt*32 + 16qp + 8g .. +8 of halo pixel hp
+            const int c = ejt * 4 + qp * 2 + g;
+            *reinterpret_cast<u32x4*>(mid + hp * 128 + ((c ^ (hp & 7)) << 4)) = o;
+          }
         }
       }
     }
     __syncthreads();
 
+    // the project weights of this chunk: requested before the depthwise phase and consumed after it where the variant
+    // has the registers (Cin = 64 runs 2 waves per SIMD), else right before their use
+    constexpr bool EARLY_W2 = CIN >= 64;
+    u32x4 fw2[NTW][4];
+    auto load_w2 = [&]() {
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const int nt = pnt0 + t * PNT_STEP;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+          fw2[t][kc] = u32x4{0u, 0u, 0u, 0u};
+          if (nt < NT) fw2[t][kc] = *reinterpret_cast<const u32x4*>(gw2 + (int64_t)(nt * 32 + l31) * p.Kp2 + c0 + (kc * 2 + g) * 8);
+        }
+      }
+    };
+    if constexpr (EARLY_W2) load_w2();
     // ================= D: dwo[out px][64] = hswish(dw3x3(mid) + bd) =================
     {
       uint2 win[3][3];  // rotating window: halo rows (relative) r % 3, columns dox*S .. +2, packed bf16 x 4
@@ -446,6 +474,7 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mbconv_fused2_kernel
 
     // ================= P: acc[out px][Cout] += dwo . W2[:, c0..c0+64)^T =================
     {
+      if constexpr (!EARLY_W2) load_w2();
       const int prow = ppt * 32 + l31;
       u32x4 fd[4];
 #pragma unroll
@@ -454,12 +483,8 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mbconv_fused2_kernel
       for (int t = 0; t < NTW; ++t) {
         const int nt = pnt0 + t * PNT_STEP;
         if (nt >= NT) continue;  // wave-uniform
-        const T* wrow = gw2 + (int64_t)(nt * 32 + l31) * p.Kp2 + c0;
 #pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-          const u32x4 fw2 = *reinterpret_cast<const u32x4*>(wrow + (kc * 2 + g) * 8);
-          MmaOps<T>::mma(fw2, fd[kc], accp[t]);
-        }
+        for (int kc = 0; kc < 4; ++kc) MmaOps<T>::mma(fw2[t][kc], fd[kc], accp[t]);
       }
     }
     // (the barrier after the next chunk's expand phase orders these dwo reads before the next depthwise phase)
@@ -561,7 +586,7 @@ int esam3_launch_mbconv_fused(int dtype, const void* x, void* out, const void* w
                               const float* wd, const float* bd, const void* w2, int Kp2, const float* b2, int B,
                               int H, int W, int Cin, int Cmid, int Cout, int stride, int residual,
                               hipStream_t stream) {
-  if (mb2_supported(dtype, Cin, Cmid, Cout, stride, Kp1, Kp2)) {
+  if (mb2_supported(dtype, Cin, Cmid, Cout, stride, Kp1, Kp2) && (int64_t)B * H * W * Cin < ((int64_t)1 << 31)) {
     MbParams q{};
     q.x = x; q.out = out; q.w1 = w1; q.b1 = b1; q.wd = wd; q.bd = bd; q.w2 = w2; q.b2 = b2;
     q.B = B; q.H = H; q.W = W; q.OH = (H + stride - 1) / stride; q.OW = (W + stride - 1) / stride;
