@@ -436,13 +436,17 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mbconv_fused2_kernel
     if constexpr (EARLY_W2) load_w2();
     // ================= D: dwo[out px][64] = hswish(dw3x3(mid) + bd) =================
     {
-      uint2 win[3][3];  // rotating window: halo rows (relative) r % 3, columns dox*S .. +2, packed bf16 x 4
+      float win[3][3][4];  // rotating window: halo rows (relative) r % 3, columns dox*S .. +2, 4 channels unpacked to f32
       auto load_row = [&](int rel) {
         const int hy = doy0 * S + rel;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           const int hp = hy * HW + dox * S + kw;
-          win[rel % 3][kw] = *reinterpret_cast<const uint2*>(mid + hp * 128 + (((cg >> 1) ^ (hp & 7)) << 4) + (cg & 1) * 8);
+          const uint2 m = *reinterpret_cast<const uint2*>(mid + hp * 128 + (((cg >> 1) ^ (hp & 7)) << 4) + (cg & 1) * 8);
+          win[rel % 3][kw][0] = __uint_as_float(m.x << 16);
+          win[rel % 3][kw][1] = __uint_as_float(m.x & 0xffff0000u);
+          win[rel % 3][kw][2] = __uint_as_float(m.y << 16);
+          win[rel % 3][kw][3] = __uint_as_float(m.y & 0xffff0000u);
         }
       };
 #pragma unroll
@@ -456,12 +460,12 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mbconv_fused2_kernel
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
-            const uint2 m = win[(r * S + kh) % 3][kw];
+            const float* m = win[(r * S + kh) % 3][kw];
             const float4 w = wt[kh * 3 + kw];
-            a[0] = fmaf(__uint_as_float(m.x << 16), w.x, a[0]);
-            a[1] = fmaf(__uint_as_float(m.x & 0xffff0000u), w.y, a[1]);
-            a[2] = fmaf(__uint_as_float(m.y << 16), w.z, a[2]);
-            a[3] = fmaf(__uint_as_float(m.y & 0xffff0000u), w.w, a[3]);
+            a[0] = fmaf(m[0], w.x, a[0]);
+            a[1] = fmaf(m[1], w.y, a[1]);
+            a[2] = fmaf(m[2], w.z, a[2]);
+            a[3] = fmaf(m[3], w.w, a[3]);
           }
         uint2 o;
         o.x = pack_bf16x2(hswish(a[0]), hswish(a[1]));
