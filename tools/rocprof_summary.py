@@ -3,14 +3,16 @@
 
     python tools/rocprof_summary.py --stats <dir with *_kernel_stats.csv / *_kernel_trace.csv> \
         --fetch <dir of the --pmc FETCH_SIZE pass> --write <dir of the --pmc WRITE_SIZE pass> \
-        --steps K --round r01
+        [--sq <dir of SQ pass 1> --sq <dir of SQ pass 2> ...] --steps K --round r02
 
 Writes profiles/<round>_kernel_stats.csv (verbatim rocprofv3 --stats table), and
 profiles/pmc_dominant_kernel.json: HBM traffic of the dominant launch (the level-0 3x3 conv of
-the sam3 neck, one gemm256_kernel<bf16, ACT_NONE> dispatch per step -- the longest one) with the
+the sam3 neck, one gemm256p_kernel<ACT_NONE, no residual> dispatch per step -- the longest one) with the
 gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section: wide coalesced reads are
 tallied at half their bytes -> doubled; WRITE_SIZE taken as is), plus that dispatch's average
-duration from the kernel trace for comparison with bench.py's HIP-event figure.
+duration from the kernel trace for comparison with bench.py's HIP-event figure; with --sq also
+profiles/pmc_dominant_kernel_sq.json: the SQ counters of the same dispatch (one rocprofv3 pass per counter group) and
+what they imply (MFMA pipe busy fraction, effective clock, wave-time split).
 """
 import argparse
 import csv
@@ -20,7 +22,7 @@ import os
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DOM = "gemm256_kernel<unsigned short, 0>"
+DOM = "gemm256p_kernel<0, false>"  # (anonymous namespace)::gemm256p_kernel<ACT_NONE, RES = false>
 
 
 def one(pattern):
@@ -36,7 +38,8 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--steps", type=int, required=True, help="timed + warm-up steps of the --stats run")
-    ap.add_argument("--round", default="r01")
+    ap.add_argument("--sq", action="append", default=[], help="directory of one SQ-counter pass (repeatable)")
+    ap.add_argument("--round", default="r02")
     args = ap.parse_args()
     prof = os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
@@ -51,8 +54,8 @@ def main():
     durs.sort(reverse=True)
     top = durs[: args.steps]
     out = {
-        "kernel": "gemm256_kernel<bf16, ACT_NONE> (256x256x64 implicit GEMM), launch = neck level-0 3x3 conv 256->256 "
-                  "@288^2, B=32 (M = 2,654,208 rows, K = 2304): the longest dispatch of this symbol in every step",
+        "kernel": "gemm256p_kernel<ACT_NONE, no residual> (bf16 256x256x64 implicit GEMM, phase-interleaved), launch = neck level-0 "
+                  "3x3 conv 256->256 @288^2, B=32 (M = 2,654,208 rows, K = 2304): the longest dispatch of this symbol in every step",
         "kernel_trace": {"dispatches_of_symbol": len(durs), "steps_in_run": args.steps,
                          "dominant_launch_avg_ns": sum(top) / max(len(top), 1),
                          "dominant_launch_min_ns": min(top) if top else None,
@@ -85,6 +88,47 @@ def main():
     with open(os.path.join(prof, "pmc_dominant_kernel.json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
+
+    if args.sq:
+        passes, flat = {}, {}
+        dur_ns = None
+        for d in args.sq:
+            with open(one(os.path.join(d, "**", "*_counter_collection.csv"))) as f:
+                rws = [r for r in csv.DictReader(f) if DOM in r["Kernel_Name"]]
+            if not rws:
+                continue
+            # the longest dispatch of the symbol in this pass = the level-0 3x3 conv
+            by_disp = {}
+            for r in rws:
+                by_disp.setdefault(r["Dispatch_Id"], []).append(r)
+            best = max(by_disp.values(), key=lambda rr: int(rr[0]["End_Timestamp"]) - int(rr[0]["Start_Timestamp"]))
+            grp = {r["Counter_Name"]: float(r["Counter_Value"]) for r in best}
+            passes[" ".join(sorted(grp))] = grp
+            flat.update(grp)
+            dur_ns = int(best[0]["End_Timestamp"]) - int(best[0]["Start_Timestamp"])
+        sq = {"kernel": out["kernel"], "command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python bench.py --steps 1 "
+                                                  "--warmup 1 --no-cpu-baseline (one pass per counter group; rows of the longest dispatch)",
+              "passes": passes, "derived": {}}
+        dv = sq["derived"]
+        tiles, nk = 10368, 36
+        mfma = tiles * nk * 8 * 32
+        dv["mfma_instructions_by_construction"] = mfma
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in flat and "GRBM_GUI_ACTIVE" in flat:
+            cyc_xcd = flat["GRBM_GUI_ACTIVE"] / 8.0
+            dv["gpu_cycles_per_xcd"] = cyc_xcd
+            dv["mfma_pipe_busy_fraction"] = round(flat["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc_xcd * 1024.0), 4)  # 1024 SIMDs
+            if dur_ns:
+                dv["effective_clock_ghz"] = round(cyc_xcd / dur_ns, 3)
+                # v_mfma_f32_32x32x16_bf16: 2*32*32*16 flop per 32 cycles per SIMD = 1024 flop / cycle / SIMD, 1024 SIMDs
+                dv["dense_bf16_peak_at_that_clock_tflops"] = round(1024 * 1024 * (cyc_xcd / dur_ns) * 1e9 / 1e12, 1)
+        if "SQ_WAVE_CYCLES" in flat:
+            wc = flat["SQ_WAVE_CYCLES"]
+            dv["wave_time_split"] = {k: round(flat[k] / wc, 3) for k in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY") if k in flat}
+        if "SQ_LDS_BANK_CONFLICT" in flat:
+            dv["lds_bank_conflict_cycles"] = flat["SQ_LDS_BANK_CONFLICT"]
+        with open(os.path.join(prof, "pmc_dominant_kernel_sq.json"), "w") as f:
+            json.dump(sq, f, indent=1)
+        print(json.dumps(sq["derived"], indent=1))
 
 
 if __name__ == "__main__":
