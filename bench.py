@@ -32,8 +32,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 BATCH = 32
-FLOPS_PER_IMAGE_G = {  # SURVEY.md §8(d) numerators (GFLOP / image, 2*MAC)
+FLOPS_PER_IMAGE_G = {  # SURVEY.md §8(d) numerators (GFLOP / image, 2*MAC), EV-M interactive graph
     "backbone": 20.3, "head": 19.9, "necks": 429.8 - 2 * 2.2, "conv_s0s1": 2.04, "decode": 4.49}
+
+
+def reference_graph_gflop(backbone: str, model: str, text: bool):
+    """GFLOP / image of the REFERENCE's layer list for the benched configuration (SURVEY.md §8(d) "Other configs"), or
+    None where the survey gives no figure (the S / L student sizes)."""
+    if text:  # config 4: ViT-H 5.4 TF + single neck 0.215 + grounding ~0.42 + text 0.0005
+        return 6035.5 if (backbone, model) == ("sam3", "vit_h") else None
+    table = {("efficientvit", "b1"): sum(FLOPS_PER_IMAGE_G.values()), ("tinyvit", "11m"): 543.2, ("repvit", "m1.1"): 511.1,
+             ("sam3", "vit_h"): 5400.0 + 429.8 - 2 * 2.2 + 2.04 + 4.49}
+    return table.get((backbone, model))
 PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 
@@ -290,7 +300,7 @@ def main():
                         timed_launches=dom["launches"],
                         avg_launch_ms=round(avg_ms, 4), algorithmic_flops_per_launch=dom["flops"],
                         algorithmic_bytes_per_launch=dom["bytes"])
-        gf_ref = sum(FLOPS_PER_IMAGE_G.values())  # reference layer list
+        gf_ref = reference_graph_gflop(args.backbone, args.model, text)  # reference layer list
         # executed GFLOP/image, measured from the per-launch algorithmic flop counts of this run
         gf_img = sum(p_["flops"] * p_["launches"] for p_ in prof) / B / 1e9
         total_k = sum(p["ms"] for p in prof)
@@ -324,7 +334,7 @@ def main():
                        "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "graph": ("reference layer list" if args.no_fuse else
                                  "linear chains composed at load time (ConvT∘1x1, 3x3∘conv_s0/s1): same outputs, fewer FLOPs"),
-                       "gflop_per_image_executed": round(gf_img, 1), "gflop_per_image_reference_graph": round(gf_ref, 1),
+                       "gflop_per_image_executed": round(gf_img, 1), "gflop_per_image_reference_graph": None if gf_ref is None else round(gf_ref, 1),
                        "end_to_end_mfma_frac": round(value * gf_img * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
                        "kernel_ms_per_step_by_stage": {k: round(v, 3) for k, v in sorted(stage_ms.items())},
                        "kernel_ms_per_step_total": round(total_k, 3),
