@@ -1,0 +1,267 @@
+// 3x3 conv (stride 1, zero-bordered NHWC input) with FEW output channels (N = 32 or 64), bf16, gfx950.
+//
+// The launches it serves are the composed `conv_3x3 o conv_s0` (256 -> 32 @288^2) and `conv_3x3 o conv_s1`
+// (256 -> 64 @144^2) of the SAM2-side neck (reference: sam3/sam3/model/necks.py:42-92 conv_3x3, followed by
+// sam3_image_processor.py:62-75 conv_s0 / conv_s1).  As an implicit GEMM they stream every input pixel through
+// L2 -> LDS nine times (once per tap) for only 32 / 64 output channels, which is what bounds the 128 x BN and the
+// 256 x 256 kernels on them.  Here a workgroup owns a 16 x 16 output patch and stages its 18 x 18 input HALO once
+// per 32-channel chunk (LDS-DMA, double buffered); the nine taps are shifted reads of the same LDS pixels, so the
+// input crosses L2 -> LDS 1.27 times instead of 9.
+//
+//   workgroup  256 threads = 4 waves; wave w owns output rows 4w..4w+3 = two 32-pixel fragments (2 rows x 16 cols)
+//   K loop     Cin/32 chunks x 9 taps x 2 k16-steps; per step 2 x N/32 v_mfma_f32_32x32x16_bf16 per wave
+//   LDS        per buffer: halo 324 px x 64 B (16-byte slot XOR-ed with bit 2 of the pixel index: the 8-lane groups
+//              of a ds_read_b128 hit distinct banks) + weights 9 x 2 x N/32 fragments of 1 KB, already in fragment
+//              order in global memory (esam3_conv3x3_narrow_windex), so their DMA is a linear copy
+//   persistent one barrier per chunk; the staging stream runs one chunk ahead and crosses output tiles
+//   epilogue   + bias, activation, half-wave exchange -> 16-byte stores; 16 pixels of a row = 16 x 2N contiguous bytes
+#include "gemm_common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ void dma_piece(const void* base, uint32_t voff, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr)
+               : "memory");
+}
+
+constexpr int TS = 16;                 // output tile side
+constexpr int HS = TS + 2;             // halo side
+constexpr int HPIX = HS * HS;          // 324
+constexpr int KC = 32;                 // channels per chunk (64 bytes per pixel)
+constexpr int A_PIECES = HPIX * 4;     // 1296 16-byte pieces
+constexpr int A_OPS = 6;               // per wave: 5 full wave-ops (4 x 5 x 64 = 1280) + wave 0's tail op
+constexpr uint32_t A_BYTES = 21 * 1024;  // 1296 pieces + the tail op's spill-over lanes
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv3x3_narrow_kernel(GemmParams p) {
+  typedef bf16_t T;
+  constexpr uint32_t B_BYTES = 18u * NT * 1024u;
+  constexpr uint32_t BUF = A_BYTES + B_BYTES;
+  constexpr int B_OPS = 18 * NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, g = lane >> 5;
+  const T* __restrict__ gA = reinterpret_cast<const T*>(p.A);
+  const T* __restrict__ gW = reinterpret_cast<const T*>(p.Wt);
+  T* __restrict__ gO = reinterpret_cast<T*>(p.out);
+  const int Wp = p.W + 2, Hp = p.H + 2;
+  const int nch = p.Cin / KC;
+  const unsigned tiles_x = p.W / TS, tiles_img = (p.H / TS) * tiles_x;
+  const unsigned nblk = (unsigned)(p.M / (TS * TS));
+
+  // persistent workgroups, XCD-contiguous tile ranges (neighbouring tiles share halo pixels in that XCD's L2)
+  const unsigned nwg = gridDim.x;
+  const unsigned xcd = blockIdx.x % 8, wg_in_xcd = blockIdx.x / 8;
+  const unsigned wgs_this_xcd = nwg / 8 + (xcd < nwg % 8 ? 1 : 0);
+  const unsigned q_ = nblk / 8, r_ = nblk % 8;
+  const unsigned xcd_first = xcd < r_ ? xcd * (q_ + 1) : r_ * (q_ + 1) + (xcd - r_) * q_;
+  const unsigned xcd_count = q_ + (xcd < r_ ? 1 : 0);
+  if (wg_in_xcd >= xcd_count) return;
+  const unsigned my_tiles = (xcd_count - wg_in_xcd + wgs_this_xcd - 1) / wgs_this_xcd;
+  struct TilePos { unsigned b, ty, tx; };
+  auto tile_pos = [&](unsigned w) {
+    const unsigned lt = xcd_first + wg_in_xcd + w * wgs_this_xcd;
+    TilePos t;
+    t.b = lt / tiles_img;
+    const unsigned ti = lt - t.b * tiles_img;
+    t.ty = ti / tiles_x;
+    t.tx = ti - t.ty * tiles_x;
+    return t;
+  };
+  auto tile_a_base = [&](const TilePos& t) -> const T* {  // halo origin = padded pixel (ty*16, tx*16)
+    return gA + ((int64_t)(t.b * (unsigned)Hp + t.ty * TS) * Wp + t.tx * TS) * p.lda;
+  };
+
+  // ---- staging: per-lane source offsets (bytes), constant over tiles and chunks -----------------------------
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  uint32_t a_voff[A_OPS];
+#pragma unroll
+  for (int o = 0; o < A_OPS; ++o) {
+    int q = (o < 5 ? (wave * 5 + o) * 64 : 1280) + lane;
+    if (q > A_PIECES - 1) q = A_PIECES - 1;  // tail op, lanes >= 16: re-fetch the last piece into the spill-over area
+    const int hp = q >> 2, s = q & 3;
+    const int c = s ^ ((hp >> 2) & 1);
+    const int hy = hp / HS, hx = hp - hy * HS;
+    a_voff[o] = (uint32_t)((((int64_t)hy * Wp + hx) * p.lda + c * 8) * 2);
+  }
+  const uint32_t b_voff = (uint32_t)lane * 16u;
+
+  // ---- fragment read offsets within a buffer ---------------------------------------------------------------------
+  uint32_t rdA[2][9];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const int hp = (4 * wave + 2 * f + (l31 >> 4) + dy) * HS + (l31 & 15) + dx;
+      rdA[f][tap] = (uint32_t)(hp * 64 + ((g * 16) ^ ((hp & 4) << 2)));
+    }
+  const uint32_t rdB = A_BYTES + (uint32_t)lane * 16u;
+
+  // ---- staging stream ------------------------------------------------------------------------------------------
+  unsigned s_w = 0;
+  int s_ch = 0;
+  const T* s_tileA = tile_a_base(tile_pos(0));
+  auto issue = [&](uint32_t par) {  // stage chunk (s_w, s_ch) into buffer `par`, then advance the stream
+    const T* aBase = s_tileA + s_ch * KC;
+    const T* bBase = gW + (int64_t)s_ch * (9 * 2 * NT * 512);
+    const uint32_t lbuf = lds0 + par * BUF;
+#pragma unroll
+    for (int o = 0; o < 5; ++o) dma_piece(aBase, a_voff[o], lbuf + (uint32_t)(wave * 5 + o) * 1024u);
+    if (wave == 0) dma_piece(aBase, a_voff[5], lbuf + 20u * 1024u);
+#pragma unroll
+    for (int j = 0; j < (B_OPS + 3) / 4; ++j) {
+      const int op = wave + 4 * j;
+      if (op < B_OPS) dma_piece(bBase + (int64_t)op * 512, b_voff, lbuf + A_BYTES + (uint32_t)op * 1024u);
+    }
+    if (++s_ch == nch) {
+      s_ch = 0;
+      ++s_w;
+      if (s_w < my_tiles) s_tileA = tile_a_base(tile_pos(s_w));
+    }
+  };
+
+  float4 bq[NT][4];
+#pragma unroll
+  for (int nf = 0; nf < NT; ++nf)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bq[nf][q] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nf * 32 + 8 * q + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+  f32x16_v acc[2][NT];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int nf = 0; nf < NT; ++nf)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[f][nf][e] = 0.f;
+
+  const unsigned total = my_tiles * (unsigned)nch;
+  issue(0);
+  bool landed = false;
+  unsigned c_w = 0;
+  int c_ch = 0;
+  for (unsigned it = 0; it < total; ++it) {
+    const uint32_t par = it & 1u;
+    if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk `it`
+    landed = false;
+    __builtin_amdgcn_s_barrier();  // every wave's pieces landed; every wave is done with the other buffer
+    if (it + 1 < total) issue(par ^ 1u);
+    const char* lbuf = smem + par * BUF;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 fb[NT], fa[2];
+#pragma unroll
+        for (int nf = 0; nf < NT; ++nf)
+          fb[nf] = *reinterpret_cast<const u32x4*>(lbuf + rdB + (uint32_t)(((tap * 2 + ks) * NT + nf) * 1024));
+#pragma unroll
+        for (int f = 0; f < 2; ++f) fa[f] = *reinterpret_cast<const u32x4*>(lbuf + rdA[f][tap] + ks * 32);
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int nf = 0; nf < NT; ++nf) MmaOps<T>::mma(fb[nf], fa[f], acc[f][nf]);
+      }
+    }
+    if (++c_ch == nch) {  // ---- epilogue of output tile c_w ----
+      const TilePos t = tile_pos(c_w);
+      // the next tile's first chunk (issued above) has had this chunk's arithmetic to land: wait for it here, before
+      // the stores, so that the next iteration's wait does not also wait for the stores (vmcnt counts stores)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      landed = true;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const unsigned r = t.ty * TS + 4 * wave + 2 * f + (l31 >> 4), c = t.tx * TS + (l31 & 15);
+        T* op = gO + ((int64_t)(t.b * (unsigned)p.H + r) * p.W + c) * p.ldc + 8 * g;
+#pragma unroll
+        for (int nf = 0; nf < NT; ++nf) {
+          float v[16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float bb[4] = {bq[nf][q].x, bq[nf][q].y, bq[nf][q].z, bq[nf][q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = acc[f][nf][4 * q + e] + bb[e];
+          }
+          act_apply_n<16>(v, p.act);
+#pragma unroll
+          for (int qp = 0; qp < 2; ++qp) {
+            const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]);
+            const uint32_t a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
+            const uint32_t b0 = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]);
+            const uint32_t b1 = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
+            // half-wave exchange: lanes 0-31 end with channels 16qp..16qp+7, lanes 32-63 with +8..+15
+            auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+            *reinterpret_cast<u32x4*>(op + nf * 32 + qp * 16) = o;
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[f][nf][e] = 0.f;
+        }
+      }
+      c_ch = 0;
+      ++c_w;
+    }
+  }
+}
+
+template <int NT>
+int launch_nt(const GemmParams& p, hipStream_t stream) {
+  constexpr size_t lds = 2 * (size_t)(A_BYTES + 18 * NT * 1024);
+  static bool attr_set = false;
+  auto kern = conv3x3_narrow_kernel<NT>;
+  if (!attr_set) {
+    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+    attr_set = true;
+  }
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HIP_CHECK_RET(hipGetDevice(&dev));
+    HIP_CHECK_RET(hipGetDeviceProperties(&prop, dev));
+    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int64_t tiles = p.M / (TS * TS);
+  const int64_t resident = (int64_t)n_cu * (int64_t)(163840 / lds);  // workgroups the LDS lets a CU hold
+  const int64_t grid = tiles < resident ? tiles : resident;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// The shapes this kernel takes; everything else stays on esam3_launch_gemm.
+bool esam3_conv3x3_narrow_ok(int dtype, int N, int Cin, int H, int W, int in_pad, int out_pad, int stride, bool has_res) {
+  return dtype == 1 && (N == 32 || N == 64) && Cin % KC == 0 && Cin >= KC && H % TS == 0 && W % TS == 0 && H > 0 &&
+         W > 0 && in_pad == 1 && out_pad == 0 && stride <= 1 && !has_res;
+}
+
+// Element index of weight (n, tap, c) in the fragment-ordered array the kernel stages with linear copies:
+// [chunk = c/32][tap][k16-step][32-channel output block][lane = (c%16)/8*32 + n%32][c%8]
+int64_t esam3_conv3x3_narrow_windex(int N, int n, int tap, int c) {
+  const int NT = N / 32;
+  const int chunk = c / KC, ks = (c % KC) / 16, gg = (c % 16) / 8, j = c % 8;
+  const int nf = n / 32, lane = gg * 32 + (n % 32);
+  return ((((int64_t)(chunk * 9 + tap) * 2 + ks) * NT + nf) * 64 + lane) * 8 + j;
+}
+
+// p.Wt: weights in esam3_conv3x3_narrow_windex order (bf16); p.A zero-bordered [B][H+2][W+2][lda]; p.out [B][H][W][ldc].
+int esam3_launch_conv3x3_narrow(const GemmParams& p, hipStream_t stream) {
+  if (!esam3_conv3x3_narrow_ok(1, p.N, p.Cin, p.H, p.W, p.in_pad, p.out_pad, p.stride, p.res != nullptr) || p.ksize != 3 ||
+      p.M % (TS * TS) != 0 || p.M >= ((int64_t)1 << 31) || (p.lda * 2) % 16 != 0 || (p.ldc * 2) % 16 != 0 ||
+      (((uintptr_t)p.A) & 15) || (((uintptr_t)p.Wt) & 15) || (((uintptr_t)p.out) & 15) ||
+      (p.bias && (((uintptr_t)p.bias) & 15)) || (int64_t)(p.H + 2) * (p.W + 2) * p.lda * 2 >= ((int64_t)1 << 32)) {
+    esam3_set_error("conv3x3_narrow: unsupported shape N=%d Cin=%d H=%d W=%d", p.N, p.Cin, p.H, p.W);
+    return -1;
+  }
+  esam3_note_gemm_kernel("conv3x3_narrow_kernel<bf16> (16x16 output patch, 18x18 halo per 32-channel chunk in LDS)");
+  return p.N == 32 ? launch_nt<1>(p, stream) : launch_nt<2>(p, stream);
+}

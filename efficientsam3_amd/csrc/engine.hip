@@ -61,6 +61,7 @@ struct HostTensor {
 
 struct PackedGemm {
   void* w = nullptr;      // [Np][Kp] activation dtype
+  void* wn = nullptr;     // bf16 3x3 convs with 32 / 64 output channels: the same weights in conv3x3_narrow's fragment order
   float* bias = nullptr;  // [N] (or [Cout] for convT) fp32
   int N = 0, K = 0, Kp = 0, Np = 0, ksize = 1, cin = 0, convt_cout = 0;
   std::string tag;
@@ -245,6 +246,15 @@ struct esam3_engine {
     g.w = upload_T(pk);
     g.bias = has_bias ? (float*)dev_upload(bias.data(), bias.size() * 4) : nullptr;
     if (!g.w) return nullptr;
+    if (dtype == 1 && ks == 3 && (N == 32 || N == 64) && cin % 32 == 0) {
+      std::vector<float> pn((size_t)N * g.K);
+      for (int n = 0; n < N; ++n)
+        for (int c = 0; c < cin; ++c)
+          for (int t = 0; t < 9; ++t)
+            pn[(size_t)esam3_conv3x3_narrow_windex(N, n, t, c)] = w->d[((size_t)n * cin + c) * 9 + t] * scale[n];
+      g.wn = upload_T(pn);
+      if (!g.wn) return nullptr;
+    }
     g.tag = wname;
     return &(gemms[wname] = g);
   }
@@ -443,6 +453,10 @@ struct esam3_engine {
     const double uniq_in = (double)M * g->cin * (g->ksize == 3 ? 1 : 1);
     const double bytes = (uniq_in + (double)g->N * g->K + (double)M * g->N + (res ? (double)M * g->N : 0.0)) * (double)esz;
     const double flops = 2.0 * (double)M * g->N * g->K;
+    if (g->wn && esam3_conv3x3_narrow_ok(dtype, g->N, g->cin, H, W, in_pad, out_pad, stride, res != nullptr)) {
+      p.Wt = g->wn;
+      return prof_launch(g->tag, flops, bytes, [&]() { return esam3_launch_conv3x3_narrow(p, st); });
+    }
     if (!prof && !watch_tag.empty() && g->tag == watch_tag) return timed_gemm(g->tag, flops, bytes, p, st);
     return prof_launch(g->tag, flops, bytes, [&]() { return esam3_launch_gemm(dtype, p, st); });
   }

@@ -800,6 +800,7 @@ int esam3_gemm_pad_k(int K, int elem_size) {
   return (K + bke - 1) / bke * bke;
 }
 
+void esam3_note_gemm_kernel(const char* name) { g_last_kernel = name; }
 const char* esam3_take_last_gemm_kernel() {
   const char* k = g_last_kernel;
   g_last_kernel = nullptr;

@@ -7,10 +7,16 @@ int esam3_gemm_pad_n(int N);
 int esam3_gemm_pad_k(int K, int elem_size);
 // name of the kernel chosen by the most recent esam3_launch_gemm on this thread (then cleared)
 const char* esam3_take_last_gemm_kernel();
+void esam3_note_gemm_kernel(const char* name);
 int esam3_launch_gemm(int dtype, const GemmParams& p, hipStream_t stream);
 // K ordering of packed dense-conv weights: korder (see GemmParams) and the packed k index of (tap, c)
 int esam3_conv_korder(int cin, int ksize, int elem_size);
 int esam3_conv_k_index(int cin, int ksize, int elem_size, int tap, int c);
+// 3x3 convs with 32 / 64 output channels on a zero-bordered input (conv3x3_narrow.hip): eligibility, the element
+// index of weight (n, tap, c) in the fragment-ordered bf16 weight array the kernel expects in p.Wt, the launcher
+bool esam3_conv3x3_narrow_ok(int dtype, int N, int Cin, int H, int W, int in_pad, int out_pad, int stride, bool has_res);
+int64_t esam3_conv3x3_narrow_windex(int N, int n, int tap, int c);
+int esam3_launch_conv3x3_narrow(const GemmParams& p, hipStream_t stream);
 
 // E0: stem 3x3/s2 conv on the NCHW fp32 network input -> NHWC T, + bias + Hardswish.
 int esam3_launch_stem(int dtype, const float* img_nchw, const float* w /*[27][Cout]*/,

@@ -198,6 +198,17 @@ int esam3_op_conv3x3_padded(int dtype, const void* x_padded, const float* w, con
   p.korder = esam3_conv_korder(Cin, 3, esz);
   p.in_pad = 1; p.out_pad = out_pad;
   if (out_pad && esam3_launch_zero_border(dtype, out, B, H + 2, W + 2, Cout, (hipStream_t)stream)) return -1;
+  if (esam3_conv3x3_narrow_ok(dtype, Cout, Cin, H, W, 1, out_pad, 1, false)) {  // the engine's choice for these shapes
+    std::vector<float> pn((size_t)Cout * K);
+    for (int n = 0; n < Cout; ++n)
+      for (int c = 0; c < Cin; ++c)
+        for (int tp = 0; tp < 9; ++tp) pn[(size_t)esam3_conv3x3_narrow_windex(Cout, n, tp, c)] = w[((size_t)n * Cin + c) * 9 + tp];
+    p.Wt = t.upT(dtype, pn);
+    if (!p.Wt) return fail("op_conv3x3_padded");
+    if (esam3_launch_conv3x3_narrow(p, (hipStream_t)stream)) return -1;
+    HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+  }
   if (esam3_launch_gemm(dtype, p, (hipStream_t)stream)) return -1;
   HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
   return 0;

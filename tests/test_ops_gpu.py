@@ -204,6 +204,10 @@ def test_squeeze_excite(mode, B, H, W, C, R):
     (3, 19, 17, 256, 256, 1),   # ragged M + padded output
     (2, 12, 12, 256, 32, 0),    # composed 3x3 o conv_s0 shape -> 128x32 kernel with in_pad
     (1, 9, 9, 64, 64, 1),       # small-K register-staged path with in_pad
+    (2, 32, 48, 256, 32, 0),    # bf16: conv3x3_narrow (16x16 patches, halo in LDS), N = 32, 8 chunks
+    (1, 16, 16, 64, 64, 0),     # bf16: conv3x3_narrow, one tile, N = 64
+    (3, 48, 32, 256, 64, 0),    # bf16: conv3x3_narrow, N = 64
+    (5, 144, 144, 96, 32, 0),   # bf16: conv3x3_narrow, more tiles than resident workgroups (persistent loop), 3 chunks
 ])
 def test_conv3x3_padded(mode, B, H, W, Cin, Cout, out_pad):
     """3x3 conv reading a zero-bordered NHWC input (no bounds checks; serves the DMA kernel)."""
