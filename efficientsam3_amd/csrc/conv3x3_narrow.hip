@@ -10,13 +10,28 @@
 //
 //   workgroup  256 threads = 4 waves; wave w owns output rows 4w..4w+3 = two 32-pixel fragments (2 rows x 16 cols)
 //   K loop     Cin/32 chunks x 9 taps x 2 k16-steps; per step 2 x N/32 v_mfma_f32_32x32x16_bf16 per wave
-//   LDS        per buffer: halo 324 px x 64 B (16-byte slot XOR-ed with bit 2 of the pixel index: the 8-lane groups
-//              of a ds_read_b128 hit distinct banks) + weights 9 x 2 x N/32 fragments of 1 KB, already in fragment
+//   LDS        per buffer: halo 324 px x 64 B (16-byte slot XOR-ed with pixel index bits; the fragment's lane -> pixel
+//              map gives each 16-lane group of a ds_read_b128 one row of 16 pixels = all 64 banks) + weights 9 x 2 x N/32 fragments of 1 KB, already in fragment
 //              order in global memory (esam3_conv3x3_narrow_windex), so their DMA is a linear copy
 //   persistent one barrier per chunk; the staging stream runs one chunk ahead and crosses output tiles
 //   epilogue   + bias, activation, half-wave exchange -> 16-byte stores; 16 pixels of a row = 16 x 2N contiguous bytes
 #include "gemm_common.h"
 #include "kernels.h"
+
+// Tuning: channels per staged chunk (16 / 32 / 64; the weight order depends on it) and 16x16 patches per workgroup
+// along x, per output width N.
+#ifndef ESAM3_NARROW_KC32
+#define ESAM3_NARROW_KC32 32
+#endif
+#ifndef ESAM3_NARROW_KC64
+#define ESAM3_NARROW_KC64 16  // two workgroups per CU instead of one: 0.21 vs 0.26 ms on 256 -> 64 @144^2, B = 32
+#endif
+#ifndef ESAM3_NARROW_MT32
+#define ESAM3_NARROW_MT32 1
+#endif
+#ifndef ESAM3_NARROW_MT64
+#define ESAM3_NARROW_MT64 1
+#endif
 
 namespace {
 
@@ -26,32 +41,53 @@ __device__ __forceinline__ void dma_piece(const void* base, uint32_t voff, uint3
 }
 
 constexpr int TS = 16;                 // output tile side
-constexpr int HS = TS + 2;             // halo side
-constexpr int HPIX = HS * HS;          // 324
-constexpr int KC = 32;                 // channels per chunk (64 bytes per pixel)
-constexpr int A_PIECES = HPIX * 4;     // 1296 16-byte pieces
-constexpr int A_OPS = 6;               // per wave: 5 full wave-ops (4 x 5 x 64 = 1280) + wave 0's tail op
-constexpr uint32_t A_BYTES = 21 * 1024;  // 1296 pieces + the tail op's spill-over lanes
+constexpr int HS = TS + 2;             // halo rows
+constexpr int kc_of(int N) { return N == 32 ? ESAM3_NARROW_KC32 : ESAM3_NARROW_KC64; }
 
-template <int NT>
+// KC = channels per chunk: 16 / 32 / 64 -> 2 / 4 / 8 16-byte slots per halo pixel in LDS
+template <int NT, int KC, int MT> struct Geo {
+  static constexpr int HSX = TS * MT + 2;                 // halo columns: MT patches side by side
+  static constexpr int HPIX = HS * HSX;
+  static constexpr int PP = KC / 8;                       // slots (pieces) per pixel
+  static constexpr int KS = KC / 16;                      // k16-steps per tap
+  static constexpr int A_PIECES = HPIX * PP;
+  static constexpr int A_OPS = (A_PIECES + 63) / 64;      // wave-ops (64 pieces = 1 KB each); the last one is partial
+  static constexpr int A_OPW = (A_OPS + 3) / 4;           // per wave
+  static constexpr uint32_t A_BYTES = A_OPS * 1024u;      // incl. the partial op's spill-over lanes
+  static constexpr int B_OPS = 9 * KS * NT;
+  static constexpr uint32_t B_BYTES = B_OPS * 1024u;
+  static constexpr uint32_t BUF = A_BYTES + B_BYTES;
+  // Bank swizzle of a pixel's slot index.  A ds_read_b128 is served in four 16-lane groups, one 256-byte bank row per
+  // LDS cycle (MI355X_MICROARCH.md, LDS); the fragment's lane -> pixel map below gives every group 16 CONSECUTIVE halo
+  // pixels, i.e. PP of them per 16/PP-pixel bank row position, which this XOR sends to PP different slots.
+  static __device__ __host__ constexpr int swz(int hp) { return (hp / (16 / PP)) & (PP - 1); }
+};
+
+template <int NT, int KC, int MT>
 __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(GemmParams p) {
   typedef bf16_t T;
-  constexpr uint32_t B_BYTES = 18u * NT * 1024u;
-  constexpr uint32_t BUF = A_BYTES + B_BYTES;
-  constexpr int B_OPS = 18 * NT;
+  typedef Geo<NT, KC, MT> G;
+  constexpr int NF = 2 * MT;  // 32-pixel fragments per wave: (patch mt, row pair f) -> index mt*2 + f
+  constexpr int HSX = G::HSX;
+  constexpr int PP = G::PP, KS = G::KS, A_OPS = G::A_OPS, A_OPW = G::A_OPW, B_OPS = G::B_OPS;
+  constexpr uint32_t A_BYTES = G::A_BYTES, BUF = G::BUF;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, g = lane >> 5;
+  // pixel of the 32-pixel fragment (2 rows x 16 columns) this lane holds: the ds_read_b128 lane groups
+  // {0-3,12-15,20-27} and {4-11,16-19,28-31} (and the same + 32) each take one row of 16 pixels
+  const int quad = l31 >> 2;
+  const int prow = (quad ^ (quad >> 1) ^ (quad >> 2)) & 1, pcol = (quad >> 1) * 4 + (l31 & 3);
   const T* __restrict__ gA = reinterpret_cast<const T*>(p.A);
   const T* __restrict__ gW = reinterpret_cast<const T*>(p.Wt);
   T* __restrict__ gO = reinterpret_cast<T*>(p.out);
   const int Wp = p.W + 2, Hp = p.H + 2;
   const int nch = p.Cin / KC;
-  const unsigned tiles_x = p.W / TS, tiles_img = (p.H / TS) * tiles_x;
-  const unsigned nblk = (unsigned)(p.M / (TS * TS));
+  const unsigned tiles_x = p.W / (TS * MT), tiles_img = (p.H / TS) * tiles_x;
+  const unsigned nblk = (unsigned)(p.M / (TS * TS * MT));
 
   // persistent workgroups, XCD-contiguous tile ranges (neighbouring tiles share halo pixels in that XCD's L2)
   const unsigned nwg = gridDim.x;
@@ -72,33 +108,33 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(GemmParams p) {
     t.tx = ti - t.ty * tiles_x;
     return t;
   };
-  auto tile_a_base = [&](const TilePos& t) -> const T* {  // halo origin = padded pixel (ty*16, tx*16)
-    return gA + ((int64_t)(t.b * (unsigned)Hp + t.ty * TS) * Wp + t.tx * TS) * p.lda;
+  auto tile_a_base = [&](const TilePos& t) -> const T* {  // halo origin = padded pixel (ty*16, tx*16*MT)
+    return gA + ((int64_t)(t.b * (unsigned)Hp + t.ty * TS) * Wp + t.tx * (TS * MT)) * p.lda;
   };
 
   // ---- staging: per-lane source offsets (bytes), constant over tiles and chunks -----------------------------
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  uint32_t a_voff[A_OPS];
+  uint32_t a_voff[A_OPW];
 #pragma unroll
-  for (int o = 0; o < A_OPS; ++o) {
-    int q = (o < 5 ? (wave * 5 + o) * 64 : 1280) + lane;
-    if (q > A_PIECES - 1) q = A_PIECES - 1;  // tail op, lanes >= 16: re-fetch the last piece into the spill-over area
-    const int hp = q >> 2, s = q & 3;
-    const int c = s ^ ((hp >> 2) & 1);
-    const int hy = hp / HS, hx = hp - hy * HS;
-    a_voff[o] = (uint32_t)((((int64_t)hy * Wp + hx) * p.lda + c * 8) * 2);
+  for (int j = 0; j < A_OPW; ++j) {
+    int q = (wave + 4 * j) * 64 + lane;  // wave-op (wave + 4j); ops past A_OPS are not issued
+    if (q > G::A_PIECES - 1) q = G::A_PIECES - 1;  // partial last op: re-fetch the last piece into the spill-over area
+    const int hp = q / PP, s = q - hp * PP;
+    const int c = s ^ G::swz(hp);
+    const int hy = hp / HSX, hx = hp - hy * HSX;
+    a_voff[j] = (uint32_t)((((int64_t)hy * Wp + hx) * p.lda + c * 8) * 2);
   }
   const uint32_t b_voff = (uint32_t)lane * 16u;
 
   // ---- fragment read offsets within a buffer ---------------------------------------------------------------------
-  uint32_t rdA[2][9];
+  uint32_t rdA[NF][9];
 #pragma unroll
-  for (int f = 0; f < 2; ++f)
+  for (int f = 0; f < NF; ++f)
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int dy = tap / 3, dx = tap - dy * 3;
-      const int hp = (4 * wave + 2 * f + (l31 >> 4) + dy) * HS + (l31 & 15) + dx;
-      rdA[f][tap] = (uint32_t)(hp * 64 + ((g * 16) ^ ((hp & 4) << 2)));
+      const int hp = (4 * wave + 2 * (f & 1) + prow + dy) * HSX + (f >> 1) * TS + pcol + dx;
+      rdA[f][tap] = (uint32_t)(hp * (PP * 16) + ((g ^ G::swz(hp)) << 4));  // slot (2*ks + g) ^ swz at ks = 0
     }
   const uint32_t rdB = A_BYTES + (uint32_t)lane * 16u;
 
@@ -108,11 +144,13 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(GemmParams p) {
   const T* s_tileA = tile_a_base(tile_pos(0));
   auto issue = [&](uint32_t par) {  // stage chunk (s_w, s_ch) into buffer `par`, then advance the stream
     const T* aBase = s_tileA + s_ch * KC;
-    const T* bBase = gW + (int64_t)s_ch * (9 * 2 * NT * 512);
+    const T* bBase = gW + (int64_t)s_ch * (B_OPS * 512);
     const uint32_t lbuf = lds0 + par * BUF;
 #pragma unroll
-    for (int o = 0; o < 5; ++o) dma_piece(aBase, a_voff[o], lbuf + (uint32_t)(wave * 5 + o) * 1024u);
-    if (wave == 0) dma_piece(aBase, a_voff[5], lbuf + 20u * 1024u);
+    for (int j = 0; j < A_OPW; ++j) {
+      const int op = wave + 4 * j;
+      if (op < A_OPS) dma_piece(aBase, a_voff[j], lbuf + (uint32_t)op * 1024u);
+    }
 #pragma unroll
     for (int j = 0; j < (B_OPS + 3) / 4; ++j) {
       const int op = wave + 4 * j;
@@ -132,9 +170,9 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(GemmParams p) {
     for (int q = 0; q < 4; ++q)
       bq[nf][q] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nf * 32 + 8 * q + 4 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
 
-  f32x16_v acc[2][NT];
+  f32x16_v acc[NF][NT];
 #pragma unroll
-  for (int f = 0; f < 2; ++f)
+  for (int f = 0; f < NF; ++f)
 #pragma unroll
     for (int nf = 0; nf < NT; ++nf)
 #pragma unroll
@@ -150,24 +188,42 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(GemmParams p) {
     if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of chunk `it`
     landed = false;
     __builtin_amdgcn_s_barrier();  // every wave's pieces landed; every wave is done with the other buffer
+#ifdef ESAM3_N_NODMA  // dev: stage only the first two chunks (arithmetic + LDS reads alone)
+    if (it + 1 < total && it < 1) issue(par ^ 1u);
+#else
     if (it + 1 < total) issue(par ^ 1u);
+#endif
     const char* lbuf = smem + par * BUF;
+#ifndef ESAM3_N_NOMMA  // dev: staging alone
+    // Software pipeline over the nine taps: the fragments of tap t+1 are read while the MFMAs of tap t run (the
+    // compiler left to itself reads one MFMA pair ahead, which exposes the LDS latency at two waves per SIMD).
+    u32x4 fb[2][KS][NT], fa[2][KS][NF];
+    auto load_tap = [&](int tap, int slot) {
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        u32x4 fb[NT], fa[2];
+      for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
         for (int nf = 0; nf < NT; ++nf)
-          fb[nf] = *reinterpret_cast<const u32x4*>(lbuf + rdB + (uint32_t)(((tap * 2 + ks) * NT + nf) * 1024));
+          fb[slot][ks][nf] = *reinterpret_cast<const u32x4*>(lbuf + rdB + (uint32_t)(((tap * KS + ks) * NT + nf) * 1024));
+        // slot (2*ks + g) ^ swz = (2*ks) ^ (g ^ swz): the k16-step is an XOR on the precomputed offset
 #pragma unroll
-        for (int f = 0; f < 2; ++f) fa[f] = *reinterpret_cast<const u32x4*>(lbuf + rdA[f][tap] + ks * 32);
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-          for (int nf = 0; nf < NT; ++nf) MmaOps<T>::mma(fb[nf], fa[f], acc[f][nf]);
+        for (int f = 0; f < NF; ++f)
+          fa[slot][ks][f] = *reinterpret_cast<const u32x4*>(lbuf + (rdA[f][tap] ^ (uint32_t)(ks * 32)));
       }
+    };
+    load_tap(0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + 1 < 9) load_tap(tap + 1, (tap + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+          for (int nf = 0; nf < NT; ++nf) MmaOps<T>::mma(fb[tap & 1][ks][nf], fa[tap & 1][ks][f], acc[f][nf]);
+      __builtin_amdgcn_sched_barrier(0);
     }
+#endif
     if (++c_ch == nch) {  // ---- epilogue of output tile c_w ----
       const TilePos t = tile_pos(c_w);
       // the next tile's first chunk (issued above) has had this chunk's arithmetic to land: wait for it here, before
@@ -175,8 +231,8 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(GemmParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       landed = true;
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        const unsigned r = t.ty * TS + 4 * wave + 2 * f + (l31 >> 4), c = t.tx * TS + (l31 & 15);
+      for (int f = 0; f < NF; ++f) {
+        const unsigned r = t.ty * TS + 4 * wave + 2 * (f & 1) + prow, c = (t.tx * MT + (f >> 1)) * TS + pcol;
         T* op = gO + ((int64_t)(t.b * (unsigned)p.H + r) * p.W + c) * p.ldc + 8 * g;
 #pragma unroll
         for (int nf = 0; nf < NT; ++nf) {
@@ -210,11 +266,12 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(GemmParams p) {
   }
 }
 
-template <int NT>
+template <int NT, int KC, int MT>
 int launch_nt(const GemmParams& p, hipStream_t stream) {
-  constexpr size_t lds = 2 * (size_t)(A_BYTES + 18 * NT * 1024);
+  constexpr size_t lds = 2 * (size_t)Geo<NT, KC, MT>::BUF;
+  static_assert(lds <= 163840, "conv3x3_narrow: the two staging buffers exceed a CU's LDS");
   static bool attr_set = false;
-  auto kern = conv3x3_narrow_kernel<NT>;
+  auto kern = conv3x3_narrow_kernel<NT, KC, MT>;
   if (!attr_set) {
     HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)lds));
@@ -228,8 +285,10 @@ int launch_nt(const GemmParams& p, hipStream_t stream) {
     HIP_CHECK_RET(hipGetDeviceProperties(&prop, dev));
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  const int64_t tiles = p.M / (TS * TS);
-  const int64_t resident = (int64_t)n_cu * (int64_t)(163840 / lds);  // workgroups the LDS lets a CU hold
+  const int64_t tiles = p.M / (TS * TS * MT);
+  int64_t per_cu = (int64_t)(163840 / lds);  // workgroups the LDS lets a CU hold
+  if (per_cu > 4) per_cu = 4;
+  const int64_t resident = (int64_t)n_cu * per_cu;
   const int64_t grid = tiles < resident ? tiles : resident;
   hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
   HIP_CHECK_RET(hipGetLastError());
@@ -240,17 +299,18 @@ int launch_nt(const GemmParams& p, hipStream_t stream) {
 
 // The shapes this kernel takes; everything else stays on esam3_launch_gemm.
 bool esam3_conv3x3_narrow_ok(int dtype, int N, int Cin, int H, int W, int in_pad, int out_pad, int stride, bool has_res) {
-  return dtype == 1 && (N == 32 || N == 64) && Cin % KC == 0 && Cin >= KC && H % TS == 0 && W % TS == 0 && H > 0 &&
+  return dtype == 1 && (N == 32 || N == 64) && Cin % kc_of(N) == 0 && Cin >= kc_of(N) && H % TS == 0 && W % TS == 0 && H > 0 &&
          W > 0 && in_pad == 1 && out_pad == 0 && stride <= 1 && !has_res;
 }
 
 // Element index of weight (n, tap, c) in the fragment-ordered array the kernel stages with linear copies:
-// [chunk = c/32][tap][k16-step][32-channel output block][lane = (c%16)/8*32 + n%32][c%8]
+// [chunk = c/KC][tap][k16-step][32-channel output block][lane = (c%16)/8*32 + n%32][c%8]
 int64_t esam3_conv3x3_narrow_windex(int N, int n, int tap, int c) {
+  const int KC = kc_of(N), KS = KC / 16;
   const int NT = N / 32;
   const int chunk = c / KC, ks = (c % KC) / 16, gg = (c % 16) / 8, j = c % 8;
   const int nf = n / 32, lane = gg * 32 + (n % 32);
-  return ((((int64_t)(chunk * 9 + tap) * 2 + ks) * NT + nf) * 64 + lane) * 8 + j;
+  return ((((int64_t)(chunk * 9 + tap) * KS + ks) * NT + nf) * 64 + lane) * 8 + j;
 }
 
 // p.Wt: weights in esam3_conv3x3_narrow_windex order (bf16); p.A zero-bordered [B][H+2][W+2][lda]; p.out [B][H][W][ldc].
@@ -263,5 +323,10 @@ int esam3_launch_conv3x3_narrow(const GemmParams& p, hipStream_t stream) {
     return -1;
   }
   esam3_note_gemm_kernel("conv3x3_narrow_kernel<bf16> (16x16 output patch, 18x18 halo per 32-channel chunk in LDS)");
-  return p.N == 32 ? launch_nt<1>(p, stream) : launch_nt<2>(p, stream);
+  if (p.N == 32) {
+    if (ESAM3_NARROW_MT32 > 1 && p.W % (TS * ESAM3_NARROW_MT32) == 0) return launch_nt<1, ESAM3_NARROW_KC32, ESAM3_NARROW_MT32>(p, stream);
+    return launch_nt<1, ESAM3_NARROW_KC32, 1>(p, stream);
+  }
+  if (ESAM3_NARROW_MT64 > 1 && p.W % (TS * ESAM3_NARROW_MT64) == 0) return launch_nt<2, ESAM3_NARROW_KC64, ESAM3_NARROW_MT64>(p, stream);
+  return launch_nt<2, ESAM3_NARROW_KC64, 1>(p, stream);
 }

@@ -246,7 +246,7 @@ struct esam3_engine {
     g.w = upload_T(pk);
     g.bias = has_bias ? (float*)dev_upload(bias.data(), bias.size() * 4) : nullptr;
     if (!g.w) return nullptr;
-    if (dtype == 1 && ks == 3 && (N == 32 || N == 64) && cin % 32 == 0) {
+    if (ks == 3 && esam3_conv3x3_narrow_ok(dtype, N, cin, 16, 16, 1, 0, 1, false)) {  // weight-side eligibility
       std::vector<float> pn((size_t)N * g.K);
       for (int n = 0; n < N; ++n)
         for (int c = 0; c < cin; ++c)

@@ -207,6 +207,7 @@ def test_squeeze_excite(mode, B, H, W, C, R):
     (2, 32, 48, 256, 32, 0),    # bf16: conv3x3_narrow (16x16 patches, halo in LDS), N = 32, 8 chunks
     (1, 16, 16, 64, 64, 0),     # bf16: conv3x3_narrow, one tile, N = 64
     (3, 48, 32, 256, 64, 0),    # bf16: conv3x3_narrow, N = 64
+    (2, 32, 96, 64, 32, 0),     # bf16: conv3x3_narrow, width a multiple of 2 and 3 patches (multi-patch workgroups)
     (5, 144, 144, 96, 32, 0),   # bf16: conv3x3_narrow, more tiles than resident workgroups (persistent loop), 3 chunks
 ])
 def test_conv3x3_padded(mode, B, H, W, Cin, Cout, out_pad):

@@ -18,6 +18,7 @@ SHAPES = [  # name, B, H, W, Cin, N, ksize, convt
     ("neck L1 convT' 1024->256 @72", 32, 72, 72, 1024, 1024, 1, 1),
     ("neck L2 1x1 1024->256 @72", 32, 72, 72, 1024, 256, 1, 0),
     ("sam2 L0 3x3 256->32 @288", 32, 288, 288, 256, 32, 3, 0),
+    ("sam2 L1 3x3 256->64 @144", 32, 144, 144, 256, 64, 3, 0),
     ("ViT-H qkv 1024->3072 (B=8)", 8, 72, 72, 1024, 3072, 1, 0),
     ("ViT-H proj 1024->1024", 8, 72, 72, 1024, 1024, 1, 0),
     ("ViT-H fc1 1024->4736", 8, 72, 72, 1024, 4736, 1, 0),
