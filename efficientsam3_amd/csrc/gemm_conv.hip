@@ -680,6 +680,81 @@ int try_thin(const GemmParams& p, hipStream_t stream, bool* done) {
 }
 
 // ======================================================================================
+// skinny GEMM: few rows (the token side of the decoders: M = images x prompt tokens, a few hundred), plain Linear.
+// The 128 x BN kernel runs such a launch on M/128 x N/BN = a handful of workgroups, each walking K serially with a
+// global-load latency per K tile (12-70 us per launch measured, 34 launches per decode step).  Here a workgroup owns
+// a 32 x 32 output block and its four waves split K; every wave issues all its fragment loads up front (16 bytes per
+// lane straight from global memory, no LDS staging), so a launch costs about one memory latency, and M/32 x N/32
+// workgroups spread over the chip.  Partial sums meet in LDS in wave order (deterministic).
+// ======================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(GemmParams p) {
+  constexpr int KF = 16 / (int)sizeof(T);  // K elements per 16-byte fragment; one MFMA step covers 2*KF
+  constexpr int LDR = 36;                  // floats per row of a partial-sum block (16-byte aligned, off the 32-bank stride)
+  constexpr int UN = 8;                    // steps whose loads are in flight together
+  __shared__ __attribute__((aligned(16))) float red[4][32][LDR];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l31 = lane & 31, g = lane >> 5;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const T* __restrict__ gA = reinterpret_cast<const T*>(p.A);
+  const T* __restrict__ gW = reinterpret_cast<const T*>(p.Wt);
+  int64_t arow = m0 + l31;
+  if (arow >= p.M) arow = p.M - 1;  // rows past M are computed and dropped
+  const int steps = p.Kp / (2 * KF) / 4;  // per wave (the launcher guarantees Kp % (8*KF) == 0)
+  const T* ap = gA + arow * p.lda + (int64_t)wave * steps * 2 * KF + g * KF;
+  const T* wp = gW + (int64_t)(n0 + l31) * p.Kp + (int64_t)wave * steps * 2 * KF + g * KF;
+  f32x16_v acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int s0 = 0; s0 < steps; s0 += UN) {
+    u32x4 fa[UN], fw[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (s0 + u < steps) {
+        fa[u] = *reinterpret_cast<const u32x4*>(ap + (s0 + u) * 2 * KF);
+        fw[u] = *reinterpret_cast<const u32x4*>(wp + (s0 + u) * 2 * KF);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+      if (s0 + u < steps) MmaOps<T>::mma(fw[u], fa[u], acc);
+  }
+  // acc[4q+e] = channel n0 + 8q + 4g + e of row m0 + l31
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    *reinterpret_cast<float4*>(&red[wave][l31][8 * q + 4 * g]) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int r = threadIdx.x >> 2, c = (threadIdx.x & 3) * 8;
+    const int m = m0 + r, n = n0 + c;
+    if (m < p.M && n < p.N) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ((red[0][r][c + e] + red[1][r][c + e]) + red[2][r][c + e]) + red[3][r][c + e];
+      epilogue_chunk<T>(p, m, n, v);
+    }
+  }
+}
+
+template <typename T>
+bool use_skinny(const GemmParams& p) {
+  constexpr int KF = 16 / (int)sizeof(T);
+  if (p.ksize != 1 || p.out_mode != OUT_PLAIN || p.in_pad || p.stride > 1) return false;
+  if (p.M > 2048 || p.M <= 0 || p.K != p.Kp || p.Kp % (8 * KF) != 0 || p.Kp > 8192) return false;
+  if ((p.lda * (int)sizeof(T)) % 16 != 0 || (((uintptr_t)p.A) & 15) || (((uintptr_t)p.Wt) & 15)) return false;
+  return true;
+}
+
+template <typename T>
+int launch_skinny(const GemmParams& p, hipStream_t stream) {
+  const dim3 grid((unsigned)((p.M + 31) / 32), (unsigned)((p.N + 31) / 32));
+  hipLaunchKernelGGL(skinny_gemm_kernel<T>, grid, dim3(256), 0, stream, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// ======================================================================================
 // launchers
 // ======================================================================================
 template <typename T, int BM, int BN, int WM, int WN>
@@ -755,6 +830,11 @@ thread_local const char* g_last_kernel = nullptr;  // name of the kernel the las
 template <typename T>
 int launch_gemm_t(const GemmParams& p, hipStream_t stream) {
   constexpr bool bf = sizeof(T) == 2;
+  // few rows: a few hundred token rows, or too few 256 x 256 tiles to occupy the chip
+  if (use_skinny<T>(p) && (p.M <= 512 || ((p.M + 255) / 256) * ((p.N + 255) / 256) < 32)) {
+    g_last_kernel = bf ? "skinny_gemm_kernel<bf16> (32x32 block, K split over 4 waves, loads straight to registers)" : "skinny_gemm_kernel<f32>";
+    return launch_skinny<T>(p, stream);
+  }
   if (use_256<T>(p)) {
     if constexpr (bf) {
       // ESAM3_GEMM256_CLASSIC=1 keeps the two-barrier kernel for A/B timing (tools/bench_gemm.py)

@@ -33,6 +33,7 @@ def _q(x, mode):
     (8, 256, 256, None, False), (300, 128, 256, "relu", True), (1000, 2048, 256, "relu", False),
     (77, 256, 2048, None, True), (5, 4, 256, "sigmoid", False), (3, 1, 256, None, False),
     (513, 32, 16, "hswish", False), (129, 64, 24, "gelu", True), (64, 384, 128, None, False),
+    (288, 256, 256, "relu", True), (2000, 64, 512, "gelu", False),  # skinny_gemm_kernel: token rows x (256 | 512) K
 ])
 def test_linear(mode, M, N, K, act, res):
     d, tdt = U.DT[mode]
