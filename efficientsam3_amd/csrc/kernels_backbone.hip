@@ -1569,6 +1569,81 @@ __global__ void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ 
   }
 }
 
+// Vectorised variant for C % 8 == 0: LPR (a power of two) lanes share a row, a lane owns up to NCH 8-channel chunks
+// (16-byte loads and stores; the scalar kernel above moves 2 bytes per lane per load) and keeps gamma / beta of its
+// chunks in registers while the wave walks `iters` groups of 64/LPR rows.
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            T* __restrict__ out, int64_t rows, int C, float eps, int act,
+                                                            int lpr, int iters) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & (lpr - 1), rw = lane / lpr, rpw = 64 / lpr;  // lane within the row, row within the wave's group
+  const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int nchunk = C >> 3;
+  float gm[NCH][8], bt[NCH][8];
+  bool ok[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int ci = sub + lpr * j;
+    ok[j] = ci < nchunk;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      gm[j][e] = ok[j] ? gamma[ci * 8 + e] : 0.f;
+      bt[j][e] = ok[j] ? beta[ci * 8 + e] : 0.f;
+    }
+  }
+  const float invC = 1.f / (float)C;
+  for (int it = 0; it < iters; ++it) {
+    const int64_t row = (wave_id * iters + it) * rpw + rw;
+    const bool rok = row < rows;
+    float v[NCH][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int64_t off = row * C + (int64_t)(sub + lpr * j) * 8;
+      if (rok && ok[j]) {
+        Vec8<T>::load(x + off, v[j]);
+        if (res) {
+          float r[8];
+          Vec8<T>::load(res + off, r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[j][e] += r[e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += v[j][e];
+    }
+    for (int o = lpr >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum * invC;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+      if (ok[j]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[j][e] - mean;
+          sq += d * d;
+        }
+      }
+    for (int o = lpr >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.f / sqrtf(sq * invC + eps);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      if (rok && ok[j]) {
+        float y[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) y[e] = (v[j][e] - mean) * rstd * gm[j][e] + bt[j][e];
+        act_apply_n<8>(y, act);
+        Vec8<T>::store(out + row * C + (int64_t)(sub + lpr * j) * 8, y);
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ void cast_to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -2002,6 +2077,28 @@ int esam3_launch_resize_bilinear(int dtype, const void* in, void* out, int B, in
 int esam3_launch_layernorm(int dtype, const void* x, const void* res, const float* gamma,
                            const float* beta, void* out, int64_t rows, int C, float eps, int act,
                            hipStream_t s) {
+  const int esz = dtype == 0 ? 4 : 2;
+  const bool aligned = !(((uintptr_t)x) & 15) && !(((uintptr_t)out) & 15) && !(res && (((uintptr_t)res) & 15)) && (C * esz) % 16 == 0;
+  if (C % 8 == 0 && C <= 2048 && aligned && rows > 0) {
+    const int nchunk = C / 8;
+    int lpr = 1;
+    while (lpr < nchunk && lpr < 64) lpr <<= 1;
+    const int nch = (nchunk + lpr - 1) / lpr;  // <= 4
+    const int rpw = 64 / lpr;
+    const int64_t groups = (rows + rpw - 1) / rpw;
+    // enough waves to fill the chip several times over before a wave starts walking more than one group
+    int iters = (int)((groups + 16383) / 16384);
+    if (iters > 8) iters = 8;
+    const int64_t waves = (groups + iters - 1) / iters;
+    const dim3 grid((unsigned)((waves + 3) / 4));
+#define ESAM3_LN(NCH_)                                                                                              \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_vec_kernel<T, NCH_>), grid, dim3(256), 0, s, (const T*)x, (const T*)res, \
+                                       gamma, beta, (T*)out, rows, C, eps, act, lpr, iters))
+    if (nch == 1) { ESAM3_LN(1); } else if (nch == 2) { ESAM3_LN(2); } else if (nch == 3) { ESAM3_LN(3); } else { ESAM3_LN(4); }
+#undef ESAM3_LN
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
   if (C > 1024) { esam3_set_error("layernorm: C=%d > 1024", C); return -1; }
   DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_kernel<T>, dim3(blocks_for(rows, 4)), dim3(256), 0, s,
                                        (const T*)x, (const T*)res, gamma, beta, (T*)out, rows, C, eps,

@@ -378,7 +378,12 @@ def test_resize_bilinear(mode):
 
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("rows,C,eps,act,res", [(1000, 256, 1e-5, None, True), (777, 64, 1e-6, "gelu", False),
-                                               (9, 256, 1e-5, None, False)])
+                                               (9, 256, 1e-5, None, False),
+                                               # vectorised kernel: 3 chunks per lane (ViT-H width), 20 chunks on 32 lanes,
+                                               # many row groups per wave, one chunk per row; C % 8 != 0 -> scalar kernel
+                                               (300, 1280, 1e-6, None, True), (77, 160, 1e-5, None, False),
+                                               (300000, 64, 1e-6, None, False), (50, 8, 1e-5, "gelu", True),
+                                               (40, 2048, 1e-5, None, False), (33, 20, 1e-5, None, True)])
 def test_layernorm(mode, rows, C, eps, act, res):
     d, tdt = U.DT[mode]
     x, r = _rand(rows, C, seed=1) * 2 + 0.3, _rand(rows, C, seed=2)
