@@ -119,6 +119,40 @@ struct GemmParams {
   int stride;         // ksize 3 only: 0/1 -> stride 1; 2 -> H, W are the INPUT dims, M = B*ceil(H/2)*ceil(W/2)
 };
 
+// ---- 8 consecutive activations <-> 8 floats (one 16-byte access for bf16, two for f32) -------
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16_t> {
+  static __device__ inline void load(const bf16_t* p, float* v) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ inline void store(bf16_t* p, const float* v) {
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]);
+    o.y = pack_bf16x2(v[2], v[3]);
+    o.z = pack_bf16x2(v[4], v[5]);
+    o.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = o;
+  }
+};
+template <> struct Vec8<float> {
+  static __device__ inline void load(const float* p, float* v) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+    v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ inline void store(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+
 // ---- error handling ---------------------------------------------------------------
 void esam3_set_error(const char* fmt, ...);
 #define HIP_CHECK_RET(expr)                                                        \

@@ -145,6 +145,88 @@ __global__ void attn_fewkeys_kernel(const T* __restrict__ q, int ldq, const T* _
   for (int d = 0; d < HD; ++d) op[d] = from_f32<T>(acc[d] * inv);
 }
 
+// Variant for head dim 16, <= NKMAX keys, 16-byte aligned rows: a thread still owns one (query, head), but its 16 query
+// values arrive in two 16-byte loads (the 8 heads of a query = 256 contiguous bytes over 8 lanes), K / V come out of
+// LDS as float4, the scores stay in registers between the max and the exp-sum pass, and a thread walks QPT queries so
+// that a workgroup stages K / V once per QPT * 32 queries.
+template <typename T, int NKMAX, int QPT>
+__global__ __launch_bounds__(256) void attn_fewkeys16_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+                                                            const T* __restrict__ v, int ldv, T* __restrict__ o, int ldo,
+                                                            int Nq, int Nk, int heads) {
+  constexpr int HD = 16;
+  extern __shared__ float skv[];  // K [Nk][heads*HD] then V [Nk][heads*HD]
+  const int64_t b = blockIdx.y;
+  const int D = heads * HD;
+  float* sk = skv;
+  float* sv = skv + Nk * D;
+  for (int i = threadIdx.x; i < Nk * D; i += blockDim.x) {
+    const int j = i / D, d = i - j * D;
+    sk[i] = to_f32<T>(k[(b * Nk + j) * (int64_t)ldk + d]);
+    sv[i] = to_f32<T>(v[(b * Nk + j) * (int64_t)ldv + d]);
+  }
+  __syncthreads();
+  const int qpb = blockDim.x / heads;
+  const int ql = threadIdx.x / heads, h = threadIdx.x - ql * heads;
+  const float scale = rsqrtf((float)HD);
+  const float4* k4 = reinterpret_cast<const float4*>(sk + h * HD);
+  const float4* v4 = reinterpret_cast<const float4*>(sv + h * HD);
+  const int d4 = D / 4;
+#pragma unroll 1
+  for (int t = 0; t < QPT; ++t) {
+    const int qi = (blockIdx.x * QPT + t) * qpb + ql;
+    if (qi >= Nq) return;
+    const T* qp = q + (b * Nq + qi) * (int64_t)ldq + h * HD;
+    float qv[HD];
+    Vec8<T>::load(qp, qv);
+    Vec8<T>::load(qp + 8, qv + 8);
+#pragma unroll
+    for (int d = 0; d < HD; ++d) qv[d] *= scale;
+    float sc[NKMAX];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < NKMAX; ++j) {
+      float a = -3.0e38f;
+      if (j < Nk) {
+        a = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 kk = k4[j * d4 + c];
+          a = fmaf(qv[4 * c], kk.x, a);
+          a = fmaf(qv[4 * c + 1], kk.y, a);
+          a = fmaf(qv[4 * c + 2], kk.z, a);
+          a = fmaf(qv[4 * c + 3], kk.w, a);
+        }
+      }
+      sc[j] = a;
+      m = fmaxf(m, a);
+    }
+    float l = 0.f, acc[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NKMAX; ++j) {
+      if (j < Nk) {
+        const float pexp = __expf(sc[j] - m);
+        l += pexp;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 vv = v4[j * d4 + c];
+          acc[4 * c] = fmaf(pexp, vv.x, acc[4 * c]);
+          acc[4 * c + 1] = fmaf(pexp, vv.y, acc[4 * c + 1]);
+          acc[4 * c + 2] = fmaf(pexp, vv.z, acc[4 * c + 2]);
+          acc[4 * c + 3] = fmaf(pexp, vv.w, acc[4 * c + 3]);
+        }
+      }
+    }
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) acc[d] *= inv;
+    T* op = o + (b * Nq + qi) * (int64_t)ldo + h * HD;
+    Vec8<T>::store(op, acc);
+    Vec8<T>::store(op + 8, acc + 8);
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // tokens = [obj_score | iou | mask x4 | sparse prompt embeddings]
 // PositionEmbeddingRandom on (coords + 0.5) / img_size, label embeddings
@@ -829,8 +911,23 @@ int esam3_launch_attn_fewkeys(int dtype, const void* q, int ldq, const void* k, 
     return -1;
   }
   const int qpb = 256 / heads;
-  dim3 grid((unsigned)((Nq + qpb - 1) / qpb), (unsigned)B);
   const size_t lds = sizeof(float) * 2 * (size_t)Nk * heads * hd;
+  const int esz = dtype == 0 ? 4 : 2;
+  auto al = [&](const void* p_, int ld) { return !(((uintptr_t)p_) & 15) && (ld * esz) % 16 == 0; };
+  if (Nk <= 16 && al(q, ldq) && al(o, ldo) && (heads * hd) % 4 == 0) {
+    constexpr int QPT = 4;
+    dim3 grid4((unsigned)((Nq + qpb * QPT - 1) / (qpb * QPT)), (unsigned)B);
+    if (Nk <= 8) {
+      DISPATCH_T(dtype, hipLaunchKernelGGL((attn_fewkeys16_kernel<T, 8, QPT>), grid4, dim3(256), lds, s, (const T*)q, ldq,
+                                           (const T*)k, ldk, (const T*)v, ldv, (T*)o, ldo, Nq, Nk, heads));
+    } else {
+      DISPATCH_T(dtype, hipLaunchKernelGGL((attn_fewkeys16_kernel<T, 16, QPT>), grid4, dim3(256), lds, s, (const T*)q, ldq,
+                                           (const T*)k, ldk, (const T*)v, ldv, (T*)o, ldo, Nq, Nk, heads));
+    }
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
+  dim3 grid((unsigned)((Nq + qpb - 1) / qpb), (unsigned)B);
   DISPATCH_T(dtype, hipLaunchKernelGGL((attn_fewkeys_kernel<T, 16>), grid, dim3(256), lds, s,
                                        (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, (T*)o, ldo,
                                        Nq, Nk, heads));

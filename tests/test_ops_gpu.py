@@ -402,6 +402,8 @@ def test_layernorm(mode, rows, C, eps, act, res):
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("B,Nq,Nk,heads,hd,few", [(2, 8, 5184, 8, 16, 0), (3, 10, 10, 8, 32, 0), (1, 23, 700, 8, 16, 0),
                                                  (2, 5184, 9, 8, 16, 1), (1, 1000, 1, 8, 16, 1),
+                                                 # few keys: <= 8 / <= 16 keys in registers, ragged query count; > 16 -> generic
+                                                 (3, 5001, 7, 8, 16, 1), (2, 777, 13, 8, 16, 1), (1, 300, 20, 8, 16, 1),
                                                  # the LDS-tiled token -> image kernel: full batch, ragged key count, one query
                                                  (32, 10, 5184, 8, 16, 0), (1, 16, 2001, 8, 16, 0), (3, 1, 1100, 8, 16, 0)])
 def test_attention(mode, B, Nq, Nk, heads, hd, few):
