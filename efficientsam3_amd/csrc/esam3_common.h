@@ -52,10 +52,27 @@ template <> struct ElemOps<bf16_t> {
 template <typename T> __host__ __device__ inline float to_f32(T v) { return ElemOps<T>::ld(v); }
 template <typename T> __host__ __device__ inline T from_f32(float v) { return ElemOps<T>::st(v); }
 
+// erf GELU, 0.5 x (1 + erf(x / sqrt 2)), with erfc from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 on erf):
+// 1 + erf(z) = erfc(-z), so the negative side needs no 1 - (1 - small) cancellation.  |GELU error| < 5e-7 for |x| <= 12,
+// an order of magnitude below the bf16 output step and the f32-mode test tolerances; about a dozen VALU operations
+// where libm's erff is a two-branch polynomial of about thirty (the GELU epilogues of the ViT-H / TinyViT MLPs were
+// VALU-bound on it).
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = x * 0.70710678118654752440f;
+  const float a = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.f));
+  float y = fmaf(t, 1.061405429f, -1.453152027f);
+  y = fmaf(t, y, 1.421413741f);
+  y = fmaf(t, y, -0.284496736f);
+  y = fmaf(t, y, 0.254829592f);
+  const float ye = (t * y) * __builtin_amdgcn_exp2f(-(a * a) * 1.4426950408889634f);  // erfc(|z|)
+  return 0.5f * x * (z < 0.f ? ye : 2.f - ye);
+}
+
 __device__ inline float act_apply(float x, int act) {
   switch (act) {
     case ACT_RELU: return x > 0.f ? x : 0.f;
-    case ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));  // exact erf GELU
+    case ACT_GELU: return gelu_fast(x);  // erf GELU
     case ACT_HSWISH: {  // x * relu6(x + 3) / 6
       float r = fminf(fmaxf(x + 3.f, 0.f), 6.f);
       return x * r * (1.f / 6.f);
@@ -76,7 +93,7 @@ __device__ __forceinline__ void act_apply_n(float (&v)[N], int act) {
     for (int i = 0; i < N; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f;
   } else if (act == ACT_GELU) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] = 0.5f * v[i] * (1.f + erff(v[i] * 0.70710678118654752440f));
+    for (int i = 0; i < N; ++i) v[i] = gelu_fast(v[i]);
   } else if (act == ACT_HSWISH) {
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = v[i] * fminf(fmaxf(v[i] + 3.f, 0.f), 6.f) * (1.f / 6.f);

@@ -359,7 +359,7 @@ __global__ void bsc_to_sbc_f32_kernel(const T* __restrict__ x, float* __restrict
 // output pixels: 64 threads reduce their 4x4 input patch to the 16-vector, then all 256 threads
 // (one per output channel, its 16 weights in registers) expand it.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_fast(x); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void mask_embed_kernel(const float* __restrict__ mask, const float* __restrict__ w0,
