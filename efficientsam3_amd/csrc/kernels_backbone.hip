@@ -138,6 +138,220 @@ __global__ void dwconv_kernel(const T* __restrict__ in, int ld_in, const float* 
   }
 }
 
+// Depthwise k x k conv, stride 1, LDS-tiled: a workgroup stages the (8J + k - 1) x (16 + k - 1) input halo of a
+// 64-channel block once (16-byte vectors, zero-filled outside the image) and every thread produces J runs of four
+// horizontally adjacent outputs for 8 channels from it with a sliding window, so an input vector is fetched from
+// global memory ~1.5-2 times instead of k times per output row, and the k*k weights come from LDS row by row.
+// Workgroups are persistent: the halo of the NEXT tile is already on its way into registers while the current one is
+// computed from LDS (a streaming kernel with separate load and compute phases keeps too few bytes in flight).
+// LDS pixel pitch = 64 channels + 32 bytes: the four runs a 16-lane ds_read_b128 group touches (pixels 4 apart)
+// then fall into four different 64-byte quarters of the 256-byte bank row.
+template <typename T, int KS, int J>
+__global__ __launch_bounds__(256, 2) void dwconv_tiled_kernel(const T* __restrict__ in, int ld_in, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, T* __restrict__ out, int ld_out,
+                                                             int H, int W, int C, int act, int tiles_x, int tiles_y, int B) {
+  constexpr int CB = 64, TW = 16, TH = 8 * J, HW_ = TW + KS - 1, HH = TH + KS - 1, P = KS / 2;
+  constexpr int PITCH = CB + 32 / (int)sizeof(T);  // elements
+  constexpr int NV = (HH * HW_ * 8 + 255) / 256;   // halo vectors (8 channels each) per thread
+  typedef uint32_t raw_t __attribute__((ext_vector_type(2 * sizeof(T))));  // 8 elements of T
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  T* tile = reinterpret_cast<T*>(dsm);                                   // [HH*HW_][PITCH]
+  float* sw = reinterpret_cast<float*>(dsm + (size_t)HH * HW_ * PITCH * sizeof(T));  // [KS*KS][CB] then bias [CB]
+  const int tiles_img = tiles_x * tiles_y;
+  const int per_cb = tiles_img * B;               // tile order: channel block slowest, then image, row, column
+  const int total = per_cb * (C / CB);
+  const int cg = threadIdx.x & 7, pt = threadIdx.x >> 3;
+
+  struct Pos { int cb, b, oy0, ox0; };
+  auto pos_of = [&](int t) {
+    Pos p;
+    p.cb = t / per_cb;
+    int r = t - p.cb * per_cb;
+    p.b = r / tiles_img;
+    r -= p.b * tiles_img;
+    const int ty = r / tiles_x;
+    p.oy0 = ty * TH;
+    p.ox0 = (r - ty * tiles_x) * TW;
+    return p;
+  };
+  raw_t hv[NV];
+  auto fetch = [&](const Pos& p) {  // this thread's halo vectors of tile p -> registers
+    const T* img = in + (int64_t)p.b * H * W * ld_in + p.cb * CB;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = threadIdx.x + 256 * i;
+      const int px = v >> 3, slot = v & 7;
+      const int hy = px / HW_, hx = px - hy * HW_;
+      const int iy = p.oy0 + hy - P, ix = p.ox0 + hx - P;
+      raw_t r = {};
+      if (v < HH * HW_ * 8 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        r = *reinterpret_cast<const raw_t*>(img + ((int64_t)iy * W + ix) * ld_in + slot * 8);
+      hv[i] = r;
+    }
+  };
+  int t = blockIdx.x;
+  if (t >= total) return;
+  Pos cur = pos_of(t);
+  fetch(cur);
+  int cb_loaded = -1;
+  for (; t < total; t += gridDim.x) {
+    if (cur.cb != cb_loaded) {  // weights of this 64-channel block (the previous tile's reads ended at the loop's last barrier)
+      for (int i = threadIdx.x; i < KS * KS * CB; i += 256) sw[i] = w[(i / CB) * C + cur.cb * CB + (i % CB)];
+      if (threadIdx.x < CB) sw[KS * KS * CB + threadIdx.x] = bias ? bias[cur.cb * CB + threadIdx.x] : 0.f;
+      cb_loaded = cur.cb;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = threadIdx.x + 256 * i;
+      if (v < HH * HW_ * 8) *reinterpret_cast<raw_t*>(tile + (v >> 3) * PITCH + (v & 7) * 8) = hv[i];
+    }
+    __syncthreads();
+    const Pos me = cur;
+    if (t + (int)gridDim.x < total) {
+      cur = pos_of(t + gridDim.x);
+      fetch(cur);  // in flight during the arithmetic below
+    }
+    float acc[J][4][8];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[j][q][e] = sw[KS * KS * CB + cg * 8 + e];
+#pragma unroll 1  // a rolled loop: unrolled, the compiler hoists all k*k weight reads above it and spills them
+    for (int ky = 0; ky < KS; ++ky) {
+      float wr[KS][8];
+#pragma unroll
+      for (int kx = 0; kx < KS; ++kx) {
+        const float4 a = *reinterpret_cast<const float4*>(sw + (ky * KS + kx) * CB + cg * 8);
+        const float4 c = *reinterpret_cast<const float4*>(sw + (ky * KS + kx) * CB + cg * 8 + 4);
+        wr[kx][0] = a.x; wr[kx][1] = a.y; wr[kx][2] = a.z; wr[kx][3] = a.w;
+        wr[kx][4] = c.x; wr[kx][5] = c.y; wr[kx][6] = c.z; wr[kx][7] = c.w;
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int run = pt + 32 * j;
+        const int row = run >> 2, col0 = (run & 3) * 4;
+        const T* lp = tile + ((row + ky) * HW_ + col0) * PITCH + cg * 8;
+#pragma unroll
+        for (int x = 0; x < 4 + KS - 1; ++x) {
+          float xv[8];
+          Vec8<T>::load(lp + x * PITCH, xv);
+#pragma unroll
+          for (int kx = 0; kx < KS; ++kx) {
+            const int q = x - kx;
+            if (q >= 0 && q < 4) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[j][q][e] = fmaf(xv[e], wr[kx][e], acc[j][q][e]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int run = pt + 32 * j;
+      const int oy = me.oy0 + (run >> 2), oxb = me.ox0 + (run & 3) * 4;
+      if (oy < H) {
+        T* orow = out + ((int64_t)(me.b * H + oy) * W) * ld_out + me.cb * CB + cg * 8;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (oxb + q < W) {
+            act_apply_n<8>(acc[j][q], act);
+            Vec8<T>::store(orow + (int64_t)(oxb + q) * ld_out, acc[j][q]);
+          }
+        }
+      }
+    }
+    __syncthreads();  // everyone is done reading the tile (and the weights) before they are overwritten
+  }
+}
+
+// Depthwise k x k conv, stride 1, bf16, on the matrix cores.  v_mfma_f32_4x4x4_16b_bf16 multiplies 16 independent
+// 4x4x4 blocks per instruction (8 cycles): with block b = 4 consecutive channels, the first operand = diag(w[tap][4b..4b+3])
+// and the second = those 4 channels of 4 horizontally adjacent pixels, one instruction accumulates one tap for
+// 4 pixels x 64 channels -- 4x redundant multiplies instead of the 32x a 32x32 tile would waste, no bf16 -> f32
+// unpacking, and k*k instructions per 256 outputs where the VALU kernels above issue ~30 per output element (they are
+// VALU-issue-bound at ~2 TB/s).  The weights are rounded to bf16, as the reference's autocast does to its conv weights.
+//   workgroup  256 threads = 4 waves, 8J x 16 outputs x 64 channels; halo staged in LDS as in dwconv_tiled_kernel
+//   lane       (b = lane/4, p = lane%4): reads 8 bytes = channels 4b..4b+3 of pixel p of a run; its 4 accumulator
+//              registers are those 4 channels of that pixel, so the result packs into one 8-byte store
+//   LDS pitch  64 channels + 64 bytes: the 4 pixels x 8 blocks a 32-lane ds_read_b64 group touches tile the 256-byte
+//              bank row exactly
+template <int KS, int J>
+__global__ __launch_bounds__(256) void dwconv_mfma_kernel(const bf16_t* __restrict__ in, int ld_in, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, bf16_t* __restrict__ out, int ld_out,
+                                                         int H, int W, int C, int act, int tiles_x) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  constexpr int CB = 64, TW = 16, TH = 8 * J, HW_ = TW + KS - 1, HH = TH + KS - 1, P = KS / 2;
+  constexpr int PITCH = CB + 32;  // elements (192 bytes)
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  bf16_t* tile = reinterpret_cast<bf16_t*>(dsm);  // [HH*HW_][PITCH]
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int c0 = blockIdx.y * CB;
+  const int b = blockIdx.z;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const bf16_t* img = in + (int64_t)b * H * W * ld_in + c0;
+  for (int v = threadIdx.x; v < HH * HW_ * 8; v += 256) {
+    const int px = v >> 3, slot = v & 7;
+    const int hy = px / HW_, hx = px - hy * HW_;
+    const int iy = oy0 + hy - P, ix = ox0 + hx - P;
+    uint4 r = make_uint4(0u, 0u, 0u, 0u);
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+      r = *reinterpret_cast<const uint4*>(img + ((int64_t)iy * W + ix) * ld_in + slot * 8);
+    *reinterpret_cast<uint4*>(tile + px * PITCH + slot * 8) = r;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = lane >> 2, pi = lane & 3;
+  // diag(w[tap][c0 + 4 blk .. + 3]): this lane is row `pi` of its block, only element k = pi is non-zero
+  s16x4 wd[KS * KS];
+#pragma unroll
+  for (int t = 0; t < KS * KS; ++t) {
+    const short wb = (short)f32_to_bf16(w[t * C + c0 + 4 * blk + pi]);
+    wd[t] = s16x4{(short)(pi == 0 ? wb : 0), (short)(pi == 1 ? wb : 0), (short)(pi == 2 ? wb : 0), (short)(pi == 3 ? wb : 0)};
+  }
+  f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+    const float4 bb = *reinterpret_cast<const float4*>(bias + c0 + 4 * blk);
+    bs = f32x4{bb.x, bb.y, bb.z, bb.w};
+  }
+  __syncthreads();
+  constexpr int RPW = TH / 4;  // tile rows per wave
+  f32x4 acc[RPW][4];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[r][q] = bs;
+  const bf16_t* lbase = tile + (wave * RPW * HW_ + pi) * PITCH + blk * 4;
+#pragma unroll
+  for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+      for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const s16x4 xv = *reinterpret_cast<const s16x4*>(lbase + ((r + ky) * HW_ + q * 4 + kx) * PITCH);
+          acc[r][q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wd[ky * KS + kx], xv, acc[r][q], 0, 0, 0);
+        }
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const int oy = oy0 + wave * RPW + r;
+    if (oy >= H) continue;
+    bf16_t* orow = out + ((int64_t)(b * H + oy) * W) * ld_out + c0 + 4 * blk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ox = ox0 + q * 4 + pi;
+      if (ox < W) {
+        float v[4] = {acc[r][q][0], acc[r][q][1], acc[r][q][2], acc[r][q][3]};
+        act_apply_n<4>(v, act);
+        *reinterpret_cast<uint2*>(orow + (int64_t)ox * ld_out) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      }
+    }
+  }
+}
+
 // 3x3 depthwise conv, column-strip variant: a thread keeps the 9 x 8 weights of its channel group
 // in registers and walks R output rows downwards with a rotating 3-row register window, so every
 // input vector is loaded (R+2)/R times instead of 3 and the weights once per R*NP outputs.
@@ -1803,6 +2017,67 @@ int esam3_launch_dwconv(int dtype, const void* in, int ld_in, const float* w, co
                                          s, (const T*)in, ld_in, w, bias, (T*)out, ld_out, H, W, C, OH,  \
                                          OW, act, gx, gy, strips));                                 \
   } while (0)
+  static const int no_mfma = getenv("ESAM3_DW_NOMFMA") ? atoi(getenv("ESAM3_DW_NOMFMA")) : 0;  // dev A/B
+  if (dtype == 1 && stride == 1 && C % 64 == 0 && !no_mfma && (ld_in * 2) % 16 == 0 && (ld_out * 2) % 8 == 0 &&
+      !(((uintptr_t)in) & 15) && !(((uintptr_t)out) & 7) && (!bias || !(((uintptr_t)bias) & 15)) && H * W >= 256) {
+    static const int jm = getenv("ESAM3_DW_JM") ? atoi(getenv("ESAM3_DW_JM")) : 1;  // dev: 8 or 16 tile rows
+    const int J = jm == 2 ? 2 : 1;
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 8 * J - 1) / (8 * J);
+    const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)(C / 64), (unsigned)B);
+    const size_t lds = (size_t)(8 * J + ksize - 1) * (16 + ksize - 1) * 192;
+#define ESAM3_DWM(KS_, J_)                                                                                              \
+  do {                                                                                                                  \
+    auto kern = dwconv_mfma_kernel<KS_, J_>;                                                                            \
+    static bool attr = false;                                                                                           \
+    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)in, ld_in, w, bias, (bf16_t*)out, ld_out, H, W, C, act, tiles_x); \
+  } while (0)
+    if (ksize == 3) { if (J == 2) ESAM3_DWM(3, 2); else ESAM3_DWM(3, 1); }
+    else { if (J == 2) ESAM3_DWM(5, 2); else ESAM3_DWM(5, 1); }
+#undef ESAM3_DWM
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
+  static const int no_tiled = getenv("ESAM3_DW_NOTILED") ? atoi(getenv("ESAM3_DW_NOTILED")) : 0;  // dev A/B
+  const int esz_ = dtype == 0 ? 4 : 2;
+  if (stride == 1 && C % 64 == 0 && !no_tiled && (ld_in * esz_) % 16 == 0 && (ld_out * esz_) % 16 == 0 &&
+      !(((uintptr_t)in) & 15) && !(((uintptr_t)out) & 15) && H * W >= 256) {
+    static const int j3 = getenv("ESAM3_DW_J3") ? atoi(getenv("ESAM3_DW_J3")) : 2;  // dev: rows of 8 per tile, k = 3 / k = 5
+    static const int j5 = getenv("ESAM3_DW_J5") ? atoi(getenv("ESAM3_DW_J5")) : 2;
+    const int J = (ksize == 3 ? j3 : j5) == 1 ? 1 : 2;
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 8 * J - 1) / (8 * J);
+    const int64_t total = (int64_t)tiles_x * tiles_y * (C / 64) * B;
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      HIP_CHECK_RET(hipGetDevice(&dev));
+      HIP_CHECK_RET(hipGetDeviceProperties(&prop, dev));
+      n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const dim3 grid((unsigned)(total < 2 * (int64_t)n_cu ? total : 2 * (int64_t)n_cu));  // persistent, two workgroups per CU
+    const size_t pitch_b = 64 * (size_t)esz_ + 32;
+    const size_t lds = (size_t)(8 * J + ksize - 1) * (16 + ksize - 1) * pitch_b + sizeof(float) * (size_t)(ksize * ksize + 1) * 64;
+#define ESAM3_DWT(KS_, J_)                                                                                                   \
+  do {                                                                                                                   \
+    if (dtype == 0) {                                                                                                    \
+      auto kern = dwconv_tiled_kernel<float, KS_, J_>;                                                                    \
+      static bool attr_f = false;                                                                                        \
+      if (!attr_f) { HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_f = true; } \
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)in, ld_in, w, bias, (float*)out, ld_out, H, W, C, act, tiles_x, tiles_y, B); \
+    } else {                                                                                                             \
+      auto kern = dwconv_tiled_kernel<bf16_t, KS_, J_>;                                                                   \
+      static bool attr_b = false;                                                                                        \
+      if (!attr_b) { HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_b = true; } \
+      hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)in, ld_in, w, bias, (bf16_t*)out, ld_out, H, W, C, act, tiles_x, tiles_y, B); \
+    }                                                                                                                    \
+  } while (0)
+    if (ksize == 3) { if (J == 2) ESAM3_DWT(3, 2); else ESAM3_DWT(3, 1); }
+    else { if (J == 2) ESAM3_DWT(5, 2); else ESAM3_DWT(5, 1); }
+#undef ESAM3_DWT
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
   static const int no_strip = getenv("ESAM3_DW_NOSTRIP") ? atoi(getenv("ESAM3_DW_NOSTRIP")) : 0;
   if (ksize == 3 && stride == 1 && !no_strip) ESAM3_DW3(1, 2, 8);
   else if (ksize == 3 && !no_strip) ESAM3_DW3(2, 2, 4);

@@ -262,6 +262,8 @@ def test_conv_transpose(mode, B, H, W, Cin, Cout, act, res, after):
 @pytest.mark.parametrize("B,H,W,C,ks,stride,act", [
     (2, 17, 19, 64, 3, 1, "hswish"), (1, 18, 18, 128, 3, 2, "hswish"), (1, 15, 13, 16, 3, 2, None),
     (2, 11, 11, 384, 5, 1, None), (1, 63, 63, 256, 3, 2, "hswish"),
+    # LDS-tiled kernel (stride 1, C % 64 == 0, >= 256 pixels): ragged tiles in both directions, several channel blocks
+    (2, 63, 63, 384, 5, 1, None), (1, 32, 32, 1024, 3, 1, "hswish"), (3, 20, 17, 64, 3, 1, "hswish"), (1, 16, 16, 128, 5, 1, None),
 ])
 def test_dwconv(mode, B, H, W, C, ks, stride, act):
     d, tdt = U.DT[mode]
