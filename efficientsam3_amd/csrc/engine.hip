@@ -531,7 +531,9 @@ struct esam3_engine {
   int mbconv(const std::string& p, const T4& x, int stride, bool residual, T4* y, const T4* dst = nullptr);
   int evit_block(const std::string& p, const T4& x, T4* y);
   int backbone(const float* img, int B, const esam3_image_features* out, T4* feat);
+  int stem_weights(const std::string& wname, const std::string& bn, int cout, float** sw_out, float** sb_out);
   int stem(const std::string& wname, const std::string& bn, int cout, int act, const float* img, int B, T4* y);
+  int stem_dsconv_fused(const std::string& stem_w, const std::string& stem_bn, const std::string& ds, const float* img, int B, T4* y);
   int conv_bn(const std::string& p, const T4& x, int stride, int act, T4* y, const T4* res = nullptr, const T4* dst = nullptr,
               int res_after_act = 1);
   int squeeze_excite(const std::string& p, T4& x);
@@ -684,9 +686,8 @@ int E::tap(const esam3_image_features* out, int i, const T4& t) {
 }
 
 // 3x3 stride-2 pad-1 conv from the NCHW fp32 image (Cin = 3) + folded BN + activation -> NHWC
-int E::stem(const std::string& wname, const std::string& bn, int cout, int act, const float* img, int B, T4* y) {
-  *y = alloc4(B, IMG / 2, IMG / 2, cout);
-  if (!ok(y->p)) return -1;
+// stem conv weights [Cout][3][3][3] (+BN) -> fp32 [27][Cout] (k = tap*3 + c) and bias, cached on the device
+int E::stem_weights(const std::string& wname, const std::string& bn, int cout, float** sw_out, float** sb_out) {
   const std::string key = wname + "#stem_packed";
   float *sw = nullptr, *sb = nullptr;
   auto it = fbufs.find(key);
@@ -708,8 +709,39 @@ int E::stem(const std::string& wname, const std::string& bn, int cout, int act, 
     sb = fbufs[key + ".bias"];
   }
   if (!sw || !sb) return -1;
+  *sw_out = sw;
+  *sb_out = sb;
+  return 0;
+}
+
+int E::stem(const std::string& wname, const std::string& bn, int cout, int act, const float* img, int B, T4* y) {
+  *y = alloc4(B, IMG / 2, IMG / 2, cout);
+  if (!ok(y->p)) return -1;
+  float *sw = nullptr, *sb = nullptr;
+  CK(stem_weights(wname, bn, cout, &sw, &sb));
   if (!dry) CK(prof_launch("stem", 0.0, 0.0, [&]() { return esam3_launch_stem(dtype, img, sw, sb, y->p, B, IMG, IMG, cout, act, st); }));
   return 0;
+}
+
+// EfficientViT input stem with one Residual(DSConv) block and 16 channels (B1): stem conv + depthwise + pointwise +
+// identity in one kernel (backbone.py:48-70, ops.py:273-312).
+int E::stem_dsconv_fused(const std::string& stem_w, const std::string& stem_bn, const std::string& ds, const float* img, int B, T4* y) {
+  *y = alloc4(B, IMG / 2, IMG / 2, 16);
+  if (!ok(y->p)) return -1;
+  float *sw = nullptr, *sb = nullptr;
+  CK(stem_weights(stem_w, stem_bn, 16, &sw, &sb));
+  auto has = [&](const std::string& n) { return find(n) != nullptr; };
+  PackedDw* d = pk_dw(ds + "depth_conv.conv.weight", has(ds + "depth_conv.conv.bias") ? ds + "depth_conv.conv.bias" : "",
+                      has(ds + "depth_conv.norm.weight") ? ds + "depth_conv.norm" : "");
+  PackedGemm* g = pk_conv(ds + "point_conv.conv.weight", has(ds + "point_conv.conv.bias") ? ds + "point_conv.conv.bias" : "",
+                          has(ds + "point_conv.norm.weight") ? ds + "point_conv.norm" : "");
+  if (!d || !g) return -1;
+  if (d->C != 16 || d->ks != 3 || g->N != 16 || g->cin != 16 || g->ksize != 1) { esam3_set_error("stem_dsconv_fused: unexpected shapes"); return -1; }
+  if (dry) return 0;
+  const double px = (double)B * (IMG / 2) * (IMG / 2);
+  return prof_launch("stem+dsconv", 2.0 * px * 16 * (27 + 9 + 16), (double)B * 3 * IMG * IMG * 4 + px * 16 * esz, [&]() {
+    return esam3_launch_stem_dsconv(dtype, img, sw, sb, d->w, d->bias, g->w, g->Kp, g->bias, y->p, B, IMG, IMG, st);
+  });
 }
 
 // Conv2d_BN (repvit.py:29-37, tiny_vit.py:38-64): bias-free 1x1 / 3x3 conv `<p>.c` + BatchNorm `<p>.bn`
@@ -1046,8 +1078,15 @@ int E::backbone(const float* img, int B, const esam3_image_features* out, T4* fe
   auto tap = [&](int i, const T4& t) -> int { return this->tap(out, i, t); };
   // E0 stem: 3x3 s2 conv + BN + Hardswish, straight from the NCHW fp32 input
   T4 x;
-  CK(stem(EVBB + "input_stem.op_list.0.conv.weight", EVBB + "input_stem.op_list.0.norm", widths[0], ACT_HSWISH, img, B, &x));
-  for (int i = 0; i < depths[0]; ++i) {  // Residual(DSConv)  ops.py:273-312
+  static const bool no_fused_stem = getenv("ESAM3_NO_FUSED_STEM") != nullptr && atoi(getenv("ESAM3_NO_FUSED_STEM")) != 0;  // A/B timing
+  const bool fused_stem = widths[0] == 16 && depths[0] == 1 && !no_fused_stem;
+  if (fused_stem) {
+    CK(stem_dsconv_fused(EVBB + "input_stem.op_list.0.conv.weight", EVBB + "input_stem.op_list.0.norm",
+                         EVBB + "input_stem.op_list.1.main.", img, B, &x));
+  } else {
+    CK(stem(EVBB + "input_stem.op_list.0.conv.weight", EVBB + "input_stem.op_list.0.norm", widths[0], ACT_HSWISH, img, B, &x));
+  }
+  for (int i = 0; i < (fused_stem ? 0 : depths[0]); ++i) {  // Residual(DSConv)  ops.py:273-312
     const std::string p = EVBB + "input_stem.op_list." + std::to_string(i + 1) + ".main.";
     T4 y = alloc4(x.B, x.H, x.W, x.C);
     if (!ok(y.p)) return -1;

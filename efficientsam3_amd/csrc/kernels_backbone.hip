@@ -72,6 +72,283 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
 }
 
 // ------------------------------------------------------------------------------------
+// EfficientViT input stem in ONE kernel (efficientvit/backbone.py:48-70): ConvLayer 3 -> 16, 3x3 stride 2, BN, Hardswish,
+// then ResidualBlock(DSConv 16 -> 16: depthwise 3x3 + BN + Hardswish, pointwise 1x1 + BN) + identity.
+// Three launches (stem, depthwise, pointwise) moved the 504^2 x 16-channel tensor through HBM five times (0.88 ms of the
+// B = 32 step); here a workgroup keeps an 18 x 18 halo of the stem output of its 16 x 16 pixels in LDS, so the image is
+// read once and only the block's output is written.  Every intermediate is rounded to the activation dtype where the
+// separate kernels stored it, so the fused path rounds exactly where the unfused one did.
+// ------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stem_dsconv_kernel(const float* __restrict__ img, const float* __restrict__ w0,
+                                                         const float* __restrict__ b0, const float* __restrict__ wd,
+                                                         const float* __restrict__ bd, const T* __restrict__ wp, int ldw,
+                                                         const float* __restrict__ bp, T* __restrict__ out, int H, int W, int OH,
+                                                         int OW, int tiles_x) {
+  constexpr int C = 16, TS = 16, HS = TS + 2, IR = 2 * HS + 1, IP = 40;  // 37 input rows / columns per halo, row pitch 40
+  __shared__ __attribute__((aligned(16))) float simg[3 * IR * IP];
+  __shared__ __attribute__((aligned(16))) float sstem[HS * HS * C];
+  __shared__ __attribute__((aligned(16))) float smid[TS * TS * C];
+  __shared__ __attribute__((aligned(16))) float sw0[27 * C];
+  __shared__ __attribute__((aligned(16))) float sb0[C];
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int b = blockIdx.y;
+  const int oy0 = ty * TS, ox0 = tx * TS;
+  const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;  // input pixel of simg[.][0][0]
+  for (int i = threadIdx.x; i < 27 * C; i += 256) sw0[i] = w0[i];
+  if (threadIdx.x < C) sb0[threadIdx.x] = b0 ? b0[threadIdx.x] : 0.f;
+  for (int i = threadIdx.x; i < 3 * IR * IR; i += 256) {
+    const int c = i / (IR * IR), r = i - c * IR * IR;
+    const int y = r / IR, x = r - y * IR;
+    const int iy = iy0 + y, ix = ix0 + x;
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = img[((int64_t)(b * 3 + c) * H + iy) * W + ix];
+    simg[(c * IR + y) * IP + x] = v;
+  }
+  const int q4 = (threadIdx.x & 3) * 4;  // this thread's 4 channels in every phase
+  float wdr[9][4], bdr[4], wpr[4][C], bpr[4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wdr[t][e] = wd[t * C + q4 + e];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    bdr[e] = bd ? bd[q4 + e] : 0.f;
+    bpr[e] = bp ? bp[q4 + e] : 0.f;
+#pragma unroll
+    for (int ci = 0; ci < C; ++ci) wpr[e][ci] = to_f32<T>(wp[(int64_t)(q4 + e) * ldw + ci]);
+  }
+  __syncthreads();
+  // ---- phase 1: stem conv on the 18 x 18 halo; item = (2 horizontally adjacent pixels, 4 channels) -------------------
+  for (int id = threadIdx.x; id < HS * (HS / 2) * 4; id += 256) {
+    const int pair = id >> 2;
+    const int hy = pair / (HS / 2), hx = (pair - hy * (HS / 2)) * 2;
+    float acc[2][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[0][e] = acc[1][e] = sb0[q4 + e];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const float* row = simg + (c * IR + 2 * hy + kh) * IP + 2 * hx;
+        float xin[5];
+#pragma unroll
+        for (int x = 0; x < 5; ++x) xin[x] = row[x];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float4 wv = *reinterpret_cast<const float4*>(sw0 + ((kh * 3 + kw) * 3 + c) * C + q4);
+          const float wk[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[0][e] = fmaf(xin[kw], wk[e], acc[0][e]);
+            acc[1][e] = fmaf(xin[kw + 2], wk[e], acc[1][e]);
+          }
+        }
+      }
+    const int sy = oy0 - 1 + hy;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int sx = ox0 - 1 + hx + u;
+      act_apply_n<4>(acc[u], ACT_HSWISH);
+      const bool inside = (unsigned)sy < (unsigned)OH && (unsigned)sx < (unsigned)OW;  // outside = the depthwise conv's zero padding
+      float4 o;
+      o.x = inside ? to_f32<T>(from_f32<T>(acc[u][0])) : 0.f;
+      o.y = inside ? to_f32<T>(from_f32<T>(acc[u][1])) : 0.f;
+      o.z = inside ? to_f32<T>(from_f32<T>(acc[u][2])) : 0.f;
+      o.w = inside ? to_f32<T>(from_f32<T>(acc[u][3])) : 0.f;
+      *reinterpret_cast<float4*>(sstem + (hy * HS + hx + u) * C + q4) = o;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: depthwise 3x3 + Hardswish; item = (pixel, 4 channels) -----------------------------------------------------
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int pix = (threadIdx.x >> 2) + 64 * r;
+    const int py = pix >> 4, px = pix & 15;
+    float acc[4] = {bdr[0], bdr[1], bdr[2], bdr[3]};
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float4 xv = *reinterpret_cast<const float4*>(sstem + ((py + kh) * HS + px + kw) * C + q4);
+        acc[0] = fmaf(xv.x, wdr[kh * 3 + kw][0], acc[0]);
+        acc[1] = fmaf(xv.y, wdr[kh * 3 + kw][1], acc[1]);
+        acc[2] = fmaf(xv.z, wdr[kh * 3 + kw][2], acc[2]);
+        acc[3] = fmaf(xv.w, wdr[kh * 3 + kw][3], acc[3]);
+      }
+    act_apply_n<4>(acc, ACT_HSWISH);
+    *reinterpret_cast<float4*>(smid + pix * C + q4) = make_float4(to_f32<T>(from_f32<T>(acc[0])), to_f32<T>(from_f32<T>(acc[1])),
+                                                                 to_f32<T>(from_f32<T>(acc[2])), to_f32<T>(from_f32<T>(acc[3])));
+  }
+  __syncthreads();
+  // ---- phase 3: pointwise 16 -> 16 + identity; item = (pixel, 4 output channels) -------------------------------------------
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int pix = (threadIdx.x >> 2) + 64 * r;
+    const int py = pix >> 4, px = pix & 15;
+    const int oy = oy0 + py, ox = ox0 + px;
+    float acc[4] = {bpr[0], bpr[1], bpr[2], bpr[3]};
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const float4 m = *reinterpret_cast<const float4*>(smid + pix * C + 4 * c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[e] = fmaf(m.x, wpr[e][4 * c4], acc[e]);
+        acc[e] = fmaf(m.y, wpr[e][4 * c4 + 1], acc[e]);
+        acc[e] = fmaf(m.z, wpr[e][4 * c4 + 2], acc[e]);
+        acc[e] = fmaf(m.w, wpr[e][4 * c4 + 3], acc[e]);
+      }
+    }
+    const float4 idn = *reinterpret_cast<const float4*>(sstem + ((py + 1) * HS + px + 1) * C + q4);
+    acc[0] += idn.x; acc[1] += idn.y; acc[2] += idn.z; acc[3] += idn.w;
+    if (oy < OH && ox < OW) {
+      T* op = out + (((int64_t)b * OH + oy) * OW + ox) * C + q4;
+      if constexpr (sizeof(T) == 2) {
+        *reinterpret_cast<uint2*>(op) = make_uint2(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]));
+      } else {
+        *reinterpret_cast<float4*>(op) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      }
+    }
+  }
+}
+
+// bf16 variant of the fused input stem on the matrix cores.  The VALU kernel above issues ~1900 instructions per
+// thread and tile (0.92 ms at B = 32: instruction-issue bound); here
+//   phase 1  stem conv      = 16 channels x (27 -> 32 patch values) x 16 pixels per v_mfma_f32_16x16x32_bf16,
+//   phase 2  depthwise 3x3  = diag(w) blocks on v_mfma_f32_4x4x4_16b_bf16 (see dwconv_mfma_kernel),
+//   phase 3  pointwise      = 16 x 16 x 16 pixels per v_mfma_f32_16x16x16_bf16,
+// and every phase leaves a lane with 4 consecutive channels of one pixel (one 8-byte LDS / global store).  The image is
+// rounded to bf16 when it is staged, as the reference's autocast does to the conv input.
+__global__ __launch_bounds__(256) void stem_dsconv_mfma_kernel(const float* __restrict__ img, const float* __restrict__ w0,
+                                                              const float* __restrict__ b0, const float* __restrict__ wd,
+                                                              const float* __restrict__ bd, const bf16_t* __restrict__ wp, int ldw,
+                                                              const float* __restrict__ bp, bf16_t* __restrict__ out, int H, int W,
+                                                              int OH, int OW, int tiles_x) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  constexpr int C = 16, TS = 16, HS = TS + 2, IR = 2 * HS + 1, IP = 40;  // 37 input rows / columns per halo, row pitch 40
+  __shared__ __attribute__((aligned(16))) bf16_t simg[3 * IR * IP];
+  __shared__ __attribute__((aligned(16))) bf16_t sstem[HS * HS * C];
+  __shared__ __attribute__((aligned(16))) bf16_t smid[TS * TS * C];
+  struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int b = blockIdx.y;
+  const int oy0 = ty * TS, ox0 = tx * TS;
+  const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;  // input pixel of simg[.][0][0]
+  // ---- phase 0: image halo -> LDS as bf16; item = (plane, row, 4 columns) --------------------------------------------
+  for (int i = threadIdx.x; i < 3 * IR * (IP / 4); i += 256) {
+    const int cy = i / (IP / 4), xg = i - cy * (IP / 4);
+    const int c = cy / IR, y = cy - c * IR;
+    const int iy = iy0 + y, ix = ix0 + 4 * xg;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)H) {
+      const float* rp = img + ((int64_t)(b * 3 + c) * H + iy) * W;
+      if (ix >= 0 && ix + 3 < W) {
+        const F4 f = *reinterpret_cast<const F4*>(rp + ix);
+        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if ((unsigned)(ix + e) < (unsigned)W) v[e] = rp[ix + e];
+      }
+    }
+    *reinterpret_cast<uint2*>(simg + cy * IP + 4 * xg) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  // phase-1 constants: patch offsets of this lane's 8 k values (k = tap*3 + c, 27 valid), weights A[co = l15][k]
+  int poff[8];
+  uint32_t pmask[4], wa[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    uint32_t m = 0u, wv = 0u;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = 2 * h + u, k = 8 * kg + e;
+      const bool valid = k < 27;
+      const int tap = valid ? k / 3 : 0, c = valid ? k - tap * 3 : 0;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      poff[e] = (c * IR + kh) * IP + kw;
+      if (valid) {
+        m |= 0xffffu << (16 * u);
+        wv |= (uint32_t)f32_to_bf16(w0[k * C + l15]) << (16 * u);
+      }
+    }
+    pmask[h] = m;
+    wa[h] = wv;
+  }
+  f32x4_v bias1, bias2, bias3;
+  s16x4 wdg[9];
+  const int cgp = (lane >> 2) & 3, pi = lane & 3;  // phase 2: channel group of the lane's block, row / pixel within the block
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    bias1[v] = b0 ? b0[4 * kg + v] : 0.f;
+    bias2[v] = bd ? bd[4 * cgp + v] : 0.f;
+    bias3[v] = bp ? bp[4 * kg + v] : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const short wb = (short)f32_to_bf16(wd[t * C + 4 * cgp + pi]);
+    wdg[t] = s16x4{(short)(pi == 0 ? wb : 0), (short)(pi == 1 ? wb : 0), (short)(pi == 2 ? wb : 0), (short)(pi == 3 ? wb : 0)};
+  }
+  const s16x4 wpa = *reinterpret_cast<const s16x4*>(wp + (int64_t)l15 * ldw + 4 * kg);  // A[co = l15][ci = 4 kg ..]
+  __syncthreads();
+  // ---- phase 1: stem conv over the 324 halo pixels, 16 per MFMA ---------------------------------------------------------
+  for (int grp = wave; grp < (HS * HS + 15) / 16; grp += 4) {
+    const int hp_raw = 16 * grp + l15;
+    const int hp = hp_raw < HS * HS ? hp_raw : HS * HS - 1;
+    const int hy = hp / HS, hx = hp - hy * HS;
+    const bf16_t* pb = simg + (2 * hy) * IP + 2 * hx;
+    uint32_t xb[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+      xb[h] = ((uint32_t)pb[poff[2 * h]] | ((uint32_t)pb[poff[2 * h + 1]] << 16)) & pmask[h];
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t av = {wa[0], wa[1], wa[2], wa[3]}, bv = {xb[0], xb[1], xb[2], xb[3]};
+    f32x4_v acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_v, av), __builtin_bit_cast(bf16x8_v, bv), bias1, 0, 0, 0);
+    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+    act_apply_n<4>(v, ACT_HSWISH);
+    const int sy = oy0 - 1 + hy, sx = ox0 - 1 + hx;
+    const bool inside = (unsigned)sy < (unsigned)OH && (unsigned)sx < (unsigned)OW;  // outside = the depthwise conv's zero padding
+    const uint2 o = inside ? make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])) : make_uint2(0u, 0u);
+    if (hp_raw < HS * HS) *reinterpret_cast<uint2*>(sstem + hp * C + 4 * kg) = o;
+  }
+  __syncthreads();
+  // ---- phase 2: depthwise 3x3 + Hardswish; one MFMA = one tap of 16 pixels (a tile row) x 16 channels ---------------------
+  {
+    const int px = 4 * (lane >> 4) + pi;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int py = 4 * wave + r;
+      f32x4_v acc = bias2;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const s16x4 xv = *reinterpret_cast<const s16x4*>(sstem + ((py + kh) * HS + px + kw) * C + 4 * cgp);
+          acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wdg[kh * 3 + kw], xv, acc, 0, 0, 0);
+        }
+      float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+      act_apply_n<4>(v, ACT_HSWISH);
+      *reinterpret_cast<uint2*>(smid + (py * TS + px) * C + 4 * cgp) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    }
+  }
+  __syncthreads();
+  // ---- phase 3: pointwise 16 -> 16 + identity; one MFMA = a tile row of 16 pixels ---------------------------------------------
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int py = 4 * wave + r;
+    const s16x4 mv = *reinterpret_cast<const s16x4*>(smid + (py * TS + l15) * C + 4 * kg);
+    f32x4_v acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wpa, mv, bias3, 0, 0, 0);
+    const uint2 idn = *reinterpret_cast<const uint2*>(sstem + ((py + 1) * HS + l15 + 1) * C + 4 * kg);
+    const float o0 = acc[0] + __uint_as_float(idn.x << 16), o1 = acc[1] + __uint_as_float(idn.x & 0xffff0000u);
+    const float o2 = acc[2] + __uint_as_float(idn.y << 16), o3 = acc[3] + __uint_as_float(idn.y & 0xffff0000u);
+    const int oy = oy0 + py, ox = ox0 + l15;
+    if (oy < OH && ox < OW)
+      *reinterpret_cast<uint2*>(out + (((int64_t)b * OH + oy) * OW + ox) * C + 4 * kg) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // depthwise k x k conv (k = 3 or 5), stride 1 or 2, pad k/2, + bias + activation
 // (DSConv / MBConv depth_conv, ops.py:290-299,344-353; LiteMLA aggreg.0.0, ops.py:560-567).
 // thread = (output pixel, 8-channel group); channel groups are the fastest index.
@@ -317,6 +594,10 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(const bf16_t* __restri
     bs = f32x4{bb.x, bb.y, bb.z, bb.w};
   }
   __syncthreads();
+#ifdef ESAM3_DW_DEV
+  const int dev = act >> 8;  // 1: no arithmetic, 2: no stores
+  act &= 255;
+#endif
   constexpr int RPW = TH / 4;  // tile rows per wave
   f32x4 acc[RPW][4];
 #pragma unroll
@@ -324,6 +605,9 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(const bf16_t* __restri
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[r][q] = bs;
   const bf16_t* lbase = tile + (wave * RPW * HW_ + pi) * PITCH + blk * 4;
+#ifdef ESAM3_DW_DEV
+  if (!(dev & 1))
+#endif
 #pragma unroll
   for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
@@ -339,6 +623,9 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(const bf16_t* __restri
   for (int r = 0; r < RPW; ++r) {
     const int oy = oy0 + wave * RPW + r;
     if (oy >= H) continue;
+#ifdef ESAM3_DW_DEV
+    if ((dev & 2) && acc[r][0][0] != 12345.f) continue;
+#endif
     bf16_t* orow = out + ((int64_t)(b * H + oy) * W) * ld_out + c0 + 4 * blk;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1988,6 +2275,24 @@ int esam3_launch_stem(int dtype, const float* img, const float* w, const float* 
   const unsigned gx = blocks_for((int64_t)OW * (Cout / VEC), 256), gy = (unsigned)(B * OH);
   DISPATCH_T(dtype, hipLaunchKernelGGL(stem_kernel<T>, dim3(gx * gy), dim3(256), 0, s, img, w, bias, (T*)out, B,
                                        H, W, Cout, act, gx, gy));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_stem_dsconv(int dtype, const float* img, const float* w0, const float* b0, const float* wd, const float* bd,
+                             const void* wp, int ldw, const float* bp, void* out, int B, int H, int W, hipStream_t s) {
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const int tiles_x = (OW + 15) / 16, tiles_y = (OH + 15) / 16;
+  const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)B);
+  static const bool valu = getenv("ESAM3_STEM_VALU") != nullptr && atoi(getenv("ESAM3_STEM_VALU")) != 0;  // A/B timing
+  if (dtype == 1 && !valu && ldw % 4 == 0 && !(((uintptr_t)wp) & 7)) {
+    hipLaunchKernelGGL(stem_dsconv_mfma_kernel, grid, dim3(256), 0, s, img, w0, b0, wd, bd, (const bf16_t*)wp, ldw, bp, (bf16_t*)out,
+                       H, W, OH, OW, tiles_x);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
+  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_dsconv_kernel<T>, grid, dim3(256), 0, s, img, w0, b0, wd, bd, (const T*)wp, ldw, bp,
+                                       (T*)out, H, W, OH, OW, tiles_x));
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

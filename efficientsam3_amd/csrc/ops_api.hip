@@ -430,6 +430,40 @@ extern "C" int esam3_bench_gemm(int dtype, int B, int H, int W, int Cin, int N, 
 }
 
 
+// Development aid (tools/bench_dw.py): average time of one depthwise-conv launch on device-resident data.
+extern "C" int esam3_bench_dwconv(int dtype, int B, int H, int W, int C, int ks, int stride, int act, int iters, float* avg_ms) {
+  Tmp t;
+  const int esz = dtype == 0 ? 4 : 2;
+  const int OH = (H + stride - 1) / stride, OW = (W + stride - 1) / stride;
+  const size_t n_in = (size_t)B * H * W * C, n_out = (size_t)B * OH * OW * C;
+  std::vector<float> hw((size_t)ks * ks * C, 0.05f), hb((size_t)C, 0.01f), ha(1 << 20);
+  uint32_t s = 777u;
+  for (auto& v : ha) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 32768.0f - 1.0f; }
+  float* w = (float*)t.up(hw.data(), hw.size() * 4);
+  float* b = (float*)t.up(hb.data(), hb.size() * 4);
+  void* a = t.raw(n_in * esz);
+  void* o = t.raw(n_out * esz);
+  void* chunk = t.upT(dtype, ha);
+  if (!w || !b || !a || !o || !chunk) return fail("bench_dwconv");
+  for (size_t off = 0; off < n_in; off += ha.size()) {
+    const size_t n = std::min(ha.size(), n_in - off);
+    (void)hipMemcpy((char*)a + off * esz, chunk, n * esz, hipMemcpyDeviceToDevice);
+  }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) if (esam3_launch_dwconv(dtype, a, C, w, b, o, C, B, H, W, C, ks, stride, act, nullptr)) return -1;
+  (void)hipEventRecord(e0, nullptr);
+  for (int i = 0; i < iters; ++i) if (esam3_launch_dwconv(dtype, a, C, w, b, o, C, B, H, W, C, ks, stride, act, nullptr)) return -1;
+  (void)hipEventRecord(e1, nullptr);
+  HIP_CHECK_RET(hipDeviceSynchronize());
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *avg_ms = ms / iters;
+  return 0;
+}
+
+
 // ---- COCO run-length encoding (eval writers: eval_efficientsam3_all_subsets.py:124-135, masks_ops.py:161-230) ----
 int esam3_rle_encode(const uint8_t* masks_dev, int n, int H, int W, uint32_t* counts_dev, int64_t capacity,
                      int32_t* offsets_dev, void* scratch_dev, int64_t scratch_bytes, void* stream) {
