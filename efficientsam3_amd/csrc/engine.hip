@@ -2021,7 +2021,10 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
   T4 u1, u2;
   CK(convT(MD + "output_upscaling.0", src, ACT_NONE, &u1, pr->sam2_fpn_dev[1], 64, 1, pr->prompt_image_dev));
   CK(layernorm(MD + "output_upscaling.1", u1.p, u1.p, u1.rows(), u1.C, 1e-6f, ACT_GELU));
-  CK(convT(MD + "output_upscaling.3", u1, ACT_GELU, &u2, pr->sam2_fpn_dev[0], 32, 0, pr->prompt_image_dev));
+  // bf16: output_upscaling.3 + GELU + the hypernetwork product run as one kernel below (the 288^2 x 32 tensor is never stored)
+  static const bool no_fused_up = getenv("ESAM3_NO_FUSED_UPSCALE") != nullptr && atoi(getenv("ESAM3_NO_FUSED_UPSCALE")) != 0;  // A/B timing
+  const bool fused_up = dtype == 1 && !no_fused_up;
+  if (!fused_up) CK(convT(MD + "output_upscaling.3", u1, ACT_GELU, &u2, pr->sam2_fpn_dev[0], 32, 0, pr->prompt_image_dev));
 
   // ---- hypernetwork MLPs, IoU head, object-score head (mask_decoder.py:224-242) ------------
   void* hyper = allocb((size_t)Bp * 4 * 32 * esz);
@@ -2054,8 +2057,19 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
     CK(linear(hp + "2", h2, DM, Bp, obj, 8, ACT_NONE));
   }
   const int64_t P4 = 16 * P;  // 288 * 288
+  PackedGemm* gu = nullptr;  // packed in the dry pass too: weight uploads must not happen while a graph is being captured
+  if (fused_up && !(gu = pk_convT(MD + "output_upscaling.3.weight", MD + "output_upscaling.3.bias"))) return -1;
   if (!dry) {
-    CK(esam3_launch_mask_product(dtype, hyper, 32, u2.p, all_masks, Bp, P4, 32, st));
+    if (fused_up) {
+      if (gu->N != 128 || gu->K != 64 || gu->convt_cout != 32) { esam3_set_error("output_upscaling.3: unexpected shape"); return -1; }
+      const double px = (double)Bp * 4 * P;  // pixels of the 144^2 map
+      CK(prof_launch("upscale+mask", 2.0 * px * 128 * 64 + 2.0 * px * 4 * 32 * 4, (px * 64 + px * 4 * 32) * esz + px * 16 * 4.0, [&]() {
+        return esam3_launch_upscale_mask(u1.p, gu->w, gu->Kp, gu->bias, pr->sam2_fpn_dev[0], pr->prompt_image_dev, hyper, 32,
+                                         all_masks, Bp, 2 * EMB, st);
+      }));
+    } else {
+      CK(esam3_launch_mask_product(dtype, hyper, 32, u2.p, all_masks, Bp, P4, 32, st));
+    }
     CK(esam3_launch_select_masks(dtype, all_masks, iou4, 8, out->low_res_dev, out->iou_dev, counters, Bp, P4,
                                  pr->multimask_output, 0.05f, 0.98f, st));
     if (out->obj_score_dev) CK(esam3_launch_strided_to_f32(dtype, obj, 8, out->obj_score_dev, Bp, st));

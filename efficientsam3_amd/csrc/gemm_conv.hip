@@ -831,7 +831,8 @@ template <typename T>
 int launch_gemm_t(const GemmParams& p, hipStream_t stream) {
   constexpr bool bf = sizeof(T) == 2;
   // few rows: a few hundred token rows, or too few 256 x 256 tiles to occupy the chip
-  if (use_skinny<T>(p) && (p.M <= 512 || ((p.M + 255) / 256) * ((p.N + 255) / 256) < 32)) {
+  static const bool no_skinny = getenv("ESAM3_NO_SKINNY") != nullptr && atoi(getenv("ESAM3_NO_SKINNY")) != 0;  // A/B, bisecting
+  if (!no_skinny && use_skinny<T>(p) && (p.M <= 512 || ((p.M + 255) / 256) * ((p.N + 255) / 256) < 32)) {
     g_last_kernel = bf ? "skinny_gemm_kernel<bf16> (32x32 block, K split over 4 waves, loads straight to registers)" : "skinny_gemm_kernel<f32>";
     return launch_skinny<T>(p, stream);
   }

@@ -91,6 +91,10 @@ int esam3_launch_bsc_to_sbc_f32(int dtype, const void* x, float* out, int B, int
 // w = {conv0.w, conv0.b, ln1.w, ln1.b, conv3.w, conv3.b, ln4.w, ln4.b, conv6.w, conv6.b} (device fp32)
 int esam3_launch_mask_embed(int dtype, const float* mask, const float* const* w, void* out, int Bp, int in_size,
                             int emb_size, hipStream_t s);
+// bf16: ConvTranspose2d(64 -> 32, k2 s2) of u1 [Bp][S*S][64] (weights wt [>=128][kp], n = tap*32 + co) + bias + feat
+// [B][4*S*S][32] gathered by img_of[bp], GELU, product with hyper [Bp][4][ld_h] -> masks [Bp][4][4*S*S] fp32
+int esam3_launch_upscale_mask(const void* u1, const void* wt, int kp, const float* bias, const void* feat, const int* img_of,
+                              const void* hyper, int ld_h, float* masks, int Bp, int S, hipStream_t s);
 int esam3_launch_mask_product(int dtype, const void* hyper, int ld_h, const void* up, float* masks,
                               int Bp, int64_t P, int C, hipStream_t s);
 

@@ -2627,7 +2627,8 @@ int esam3_launch_layernorm(int dtype, const void* x, const void* res, const floa
                            hipStream_t s) {
   const int esz = dtype == 0 ? 4 : 2;
   const bool aligned = !(((uintptr_t)x) & 15) && !(((uintptr_t)out) & 15) && !(res && (((uintptr_t)res) & 15)) && (C * esz) % 16 == 0;
-  if (C % 8 == 0 && C <= 2048 && aligned && rows > 0) {
+  static const int no_vec = getenv("ESAM3_NO_LNVEC") ? atoi(getenv("ESAM3_NO_LNVEC")) : 0;  // A/B, bisecting: 1 all, else that C
+  if (C % 8 == 0 && C <= 2048 && aligned && rows > 0 && !((no_vec == 1 || no_vec == C || (no_vec < 0 && rows == -no_vec)) && C <= 1024)) {
     const int nchunk = C / 8;
     int lpr = 1;
     while (lpr < nchunk && lpr < 64) lpr <<= 1;

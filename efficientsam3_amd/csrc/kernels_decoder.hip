@@ -1,5 +1,6 @@
 // Prompt-encoder / two-way mask-decoder / post-processing kernels
 // (sam/prompt_encoder.py, sam/transformer.py, sam/mask_decoder.py, model/utils/sam1_utils.py).
+#include "gemm_common.h"
 #include "kernels.h"
 
 namespace {
@@ -441,6 +442,99 @@ __global__ __launch_bounds__(256) void mask_embed_kernel(const float* __restrict
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc = fmaf(w[k], h[j][k], acc);
     out[(bp * P + p0 + j) * 256 + c] = from_f32<T>(acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Mask head tail in one kernel (mask_decoder.py:213-231): output_upscaling.3 = ConvTranspose2d(64 -> 32, k2 s2) of the
+// 144^2 map + the 288^2 high-res feature (feat_s0), GELU, then masks[bp][k] = sum_c hyper[bp][k][c] * up[bp][c].
+// The 288^2 x 32-channel tensor (170 MB at 32 prompts) is never written: a wave takes 32 consecutive pixels of the 144^2
+// map, runs the four taps as 32 x 32 x 64 MFMA products, adds bias + feat_s0, applies GELU and dots its 16 channels per
+// tap with the four hypernetwork vectors in registers; the two half-waves (channel halves) are summed by a lane swap.
+// bf16 only (the f32 mode keeps the separate kernels).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upscale_mask_kernel(const bf16_t* __restrict__ u1, const bf16_t* __restrict__ wt, int kp,
+                                                          const float* __restrict__ bias, const bf16_t* __restrict__ feat,
+                                                          const int* __restrict__ img_of, const bf16_t* __restrict__ hyper, int ld_h,
+                                                          float* __restrict__ masks, int S /*144*/, int frags_per_wave) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, g = lane >> 5;
+  const int bp = blockIdx.y;
+  const int P = S * S, OS = 2 * S;
+  const int64_t P4 = (int64_t)OS * OS;
+  const int img = img_of ? img_of[bp] : bp;
+  // weights: tap j = rows j*32 .. j*32+31 of wt [128][kp]; this lane's fragment rows are channel l31
+  u32x4 fw[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      fw[j][ks] = *reinterpret_cast<const u32x4*>(wt + (int64_t)(j * 32 + l31) * kp + (2 * ks + g) * 8);
+  // this lane's 16 channels are 8q + 4g + e: bias and the four hypernetwork vectors at those channels
+  float bs[16], hw[4][16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 8 * q + 4 * g + e;
+      bs[4 * q + e] = bias ? bias[c] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hw[k][4 * q + e] = to_f32<bf16_t>(hyper[((int64_t)bp * 4 + k) * ld_h + c]);
+    }
+  const bf16_t* ub = u1 + (int64_t)bp * P * 64;
+  const bf16_t* fb = feat + (int64_t)img * P4 * 32;
+  float* mb = masks + (int64_t)bp * 4 * P4;
+  const int frag0 = (blockIdx.x * 4 + wave) * frags_per_wave;
+  for (int f = 0; f < frags_per_wave; ++f) {
+    const int pix0 = (frag0 + f) * 32;
+    if (pix0 >= P) break;  // wave-uniform
+    int pix = pix0 + l31;
+    const bool pok = pix < P;
+    if (!pok) pix = P - 1;
+    const int y = pix / S, x = pix - y * S;
+    u32x4 fa[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fa[ks] = *reinterpret_cast<const u32x4*>(ub + (int64_t)pix * 64 + (2 * ks + g) * 8);
+    float part[4][4];  // [tap][mask]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x16_v acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) MmaOps<bf16_t>::mma(fw[j][ks], fa[ks], acc);
+      const int oy = 2 * y + (j >> 1), ox = 2 * x + (j & 1);
+      const bf16_t* rp = fb + ((int64_t)oy * OS + ox) * 32 + 4 * g;
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint2 u = *reinterpret_cast<const uint2*>(rp + 8 * q);
+        const float r[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                            __uint_as_float(u.y & 0xffff0000u)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // the separate kernels stored this value in bf16 before the product read it back
+          const float v = to_f32<bf16_t>(from_f32<bf16_t>(gelu_fast(acc[4 * q + e] + bs[4 * q + e] + r[e])));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) s4[k] = fmaf(v, hw[k][4 * q + e], s4[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) part[j][k] = s4[k];
+    }
+    // sum the two channel halves: after the swap a lane holds (its own value of one tap row, the other half's value of it)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // taps 0,1 (output row 2y) end up complete in lanes 0-31, taps 2,3 (row 2y+1) in lanes 32-63
+      float keep0 = g == 0 ? part[0][k] : part[2][k], keep1 = g == 0 ? part[1][k] : part[3][k];
+      const float give0 = g == 0 ? part[2][k] : part[0][k], give1 = g == 0 ? part[3][k] : part[1][k];
+      keep0 += __shfl_xor(give0, 32);
+      keep1 += __shfl_xor(give1, 32);
+      if (pok) {
+        float* mp = mb + (int64_t)k * P4 + (int64_t)(2 * y + g) * OS + 2 * x;
+        *reinterpret_cast<float2*>(mp) = make_float2(keep0, keep1);
+      }
+    }
   }
 }
 
@@ -914,7 +1008,8 @@ int esam3_launch_attn_fewkeys(int dtype, const void* q, int ldq, const void* k, 
   const size_t lds = sizeof(float) * 2 * (size_t)Nk * heads * hd;
   const int esz = dtype == 0 ? 4 : 2;
   auto al = [&](const void* p_, int ld) { return !(((uintptr_t)p_) & 15) && (ld * esz) % 16 == 0; };
-  if (Nk <= 16 && al(q, ldq) && al(o, ldo) && (heads * hd) % 4 == 0) {
+  static const bool no_fk16 = getenv("ESAM3_NO_FEWKEYS16") != nullptr && atoi(getenv("ESAM3_NO_FEWKEYS16")) != 0;  // A/B, bisecting
+  if (!no_fk16 && Nk <= 16 && al(q, ldq) && al(o, ldo) && (heads * hd) % 4 == 0) {
     constexpr int QPT = 4;
     dim3 grid4((unsigned)((Nq + qpb * QPT - 1) / (qpb * QPT)), (unsigned)B);
     if (Nk <= 8) {
@@ -994,6 +1089,21 @@ int esam3_launch_mask_product(int dtype, const void* hyper, int ld_h, const void
   dim3 grid(blocks_for(P, 256), (unsigned)Bp);
   DISPATCH_T(dtype, hipLaunchKernelGGL((mask_product_kernel<T, 32>), grid, dim3(256), 0, s,
                                        (const T*)hyper, ld_h, (const T*)up, masks, P));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_launch_upscale_mask(const void* u1, const void* wt, int kp, const float* bias, const void* feat, const int* img_of,
+                              const void* hyper, int ld_h, float* masks, int Bp, int S, hipStream_t s) {
+  if (kp % 8 || (((uintptr_t)u1) & 15) || (((uintptr_t)wt) & 15) || (((uintptr_t)feat) & 7) || (((uintptr_t)masks) & 7)) {
+    esam3_set_error("upscale_mask: misaligned operands");
+    return -1;
+  }
+  const int frags = (S * S + 31) / 32;
+  const int fpw = 3;  // fragments per wave: the weights / hypernetwork vectors are loaded once per wave
+  dim3 grid((unsigned)((frags + 4 * fpw - 1) / (4 * fpw)), (unsigned)Bp);
+  hipLaunchKernelGGL(upscale_mask_kernel, grid, dim3(256), 0, s, (const bf16_t*)u1, (const bf16_t*)wt, kp, bias, (const bf16_t*)feat,
+                     img_of, (const bf16_t*)hyper, ld_h, masks, S, fpw);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -81,6 +81,7 @@ def test_student_predict_inst_vs_golden(student, mode):
     state = proc.set_image(torch.from_numpy(np.ascontiguousarray(np.moveaxis(img, -1, 0))))
     # f32: 1e-3 / mask IoU 1 - 1e-4 (named exceptions below).  bf16: per case 1.5 x the reference's own bf16 error.
     yard = U.bf16_yardstick(student["gdir"])
+    ties = U.load_ties(student["gdir"])
     failures = []
     for name, case in student["manifest"]["cases"].items():
         lim = (1e-3, 1e-3, F32_IOU_EXCEPTIONS.get((student["bt"], name), 1.0 - 1e-4)) if mode == "f32" \
@@ -89,11 +90,15 @@ def test_student_predict_inst_vs_golden(student, mode):
         state["original_height"], state["original_width"] = case["hw"]
         masks, iou, low = model.predict_inst(state, **U.case_kwargs(case))
         assert list(masks.shape) == list(g["mask_shape"]) and low.shape == g["low_res"].shape
-        e_low = float(np.abs(low - g["low_res"]).max())
         lim_low = lim[0]
-        e_iou = float(np.abs(iou - g["iou"]).max())
+        # bf16: a prompt at the 0.98 stability threshold may take the reference's other candidate (U.errors_with_ties)
+        e_low, e_iou, flipped = U.errors_with_ties(name, low, iou, g["low_res"], g["iou"], lim_low, lim[1],
+                                                   ties if mode == "bf16" else (None, None))
         ref_bits = np.unpackbits(g["mask_bits"])[: masks.size].reshape(masks.shape).astype(bool)
-        miou = _iou(masks, ref_bits)
+        keep = [i for i in range(masks.shape[0]) if i not in flipped] if masks.ndim == 4 else None
+        miou = _iou(masks, ref_bits) if not flipped else (_iou(masks[keep], ref_bits[keep]) if keep else 1.0)
+        if flipped:
+            print(f"[{student['bt']} {mode}] {name}: prompts {flipped} took the reference's alternative candidate (stability tie)")
         print(f"[{student['bt']} {mode}] {name}: low_res err {e_low:.3e} (allowed {lim[0]:.3e}) iou err {e_iou:.3e} ({lim[1]:.3e}) "
               f"mask IoU {miou:.6f} (floor {lim[2]:.6f})")
         for what, v, ok in (("low_res", e_low, e_low <= lim_low), ("iou", e_iou, e_iou <= lim[1]),
