@@ -1,0 +1,58 @@
+"""ORACLE tooling (test infrastructure only): COMPLETE stage tensors of the reference.
+
+`oracle/gen_golden.py` stores 4 096-element strided samples (+ moments) of every stage tensor; a localised kernel bug
+-- one wrong tile edge -- can hide between the strides.  This script runs the REAL reference (fp32) on the seeded EV-M
+fixture image 0 and stores two tensors completely: the last backbone stage (every backbone kernel's tiles feed it) and
+the level-2 output of the SAM3-side neck (72 x 72 x 256: every output tile of the 256 x 256 GEMM kernel at that size).
+
+    PYTHONDONTWRITEBYTECODE=1 CUDA_VISIBLE_DEVICES="" HIP_VISIBLE_DEVICES="" \
+    PYTHONPATH=oracle/shims:/root/reference/sam3:. python oracle/gen_golden_full.py
+
+Output: tests/golden/stages_full_img0.npz   (`stage4`, `sam3_fpn2`; fp32, NCHW)
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from efficientsam3_amd import schema, synth  # noqa: E402
+from oracle import gen_golden as G  # noqa: E402
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count() or 8)
+    from sam3 import build_efficientsam3_image_model  # the REAL reference
+    from sam3.model.sam3_image_processor import Sam3Processor
+    model = build_efficientsam3_image_model(
+        device="cpu", checkpoint_path=None, load_from_HF=False, enable_inst_interactivity=True,
+        backbone_type="efficientvit", model_name="b1", text_encoder_type="MobileCLIP-S0", text_encoder_context_length=16)
+    sd = schema.synthetic_state_dict("efficientvit", "b1", seed=0)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected[:5]
+    model.eval()
+    proc = Sam3Processor(model, device="cpu")
+    bb = model.backbone.vision_backbone.trunk.model.backbone
+    img = synth.smooth_image_u8(seed=1)
+    with torch.inference_mode():
+        x = torch.from_numpy(synth.normalise_to_chw_f32(img))[None]
+        stages = G.reference_stage_taps("efficientvit", bb, x)
+        state = proc.set_image(torch.from_numpy(np.ascontiguousarray(np.moveaxis(img, -1, 0))))
+    out = {"stage4": stages["stage4"].float().numpy(), "sam3_fpn2": state["backbone_out"]["backbone_fpn"][2].float().numpy()}
+    # consistency with the strided fixtures of gen_golden.py
+    gold = np.load(os.path.join(G.GOLD, "stages_img0.npz"))
+    for k, v in out.items():
+        assert np.array_equal(G.sample(torch.from_numpy(v)), gold[k]), k
+        print(k, v.shape, float(np.abs(v).max()))
+    np.savez_compressed(os.path.join(G.GOLD, "stages_full_img0.npz"), **out)
+    print("wrote", os.path.join(G.GOLD, "stages_full_img0.npz"))
+
+
+if __name__ == "__main__":
+    main()
