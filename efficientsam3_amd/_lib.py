@@ -67,6 +67,7 @@ SIGNATURES = {
     "esam3_destroy": (None, [_P]),
     "esam3_load_weight": (_I, [_P, C.c_char_p, _P, C.POINTER(_L), _I]),
     "esam3_finalize": (_I, [_P]),
+    "esam3_release_host_weights": (C.c_int64, [_P]),
     "esam3_encode_image": (_I, [_P, _P, _I, C.POINTER(ImageFeatures), _P]),
     "esam3_decode": (_I, [_P, C.POINTER(Prompts), C.POINTER(DecodeOut), _P]),
     "esam3_postprocess_masks": (_I, [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P]),

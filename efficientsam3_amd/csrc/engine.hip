@@ -57,6 +57,9 @@ const std::string PE = SAM + "sam_prompt_encoder.";
 struct HostTensor {
   std::vector<float> d;
   std::vector<int64_t> shape;
+  bool packed = false;        // consumed by one of the cache-first packers (pk_conv / pk_convT / pk_linear / pk_dw)
+  bool released = false;      // esam3_release_host_weights: the name and shape stay, the data is gone
+  mutable uint32_t touched = 0;  // epoch of the last find() / need()
 };
 
 struct PackedGemm {
@@ -154,15 +157,23 @@ struct esam3_engine {
   }
 
   // ---------------- raw weight access ----------------
+  uint32_t epoch = 1;
   const HostTensor* find(const std::string& n) const {
     auto it = raw.find(n);
-    return it == raw.end() ? nullptr : &it->second;
+    if (it == raw.end()) return nullptr;
+    it->second.touched = epoch;
+    return &it->second;
   }
   const HostTensor* need(const std::string& n) const {
     const HostTensor* t = find(n);
-    if (!t) esam3_set_error("missing weight '%s'", n.c_str());
+    if (!t) { esam3_set_error("missing weight '%s'", n.c_str()); return nullptr; }
+    if (t->released) {
+      esam3_set_error("weight '%s' was freed by esam3_release_host_weights() and is requested again", n.c_str());
+      return nullptr;
+    }
     return t;
   }
+  static void mark_packed(const HostTensor* t) { if (t) const_cast<HostTensor*>(t)->packed = true; }
 
   void* dev_upload(const void* src, size_t bytes) {
     void* p = nullptr;
@@ -256,6 +267,8 @@ struct esam3_engine {
       if (!g.wn) return nullptr;
     }
     g.tag = wname;
+    mark_packed(w);
+    if (!bname.empty()) mark_packed(find(bname));
     return &(gemms[wname] = g);
   }
   // ConvTranspose2d k2 s2: [Cin][Cout][2][2] -> GEMM with N = 4*Cout, n = tap*Cout + co
@@ -279,6 +292,8 @@ struct esam3_engine {
     g.bias = (float*)dev_upload(b->d.data(), b->d.size() * 4);
     if (!g.w) return nullptr;
     g.tag = wname;
+    mark_packed(w);
+    mark_packed(b);
     return &(gemms[wname] = g);
   }
   // ---- exact algebraic composition of linear chains (no activation in between) ----------
@@ -379,6 +394,8 @@ struct esam3_engine {
     }
     if (!g.w) return nullptr;
     g.tag = wname;
+    mark_packed(w);
+    if (!bname.empty()) mark_packed(find(bname));
     return &(gemms[wname] = g);
   }
   PackedDw* pk_dw(const std::string& wname, const std::string& bname, const std::string& bn) {
@@ -405,6 +422,8 @@ struct esam3_engine {
     d.w = (float*)dev_upload(pk.data(), pk.size() * 4);
     d.bias = has_bias ? (float*)dev_upload(bias.data(), bias.size() * 4) : nullptr;
     if (!d.w) return nullptr;
+    mark_packed(w);
+    if (!bname.empty()) mark_packed(find(bname));
     return &(dws[wname] = d);
   }
 
@@ -2217,6 +2236,43 @@ int esam3_finalize(esam3_engine* e) {
   if (e->cfg.interactive) CK(e->precompute_pe());
   e->finalized = true;
   return 0;
+}
+
+// fp32 host copies of image-encoder / mask-decoder weights that a packer has consumed and that a complete dry pass of
+// encode + decode does not look at again (neither data nor shape) are freed; everything else stays.
+int64_t esam3_release_host_weights(esam3_engine* e) {
+  if (!e) { esam3_set_error("null engine"); return -1; }
+  if (!e->finalized) { esam3_set_error("esam3_release_host_weights before esam3_finalize"); return -1; }
+  DeviceGuard guard(e->cfg.device);
+  if (!guard.ok) { esam3_set_error("esam3_release_host_weights: hipSetDevice(%d) failed", e->cfg.device); return -1; }
+  ++e->epoch;
+  e->dry = true;
+  e->arena.dry = true;
+  esam3_image_features f{};
+  void* dummy = reinterpret_cast<void*>(4096);
+  for (int i = 0; i < 3; ++i) f.sam3_fpn_dev[i] = dummy;
+  if (e->cfg.interactive) for (int i = 0; i < 3; ++i) f.sam2_fpn_dev[i] = dummy;
+  int rc = e->encode(nullptr, 1, &f);
+  if (rc == 0 && e->cfg.interactive) {
+    esam3_prompts pr{};
+    pr.n_images = 1; pr.n_prompts = 1; pr.n_points = 1;
+    esam3_decode_out o{};
+    rc = e->decode(&pr, &o);
+  }
+  e->dry = false;
+  e->arena.dry = false;
+  if (rc) return -1;
+  int64_t freed = 0;
+  for (auto& kv : e->raw) {
+    HostTensor& t = kv.second;
+    const bool in_scope = kv.first.rfind("backbone.vision_backbone.", 0) == 0 || kv.first.rfind("inst_interactive_predictor.", 0) == 0;
+    if (in_scope && t.packed && !t.released && t.touched != e->epoch) {
+      freed += (int64_t)t.d.size() * 4;
+      std::vector<float>().swap(t.d);
+      t.released = true;
+    }
+  }
+  return freed;
 }
 
 static int run_sized(esam3_engine* e, void* stream, const std::function<int()>& graph) {

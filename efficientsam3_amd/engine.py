@@ -99,6 +99,14 @@ class HipEngine:
             _lib.check(self.lib.esam3_finalize(self.handle), "esam3_finalize")
         self.finalized = True
 
+    def release_host_weights(self) -> int:
+        """Free the engine's fp32 host copies of packed image-encoder / mask-decoder weights; returns the bytes freed."""
+        with torch.cuda.device(self.dev_index):
+            n = int(self.lib.esam3_release_host_weights(self.handle))
+        if n < 0:
+            _lib.check(-1, "esam3_release_host_weights")
+        return n
+
     # ---- image encoder -------------------------------------------------------------------
     def preprocess_u8(self, img_hwc_u8: torch.Tensor) -> torch.Tensor:
         """[B,H,W,3] uint8 on device -> [B,3,H,W] fp32 normalised (sam3_image_processor.py:24-31)."""

@@ -94,6 +94,11 @@ int esam3_load_weight(esam3_engine* e, const char* name, const float* host_data,
                       const int64_t* shape, int ndim);
 /* fold BatchNorm, pack to the GEMM layouts, upload; must precede encode/decode */
 int esam3_finalize(esam3_engine* e);
+/* Optional, after esam3_finalize: free the engine's fp32 host copies of the image-encoder and mask-decoder weights that
+ * have been packed for the device and that a complete encode + decode pass never looks at again (esam3_load_weight keeps
+ * one copy per tensor because layers are packed on first use).  Text / grounding weights are kept.  Returns the number of
+ * bytes freed, -1 on error. */
+int64_t esam3_release_host_weights(esam3_engine* e);
 
 int esam3_encode_image(esam3_engine* e, const float* img_nchw_f32_dev, int B,
                        const esam3_image_features* out, void* hip_stream);
