@@ -451,7 +451,7 @@ struct esam3_engine {
   // ---------------- launch helpers ----------------
   int gemm(const PackedGemm* g, const void* A, int lda, int64_t M, int H, int W, void* out, int ldc,
            int act, const void* res = nullptr, int ldr = 0, int res_after_act = 1, int res_mod = 0,
-           const int* res_bidx = nullptr, int in_pad = 0, int out_pad = 0, int stride = 1) {
+           const int* res_bidx = nullptr, int in_pad = 0, int out_pad = 0, int stride = 1, int out_f32 = 0) {
     if (!g) return -1;
     if (stride != 1 && (g->ksize != 3 || in_pad || out_pad)) { esam3_set_error("strided conv: only plain 3x3"); return -1; }
     if (in_pad && g->ksize != 3) { esam3_set_error("padded input given to a %dx%d conv", g->ksize, g->ksize); return -1; }
@@ -469,6 +469,7 @@ struct esam3_engine {
     p.in_pad = in_pad;
     p.out_pad = out_pad;
     p.stride = stride;
+    p.out_f32 = out_f32;
     const double uniq_in = (double)M * g->cin * (g->ksize == 3 ? 1 : 1);
     const double bytes = (uniq_in + (double)g->N * g->K + (double)M * g->N + (res ? (double)M * g->N : 0.0)) * (double)esz;
     const double flops = 2.0 * (double)M * g->N * g->K;
@@ -531,10 +532,19 @@ struct esam3_engine {
                        });
   }
   int linear(const std::string& prefix, const void* A, int lda, int64_t M, void* out, int ldc, int act,
-             const void* res = nullptr, int ldr = 0, int res_mod = 0) {
+             const void* res = nullptr, int ldr = 0, int res_mod = 0, int out_f32 = 0) {
     PackedGemm* g = pk_linear(prefix);
     if (!g) return -1;
-    return gemm(g, A, lda, M, 1, 1, out, ldc, act, res, ldr, 1, res_mod);
+    return gemm(g, A, lda, M, 1, 1, out, ldc, act, res, ldr, 1, res_mod, nullptr, 0, 0, 1, out_f32);
+  }
+  // LayerNorm with separate row dtypes (0 f32, 1 bf16): the fp32 residual stream of the bf16 engine
+  int layernorm_io(int in_dtype, int out_dtype, const std::string& prefix, const void* x, void* out, int64_t rows, int C, float eps) {
+    float* g = fvec(prefix + ".weight");
+    float* b = fvec(prefix + ".bias");
+    if (!g || !b) return -1;
+    if (dry) return 0;
+    return prof_launch("layernorm", 8.0 * (double)rows * C, (double)rows * C * (double)((in_dtype ? 2 : 4) + (out_dtype ? 2 : 4)),
+                       [&]() { return esam3_launch_layernorm_io(in_dtype, out_dtype, x, nullptr, g, b, out, rows, C, eps, ACT_NONE, st); });
   }
   int layernorm(const std::string& prefix, const void* x, void* out, int64_t rows, int C, float eps,
                 int act = ACT_NONE) {
@@ -1057,20 +1067,33 @@ int E::backbone_vit(const float* img, int B, const esam3_image_features* out, T4
   float* rope_glob = vit_rope_table(G, (float)ws / (float)G);  // rope_interp: scaled to the window extent
   if (!rope_win || !rope_glob) return -1;
 
-  T4 x = alloc4(B, G, G, D), y = alloc4(B, G, G, D);
+  // bf16 engine: the residual stream x / y of the blocks is kept in fp32, as the reference's autocast keeps it (fp32 pos_embed + bf16
+  // conv output -> fp32; every `x + branch` adds a bf16 branch to the fp32 stream, vitdet.py:339-515): LayerNorm reads fp32 rows and
+  // writes the bf16 GEMM input, the two residual GEMMs of a block (attn.proj, mlp.fc2) read and write fp32 rows.
+  static const bool bf16_stream = getenv("ESAM3_BF16_STREAM") != nullptr && atoi(getenv("ESAM3_BF16_STREAM")) != 0;  // A/B: round-1 behaviour
+  const bool s32 = dtype == 1 && !bf16_stream && rows >= 1024;
+  const int sdt = s32 ? 0 : dtype;  // dtype of the stream rows
+  T4 x = alloc4(B, G, G, D), y = alloc4(B, G, G, D);  // engine-dtype views: patch embedding, stage taps, the trunk output
+  void* xs = s32 ? allocb((size_t)rows * D * 4) : x.p;
+  void* ys = s32 ? allocb((size_t)rows * D * 4) : y.p;
   void* ln = allocb((size_t)rows * D * esz);
   void* qkv = allocb((size_t)rows * 3 * D * esz);   // also holds the patch rows and the attention output
   void* hid = allocb((size_t)rows * 4736 * esz);
-  if (!ok(x.p) || !ok(y.p) || !ok(ln) || !ok(qkv) || !ok(hid)) return -1;
+  if (!ok(x.p) || !ok(y.p) || !ok(xs) || !ok(ys) || !ok(ln) || !ok(qkv) || !ok(hid)) return -1;
+  auto stream_view = [&]() -> int {  // x (engine dtype) <- xs
+    if (!s32 || dry) return 0;
+    return prof_launch("cast", 0.0, (double)rows * D * 6.0, [&]() { return esam3_launch_cast_from_f32(dtype, (const float*)xs, x.p, rows * D, st); });
+  };
   if (!dry) CK(prof_launch("patchify", 0.0, 0.0, [&]() { return esam3_launch_patchify(dtype, img, qkv, B, IMG, P, ldk, st); }));
   CK(gemm(gpe, qkv, ldk, rows, 1, 1, y.p, D, ACT_NONE, pos_full, D, 1, G * G));
-  CK(layernorm(p + "ln_pre", y.p, x.p, rows, D, 1e-5f));
+  CK(layernorm_io(dtype, sdt, p + "ln_pre", y.p, xs, rows, D, 1e-5f));
+  CK(stream_view());
   CK(tap(out, 0, x));
   int stage = 1;
   for (int i = 0; i < depth; ++i) {
     const std::string q = p + "blocks." + std::to_string(i) + ".";
     const bool global = (i % 8) == 7;
-    CK(layernorm(q + "norm1", x.p, ln, rows, D, 1e-5f));
+    CK(layernorm_io(sdt, dtype, q + "norm1", xs, ln, rows, D, 1e-5f));
     CK(linear(q + "attn.qkv", ln, D, rows, qkv, 3 * D, ACT_NONE));
     if (!dry) {
       const double keys = global ? (double)G * G : (double)ws * ws;
@@ -1080,11 +1103,14 @@ int E::backbone_vit(const float* img, int B, const esam3_image_features* out, T4
                                                        heads, 64, global ? rope_glob : rope_win, st);
                      }));
     }
-    CK(linear(q + "attn.proj", ln, D, rows, y.p, D, ACT_NONE, x.p, D));
-    CK(layernorm(q + "norm2", y.p, ln, rows, D, 1e-5f));
+    CK(linear(q + "attn.proj", ln, D, rows, ys, D, ACT_NONE, xs, D, 0, s32 ? 1 : 0));
+    CK(layernorm_io(sdt, dtype, q + "norm2", ys, ln, rows, D, 1e-5f));
     CK(linear(q + "mlp.fc1", ln, D, rows, hid, 4736, ACT_GELU));
-    CK(linear(q + "mlp.fc2", hid, 4736, rows, x.p, D, ACT_NONE, y.p, D));
-    if (global) CK(tap(out, stage++, x));
+    CK(linear(q + "mlp.fc2", hid, 4736, rows, xs, D, ACT_NONE, ys, D, 0, s32 ? 1 : 0));
+    if (global) {
+      CK(stream_view());
+      CK(tap(out, stage++, x));
+    }
   }
   *feat = x;
   return 0;

@@ -134,6 +134,9 @@ struct GemmParams {
                       // (channel-chunk major: the 9 taps of one 128-byte channel chunk are
                       //  consecutive K tiles, so shifted re-reads of the same pixels hit in L2)
   int stride;         // ksize 3 only: 0/1 -> stride 1; 2 -> H, W are the INPUT dims, M = B*ceil(H/2)*ceil(W/2)
+  int out_f32;        // 1 (bf16 GEMMs on gemm256p, plain rows, no activation): `out` and `res` are fp32 (ldc / ldr in fp32
+                      // elements) -- the residual stream of a LayerNorm / attention stack kept in fp32 as the reference's
+                      // autocast does (fp32 x + bf16 branch -> fp32)
 };
 
 // ---- 8 consecutive activations <-> 8 floats (one 16-byte access for bf16, two for f32) -------

@@ -52,7 +52,7 @@ __device__ __forceinline__ void dma_piece(const void* base, uint32_t voff, uint3
                : "memory");
 }
 
-template <int ACT, bool RES>
+template <int ACT, bool RES, bool OUT32 = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
   typedef bf16_t T;
   constexpr int BKE = 64;                  // K elements per tile (128 bytes)
@@ -353,6 +353,36 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
 #else
     if (nbw < p.N) {
 #endif
+     if constexpr (OUT32) {
+      // fp32 output (+ fp32 residual) straight from the accumulator layout: plain rows, no activation.  A lane owns 4
+      // consecutive channels of a pixel = one float4 per (block, q); the four q of a block complete 128-byte lines.
+      float* __restrict__ gO32 = reinterpret_cast<float*>(p.out);
+      const float* __restrict__ gR32 = reinterpret_cast<const float*>(p.res);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's first K tiles have landed (see the bf16 path)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned m = m0 + (unsigned)(wm * 128 + i * 32 + l31);
+        const bool mok = m < M32;
+        unsigned rrow = m;
+        if (p.res_mod > 0) rrow = m % (unsigned)p.res_mod;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int n = nbw + j * 32 + 8 * q + 4 * g;
+            float4 v = make_float4(acc[i][j][4 * q] + bq[j][q].x, acc[i][j][4 * q + 1] + bq[j][q].y, acc[i][j][4 * q + 2] + bq[j][q].z,
+                                   acc[i][j][4 * q + 3] + bq[j][q].w);
+            if constexpr (RES) {
+              if (mok) {
+                const float4 r = *reinterpret_cast<const float4*>(gR32 + (int64_t)rrow * p.ldr + n);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+              }
+            }
+            if (mok) *reinterpret_cast<float4*>(gO32 + (int64_t)m * p.ldc + n) = v;
+          }
+        if (i == 1 && has_next) { stream_look_ahead(w + 2); looked = true; }
+      }
+     } else {
       // channel-direction part of the addresses (a 64-channel block never straddles a ConvT tap: Cout % 64 == 0)
       int64_t ocol = nbw, rcol = nbw;
       if (convt) {
@@ -503,6 +533,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
         }
         ESAM3_TRACE(8 + i);
       }
+     }
       c_landed = has_next;
     }
     if (!has_next) break;
@@ -522,6 +553,9 @@ bool esam3_gemm256p_ok(const GemmParams& p) {
   if ((p.out_mode == OUT_CONVT2X2 || p.out_pad) && p.W < 8) return false;  // epilogue row walker: one wrap per 8-pixel step
   if ((((uintptr_t)p.out) & 15) || (((uintptr_t)p.A) & 15) || (((uintptr_t)p.Wt) & 15)) return false;
   if (p.bias && (((uintptr_t)p.bias) & 15)) return false;
+  if (p.out_f32 && (p.act != ACT_NONE || p.out_mode != OUT_PLAIN || p.out_pad || p.ksize != 1 || p.res_bidx || p.ldc % 4 || (p.res && p.ldr % 4) ||
+                    (p.res && (((uintptr_t)p.res) & 15))))
+    return false;
   return true;
 }
 
@@ -550,6 +584,17 @@ int esam3_launch_gemm256p(const GemmParams& p, hipStream_t stream) {
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const int64_t grid = tiles < n_cu ? tiles : n_cu;  // persistent: one workgroup per CU
+  if (p.out_f32) {  // fp32 output / residual stream (esam3_gemm256p_ok has checked: no activation, plain rows)
+    void (*k32)(GemmParams) = p.res ? gemm256p_kernel<ACT_NONE, true, true> : gemm256p_kernel<ACT_NONE, false, true>;
+    static bool attr32[2] = {false, false};
+    if (!attr32[p.res ? 1 : 0]) {
+      HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(k32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr32[p.res ? 1 : 0] = true;
+    }
+    hipLaunchKernelGGL(k32, dim3((unsigned)grid), dim3(512), lds, stream, p);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(kerns[p.act + (p.res ? 5 : 0)], dim3((unsigned)grid), dim3(512), lds, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;

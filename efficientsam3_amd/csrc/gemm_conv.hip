@@ -830,6 +830,16 @@ thread_local const char* g_last_kernel = nullptr;  // name of the kernel the las
 template <typename T>
 int launch_gemm_t(const GemmParams& p, hipStream_t stream) {
   constexpr bool bf = sizeof(T) == 2;
+  if (p.out_f32) {  // fp32 output / residual: only the DMA kernel writes it
+    if constexpr (bf) {
+      if (use_256<T>(p) && esam3_gemm256p_ok(p)) {
+        g_last_kernel = "gemm256p_kernel<bf16, fp32 output> (256x256x64, fp32 residual stream)";
+        return esam3_launch_gemm256p(p, stream);
+      }
+    }
+    esam3_set_error("gemm: fp32 output requested for a shape the 256x256 DMA kernel does not take (M=%lld N=%d K=%d)", (long long)p.M, p.N, p.K);
+    return -1;
+  }
   // few rows: a few hundred token rows, or too few 256 x 256 tiles to occupy the chip
   static const bool no_skinny = getenv("ESAM3_NO_SKINNY") != nullptr && atoi(getenv("ESAM3_NO_SKINNY")) != 0;  // A/B, bisecting
   if (!no_skinny && use_skinny<T>(p) && (p.M <= 512 || ((p.M + 255) / 256) * ((p.N + 255) / 256) < 32)) {

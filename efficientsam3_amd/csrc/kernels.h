@@ -51,6 +51,9 @@ int esam3_launch_resize_bilinear(int dtype, const void* in, void* out, int B, in
                                  int OH, int OW, int C, hipStream_t s);
 
 // y = act(LN(x (+ res))) over the last dim C (biased variance), one wavefront per row.
+// the same with separate row dtypes (0 f32, 1 bf16): fp32 rows in / bf16 rows out for an fp32 residual stream, and back
+int esam3_launch_layernorm_io(int in_dtype, int out_dtype, const void* x, const void* res, const float* gamma, const float* beta,
+                              void* out, int64_t rows, int C, float eps, int act, hipStream_t s);
 int esam3_launch_layernorm(int dtype, const void* x, const void* res, const float* gamma,
                            const float* beta, void* out, int64_t rows, int C, float eps, int act,
                            hipStream_t s);

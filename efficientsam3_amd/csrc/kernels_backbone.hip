@@ -2041,10 +2041,10 @@ __global__ void layernorm_kernel(const T* __restrict__ x, const T* __restrict__ 
 // Vectorised variant for C % 8 == 0: LPR (a power of two) lanes share a row, a lane owns up to NCH 8-channel chunks
 // (16-byte loads and stores; the scalar kernel above moves 2 bytes per lane per load) and keeps gamma / beta of its
 // chunks in registers while the wave walks `iters` groups of 64/LPR rows.
-template <typename T, int NCH>
-__global__ __launch_bounds__(256) void layernorm_vec_kernel(const T* __restrict__ x, const T* __restrict__ res,
+template <typename TI, typename TO, int NCH>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const TI* __restrict__ x, const TI* __restrict__ res,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            T* __restrict__ out, int64_t rows, int C, float eps, int act,
+                                                            TO* __restrict__ out, int64_t rows, int C, float eps, int act,
                                                             int lpr, int iters) {
   const int lane = threadIdx.x & 63;
   const int sub = lane & (lpr - 1), rw = lane / lpr, rpw = 64 / lpr;  // lane within the row, row within the wave's group
@@ -2072,10 +2072,10 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const T* __restrict_
     for (int j = 0; j < NCH; ++j) {
       const int64_t off = row * C + (int64_t)(sub + lpr * j) * 8;
       if (rok && ok[j]) {
-        Vec8<T>::load(x + off, v[j]);
+        Vec8<TI>::load(x + off, v[j]);
         if (res) {
           float r[8];
-          Vec8<T>::load(res + off, r);
+          Vec8<TI>::load(res + off, r);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[j][e] += r[e];
         }
@@ -2107,7 +2107,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const T* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) y[e] = (v[j][e] - mean) * rstd * gm[j][e] + bt[j][e];
         act_apply_n<8>(y, act);
-        Vec8<T>::store(out + row * C + (int64_t)(sub + lpr * j) * 8, y);
+        Vec8<TO>::store(out + row * C + (int64_t)(sub + lpr * j) * 8, y);
       }
     }
   }
@@ -2622,13 +2622,15 @@ int esam3_launch_resize_bilinear(int dtype, const void* in, void* out, int B, in
   return 0;
 }
 
-int esam3_launch_layernorm(int dtype, const void* x, const void* res, const float* gamma,
-                           const float* beta, void* out, int64_t rows, int C, float eps, int act,
-                           hipStream_t s) {
-  const int esz = dtype == 0 ? 4 : 2;
-  const bool aligned = !(((uintptr_t)x) & 15) && !(((uintptr_t)out) & 15) && !(res && (((uintptr_t)res) & 15)) && (C * esz) % 16 == 0;
+// in_dtype / out_dtype: 0 f32, 1 bf16 (mixed = the fp32 residual stream of a bf16 engine: fp32 rows in, bf16 rows out)
+int esam3_launch_layernorm_io(int in_dtype, int out_dtype, const void* x, const void* res, const float* gamma, const float* beta,
+                              void* out, int64_t rows, int C, float eps, int act, hipStream_t s) {
+  const int esz = in_dtype == 0 ? 4 : 2, osz = out_dtype == 0 ? 4 : 2;
+  const bool aligned = !(((uintptr_t)x) & 15) && !(((uintptr_t)out) & 15) && !(res && (((uintptr_t)res) & 15)) && (C * esz) % 16 == 0 &&
+                       (C * osz) % 16 == 0;
   static const int no_vec = getenv("ESAM3_NO_LNVEC") ? atoi(getenv("ESAM3_NO_LNVEC")) : 0;  // A/B, bisecting: 1 all, else that C
-  if (C % 8 == 0 && C <= 2048 && aligned && rows > 0 && !((no_vec == 1 || no_vec == C || (no_vec < 0 && rows == -no_vec)) && C <= 1024)) {
+  const bool mixed = in_dtype != out_dtype;
+  if (C % 8 == 0 && C <= 2048 && aligned && rows > 0 && (mixed || !((no_vec == 1 || no_vec == C) && C <= 1024))) {
     const int nchunk = C / 8;
     int lpr = 1;
     while (lpr < nchunk && lpr < 64) lpr <<= 1;
@@ -2640,20 +2642,35 @@ int esam3_launch_layernorm(int dtype, const void* x, const void* res, const floa
     if (iters > 8) iters = 8;
     const int64_t waves = (groups + iters - 1) / iters;
     const dim3 grid((unsigned)((waves + 3) / 4));
-#define ESAM3_LN(NCH_)                                                                                              \
-  DISPATCH_T(dtype, hipLaunchKernelGGL((layernorm_vec_kernel<T, NCH_>), grid, dim3(256), 0, s, (const T*)x, (const T*)res, \
-                                       gamma, beta, (T*)out, rows, C, eps, act, lpr, iters))
+#define ESAM3_LN_IO(TI_, TO_, NCH_)                                                                                            \
+  hipLaunchKernelGGL((layernorm_vec_kernel<TI_, TO_, NCH_>), grid, dim3(256), 0, s, (const TI_*)x, (const TI_*)res, gamma, beta, \
+                     (TO_*)out, rows, C, eps, act, lpr, iters)
+#define ESAM3_LN(NCH_)                                                                       \
+  do {                                                                                       \
+    if (in_dtype == 0 && out_dtype == 0) ESAM3_LN_IO(float, float, NCH_);                    \
+    else if (in_dtype == 1 && out_dtype == 1) ESAM3_LN_IO(bf16_t, bf16_t, NCH_);             \
+    else if (in_dtype == 0) ESAM3_LN_IO(float, bf16_t, NCH_);                                \
+    else ESAM3_LN_IO(bf16_t, float, NCH_);                                                   \
+  } while (0)
     if (nch == 1) { ESAM3_LN(1); } else if (nch == 2) { ESAM3_LN(2); } else if (nch == 3) { ESAM3_LN(3); } else { ESAM3_LN(4); }
 #undef ESAM3_LN
+#undef ESAM3_LN_IO
     HIP_CHECK_RET(hipGetLastError());
     return 0;
   }
+  if (mixed) { esam3_set_error("layernorm: mixed in/out dtypes need C %% 8 == 0, C <= 2048 and 16-byte aligned rows (C=%d)", C); return -1; }
+  const int dtype = in_dtype;
   if (C > 1024) { esam3_set_error("layernorm: C=%d > 1024", C); return -1; }
   DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_kernel<T>, dim3(blocks_for(rows, 4)), dim3(256), 0, s,
                                        (const T*)x, (const T*)res, gamma, beta, (T*)out, rows, C, eps,
                                        act));
   HIP_CHECK_RET(hipGetLastError());
   return 0;
+}
+
+int esam3_launch_layernorm(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* out, int64_t rows,
+                           int C, float eps, int act, hipStream_t s) {
+  return esam3_launch_layernorm_io(dtype, dtype, x, res, gamma, beta, out, rows, C, eps, act, s);
 }
 
 int esam3_launch_cast_to_f32(int dtype, const void* in, float* out, int64_t n, hipStream_t s) {

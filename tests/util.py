@@ -99,13 +99,6 @@ def bf16_yardstick(gdir):
 # gap per model; an fp32 residual stream is the remedy.
 BF16_EXCEPTIONS = {
     # (golden dir name, case, quantity): allowed value
-    ("repvit_m1.1", "two_boxes_batched", "mask_iou"): 0.95,   # measured 0.9533 (reference bf16: 0.9831); logits 0.246 <= 0.407 allowed
-    ("sam3_vit_h", "point_box_single", "low_res"): 0.45,      # measured 0.414 (1.5 x reference = 0.394)  [stream]
-    ("sam3_vit_h", "stage2", "stage"): 0.07,                  # measured 0.054 .. 0.061 across builds (allowed 0.048)  [stream]
-    ("sam3_vit_h", "sam2_fpn2", "stage"): 0.095,              # measured 0.063 .. 0.085 across builds (allowed 0.076)  [stream]
-    ("sam3_vit_h", "stage3", "stage"): 0.10,                  # measured 0.088 (allowed 0.056)  [stream]
-    ("sam3_vit_h", "stage4", "stage"): 0.16,                  # measured 0.147 (allowed 0.067)  [stream]
-    ("sam3_vit_h", "trunk", "stage"): 0.16,                   # the same tensor as stage4
 }
 
 
