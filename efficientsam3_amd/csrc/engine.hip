@@ -1568,7 +1568,9 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
   const void* pos = tbufs["pcs_pos72"];
   auto L = [&](const std::string& w, const std::string& b, int r0, int n, const std::string& key) { return pk_rows(w, b, r0, n, key); };
   auto lin = [&](PackedGemm* g, const void* A, int lda, int64_t M, void* o, int ldc, int act, const void* res = nullptr,
-                 int ldr = 0, int res_mod = 0) -> int { return gemm(g, A, lda, M, 1, 1, o, ldc, act, res, ldr, 1, res_mod); };
+                 int ldr = 0, int res_mod = 0, int out_f32 = 0) -> int {
+    return gemm(g, A, lda, M, 1, 1, o, ldc, act, res, ldr, 1, res_mod, nullptr, 0, 0, 1, out_f32);
+  };
   auto attn = [&](const void* q, int ldq, int qo, const void* kv, int ldk, int ko, int vo, void* o, int Nq, int Nk,
                   const uint8_t* mask, const float* by = nullptr, const float* bx = nullptr, int q0 = 0) -> int {
     if (dry) return 0;
@@ -1741,6 +1743,28 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
   for (int k = 0; k < 4; ++k) if (!rpbx[k] || !rpby[k]) return -1;
   void* ph = allocb((size_t)B * DM * esz);
   float* presence_logits = out->presence_logit_dev;
+  // bf16 engine: the decoder's query stream is kept in fp32, as it is in the reference under autocast (post-norm layers: every
+  // LayerNorm returns fp32, `tgt + branch` adds the bf16 branch to it, decoder.py:120-200); `x` is its bf16 view = the GEMM input.
+  static const bool bf16_stream = getenv("ESAM3_BF16_STREAM") != nullptr && atoi(getenv("ESAM3_BF16_STREAM")) != 0;  // A/B: round-1 behaviour
+  const bool ds32 = dtype == 1 && !bf16_stream;
+  float* xs = ds32 ? (float*)allocb(sizeof(float) * (size_t)R * DM) : nullptr;
+  if (ds32 && !ok(xs)) return -1;
+  auto view = [&]() -> int {  // x <- xs
+    if (!ds32 || dry) return 0;
+    return esam3_launch_cast_from_f32(dtype, xs, x, R * DM, st);
+  };
+  auto LNs = [&](const std::string& name) -> int {  // stream = LN(stream)
+    if (!ds32) return LN(name, x, x, R);
+    CK(layernorm_io(0, 0, name, xs, xs, R, DM, 1e-5f));
+    return view();
+  };
+  auto LNout = [&](const std::string& name, void* o) -> int {  // o (engine dtype) = LN(stream)
+    return ds32 ? layernorm_io(0, dtype, name, xs, o, R, DM, 1e-5f) : LN(name, x, o, R);
+  };
+  auto linres = [&](PackedGemm* g, const void* A, int lda) -> int {  // stream += A . W^T + b
+    return ds32 ? lin(g, A, lda, R, xs, DM, ACT_NONE, xs, DM, 0, 1) : lin(g, A, lda, R, x, DM, ACT_NONE, x, DM);
+  };
+  if (ds32 && !dry) CK(esam3_launch_cast_to_f32(dtype, x, xs, R * DM, st));
   for (int i = 0; i < 6; ++i) {
     const std::string p = t + "layers." + std::to_string(i) + ".";
     // conditional query position: MLP(sine(reference box)); zero for the presence token
@@ -1757,28 +1781,28 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
     CK(lin(L(sa + "in_proj_weight", sa + "in_proj_bias", 0, 2 * DM, sa + "#qk"), xp, DM, R, dq, 3 * DM, ACT_NONE));
     CK(lin(L(sa + "in_proj_weight", sa + "in_proj_bias", 2 * DM, DM, sa + "#v"), x, DM, R, (char*)dq + 2 * DM * esz, 3 * DM, ACT_NONE));
     CK(attn(dq, 3 * DM, 0, dq, 3 * DM, DM, 2 * DM, da, QR, QR, nullptr));
-    CK(lin(pk_linear(sa + "out_proj"), da, DM, R, x, DM, ACT_NONE, x, DM));
-    CK(LN(p + "norm2", x, x, R));
+    CK(linres(pk_linear(sa + "out_proj"), da, DM));
+    CK(LNs(p + "norm2"));
     // cross-attention to the prompt tokens
     CK(addk(x, qpos, xp, R * DM));
     CK(lin(L(ct + "in_proj_weight", ct + "in_proj_bias", 0, DM, ct + "#q"), xp, DM, R, dq, DM, ACT_NONE));
     CK(lin(L(ct + "in_proj_weight", ct + "in_proj_bias", DM, 2 * DM, ct + "#kv"), prompt, DM, B * Sp, pkv, 2 * DM, ACT_NONE));
     CK(attn(dq, DM, 0, pkv, 2 * DM, 0, DM, da, QR, Sp, pmask));
-    CK(lin(pk_linear(ct + "out_proj"), da, DM, R, x, DM, ACT_NONE, x, DM));
-    CK(LN(p + "catext_norm", x, x, R));
+    CK(linres(pk_linear(ct + "out_proj"), da, DM));
+    CK(LNs(p + "catext_norm"));
     // cross-attention to the image memory with the box-relative position bias (none for the presence token)
     CK(addk(x, qpos, xp, R * DM));
     CK(lin(L(ci + "in_proj_weight", ci + "in_proj_bias", 0, DM, ci + "#q"), xp, DM, R, dq, DM, ACT_NONE));
     CK(lin(L(ci + "in_proj_weight", ci + "in_proj_bias", DM, DM, ci + "#k"), mem, DM, B * P, mkv, 2 * DM, ACT_NONE, tbufs[ci + "#posk"], DM, (int)P));
     CK(lin(L(ci + "in_proj_weight", ci + "in_proj_bias", 2 * DM, DM, ci + "#v"), mem, DM, B * P, (char*)mkv + DM * esz, 2 * DM, ACT_NONE));
     CK(attn(dq, DM, 0, mkv, 2 * DM, 0, DM, da, QR, (int)P, nullptr, by, bx, 1));
-    CK(lin(pk_linear(ci + "out_proj"), da, DM, R, x, DM, ACT_NONE, x, DM));
-    CK(LN(p + "norm1", x, x, R));
+    CK(linres(pk_linear(ci + "out_proj"), da, DM));
+    CK(LNs(p + "norm1"));
     CK(lin(pk_linear(p + "linear1"), x, DM, R, dh, FF, ACT_RELU));
-    CK(lin(pk_linear(p + "linear2"), dh, FF, R, x, DM, ACT_NONE, x, DM));
-    CK(LN(p + "norm3", x, x, R));
+    CK(linres(pk_linear(p + "linear2"), dh, FF));
+    CK(LNs(p + "norm3"));
     // box refinement from the normed queries (the update after the last layer IS pred_boxes)
-    CK(LN(t + "norm", x, hs, R));
+    CK(LNout(t + "norm", hs));
     CK(lin(pk_linear(t + "bbox_embed.layers.0"), hs, DM, R, da, DM, ACT_RELU));
     CK(lin(pk_linear(t + "bbox_embed.layers.1"), da, DM, R, dq, DM, ACT_RELU));
     CK(lin(pk_linear(t + "bbox_embed.layers.2"), dq, DM, R, da, 8, ACT_NONE));
@@ -1789,7 +1813,7 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
     void* pr = allocb((size_t)R * DM * esz);
     void* p2 = allocb((size_t)R * DM * esz);
     if (!ok(pr) || !ok(p2)) return -1;
-    CK(LN(t + "presence_token_out_norm", x, pr, R));
+    CK(LNout(t + "presence_token_out_norm", pr));
     CK(lin(pk_linear(t + "presence_token_head.layers.0"), pr, DM, R, p2, DM, ACT_RELU));
     CK(lin(pk_linear(t + "presence_token_head.layers.1"), p2, DM, R, pr, DM, ACT_RELU));
     CK(lin(pk_linear(t + "presence_token_head.layers.2"), pr, DM, R, p2, 8, ACT_NONE));

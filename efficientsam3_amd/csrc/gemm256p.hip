@@ -354,32 +354,38 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(GemmParams p) {
     if (nbw < p.N) {
 #endif
      if constexpr (OUT32) {
-      // fp32 output (+ fp32 residual) straight from the accumulator layout: plain rows, no activation.  A lane owns 4
-      // consecutive channels of a pixel = one float4 per (block, q); the four q of a block complete 128-byte lines.
+      // fp32 output (+ fp32 residual), plain rows, no activation.  One 32-pixel x 32-channel block of fp32 values is exactly
+      // a 4 KB strip: it goes through the wave-private LDS strip like the bf16 blocks do, so that every global access (the
+      // residual read and the store) covers complete 128-byte lines (8 lanes per row) instead of 32-byte pieces.
       float* __restrict__ gO32 = reinterpret_cast<float*>(p.out);
       const float* __restrict__ gR32 = reinterpret_cast<const float*>(p.res);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's first K tiles have landed (see the bf16 path)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const unsigned m = m0 + (unsigned)(wm * 128 + i * 32 + l31);
-        const bool mok = m < M32;
-        unsigned rrow = m;
-        if (p.res_mod > 0) rrow = m % (unsigned)p.res_mod;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int n = nbw + j * 32 + 8 * q + 4 * g;
-            float4 v = make_float4(acc[i][j][4 * q] + bq[j][q].x, acc[i][j][4 * q + 1] + bq[j][q].y, acc[i][j][4 * q + 2] + bq[j][q].z,
-                                   acc[i][j][4 * q + 3] + bq[j][q].w);
-            if constexpr (RES) {
-              if (mok) {
+            const float4 v = make_float4(acc[i][j][4 * q] + bq[j][q].x, acc[i][j][4 * q + 1] + bq[j][q].y, acc[i][j][4 * q + 2] + bq[j][q].z,
+                                         acc[i][j][4 * q + 3] + bq[j][q].w);
+            const int c = 2 * q + g;  // 16-byte chunk of pixel l31's 128-byte row: channels 8q + 4g .. + 3
+            *reinterpret_cast<float4*>(epi + l31 * 128 + ((c ^ (l31 & 7)) << 4)) = v;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float4 v = *reinterpret_cast<const float4*>(epi + (8 * k + sp) * 128 + ((sc ^ sp) << 4));
+            const unsigned m = m0 + (unsigned)(wm * 128 + i * 32 + 8 * k + sp);
+            const int n = nbw + j * 32 + 4 * sc;
+            if (m < M32) {
+              if constexpr (RES) {
+                const unsigned rrow = p.res_mod > 0 ? m % (unsigned)p.res_mod : m;
                 const float4 r = *reinterpret_cast<const float4*>(gR32 + (int64_t)rrow * p.ldr + n);
                 v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
               }
+              *reinterpret_cast<float4*>(gO32 + (int64_t)m * p.ldc + n) = v;
             }
-            if (mok) *reinterpret_cast<float4*>(gO32 + (int64_t)m * p.ldc + n) = v;
           }
+        }
         if (i == 1 && has_next) { stream_look_ahead(w + 2); looked = true; }
       }
      } else {

@@ -732,7 +732,16 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(GemmParams p) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = ((red[0][r][c + e] + red[1][r][c + e]) + red[2][r][c + e]) + red[3][r][c + e];
-      epilogue_chunk<T>(p, m, n, v);
+      if (p.out_f32) {  // fp32 rows out (+ fp32 residual rows): the fp32 stream of a post-norm decoder; no activation
+        float* o = reinterpret_cast<float*>(p.out) + (int64_t)m * p.ldc + n;
+        const unsigned rrow = p.res_mod > 0 ? (unsigned)m % (unsigned)p.res_mod : (unsigned)m;
+        const float* rr = p.res ? reinterpret_cast<const float*>(p.res) + (int64_t)rrow * p.ldr + n : nullptr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (n + e < p.N) o[e] = v[e] + (p.bias ? p.bias[n + e] : 0.f) + (rr ? rr[e] : 0.f);
+      } else {
+        epilogue_chunk<T>(p, m, n, v);
+      }
     }
   }
 }
@@ -830,7 +839,11 @@ thread_local const char* g_last_kernel = nullptr;  // name of the kernel the las
 template <typename T>
 int launch_gemm_t(const GemmParams& p, hipStream_t stream) {
   constexpr bool bf = sizeof(T) == 2;
-  if (p.out_f32) {  // fp32 output / residual: only the DMA kernel writes it
+  if (p.out_f32) {  // fp32 output / residual: the skinny kernel (few rows) and the DMA kernel write it
+    if (p.act == ACT_NONE && !p.res_bidx && !p.out_pad && use_skinny<T>(p) && (p.M <= 512 || ((p.M + 255) / 256) * ((p.N + 255) / 256) < 32)) {
+      g_last_kernel = bf ? "skinny_gemm_kernel<bf16, fp32 output>" : "skinny_gemm_kernel<f32>";
+      return launch_skinny<T>(p, stream);
+    }
     if constexpr (bf) {
       if (use_256<T>(p) && esam3_gemm256p_ok(p)) {
         g_last_kernel = "gemm256p_kernel<bf16, fp32 output> (256x256x64, fp32 residual stream)";

@@ -14,11 +14,12 @@ from efficientsam3_amd import schema, synth
 
 SAMPLE = 8192
 BF16_FACTOR = 1.5  # engine-bf16 error allowed as a multiple of the reference's own bf16 error (tests/util.py)
-# Named exception (tests/util.py BF16_EXCEPTIONS, [stream]): the 200-query decoder state and the 5184-token fusion memory
-# are residual streams the reference's autocast keeps in fp32 and the engine stores in bf16.  Measured on MI355X: class
-# logits 0.022-0.036 against 0.013 for the reference's own bf16 run (x 2.8), boxes 0.029 / 0.013, presence logit
-# 0.006-0.015 / 0.0015; the mask logits (0.68 / 1.06) are inside the 1.5 x rule.
-PCS_BF16_STREAM_FACTOR = 3.0
+# Since the detector's 200-query decoder stream is kept in fp32 (as the reference's autocast keeps it), the fixture cases
+# (same image and prompts as the yardstick run) are inside the 1.5 x rule on every output: class logits 0.010-0.011
+# against 0.013 for the reference's own bf16 run, boxes 0.014-0.017 / 0.012-0.014, mask logits 0.50-0.55 / 0.93-1.06.
+# The config-4 batch-8 test compares four OTHER image / prompt pairs with a yardstick that was measured on one image:
+# its limit is 2 x that figure (measured 0.011-0.017 / 0.010 on the class logits, 0.016-0.019 / 0.015 on the boxes).
+PCS_OTHER_INPUTS_FACTOR = 2.0
 PRESENCE_BF16_ULP = 2.0 ** -6  # the presence logit is ONE number per image (about -2): one bf16 ulp at that magnitude
 
 
@@ -90,8 +91,8 @@ def test_pcs_engine_vs_golden(pcs_gold, pcs_sd, mode):
     for pi in range(len(man["prompts"])):
         y = yard[man["prompts"][pi]]
         lim = dict(logits=1e-4, boxes=1e-4, presence=1e-4, masks=2e-3) if mode == "f32" else \
-            dict(logits=PCS_BF16_STREAM_FACTOR * y["pred_logits"], boxes=PCS_BF16_STREAM_FACTOR * y["pred_boxes"],
-                 presence=PCS_BF16_STREAM_FACTOR * y["presence_logit_dec"] + PRESENCE_BF16_ULP, masks=BF16_FACTOR * y["pred_masks"])
+            dict(logits=BF16_FACTOR * y["pred_logits"], boxes=BF16_FACTOR * y["pred_boxes"],
+                 presence=BF16_FACTOR * y["presence_logit_dec"] + PRESENCE_BF16_ULP, masks=BF16_FACTOR * y["pred_masks"])
         state["backbone_out"]["language_features"] = torch.from_numpy(g[f"{pi}_language_features"]).to("cuda")
         state["backbone_out"]["language_mask"] = torch.from_numpy(g[f"{pi}_language_mask"]).to("cuda")
         out = model.forward_grounding(state["backbone_out"], geometric_prompt=model._get_dummy_prompt())
@@ -175,7 +176,14 @@ def test_pcs_engine_geometric_prompts_vs_golden(pcs_gold, pcs_sd, mode):
     proc = Sam3Processor(model, confidence_threshold=man["confidence_threshold"])
     img = synth.smooth_image_u8(seed=1)
     state = proc.set_image(torch.from_numpy(np.ascontiguousarray(np.moveaxis(img, -1, 0))))
-    lim = dict(f32=dict(logits=1e-4, boxes=1e-4, presence=1e-4, masks=2e-3), bf16=dict(logits=0.08, boxes=0.06, presence=0.08, masks=2.5))[mode]
+    # bf16: the geometric cases have no reference-bf16 run of their own: 2 x the model's yardstick on the text cases (same image)
+    with open(os.path.join(os.path.dirname(__file__), "golden", "pcs_ev_m", "bf16ref_manifest.json")) as f:
+        yard = json.load(f)["cases"]
+    ymax = {k: max(c[k] for c in yard.values()) for k in ("pred_logits", "pred_boxes", "presence_logit_dec", "pred_masks")}
+    lim = dict(f32=dict(logits=1e-4, boxes=1e-4, presence=1e-4, masks=2e-3),
+               bf16=dict(logits=PCS_OTHER_INPUTS_FACTOR * ymax["pred_logits"], boxes=PCS_OTHER_INPUTS_FACTOR * ymax["pred_boxes"],
+                         presence=PCS_OTHER_INPUTS_FACTOR * ymax["presence_logit_dec"] + PRESENCE_BF16_ULP,
+                         masks=PCS_OTHER_INPUTS_FACTOR * ymax["pred_masks"]))[mode]
     fpn = state["backbone_out"]["_esam3_nhwc_sam3"]
     for name in man["geometric_cases"]:
         lf = torch.from_numpy(g[f"{name}_language_features"]).to("cuda")
@@ -255,9 +263,9 @@ def test_config4_batch_8_is_image_independent():
         yard = json.load(f)["cases"]
     y = {k: max(c[k] for c in yard.values()) for k in keys}
     lims = dict(f32=dict(pred_logits=1e-4, pred_boxes=1e-4, presence_logit_dec=1e-4, pred_masks=4e-3),
-                bf16=dict(pred_logits=PCS_BF16_STREAM_FACTOR * y["pred_logits"], pred_boxes=PCS_BF16_STREAM_FACTOR * y["pred_boxes"],
-                          presence_logit_dec=PCS_BF16_STREAM_FACTOR * y["presence_logit_dec"] + PRESENCE_BF16_ULP,
-                          pred_masks=PCS_BF16_STREAM_FACTOR * y["pred_masks"]))
+                bf16=dict(pred_logits=PCS_OTHER_INPUTS_FACTOR * y["pred_logits"], pred_boxes=PCS_OTHER_INPUTS_FACTOR * y["pred_boxes"],
+                          presence_logit_dec=PCS_OTHER_INPUTS_FACTOR * y["presence_logit_dec"] + PRESENCE_BF16_ULP,
+                          pred_masks=PCS_OTHER_INPUTS_FACTOR * y["pred_masks"]))
     for mode in ("bf16", "f32"):
         model = build_sam3_image_model(device="cuda", enable_inst_interactivity=False, dtype=mode, state_dict=sd,
                                        text_encoder_type="MobileCLIP-S0", text_encoder_context_length=16)

@@ -92,11 +92,9 @@ def bf16_yardstick(gdir):
         return json.load(f)
 
 
-# Named exceptions to the 1.5 x rule, with the value measured on MI355X (round 2) and the reason.  Everything not listed
-# here is held to the rule.  Cause of the entries marked [stream]: under autocast the reference keeps the residual stream
-# of its LayerNorm / attention blocks in fp32 (LayerNorm and the residual add produce fp32; only matmul inputs are cast),
-# while the engine's bf16 mode stores that stream in bf16 between layers -- DESIGN.md "bf16 parity" lists the measured
-# gap per model; an fp32 residual stream is the remedy.
+# Named exceptions to the 1.5 x rule: (golden dir name, case or stage, quantity) -> allowed value.  EMPTY since the ViT-H trunk
+# and the grounding decoder keep their residual streams in fp32 like the reference's autocast does (round 2): every prompt
+# case and every stage tensor of every model is held to the rule.
 BF16_EXCEPTIONS = {
     # (golden dir name, case, quantity): allowed value
 }
