@@ -100,38 +100,51 @@ def _fpn(frame):
     return [torch.randn((1, c, s, s), generator=g) for c, s in ((4, 8), (8, 4), (16, 2))]
 
 
-def _chunk_worker(rank, world, port, begin, num_frames, q):
+def _chunk_worker(rank, world, port, begin, num_frames, q, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank))
-    esdist.init_process_group("gloo")
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    esdist.init_process_group(backend)
+    dev = torch.device("cuda", rank) if backend == "nccl" else torch.device("cpu")
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
     try:
         end = min(begin + world, num_frames)
         mine = esdist.local_frame_index(begin, end, rank)
         # non-contiguous input on purpose: the helper must make it contiguous
-        out_local = {k: (v.transpose(-1, -2).contiguous().transpose(-1, -2) if v.dim() == 4 else v)
+        out_local = {k: (v.transpose(-1, -2).contiguous().transpose(-1, -2) if v.dim() == 4 else v).to(dev)
                      for k, v in _detector_out(mine).items()}
-        buf = esdist.gather_detector_chunk(out_local, begin, num_frames, sam2_fpn=_fpn(mine), vision_pos_enc="pos",
+        buf = esdist.gather_detector_chunk(out_local, begin, num_frames, sam2_fpn=[x.to(dev) for x in _fpn(mine)], vision_pos_enc="pos",
                                            async_op=True)
         res = {}
         for f, fb in buf.items():
             for k, (t, h) in fb.items():
                 if h is not None:
                     h.wait()
-            res[f] = {k: (t.float().numpy() if torch.is_tensor(t) else t) for k, (t, h) in fb.items()}
+            res[f] = {k: (t.float().cpu().numpy() if torch.is_tensor(t) else t) for k, (t, h) in fb.items()}
         q.put((rank, mine, res))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.gpu
 @pytest.mark.parametrize("begin,num_frames", [(0, 7), (6, 7)])
-def test_detector_chunk_all_gather(begin, num_frames):
+def test_detector_chunk_all_gather_rccl(begin, num_frames):
+    """The same chunk exchange with device tensors over RCCL (backend "nccl") between two GPUs of one node; skipped on a
+    single-GPU box."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    test_detector_chunk_all_gather(begin, num_frames, backend="nccl")
+
+
+@pytest.mark.parametrize("begin,num_frames", [(0, 7), (6, 7)])
+def test_detector_chunk_all_gather(begin, num_frames, backend="gloo"):
     """Sam3ImageOnVideoMultiGPU's chunk exchange (sam3_image.py:792-883) on gloo: every rank ends with the detector
     outputs and bf16 SAM2 features of every frame of the chunk; frames past the end of the video are dropped."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_chunk_worker, args=(r, world, port, begin, num_frames, q)) for r in range(world)]
+    procs = [ctx.Process(target=_chunk_worker, args=(r, world, port, begin, num_frames, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]
