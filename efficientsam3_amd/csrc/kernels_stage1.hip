@@ -1,6 +1,7 @@
-// Stage-1 distillation loss, forward (stage1/train_image_encoder_stage1.py:271-307): masked MSE and
-// masked cosine loss between the student embedding and the teacher embedding, both [B][HW][C] token-major (NHWC).
-// HBM-bound: each embedding is read exactly once; fixed-order reductions (no atomics).
+// Stage-1 distillation loss, forward and dL/dpreds (stage1/train_image_encoder_stage1.py:186-210,271-307):
+// masked MSE and masked cosine loss between the student embedding and the teacher embedding, both [B][HW][C] token-major
+// (NHWC), and the gradient of  masked_mse + w * masked_cosine_loss  with respect to the student embedding.
+// HBM-bound: each embedding is read once (twice by the backward kernel, the second time out of L2); fixed-order reductions.
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
@@ -124,6 +125,123 @@ int launch_pixel(int teacher_dtype, const void* preds, const void* teacher, floa
   return 0;
 }
 
+// per image: 1 / max(#valid, 1)
+__global__ __launch_bounds__(256) void valid_recip_kernel(const uint8_t* __restrict__ valid, int HW, float* __restrict__ out) {
+  __shared__ int sc[256];
+  const int b = blockIdx.x;
+  int n = 0;
+  for (int i = threadIdx.x; i < HW; i += 256) n += valid[(int64_t)b * HW + i] ? 1 : 0;
+  sc[threadIdx.x] = n;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sc[threadIdx.x] += sc[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[b] = 1.f / fmaxf((float)sc[0], 1.f);
+}
+
+template <int DP> struct Store8;
+template <> struct Store8<0> {
+  static __device__ inline void st(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+template <> struct Store8<1> {
+  static __device__ inline void st(uint16_t* p, const float* v) {
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = o;
+  }
+};
+
+// dL/dpreds of  L = mean_b [ sum_valid |p - t|^2 / n_b ] + w * mean_b [ sum_valid (1 - cos(p, t)) / n_b ]  (times grad_scale,
+// e.g. 1 / ACCUMULATION_STEPS): for a valid pixel of image b
+//   g = s_b * ( 2 (p - t)  -  w * ( t - (p.t / |p|^2) p ) / (|p| |t|) ),   s_b = grad_scale / (B n_b);   0 for masked pixels.
+// (F.cosine_similarity clamps each norm at 1e-8: a clamped |p| is a constant, so its p-term vanishes.)  One wavefront per pixel.
+template <int DP, int DTT>
+__global__ __launch_bounds__(256) void distill_backward_kernel(const typename Elem<DP>::type* __restrict__ preds,
+                                                               const typename Elem<DTT>::type* __restrict__ teacher,
+                                                               const uint8_t* __restrict__ valid, const float* __restrict__ recip_n,
+                                                               typename Elem<DP>::type* __restrict__ grad, int64_t n_pix, int HW,
+                                                               int C, float w_cos, float scale_over_b) {
+  const int lane = threadIdx.x & 63;
+  const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= n_pix) return;
+  const auto* p = preds + pix * C;
+  const auto* t = teacher + pix * C;
+  auto* g = grad + pix * C;
+  if (!valid[pix]) {
+    const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c0 = lane * 8; c0 < C; c0 += 512) Store8<DP>::st(g + c0, z);
+    return;
+  }
+  float dot = 0.f, np_ = 0.f, nt = 0.f;
+  for (int c0 = lane * 8; c0 < C; c0 += 512) {
+    float a[8], b[8];
+    Elem<DP>::load8(p + c0, a);
+    Elem<DTT>::load8(t + c0, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      dot = fmaf(a[e], b[e], dot);
+      np_ = fmaf(a[e], a[e], np_);
+      nt = fmaf(b[e], b[e], nt);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    dot += __shfl_xor(dot, o, 64);
+    np_ += __shfl_xor(np_, o, 64);
+    nt += __shfl_xor(nt, o, 64);
+  }
+  const float s = scale_over_b * recip_n[pix / HW];
+  const float lp = sqrtf(np_), lt = sqrtf(nt);
+  const float inv = 1.f / (fmaxf(lp, 1e-8f) * fmaxf(lt, 1e-8f));
+  const float kt = -w_cos * inv;                                   // coefficient of t
+  const float kp = lp > 1e-8f ? w_cos * inv * dot / np_ : 0.f;     // coefficient of p from d|p|
+  for (int c0 = lane * 8; c0 < C; c0 += 512) {
+    float a[8], b[8], o[8];
+    Elem<DP>::load8(p + c0, a);
+    Elem<DTT>::load8(t + c0, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = s * (2.f * (a[e] - b[e]) + kt * b[e] + kp * a[e]);
+    Store8<DP>::st(g + c0, o);
+  }
+}
+
+template <int DP>
+int launch_backward(int teacher_dtype, const void* preds, const void* teacher, const uint8_t* valid, const float* recip, void* grad,
+                    int64_t n_pix, int HW, int C, float w, float sb, hipStream_t s) {
+  const dim3 grid((unsigned)((n_pix + 3) / 4));
+  using P = typename Elem<DP>::type;
+  if (teacher_dtype == 0) hipLaunchKernelGGL((distill_backward_kernel<DP, 0>), grid, dim3(256), 0, s, (const P*)preds, (const float*)teacher, valid, recip, (P*)grad, n_pix, HW, C, w, sb);
+  else if (teacher_dtype == 1) hipLaunchKernelGGL((distill_backward_kernel<DP, 1>), grid, dim3(256), 0, s, (const P*)preds, (const uint16_t*)teacher, valid, recip, (P*)grad, n_pix, HW, C, w, sb);
+  else hipLaunchKernelGGL((distill_backward_kernel<DP, 2>), grid, dim3(256), 0, s, (const P*)preds, (const __half*)teacher, valid, recip, (P*)grad, n_pix, HW, C, w, sb);
+  return 0;
+}
+
+}  // namespace
+
+int esam3_distill_loss_backward(int preds_dtype, const void* preds_dev, int teacher_dtype, const void* teacher_dev,
+                                const uint8_t* valid_dev, int B, int HW, int C, float cosine_weight, float grad_scale,
+                                void* grad_preds_dev, float* scratch_dev, void* stream) {
+  if (!preds_dev || !teacher_dev || !valid_dev || !grad_preds_dev || !scratch_dev || B <= 0 || HW <= 0 || C <= 0 || C % 8 ||
+      preds_dtype < 0 || preds_dtype > 1 || teacher_dtype < 0 || teacher_dtype > 2) {
+    esam3_set_error("esam3_distill_loss_backward: bad argument (B=%d HW=%d C=%d dtypes %d/%d; C must be a multiple of 8)", B, HW, C,
+                    preds_dtype, teacher_dtype);
+    return -1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(valid_recip_kernel, dim3((unsigned)B), dim3(256), 0, s, valid_dev, HW, scratch_dev);
+  const int64_t n_pix = (int64_t)B * HW;
+  const float sb = grad_scale / (float)B;
+  if (preds_dtype == 0) launch_backward<0>(teacher_dtype, preds_dev, teacher_dev, valid_dev, scratch_dev, grad_preds_dev, n_pix, HW, C, cosine_weight, sb, s);
+  else launch_backward<1>(teacher_dtype, preds_dev, teacher_dev, valid_dev, scratch_dev, grad_preds_dev, n_pix, HW, C, cosine_weight, sb, s);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+namespace {
 }  // namespace
 
 int esam3_distill_loss(int preds_dtype, const void* preds_dev, int teacher_dtype, const void* teacher_dev,

@@ -203,3 +203,71 @@ def gather_detector_chunk(out_local: dict, frame_idx_begin: int, num_frames: int
             fb["tracker_backbone_pos_enc"] = (vision_pos_enc, None)
         buf[f] = fb
     return buf
+
+
+# ---- stage-1 training: the gradient exchange of data-parallel distillation ------------------------
+class GradientAllReducer:
+    """Bucketed averaging all-reduce of a list of gradient tensors across the data-parallel ranks -- the exchange
+    ``torch.nn.parallel.DistributedDataParallel`` performs for the student trunk in stage 1
+    (stage1/train_image_encoder_stage1.py:67-72).  Gradients are packed, in the order given, into flat buckets of about
+    ``bucket_bytes`` (xGMI rings are per-link bound: a few large collectives beat many small ones; the default 64 MB is one
+    bucket for an EV-M trunk and a handful for ViT-H), each bucket is reduced with one asynchronous ``all_reduce`` issued
+    as soon as it is full (so buckets overlap with whatever produces the later gradients), and ``finish()`` waits,
+    divides by the world size and scatters the averages back into the original tensors.  The flat buckets are allocated
+    once and reused every step.  Backend "nccl" is RCCL on ROCm; gloo serves the CPU tests."""
+
+    def __init__(self, params: Sequence[torch.Tensor], bucket_bytes: int = 64 << 20, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets: List[dict] = []
+        cur, cur_bytes = [], 0
+        for i, p in enumerate(params):
+            nbytes = p.numel() * p.element_size()
+            if cur and (cur_bytes + nbytes > bucket_bytes or p.dtype != params[cur[0]].dtype or p.device != params[cur[0]].device):
+                self._close(params, cur)
+                cur, cur_bytes = [], 0
+            cur.append(i)
+            cur_bytes += nbytes
+        if cur:
+            self._close(params, cur)
+        self._pending: List[Tuple[int, object]] = []
+        self._filled = [0] * len(self.buckets)
+
+    def _close(self, params, idx):
+        n = sum(params[i].numel() for i in idx)
+        self.buckets.append({"idx": list(idx), "flat": torch.empty(n, dtype=params[idx[0]].dtype, device=params[idx[0]].device)})
+
+    @property
+    def n_buckets(self) -> int:
+        return len(self.buckets)
+
+    def start(self, grads: Sequence[torch.Tensor]) -> None:
+        """Pack every bucket and issue its all-reduce (asynchronously when a process group exists)."""
+        assert not self._pending, "finish() the previous step first"
+        for bi, b in enumerate(self.buckets):
+            off = 0
+            for i in b["idx"]:
+                g = grads[i]
+                b["flat"][off:off + g.numel()].copy_(g.reshape(-1))
+                off += g.numel()
+            work = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True) if self.world > 1 else None
+            self._pending.append((bi, work))
+
+    def finish(self, grads: Sequence[torch.Tensor]) -> None:
+        """Wait for the buckets, average, and write the result back into ``grads`` (in place)."""
+        for bi, work in self._pending:
+            if work is not None:
+                work.wait()
+            b = self.buckets[bi]
+            if self.world > 1:
+                b["flat"].div_(self.world)
+            off = 0
+            for i in b["idx"]:
+                g = grads[i]
+                g.copy_(b["flat"][off:off + g.numel()].view_as(g))
+                off += g.numel()
+        self._pending = []
+
+    def __call__(self, grads: Sequence[torch.Tensor]) -> None:
+        self.start(grads)
+        self.finish(grads)

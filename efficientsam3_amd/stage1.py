@@ -50,6 +50,27 @@ def distill_loss(preds: torch.Tensor, teacher: torch.Tensor, valid: torch.Tensor
     return m[0], m[1], per
 
 
+def distill_loss_backward(preds: torch.Tensor, teacher: torch.Tensor, valid: torch.Tensor, cosine_weight: float = 0.0,
+                          grad_scale: float = 1.0) -> torch.Tensor:
+    """dL/dpreds of ``masked_mse + cosine_weight * masked_cosine_loss`` times ``grad_scale`` (= 1 / ACCUMULATION_STEPS in
+    stage1/train_image_encoder_stage1.py:186-210): [B, HW, C] in the dtype of ``preds``, zero at masked pixels -- the tensor
+    ``loss.backward()`` hands to the student trunk."""
+    assert preds.is_cuda and teacher.is_cuda and valid.is_cuda
+    assert preds.dim() == 3 and preds.shape == teacher.shape and preds.dtype in (torch.float32, torch.bfloat16)
+    assert teacher.dtype in _DT and valid.dtype == torch.uint8 and tuple(valid.shape) == tuple(preds.shape[:2])
+    b, hw, c = preds.shape
+    preds, teacher, valid = preds.contiguous(), teacher.contiguous(), valid.contiguous()
+    grad = torch.empty_like(preds)
+    scratch = torch.empty((b,), dtype=torch.float32, device=preds.device)
+    lib = _lib.load()
+    with torch.cuda.device(preds.device):
+        _lib.check(lib.esam3_distill_loss_backward(_DT[preds.dtype], preds.data_ptr(), _DT[teacher.dtype], teacher.data_ptr(),
+                                                   valid.data_ptr(), b, hw, c, float(cosine_weight), float(grad_scale),
+                                                   grad.data_ptr(), scratch.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "esam3_distill_loss_backward")
+    return grad
+
+
 def pack_embedding(seed: int, embedding_chw: np.ndarray) -> bytes:
     return np.int32(seed).tobytes() + np.ascontiguousarray(embedding_chw, dtype=np.float16).tobytes()
 

@@ -24,8 +24,9 @@
  *          encoder, DETR decoder, scoring, mask head.
  *   esam3_rle_encode / esam3_rle_to_string / esam3_rle_from_string
  *       <- the evaluation writers' mask -> COCO RLE step (sam3/sam3/train/masks_ops.py:161-250).
- *   esam3_distill_loss
- *       <- masked_mse / masked_cosine_loss of stage-1 distillation (stage1/train_image_encoder_stage1.py:271-307).
+ *   esam3_distill_loss / esam3_distill_loss_backward
+ *       <- masked_mse / masked_cosine_loss of stage-1 distillation (stage1/train_image_encoder_stage1.py:271-307) and the
+ *          gradient of their weighted sum with respect to the student embedding (what loss.backward() hands to the trunk).
  *
  * Conventions: every pointer named *_dev is device memory owned by the caller; tensors are
  * NHWC (channels innermost) in the engine's activation dtype unless stated; all functions
@@ -190,6 +191,13 @@ int64_t esam3_rle_from_string(const char* s, int64_t len, uint32_t* counts_host,
 int esam3_distill_loss(int preds_dtype, const void* preds_dev, int teacher_dtype, const void* teacher_dev,
                        const uint8_t* valid_dev, int B, int HW, int C, float* per_image_dev, float* scratch_dev,
                        void* hip_stream);
+
+/* dL/dpreds of  masked_mse + cosine_weight * masked_cosine_loss  (the loss of stage1/train_image_encoder_stage1.py:186-210),
+ * times grad_scale (1 / ACCUMULATION_STEPS): grad_preds_dev [B][HW][C] in the dtype of preds, zero at masked pixels.
+ * scratch_dev: B floats. */
+int esam3_distill_loss_backward(int preds_dtype, const void* preds_dev, int teacher_dtype, const void* teacher_dev,
+                                const uint8_t* valid_dev, int B, int HW, int C, float cosine_weight, float grad_scale,
+                                void* grad_preds_dev, float* scratch_dev, void* hip_stream);
 
 /* Per-launch timing with HIP events on the launch stream (bench.py roofline leg): enable,
  * run encode/decode, then fetch a JSON report (syncs the device, clears the records). */

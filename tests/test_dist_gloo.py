@@ -244,3 +244,71 @@ def test_bench_respawns_itself_for_multi_gpu(monkeypatch):
     a = seen["argv"]
     assert a[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in a and "127.0.0.1" in a
     assert a[-4:] == ["--gpus", "4", "--steps", "2"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+# ---- GradientAllReducer: the data-parallel gradient exchange of stage 1 ---------------------------------------------
+def _grads(rank, shapes, dtype=torch.float32):
+    g = torch.Generator().manual_seed(4000 + rank)
+    return [torch.randn(s, generator=g).to(dtype) for s in shapes]
+
+
+_GSHAPES = [(64, 3, 3, 3), (64,), (128, 64, 1, 1), (1000,), (7, 5), (300000,), (1,)]
+
+
+def _allreduce_worker(rank, world, port, backend, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    esdist.init_process_group(backend)
+    dev = torch.device("cuda", rank) if backend == "nccl" else torch.device("cpu")
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+    try:
+        grads = [g.to(dev) for g in _grads(rank, _GSHAPES)]
+        red = esdist.GradientAllReducer(grads, bucket_bytes=256 << 10)   # small buckets: several of them, one tensor alone > bucket
+        flats = [b["flat"].data_ptr() for b in red.buckets]
+        for step in range(2):                                            # the flat buckets are reused
+            cur = [g.clone() * (step + 1) for g in grads]
+            red(cur)
+            assert [b["flat"].data_ptr() for b in red.buckets] == flats
+        q.put((rank, red.n_buckets, [c.cpu().numpy() for c in cur]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_allreduce(backend):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_allreduce_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [2 * (a + b) / 2 for a, b in zip(_grads(0, _GSHAPES), _grads(1, _GSHAPES))]   # step 2: grads * 2, averaged
+    for rank, nb, got in results:
+        assert nb >= 3                                                   # (64*27 + 64 + 8192) | 1000 + 35 ... | 300000 alone | ...
+        for g, w in zip(got, want):
+            np.testing.assert_allclose(g, w.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_gradient_allreducer_gloo():
+    """Bucketed averaging all-reduce of a gradient list (stage-1 data parallelism, train_image_encoder_stage1.py:67-72)."""
+    _run_allreduce("gloo")
+
+
+@pytest.mark.gpu
+def test_gradient_allreducer_rccl():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    _run_allreduce("nccl")
+
+
+def test_gradient_allreducer_single_process_is_identity():
+    grads = _grads(0, _GSHAPES)
+    keep = [g.clone() for g in grads]
+    esdist.GradientAllReducer(grads)(grads)
+    for a, b in zip(grads, keep):
+        assert torch.equal(a, b)

@@ -346,3 +346,46 @@ def test_rle_string_decoder_rejects_malformed_input():
     assert dec(b"\x10\x11") == -1             # below '0'
     assert dec(b"o" * 20 + b"0") == -1        # 'o' = continuation bit set, 20 times
     assert dec(b"o") == -1                    # truncated
+
+
+def test_selection_tie_fixtures_and_matching_rule():
+    """tests/util.py: errors_with_ties -- a single-mask prompt may match a recorded alternative of the reference ONLY if the
+    tie manifest lists it, and only within the same limits; the committed manifests are consistent with their arrays."""
+    import json
+    import os
+    from tests import util as U
+    root = os.path.join(os.path.dirname(__file__), "golden")
+    n_alt = 0
+    for d in ("", "repvit_m1.1", "repvit_m2.3", "tinyvit_11m", "sam3_vit_h"):
+        cases, arr = U.load_ties(os.path.join(root, d))
+        assert cases is not None
+        for name, c in cases.items():
+            assert len(c["stability_mask0"]) == len(c["selected"]) == len(c["iou_pred"])
+            for i, alts in c["alternatives"].items():
+                st, sel, iou = c["stability_mask0"][int(i)], c["selected"][int(i)], c["iou_pred"][int(i)]
+                assert sel not in alts and (abs(st - 0.98) < 5e-3 or st < 0.98)
+                for k in alts:
+                    assert arr[f"{name}/alt_low_res/{i}/{k}"].shape == (288, 288)
+                    assert k == 0 or iou[k] >= max(iou[1:]) - 1e-2
+                    n_alt += 1
+    assert n_alt >= 4
+    # the matching rule on synthetic data: prompt 1 of a 2-prompt case has one alternative (mask 3)
+    rng = np.random.default_rng(0)
+    g_low = rng.standard_normal((2, 1, 8, 8)).astype(np.float32)
+    g_iou = np.array([[0.5], [0.6]], np.float32)
+    alt = rng.standard_normal((8, 8)).astype(np.float32)
+    ties = ({"case": {"alternatives": {"1": [3]}}}, {"case/alt_low_res/1/3": alt, "case/alt_iou/1/3": np.float32(0.61)})
+    low = g_low.copy()
+    low[1, 0] = alt + 0.01
+    iou = np.array([[0.5], [0.612]], np.float32)
+    e_low, e_iou, flipped = U.errors_with_ties("case", low, iou, g_low, g_iou, 0.05, 0.01, ties)
+    assert flipped == [1] and e_low <= 0.0101 and e_iou <= 0.0021
+    e_low, _, flipped = U.errors_with_ties("case", low, iou, g_low, g_iou, 0.05, 0.01, (None, None))       # f32 mode: no allowance
+    assert flipped == [] and e_low > 0.5
+    low[0, 0] = alt                                                                                       # prompt 0 has no alternative listed
+    e_low, _, flipped = U.errors_with_ties("case", low, iou, g_low, g_iou, 0.05, 0.01, ties)
+    assert flipped == [1] and e_low > 0.5
+    low[0, 0] = g_low[0, 0]
+    low[1, 0] = alt + 0.2                                                                                 # outside the limit: no match
+    e_low, _, flipped = U.errors_with_ties("case", low, iou, g_low, g_iou, 0.05, 0.01, ties)
+    assert flipped == [] and e_low > 0.5

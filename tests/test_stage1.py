@@ -75,6 +75,40 @@ def test_distill_loss_kernel_vs_reference_values(stage1_gold, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["small", "full"])
+@pytest.mark.parametrize("w_cos", [0.0, 0.5])
+def test_distill_loss_backward_vs_autograd(name, w_cos):
+    """dL/dpreds of masked_mse + w * masked_cosine_loss / ACCUMULATION_STEPS (train_image_encoder_stage1.py:186-210) vs
+    torch.autograd through the oracle's restatement of the two loss functions (itself pinned to the reference's values by
+    test_oracle_loss_matches_reference_values)."""
+    from oracle import ref_stage1
+    b, c, hw, img, sizes = synth.stage1_cases()[name]
+    preds, teacher = synth.stage1_embeddings(name)
+    accum = 2.0
+    pt = torch.from_numpy(preds).clone().requires_grad_(True)          # [B, C, H, W] fp32 on the CPU
+    tt = torch.from_numpy(teacher)
+    mask = ref_stage1.build_valid_mask(img, sizes, (hw, hw))
+    loss = ref_stage1.masked_mse(pt, tt, mask)
+    if w_cos:
+        loss = loss + w_cos * ref_stage1.masked_cosine_loss(pt, tt, mask)
+    (loss / accum).backward()
+    want = pt.grad.permute(0, 2, 3, 1).reshape(b, hw * hw, c)
+    valid = torch.from_numpy(stage1.valid_mask(img, sizes, (hw, hw))).cuda()
+    p = torch.from_numpy(preds).permute(0, 2, 3, 1).reshape(b, hw * hw, c).contiguous().cuda()
+    t = torch.from_numpy(teacher).permute(0, 2, 3, 1).reshape(b, hw * hw, c).contiguous().cuda()
+    scale = float(want.abs().max())
+    for tdt in (torch.float32, torch.float16):          # the teacher values are fp16-representable: same result
+        g = stage1.distill_loss_backward(p, t.to(tdt), valid, cosine_weight=w_cos, grad_scale=1.0 / accum)
+        assert g.dtype == torch.float32 and g.shape == p.shape
+        assert float((g.cpu() - want).abs().max()) <= 2e-6 * max(scale, 1e-30) + 1e-12
+        assert float(g[valid == 0].abs().max() if (valid == 0).any() else 0.0) == 0.0   # masked pixels get no gradient
+    gb = stage1.distill_loss_backward(p.to(torch.bfloat16), t.to(torch.bfloat16), valid, cosine_weight=w_cos, grad_scale=1.0 / accum)
+    assert gb.dtype == torch.bfloat16
+    assert float((gb.float().cpu() - want).abs().max()) <= 3e-2 * scale    # bf16 inputs and output: rounding only
+    assert torch.equal(stage1.distill_loss_backward(p, t, valid, w_cos, 0.5), stage1.distill_loss_backward(p, t, valid, w_cos, 0.5))
+
+
+@pytest.mark.gpu
 def test_paired_forward_composes_trunks_and_loss():
     """BASELINE config 5 (forward): ViT-H teacher trunk + EV-M student trunk on the same images, then the loss.  The
     trunks have their own parity tests (test_students_gpu.py, test_e2e_gpu.py); here the composition is checked:
