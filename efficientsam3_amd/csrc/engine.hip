@@ -903,6 +903,25 @@ int E::backbone_repvit(const float* img, int B, const esam3_image_features* out,
 int E::tv_mbconv(const std::string& p, const T4& x, T4* y) {
   const T4 dst = alloc4(x.B, x.H, x.W, x.C);
   if (!ok(dst.p)) return -1;
+  // bf16, 64 channels (TinyViT-5M / -11M layer 0 at 252^2): conv1 -> GELU -> dw3x3 -> GELU -> conv3 -> + x -> GELU in one kernel, the
+  // 4x-expanded tensor (1 GB at B = 32) stays in the CU (mbconv_fused.hip v2, GELU variant)
+  static const bool no_fused_tv = getenv("ESAM3_NO_FUSED_TV_MBCONV") != nullptr && atoi(getenv("ESAM3_NO_FUSED_TV_MBCONV")) != 0;  // A/B timing
+  if (!no_fused_tv && x.C == 64 && x.ld == x.C && esam3_mbconv_fused2_ok(dtype, 64, 256, 64, 1)) {
+    PackedGemm* g1 = pk_conv(p + "conv1.c.weight", "", p + "conv1.bn");
+    PackedGemm* g2 = pk_conv(p + "conv3.c.weight", "", p + "conv3.bn");
+    PackedDw* dw = pk_dw(p + "conv2.c.weight", "", p + "conv2.bn");
+    if (!g1 || !g2 || !dw) return -1;
+    if (g1->N == 256 && g1->cin == 64 && g2->N == 64 && g2->cin == 256 && dw->C == 256 && dw->ks == 3 && g1->bias && g2->bias) {
+      *y = dst;
+      if (dry) return 0;
+      const double px = (double)x.rows();
+      return prof_launch("mbconv_fused_gelu:" + p.substr(p.size() > 40 ? p.size() - 40 : 0), 2.0 * px * 256 * (64 + 9 + 64),
+                         px * 64 * 3 * (double)esz, [&]() {
+                           return esam3_launch_mbconv_fused(dtype, x.p, y->p, g1->w, g1->Kp, g1->bias, dw->w, dw->bias, g2->w, g2->Kp,
+                                                            g2->bias, x.B, x.H, x.W, 64, 256, 64, 1, /*shortcut + GELU variant*/ 3, st);
+                         });
+    }
+  }
   const size_t mk = arena.mark();
   T4 a, d;
   CK(conv_bn(p + "conv1", x, 1, ACT_GELU, &a));

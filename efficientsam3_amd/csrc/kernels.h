@@ -156,6 +156,8 @@ int esam3_launch_zero_border(int dtype, void* x, int B, int Hp, int Wp, int C, h
 size_t esam3_mbconv_fused_lds(int dtype, int Cin, int Cmid, int Cout, int stride);
 // true when esam3_launch_mbconv_fused runs this shape on the v2 kernel (bf16, EfficientViT-B1 stage 1-3 shapes)
 bool esam3_mbconv_fused2_ok(int dtype, int Cin, int Cmid, int Cout, int stride);
+// `residual`: bit 0 = identity shortcut; bit 1 (v2 shape 64 -> 64, stride 1 only) = TinyViT MBConv: GELU instead of Hardswish after
+// the expand and the depthwise conv, and a GELU after the shortcut add (tiny_vit.py:73-108)
 int esam3_launch_mbconv_fused(int dtype, const void* x, void* out, const void* w1, int Kp1, const float* b1,
                               const float* wd, const float* bd, const void* w2, int Kp2, const float* b2, int B,
                               int H, int W, int Cin, int Cmid, int Cout, int stride, int residual,

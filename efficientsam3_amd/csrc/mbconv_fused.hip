@@ -29,6 +29,7 @@ struct MbParams {
   const float* b2;   // [Cout]
   int B, H, W, OH, OW, Cin, Cmid, Cout, Kp1, Kp2;
   int residual;      // 1: out += x (stride 1, Cin == Cout)
+  int gelu;          // v2 only, 1: TinyViT MBConv (tiny_vit.py:73-108): GELU after expand and depthwise, and after the shortcut add
   int x_pitch;       // bytes per pixel row of the x tile in LDS (Cin padded to a 32-byte chunk)
   int tiles_x, tiles_y;
 };
@@ -36,6 +37,7 @@ struct MbParams {
 __device__ __forceinline__ float hswish(float x) {
   return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
 }
+template <bool GELU> __device__ __forceinline__ float actf(float x) { return GELU ? gelu_fast(x) : hswish(x); }
 
 // 16-byte slot swizzle for a tile with `slots` 16-byte slots per row (power of two), so that
 // 16 consecutive rows at the same logical slot fall into 16 different bank slots
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void mbconv_fused_kernel(MbParams p) {
 //     packed cells in registers and its 9 x 8 weights in registers (2.25 - 4.5 LDS reads per output instead of 9).
 // Template: stride, Cin, Cout (the EfficientViT-B1 MBConv shapes of stages 1-3, backbone.py:91-147); Cmid % 64 == 0.
 // ======================================================================================
-template <int S, int CIN, int COUT>
+template <int S, int CIN, int COUT, bool GELU = false>
 __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mbconv_fused2_kernel(MbParams p) {
   typedef bf16_t T;
   constexpr int TH = 8, TW = S == 1 ? 16 : 8;          // output tile
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mbconv_fused2_kernel
           for (int q = 0; q < 4; ++q) {
             const float bb[4] = {b1v[q].x, b1v[q].y, b1v[q].z, b1v[q].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * q + e] = in ? hswish(acc[4 * q + e] + bb[e]) : 0.f;
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = in ? actf<GELU>(acc[4 * q + e] + bb[e]) : 0.f;
           }
 #pragma unroll
           for (int qp = 0; qp < 2; ++qp) {
@@ -468,8 +470,8 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mbconv_fused2_kernel
             a[3] = fmaf(m[3], w.w, a[3]);
           }
         uint2 o;
-        o.x = pack_bf16x2(hswish(a[0]), hswish(a[1]));
-        o.y = pack_bf16x2(hswish(a[2]), hswish(a[3]));
+        o.x = pack_bf16x2(actf<GELU>(a[0]), actf<GELU>(a[1]));
+        o.y = pack_bf16x2(actf<GELU>(a[2]), actf<GELU>(a[3]));
         const int op = (doy0 + r) * TW + dox;
         *reinterpret_cast<uint2*>(dwo + op * 128 + swz(op, cg >> 1) + (cg & 1) * 8) = o;
       }
@@ -516,6 +518,10 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mbconv_fused2_kernel
           v[4 * q + 2] += __uint_as_float(u.y << 16); v[4 * q + 3] += __uint_as_float(u.y & 0xffff0000u);
         }
       }
+      if constexpr (GELU) {  // TinyViT: the activation follows the shortcut add
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = gelu_fast(v[e]);
+      }
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp) {
         const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
@@ -531,13 +537,13 @@ __global__ __launch_bounds__(256, (CIN >= 64 ? 2 : 3)) void mbconv_fused2_kernel
   }
 }
 
-template <int S, int CIN, int COUT>
+template <int S, int CIN, int COUT, bool GELU = false>
 int launch_mb2(MbParams p, hipStream_t stream) {
   constexpr int TH = 8, TW = S == 1 ? 16 : 8;
   p.tiles_x = (p.OW + TW - 1) / TW;
   p.tiles_y = (p.OH + TH - 1) / TH;
   const unsigned grid = (unsigned)p.B * p.tiles_x * p.tiles_y;
-  hipLaunchKernelGGL((mbconv_fused2_kernel<S, CIN, COUT>), dim3(grid), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((mbconv_fused2_kernel<S, CIN, COUT, GELU>), dim3(grid), dim3(256), 0, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -594,7 +600,12 @@ int esam3_launch_mbconv_fused(int dtype, const void* x, void* out, const void* w
     MbParams q{};
     q.x = x; q.out = out; q.w1 = w1; q.b1 = b1; q.wd = wd; q.bd = bd; q.w2 = w2; q.b2 = b2;
     q.B = B; q.H = H; q.W = W; q.OH = (H + stride - 1) / stride; q.OW = (W + stride - 1) / stride;
-    q.Cin = Cin; q.Cmid = Cmid; q.Cout = Cout; q.Kp1 = Kp1; q.Kp2 = Kp2; q.residual = residual;
+    q.Cin = Cin; q.Cmid = Cmid; q.Cout = Cout; q.Kp1 = Kp1; q.Kp2 = Kp2; q.residual = residual & 1; q.gelu = (residual >> 1) & 1;
+    if (q.gelu) {  // TinyViT MBConv: one instantiated shape (64 -> 256 -> 64, stride 1)
+      if (stride == 1 && Cin == 64 && Cout == 64) return launch_mb2<1, 64, 64, true>(q, stream);
+      esam3_set_error("mbconv_fused: the GELU variant is built for 64 -> 64 channels, stride 1");
+      return -1;
+    }
     if (stride == 2 && Cin == 16) return launch_mb2<2, 16, 32>(q, stream);
     if (stride == 2 && Cin == 32) return launch_mb2<2, 32, 64>(q, stream);
     if (stride == 2) return launch_mb2<2, 64, 128>(q, stream);
