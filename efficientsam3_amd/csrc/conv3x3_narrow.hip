@@ -270,13 +270,8 @@ template <int NT, int KC, int MT>
 int launch_nt(const GemmParams& p, hipStream_t stream) {
   constexpr size_t lds = 2 * (size_t)Geo<NT, KC, MT>::BUF;
   static_assert(lds <= 163840, "conv3x3_narrow: the two staging buffers exceed a CU's LDS");
-  static bool attr_set = false;
   auto kern = conv3x3_narrow_kernel<NT, KC, MT>;
-  if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds));
-    attr_set = true;
-  }
+  if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)) return -1;
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;

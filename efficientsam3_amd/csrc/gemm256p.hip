@@ -27,6 +27,7 @@
 // Hazards (DMA write -> ds_read, ds_read -> DMA overwrite) are ordered by counted waits followed by a barrier
 // that every reader / writer passes; the derivation is in DESIGN.md ("gemm256p: phase schedule").
 #include "gemm_common.h"
+#include "kernels.h"
 
 #ifdef ESAM3_P_TRACE  /* dev build only (tools/dev_variants.sh): cycle stamps of workgroups 0-7, waves 0 and 4 */
 __device__ unsigned long long g_trace[8 * 2 * 16 * 16];
@@ -567,19 +568,12 @@ bool esam3_gemm256p_ok(const GemmParams& p) {
 
 int esam3_launch_gemm256p(const GemmParams& p, hipStream_t stream) {
   constexpr size_t lds = 163840;  // 2 x 64 KB K-tile buffers + 8 x 4 KB epilogue strips = all of a CU's LDS
-  static bool attr_set = false;
   void (*kerns[10])(GemmParams) = {
       gemm256p_kernel<ACT_NONE, false>, gemm256p_kernel<ACT_RELU, false>, gemm256p_kernel<ACT_GELU, false>,
       gemm256p_kernel<ACT_HSWISH, false>, gemm256p_kernel<ACT_SIGMOID, false>,
       gemm256p_kernel<ACT_NONE, true>, gemm256p_kernel<ACT_RELU, true>, gemm256p_kernel<ACT_GELU, true>,
       gemm256p_kernel<ACT_HSWISH, true>, gemm256p_kernel<ACT_SIGMOID, true>};
   if (p.act < 0 || p.act > 4) { esam3_set_error("gemm: bad activation %d", p.act); return -1; }
-  if (!attr_set) {
-    for (auto k : kerns)
-      HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds));
-    attr_set = true;
-  }
   const int64_t tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   static int n_cu = 0;
   if (!n_cu) {
@@ -592,15 +586,12 @@ int esam3_launch_gemm256p(const GemmParams& p, hipStream_t stream) {
   const int64_t grid = tiles < n_cu ? tiles : n_cu;  // persistent: one workgroup per CU
   if (p.out_f32) {  // fp32 output / residual stream (esam3_gemm256p_ok has checked: no activation, plain rows)
     void (*k32)(GemmParams) = p.res ? gemm256p_kernel<ACT_NONE, true, true> : gemm256p_kernel<ACT_NONE, false, true>;
-    static bool attr32[2] = {false, false};
-    if (!attr32[p.res ? 1 : 0]) {
-      HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(k32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr32[p.res ? 1 : 0] = true;
-    }
+    if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(k32), (int)lds)) return -1;
     hipLaunchKernelGGL(k32, dim3((unsigned)grid), dim3(512), lds, stream, p);
     HIP_CHECK_RET(hipGetLastError());
     return 0;
   }
+  if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(kerns[p.act + (p.res ? 5 : 0)]), (int)lds)) return -1;
   hipLaunchKernelGGL(kerns[p.act + (p.res ? 5 : 0)], dim3((unsigned)grid), dim3(512), lds, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;

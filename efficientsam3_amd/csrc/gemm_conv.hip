@@ -29,7 +29,12 @@
 // serve the 3x3 convs.  Producers write such buffers through out_pad.
 #include <cstdlib>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "gemm_common.h"
+#include "kernels.h"
 
 // gemm256p.hip
 bool esam3_gemm256p_ok(const GemmParams& p);
@@ -772,13 +777,8 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
   constexpr size_t lds_ab = 2 * (size_t)(BM + BN) * 128;
   constexpr size_t lds_c = (size_t)BM * LDN * 4;
   constexpr size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
-  static bool attr_set = false;
   auto kern = conv_gemm_kernel<T, BM, BN, WM, WN>;
-  if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)) return -1;
   const int64_t tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   if (tiles <= 0) return 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(WM * WN * 64), lds, stream, p);
@@ -789,17 +789,11 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
 template <typename T>
 int launch_256(const GemmParams& p, hipStream_t stream) {
   constexpr size_t lds = 2 * (size_t)(256 + 256) * 128;  // 128 KB
-  static bool attr_set = false;
   void (*kerns[5])(GemmParams) = {gemm256_kernel<T, ACT_NONE>, gemm256_kernel<T, ACT_RELU>, gemm256_kernel<T, ACT_GELU>,
                                   gemm256_kernel<T, ACT_HSWISH>, gemm256_kernel<T, ACT_SIGMOID>};
   if (p.act < 0 || p.act > 4) { esam3_set_error("gemm: bad activation %d", p.act); return -1; }
-  if (!attr_set) {
-    for (auto k : kerns)
-      HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
   auto kern = kerns[p.act];
+  if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)) return -1;
   const int64_t tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   static int n_cu = 0;
   if (!n_cu) {
@@ -905,6 +899,20 @@ int esam3_gemm_pad_k(int K, int elem_size) {
 }
 
 void esam3_note_gemm_kernel(const char* name) { g_last_kernel = name; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember (device, kernel) pairs, not a
+// process-wide flag, so that a second engine on another GPU of the same process also gets its > 64 KB of LDS.
+int esam3_allow_dyn_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  HIP_CHECK_RET(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({dev, kernel})) return 0;
+  HIP_CHECK_RET(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({dev, kernel});
+  return 0;
+}
 const char* esam3_take_last_gemm_kernel() {
   const char* k = g_last_kernel;
   g_last_kernel = nullptr;

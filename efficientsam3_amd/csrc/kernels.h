@@ -8,6 +8,8 @@ int esam3_gemm_pad_k(int K, int elem_size);
 // name of the kernel chosen by the most recent esam3_launch_gemm on this thread (then cleared)
 const char* esam3_take_last_gemm_kernel();
 void esam3_note_gemm_kernel(const char* name);
+// allow `bytes` of dynamic LDS for `kernel` on the current device (once per device and kernel)
+int esam3_allow_dyn_lds(const void* kernel, int bytes);
 int esam3_launch_gemm(int dtype, const GemmParams& p, hipStream_t stream);
 // K ordering of packed dense-conv weights: korder (see GemmParams) and the packed k index of (tap, c)
 int esam3_conv_korder(int cin, int ksize, int elem_size);

@@ -2333,8 +2333,7 @@ int esam3_launch_dwconv(int dtype, const void* in, int ld_in, const float* w, co
 #define ESAM3_DWM(KS_, J_)                                                                                              \
   do {                                                                                                                  \
     auto kern = dwconv_mfma_kernel<KS_, J_>;                                                                            \
-    static bool attr = false;                                                                                           \
-    if (!attr) { HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; } \
+    if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return -1;                                \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)in, ld_in, w, bias, (bf16_t*)out, ld_out, H, W, C, act, tiles_x); \
   } while (0)
     if (ksize == 3) { if (J == 2) ESAM3_DWM(3, 2); else ESAM3_DWM(3, 1); }
@@ -2367,13 +2366,11 @@ int esam3_launch_dwconv(int dtype, const void* in, int ld_in, const float* w, co
   do {                                                                                                                   \
     if (dtype == 0) {                                                                                                    \
       auto kern = dwconv_tiled_kernel<float, KS_, J_>;                                                                    \
-      static bool attr_f = false;                                                                                        \
-      if (!attr_f) { HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_f = true; } \
+      if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return -1;                               \
       hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const float*)in, ld_in, w, bias, (float*)out, ld_out, H, W, C, act, tiles_x, tiles_y, B); \
     } else {                                                                                                             \
       auto kern = dwconv_tiled_kernel<bf16_t, KS_, J_>;                                                                   \
-      static bool attr_b = false;                                                                                        \
-      if (!attr_b) { HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_b = true; } \
+      if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return -1;                               \
       hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, (const bf16_t*)in, ld_in, w, bias, (bf16_t*)out, ld_out, H, W, C, act, tiles_x, tiles_y, B); \
     }                                                                                                                    \
   } while (0)
@@ -2434,12 +2431,7 @@ static int lite_mla_t(const void* ms, int ld, void* out, int ld_out, float* kv, 
     const int n_split = mla_splits(B, N, tpt);
     float* partial = kv + (size_t)B * groups * PAIRS;
     auto kern = mla_kv_kernel<T, DIM>;
-    static bool attr_set = false;
-    if (!attr_set) {
-      HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        160 * 1024 - 1024));
-      attr_set = true;
-    }
+    if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 1024)) return -1;
     hipLaunchKernelGGL(kern, dim3((unsigned)(B * n_split)), dim3(256), lds_kv, s, (const T*)ms, ld, partial, N, groups,
                        n_split);
     const int64_t total = (int64_t)B * groups * PAIRS;
@@ -2482,12 +2474,7 @@ static int launch_window_attn(const void* qkv, int ld, const void* pad_qkv, cons
   constexpr int N = WS * WS, TPP = (N + QB - 1) / QB;
   constexpr size_t lds = sizeof(float) * PAIRS * (2 * N * 32 + N);
   auto kern = window_attn_kernel<T, WS, QB, PAIRS>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)lds));
-    attr_set = true;
-  }
+  if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)) return -1;
   const int nwx = (W + WS - 1) / WS, nwy = (H + WS - 1) / WS;
   const int total = B * nwx * nwy * heads;
   hipLaunchKernelGGL(kern, dim3((unsigned)((total + PAIRS - 1) / PAIRS)), dim3(PAIRS * TPP), lds, s, (const T*)qkv, ld,

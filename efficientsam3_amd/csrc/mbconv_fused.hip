@@ -558,13 +558,8 @@ bool mb2_supported(int dtype, int Cin, int Cmid, int Cout, int stride, int Kp1, 
 
 template <typename T, int S>
 int launch_mb(const MbParams& p, size_t lds, hipStream_t stream) {
-  static bool attr_set = false;
   auto kern = mbconv_fused_kernel<T, S>;
-  if (!attr_set) {
-    HIP_CHECK_RET(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return -1;
   const unsigned grid = (unsigned)p.B * p.tiles_x * p.tiles_y;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
   HIP_CHECK_RET(hipGetLastError());
