@@ -121,6 +121,8 @@ SIGNATURES = {
     "esam3_op_conv3x3_padded": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_conv_transpose2x2": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_mbconv_fused": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "esam3_op_mbconv3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "esam3_op_lite_mla_block": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "esam3_op_dwconv": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_stem": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "esam3_op_lite_mla": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),

@@ -780,7 +780,10 @@ int E::mbconv(const std::string& p, const T4& x, int stride, bool residual, T4* 
   const HostTensor* ew = need(p + "inverted_conv.conv.weight");
   if (!ew) return -1;
   const int cmid = (int)ew->shape[0];
-  if (esam3_mbconv_fused2_ok(dtype, x.C, cmid, y->C, stride) && x.ld == x.C) {
+  // round 4: mbconv3 (evit_fused.hip: depthwise phase on the matrix cores, channels up to 256) also covers the local modules of
+  // stages 3-4 and the 128 -> 256 stage entry; ESAM3_MB_V2=1 (dev builds) keeps the round-2 kernel / the layer list for A/B
+  const bool use_v3 = esam3_mbconv3_ok(dtype, x.C, cmid, y->C, stride) && x.ld == x.C && !esam3_dev_flag("ESAM3_MB_V2");
+  if (use_v3 || (esam3_mbconv_fused2_ok(dtype, x.C, cmid, y->C, stride) && x.ld == x.C)) {
     auto pkc = [&](const std::string& q) {
       return pk_conv(q + ".conv.weight", find(q + ".conv.bias") ? q + ".conv.bias" : "",
                      find(q + ".norm.weight") ? q + ".norm" : "");
@@ -796,6 +799,9 @@ int E::mbconv(const std::string& p, const T4& x, int stride, bool residual, T4* 
     return prof_launch("mbconv_fused_s" + std::to_string(stride) + ":" + p.substr(p.size() > 40 ? p.size() - 40 : 0),
                        2.0 * (px * x.C * cmid + opx * cmid * 9 + opx * cmid * y->C),
                        (px * x.C * (residual ? 2 : 1) + opx * y->C) * (double)esz, [&]() {
+                         if (use_v3)
+                           return esam3_launch_mbconv3(x.p, y->p, g1->w, g1->Kp, g1->bias, dw->w, dw->bias, g2->w, g2->Kp,
+                                                       g2->bias, x.B, x.H, x.W, x.C, cmid, y->C, stride, residual ? 1 : 0, st);
                          return esam3_launch_mbconv_fused(dtype, x.p, y->p, g1->w, g1->Kp, g1->bias, dw->w, dw->bias,
                                                           g2->w, g2->Kp, g2->bias, x.B, x.H, x.W, x.C, cmid, y->C,
                                                           stride, residual ? 1 : 0, st);
@@ -821,7 +827,33 @@ int E::evit_block(const std::string& p, const T4& x, T4* y) {
   *y = alloc4(x.B, x.H, x.W, x.C);
   if (!ok(x1.p) || !ok(y->p)) return -1;
   const size_t mk = arena.mark();
-  {
+  // round 4 (bf16, dim 16, 128 / 256 channels): the whole context module in three launches (evit_fused.hip: mla1 -> kvprep ->
+  // mla2); the 3C-channel qkv tensor, its aggregation and the 6C-channel concat never reach HBM.  ESAM3_NO_MLA_FUSED=1 (dev
+  // builds) runs the layer list below.
+  if (esam3_mla_fused_ok(dtype, x.C, dim) && x.ld == x.C && total3 == 3 * x.C && !find(c + "qkv.conv.bias") &&
+      !find(c + "qkv.norm.weight") && !find(c + "aggreg.0.0.bias") && !find(c + "aggreg.0.1.bias") &&
+      !find(c + "proj.conv.bias") && find(c + "proj.norm.weight") && !esam3_dev_flag("ESAM3_NO_MLA_FUSED")) {
+    PackedGemm* gq = pk_conv(c + "qkv.conv.weight", "", "");
+    PackedDw* d5 = pk_dw(c + "aggreg.0.0.weight", "", "");
+    PackedGemm* gg = pk_conv_like_linear(c + "aggreg.0.1.weight", "");
+    PackedGemm* gp = pk_conv(c + "proj.conv.weight", "", c + "proj.norm");
+    if (!gq || !d5 || !gg || !gp) return -1;
+    if (d5->ks != 5 || gg->K != 16 || gp->K != 2 * x.C) { esam3_set_error("evit_block %s: unexpected LiteMLA shapes", p.c_str()); return -1; }
+    size_t qb, kb, tb;
+    esam3_mla_fused_scratch(x.B, x.H, x.W, x.C, &qb, &kb, &tb);
+    void* qms = allocb(qb);
+    float* kvp = (float*)allocb(kb);
+    void* tab = allocb(tb);
+    if (!ok(qms) || !ok(kvp) || !ok(tab)) return -1;
+    if (!dry) {
+      const double px = (double)x.rows(), C_ = (double)x.C;
+      CK(prof_launch("lite_mla_fused", 2.0 * px * (3 * C_ * C_ + 3 * C_ * 25 + 3 * C_ * 16 + 4 * C_ * 17 + 2 * C_ * C_),
+                     px * C_ * 3.0 * (double)esz, [&]() {
+                       return esam3_launch_mla_fused(x.p, x1.p, gq->w, gq->Kp, d5->w, gg->w, gg->Kp, gp->w, gp->Kp, gp->bias, qms, kvp,
+                                                     tab, x.B, x.H, x.W, x.C, st);
+                     }));
+    }
+  } else {
     // multi-scale qkv tensor [B,H,W, 2*total3]: [qkv | aggreg(qkv)]   (ops.py:656-662)
     T4 ms = alloc4(x.B, x.H, x.W, 2 * total3);
     if (!ok(ms.p)) return -1;

@@ -185,6 +185,21 @@ int esam3_launch_mbconv_fused(int dtype, const void* x, void* out, const void* w
                               int H, int W, int Cin, int Cmid, int Cout, int stride, int residual,
                               hipStream_t stream);
 
+// round-4 fused MBConv (evit_fused.hip, bf16): depthwise phase on the matrix cores, channels up to 256; same arguments as
+// esam3_launch_mbconv_fused (w1 / w2 packed [N][Kp] bf16, wd fp32 [9][Cmid])
+bool esam3_mbconv3_ok(int dtype, int Cin, int Cmid, int Cout, int stride);
+int esam3_launch_mbconv3(const void* x, void* out, const void* w1, int Kp1, const float* b1, const float* wd, const float* bd,
+                         const void* w2, int Kp2, const float* b2, int B, int H, int W, int Cin, int Cmid, int Cout, int stride,
+                         int residual, hipStream_t stream);
+
+// fused LiteMLA context module (evit_fused.hip, bf16, dim 16, C = 128 / 256): out = x + proj(BN)(relu linear attention of the
+// two-scale qkv); scratch sizes from esam3_mla_fused_scratch
+bool esam3_mla_fused_ok(int dtype, int C, int dim);
+void esam3_mla_fused_scratch(int B, int H, int W, int C, size_t* qms_bytes, size_t* kvp_bytes, size_t* tab_bytes);
+int esam3_launch_mla_fused(const void* x, void* out, const void* wqkv, int Kpq, const float* wdw, const void* wgrp, int Kpg,
+                           const void* wproj, int Kpp, const float* bproj, void* qms, float* kvp, void* tab, int B, int H, int W,
+                           int C, hipStream_t stream);
+
 // bf16 MFMA flash attention, heads x 32, no mask / bias (returns 1 when the shape is not eligible)
 int esam3_launch_attn_mfma32(const void* q, int ldq, int q_off, const void* kv, int ldk, int k_off, int v_off, void* out,
                              int ldo, int B, int Nq, int Nk, int heads, hipStream_t s);

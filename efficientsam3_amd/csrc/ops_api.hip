@@ -292,6 +292,66 @@ int esam3_op_mbconv_fused(int dtype, const void* x, const float* w1, const float
   return 0;
 }
 
+int esam3_op_mbconv3(const void* x, const float* w1, const float* b1, const float* wd, const float* bd, const float* w2,
+                     const float* b2, void* out, int B, int H, int W, int Cin, int Cmid, int Cout, int stride, int residual,
+                     void* stream) {
+  Tmp t;
+  const int Kp1 = esam3_gemm_pad_k(Cin, 2), Np1 = esam3_gemm_pad_n(Cmid);
+  const int Kp2 = esam3_gemm_pad_k(Cmid, 2), Np2 = esam3_gemm_pad_n(Cout);
+  std::vector<float> p1((size_t)Np1 * Kp1, 0.f), p2((size_t)Np2 * Kp2, 0.f), pd((size_t)9 * Cmid);
+  for (int n = 0; n < Cmid; ++n)
+    for (int k = 0; k < Cin; ++k) p1[(size_t)n * Kp1 + k] = w1[(size_t)n * Cin + k];
+  for (int n = 0; n < Cout; ++n)
+    for (int k = 0; k < Cmid; ++k) p2[(size_t)n * Kp2 + k] = w2[(size_t)n * Cmid + k];
+  for (int c = 0; c < Cmid; ++c)
+    for (int tp = 0; tp < 9; ++tp) pd[(size_t)tp * Cmid + c] = wd[(size_t)c * 9 + tp];
+  void* d1 = t.upT(1, p1);
+  void* d2 = t.upT(1, p2);
+  float* dd = (float*)t.up(pd.data(), pd.size() * 4);
+  float* db1 = (float*)t.up(b1, (size_t)Cmid * 4);
+  float* dbd = bd ? (float*)t.up(bd, (size_t)Cmid * 4) : nullptr;
+  float* db2 = (float*)t.up(b2, (size_t)Cout * 4);
+  if (!d1 || !d2 || !dd || !db1 || !db2) return fail("op_mbconv3");
+  if (esam3_launch_mbconv3(x, out, d1, Kp1, db1, dd, dbd, d2, Kp2, db2, B, H, W, Cin, Cmid, Cout, stride, residual,
+                           (hipStream_t)stream))
+    return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int esam3_op_lite_mla_block(const void* x, const float* wqkv, const float* wdw, const float* wgrp, const float* wproj,
+                            const float* bproj, void* out, int B, int H, int W, int C, void* stream) {
+  Tmp t;
+  if (!esam3_mla_fused_ok(1, C, 16)) { esam3_set_error("op_lite_mla_block: C = %d is not instantiated", C); return -1; }
+  const int C3 = 3 * C;
+  const int Kpq = esam3_gemm_pad_k(C, 2), Npq = esam3_gemm_pad_n(C3);
+  const int Kpg = esam3_gemm_pad_k(16, 2);
+  const int Kpp = esam3_gemm_pad_k(2 * C, 2), Npp = esam3_gemm_pad_n(C);
+  std::vector<float> pq((size_t)Npq * Kpq, 0.f), pg((size_t)C3 * Kpg, 0.f), pp((size_t)Npp * Kpp, 0.f), pd((size_t)25 * C3);
+  for (int n = 0; n < C3; ++n)
+    for (int k = 0; k < C; ++k) pq[(size_t)n * Kpq + k] = wqkv[(size_t)n * C + k];
+  for (int n = 0; n < C3; ++n)
+    for (int k = 0; k < 16; ++k) pg[(size_t)n * Kpg + k] = wgrp[(size_t)n * 16 + k];
+  for (int n = 0; n < C; ++n)
+    for (int k = 0; k < 2 * C; ++k) pp[(size_t)n * Kpp + k] = wproj[(size_t)n * 2 * C + k];
+  for (int c = 0; c < C3; ++c)
+    for (int tp = 0; tp < 25; ++tp) pd[(size_t)tp * C3 + c] = wdw[(size_t)c * 25 + tp];
+  void* dq = t.upT(1, pq);
+  void* dg = t.upT(1, pg);
+  void* dp = t.upT(1, pp);
+  float* dd = (float*)t.up(pd.data(), pd.size() * 4);
+  float* db = (float*)t.up(bproj, (size_t)C * 4);
+  size_t qb, kb, tb;
+  esam3_mla_fused_scratch(B, H, W, C, &qb, &kb, &tb);
+  void* qms = t.raw(qb);
+  float* kvp = (float*)t.raw(kb);
+  void* tab = t.raw(tb);
+  if (!dq || !dg || !dp || !dd || !db || !qms || !kvp || !tab) return fail("op_lite_mla_block");
+  if (esam3_launch_mla_fused(x, out, dq, Kpq, dd, dg, Kpg, dp, Kpp, db, qms, kvp, tab, B, H, W, C, (hipStream_t)stream)) return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
 int esam3_op_dwconv(int dtype, const void* x, const float* w, const float* bias, void* out, int B, int H, int W,
                     int C, int ks, int stride, int act, void* stream) {
   Tmp t;

@@ -377,6 +377,19 @@ int esam3_op_mbconv_fused(int dtype, const void* x_dev, const float* w1_host, co
                           const float* wd_host, const float* bd_host, const float* w2_host,
                           const float* b2_host, void* out_dev, int B, int H, int W, int Cin, int Cmid,
                           int Cout, int stride, int residual, void* hip_stream);
+/* round-4 fused MBConv on the bf16 engine (csrc/evit_fused.hip: depthwise phase on the matrix cores; EfficientViT-B0/B1 shapes
+ * up to 256 channels, the local modules of the EfficientViTBlocks included); same host weight layout as esam3_op_mbconv_fused;
+ * x_dev / out_dev bf16 NHWC.  Reference: backbones/efficientvit/nn/ops.py:315-367,740-770 */
+int esam3_op_mbconv3(const void* x_dev, const float* w1_host, const float* b1_host, const float* wd_host,
+                     const float* bd_host, const float* w2_host, const float* b2_host, void* out_dev, int B, int H, int W,
+                     int Cin, int Cmid, int Cout, int stride, int residual, void* hip_stream);
+/* fused LiteMLA context module of an EfficientViTBlock on the bf16 engine (csrc/evit_fused.hip): out = x + BN(proj(relu linear
+ * attention over [qkv ; aggreg(qkv)])), dim 16, C = 128 | 256.  wqkv [3C][C], wdw [3C][1][5][5], wgrp [3C][16] (groups of 16),
+ * wproj [C][2C] with BatchNorm folded, bproj [C]: host fp32; x_dev / out_dev bf16 NHWC.
+ * Reference: backbones/efficientvit/nn/ops.py:521-671 (LiteMLA), :740-770 (ResidualBlock) */
+int esam3_op_lite_mla_block(const void* x_dev, const float* wqkv_host, const float* wdw_host, const float* wgrp_host,
+                            const float* wproj_host, const float* bproj_host, void* out_dev, int B, int H, int W, int C,
+                            void* hip_stream);
 /* depthwise k x k (3|5), stride 1|2; w_host PyTorch [C][1][k][k] */
 int esam3_op_dwconv(int dtype, const void* x_dev, const float* w_host, const float* bias_host,
                     void* out_dev, int B, int H, int W, int C, int ksize, int stride, int act,

@@ -661,3 +661,92 @@ def test_resize_shuffle(mode, B, IH, OH, C, taps, act, pad):
     a_ = torch.einsum("oc,bchw->bohw", wmat, F.interpolate(y[:, :C], size=(OH, OH), mode="bilinear", align_corners=False)) + 0.3
     b_ = F.interpolate(torch.einsum("oc,bchw->bohw", wmat, y[:, :C]) + 0.3, size=(OH, OH), mode="bilinear", align_corners=False)
     assert float((a_ - b_).abs().max()) < 1e-4
+
+
+def _rel_l2(got, ref):
+    return float((got.double() - ref.double()).norm() / ref.double().norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cmid,Cout,stride,res", [
+    (2, 40, 40, 16, 64, 32, 2, 0),      # stages.0.op_list.0
+    (1, 30, 26, 32, 128, 32, 1, 1),     # stages.0.op_list.1, ragged 8x16 tiles
+    (1, 41, 23, 32, 128, 64, 2, 0),     # stages.1.op_list.0, odd sizes
+    (2, 33, 50, 64, 256, 64, 1, 1),     # stages.1.op_list.1/2
+    (2, 21, 19, 64, 256, 128, 2, 0),    # stages.2.op_list.0 (126 -> 63 style)
+    (1, 16, 16, 128, 512, 128, 1, 1),   # EfficientViTBlock local module, stage 3 (one full tile row pair)
+    (2, 63, 63, 128, 512, 128, 1, 1),   # the same at the real stage-3 size (ragged right / bottom tiles)
+    (1, 31, 29, 128, 512, 256, 2, 0),   # stages.3.op_list.0: stride 2, 8 waves
+    (1, 9, 9, 256, 1024, 256, 1, 1),    # stage-4 local module: 16 chunks, Cout 256, 8 waves
+    (2, 32, 32, 256, 1024, 256, 1, 1),  # the same at the real stage-4 size
+    (3, 64, 64, 16, 64, 32, 2, 0),      # several full tiles per image
+])
+def test_mbconv3(B, H, W, Cin, Cmid, Cout, stride, res):
+    """Round-4 fused MBConv (csrc/evit_fused.hip: expand on MFMA -> depthwise 3x3 on v_mfma_f32_4x4x4 -> project on MFMA) vs the
+    three-layer PyTorch reference (efficientvit/nn/ops.py:315-367 with Hardswish, BN folded), with the kernel's rounding points:
+    bf16 activations between the layers, bf16 depthwise weights (the reference's autocast rounds them too)."""
+    mode = "bf16"
+    d, tdt = U.DT[mode]
+    x = _rand(B, Cin, H, W, seed=1)
+    w1, b1 = _rand(Cmid, Cin, 1, 1, seed=2) * (2.0 / Cin) ** 0.5, _rand(Cmid, seed=3) * 0.1
+    wd, bd = _rand(Cmid, 1, 3, 3, seed=4) * 0.4, _rand(Cmid, seed=5) * 0.1
+    w2, b2 = _rand(Cout, Cmid, 1, 1, seed=6) / Cmid ** 0.5, _rand(Cout, seed=7) * 0.1
+    xq = _q(x, mode)
+    m = _q(F.hardswish(F.conv2d(xq, _q(w1, mode), b1)), mode)
+    m = _q(F.hardswish(F.conv2d(m, _q(wd, mode), bd, stride=stride, padding=1, groups=Cmid)), mode)
+    ref = F.conv2d(m, _q(w2, mode), b2)
+    if res:
+        ref = ref + xq
+    x_d = U.to_dev_nhwc(x, tdt)
+    OH, OW = ref.shape[-2:]
+    out = torch.full((B, OH, OW, Cout), float("nan"), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_mbconv3(U.P(x_d), U.H(U.np32(w1)), U.H(U.np32(b1)), U.H(U.np32(wd)), U.H(U.np32(bd)),
+                                     U.H(U.np32(w2)), U.H(U.np32(b2)), U.P(out), B, H, W, Cin, Cmid, Cout, stride, res, None),
+            "op_mbconv3")
+    got = U.from_dev_nhwc(out)
+    assert torch.isfinite(got).all()
+    assert _rel_l2(got, ref) < 6e-3, _rel_l2(got, ref)
+    U.assert_close(got, ref, mode, f"mbconv3 {Cin}->{Cmid}->{Cout} s{stride}", scale=0.7)
+
+
+def _lite_mla_block_ref(x, wqkv, wdw, wgrp, wproj, bproj, dim=16):
+    """ops.py:521-671 + the ResidualBlock shortcut, with the fused kernels' rounding points (bf16 tensors between the layers)."""
+    q = lambda t: t.to(torch.bfloat16).float()
+    B, C, H, W = x.shape
+    xq = q(x)
+    qkv = q(F.conv2d(xq, q(wqkv)[:, :, None, None]))
+    agg = q(F.conv2d(qkv, q(wdw), padding=2, groups=3 * C))
+    agg = q(F.conv2d(agg, q(wgrp)[:, :, None, None], groups=3 * C // dim))
+    ms = torch.cat([qkv, agg], dim=1).reshape(B, -1, 3 * dim, H * W).double()
+    qq, kk, vv = F.relu(ms[:, :, :dim]), F.relu(ms[:, :, dim:2 * dim]), ms[:, :, 2 * dim:]
+    v1 = F.pad(vv, (0, 0, 0, 1), value=1.0)
+    o = torch.matmul(torch.matmul(v1, kk.transpose(-1, -2)), qq)
+    att = q((o[:, :, :-1] / (o[:, :, -1:] + 1e-15)).reshape(B, -1, H, W).float())
+    return F.conv2d(att, q(wproj)[:, :, None, None], bproj) + xq
+
+
+@pytest.mark.parametrize("B,H,W,C", [
+    (1, 8, 16, 128),     # exactly one tile
+    (2, 21, 19, 128),    # ragged tiles, several partial kv tiles per image
+    (1, 63, 63, 128),    # the real stage-3 map
+    (1, 9, 9, 256),      # stage-4 width, one partial tile
+    (2, 32, 32, 256),    # the real stage-4 map
+])
+def test_lite_mla_block(B, H, W, C):
+    """Fused LiteMLA context module (csrc/evit_fused.hip: mla1 -> kvprep -> mla2) against the reference formula in fp64 with
+    the kernels' bf16 rounding points."""
+    tdt = torch.bfloat16
+    x = _rand(B, C, H, W, seed=1)
+    wqkv = _rand(3 * C, C, seed=2) / C ** 0.5
+    wdw = _rand(3 * C, 1, 5, 5, seed=3) * 0.2
+    wgrp = _rand(3 * C, 16, seed=4) / 4.0
+    wproj = _rand(C, 2 * C, seed=5) / (2 * C) ** 0.5
+    bproj = _rand(C, seed=6) * 0.1
+    ref = _lite_mla_block_ref(x, wqkv, wdw, wgrp, wproj, bproj)
+    x_d = U.to_dev_nhwc(x, tdt)
+    out = torch.full((B, H, W, C), float("nan"), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_lite_mla_block(U.P(x_d), U.H(U.np32(wqkv)), U.H(U.np32(wdw)), U.H(U.np32(wgrp)), U.H(U.np32(wproj)),
+                                            U.H(U.np32(bproj)), U.P(out), B, H, W, C, None), "op_lite_mla_block")
+    got = U.from_dev_nhwc(out)
+    assert torch.isfinite(got).all()
+    assert _rel_l2(got, ref) < 8e-3, _rel_l2(got, ref)
+    U.assert_close(got, ref, "bf16", f"lite_mla_block C={C} {H}x{W}", scale=1.0)
