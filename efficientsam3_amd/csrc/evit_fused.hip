@@ -37,6 +37,28 @@ __device__ __forceinline__ float hsw(float x) {
   return x * t;
 }
 
+// the same on pairs: v_pk_fma_f32 + two clamps + v_pk_mul_f32 = two VALU instructions per element instead of three (the fused
+// kernels are instruction-issue bound: profiles/r04/pmc_c_summary.txt).  Plain C: an inline-assembly v_pk_fma_f32 ... clamp
+// would save one more, but hipcc pads no MFMA-result -> VALU-read wait states for an asm reader (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ f32x2_v hsw2(f32x2_v x) {
+  f32x2_v t = __builtin_elementwise_fma(x, (f32x2_v)(1.f / 6.f), (f32x2_v)(0.5f));
+  t = __builtin_elementwise_min(__builtin_elementwise_max(t, (f32x2_v)(0.f)), (f32x2_v)(1.f));
+  return x * t;
+}
+template <int N> __device__ __forceinline__ void hsw_n(float (&v)[N]) {
+  static_assert(N % 2 == 0, "pairs");
+#pragma unroll
+  for (int i = 0; i < N; i += 2) {
+    const f32x2_v r = hsw2(f32x2_v{v[i], v[i + 1]});
+    v[i] = r.x;
+    v[i + 1] = r.y;
+  }
+}
+__device__ __forceinline__ uint2 hsw_pack4(const f32x4& a) {   // 4 accumulators -> Hardswish -> 4 bf16
+  const f32x2_v lo = hsw2(f32x2_v{a[0], a[1]}), hi = hsw2(f32x2_v{a[2], a[3]});
+  return make_uint2(pack_bf16x2(lo.x, lo.y), pack_bf16x2(hi.x, hi.y));
+}
+
 // workgroup L of a 1-D grid of nb -> an index such that every XCD (L % 8) owns one contiguous range (bijective)
 __device__ __forceinline__ unsigned xcd_contig(unsigned L, unsigned nb) {
   const unsigned q = nb / 8, r = nb % 8, xcd = L % 8, idx = L / 8;
@@ -57,50 +79,90 @@ __device__ __forceinline__ void dsr64(s16x4& d, unsigned addr) {
   static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "i"(OFF));
 }
-template <int N> __device__ __forceinline__ void ds_wait(s16x4 (&c)[2]) {
-  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(c[0]), "+v"(c[1]) : "i"(N));
+template <int N> __device__ __forceinline__ void ds_wait(s16x4 (&c)[3]) {
+  asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]) : "i"(N));
 }
-template <int N> __device__ __forceinline__ void ds_wait(s16x4 (&c)[4]) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]) : "i"(N));
+template <int N> __device__ __forceinline__ void ds_wait(s16x4 (&c)[5]) {
+  asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]) : "i"(N));
 }
-template <int N> __device__ __forceinline__ void ds_wait(s16x4 (&c)[8]) {
-  asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]) : "i"(N));
-}
-// KSZ x KSZ taps, accumulator i = (row r = i / QN of the wave's RPW rows, run q = i % QN of 4 pixels); `addr` = LDS byte address
-// of (first row, pixel pi, channel block) ; halo row pitch HW pixels, pixel pitch PITCH bytes, stride S
-template <int KSZ, int RPW, int QN, int S, int HW, int PITCH>
-struct DwMfma {
-  static constexpr int NACC = RPW * QN, NTAP = KSZ * KSZ;
-  template <int TAP, int I> static constexpr int off() {
-    return (((I / QN) * S + TAP / KSZ) * HW + (I % QN) * 4 * S + TAP % KSZ) * PITCH;
-  }
-  template <int TAP, int I = 0> static __device__ __forceinline__ void issue(s16x4 (&buf)[NACC], unsigned addr) {
-    if constexpr (I < NACC) {
-      dsr64<off<TAP, I>()>(buf[I], addr);
-      issue<TAP, I + 1>(buf, addr);
+// A lane block (4 channels x 4 horizontally adjacent pixels) owns ROWS consecutive output rows of ONE pixel run: walking the
+// IR = (ROWS - 1) S + KSZ input rows, every loaded operand (input row ir, column tap kx) feeds the up-to-KSZ output rows whose
+// window contains that row -- KSZ x IR reads for KSZ^2 x ROWS MFMAs (3 x 10 for 72 at ROWS = 8, stride 1) instead of one read per
+// MFMA.  `addr` = LDS byte address of (first input row, pixel pi of the run, channel block); batch = one input row.
+template <int KSZ, int ROWS, int S, int HW, int PITCH>
+struct DwRows {
+  static constexpr int IR = (ROWS - 1) * S + KSZ, NTAP = KSZ * KSZ;
+  template <int R, int I = 0> static __device__ __forceinline__ void issue(s16x4 (&buf)[KSZ], unsigned addr) {
+    if constexpr (I < KSZ) {
+      dsr64<(R * HW + I) * PITCH>(buf[I], addr);
+      issue<R, I + 1>(buf, addr);
     }
   }
-  template <int TAP = 0> static __device__ __forceinline__ void step(s16x4 (&cur)[NACC], s16x4 (&nxt)[NACC], unsigned addr,
-                                                                     const s16x4 (&wdg)[NTAP], f32x4 (&acc)[NACC]) {
-    if constexpr (TAP + 1 < NTAP) {
-      issue<TAP + 1>(nxt, addr);
-      ds_wait<NACC>(cur);
+  // column tap outermost: consecutive MFMAs go to different accumulators (the rows the input row R belongs to)
+  template <int R, int KX, int KY> static __device__ __forceinline__ void consume_ky(const s16x4& x, const s16x4 (&wdg)[NTAP],
+                                                                                    f32x4 (&acc)[ROWS]) {
+    if constexpr (KY < KSZ) {
+      if constexpr (R - KY >= 0 && (R - KY) % S == 0 && (R - KY) / S < ROWS)
+        acc[(R - KY) / S] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wdg[KY * KSZ + KX], x, acc[(R - KY) / S], 0, 0, 0);
+      consume_ky<R, KX, KY + 1>(x, wdg, acc);
+    }
+  }
+  template <int R, int KX = 0> static __device__ __forceinline__ void consume(const s16x4 (&cur)[KSZ], const s16x4 (&wdg)[NTAP],
+                                                                              f32x4 (&acc)[ROWS]) {
+    if constexpr (KX < KSZ) {
+      consume_ky<R, KX, 0>(cur[KX], wdg, acc);
+      consume<R, KX + 1>(cur, wdg, acc);
+    }
+  }
+  template <int R = 0> static __device__ __forceinline__ void step(s16x4 (&cur)[KSZ], s16x4 (&nxt)[KSZ], unsigned addr,
+                                                                   const s16x4 (&wdg)[NTAP], f32x4 (&acc)[ROWS]) {
+    if constexpr (R + 1 < IR) {
+      issue<R + 1>(nxt, addr);
+      ds_wait<KSZ>(cur);
     } else {
       ds_wait<0>(cur);
     }
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wdg[TAP], cur[i], acc[i], 0, 0, 0);
-    if constexpr (TAP + 1 < NTAP) step<TAP + 1>(nxt, cur, addr, wdg, acc);
+    consume<R>(cur, wdg, acc);
+    if constexpr (R + 1 < IR) step<R + 1>(nxt, cur, addr, wdg, acc);
   }
-  static __device__ __forceinline__ void run(unsigned addr, const s16x4 (&wdg)[NTAP], f32x4 (&acc)[NACC]) {
-    s16x4 a[NACC], b[NACC];
+  static __device__ __forceinline__ void run(unsigned addr, const s16x4 (&wdg)[NTAP], f32x4 (&acc)[ROWS]) {
+    s16x4 a[KSZ], b[KSZ];
     issue<0>(a, addr);
     step<0>(a, b, addr, wdg, acc);
   }
 };
+// One LDS-DMA piece: 64 lanes x 16 B from (scalar base + per-lane 32-bit byte offset) to LDS [lds .. lds + 1024) (gemm256p.hip's
+// idiom).  Inline assembly: M0 is written in the statement that uses it; s_nop 3 covers a freshly written SGPR base.  The
+// compiler does not count these loads: every consumer sits behind an explicit s_waitcnt vmcnt(0) + barrier.
+__device__ __forceinline__ void dma_piece(const void* base, uint32_t voff, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base),
+               "s"(__builtin_amdgcn_readfirstlane(lds))
+               : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const char* p) {
   return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
+
+template <int KSZ, int ROWS, int S, int HW, int PITCH, int AHEAD = (KSZ == 3 ? 3 : 2)>
+struct DwRows3 {   // as DwRows, AHEAD input rows of reads in flight (lgkmcnt is a 4-bit counter: AHEAD * KSZ <= 15)
+  static constexpr int IR = (ROWS - 1) * S + KSZ, NTAP = KSZ * KSZ, NB = AHEAD + 1;
+  typedef DwRows<KSZ, ROWS, S, HW, PITCH> Base;
+  template <int R> static __device__ __forceinline__ void step(s16x4 (&buf)[NB][KSZ], unsigned addr, const s16x4 (&wdg)[NTAP],
+                                                               f32x4 (&acc)[ROWS]) {
+    if constexpr (R + AHEAD < IR) Base::template issue<R + AHEAD>(buf[(R + AHEAD) % NB], addr);
+    constexpr int inflight = (IR - 1 - R) < AHEAD ? (IR - 1 - R) : AHEAD;   // rows issued after row R
+    ds_wait<inflight * KSZ>(buf[R % NB]);
+    Base::template consume<R>(buf[R % NB], wdg, acc);
+    if constexpr (R + 1 < IR) step<R + 1>(buf, addr, wdg, acc);
+  }
+  static __device__ __forceinline__ void run(unsigned addr, const s16x4 (&wdg)[NTAP], f32x4 (&acc)[ROWS]) {
+    s16x4 buf[NB][KSZ];
+    Base::template issue<0>(buf[0], addr);
+    if constexpr (AHEAD >= 2 && IR > 1) Base::template issue<1>(buf[1], addr);
+    if constexpr (AHEAD >= 3 && IR > 2) Base::template issue<2>(buf[2], addr);
+    step<0>(buf, addr, wdg, acc);
+  }
+};
 
 __device__ __forceinline__ s16x4 diag_bf16(float w, int pi) {
   const short wb = (short)f32_to_bf16(w);
@@ -119,7 +181,14 @@ struct Mb3Params {
   int B, H, W, OH, OW, Cmid, Kp1, Kp2;
   int residual;
   int tiles_x, tiles_y;
+  int abl;           // -DESAM3_DEV builds only: phase ablation mask (ESAM3_MB3_ABL), see tools/evit_fused_bench.py
 };
+
+#ifdef ESAM3_DEV
+#define MB3_ABL(bit) (p.abl & (bit))
+#else
+#define MB3_ABL(bit) 0
+#endif
 
 template <int S, int CIN, int COUT, int NW>
 __global__ __launch_bounds__(NW * 64, (NW == 4 && CIN <= 32 && S == 1) ? 3 : 2) void mbconv3_kernel(Mb3Params p) {
@@ -188,10 +257,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CIN <= 32 && S == 1) ? 3 : 2) 
   const int ppt = wave % PW;
   const int pnt0 = wave / PW;
 
-  // depthwise phase: lane = (block of 4 channels, pixel within a run of 4); a wave owns RPW output rows
-  constexpr int RPW = TH / NW, QN = TW / 4;
+  // depthwise phase: lane = (block of 4 channels, pixel within a run of 4); a wave owns ONE run of 4 output columns (QN runs per
+  // row) and DROWS consecutive output rows of it
+  constexpr int QN = TW / 4, WPQ = NW / QN, DROWS = TH / WPQ;
   const int blk = lane >> 2, pi = lane & 3;
-  const char* dbase = mid + ((wave * RPW * S) * HW + pi * S) * PITCH + blk * 8;
+  const int dq = wave % QN, drow0 = (wave / QN) * DROWS;
+  const char* dbase = mid + ((drow0 * S) * HW + (4 * dq + pi) * S) * PITCH + blk * 8;
 
   const int nchunks = p.Cmid / 64;
   for (int ch = 0; ch < nchunks; ++ch) {
@@ -206,7 +277,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CIN <= 32 && S == 1) ? 3 : 2) 
       bsv = f32x4{bb.x, bb.y, bb.z, bb.w};
     }
     // ================= E: mid[halo px][64] = hswish(W1[c0..c0+64) . x + b1), 0 outside the image =================
-    {
+    if (!MB3_ABL(2)) {
       u32x4 fw[KS];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
@@ -234,7 +305,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CIN <= 32 && S == 1) ? 3 : 2) 
             for (int kk = 0; kk < KB; ++kk) {
               fa[uu][kk] = u32x4{0u, 0u, 0u, 0u};
               const int u = u0 + uu < UPW ? u0 + uu : 0;
-              if (u0 + uu < UPW && xoff[u] >= 0)
+              if (u0 + uu < UPW && xoff[u] >= 0 && !MB3_ABL(1))
                 fa[uu][kk] = *reinterpret_cast<const u32x4*>(gx + xoff[u] + (2 * (k0 + kk) + g) * 8);
             }
 #pragma unroll
@@ -273,29 +344,27 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CIN <= 32 && S == 1) ? 3 : 2) 
     __syncthreads();
 
     // ================= D: dwo[out px][64] = hswish(dw3x3(mid) + bd) on v_mfma_f32_4x4x4_16b_bf16 =================
-    {
+    if (!MB3_ABL(4)) {
       s16x4 wdg[9];
 #pragma unroll
       for (int t = 0; t < 9; ++t) wdg[t] = diag_bf16(wdf[t], pi);
-      f32x4 acc[RPW * QN];
+      f32x4 acc[DROWS];
 #pragma unroll
-      for (int i = 0; i < RPW * QN; ++i) acc[i] = bsv;
-      DwMfma<3, RPW, QN, S, HW, PITCH>::run(lds_addr(dbase), wdg, acc);
+      for (int i = 0; i < DROWS; ++i) acc[i] = bsv;
+      DwRows<3, DROWS, S, HW, PITCH>::run(lds_addr(dbase), wdg, acc);
 #pragma unroll
-      for (int r = 0; r < RPW; ++r)
-#pragma unroll
-        for (int q = 0; q < QN; ++q) {
-          const int op = (wave * RPW + r) * TW + 4 * q + pi;
-          uint2 o;
-          o.x = pack_bf16x2(hsw(acc[r * QN + q][0]), hsw(acc[r * QN + q][1]));
-          o.y = pack_bf16x2(hsw(acc[r * QN + q][2]), hsw(acc[r * QN + q][3]));
-          *reinterpret_cast<uint2*>(dwo + op * 128 + swz(op, blk >> 1) + (blk & 1) * 8) = o;
-        }
+      for (int r = 0; r < DROWS; ++r) {
+        const int op = (drow0 + r) * TW + 4 * dq + pi;
+        uint2 o;
+        o.x = pack_bf16x2(hsw(acc[r][0]), hsw(acc[r][1]));
+        o.y = pack_bf16x2(hsw(acc[r][2]), hsw(acc[r][3]));
+        *reinterpret_cast<uint2*>(dwo + op * 128 + swz(op, blk >> 1) + (blk & 1) * 8) = o;
+      }
     }
     __syncthreads();
 
     // ================= P: acc[out px][Cout] += dwo . W2[:, c0..c0+64)^T =================
-    {
+    if (!MB3_ABL(8)) {
       const int prow = ppt * 32 + l31;
       u32x4 fd[4];
 #pragma unroll
@@ -316,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CIN <= 32 && S == 1) ? 3 : 2) 
   }
 
   // ================= out = acc + b2 (+ x): 16-byte NHWC stores =================
-  {
+  if (!MB3_ABL(16) || accp[0][0] == 12345.f) {
     const int op = ppt * 32 + l31;
     const int oy = oy0 + op / TW, ox = ox0 + op % TW;
     const bool ok = oy < p.OH && ox < p.OW;
@@ -359,7 +428,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && CIN <= 32 && S == 1) ? 3 : 2) 
 //       x fragments stay in registers for all chunks) -> mid[halo px][96] bf16 (no bias: pixels outside the image give 0 =
 //       the depthwise conv's zero padding)
 //   D   aggreg.0.0: depthwise 5x5 of mid -> dwo[px][96] on v_mfma_f32_4x4x4_16b_bf16; block slot = (4-channel group of 24,
-//       row pair of 4): 96 slots = 6 waves
+//       run of 4 columns, all 8 rows of it): 96 slots = 6 waves; every operand read feeds up to 5 output rows
 //   P   aggreg.0.1: grouped 1x1 (16 -> 16 per group) dwo -> ago[px][96]: one v_mfma_f32_16x16x16_bf16 per (group, tile row)
 //   KVQ relu(q) of the two scales (mid centre, ago) -> qms[b][token][chunk*64 + scale*32 + head*16 + d];
 //       kv partial of each of the 4 (scale, head) groups over this tile's pixels: D[dv][dk] += V^T . relu(K) with the pixels as
@@ -392,9 +461,11 @@ __global__ __launch_bounds__(512, 2) void mla1_kernel(Mla1Params p) {
   constexpr int HEADS = C / 16, C3 = 3 * C, KS = C / 16, NCH = HEADS / 2;
   constexpr int TH = 8, TW = 16, HH = TH + 4, HW = TW + 4, HP = HH * HW;   // 12 x 20 halo
   constexpr int PITCH = 192;
-  __shared__ __attribute__((aligned(16))) char mid[256 * PITCH];
-  __shared__ __attribute__((aligned(16))) char dwo[128 * PITCH];
-  __shared__ __attribute__((aligned(16))) char ago[128 * PITCH];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* mid = smem;                    // [256 halo px][192 B]
+  char* dwo = mid + 256 * PITCH;       // [128 px][192 B]
+  char* ago = dwo + 128 * PITCH;       // [128 px][192 B]
+  char* wqs = ago + 128 * PITCH;       // this chunk's 96 rows of Wqkv: [96][C] bf16, 16-byte slot ^ (row & 15), filled by LDS-DMA
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -413,6 +484,22 @@ __global__ __launch_bounds__(512, 2) void mla1_kernel(Mla1Params p) {
   const T* __restrict__ gwg = reinterpret_cast<const T*>(p.wgrp);
   T* __restrict__ gq = reinterpret_cast<T*>(p.qms);
 
+  // weights of a chunk: 96 rows x C columns = 12 / 24 KB = 12 / 24 DMA pieces (wave w issues pieces w, w + 8, ...); the swizzle
+  // is applied to the source address
+  const uint32_t wq_lds = lds_addr(wqs);
+  auto dma_wq = [&](int ch) {
+#pragma unroll
+    for (int j = 0; j < (96 * C * 2 / 1024 + 7) / 8; ++j) {
+      const int piece = wave + 8 * j;
+      if (piece < 96 * C * 2 / 1024) {   // wave-uniform
+        const int byte = piece * 1024 + lane * 16;
+        const int row = byte / (C * 2), pslot = (byte - row * (C * 2)) >> 4;
+        const uint32_t voff = (uint32_t)(((ch * 96 + row) * p.Kpq + ((pslot ^ (row & 15)) << 3)) * 2);
+        dma_piece(gwq, voff, wq_lds + (uint32_t)piece * 1024u);
+      }
+    }
+  };
+  dma_wq(0);
   // ---- x fragments of this wave's halo pixel tile (pixels 32 wave .. + 31), kept for all chunks ----
   u32x4 fa[KS];
   {
@@ -427,14 +514,16 @@ __global__ __launch_bounds__(512, 2) void mla1_kernel(Mla1Params p) {
       if (in) fa[ks] = *reinterpret_cast<const u32x4*>(px + (2 * ks + g) * 8);
     }
   }
-  // depthwise phase: waves 0..5, block slot = wave*16 + blk -> (channel group cg of 24, row pair sub of 4)
+  // depthwise phase: waves 0..5, block slot = wave*16 + blk -> (channel group cg of 24, column run dq of 4)
   const int blk = lane >> 2, pi = lane & 3;
   const int dslot = wave * 16 + blk;
-  const int cg = dslot % 24, sub = dslot / 24;
-  const char* dbase = mid + ((2 * sub) * HW + pi) * PITCH + cg * 8;
+  const int cg = dslot % 24, dq = dslot / 24;   // (4-channel group, run of 4 columns): all 8 output rows of that run
+  const char* dbase = mid + (4 * dq + pi) * PITCH + cg * 8;
   // this lane's output pixel in the P phase (tile row = wave) inside the image?
   const bool p_in = (oy0 + wave) < p.H && (ox0 + l15) < p.W;
 
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // Wqkv chunk 0 is in LDS
   for (int ch = 0; ch < NCH; ++ch) {
     const int c0 = ch * 96;   // first qkv channel of the chunk (heads 2ch, 2ch + 1)
     // ================= E: mid[halo px][96] = Wqkv[c0 .. c0+96) . x =================
@@ -443,24 +532,32 @@ __global__ __launch_bounds__(512, 2) void mla1_kernel(Mla1Params p) {
       f32x16_v acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const T* wrow = gwq + (int64_t)(c0 + j * 32 + l31) * p.Kpq + g * 8;
+      const int wr = j * 32 + l31;
+      const char* wrow = wqs + wr * (C * 2);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const u32x4 fw = *reinterpret_cast<const u32x4*>(wrow + ks * 16);
+        const u32x4 fw = *reinterpret_cast<const u32x4*>(wrow + (((2 * ks + g) ^ (wr & 15)) << 4));
         MmaOps<T>::mma(fw, fa[ks], acc);
       }
       const int hp = wave * 32 + l31;
+      u32x4 o[2];
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp) {
         const uint32_t a0 = pack_bf16x2(acc[8 * qp + 0], acc[8 * qp + 1]), a1 = pack_bf16x2(acc[8 * qp + 2], acc[8 * qp + 3]);
         const uint32_t c0_ = pack_bf16x2(acc[8 * qp + 4], acc[8 * qp + 5]), c1_ = pack_bf16x2(acc[8 * qp + 6], acc[8 * qp + 7]);
         auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0_, false, false);
         auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
-        const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};  // channels j*32 + 16qp + 8g .. +8 of halo pixel hp
-        *reinterpret_cast<u32x4*>(mid + hp * PITCH + ((j * 4 + qp * 2 + g) << 4)) = o;
+        o[qp] = u32x4{s0[0], s1[0], s0[1], s1[1]};  // channels j*32 + 16qp + 8g .. +8 of halo pixel hp
       }
+      // lane-dependent order of the two pieces: 2-way instead of 4-way bank conflicts (pixel pitch 192 B = 64 mod 128)
+      const bool flip = (l31 >> 1) & 1;
+      const u32x4 w0 = flip ? o[1] : o[0], w1v = flip ? o[0] : o[1];
+      char* rowp = mid + hp * PITCH + ((j * 4 + g) << 4);
+      *reinterpret_cast<u32x4*>(rowp + (flip ? 32 : 0)) = w0;
+      *reinterpret_cast<u32x4*>(rowp + (flip ? 0 : 32)) = w1v;
     }
     __syncthreads();
+    if (ch + 1 < NCH) dma_wq(ch + 1);   // the expand phase is done with the buffer; lands under the other three phases
 
     // ================= D: dwo[px][96] = dw5x5(mid) =================
     if (wave < 6) {
@@ -470,17 +567,15 @@ __global__ __launch_bounds__(512, 2) void mla1_kernel(Mla1Params p) {
       f32x4 acc[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-      DwMfma<5, 2, 4, 1, HW, PITCH>::run(lds_addr(dbase), wdg, acc);
+      DwRows3<5, 8, 1, HW, PITCH, 2>::run(lds_addr(dbase), wdg, acc);
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int op = (2 * sub + r) * TW + 4 * q + pi;
-          uint2 o;
-          o.x = pack_bf16x2(acc[r * 4 + q][0], acc[r * 4 + q][1]);
-          o.y = pack_bf16x2(acc[r * 4 + q][2], acc[r * 4 + q][3]);
-          *reinterpret_cast<uint2*>(dwo + op * PITCH + cg * 8) = o;
-        }
+      for (int r = 0; r < 8; ++r) {
+        const int op = r * TW + 4 * dq + pi;
+        uint2 o;
+        o.x = pack_bf16x2(acc[r][0], acc[r][1]);
+        o.y = pack_bf16x2(acc[r][2], acc[r][3]);
+        *reinterpret_cast<uint2*>(dwo + op * PITCH + cg * 8) = o;
+      }
     }
     __syncthreads();
 
@@ -540,6 +635,7 @@ __global__ __launch_bounds__(512, 2) void mla1_kernel(Mla1Params p) {
       for (int i = 0; i < 4; ++i) o[(4 * kg + i) * 16 + l15] = akv[i];
       if (kg == 0) o[256 + l15] = aks[0];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next chunk's weights
     __syncthreads();
   }
 }
@@ -551,11 +647,21 @@ __global__ __launch_bounds__(256) void mla_kvprep_kernel(const float* __restrict
   const int b = bg / G, gi = bg - b * G;
   const int t = threadIdx.x, m = t >> 4, k = t & 15;
   const float* src = kvp + ((int64_t)b * P * G + gi) * 272;
-  float s = 0.f, sk = 0.f;
-  for (int q = 0; q < P; ++q) {
-    s += src[(int64_t)q * G * 272 + m * 16 + k];
-    sk += src[(int64_t)q * G * 272 + 256 + k];
+  // eight interleaved partial sums (independent loads in flight), combined in a fixed order: deterministic
+  float s8[8], k8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s8[j] = k8[j] = 0.f;
+  for (int q0 = 0; q0 < P; q0 += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (q0 + j < P) {
+        s8[j] += src[(int64_t)(q0 + j) * G * 272 + m * 16 + k];
+        k8[j] += src[(int64_t)(q0 + j) * G * 272 + 256 + k];
+      }
+    }
   }
+  const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+  const float sk = ((k8[0] + k8[1]) + (k8[2] + k8[3])) + ((k8[4] + k8[5]) + (k8[6] + k8[7]));
   bf16_t* o = tab + (int64_t)bg * 4 * 256;
   const int li = (m + 16 * (k >> 2)) * 4 + (k & 3);
   const bf16_t h = f32_to_bf16(s), hk = f32_to_bf16(sk);
@@ -609,6 +715,20 @@ __global__ __launch_bounds__(NW * 64, 2) void mla2_kernel(Mla2Params p) {
   const int ppt = wave & 3, pnt0 = wave >> 2;
   constexpr int IPW = 32 / NW;   // (token block, group) items per wave and chunk
 
+  // every q fragment of the tile is requested before the first chunk (one HBM round trip per workgroup instead of one per
+  // chunk: the kernel was 84 % parked at waitcnt, profiles/r04/pmc_c_summary.txt)
+  s16x4 qall[NCH][IPW];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int it = 0; it < IPW; ++it) {
+      const int item = wave * IPW + it;
+      const int pb = item >> 2, gl = item & 3;
+      const int n = n0 + pb * 16 + l15;
+      qall[ch][it] = s16x4{0, 0, 0, 0};
+      if (n < p.N) qall[ch][it] = *reinterpret_cast<const s16x4*>(gq + ((int64_t)b * p.N + n) * (2 * C) + ch * 64 + gl * 16 + 4 * kg);
+    }
+#pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     char* at = atl[ch & 1];
     // ---- A: att chunk -> LDS ----
@@ -617,9 +737,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mla2_kernel(Mla2Params p) {
       const int item = wave * IPW + it;
       const int pb = item >> 2, gl = item & 3;           // token block of 16, group within the chunk (scale*2 + head&1)
       const int gnat = (gl >> 1) * HEADS + 2 * ch + (gl & 1);
-      const int n = n0 + pb * 16 + l15;
-      s16x4 qf = {0, 0, 0, 0};
-      if (n < p.N) qf = *reinterpret_cast<const s16x4*>(gq + ((int64_t)b * p.N + n) * (2 * C) + ch * 64 + gl * 16 + 4 * kg);
+      const s16x4 qf = qall[ch][it];
       const T* tb = gt + ((int64_t)b * G + gnat) * 1024 + lane * 4;
       const s16x4 ah = *reinterpret_cast<const s16x4*>(tb), al = *reinterpret_cast<const s16x4*>(tb + 256);
       const s16x4 kh = *reinterpret_cast<const s16x4*>(tb + 512), kl = *reinterpret_cast<const s16x4*>(tb + 768);
@@ -690,6 +808,555 @@ __global__ __launch_bounds__(NW * 64, 2) void mla2_kernel(Mla2Params p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// mbconv3s: the same three phases for Cin <= 64 (the six high-resolution MBConvs), rebuilt around what the phase ablation of
+// mbconv3 showed (profiles/r04/evit_fused_bench_b.txt: every phase's cost ADDS UP -- the workgroup is a chain of memory / LDS
+// latencies, not a throughput problem):
+//   * PERSISTENT workgroups walk the tiles of their XCD's contiguous range; the pixel fragments of a tile (UPW x KS 16-byte
+//     registers) are loaded ONCE, kept for all chunks, and the NEXT tile's are requested as soon as the last expand phase of
+//     the current tile has consumed them -- the HBM latency hides behind the depthwise + project phases and the epilogue;
+//   * W1 fragments + expand bias of chunk c+1 are requested at the start of chunk c's depthwise phase, W2 fragments of chunk
+//     c before its expand phase, the shortcut pixels at the start of the last depthwise phase: no phase starts by waiting
+//     for a global load it has just issued;
+//   * the expand epilogue writes its two 16-byte pieces in a lane-dependent order (2-way instead of 4-way bank conflicts);
+//   * the depthwise LDS reads run three input rows ahead of the MFMAs (DwRows3).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int S, int CIN, int COUT>
+__global__ __launch_bounds__(256, 2) void mbconv3s_kernel(Mb3Params p) {
+  typedef bf16_t T;
+  constexpr int NW = 4;
+  constexpr int TH = 8, TW = S == 1 ? 16 : 8, OP = TH * TW;
+  constexpr int HH = TH * S + (S == 1 ? 2 : 1), HW = TW * S + (S == 1 ? 2 : 1), HP = HH * HW;
+  constexpr int NPT = (HP + 31) / 32, MP = NPT * 32;
+  constexpr int KS = CIN / 16, NT = COUT / 32, PT = OP / 32;
+  constexpr int PITCH = S == 1 ? 192 : 160;
+  static_assert(CIN <= 64 && CIN % 16 == 0 && COUT % 32 == 0, "shape");
+  constexpr bool PF_RES = CIN <= 32;   // shortcut pixels prefetched during the last depthwise phase (registers permitting)
+  __shared__ __attribute__((aligned(16))) char mid[MP * PITCH];
+  __shared__ __attribute__((aligned(16))) char dwo[OP * 128];
+  // per-channel vectors of the whole layer, staged once per (persistent) workgroup: expand bias, depthwise bias (fp32) and the
+  // nine depthwise taps as ready-made bf16 MFMA operands; Cmid <= 256
+  __shared__ __attribute__((aligned(16))) float sb1[256];
+  __shared__ __attribute__((aligned(16))) float sbd[256];
+  __shared__ __attribute__((aligned(16))) uint64_t swd[9 * 256];   // diag operand of channel c: bf16(w) in element c % 4
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, g = lane >> 5;
+  const T* __restrict__ gx = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ gw1 = reinterpret_cast<const T*>(p.w1);
+  const T* __restrict__ gw2 = reinterpret_cast<const T*>(p.w2);
+  T* __restrict__ go = reinterpret_cast<T*>(p.out);
+
+  // ---- this workgroup's tiles: XCD xcd owns the contiguous range [first, first + cnt), its workgroups stride through it ----
+  const unsigned tpi = (unsigned)(p.tiles_x * p.tiles_y), ntiles = tpi * (unsigned)p.B;
+  const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7, wi = blockIdx.x >> 3;
+  const unsigned nx = nwg / 8 + (xcd < nwg % 8 ? 1u : 0u);
+  const unsigned tq = ntiles / 8, tr = ntiles % 8;
+  const unsigned first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, cnt = tq + (xcd < tr ? 1u : 0u);
+  if (wi >= cnt) return;
+  for (int c = tid; c < p.Cmid; c += 256) {
+    sb1[c] = p.b1[c];
+    sbd[c] = p.bd ? p.bd[c] : 0.f;
+#pragma unroll
+    for (int k9 = 0; k9 < 9; ++k9) swd[k9 * 256 + c] = (uint64_t)f32_to_bf16(p.wd[k9 * p.Cmid + c]) << (16 * (c & 3));
+  }
+
+  constexpr int UPW = (2 * NPT + NW - 1) / NW;
+  const int ejt = wave & 1;
+  constexpr int PW = PT < NW ? PT : NW, CW = NW / PW, NTW = (NT + CW - 1) / CW;
+  const int ppt = wave % PW, pnt0 = wave / PW;
+  constexpr int QN = TW / 4, WPQ = NW / QN, DROWS = TH / WPQ;
+  const int blk = lane >> 2, pi = lane & 3;
+  const int dq = wave % QN, drow0 = (wave / QN) * DROWS;
+  const unsigned daddr = lds_addr(mid + ((drow0 * S) * HW + (4 * dq + pi) * S) * PITCH + blk * 8);
+  const int nchunks = p.Cmid / 64;
+
+  // pixel fragments of a tile -> xf; xin bit u = unit u's halo pixel is inside the image
+  u32x4 xf[UPW][KS];
+  unsigned xin = 0;
+  auto load_x = [&](unsigned tile, unsigned& b_, int& oy0_, int& ox0_) {
+    b_ = tile / tpi;
+    const unsigned ti = tile - b_ * tpi;
+    const int ty = (int)(ti / (unsigned)p.tiles_x), tx = (int)(ti - ty * p.tiles_x);
+    oy0_ = ty * TH; ox0_ = tx * TW;
+    const int iy0 = oy0_ * S - 1, ix0 = ox0_ * S - 1;
+    xin = 0;
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+      const int pt = (wave + NW * u) >> 1;
+      const int hp = pt * 32 + l31;
+      const int hy = hp / HW, hx = hp - hy * HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      const bool in = pt < NPT && hp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const T* px = gx + (int64_t)(((b_ * (unsigned)p.H + (in ? iy : 0)) * (unsigned)p.W + (in ? ix : 0)) * (unsigned)CIN);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        xf[u][ks] = u32x4{0u, 0u, 0u, 0u};
+        if (in) xf[u][ks] = *reinterpret_cast<const u32x4*>(px + (2 * ks + g) * 8);
+      }
+      if (in) xin |= 1u << u;
+    }
+  };
+  u32x4 fw[KS];
+  auto load_w1 = [&](int c0) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      fw[ks] = *reinterpret_cast<const u32x4*>(gw1 + (int64_t)(c0 + ejt * 32 + l31) * p.Kp1 + (2 * ks + g) * 8);
+  };
+
+  unsigned b = 0;
+  int oy0 = 0, ox0 = 0;
+  load_x(first + wi, b, oy0, ox0);
+  load_w1(0);
+  __syncthreads();   // the staged vectors
+
+  for (unsigned t = wi; t < cnt; t += nx) {
+    const bool has_next = t + nx < cnt;
+    unsigned nb = b;
+    int noy0 = oy0, nox0 = ox0;
+    // units with a pixel outside the image / padding rows exist in this tile for this wave?
+    unsigned all_units = 0;
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) all_units |= ((wave + NW * u) >> 1) < NPT ? 1u << u : 0u;
+    const bool any_out = __builtin_amdgcn_ballot_w64((xin & all_units) != all_units) != 0ull;
+    const unsigned xin_t = xin;   // this tile's flags (xin is rewritten by the next tile's load_x)
+
+    f32x16_v accp[NTW];
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accp[tt][r] = 0.f;
+    uint2 resv[NTW][4];   // shortcut pixels (requested during the last depthwise phase)
+    const int opp = ppt * 32 + l31;
+    const int ooy = oy0 + opp / TW, oox = ox0 + opp % TW;
+    const bool ok = ooy < p.OH && oox < p.OW;
+    const int64_t opix = ((int64_t)b * p.OH + ooy) * p.OW + oox;
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int c0 = ch * 64;
+      // project weights of this chunk and the depthwise weights: requested before the expand phase
+      u32x4 fw2[NTW][4];
+#pragma unroll
+      for (int tt = 0; tt < NTW; ++tt) {
+        const int nt = pnt0 + tt * CW;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+          fw2[tt][kc] = u32x4{0u, 0u, 0u, 0u};
+          if (nt < NT) fw2[tt][kc] = *reinterpret_cast<const u32x4*>(gw2 + (int64_t)(nt * 32 + l31) * p.Kp2 + c0 + (kc * 2 + g) * 8);
+        }
+      }
+      // ================= E =================
+      f32x16_v binit;   // bias in the accumulator layout: register 4q + e = channel 8q + 4g + e of the 32-channel tile
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bb = *reinterpret_cast<const float4*>(sb1 + c0 + ejt * 32 + 8 * q + 4 * g);
+        binit[4 * q + 0] = bb.x; binit[4 * q + 1] = bb.y; binit[4 * q + 2] = bb.z; binit[4 * q + 3] = bb.w;
+      }
+#pragma unroll
+      for (int u = 0; u < UPW; ++u) {
+        const int pt = (wave + NW * u) >> 1;
+        if (pt >= NPT) continue;  // wave-uniform
+        const int hp = pt * 32 + l31;
+        f32x16_v acc = binit;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) MmaOps<T>::mma(fw[ks], xf[u][ks], acc);
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = acc[e];
+        hsw_n<16>(v);
+        if (any_out) {
+          const bool in = (xin_t >> u) & 1u;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] = in ? v[e] : 0.f;
+        }
+        u32x4 o[2];
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
+          const uint32_t c0_ = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]), c1_ = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
+          auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0_, false, false);
+          auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
+          o[qp] = u32x4{s0[0], s1[0], s0[1], s1[1]};  // channels ejt*32 + 16qp + 8g .. +8 of halo pixel hp
+        }
+        // lanes whose pixel index has bit 1 set write the qp = 1 piece first: the 8 lanes of a ds_write_b128 group then hit
+        // 4 distinct 16-byte bank slots instead of 2 (pixel pitch 192 B = 64 mod 128, pieces 32 B apart)
+        const bool flip = (l31 >> 1) & 1;
+        const u32x4 w0 = flip ? o[1] : o[0], w1v = flip ? o[0] : o[1];
+        char* rowp = mid + hp * PITCH + ((ejt * 4 + g) << 4);
+        *reinterpret_cast<u32x4*>(rowp + (flip ? 32 : 0)) = w0;
+        *reinterpret_cast<u32x4*>(rowp + (flip ? 0 : 32)) = w1v;
+      }
+      __syncthreads();
+      // next chunk's W1 fragments + bias (chunk 0 again for the next tile); after the last expand phase of this tile the next
+      // tile's pixel fragments
+      const bool last = ch + 1 == nchunks;
+      if (!last) load_w1(c0 + 64);
+      else if (has_next) {
+        if (nchunks > 1) load_w1(0);
+        load_x(first + t + nx, nb, noy0, nox0);
+      }
+      if (PF_RES && last && p.residual) {
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt) {
+          const int nt = pnt0 + tt * CW;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            resv[tt][q] = make_uint2(0u, 0u);
+            if (ok && nt < NT) resv[tt][q] = *reinterpret_cast<const uint2*>(gx + opix * CIN + nt * 32 + 8 * q + 4 * g);
+          }
+        }
+      }
+      // ================= D =================
+      {
+        s16x4 wdg[9];   // diag(w[tap][4 blk ..]): this lane is row pi of its block, element pi = its channel's tap
+#pragma unroll
+        for (int k9 = 0; k9 < 9; ++k9) wdg[k9] = __builtin_bit_cast(s16x4, swd[k9 * 256 + c0 + 4 * blk + pi]);
+        const float4 bb = *reinterpret_cast<const float4*>(sbd + c0 + 4 * blk);
+        f32x4 acc[DROWS];
+#pragma unroll
+        for (int i = 0; i < DROWS; ++i) acc[i] = f32x4{bb.x, bb.y, bb.z, bb.w};
+        DwRows3<3, DROWS, S, HW, PITCH, (CIN >= 64 ? 2 : 3)>::run(daddr, wdg, acc);
+#pragma unroll
+        for (int r = 0; r < DROWS; ++r) {
+          const int op = (drow0 + r) * TW + 4 * dq + pi;
+          *reinterpret_cast<uint2*>(dwo + op * 128 + swz(op, blk >> 1) + (blk & 1) * 8) = hsw_pack4(acc[r]);
+        }
+      }
+      __syncthreads();
+      // ================= P =================
+      {
+        const int prow = ppt * 32 + l31;
+        u32x4 fd[4];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) fd[kc] = *reinterpret_cast<const u32x4*>(dwo + prow * 128 + swz(prow, kc * 2 + g));
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt) {
+          const int nt = pnt0 + tt * CW;
+          if (nt >= NT) continue;  // wave-uniform
+#pragma unroll
+          for (int kc = 0; kc < 4; ++kc) MmaOps<T>::mma(fw2[tt][kc], fd[kc], accp[tt]);
+        }
+      }
+    }
+    // ================= out = acc + b2 (+ x) =================
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt) {
+      const int nt = pnt0 + tt * CW;
+      if (nt >= NT) continue;
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.b2 + nt * 32 + 8 * q + 4 * g);
+        v[4 * q + 0] = accp[tt][4 * q + 0] + bb.x; v[4 * q + 1] = accp[tt][4 * q + 1] + bb.y;
+        v[4 * q + 2] = accp[tt][4 * q + 2] + bb.z; v[4 * q + 3] = accp[tt][4 * q + 3] + bb.w;
+        if (p.residual) {
+          uint2 u2 = resv[tt][q];
+          if constexpr (!PF_RES) {
+            u2 = make_uint2(0u, 0u);
+            if (ok) u2 = *reinterpret_cast<const uint2*>(gx + opix * CIN + nt * 32 + 8 * q + 4 * g);
+          }
+          v[4 * q + 0] += __uint_as_float(u2.x << 16); v[4 * q + 1] += __uint_as_float(u2.x & 0xffff0000u);
+          v[4 * q + 2] += __uint_as_float(u2.y << 16); v[4 * q + 3] += __uint_as_float(u2.y & 0xffff0000u);
+        }
+      }
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
+        const uint32_t c0_ = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]), c1_ = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
+        auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0_, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
+        if (ok) {
+          const u32x4 o4 = {s0[0], s1[0], s0[1], s1[1]};
+          *reinterpret_cast<u32x4*>(go + opix * COUT + nt * 32 + 16 * qp + 8 * g) = o4;
+        }
+      }
+    }
+    b = nb; oy0 = noy0; ox0 = nox0;
+  }
+}
+
+template <int S, int CIN, int COUT>
+int launch_mb3s(Mb3Params p, hipStream_t stream) {
+  constexpr int TH = 8, TW = S == 1 ? 16 : 8;
+  p.tiles_x = (p.OW + TW - 1) / TW;
+  p.tiles_y = (p.OH + TH - 1) / TH;
+  const unsigned ntiles = (unsigned)p.B * p.tiles_x * p.tiles_y;
+  // persistent: two workgroups per CU (LDS 52 - 58 KB each), a multiple of the 8 XCDs
+  unsigned grid = 256 * 2;
+  const int gd = esam3_dev_flag("ESAM3_MB3S_GRID");
+  if (gd > 0) grid = (unsigned)gd;
+  if (grid > ntiles) grid = ntiles;
+  hipLaunchKernelGGL((mbconv3s_kernel<S, CIN, COUT>), dim3(grid), dim3(256), 0, stream, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// mbconv3b: stride-1 MBConv with Cin = Cout = 128 / 256 (the local modules of the EfficientViTBlocks of stages 3 - 4; the
+// expanded tensor has 512 / 1024 channels).  The generic kernel re-reads the tile's pixel fragments and every weight fragment
+// from L2 for every 64-channel chunk and every wave that needs them (0.45 - 0.5 MB per chunk through one CU's L1): the x loads
+// and the expand phase were 0.15 of 0.24 ms in its ablation.  Here, per persistent 8-wave workgroup:
+//   * waves 0..5 own one 32-pixel tile of the 10 x 18 halo each and keep its pixel fragments in registers for all chunks
+//     (the next tile's are requested after the last expand phase);
+//   * the chunk's weights go global -> registers -> LDS ONCE per workgroup: W1[64][Cin] (16-byte slot ^ (row & 15): conflict-
+//     free ds_read_b128 A fragments) and W2[Cout][64] (GEMM swizzle); the registers are loaded one chunk ahead (W2 of chunk
+//     c+1 and W1 of chunk c+2 are requested after chunk c's first barrier and written to LDS after chunk c+1's), so no phase
+//     waits for a load it has just issued, and the (tile, chunk) sequence is one flat stream across tile boundaries;
+//   * per-channel vectors (b1, bd, the nine depthwise taps as bf16) are staged in LDS once per workgroup.
+// LDS: mid 36 KB + dwo 16 KB + W1 16 / 32 KB + W2 16 / 32 KB + vectors 6.5 / 13 KB (Cmid 512 / 1024).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
+  typedef bf16_t T;
+  constexpr int COUT = CIN, CMID = 4 * CIN, NW = 8, S = 1;
+  constexpr int TH = 8, TW = 16, OP = TH * TW, HH = 10, HW = 18, HP = HH * HW, NPT = 6, MP = NPT * 32;
+  constexpr int KS = CIN / 16, NT = COUT / 32, NCH = CMID / 64;
+  constexpr int PITCH = 192;
+  constexpr int W1B = 64 * CIN * 2, W2B = COUT * 128;              // bytes of one chunk's weights
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* mid = smem;                                  // [192 halo px][192 B]
+  char* dwo = mid + MP * PITCH;                      // [128 px][128 B] GEMM swizzle
+  char* w1s = dwo + OP * 128;                        // [64 rows][CIN] bf16, slot ^ (row & 15)
+  char* w2s = w1s + W1B;                             // [COUT rows][64] bf16, swz(row, slot)
+  float* sb1 = reinterpret_cast<float*>(w2s + W2B);  // [CMID]
+  float* sbd = sb1 + CMID;                           // [CMID]
+  uint16_t* swd = reinterpret_cast<uint16_t*>(sbd + CMID);  // [9][CMID] bf16
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, g = lane >> 5;
+  const T* __restrict__ gx = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ gw1 = reinterpret_cast<const T*>(p.w1);
+  const T* __restrict__ gw2 = reinterpret_cast<const T*>(p.w2);
+  T* __restrict__ go = reinterpret_cast<T*>(p.out);
+
+  const unsigned tpi = (unsigned)(p.tiles_x * p.tiles_y), ntiles = tpi * (unsigned)p.B;
+  const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7, wi = blockIdx.x >> 3;
+  const unsigned nx = nwg / 8 + (xcd < nwg % 8 ? 1u : 0u);
+  const unsigned tq = ntiles / 8, tr = ntiles % 8;
+  const unsigned first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, cnt = tq + (xcd < tr ? 1u : 0u);
+  if (wi >= cnt) return;
+  for (int c = tid; c < CMID; c += 512) {
+    sb1[c] = p.b1[c];
+    sbd[c] = p.bd ? p.bd[c] : 0.f;
+#pragma unroll
+    for (int k9 = 0; k9 < 9; ++k9) swd[k9 * CMID + c] = f32_to_bf16(p.wd[k9 * CMID + c]);
+  }
+
+  // ---- weight staging by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B -> 1 KB of LDS, lane-linear): the swizzles are
+  //      applied to the SOURCE address (cdna_hip_programming.md 5.4 rule 21); wave w issues pieces w, w + 8, ...
+  const uint32_t w1_lds = lds_addr(w1s), w2_lds = lds_addr(w2s);
+  auto dma_w1 = [&](int ch) {   // W1 rows ch*64 .. +64, all CIN columns -> [row][CIN] with 16-byte slot ^ (row & 15)
+#pragma unroll
+    for (int j = 0; j < W1B / 8192; ++j) {
+      const int piece = wave + 8 * j;
+      const int byte = piece * 1024 + lane * 16;
+      const int row = byte / (CIN * 2), pslot = (byte - row * (CIN * 2)) >> 4;
+      const uint32_t voff = (uint32_t)(((ch * 64 + row) * p.Kp1 + ((pslot ^ (row & 15)) << 3)) * 2);
+      dma_piece(gw1, voff, w1_lds + (uint32_t)piece * 1024u);
+    }
+  };
+  auto dma_w2 = [&](int ch) {   // W2 rows 0 .. COUT, columns ch*64 .. +64 -> [row][128 B] with the GEMM swizzle
+#pragma unroll
+    for (int j = 0; j < W2B / 8192; ++j) {
+      const int piece = wave + 8 * j;
+      const int byte = piece * 1024 + lane * 16;
+      const int row = byte >> 7, pslot = (byte & 127) >> 4;
+      const uint32_t voff = (uint32_t)((row * p.Kp2 + ch * 64 + ((pslot ^ ((row >> 1) & 7)) << 3)) * 2);
+      dma_piece(gw2, voff, w2_lds + (uint32_t)piece * 1024u);
+    }
+  };
+
+  // ---- pixel fragments: waves 0..5 own halo pixel tile `wave` ----
+  u32x4 fa[KS];
+  bool xin = false;
+  auto load_x = [&](unsigned tile, unsigned& b_, int& oy0_, int& ox0_) {
+    b_ = tile / tpi;
+    const unsigned ti = tile - b_ * tpi;
+    const int ty = (int)(ti / (unsigned)p.tiles_x), tx = (int)(ti - ty * p.tiles_x);
+    oy0_ = ty * TH; ox0_ = tx * TW;
+    const int hp = wave * 32 + l31;
+    const int hy = hp / HW, hx = hp - hy * HW;
+    const int iy = oy0_ - 1 + hy, ix = ox0_ - 1 + hx;
+    xin = wave < NPT && hp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const T* px = gx + (int64_t)(((b_ * (unsigned)p.H + (xin ? iy : 0)) * (unsigned)p.W + (xin ? ix : 0)) * (unsigned)CIN);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      fa[ks] = u32x4{0u, 0u, 0u, 0u};
+      if (xin) fa[ks] = *reinterpret_cast<const u32x4*>(px + (2 * ks + g) * 8);
+    }
+  };
+
+  constexpr int CW = 2, NTW = NT / CW;     // project: pixel tile = wave & 3, channel tiles (wave >> 2) + 2t
+  const int ppt = wave & 3, pnt0 = wave >> 2;
+  constexpr int DROWS = 4;                 // depthwise: run of 4 columns = wave & 3, rows 4 (wave >> 2) .. + 4
+  const int blk = lane >> 2, pi = lane & 3;
+  const int dq = wave & 3, drow0 = (wave >> 2) * DROWS;
+  const unsigned daddr = lds_addr(mid + (drow0 * HW + 4 * dq + pi) * PITCH + blk * 8);
+
+  unsigned b = 0;
+  int oy0 = 0, ox0 = 0;
+  load_x(first + wi, b, oy0, ox0);
+  // prologue of the weight stream: W1(0) -> LDS
+  dma_w1(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (unsigned t = wi; t < cnt; t += nx) {
+    const bool has_next = t + nx < cnt;
+    unsigned nb = b;
+    int noy0 = oy0, nox0 = ox0;
+    const bool any_out = __builtin_amdgcn_ballot_w64(!xin && wave < NPT) != 0ull;
+    const bool xin_t = xin;
+    f32x16_v accp[NTW];
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accp[tt][r] = 0.f;
+    const int opp = ppt * 32 + l31;
+    const int ooy = oy0 + opp / TW, oox = ox0 + opp % TW;
+    const bool ok = ooy < p.OH && oox < p.OW;
+    const int64_t opix = ((int64_t)b * p.OH + ooy) * p.OW + oox;
+
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c0 = ch * 64;
+      dma_w2(ch);   // W2 buffer is free (barrier C of the previous chunk); lands under the expand phase
+      // ================= E (waves 0..5): mid[px tile = wave][64] =================
+      if (wave < NPT) {
+        const int hp = wave * 32 + l31;
+#pragma unroll
+        for (int ejt = 0; ejt < 2; ++ejt) {
+          f32x16_v acc;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 bb = *reinterpret_cast<const float4*>(sb1 + c0 + ejt * 32 + 8 * q + 4 * g);
+            acc[4 * q + 0] = bb.x; acc[4 * q + 1] = bb.y; acc[4 * q + 2] = bb.z; acc[4 * q + 3] = bb.w;
+          }
+          const int row = ejt * 32 + l31;
+          const char* wrow = w1s + row * (CIN * 2);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const u32x4 fwv = *reinterpret_cast<const u32x4*>(wrow + (((2 * ks + g) ^ (row & 15)) << 4));
+            MmaOps<T>::mma(fwv, fa[ks], acc);
+          }
+          float v[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] = acc[e];
+          hsw_n<16>(v);
+          if (any_out) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = xin_t ? v[e] : 0.f;
+          }
+          u32x4 o[2];
+#pragma unroll
+          for (int qp = 0; qp < 2; ++qp) {
+            const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
+            const uint32_t c0_ = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]), c1_ = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
+            auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0_, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
+            o[qp] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+          }
+          const bool flip = (l31 >> 1) & 1;
+          const u32x4 w0 = flip ? o[1] : o[0], w1v = flip ? o[0] : o[1];
+          char* rowp = mid + hp * PITCH + ((ejt * 4 + g) << 4);
+          *reinterpret_cast<u32x4*>(rowp + (flip ? 32 : 0)) = w0;
+          *reinterpret_cast<u32x4*>(rowp + (flip ? 0 : 32)) = w1v;
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of W2(ch) have landed
+      __syncthreads();   // A: mid and W2(ch) complete; W1 buffer free (expand done)
+      {
+        const bool last = ch + 1 == NCH;
+        if (!last || has_next) dma_w1((ch + 1) % NCH);   // flat (tile, chunk) stream; lands under depthwise + project
+        if (last && has_next) load_x(first + t + nx, nb, noy0, nox0);
+      }
+      // ================= D =================
+      {
+        s16x4 wdg[9];
+#pragma unroll
+        for (int k9 = 0; k9 < 9; ++k9) {
+          const uint64_t wv = (uint64_t)swd[k9 * CMID + c0 + 4 * blk + pi] << (16 * pi);
+          wdg[k9] = __builtin_bit_cast(s16x4, wv);
+        }
+        const float4 bb = *reinterpret_cast<const float4*>(sbd + c0 + 4 * blk);
+        f32x4 acc[DROWS];
+#pragma unroll
+        for (int i = 0; i < DROWS; ++i) acc[i] = f32x4{bb.x, bb.y, bb.z, bb.w};
+        DwRows3<3, DROWS, S, HW, PITCH, 2>::run(daddr, wdg, acc);
+#pragma unroll
+        for (int r = 0; r < DROWS; ++r) {
+          const int op = (drow0 + r) * TW + 4 * dq + pi;
+          *reinterpret_cast<uint2*>(dwo + op * 128 + swz(op, blk >> 1) + (blk & 1) * 8) = hsw_pack4(acc[r]);
+        }
+      }
+      __syncthreads();   // B: dwo complete
+      // ================= P =================
+      {
+        const int prow = ppt * 32 + l31;
+        u32x4 fd[4];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) fd[kc] = *reinterpret_cast<const u32x4*>(dwo + prow * 128 + swz(prow, kc * 2 + g));
+#pragma unroll
+        for (int tt = 0; tt < NTW; ++tt) {
+          const int wr = (pnt0 + tt * CW) * 32 + l31;
+#pragma unroll
+          for (int kc = 0; kc < 4; ++kc) {
+            const u32x4 fw2 = *reinterpret_cast<const u32x4*>(w2s + wr * 128 + swz(wr, kc * 2 + g));
+            MmaOps<T>::mma(fw2, fd[kc], accp[tt]);
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of W1(ch + 1) (and the next tile's pixels) have landed
+      __syncthreads();   // C: W1(ch + 1) complete, W2 buffer free
+    }
+    // ================= out = acc + b2 + x =================
+#pragma unroll
+    for (int tt = 0; tt < NTW; ++tt) {
+      const int nt = pnt0 + tt * CW;
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.b2 + nt * 32 + 8 * q + 4 * g);
+        v[4 * q + 0] = accp[tt][4 * q + 0] + bb.x; v[4 * q + 1] = accp[tt][4 * q + 1] + bb.y;
+        v[4 * q + 2] = accp[tt][4 * q + 2] + bb.z; v[4 * q + 3] = accp[tt][4 * q + 3] + bb.w;
+        if (p.residual && ok) {
+          const uint2 u2 = *reinterpret_cast<const uint2*>(gx + opix * CIN + nt * 32 + 8 * q + 4 * g);
+          v[4 * q + 0] += __uint_as_float(u2.x << 16); v[4 * q + 1] += __uint_as_float(u2.x & 0xffff0000u);
+          v[4 * q + 2] += __uint_as_float(u2.y << 16); v[4 * q + 3] += __uint_as_float(u2.y & 0xffff0000u);
+        }
+      }
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
+        const uint32_t c0_ = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]), c1_ = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
+        auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0_, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
+        if (ok) {
+          const u32x4 o4 = {s0[0], s1[0], s0[1], s1[1]};
+          *reinterpret_cast<u32x4*>(go + opix * COUT + nt * 32 + 16 * qp + 8 * g) = o4;
+        }
+      }
+    }
+    b = nb; oy0 = noy0; ox0 = nox0;
+  }
+}
+
+template <int CIN>
+int launch_mb3b(Mb3Params p, hipStream_t stream) {
+  p.tiles_x = (p.OW + 15) / 16;
+  p.tiles_y = (p.OH + 7) / 8;
+  const unsigned ntiles = (unsigned)p.B * p.tiles_x * p.tiles_y;
+  constexpr size_t lds = (size_t)192 * 192 + 128 * 128 + 64 * CIN * 2 + CIN * 128 + (size_t)4 * CIN * (4 + 4 + 18);
+  auto kern = mbconv3b_kernel<CIN>;
+  if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)) return -1;
+  unsigned grid = 256;   // one persistent workgroup per CU, a multiple of the 8 XCDs
+  if (grid > ntiles) grid = ntiles;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
 template <int S, int CIN, int COUT, int NW>
 int launch_mb3(Mb3Params p, hipStream_t stream) {
   constexpr int TH = 8, TW = S == 1 ? 16 : 8;
@@ -724,6 +1391,19 @@ int esam3_launch_mbconv3(const void* x, void* out, const void* w1, int Kp1, cons
   q.x = x; q.out = out; q.w1 = w1; q.b1 = b1; q.wd = wd; q.bd = bd; q.w2 = w2; q.b2 = b2;
   q.B = B; q.H = H; q.W = W; q.OH = (H + stride - 1) / stride; q.OW = (W + stride - 1) / stride;
   q.Cmid = Cmid; q.Kp1 = Kp1; q.Kp2 = Kp2; q.residual = residual & 1;
+  q.abl = esam3_dev_flag("ESAM3_MB3_ABL");
+  if (Cin <= 64 && !esam3_dev_flag("ESAM3_MB3_GENERIC")) {   // persistent + prefetching variant
+    if (Cmid > 256) { esam3_set_error("mbconv3s: Cmid %d > 256", Cmid); return -1; }
+    if (stride == 2 && Cin == 16) return launch_mb3s<2, 16, 32>(q, stream);
+    if (stride == 2 && Cin == 32) return launch_mb3s<2, 32, 64>(q, stream);
+    if (stride == 1 && Cin == 32) return launch_mb3s<1, 32, 32>(q, stream);
+    if (stride == 1) return launch_mb3s<1, 64, 64>(q, stream);
+    // 64 -> 128 stride 2: 5 x 4 pixel fragments per lane do not fit next to the prefetches: generic kernel below
+  }
+  if (stride == 1 && Cin >= 128 && Cmid == 4 * Cin && !esam3_dev_flag("ESAM3_MB3_GENERIC")) {   // weights through LDS, resident pixels
+    if (Cin == 128) return launch_mb3b<128>(q, stream);
+    return launch_mb3b<256>(q, stream);
+  }
   if (stride == 2) {
     if (Cin == 16) return launch_mb3<2, 16, 32, 4>(q, stream);
     if (Cin == 32) return launch_mb3<2, 32, 64, 4>(q, stream);
@@ -761,8 +1441,14 @@ int esam3_launch_mla_fused(const void* x, void* out, const void* wqkv, int Kpq, 
   a.B = B; a.H = H; a.W = W; a.Kpq = Kpq; a.Kpg = Kpg;
   a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 7) / 8;
   const int tiles = a.tiles_x * a.tiles_y, G = 2 * (C / 16);
-  if (C == 128) hipLaunchKernelGGL((mla1_kernel<128>), dim3((unsigned)(B * tiles)), dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL((mla1_kernel<256>), dim3((unsigned)(B * tiles)), dim3(512), 0, stream, a);
+  const size_t lds1 = (size_t)(256 + 128 + 128) * 192 + (size_t)96 * C * 2;
+  if (C == 128) {
+    if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(mla1_kernel<128>), (int)lds1)) return -1;
+    hipLaunchKernelGGL((mla1_kernel<128>), dim3((unsigned)(B * tiles)), dim3(512), lds1, stream, a);
+  } else {
+    if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(mla1_kernel<256>), (int)lds1)) return -1;
+    hipLaunchKernelGGL((mla1_kernel<256>), dim3((unsigned)(B * tiles)), dim3(512), lds1, stream, a);
+  }
   HIP_CHECK_RET(hipGetLastError());
   hipLaunchKernelGGL(mla_kvprep_kernel, dim3((unsigned)(B * G)), dim3(256), 0, stream, kvp, reinterpret_cast<bf16_t*>(tab), tiles * 2, G);
   HIP_CHECK_RET(hipGetLastError());

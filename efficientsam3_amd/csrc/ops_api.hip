@@ -3,6 +3,7 @@
 // can compare one operator at a time against the oracle.  Test-sized: every call uploads
 // its weights, synchronises and frees them.
 #include <algorithm>
+#include <cstdio>
 #include <vector>
 
 #include "../../include/esam3.h"
@@ -35,6 +36,29 @@ struct Tmp {  // scoped device allocations
     return p;
   }
 };
+
+// -DESAM3_DEV builds: ESAM3_OP_REPEAT=N re-launches the operator N times between two HIP events and prints the average
+// (tools/evit_fused_bench.py); the release library launches once
+template <typename F>
+int op_timed(const char* what, hipStream_t s, F&& launch) {
+  const int reps = esam3_dev_flag("ESAM3_OP_REPEAT");
+  if (reps <= 0) return launch();
+  hipEvent_t a, b;
+  HIP_CHECK_RET(hipEventCreate(&a));
+  HIP_CHECK_RET(hipEventCreate(&b));
+  if (launch()) return -1;   // warm-up
+  HIP_CHECK_RET(hipEventRecord(a, s));
+  for (int i = 0; i < reps; ++i)
+    if (launch()) return -1;
+  HIP_CHECK_RET(hipEventRecord(b, s));
+  HIP_CHECK_RET(hipEventSynchronize(b));
+  float ms = 0.f;
+  HIP_CHECK_RET(hipEventElapsedTime(&ms, a, b));
+  fprintf(stderr, "[op_timed] %s: %.4f ms per launch (%d launches)\n", what, ms / reps, reps);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return 0;
+}
 
 int fail(const char* what) {
   esam3_set_error("%s: device allocation/upload failed", what);
@@ -285,8 +309,10 @@ int esam3_op_mbconv_fused(int dtype, const void* x, const float* w1, const float
   float* dbd = bd ? (float*)t.up(bd, (size_t)Cmid * 4) : nullptr;
   float* db2 = (float*)t.up(b2, (size_t)Cout * 4);
   if (!d1 || !d2 || !dd || !db1 || !db2) return fail("op_mbconv_fused");
-  if (esam3_launch_mbconv_fused(dtype, x, out, d1, Kp1, db1, dd, dbd, d2, Kp2, db2, B, H, W, Cin, Cmid, Cout, stride,
-                                residual, (hipStream_t)stream))
+  if (op_timed("mbconv_fused", (hipStream_t)stream, [&]() {
+        return esam3_launch_mbconv_fused(dtype, x, out, d1, Kp1, db1, dd, dbd, d2, Kp2, db2, B, H, W, Cin, Cmid, Cout, stride, residual,
+                                         (hipStream_t)stream);
+      }))
     return -1;
   HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
   return 0;
@@ -312,8 +338,10 @@ int esam3_op_mbconv3(const void* x, const float* w1, const float* b1, const floa
   float* dbd = bd ? (float*)t.up(bd, (size_t)Cmid * 4) : nullptr;
   float* db2 = (float*)t.up(b2, (size_t)Cout * 4);
   if (!d1 || !d2 || !dd || !db1 || !db2) return fail("op_mbconv3");
-  if (esam3_launch_mbconv3(x, out, d1, Kp1, db1, dd, dbd, d2, Kp2, db2, B, H, W, Cin, Cmid, Cout, stride, residual,
-                           (hipStream_t)stream))
+  if (op_timed("mbconv3", (hipStream_t)stream, [&]() {
+        return esam3_launch_mbconv3(x, out, d1, Kp1, db1, dd, dbd, d2, Kp2, db2, B, H, W, Cin, Cmid, Cout, stride, residual,
+                                    (hipStream_t)stream);
+      }))
     return -1;
   HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
   return 0;
@@ -347,7 +375,10 @@ int esam3_op_lite_mla_block(const void* x, const float* wqkv, const float* wdw, 
   float* kvp = (float*)t.raw(kb);
   void* tab = t.raw(tb);
   if (!dq || !dg || !dp || !dd || !db || !qms || !kvp || !tab) return fail("op_lite_mla_block");
-  if (esam3_launch_mla_fused(x, out, dq, Kpq, dd, dg, Kpg, dp, Kpp, db, qms, kvp, tab, B, H, W, C, (hipStream_t)stream)) return -1;
+  if (op_timed("lite_mla_block", (hipStream_t)stream, [&]() {
+        return esam3_launch_mla_fused(x, out, dq, Kpq, dd, dg, Kpg, dp, Kpp, db, qms, kvp, tab, B, H, W, C, (hipStream_t)stream);
+      }))
+    return -1;
   HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
