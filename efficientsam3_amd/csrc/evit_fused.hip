@@ -441,11 +441,17 @@ struct Mla1Params {
   const void* wqkv;     // packed [>=3C][Kpq] bf16
   const float* wdw;     // [25][3C] fp32 (aggreg.0.0)
   const void* wgrp;     // [3C][Kpg] bf16: row = output channel, 16 inputs of its group (aggreg.0.1)
-  void* qms;            // [B][H*W][2C] bf16: relu(q), channel = chunk*64 + scale*32 + (head & 1)*16 + d
+  void* qms;            // bf16 relu(q): [B][tiles][heads / 2 chunks][4 groups = scale*2 + head&1][8 tile rows][16 px][16 ch]
   float* kvp;           // [B][tiles*2][2*heads][272] fp32 partials, [dv][dk] with row 16 = ksum
   int B, H, W, Kpq, Kpg;
   int tiles_x, tiles_y;
+  int abl;              // -DESAM3_DEV builds only: phase ablation mask (ESAM3_MLA1_ABL)
 };
+#ifdef ESAM3_DEV
+#define MLA1_ABL(bit) (p.abl & (bit))
+#else
+#define MLA1_ABL(bit) 0
+#endif
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
@@ -526,7 +532,13 @@ __global__ __launch_bounds__(512, 2) void mla1_kernel(Mla1Params p) {
   __syncthreads();   // Wqkv chunk 0 is in LDS
   for (int ch = 0; ch < NCH; ++ch) {
     const int c0 = ch * 96;   // first qkv channel of the chunk (heads 2ch, 2ch + 1)
+    // the grouped conv's six 16 x 16 weight blocks of this chunk (A operands of the P phase): requested now, used three
+    // phases later (the P phase cost 35 of 127 us waiting for them, profiles/r04/mla_ablation_e.txt)
+    s16x4 wga[6];
+#pragma unroll
+    for (int gi = 0; gi < 6; ++gi) wga[gi] = *reinterpret_cast<const s16x4*>(gwg + (int64_t)(c0 + gi * 16 + l15) * p.Kpg + 4 * kg);
     // ================= E: mid[halo px][96] = Wqkv[c0 .. c0+96) . x =================
+    if (!MLA1_ABL(1))
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       f32x16_v acc;
@@ -560,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void mla1_kernel(Mla1Params p) {
     if (ch + 1 < NCH) dma_wq(ch + 1);   // the expand phase is done with the buffer; lands under the other three phases
 
     // ================= D: dwo[px][96] = dw5x5(mid) =================
-    if (wave < 6) {
+    if (wave < 6 && !MLA1_ABL(2)) {
       s16x4 wdg[25];
 #pragma unroll
       for (int t = 0; t < 25; ++t) wdg[t] = diag_bf16(p.wdw[t * C3 + c0 + 4 * cg + pi], pi);
@@ -580,13 +592,12 @@ __global__ __launch_bounds__(512, 2) void mla1_kernel(Mla1Params p) {
     __syncthreads();
 
     // ================= P: ago[px][96] = grouped 1x1 of dwo; tile row = wave, 6 groups of 16 channels =================
-    {
+    if (!MLA1_ABL(4)) {
       const int op = wave * 16 + l15;
 #pragma unroll
       for (int gi = 0; gi < 6; ++gi) {
-        const s16x4 wa = *reinterpret_cast<const s16x4*>(gwg + (int64_t)(c0 + gi * 16 + l15) * p.Kpg + 4 * kg);
         const s16x4 xb = *reinterpret_cast<const s16x4*>(dwo + op * PITCH + gi * 32 + kg * 8);
-        const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa, xb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wga[gi], xb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         uint2 o;   // channels gi*16 + 4kg .. +4 of pixel op; pixels of the tile that lie outside the image must not reach kv
         o.x = p_in ? pack_bf16x2(d[0], d[1]) : 0u;
         o.y = p_in ? pack_bf16x2(d[2], d[3]) : 0u;
@@ -596,25 +607,25 @@ __global__ __launch_bounds__(512, 2) void mla1_kernel(Mla1Params p) {
     __syncthreads();
 
     // ================= KVQ =================
-    // relu(q): 128 pixels x 8 16-byte pieces [scale][head][half]
+    // relu(q) -> qms[b][tile][chunk][gl = scale*2 + head][tile row][px][16 ch]: the 16 pixels x 32 bytes of a (group, tile row) are
+    // contiguous = exactly what one MFMA B-operand load of pass 2 reads (the token-major layout gave it 32-byte pieces 512
+    // bytes apart).  item = (gl, row, px, half): 32 consecutive lanes write one 512-byte run
+    if (!MLA1_ABL(8))
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const int item = tid + 512 * it;
-      const int px = item >> 3, sl = item & 7;
-      const int scale = sl >> 2, hh = (sl >> 1) & 1, half = sl & 1;
-      const int py = px >> 4, pxx = px & 15;
+      const int half = item & 1, pxx = (item >> 1) & 15, py = (item >> 5) & 7, gl = item >> 8;
+      const int scale = gl >> 1, hh = gl & 1;
+      const int px = py * 16 + pxx;
       const char* src = (scale ? ago + px * PITCH : mid + ((py + 2) * HW + pxx + 2) * PITCH) + hh * 96 + half * 16;
       const uint4 v = *reinterpret_cast<const uint4*>(src);
       const s16x4 lo = relu_bf16x4(__builtin_bit_cast(s16x4, make_uint2(v.x, v.y)));
       const s16x4 hi = relu_bf16x4(__builtin_bit_cast(s16x4, make_uint2(v.z, v.w)));
       const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-      const int oy = oy0 + py, ox = ox0 + pxx;
-      if (oy < p.H && ox < p.W)
-        *reinterpret_cast<uint4*>(gq + ((int64_t)b * N + (int64_t)oy * p.W + ox) * (2 * C) + ch * 64 + sl * 8) =
-            make_uint4(l2.x, l2.y, h2.x, h2.y);
+      *reinterpret_cast<uint4*>(gq + (((int64_t)b * tpi + ti) * NCH + ch) * 8192 + item * 8) = make_uint4(l2.x, l2.y, h2.x, h2.y);
     }
     // kv partials: wave = (group gsel of 4, pixel half); 4 tile rows of 16 pixels each = 4 MFMA steps
-    {
+    if (!MLA1_ABL(16)) {
       const int gsel = wave & 3, half = wave >> 2;
       const int scale = gsel >> 1, hh = gsel & 1;
       f32x4 akv = {0.f, 0.f, 0.f, 0.f}, aks = {0.f, 0.f, 0.f, 0.f};
@@ -680,13 +691,13 @@ __global__ __launch_bounds__(256) void mla_kvprep_kernel(const float* __restrict
 // two att buffers -> one barrier per chunk.  out = acc + b (BN folded) + x.
 // =====================================================================================================================
 struct Mla2Params {
-  const void* qms;      // [B][N][2C]
+  const void* qms;      // pass 1's layout: [B][tiles][chunks][4][8][16][16]
   const void* tab;      // [B][2*heads][4][256] bf16
   const void* wp;       // packed [>=C][Kpp] bf16 (proj, BN folded)
   const float* bp;      // [C]
-  const void* x;        // [B][N][C] shortcut
-  void* out;            // [B][N][C]
-  int B, N, Kpp, tiles;
+  const void* x;        // [B][H][W][C] shortcut
+  void* out;            // [B][H][W][C]
+  int B, H, W, Kpp, tiles_x, tiles_y;
 };
 
 template <int C, int NW>
@@ -699,8 +710,10 @@ __global__ __launch_bounds__(NW * 64, 2) void mla2_kernel(Mla2Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, g = lane >> 5, l15 = lane & 15, kg = lane >> 4;
   const unsigned bid = xcd_contig(blockIdx.x, gridDim.x);
-  const unsigned b = bid / (unsigned)p.tiles;
-  const int n0 = (int)(bid - b * (unsigned)p.tiles) * 128;
+  const unsigned tpi = (unsigned)(p.tiles_x * p.tiles_y);
+  const unsigned b = bid / tpi;
+  const unsigned ti = bid - b * tpi;
+  const int oy0 = (int)(ti / (unsigned)p.tiles_x) * 8, ox0 = (int)(ti % (unsigned)p.tiles_x) * 16;
   const T* __restrict__ gq = reinterpret_cast<const T*>(p.qms);
   const T* __restrict__ gt = reinterpret_cast<const T*>(p.tab);
   const T* __restrict__ gw = reinterpret_cast<const T*>(p.wp);
@@ -723,10 +736,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mla2_kernel(Mla2Params p) {
 #pragma unroll
     for (int it = 0; it < IPW; ++it) {
       const int item = wave * IPW + it;
-      const int pb = item >> 2, gl = item & 3;
-      const int n = n0 + pb * 16 + l15;
-      qall[ch][it] = s16x4{0, 0, 0, 0};
-      if (n < p.N) qall[ch][it] = *reinterpret_cast<const s16x4*>(gq + ((int64_t)b * p.N + n) * (2 * C) + ch * 64 + gl * 16 + 4 * kg);
+      const int pb = item >> 2, gl = item & 3;   // tile row, group within the chunk
+      qall[ch][it] = *reinterpret_cast<const s16x4*>(gq + (((int64_t)b * tpi + ti) * NCH + ch) * 8192 + ((gl * 8 + pb) * 16 + l15) * 16 + 4 * kg);
     }
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
@@ -775,9 +786,10 @@ __global__ __launch_bounds__(NW * 64, 2) void mla2_kernel(Mla2Params p) {
   }
   // ---- out = acc + b + x ----
   {
-    const int n = n0 + ppt * 32 + l31;
-    const bool ok = n < p.N;
-    const int64_t row = (int64_t)b * p.N + n;
+    const int op = ppt * 32 + l31;
+    const int oy = oy0 + (op >> 4), ox = ox0 + (op & 15);
+    const bool ok = oy < p.H && ox < p.W;
+    const int64_t row = ((int64_t)b * p.H + oy) * p.W + ox;
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
       const int nt = pnt0 + t * CW;
@@ -1419,10 +1431,10 @@ int esam3_launch_mbconv3(const void* x, void* out, const void* w1, int Kp1, cons
 // ---- LiteMLA context module (ops.py:521-671 inside ResidualBlock, :740-770), fused: C = 128 / 256 channels, dim = 16 ----
 bool esam3_mla_fused_ok(int dtype, int C, int dim) { return dtype == 1 && dim == 16 && (C == 128 || C == 256); }
 
-// scratch: qms bf16 [B][N][2C], kvp fp32 [B][tiles*2][2*heads][272], tab bf16 [B][2*heads][1024]
+// scratch: qms bf16 [B][tiles][chunks][4][128][16], kvp fp32 [B][tiles*2][2*heads][272], tab bf16 [B][2*heads][1024]
 void esam3_mla_fused_scratch(int B, int H, int W, int C, size_t* qms_bytes, size_t* kvp_bytes, size_t* tab_bytes) {
   const int tiles = ((W + 15) / 16) * ((H + 7) / 8), G = 2 * (C / 16);
-  *qms_bytes = (size_t)B * H * W * 2 * C * 2;
+  *qms_bytes = (size_t)B * tiles * (C / 32) * 8192 * 2;   // [tiles][heads / 2 chunks][4 groups][128 px][16 ch] bf16
   *kvp_bytes = (size_t)B * tiles * 2 * G * 272 * 4;
   *tab_bytes = (size_t)B * G * 1024 * 2;
 }
@@ -1432,7 +1444,7 @@ void esam3_mla_fused_scratch(int B, int H, int W, int C, size_t* qms_bytes, size
 int esam3_launch_mla_fused(const void* x, void* out, const void* wqkv, int Kpq, const float* wdw, const void* wgrp, int Kpg,
                            const void* wproj, int Kpp, const float* bproj, void* qms, float* kvp, void* tab, int B, int H, int W,
                            int C, hipStream_t stream) {
-  if (!esam3_mla_fused_ok(1, C, 16) || Kpq < C || Kpg < 16 || Kpp < 2 * C || (int64_t)B * H * W * 2 * C >= ((int64_t)1 << 31)) {
+  if (!esam3_mla_fused_ok(1, C, 16) || Kpq < C || Kpg < 16 || Kpp < 2 * C || (int64_t)B * (H + 8) * (W + 16) * 2 * C >= ((int64_t)1 << 31)) {
     esam3_set_error("mla_fused: unsupported configuration C = %d", C);
     return -1;
   }
@@ -1440,6 +1452,7 @@ int esam3_launch_mla_fused(const void* x, void* out, const void* wqkv, int Kpq, 
   a.x = x; a.wqkv = wqkv; a.wdw = wdw; a.wgrp = wgrp; a.qms = qms; a.kvp = kvp;
   a.B = B; a.H = H; a.W = W; a.Kpq = Kpq; a.Kpg = Kpg;
   a.tiles_x = (W + 15) / 16; a.tiles_y = (H + 7) / 8;
+  a.abl = esam3_dev_flag("ESAM3_MLA1_ABL");
   const int tiles = a.tiles_x * a.tiles_y, G = 2 * (C / 16);
   const size_t lds1 = (size_t)(256 + 128 + 128) * 192 + (size_t)96 * C * 2;
   if (C == 128) {
@@ -1454,9 +1467,9 @@ int esam3_launch_mla_fused(const void* x, void* out, const void* wqkv, int Kpq, 
   HIP_CHECK_RET(hipGetLastError());
   Mla2Params q{};
   q.qms = qms; q.tab = tab; q.wp = wproj; q.bp = bproj; q.x = x; q.out = out;
-  q.B = B; q.N = H * W; q.Kpp = Kpp; q.tiles = (H * W + 127) / 128;
-  if (C == 128) hipLaunchKernelGGL((mla2_kernel<128, 4>), dim3((unsigned)(B * q.tiles)), dim3(256), 0, stream, q);
-  else hipLaunchKernelGGL((mla2_kernel<256, 8>), dim3((unsigned)(B * q.tiles)), dim3(512), 0, stream, q);
+  q.B = B; q.H = H; q.W = W; q.Kpp = Kpp; q.tiles_x = a.tiles_x; q.tiles_y = a.tiles_y;
+  if (C == 128) hipLaunchKernelGGL((mla2_kernel<128, 4>), dim3((unsigned)(B * tiles)), dim3(256), 0, stream, q);
+  else hipLaunchKernelGGL((mla2_kernel<256, 8>), dim3((unsigned)(B * tiles)), dim3(512), 0, stream, q);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

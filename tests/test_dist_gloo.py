@@ -519,3 +519,76 @@ def test_video_grounding_single_process():
         assert set(out) == {"pred_logits", "pred_boxes", "pred_boxes_xyxy", "pred_masks"}
         assert torch.equal(out["pred_masks"], _detector_out(t)["pred_masks"])
     assert v.chunks_built == [(0, 1), (1, 2), (2, 3)] and len(buf) <= 2
+
+
+# ---- the same bookkeeping pinned against the REAL reference function (oracle/gen_golden_video_grounding.py) ------------------
+def _describe(x):
+    if torch.is_tensor(x):
+        return {"shape": list(x.shape), "dtype": str(x.dtype).replace("torch.", ""), "sum": float(x.double().sum()),
+                "abs_sum": float(x.double().abs().sum())}
+    return {"value": x}
+
+
+def _video_trace_worker(rank, world, port, schedules, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    esdist.init_process_group("gloo")
+    try:
+        traces = {}
+        for num_frames, reverse in schedules:
+            calls = []
+
+            def detect(frame):
+                calls.append(frame)
+                return _detector_out(frame), _fpn(frame), "pos"
+
+            v = esdist.VideoGroundingMultiGPU(detect)
+            buf, per_call = {}, []
+            order = range(num_frames - 1, -1, -1) if reverse else range(num_frames)
+            for t in order:
+                n0 = len(calls)
+                out = v.forward(t, num_frames, buf, track_in_reverse=reverse, return_sam2_backbone_feats=True)
+                per_call.append({"frame": t, "detector_ran_on": calls[n0:], "buffered_frames": sorted(buf),
+                                 "out": {k: _describe(x) for k, x in sorted(out.items())}})
+            traces[f"{num_frames}_{'reverse' if reverse else 'forward'}"] = per_call
+        q.put((rank, traces))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_video_grounding_matches_reference_trace():
+    """`VideoGroundingMultiGPU.forward` against the trace of the reference's own `forward_video_grounding_multigpu`
+    (sam3/sam3/model/sam3_image.py:701-883) run on two gloo ranks with the same stub detector
+    (tests/golden/video_grounding/trace.json, written by oracle/gen_golden_video_grounding.py): per rank and per call the frames
+    the detector ran on (chunk order, round-robin assignment, next chunk built one call ahead), the frames left in the buffer
+    (previous chunk dropped), the returned keys and every tensor's shape / dtype / checksum (the all-gathered detector outputs
+    and the bf16 SAM2 features)."""
+    import json
+    with open(os.path.join(os.path.dirname(__file__), "golden", "video_grounding", "trace.json")) as f:
+        ref = json.load(f)
+    world = ref["world_size"]
+    schedules = [(5, False), (4, False), (5, True)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_video_trace_worker, args=(r, world, port, schedules, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        for name, ref_calls in ref["ranks"][str(r)].items():
+            mine = got[r][name]
+            assert len(mine) == len(ref_calls), (r, name)
+            for a, b in zip(mine, ref_calls):
+                assert a["frame"] == b["frame"] and a["detector_ran_on"] == b["detector_ran_on"], (r, name, a["frame"])
+                assert a["buffered_frames"] == b["buffered_frames"], (r, name, a["frame"], a["buffered_frames"], b["buffered_frames"])
+                assert sorted(a["out"]) == sorted(b["out"]), (r, name, a["frame"], sorted(a["out"]), sorted(b["out"]))
+                for k, d in b["out"].items():
+                    m = a["out"][k]
+                    if "value" in d:
+                        assert m == d, (k, m, d)
+                    else:
+                        assert m["shape"] == d["shape"] and m["dtype"] == d["dtype"], (k, m, d)
+                        assert abs(m["sum"] - d["sum"]) <= 1e-9 * max(1.0, d["abs_sum"]) and abs(m["abs_sum"] - d["abs_sum"]) <= 1e-9 * max(1.0, d["abs_sum"]), (k, m, d)

@@ -420,6 +420,12 @@ def test_selection_tie_fixtures_and_matching_rule():
     yard = {"cases": {"a": {"low_res": 0.2, "iou": 1e-3, "mask_iou": 0.99}, "b": {"low_res": 0.3, "iou": 3e-3, "mask_iou": 0.98}}}
     la, lb = U.bf16_case_limits(yard, "a", score_peak=0.7), U.bf16_case_limits(yard, "b", score_peak=0.3)
     assert abs(la[1] - (1.5e-3 + 2.0 ** -9)) < 1e-12 and abs(lb[1] - (4.5e-3 + 2.0 ** -10)) < 1e-12 and la[1] < lb[1]
+    # the yardstick as a distribution: the worst of the fixture image's draw and the further draws, selection flips left out
+    draws = {"cases": {"a": {"low_res": [0.25, 12.7, 0.18], "iou": [2e-3, 0.15, 5e-4], "mask_iou": [0.985, 0.69, 0.995]}}}
+    ya = U.bf16_case_yard(yard, "a", draws)
+    assert ya == {"low_res": 0.25, "iou": 2e-3, "mask_iou": 0.985, "n_draws": 3}          # the 12.7 draw is a flip (> 5 x 0.2)
+    assert U.bf16_case_yard(yard, "b", draws) == {"low_res": 0.3, "iou": 3e-3, "mask_iou": 0.98, "n_draws": 1}
+    assert U.BF16_EXCEPTIONS == {}
 
 
 def test_host_result_buffers_are_never_reused_while_referenced():

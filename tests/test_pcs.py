@@ -286,3 +286,76 @@ def test_config4_batch_8_is_image_independent():
                 assert e[k] <= lims[mode][k], (mode, i, k, e[k], lims[mode][k])
         del model, eng, out, g, x
         torch.cuda.empty_cache()
+
+
+# ---- the video path's multi-GPU entry around the REAL detector ---------------------------------------------
+def _video_engine_worker(q):
+    """One rank, RCCL ("nccl") group forced: `VideoGroundingMultiGPU` drives the engine (encode -> ground + SAM2 FPN in bf16) on
+    device tensors through the same all-gather code a multi-rank job runs."""
+    import torch.distributed as tdist
+    from efficientsam3_amd import Sam3Processor, build_efficientsam3_image_model
+    from efficientsam3_amd import dist as esdist
+    try:
+        torch.cuda.set_device(0)
+        esdist.init_process_group("nccl", device=torch.device("cuda", 0), force=True)
+        sd = schema.synthetic_state_dict("efficientvit", "b1", seed=0, enable_inst_interactivity=True)
+        sd.update(schema.synthetic_text_state_dict("MobileCLIP-S0", 16, seed=0))
+        sd.update(schema.synthetic_pcs_state_dict(seed=0))
+        model = build_efficientsam3_image_model(device="cuda", enable_inst_interactivity=True, backbone_type="efficientvit",
+                                                model_name="b1", dtype="bf16", state_dict=sd, text_encoder_type="MobileCLIP-S0",
+                                                text_encoder_context_length=16)
+        proc = Sam3Processor(model)
+        text = model.backbone.forward_text(["dog"], device="cuda")
+        frames = [torch.from_numpy(np.ascontiguousarray(np.moveaxis(synth.smooth_image_u8(seed=20 + t), -1, 0))) for t in range(3)]
+        direct, calls = {}, []
+
+        def detect(t):
+            calls.append(t)
+            bo = proc.set_image(frames[t])["backbone_out"]
+            bo.update(text)
+            out = dict(model.forward_grounding(bo, geometric_prompt=model._get_dummy_prompt()))
+            from efficientsam3_amd import box_ops
+            out["pred_boxes_xyxy"] = box_ops.box_cxcywh_to_xyxy(out["pred_boxes"])
+            s2 = bo["sam2_backbone_out"]
+            direct[t] = (out, [x.to(torch.bfloat16) for x in s2["backbone_fpn"]])
+            return out, s2["backbone_fpn"], s2["vision_pos_enc"]
+
+        v = esdist.VideoGroundingMultiGPU(detect, force_collective=True)
+        buf, ok, n_buf = {}, True, []
+        for t in range(3):
+            out = v.forward(t, 3, buf, return_sam2_backbone_feats=True)
+            torch.cuda.synchronize()
+            ref_out, ref_fpn = direct[t]
+            for k in ("pred_logits", "pred_boxes", "pred_boxes_xyxy", "pred_masks"):
+                ok &= bool(torch.equal(out[k], ref_out[k])) and out[k].is_cuda
+            for i in range(3):
+                g = out[f"tracker_backbone_fpn_{i}"]
+                ok &= g.dtype == torch.bfloat16 and bool(torch.equal(g, ref_fpn[i])) and tuple(g.shape) == tuple(ref_fpn[i].shape)
+            ok &= "tracker_backbone_pos_enc" in out
+            n_buf.append(len(buf))
+        q.put({"ok": bool(ok), "calls": calls, "chunks": v.chunks_built, "n_buf": n_buf, "backend": tdist.get_backend(),
+               "finite": bool(all(torch.isfinite(direct[t][0]["pred_masks"]).all() for t in direct))})
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put({"ok": False, "error": repr(e), "trace": traceback.format_exc()})
+    finally:
+        if tdist.is_initialized():
+            tdist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_video_grounding_entry_drives_the_engine():
+    """`dist.VideoGroundingMultiGPU` (the reference's `forward_video_grounding_multigpu`, sam3/sam3/model/sam3_image.py:701-883; its
+    bookkeeping is pinned against the reference's own trace by tests/test_dist_gloo.py) around the REAL detector: three frames
+    through `set_image` -> `forward_grounding` + the SAM2 FPN cast to bf16, all-gathered over RCCL in a one-rank group.  Every
+    frame read back from the buffer equals the detector's direct output bit for bit, the chunks are built one call ahead."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_video_engine_worker, args=(q,))
+    p.start()
+    rep = q.get(timeout=600)
+    p.join(timeout=60)
+    assert rep.get("ok"), rep
+    assert rep["backend"] == "nccl" and rep["finite"]
+    assert rep["calls"] == [0, 1, 2] and rep["chunks"] == [(0, 1), (1, 2), (2, 3)] and max(rep["n_buf"]) <= 2

@@ -151,6 +151,12 @@ def test_other_sizes_vs_oracle_live(bt, mn):
               f"iou err {e_iou:.3e} ({lim[1]:.3e}) mask IoU {miou:.6f} (floor {lim[2]:.6f})")
         assert e_trunk <= lim_t, (bt, mn, mode, e_trunk, lim_t)
         assert e_low <= lim[0] and e_iou <= lim[1] and miou >= lim[2], (bt, mn, mode, e_low, e_iou, miou, lim)
+        if mode == "f32":
+            low_f32 = low.copy()
+        else:  # the bf16 engine against its own f32 twin (same kernels' other arithmetic): inside the same envelope
+            e_twin = float(np.abs(low - low_f32).max())
+            print(f"[{bt}-{mn}] bf16 engine vs its f32 twin: low_res err {e_twin:.3e} ({lim[0]:.3e})")
+            assert e_twin <= lim[0], (bt, mn, e_twin, lim[0])
         del model
 
 
@@ -177,7 +183,7 @@ def test_tinyvit_full_shard_32_is_image_independent(golden_dir):
     for i in range(4, 32):
         assert torch.equal(out["trunk"][i], out["trunk"][i % 4]) and torch.equal(low[i], low[i % 4]) and torch.equal(iou[i], iou[i % 4]), i
     assert torch.isfinite(low).all() and float(low.std()) > 0.1
-    lim = U.bf16_worst_case_limits(U.bf16_yardstick(os.path.join(golden_dir, "tinyvit_11m")))
+    lim = U.bf16_worst_case_limits(U.bf16_yardstick(os.path.join(golden_dir, "tinyvit_11m")), os.path.join(golden_dir, "tinyvit_11m"))
     # the yardstick was taken on the smooth fixture image; two of these four inputs are uniform-noise images, whose masks
     # are speckle (mask IoU 0.9754 and 0.9639 measured on image 1 by two builds that differ in one bias summation order,
     # against a floor of 0.9778): 0.95 for the inputs without a fixture

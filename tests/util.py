@@ -92,23 +92,43 @@ def bf16_yardstick(gdir):
         return json.load(f)
 
 
-# Named exceptions to the 1.5 x rule: (golden dir name, case or stage, quantity) -> allowed value, each with the measured
-# numbers.  Stage tensors and low-res logits have NO exception (every model, every case).  The entries below are single
-# draws of quantities that amplify noise:
-#   * a 4-number IoU-head maximum whose reference draw happens to be the luckiest of the model's eleven cases;
-#   * the IoU of a thresholded mask that covers 78 % of the image with wide plateaus of logits near zero, where a pixel
-#     flips for any error of a few 1e-2 -- the engine's logits on that case are CLOSER to the reference's fp32 run
-#     (0.196) than the reference's own bf16 run is (0.272); a +-1 ulp change anywhere upstream moves this IoU by +-0.01
-#     (0.953 and 0.964 were measured on two builds that differ in the summation order of one bias).
-BF16_EXCEPTIONS = {
-    # engine 3.4e-3; the reference's own bf16 draw on this case 1.0e-3, on the model's other cases 0.9e-3 ... 3.4e-3
-    ("efficientvit_b1", "neg_pos_points_orig600x800", "iou"): 3.8e-3,
-    # engine 0.953 ... 0.964 (per prompt 0.962 / 0.978); rule 0.9727; reference-bf16 0.9831
-    ("repvit_m1.1", "two_boxes_batched", "mask_iou"): 0.95,
-    # engine 1.8e-3 / 5.3e-3 on two builds (bf16 / fp32 token stream of the mask decoder); the reference's own bf16 draws on this
-    # model's three cases: 1.8e-3, 4.1e-3, 5.0e-3
-    ("tinyvit_5m", "point_multimask", "iou"): 6.0e-3,
-}
+# No named exception to the 1.5 x rule remains (round 4): the three entries of round 3 (two 4-number IoU-head maxima and the
+# thresholded-mask IoU of RepViT-M1.1 `two_boxes_batched`) were single draws of noisy quantities measured against a single
+# draw of the reference; with the yardstick taken over several images (`bf16_case_yard`) the engine is inside 1.5 x on all.
+BF16_EXCEPTIONS = {}
+
+
+def bf16_draws(gdir):
+    """tests/golden[/<model>]/bf16ref_draws.json (oracle/gen_golden_bf16ref_draws.py): the reference-bf16-vs-reference-fp32
+    distances of every prompt case on several further seeded images, or None where the model has no such file"""
+    import json
+    import os
+    p = os.path.join(gdir, "bf16ref_draws.json")
+    if not os.path.exists(p):
+        return None
+    with open(p) as f:
+        return json.load(f)
+
+
+# a draw on which the reference's OWN bf16 run selected another mask candidate than its fp32 run (stability score across the
+# 0.98 threshold / another argmax of the predicted IoUs, mask_decoder.py:256-290) is not bf16 noise but a different output:
+# its logit distance is an order of magnitude above the others' (10 - 20 against 0.2 - 0.7).  Such draws say nothing about
+# how far a faithful bf16 run may be and are left out of the yardstick (they are what `errors_with_ties` handles).
+FLIP_FACTOR = 5.0
+
+
+def bf16_case_yard(yard, name, draws=None):
+    """the reference's own bf16 distance for prompt case `name` as a DISTRIBUTION: the fixture image's draw (bf16ref_manifest)
+    and the further draws of bf16ref_draws.json that are not selection flips -> the worst of them per quantity"""
+    c = yard["cases"][name]
+    low, iou, miou = [c["low_res"]], [c["iou"]], [c["mask_iou"]]
+    if draws is not None and name in draws["cases"]:
+        d = draws["cases"][name]
+        for lo, io, mi in zip(d["low_res"], d["iou"], d["mask_iou"]):
+            if lo > FLIP_FACTOR * c["low_res"]:
+                continue
+            low.append(lo); iou.append(io); miou.append(mi)
+    return {"low_res": max(low), "iou": max(iou), "mask_iou": min(miou), "n_draws": len(low)}
 
 
 def _gname(gdir):
@@ -126,11 +146,13 @@ def bf16_half_ulp(v: float) -> float:
 
 def bf16_case_limits(yard, name, gdir=None, score_peak=1.0):
     """(low-res logit max-abs-err, IoU-head max-abs-err, thresholded-mask IoU floor) allowed for prompt case `name`:
-    every quantity PER CASE, FACTOR x the distance the reference's own bf16-autocast run of that case is from its fp32 run.
-    The IoU head returns <= 4 scores that both the reference and the engine hold in bf16, so each carries an independent
-    rounding of up to half a bf16 ulp at the score (`score_peak`: the case's largest reference score; 2e-3 for scores in
-    [0.5, 1)) -- that term is added to the score limit, as bf16_stage_limit does for stage tensors."""
-    c = yard["cases"][name]
+    every quantity PER CASE, FACTOR x the distance the reference's own bf16-autocast run of that case is from its fp32 run --
+    the worst over the fixture image and the further seeded images of bf16ref_draws.json (`bf16_case_yard`; a maximum over a
+    logit map, a 4-number maximum and a thresholded IoU are noisy single draws).  The IoU head returns <= 4 scores that both
+    the reference and the engine hold in bf16, so each carries an independent rounding of up to half a bf16 ulp at the score
+    (`score_peak`: the case's largest reference score; 2e-3 for scores in [0.5, 1)) -- that term is added to the score limit,
+    as bf16_stage_limit does for stage tensors."""
+    c = bf16_case_yard(yard, name, bf16_draws(gdir) if gdir is not None else None)
     # absolute floor of the mask IoU: a mask whose reference bf16 run happened to flip no pixel at all (IoU 1.0) still
     # has zero crossings (2e-3 of the union)
     lim = [BF16_FACTOR * c["low_res"], BF16_FACTOR * c["iou"] + bf16_half_ulp(score_peak),
@@ -142,9 +164,9 @@ def bf16_case_limits(yard, name, gdir=None, score_peak=1.0):
     return tuple(lim)
 
 
-def bf16_worst_case_limits(yard):
-    """limits for inputs that have no fixture of their own: the loosest case of the model's yardstick"""
-    lims = [bf16_case_limits(yard, n) for n in yard["cases"]]
+def bf16_worst_case_limits(yard, gdir=None):
+    """limits for inputs that have no fixture of their own: the loosest case of the model's yardstick (all draws, `gdir` given)"""
+    lims = [bf16_case_limits(yard, n, gdir) for n in yard["cases"]]
     return max(l[0] for l in lims), max(l[1] for l in lims), min(l[2] for l in lims)
 
 
