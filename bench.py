@@ -54,7 +54,7 @@ PEAK_BF16_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(sample_images: int = 2):
+def cpu_baseline(sample_images: int = 5):
     """Time the oracle on the host cores: set_image + one predict_inst per image."""
     import numpy as np
     import torch
@@ -78,7 +78,8 @@ def cpu_baseline(sample_images: int = 2):
         times.append(time.perf_counter() - t0)
     t = float(np.median(times[1:]))
     return {"value": round(1.0 / t, 4), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{sample_images} images (after 1 warm-up) of the same synthetic workload, "
+            "seconds_per_image": [round(x, 3) for x in times[1:]],
+            "sample": f"median of {sample_images} images (after 1 warm-up) of the same synthetic workload, "
                       f"fp32 oracle, set_image + predict_inst(point+box), torch CPU {threads} threads"}
 
 
@@ -337,6 +338,9 @@ def main():
         # executed GFLOP/image, measured from the per-launch algorithmic flop counts of this run
         gf_img = sum(p_.get("algorithmic_flops_total", p_["algorithmic_flops"] * p_["launches"]) for p_ in prof) / B / 1e9
         total_k = sum(p["ms"] for p in prof)
+        # the whole step against its own floors: every launch priced at max(flops / MFMA peak, bytes / HBM peak) of ITS algorithmic work
+        floor_ms = sum(max(p_.get("algorithmic_flops_total", p_["algorithmic_flops"] * p_["launches"]) / (PEAK_BF16_TFLOPS * 1e12),
+                           p_.get("algorithmic_bytes_total", p_["algorithmic_bytes"] * p_["launches"]) / (PEAK_HBM_GBS * 1e9)) * 1e3 for p_ in prof)
         stage_ms = {}
         for p_ in prof:
             t_ = p_["tag"]
@@ -374,7 +378,8 @@ def main():
                        "gflop_per_image_executed": round(gf_img, 1), "gflop_per_image_reference_graph": None if gf_ref is None else round(gf_ref, 1),
                        "end_to_end_mfma_frac": round(value * gf_img * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
                        "kernel_ms_per_step_by_stage": {k: round(v, 3) for k, v in sorted(stage_ms.items())},
-                       "kernel_ms_per_step_total": round(total_k, 3),
+                       "kernel_ms_per_step_total": round(total_k, 3), "kernel_floor_ms_per_step": round(floor_ms, 3),
+                       "launches_per_step": sum(p_["launches"] for p_ in prof),
                        "kernel_ms_note": "per-stage kernel times come from one fully event-instrumented step before the "
                                          "timed region; in the timed steps only the dominant launch carries HIP events",
                        "pcie_inclusive_images_per_s": None if host_incl is None else round(host_incl, 1),
@@ -386,6 +391,7 @@ def main():
                                          "included); measured after the timed region, not `value`",
                        "mask_fg_fraction": round(fg, 4), "workspace_gb": round(eng.workspace_bytes() / 2 ** 30, 2)},
             "roofline": roof,
+            "step_roofline_frac": round(floor_ms / total_k, 4) if total_k > 0 else None,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

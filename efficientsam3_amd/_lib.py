@@ -106,6 +106,12 @@ SIGNATURES = {
     "esam3_dwconv_wgrad": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "esam3_lite_mla_backward": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "esam3_dwconv_dgrad": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "esam3_train_pack_bytes": (_L, [_I, _I, _I]),
+    "esam3_train_linear": (_I, [_I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
+    "esam3_train_conv3x3": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "esam3_train_dwconv": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "esam3_train_stem": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "esam3_resize_bilinear_backward": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_bn_train_workspace": (_L, [_I]),
     "esam3_bn_train_forward": (_I, [_I, _P, _P, _L, _I, _P, _P, _P, _P, C.c_double, C.c_double, _P, _P, _P, _P]),
     "esam3_bn_train_backward": (_I, [_I, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P]),

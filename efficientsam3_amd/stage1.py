@@ -354,7 +354,7 @@ class Stage1Updater:
                 float(self.growth_factor), float(self.backoff_factor), int(self.growth_interval), int(self.amp), int(zero_grads),
                 self.bf16.data_ptr() if self.bf16 is not None else None, self._ws.data_ptr(),
                 torch.cuda.current_stream().cuda_stream), "esam3_stage1_update")
-        return self.state[3]
+        return self.state[3].clone()   # a copy: state[3] is overwritten by the next step
 
     # NativeScalerWithGradNormCount.state_dict is GradScaler's: {"scale", "growth_factor", "backoff_factor",
     # "growth_interval", "_growth_tracker"}; the optimizer's adds the step count and the two moments

@@ -1,0 +1,270 @@
+"""One stage-1 distillation TRAINING STEP of an EfficientViT student on the HIP kernels.
+
+Reference: ``stage1/train_image_encoder_stage1.py:165-226`` (``train_one_epoch``: ``model.train()`` -> forward of
+``ImageStudentEncoder`` (``stage1/model.py:188-211``: backbone -> Conv1x1 + BatchNorm + GELU -> Conv3x3 -> bilinear resize to the
+embedding size) -> ``masked_mse`` + ``COSINE x masked_cosine_loss`` against the saved teacher embeddings, / ACCUMULATION_STEPS
+-> ``loss_scaler(loss, optimizer, clip_grad, parameters, update_grad)`` (``stage1/utils.py:341-368``: scale, backward, unscale,
+clip, AdamW step, scaler update) -> ``optimizer.zero_grad()``), optimizer from ``stage1/optimizer.py:6-46``.
+
+Everything that is a tensor lives on the GPU for the whole step:
+
+* the trainable parameters, their gradients and the two AdamW moments are four flat fp32 arenas (``stage1.Stage1Updater``); the
+  layer objects hold VIEWS of the parameter arena, so the update kernel's result is what the next forward reads -- nothing is
+  re-uploaded, re-packed on the host or synchronised (``train_blocks``: the ``esam3_train_*`` entry points pack on the device);
+* BatchNorm running statistics are device buffers loaded from / exported to the state dict under the reference's names
+  (``...norm.running_mean``, ``...running_var``, ``...num_batches_tracked``);
+* every gradient is written into its view of the gradient arena the moment it exists (last layer first) and handed to
+  ``dist.GradientAllReducer.push`` -- the bucketed averaging all-reduce over RCCL that ``DistributedDataParallel`` performs for the
+  reference (``train_image_encoder_stage1.py:67-72``) -- before ``Stage1Updater.step`` un-scales, clips and applies AdamW.
+
+The module owns no arithmetic: it sequences kernels (``train_blocks``, ``stage1``) and moves views around."""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import train_blocks as tb
+from .stage1 import ArenaLayout, Stage1Updater, distill_loss, distill_loss_backward, valid_mask
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+EFFICIENTVIT = {"b0": ([8, 16, 32, 64, 128], [1, 2, 2, 2, 2], 16), "b1": ([16, 32, 64, 128, 256], [1, 2, 3, 3, 4], 16)}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def conv3x3_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """dense 3x3, padding 1, NHWC; w [Cout, Cin, 3, 3] device fp32"""
+    b, h, wd, cin = x.shape
+    cout = w.shape[0]
+    out = torch.empty((b, h, wd, cout), dtype=x.dtype, device=x.device)
+    lib = _lib.load()
+    ws = tb._ws(lib.esam3_train_pack_bytes(_DT[x.dtype], cout, 9 * cin), x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.esam3_train_conv3x3(_DT[x.dtype], x.data_ptr(), tb._dev_f32(w).data_ptr(), None if bias is None else tb._dev_f32(bias).data_ptr(),
+                                           out.data_ptr(), b, h, wd, cin, cout, 0, ws.data_ptr(), _stream()), "esam3_train_conv3x3")
+    return out
+
+
+def conv3x3_dgrad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """dx of the same conv: the 3x3 conv of dy with the rotated, channel-transposed weight (packed that way on the device)"""
+    b, h, wd, cout = dy.shape
+    cin = w.shape[1]
+    dx = torch.empty((b, h, wd, cin), dtype=dy.dtype, device=dy.device)
+    lib = _lib.load()
+    ws = tb._ws(lib.esam3_train_pack_bytes(_DT[dy.dtype], cin, 9 * cout), dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(lib.esam3_train_conv3x3(_DT[dy.dtype], dy.data_ptr(), tb._dev_f32(w).data_ptr(), None, dx.data_ptr(), b, h, wd, cout, cin, 1,
+                                           ws.data_ptr(), _stream()), "esam3_train_conv3x3")
+    return dx
+
+
+def conv3x3_wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """dw [Cout, Cin, 3, 3] fp32: tap (ky, kx) is the 1x1 weight gradient of dy against x shifted by (ky - 1, kx - 1) (zero outside the image):
+    nine launches of the row-reduction GEMM ``esam3_linear_wgrad`` on shifted copies (data movement only)"""
+    b, h, wd, cin = x.shape
+    cout = dy.shape[-1]
+    xp = torch.zeros((b, h + 2, wd + 2, cin), dtype=x.dtype, device=x.device)
+    xp[:, 1:h + 1, 1:wd + 1] = x
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    for ky in range(3):
+        for kx in range(3):
+            dw[:, :, ky, kx] = tb.linear_wgrad(dy, xp[:, ky:ky + h, kx:kx + wd].contiguous())
+    return dw
+
+
+def resize_forward(x: torch.Tensor, size: int) -> torch.Tensor:
+    b, h, w, c = x.shape
+    out = torch.empty((b, size, size, c), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().esam3_op_resize_bilinear(_DT[x.dtype], x.data_ptr(), out.data_ptr(), b, h, w, size, size, c, _stream()),
+                   "esam3_op_resize_bilinear")
+    return out
+
+
+def resize_backward(dy: torch.Tensor, in_hw: Tuple[int, int]) -> torch.Tensor:
+    b, oh, ow, c = dy.shape
+    dx = torch.empty((b, in_hw[0], in_hw[1], c), dtype=dy.dtype, device=dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(_lib.load().esam3_resize_bilinear_backward(_DT[dy.dtype], dy.data_ptr(), dx.data_ptr(), b, in_hw[0], in_hw[1], oh, ow, c, _stream()),
+                   "esam3_resize_bilinear_backward")
+    return dx
+
+
+class HeadTrain:
+    """``ImageStudentEncoder.head`` + the final resize (stage1/model.py:193-211): Conv2d(Cin, E, 1, bias=False) -> BatchNorm2d(E) -> GELU ->
+    Conv2d(E, E, 3, padding=1) -> F.interpolate((S, S), bilinear) when the map is not S x S already.  Parameters under ``head.0.weight``,
+    ``head.1.weight`` / ``.bias`` (+ running statistics), ``head.3.weight`` / ``.bias``."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], embed_size: int, prefix: str = "head."):
+        g = lambda k: sd[prefix + k]  # noqa: E731
+        w0 = g("0.weight")
+        self.l0 = tb.ConvLayerTrain("pw", w0.reshape(w0.shape[0], w0.shape[1]), g("1.weight"), g("1.bias"), act="gelu",
+                                    running_mean=sd.get(prefix + "1.running_mean"), running_var=sd.get(prefix + "1.running_var"))
+        self.w3, self.b3, self.embed_size, self.prefix = g("3.weight"), g("3.bias"), embed_size, prefix
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self.a = self.l0.forward(x)
+        c = conv3x3_forward(self.a, self.w3, self.b3)
+        self.hw = tuple(c.shape[1:3])
+        return c if self.hw == (self.embed_size, self.embed_size) else resize_forward(c, self.embed_size)
+
+    def backward(self, dy: torch.Tensor, sink=None):
+        d_c = dy if self.hw == (self.embed_size, self.embed_size) else resize_backward(dy, self.hw)
+        grads = {}
+
+        def put(name, gval, shape):
+            grads[self.prefix + name] = gval.reshape(shape)
+            if sink is not None:
+                sink(self.prefix + name, grads[self.prefix + name])
+
+        put("3.bias", tb.colsum(d_c), self.b3.shape)
+        put("3.weight", conv3x3_wgrad(d_c, self.a), self.w3.shape)
+        d_a = conv3x3_dgrad(d_c, self.w3)
+        dx, g0 = self.l0.backward(d_a)
+        put("1.weight", g0["gamma"], g0["gamma"].shape)
+        put("1.bias", g0["beta"], g0["beta"].shape)
+        put("0.weight", g0["weight"], tuple(self.l0.w.shape) + (1, 1))
+        return dx, grads
+
+
+class Stage1Trainer:
+    """A stage-1 student (EfficientViT-B0 / B1 backbone + head) that trains: ``step(images, teacher, sizes_before_pad)`` is one
+    iteration of ``train_one_epoch`` (module docstring).  ``state_dict`` is the reference ``ImageStudentEncoder``'s
+    (``backbone.model.<EfficientViTBackbone keys>``, ``head.*``), BatchNorm buffers included; ``state_dict()`` returns it back (fp32, host)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], model_name: str = "b1", embed_size: int = 72, dtype: str = "f32", device="cuda",
+                 lr: float = 5e-4, weight_decay: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8, clip_grad: float = 5.0, amp: bool = False,
+                 cosine_weight: float = 0.0, accumulation_steps: int = 1, init_scale: float = 65536.0, growth_interval: int = 2000,
+                 bn_momentum: float = 0.1, group=None, force_collective: bool = False):
+        from .dist import GradientAllReducer
+        self.device = torch.device(device)
+        tb.DEVICE = str(self.device)
+        self.tdtype = {"f32": torch.float32, "bf16": torch.bfloat16}[dtype]
+        self.widths, self.depths, self.dim = EFFICIENTVIT[model_name]
+        self.embed_size, self.cosine_weight, self.accumulation_steps = embed_size, float(cosine_weight), int(accumulation_steps)
+        is_buffer = lambda k: k.endswith(("running_mean", "running_var", "num_batches_tracked"))  # noqa: E731
+        named_shapes = [(k, tuple(v.shape)) for k, v in state_dict.items() if not is_buffer(k)]
+        self.layout = ArenaLayout(named_shapes)
+        self.updater = Stage1Updater(self.layout, self.device, lr=lr, weight_decay=weight_decay, betas=betas, eps=eps, clip_grad=clip_grad,
+                                     amp=amp, init_scale=init_scale, growth_interval=growth_interval)
+        self.updater.load_params(state_dict)
+        # what the layers see: parameters = views of the arena, BatchNorm buffers = device copies of the state dict's
+        self.buffers = {k: torch.as_tensor(v).to(self.device, torch.float32).contiguous() for k, v in state_dict.items()
+                        if k.endswith(("running_mean", "running_var"))}
+        self.batches_tracked = {k: int(v) for k, v in state_dict.items() if k.endswith("num_batches_tracked")}
+        views = {name: self.updater.param(name) for name, _ in named_shapes}
+        views.update(self.buffers)
+        self.trunk = tb.EfficientViTTrunkTrain(views, self.widths, self.depths, self.dim, dtype=self.tdtype, prefix="backbone.model.")
+        for _, layer in self.trunk.norm_layers():
+            layer.momentum = bn_momentum
+        self.head = HeadTrain(views, embed_size)
+        self.head.l0.momentum = bn_momentum
+        self.names = [n for n, _ in named_shapes]
+        # gradients arrive head first, then the trunk from its last layer to the stem: the bucket order of the all-reduce
+        self._arrival = None
+        self._reducer_cls, self._group, self._force = GradientAllReducer, group, force_collective
+        self.reducer = None
+        self._micro = 0   # micro-steps accumulated since the last update
+        self.last = {}
+
+    # ---- forward / backward -------------------------------------------------------------------------------------------------
+    def forward(self, images_nchw_f32: torch.Tensor) -> torch.Tensor:
+        """student embeddings [B, S, S, E] (NHWC) in the compute dtype"""
+        feats = self.trunk.forward(images_nchw_f32)
+        return self.head.forward(feats)
+
+    def backward(self, d_preds: torch.Tensor) -> None:
+        """fills the gradient arena (accumulating: ``+=`` into the views, as autograd accumulates into ``.grad``)"""
+        order = []
+        first = self._micro == 0   # first micro-step after an update: the arena was zeroed -> plain copies; later ones accumulate
+
+        def sink(name, gval):
+            dst = self.updater.grad(name)
+            if first:
+                dst.copy_(gval)
+            else:
+                dst.add_(gval.to(torch.float32))
+            order.append(name)
+
+        d_feats, _ = self.head.backward(d_preds, sink=sink)
+        self.trunk.backward(d_feats, sink=lambda n, gv: sink("backbone.model." + n, gv))
+        if self._arrival is None:
+            self._arrival = order
+            assert sorted(order) == sorted(self.names), (set(self.names) ^ set(order))
+
+    def step(self, images_nchw_f32: torch.Tensor, teacher: torch.Tensor, sizes_before_pad: Sequence[Tuple[int, int]], lr: Optional[float] = None,
+             update_grad: bool = True) -> dict:
+        """one iteration: forward, loss, backward (scaled by the loss scale / accumulation steps), all-reduce, update.
+        ``teacher`` [B, S, S, E] (NHWC; fp32 / bf16 / fp16 as saved).  Returns device scalars: loss, grad_norm (None when
+        ``update_grad`` is False: an accumulation step)."""
+        b = images_nchw_f32.shape[0]
+        preds = self.forward(images_nchw_f32)
+        s, e = self.embed_size, preds.shape[-1]
+        valid = torch.from_numpy(valid_mask(images_nchw_f32.shape[-1], sizes_before_pad, (s, s))).to(self.device)
+        p2, t2 = preds.reshape(b, s * s, e), teacher.reshape(b, s * s, e)
+        mse, cos, _ = distill_loss(p2, t2, valid)
+        loss = (mse + self.cosine_weight * cos) / self.accumulation_steps
+        # d(loss x scale) / d(preds).  The loss scale lives in the updater's device state (it moves when a step is skipped / after
+        # growth_interval clean steps); it is read back once per iteration -- the reference's loop synchronises every iteration too
+        # (loss.item(), torch.cuda.synchronize(): train_image_encoder_stage1.py:206,226)
+        scale = float(self.updater.loss_scale) if self.updater.amp else 1.0
+        d = distill_loss_backward(p2, t2, valid, cosine_weight=self.cosine_weight, grad_scale=scale / self.accumulation_steps)
+        self.backward(d.reshape(b, s, s, e))
+        for k in self.batches_tracked:
+            self.batches_tracked[k] += 1
+        out = {"loss": loss, "grad_norm": None}
+        self._micro += 1
+        if update_grad:
+            self._allreduce()
+            out["grad_norm"] = self.updater.step(lr=lr).clone()
+            self._micro = 0
+        self.last = out
+        return out
+
+    def _allreduce(self) -> None:
+        import torch.distributed as dist
+        if not (dist.is_initialized() and (dist.get_world_size(self._group) > 1 or self._force)):
+            return
+        grads = [self.updater.grad(n) for n in self._arrival]
+        if self.reducer is None:
+            self.reducer = self._reducer_cls(grads, group=self._group, force_collective=self._force)
+        for i, g_ in enumerate(grads):
+            self.reducer.push(i, g_)
+        self.reducer.finish(grads)
+
+    # ---- state ----------------------------------------------------------------------------------------------------------------
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        sd = {n: self.updater.param(n).detach().cpu().clone() for n in self.names}
+        for prefix, layer in [("backbone.model." + p, l) for p, l in self.trunk.norm_layers()] + [("head.1", self.head.l0)]:
+            sd[prefix + ".running_mean"] = layer.running_mean.detach().cpu().clone()
+            sd[prefix + ".running_var"] = layer.running_var.detach().cpu().clone()
+        for k, v in self.batches_tracked.items():
+            sd[k] = torch.tensor(v, dtype=torch.long)
+        return sd
+
+    def gradients(self) -> Dict[str, torch.Tensor]:
+        return {n: self.updater.grad(n).detach().cpu().clone() for n in self.names}
+
+
+def adamw_state_dict(updater: Stage1Updater, names: Sequence[str]) -> dict:
+    """the arena's optimizer state in ``torch.optim.AdamW.state_dict()`` layout for the two groups ``set_weight_decay`` builds
+    (stage1/optimizer.py:32-46: has_decay first, then no_decay, each in ``named_parameters`` order; no lr_scale split): resumable by the
+    reference's ``optimizer.load_state_dict``"""
+    from .stage1 import weight_decay_groups
+    shapes = dict(updater.layout.named_shapes)
+    decay = weight_decay_groups([(n, shapes[n]) for n in names])
+    order = [n for n in names if decay[n]] + [n for n in names if not decay[n]]
+    st = updater.state.cpu()
+    state = {i: {"step": torch.tensor(float(st[4])), "exp_avg": updater.view(updater.exp_avg, n).detach().cpu().clone(),
+                 "exp_avg_sq": updater.view(updater.exp_avg_sq, n).detach().cpu().clone()} for i, n in enumerate(order)}
+    n_decay = sum(1 for n in names if decay[n])
+    common = dict(lr=updater.lr, betas=tuple(updater.betas), eps=updater.eps, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                  differentiable=False, fused=None)
+    groups = [dict(common, weight_decay=updater.weight_decay, params=list(range(n_decay))),
+              dict(common, weight_decay=0.0, params=list(range(n_decay, len(order))))]
+    return {"state": state, "param_groups": groups, "param_names": order}

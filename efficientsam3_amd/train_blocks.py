@@ -4,9 +4,12 @@ blocks of the stage-1 student-trunk backward, which as a whole is not built).  T
 1x1 expand + Hardswish, depthwise 3x3 + Hardswish, 1x1 project, BatchNorm after each; ResidualBlock adds the input), run under
 ``model.train()`` by ``stage1/train_image_encoder_stage1.py:165``.  Everything is NHWC on the GPU; weight gradients come back fp32.
 
-This module is a thin composition: it owns no arithmetic.  It exists so that the gradient kernels (``esam3_act_backward``,
-``esam3_bn_train_backward``, ``esam3_linear_wgrad``, ``esam3_dwconv_wgrad``) are exercised in the order and with the tensors a real
-block hands them, and checked against ``torch.autograd`` (tests/test_train_blocks.py)."""
+This module is a thin composition: it owns no arithmetic.  It sequences the gradient kernels (``esam3_act_backward``,
+``esam3_bn_train_backward``, ``esam3_linear_wgrad``, ``esam3_dwconv_wgrad``, ...) in the order and with the tensors a real block hands
+them; every block is checked against ``torch.autograd`` (tests/test_train_blocks.py).  Weights may be host tensors (the block tests:
+packed on the CPU by the ``esam3_op_*`` test entry points) or DEVICE fp32 tensors -- views of the optimizer's flat arena
+(``stage1.Stage1Updater``), the form ``stage1_train.Stage1Trainer`` uses: then the ``esam3_train_*`` entry points re-pack them on the
+device every call (no host copy, no synchronisation) and a parameter update is seen by the next forward without any reload."""
 from __future__ import annotations
 
 import numpy as np
@@ -44,21 +47,47 @@ def act_backward(x: torch.Tensor, dy: torch.Tensor, act) -> torch.Tensor:
     return dx
 
 
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _dev_f32(t: torch.Tensor) -> torch.Tensor:
+    assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "device-resident weights are contiguous fp32 (arena views)"
+    return t
+
+
 def linear_forward(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor = None) -> torch.Tensor:
     """x [..., K] @ w[N, K]^T (+ bias): a 1x1 conv on NHWC rows"""
     k, n = x.shape[-1], w.shape[0]
     m = x.numel() // k
     out = torch.empty(x.shape[:-1] + (n,), dtype=x.dtype, device=x.device)
+    lib = _lib.load()
+    if w.is_cuda:   # device-resident master weight: packed on the device, no host round trip
+        ws = _ws(lib.esam3_train_pack_bytes(_DT[x.dtype], n, k), x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.esam3_train_linear(_DT[x.dtype], x.data_ptr(), _dev_f32(w).data_ptr(), None if bias is None else _dev_f32(bias).data_ptr(),
+                                              out.data_ptr(), m, n, k, 0, ws.data_ptr(), _stream()), "esam3_train_linear")
+        return out
     wh = _host(w)
     bh = None if bias is None else _host(bias)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().esam3_op_linear(_DT[x.dtype], x.data_ptr(), wh.ctypes.data, None if bh is None else bh.ctypes.data, None,
-                                               out.data_ptr(), m, n, k, 0, _stream()), "esam3_op_linear")
+        _lib.check(lib.esam3_op_linear(_DT[x.dtype], x.data_ptr(), wh.ctypes.data, None if bh is None else bh.ctypes.data, None,
+                                       out.data_ptr(), m, n, k, 0, _stream()), "esam3_op_linear")
     return out
 
 
 def linear_dgrad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """dx [..., K] = dy [..., N] @ w[N, K]: the forward operator with the transposed weight"""
+    if w.is_cuda:
+        n, k = w.shape
+        m = dy.numel() // n
+        dx = torch.empty(dy.shape[:-1] + (k,), dtype=dy.dtype, device=dy.device)
+        lib = _lib.load()
+        ws = _ws(lib.esam3_train_pack_bytes(_DT[dy.dtype], k, n), dy.device)
+        with torch.cuda.device(dy.device):
+            _lib.check(lib.esam3_train_linear(_DT[dy.dtype], dy.data_ptr(), _dev_f32(w).data_ptr(), None, dx.data_ptr(), m, k, n, 1, ws.data_ptr(),
+                                              _stream()), "esam3_train_linear")
+        return dx
     return linear_forward(dy, w.t().contiguous())
 
 
@@ -79,11 +108,18 @@ def dwconv_forward(x: torch.Tensor, w: torch.Tensor, stride: int = 1, bias: torc
     """depthwise k x k (3 | 5), padding k / 2, on x [B, H, W, C]; w [C, 1, k, k]"""
     b, h, wd, c = x.shape
     out = torch.empty((b, (h + stride - 1) // stride, (wd + stride - 1) // stride, c), dtype=x.dtype, device=x.device)
+    ks = int(w.shape[-1])
+    if w.is_cuda:
+        ws = _ws(4 * ks * ks * c, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().esam3_train_dwconv(_DT[x.dtype], x.data_ptr(), _dev_f32(w).data_ptr(), None if bias is None else _dev_f32(bias).data_ptr(),
+                                                      out.data_ptr(), b, h, wd, c, ks, stride, ws.data_ptr(), _stream()), "esam3_train_dwconv")
+        return out
     wh = _host(w)
     bh = None if bias is None else _host(bias)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().esam3_op_dwconv(_DT[x.dtype], x.data_ptr(), wh.ctypes.data, None if bh is None else bh.ctypes.data, out.data_ptr(), b, h,
-                                               wd, c, int(w.shape[-1]), stride, 0, _stream()), "esam3_op_dwconv")
+                                               wd, c, ks, stride, 0, _stream()), "esam3_op_dwconv")
     return out
 
 
@@ -127,15 +163,18 @@ class ConvLayerTrain:
     ``beta`` are given, else a conv bias -> activation, with the tensors the backward needs kept on the object."""
 
     def __init__(self, kind: str, weight: torch.Tensor, gamma: torch.Tensor = None, beta: torch.Tensor = None, act=None, eps: float = 1e-5,
-                 momentum: float = 0.1, stride: int = 1, bias: torch.Tensor = None):
+                 momentum: float = 0.1, stride: int = 1, bias: torch.Tensor = None, running_mean: torch.Tensor = None,
+                 running_var: torch.Tensor = None):
         assert kind in ("pw", "dw") and (stride == 1 or kind == "dw") and (gamma is None) == (beta is None)
         self.kind, self.w, self.act, self.eps, self.momentum, self.stride, self.bias = kind, weight, act, eps, momentum, stride, bias
         self.norm = gamma is not None
         if self.norm:
+            # device fp32 tensors are kept AS GIVEN (views of the optimizer's arena stay views: an update is seen at once)
             self.gamma, self.beta = gamma.float().to(DEVICE).contiguous(), beta.float().to(DEVICE).contiguous()
             c = gamma.numel()
-            self.running_mean = torch.zeros(c, dtype=torch.float32, device=DEVICE)
-            self.running_var = torch.ones(c, dtype=torch.float32, device=DEVICE)
+            # BatchNorm buffers: the state dict's norm.running_mean / running_var when given (updated in place, exported by the trainer)
+            self.running_mean = torch.zeros(c, dtype=torch.float32, device=DEVICE) if running_mean is None else running_mean.float().to(DEVICE).contiguous()
+            self.running_var = torch.ones(c, dtype=torch.float32, device=DEVICE) if running_var is None else running_var.float().to(DEVICE).contiguous()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self.x = x
@@ -175,7 +214,8 @@ class MBConvTrain:
         """``params``: "<layer>.weight" plus either "<layer>.gamma" / ".beta" (a BatchNorm follows) or "<layer>.bias" (the fewer_norm form of
         stages 3-4 and of the EfficientViTBlock's local module: use_bias=(True, True, False), norm=(None, None, bn2d), ops.py:704-711)."""
         assert not (residual and stride != 1)
-        kw = lambda n: dict(gamma=params.get(f"{n}.gamma"), beta=params.get(f"{n}.beta"), bias=params.get(f"{n}.bias"))  # noqa: E731
+        kw = lambda n: dict(gamma=params.get(f"{n}.gamma"), beta=params.get(f"{n}.beta"), bias=params.get(f"{n}.bias"),  # noqa: E731
+                            running_mean=params.get(f"{n}.running_mean"), running_var=params.get(f"{n}.running_var"))
         self.inv = ConvLayerTrain("pw", params["inverted.weight"], act=act, **kw("inverted"))
         self.dw = ConvLayerTrain("dw", params["depth.weight"], act=act, stride=stride, **kw("depth"))
         self.pw = ConvLayerTrain("pw", params["point.weight"], act=None, **kw("point"))
@@ -199,8 +239,9 @@ class DSConvTrain:
     BatchNorm + Hardswish, pointwise 1x1 + BatchNorm; ``y = x + block(x)``."""
 
     def __init__(self, params: dict, residual: bool = True, act="hswish"):
-        self.dw = ConvLayerTrain("dw", params["depth.weight"], params["depth.gamma"], params["depth.beta"], act)
-        self.pw = ConvLayerTrain("pw", params["point.weight"], params["point.gamma"], params["point.beta"], None)
+        rs = lambda n: dict(running_mean=params.get(f"{n}.running_mean"), running_var=params.get(f"{n}.running_var"))  # noqa: E731
+        self.dw = ConvLayerTrain("dw", params["depth.weight"], params["depth.gamma"], params["depth.beta"], act, **rs("depth"))
+        self.pw = ConvLayerTrain("pw", params["point.weight"], params["point.gamma"], params["point.beta"], None, **rs("point"))
         self.residual = residual
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -227,14 +268,22 @@ def lite_mla_backward(ms: torch.Tensor, dout: torch.Tensor, groups: int, dim: in
 
 
 def _blockdiag(wg: torch.Tensor, gs: int) -> torch.Tensor:
-    """grouped 1x1 weight [C, gs, 1, 1] (group size gs) -> the dense block-diagonal [C, C] matrix the engine's GEMM runs"""
+    """grouped 1x1 weight [C, gs, 1, 1] (group size gs) -> the dense block-diagonal [C, C] matrix the engine's GEMM runs; pure data
+    movement, on the weight's own device (a device-resident weight changes every step: rebuilt per forward)"""
     c = wg.shape[0]
-    dense = torch.zeros((c, c), dtype=torch.float32)
-    w2 = wg.detach().float().cpu().reshape(c, gs)
-    for o in range(c):
-        g0 = (o // gs) * gs
-        dense[o, g0:g0 + gs] = w2[o]
-    return dense
+    g = c // gs
+    dense = torch.zeros((g, gs, g, gs), dtype=torch.float32, device=wg.device)
+    idx = torch.arange(g, device=wg.device)
+    dense[idx, :, idx, :] = wg.detach().float().reshape(g, gs, gs)
+    return dense.reshape(c, c)
+
+
+def _blockdiag_extract(dense: torch.Tensor, gs: int) -> torch.Tensor:
+    """the diagonal gs x gs blocks of a dense [C, C] matrix -> [C, gs, 1, 1] (the grouped weight's gradient inside dy^T x)"""
+    c = dense.shape[0]
+    g = c // gs
+    idx = torch.arange(g, device=dense.device)
+    return dense.reshape(g, gs, g, gs)[idx, :, idx, :].reshape(c, gs, 1, 1).contiguous()
 
 
 class LiteMLATrain:
@@ -244,14 +293,15 @@ class LiteMLATrain:
     def __init__(self, params: dict, dim: int, eps: float = 1e-15):
         self.p, self.dim, self.eps = params, dim, eps
         self.c = params["qkv.weight"].shape[1]
-        self.proj = ConvLayerTrain("pw", params["proj.weight"], params["proj.gamma"], params["proj.beta"], None)
-        self.wg_dense = _blockdiag(params["aggreg.pw.weight"], dim)
+        self.proj = ConvLayerTrain("pw", params["proj.weight"], params["proj.gamma"], params["proj.beta"], None,
+                                   running_mean=params.get("proj.running_mean"), running_var=params.get("proj.running_var"))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         b, h, w, c = x.shape
         self.x = x
         self.qkv = linear_forward(x, self.p["qkv.weight"])                       # [B, H, W, 3C]
         self.agg1 = dwconv_forward(self.qkv, self.p["aggreg.dw.weight"], 1)     # depthwise 5x5
+        self.wg_dense = _blockdiag(self.p["aggreg.pw.weight"], self.dim)         # from the CURRENT grouped weight
         agg2 = linear_forward(self.agg1, self.wg_dense)                          # grouped 1x1 as a block-diagonal GEMM
         self.ms = torch.cat([self.qkv, agg2], dim=-1).reshape(b, h * w, 6 * c).contiguous()
         self.groups = 2 * (c // self.dim)
@@ -268,8 +318,7 @@ class LiteMLATrain:
         d_ms = d_ms.reshape(b, h, w, 6 * c)
         d_qkv_direct, d_agg2 = d_ms[..., :3 * c].contiguous(), d_ms[..., 3 * c:].contiguous()
         dense = linear_wgrad(d_agg2, self.agg1)                                  # [3C, 3C]; only its diagonal blocks are the grouped weight's
-        gs = self.dim
-        dwg = torch.stack([dense[o, (o // gs) * gs:(o // gs) * gs + gs] for o in range(3 * c)]).reshape(3 * c, gs, 1, 1)
+        dwg = _blockdiag_extract(dense, self.dim)
         d_agg1 = linear_dgrad(d_agg2, self.wg_dense)
         dwd = dwconv_wgrad(self.qkv, d_agg1, 1, 5)
         d_qkv = (d_qkv_direct.float() + dwconv_dgrad(d_agg1, self.p["aggreg.dw.weight"], (h, w), 1).float()).to(dy.dtype)
@@ -306,6 +355,12 @@ def stem_forward(img_nchw_f32: torch.Tensor, w: torch.Tensor, dtype: torch.dtype
     b, _, h, wd = img_nchw_f32.shape
     cout = w.shape[0]
     out = torch.empty((b, (h + 1) // 2, (wd + 1) // 2, cout), dtype=dtype, device=img_nchw_f32.device)
+    if w.is_cuda:
+        ws = _ws(108 * cout, img_nchw_f32.device)
+        with torch.cuda.device(img_nchw_f32.device):
+            _lib.check(_lib.load().esam3_train_stem(_DT[dtype], img_nchw_f32.data_ptr(), _dev_f32(w).data_ptr(), out.data_ptr(), b, h, wd, cout,
+                                                    ws.data_ptr(), _stream()), "esam3_train_stem")
+        return out
     wh = _host(w)
     with torch.cuda.device(img_nchw_f32.device):
         _lib.check(_lib.load().esam3_op_stem(_DT[dtype], img_nchw_f32.data_ptr(), wh.ctypes.data, None, out.data_ptr(), b, h, wd, cout, 0, _stream()),
@@ -324,12 +379,13 @@ def stem_im2col(img_nchw_f32: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 class StemConvTrain:
     """input_stem.op_list.0: ConvLayer(3 -> C0, 3x3, stride 2) + BatchNorm + Hardswish on the image (backbone.py:50-58).  No input gradient."""
 
-    def __init__(self, weight: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, dtype: torch.dtype, act="hswish", eps=1e-5, momentum=0.1):
+    def __init__(self, weight: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, dtype: torch.dtype, act="hswish", eps=1e-5, momentum=0.1,
+                 running_mean: torch.Tensor = None, running_var: torch.Tensor = None):
         self.w, self.act, self.dtype, self.eps, self.momentum = weight, act, dtype, eps, momentum
         self.gamma, self.beta = gamma.float().to(DEVICE).contiguous(), beta.float().to(DEVICE).contiguous()
         c = gamma.numel()
-        self.running_mean = torch.zeros(c, dtype=torch.float32, device=DEVICE)
-        self.running_var = torch.ones(c, dtype=torch.float32, device=DEVICE)
+        self.running_mean = torch.zeros(c, dtype=torch.float32, device=DEVICE) if running_mean is None else running_mean.float().to(DEVICE).contiguous()
+        self.running_var = torch.ones(c, dtype=torch.float32, device=DEVICE) if running_var is None else running_var.float().to(DEVICE).contiguous()
 
     def forward(self, img: torch.Tensor) -> torch.Tensor:
         self.img = img
@@ -365,6 +421,9 @@ class EfficientViTTrunkTrain:
             if prefix + f"{base}.{name}.norm.weight" in sd:
                 p[f"{kind}.gamma"] = g(f"{base}.{name}.norm.weight"); back[f"{kind}.gamma"] = f"{base}.{name}.norm.weight"
                 p[f"{kind}.beta"] = g(f"{base}.{name}.norm.bias"); back[f"{kind}.beta"] = f"{base}.{name}.norm.bias"
+                for stat in ("running_mean", "running_var"):   # BatchNorm buffers: loaded when the state dict has them
+                    if prefix + f"{base}.{name}.norm.{stat}" in sd:
+                        p[f"{kind}.{stat}"] = g(f"{base}.{name}.norm.{stat}")
             return p, back
 
         def mbconv(base, residual, stride):
@@ -374,7 +433,10 @@ class EfficientViTTrunkTrain:
                 p.update(a); back.update(b_)
             return MBConvTrain(p, residual=residual, stride=stride), back
 
-        self.stem = StemConvTrain(g("input_stem.op_list.0.conv.weight"), g("input_stem.op_list.0.norm.weight"), g("input_stem.op_list.0.norm.bias"), dtype)
+        self.shapes = {k[len(prefix):]: tuple(v.shape) for k, v in sd.items() if k.startswith(prefix)}
+        self.stem = StemConvTrain(g("input_stem.op_list.0.conv.weight"), g("input_stem.op_list.0.norm.weight"), g("input_stem.op_list.0.norm.bias"), dtype,
+                                  running_mean=sd.get(prefix + "input_stem.op_list.0.norm.running_mean"),
+                                  running_var=sd.get(prefix + "input_stem.op_list.0.norm.running_var"))
         for i in range(1, depth_list[0] + 1):
             base = f"input_stem.op_list.{i}.main"
             p, back = {}, {}
@@ -392,6 +454,9 @@ class EfficientViTTrunkTrain:
                 pc = {"qkv.weight": g(f"{cb}.qkv.conv.weight").flatten(1), "aggreg.dw.weight": g(f"{cb}.aggreg.0.0.weight"),
                       "aggreg.pw.weight": g(f"{cb}.aggreg.0.1.weight"), "proj.weight": g(f"{cb}.proj.conv.weight").flatten(1),
                       "proj.gamma": g(f"{cb}.proj.norm.weight"), "proj.beta": g(f"{cb}.proj.norm.bias")}
+                for stat in ("running_mean", "running_var"):
+                    if prefix + f"{cb}.proj.norm.{stat}" in sd:
+                        pc[f"proj.{stat}"] = g(f"{cb}.proj.norm.{stat}")
                 back = {"context.qkv.weight": f"{cb}.qkv.conv.weight", "context.aggreg.dw.weight": f"{cb}.aggreg.0.0.weight",
                         "context.aggreg.pw.weight": f"{cb}.aggreg.0.1.weight", "context.proj.weight": f"{cb}.proj.conv.weight",
                         "context.proj.gamma": f"{cb}.proj.norm.weight", "context.proj.beta": f"{cb}.proj.norm.bias"}
@@ -407,15 +472,40 @@ class EfficientViTTrunkTrain:
             x = blk.forward(x)
         return x
 
-    def backward(self, dy: torch.Tensor) -> dict:
+    def backward(self, dy: torch.Tensor, sink=None) -> dict:
+        """gradients of every parameter under its state-dict name AND in its state-dict shape (a 1x1 conv weight comes back
+        [N, K, 1, 1]); ``sink(name, grad)`` is called as soon as a gradient exists (last layer first: the order a bucketed all-reduce
+        wants, ``dist.GradientAllReducer.push``)"""
         grads = {}
+
+        def put(name, gval):
+            grads[name] = gval.reshape(self.shapes[name])
+            if sink is not None:
+                sink(name, grads[name])
+
         d = dy
         for blk, back in reversed(self.layers):
             d, g_ = blk.backward(d)
             for k, name in back.items():
-                grads[name] = g_[k]
+                put(name, g_[k])
         _, g_ = self.stem.backward(d)
-        grads["input_stem.op_list.0.conv.weight"] = g_["weight"]
-        grads["input_stem.op_list.0.norm.weight"] = g_["gamma"]
-        grads["input_stem.op_list.0.norm.bias"] = g_["beta"]
+        put("input_stem.op_list.0.conv.weight", g_["weight"])
+        put("input_stem.op_list.0.norm.weight", g_["gamma"])
+        put("input_stem.op_list.0.norm.bias", g_["beta"])
         return grads
+
+    def norm_layers(self):
+        """(state-dict prefix of the BatchNorm, layer object holding running_mean / running_var) of every BatchNorm of the trunk"""
+        out = [("input_stem.op_list.0.norm", self.stem)]
+        for blk, back in self.layers:
+            subs = []
+            if isinstance(blk, EfficientViTBlockTrain):
+                subs = [("context.proj", blk.context.proj), ("local.inverted", blk.local.inv), ("local.depth", blk.local.dw), ("local.point", blk.local.pw)]
+            elif isinstance(blk, MBConvTrain):
+                subs = [("inverted", blk.inv), ("depth", blk.dw), ("point", blk.pw)]
+            elif isinstance(blk, DSConvTrain):
+                subs = [("depth", blk.dw), ("point", blk.pw)]
+            for key, layer in subs:
+                if getattr(layer, "norm", False) and f"{key}.gamma" in back:
+                    out.append((back[f"{key}.gamma"][:-len(".weight")], layer))
+        return out

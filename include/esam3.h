@@ -245,6 +245,33 @@ int esam3_lite_mla_backward(int dtype, const void* ms_dev, const void* dout_dev,
 int esam3_dwconv_dgrad(int dtype, const void* dy_dev, const float* w_dev, void* dx_dev, int B, int H, int W, int C, int ksize,
                        int stride, void* hip_stream);
 
+/* Training-path operators on DEVICE-RESIDENT fp32 master weights (csrc/kernels_train_dev.hip): the parameters of a stage-1 student
+ * live in the optimizer's flat fp32 arena on the device (esam3_stage1_update) and change every step, so these entry points take the
+ * weight where it lies, re-pack it on the device into the forward kernel's layout (workspace_dev) and launch the engine's own
+ * kernels -- no host copy, no synchronisation.  Replaces, for the student of stage1/model.py:188-211 under model.train()
+ * (stage1/train_image_encoder_stage1.py:165-217), the forward of every Conv2d and, with `transpose` / `dgrad`, its data gradient.
+ *   esam3_train_pack_bytes: workspace bytes of esam3_train_linear (N, K) / esam3_train_conv3x3 (N = Cout, K = 9 Cin);
+ *     esam3_train_dwconv needs 4 k k C bytes, esam3_train_stem 108 Cout bytes.
+ *   esam3_train_linear: out[M][N] = x[M][K] . W^T + bias, W = w_dev [N][K] (transpose = 0) or w_dev [K][N] read transposed
+ *     (transpose = 1: the data gradient dx[M][N] = dy[M][K] . W of a Linear whose weight is [K][N]).
+ *   esam3_train_conv3x3: 3x3, padding 1, w_dev [Cout][Cin][3][3] (+ bias); dgrad = 1: x is dy [B][H][W][Cin] with Cin = the
+ *     FORWARD conv's output channels, w_dev the forward weight [Cin][Cout][3][3], out = dx [B][H][W][Cout].
+ *   esam3_train_dwconv: depthwise k x k (3 | 5), stride 1 | 2, w_dev [C][1][k][k].  esam3_train_stem: the 3 -> Cout stride-2 3x3
+ *     stem conv on the fp32 NCHW image, w_dev [Cout][3][3][3], no bias / activation (BatchNorm + Hardswish follow as steps).
+ *   esam3_resize_bilinear_backward: dx [B][IH][IW][C] = adjoint of F.interpolate(x, (OH, OW), bilinear, align_corners=False)
+ *     applied to dy [B][OH][OW][C] (the student's final resize, stage1/model.py:205-210); C % 8 == 0. */
+int64_t esam3_train_pack_bytes(int dtype, int N, int K);
+int esam3_train_linear(int dtype, const void* x_dev, const float* w_dev, const float* bias_dev, void* out_dev, int64_t M, int N, int K,
+                       int transpose, void* workspace_dev, void* hip_stream);
+int esam3_train_conv3x3(int dtype, const void* x_dev, const float* w_dev, const float* bias_dev, void* out_dev, int B, int H, int W,
+                        int Cin, int Cout, int dgrad, void* workspace_dev, void* hip_stream);
+int esam3_train_dwconv(int dtype, const void* x_dev, const float* w_dev, const float* bias_dev, void* out_dev, int B, int H, int W, int C,
+                       int ksize, int stride, void* workspace_dev, void* hip_stream);
+int esam3_train_stem(int dtype, const float* img_nchw_dev, const float* w_dev, void* out_dev, int B, int H, int W, int Cout,
+                     void* workspace_dev, void* hip_stream);
+int esam3_resize_bilinear_backward(int dtype, const void* dy_dev, void* dx_dev, int B, int IH, int IW, int OH, int OW, int C,
+                                   void* hip_stream);
+
 /* Update half of the stage-1 training step: AMP loss scaler + gradient-norm clipping + AdamW on ONE flat fp32 arena.
  * Replaces, for a student whose trainable parameters live in `params` (each tensor padded to a multiple of 256 elements),
  *   NativeScalerWithGradNormCount.__call__ after backward (stage1/utils.py:347-362): GradScaler.unscale_ (non-finite
