@@ -751,6 +751,7 @@ struct esam3_engine {
   int encode(const float* img, int B, const esam3_image_features* out);
   int decode(const esam3_prompts* pr, const esam3_decode_out* out);
   int precompute_pe();
+  PackedGemm* pk_kv_cat(const std::string& ap);
   // ---- PCS text-grounding detector -------------------------------------------------------------
   bool pcs_ready = false;
   bool text_causal = false;  // MobileCLIP-B masks its text self-attention causally (esam3_set_text_causal)
@@ -2224,6 +2225,29 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
 // PositionEmbeddingRandom on the 72x72 grid (prompt_encoder.py:223-234) and its projections
 // through the k_proj / q_proj weights of the image-side cross attentions, so that
 // proj(keys + pe) = proj(keys) + PEproj is a residual in the GEMM epilogue.
+// k_proj and v_proj of a token -> image attention concatenated into one [256][256] linear (rows: k then v)
+PackedGemm* E::pk_kv_cat(const std::string& ap) {
+  const std::string key = ap + "kv_proj#cat";
+  auto it = gemms.find(key + ".weight");
+  if (it != gemms.end()) return &it->second;
+  if (!find(key + ".weight")) {
+    const HostTensor *kw = need(ap + "k_proj.weight"), *vw = need(ap + "v_proj.weight"), *kbias = need(ap + "k_proj.bias"),
+                     *vbias = need(ap + "v_proj.bias");
+    if (!kw || !vw || !kbias || !vbias) return nullptr;
+    HostTensor cw, cb;
+    cw.shape = {kw->shape[0] + vw->shape[0], kw->shape[1]};
+    cw.d = kw->d;
+    cw.d.insert(cw.d.end(), vw->d.begin(), vw->d.end());
+    cb.shape = {(int64_t)(kbias->d.size() + vbias->d.size())};
+    cb.d = kbias->d;
+    cb.d.insert(cb.d.end(), vbias->d.begin(), vbias->d.end());
+    mark_packed(kw); mark_packed(vw); mark_packed(kbias); mark_packed(vbias);   // consumed: the concatenation is what gets packed
+    raw[key + ".weight"] = std::move(cw);
+    raw[key + ".bias"] = std::move(cb);
+  }
+  return pk_conv_like_linear(key + ".weight", key + ".bias");
+}
+
 int E::precompute_pe() {
   const HostTensor* g = need(PE + "pe_layer.positional_encoding_gaussian_matrix");
   if (!g) return -1;
@@ -2264,6 +2288,28 @@ int E::precompute_pe() {
     dry = was_dry;
     if (rc) return -1;
     tbufs[n + "#pe"] = o;
+  }
+  // bf16 engine: k_proj and v_proj of a token -> image attention as ONE N = 256 GEMM over the image tokens (they are read once);
+  // its position table is pe . Wk^T in the k half and zero in the v half (v takes no position encoding, transformer.py:165-170)
+  if (dtype == 1) {
+    const std::string aps[3] = {MD + "transformer.layers.0.cross_attn_token_to_image.", MD + "transformer.layers.1.cross_attn_token_to_image.",
+                                MD + "transformer.final_attn_token_to_image."};
+    for (const auto& ap : aps) {
+      PackedGemm* gcat = pk_kv_cat(ap);
+      if (!gcat) return -1;
+      const int nkv = gcat->N, nk = nkv / 2;
+      PackedGemm* gm = pk_rows(ap + "kv_proj#cat.weight", "", 0, nkv, ap + "kv_proj#pe_w", nk);   // v rows zeroed, no bias
+      if (!gm) return -1;
+      void* o = nullptr;
+      HIP_CHECK_RET(hipMalloc(&o, (size_t)EMB * EMB * gm->N * esz));
+      owned.push_back(o);
+      const bool was_dry = dry;
+      dry = false;
+      const int rc = gemm(gm, pe_dev, DM, (int64_t)EMB * EMB, 1, 1, o, gm->N, ACT_NONE);
+      dry = was_dry;
+      if (rc) return -1;
+      tbufs[ap + "kv_proj#pe"] = o;
+    }
   }
   HIP_CHECK_RET(hipStreamSynchronize(st));
   return 0;
@@ -2368,13 +2414,20 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
   void* tv = allocb((size_t)TR * DM * esz);
   void* ta = allocb((size_t)TR * DM * esz);
   void* th = allocb((size_t)TR * 2048 * esz);
-  void* ik = allocb((size_t)Bp * P * 128 * esz);
-  void* iv = allocb((size_t)Bp * P * 128 * esz);
-  if (!ok(qin) || !ok(tq) || !ok(tk) || !ok(tv) || !ok(ta) || !ok(th) || !ok(ik) || !ok(iv)) return -1;
+  void* ikv = allocb((size_t)Bp * P * 256 * esz);   // [k | v] rows of the merged projection, or ik then iv
+  if (!ok(qin) || !ok(tq) || !ok(tk) || !ok(tv) || !ok(ta) || !ok(th) || !ok(ikv)) return -1;
+  void* ik = ikv;
+  void* iv = (char*)ikv + (size_t)Bp * P * 128 * esz;
+  static const bool no_t2i_mfma = esam3_dev_flag("ESAM3_NO_T2I_MFMA") != 0;  // A/B: separate k / v GEMMs + the VALU attention
+  const bool t2i_mfma = !no_t2i_mfma && esam3_t2i_mfma_ok(dtype, T, (int)P, 8, 16);
   float* t2i_scratch = nullptr;  // per-chunk softmax partials of the token -> image attention
-  if (const int64_t nf = esam3_attn_scratch_floats(Bp, T, (int)P, 8, 16)) {
-    t2i_scratch = (float*)allocb((size_t)nf * sizeof(float));
-    if (!ok(t2i_scratch)) return -1;
+  {
+    int64_t nf = esam3_attn_scratch_floats(Bp, T, (int)P, 8, 16);
+    if (t2i_mfma) nf = std::max(nf, esam3_t2i_mfma_scratch_floats(Bp, T, (int)P));
+    if (nf) {
+      t2i_scratch = (float*)allocb((size_t)nf * sizeof(float));
+      if (!ok(t2i_scratch)) return -1;
+    }
   }
 
   auto add = [&](const void* a, const void* b, void* o, int64_t n) -> int {
@@ -2402,10 +2455,19 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
   auto t2i = [&](const std::string& ap, const std::string& norm) -> int {
     CK(q_plus_pe());
     CK(linear(ap + "q_proj", qin, DM, TR, tq, 128, ACT_NONE));
+    if (t2i_mfma) {
+      // one N = 256 GEMM writes [k | v] rows; the attention runs on the matrix cores out of the two halves
+      PackedGemm* gkv = pk_kv_cat(ap);
+      if (!gkv) return -1;
+      CK(gemm(gkv, keys, DM, Bp * P, 1, 1, ikv, 256, ACT_NONE, tbufs[ap + "kv_proj#pe"], 256, 1, (int)P));
+      if (!dry) CK(prof_launch("attn_t2i", 4.0 * Bp * T * (double)P * 128, 2.0 * (double)Bp * P * 128 * (double)esz, [&]() {
+        return esam3_launch_t2i_mfma(tq, 128, ikv, 256, (const char*)ikv + 128 * esz, 256, ta, Bp, T, (int)P, t2i_scratch, st); }));
+    } else {
     CK(linear(ap + "k_proj", keys, DM, Bp * P, ik, 128, ACT_NONE, tbufs[ap + "k_proj#pe"], 128, (int)P));
     CK(linear(ap + "v_proj", keys, DM, Bp * P, iv, 128, ACT_NONE));
     if (!dry) CK(prof_launch("attn_t2i", 4.0 * Bp * T * (double)P * 128, 2.0 * (double)Bp * P * 128 * (double)esz, [&]() {
       return esam3_launch_attn(dtype, tq, 128, ik, 128, iv, 128, ta, 128, Bp, T, (int)P, 8, 16, t2i_scratch, st); }));
+    }
     CK(tok_proj(ap + "out_proj", ta, 128, true));
     return tok_ln(norm);
   };
@@ -2430,12 +2492,27 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
     // (4) image attends to the tokens (transformer.py:177-182)
     const std::string ip = lp + "cross_attn_image_to_token.";
     CK(q_plus_pe());
-    CK(linear(ip + "q_proj", keys, DM, Bp * P, ik, 128, ACT_NONE, tbufs[ip + "q_proj#pe"], 128, (int)P));
     CK(linear(ip + "k_proj", qin, DM, TR, tk, 128, ACT_NONE));
     CK(linear(ip + "v_proj", queries, DM, TR, tv, 128, ACT_NONE));
-    if (!dry) CK(prof_launch("attn_fewkeys", 0.0, 0.0, [&]() { return esam3_launch_attn_fewkeys(dtype, ik, 128, tk, 128, tv, 128, iv, 128, Bp, (int)P, T, 8, 16, st); }));
-    CK(linear(ip + "out_proj", iv, 128, Bp * P, keys, DM, ACT_NONE, keys, DM));
-    CK(ln(lp + "norm4", keys, Bp * P));
+    static const bool no_i2t_fused = esam3_dev_flag("ESAM3_NO_I2T_FUSED") != 0;  // A/B: q_proj / attn_fewkeys / out_proj / layernorm
+    if (!no_i2t_fused && esam3_i2t_fused_ok(dtype, (int)P, T, 8, 16, DM)) {
+      // q_proj + attention over the T prompt tokens + out_proj + residual + norm4 in one pass over the image tokens
+      PackedGemm *gq = pk_linear(ip + "q_proj"), *go = pk_linear(ip + "out_proj");
+      float *gam = fvec(lp + "norm4.weight"), *bet = fvec(lp + "norm4.bias");
+      if (!gq || !go || !gam || !bet) return -1;
+      if (!dry) {
+        const double rows = (double)Bp * P;
+        CK(prof_launch("i2t_fused", 2.0 * rows * (2.0 * DM * 128 + 2.0 * T * 128), 2.0 * rows * DM * (double)esz, [&]() {
+          return esam3_launch_i2t_fused(keys, keys, gq->w, gq->Kp, gq->bias, tbufs[ip + "q_proj#pe"], go->w, go->Kp, go->bias, gam, bet,
+                                        1e-5f, tk, 128, tv, 128, Bp, (int)P, T, st);
+        }));
+      }
+    } else {
+      CK(linear(ip + "q_proj", keys, DM, Bp * P, ik, 128, ACT_NONE, tbufs[ip + "q_proj#pe"], 128, (int)P));
+      if (!dry) CK(prof_launch("attn_fewkeys", 0.0, 0.0, [&]() { return esam3_launch_attn_fewkeys(dtype, ik, 128, tk, 128, tv, 128, iv, 128, Bp, (int)P, T, 8, 16, st); }));
+      CK(linear(ip + "out_proj", iv, 128, Bp * P, keys, DM, ACT_NONE, keys, DM));
+      CK(ln(lp + "norm4", keys, Bp * P));
+    }
   }
   CK(t2i(tp + "final_attn_token_to_image.", tp + "norm_final_attn"));
   // queries == hs [Bp][T][256]; keys == src [Bp][72*72][256]

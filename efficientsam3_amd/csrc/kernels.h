@@ -10,6 +10,18 @@ const char* esam3_take_last_gemm_kernel();
 void esam3_note_gemm_kernel(const char* name);
 // allow `bytes` of dynamic LDS for `kernel` on the current device (once per device and kernel)
 int esam3_allow_dyn_lds(const void* kernel, int bytes);
+// decoder_fused.hip: "image attends to the tokens" of the two-way transformer in one kernel (q_proj + attention over T <= 16
+// prompt tokens + out_proj + residual + LayerNorm), bf16, 8 heads x 16
+// token -> image attention (<= 16 queries, 8 heads x 16) on the matrix cores; k / v may be the two halves of one [rows][256] tensor
+bool esam3_t2i_mfma_ok(int dtype, int Nq, int Nk, int heads, int hd);
+int64_t esam3_t2i_mfma_scratch_floats(int Bp, int Nq, int Nk);
+int esam3_launch_t2i_mfma(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int Bp, int Nq, int Nk,
+                          float* scratch, hipStream_t s);
+int esam3_launch_attn_t2i_merge(int dtype, const float* parts, void* o, int B, int Nq, int nparts, hipStream_t s);
+bool esam3_i2t_fused_ok(int dtype, int P, int T, int heads, int hd, int C);
+int esam3_launch_i2t_fused(const void* x, void* out, const void* wq, int kpq, const float* bq, const void* peq, const void* wo, int kpo,
+                           const float* bo, const float* gamma, const float* beta, float eps, const void* tk, int ldk, const void* tv,
+                           int ldv, int Bp, int P, int T, hipStream_t s);
 int esam3_launch_gemm(int dtype, const GemmParams& p, hipStream_t stream);
 // K ordering of packed dense-conv weights: korder (see GemmParams) and the packed k index of (tap, c)
 int esam3_conv_korder(int cin, int ksize, int elem_size);

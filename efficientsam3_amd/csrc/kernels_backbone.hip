@@ -2158,6 +2158,228 @@ __global__ __launch_bounds__(256) void resize_shuffle_kernel(const T* __restrict
   }
 }
 
+// The same kernel without the per-workgroup LDS tables (used for the 1x1 level and as the general fallback; the ConvT levels
+// take the row-persistent form below): bilinear_srcf is monotone, so the first output index whose source index reaches the
+// cell is at most two steps above the estimate (cell + 0.5) / scale - 1.5.  ATen's operation order, as the table form.
+template <typename T>
+__global__ __launch_bounds__(256) void resize_shuffle_direct_kernel(const T* __restrict__ in, const float* __restrict__ bias,
+                                                                    T* __restrict__ out, int IH, int IW, int OH, int OW, int C,
+                                                                    int taps, int act, int P, int cg_shift, int tap_shift, int abl) {
+  const int CG = 1 << cg_shift;
+  const unsigned r = blockIdx.x * 256u + (unsigned)threadIdx.x;
+  const int cg = (int)(r & (unsigned)(CG - 1));
+  const int tap = (int)((r >> cg_shift) & (unsigned)(taps - 1));
+  const int cx = (int)(r >> (cg_shift + tap_shift));
+  if (cx >= IW) return;
+  const int b = blockIdx.y / IH, cy = blockIdx.y - b * IH;
+  const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+  int oy0 = (int)(((float)cy + 0.5f) * ((float)OH / (float)IH) - 1.5f);
+  int ox0 = (int)(((float)cx + 0.5f) * ((float)OW / (float)IW) - 1.5f);
+  oy0 = oy0 < 0 ? 0 : oy0;
+  ox0 = ox0 < 0 ? 0 : ox0;
+  while (oy0 < OH && (int)bilinear_srcf(oy0, sy) < cy) ++oy0;
+  while (ox0 < OW && (int)bilinear_srcf(ox0, sx) < cx) ++ox0;
+  if (oy0 >= OH || ox0 >= OW || (int)bilinear_srcf(oy0, sy) != cy || (int)bilinear_srcf(ox0, sx) != cx) return;  // owns no output
+  // the columns of this cell: at most MAXO per axis (down-scaling cells own 0 or 1, up-scaling by r owns <= ceil(r) + 1)
+  constexpr int MAXO = 4;
+  float lxs[MAXO];
+  int nx = 0;
+#pragma unroll
+  for (int i = 0; i < MAXO; ++i) {
+    const float f = bilinear_srcf(ox0 + i, sx);
+    const bool in_cell = ox0 + i < OW && (int)f == cx && nx == i;
+    lxs[i] = f - (float)cx;
+    nx += in_cell ? 1 : 0;
+  }
+  const int s = taps == 4 ? 2 : 1;
+  const int FW = s * OW, FH = s * OH;
+  const int y1 = cy + (cy < IH - 1 ? 1 : 0), x1 = cx + (cx < IW - 1 ? 1 : 0);
+  const int CI = taps * C;
+  const T* base = in + (int64_t)b * IH * IW * CI + tap * C + cg * VEC;
+  float a[VEC], bb[VEC], c[VEC], d[VEC];
+#ifdef ESAM3_DEV
+  if (abl & 1) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { a[e] = (float)(cx + e); bb[e] = (float)(cy - e); c[e] = (float)(tap * e); d[e] = (float)(cg + e); }
+  } else
+#endif
+  {
+    Vec8<T>::load(base + ((int64_t)cy * IW + cx) * CI, a);
+    Vec8<T>::load(base + ((int64_t)cy * IW + x1) * CI, bb);
+    Vec8<T>::load(base + ((int64_t)y1 * IW + cx) * CI, c);
+    Vec8<T>::load(base + ((int64_t)y1 * IW + x1) * CI, d);
+  }
+  float bv[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) bv[e] = bias ? bias[cg * VEC + e] : 0.f;
+  const int dy = tap >> 1, dx = tap & 1;
+  for (int oy = oy0; oy < OH; ++oy) {
+    const float fy = bilinear_srcf(oy, sy);
+    if ((int)fy != cy) break;
+    const float ly = fy - (float)cy, hy = 1.f - ly;
+    const int Y = s == 2 ? 2 * oy + dy : oy;
+    T* orow = out + (((int64_t)b * (FH + 2 * P) + Y + P) * (int64_t)(FW + 2 * P) + P) * C + cg * VEC;
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) {
+      if (i < nx) {
+        const float lx = lxs[i], hx = 1.f - lx;
+        const int X = s == 2 ? 2 * (ox0 + i) + dx : ox0 + i;
+        float o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = (hy * (hx * a[e] + lx * bb[e]) + ly * (hx * c[e] + lx * d[e])) + bv[e];  // ATen's order
+        act_apply_n<VEC>(o, act);
+#ifdef ESAM3_DEV
+        if ((abl & 2) && o[0] != 12345.678f) continue;             // ablation: no stores (the arithmetic stays live)
+        if ((abl & 4) && (i != 0 || oy != oy0)) continue;          // ablation: one store per thread
+#endif
+        Vec8<T>::store(orow + (int64_t)X * C, o);
+      }
+    }
+  }
+}
+
+// Row-persistent, wave-uniform form for the ConvT levels (taps = 4, C = 256 or 512).  Measured with loads and stores ablated
+// (profiles/r04/resize_shuffle_abl.txt) the per-thread forms spend 0.146 ms of the level-0 launch on VALU issue alone -- every
+// lane recomputes the cell's output range, fractions and 64-bit addresses -- and a plain fill writes the same bytes in 0.105 ms.
+// Here one WAVE owns (image, source row cy, 512 consecutive channels of the tap-major input row, a run of source columns) and
+// walks the columns: the cell's output rows / columns, fractions and row base addresses are wave-uniform (scalar registers,
+// scalar branches), the right-hand corners of one cell are the left-hand corners of the next (half the loads) and the column
+// after that is requested one cell ahead, so a wave never waits for a load it has just issued.  The per-axis maps (first
+// output index and count of every source cell, fraction of every output index) are built by the launcher with ATen's float
+// arithmetic and travel in the kernel arguments; lane i keeps column i's entries, the walk reads them with v_readlane.
+// With C = 512 the wave is one tap; with C = 256 it is the tap pair (dy, 0 / 1): the column parity is the lane's upper bit.
+struct RsAxisTables {
+  static constexpr int MAX_IN = 64, MAX_OUT = 192;
+  int first[2][MAX_IN];    // [0] rows, [1] columns: first output index whose interpolation footprint starts in the cell
+  int count[2][MAX_IN];    // how many consecutive output indices do
+  float frac[2][MAX_OUT];  // fraction of every output index
+};
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+template <typename T, int L2CG, int ACT>
+__global__ __launch_bounds__(256) void resize_shuffle_row_kernel(const T* __restrict__ in, const float* __restrict__ bias,
+                                                                 T* __restrict__ out, int nrows, int IH, int IW, int OH, int OW, int P,
+                                                                 int split, const RsAxisTables tab, int abl) {
+  constexpr int CG = 1 << L2CG, C = CG * VEC, UPC = 4 * CG / 64;  // wave units per cell
+  constexpr int MAXO = 4;
+#ifdef ESAM3_DEV
+  int lin = 0;   // ablation 8: the wave's stores go to one private contiguous region instead of the pixel-shuffled rows
+#endif
+  const int lane = threadIdx.x & 63;
+  const int unit = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
+  const int tg = unit % UPC, r_ = unit / UPC;
+  const int seg = r_ % split, row = r_ / split;
+  if (row >= nrows) return;
+  const int b = row / IH, cy = row - b * IH;
+  const int per = (IW + split - 1) / split, cxs = seg * per, cxe = cxs + per < IW ? cxs + per : IW;
+  const int oy0 = tab.first[0][cy], ny = tab.count[0][cy];
+  if (ny == 0 || cxs >= cxe) return;
+  float lys[MAXO];
+#pragma unroll
+  for (int j = 0; j < MAXO; ++j) lys[j] = tab.frac[0][oy0 + j < OH ? oy0 + j : OH - 1];
+  // lane i: the column tables of source column i
+  const int lc = lane < IW ? lane : IW - 1;
+  const int xf_l = tab.first[1][lc], xn_l = tab.count[1][lc];
+  float xfr_l[MAXO];
+#pragma unroll
+  for (int k = 0; k < MAXO; ++k) xfr_l[k] = tab.frac[1][xf_l + k < OW ? xf_l + k : OW - 1];
+  const int FW = 2 * OW, FH = 2 * OH;
+  const int y1 = cy + (cy < IH - 1 ? 1 : 0);
+  constexpr int CI = 4 * C;
+  const int dy = CG == 64 ? tg >> 1 : tg;
+  const int dx_lane = CG == 64 ? 0 : lane >> L2CG, dx_wave = CG == 64 ? tg & 1 : 0;
+  const int cg = lane & (CG - 1);
+  const T* rowT = in + ((int64_t)(b * IH + cy) * IW) * CI + tg * 512 + lane * VEC;
+  const T* rowB = in + ((int64_t)(b * IH + y1) * IW) * CI + tg * 512 + lane * VEC;
+  f32x2_v bv[VEC / 2];
+#pragma unroll
+  for (int e = 0; e < VEC / 2; ++e)
+    bv[e] = bias ? f32x2_v{bias[cg * VEC + 2 * e], bias[cg * VEC + 2 * e + 1]} : f32x2_v{0.f, 0.f};
+  const int ooff = dx_lane * C + cg * VEC;   // the lane's element offset inside an output row segment
+  T* const obase = out + (((int64_t)b * (FH + 2 * P) + dy + P) * (int64_t)(FW + 2 * P) + P + dx_wave) * C + ooff;
+  const int64_t orow_pitch = (int64_t)(FW + 2 * P) * C;
+  float La[VEC], Lc[VEC], Ra[VEC], Rc[VEC];
+  Vec8<T>::load(rowT + (int64_t)cxs * CI, La);
+  Vec8<T>::load(rowB + (int64_t)cxs * CI, Lc);
+  {
+    const int x1 = cxs + 1 < IW ? cxs + 1 : IW - 1;
+    Vec8<T>::load(rowT + (int64_t)x1 * CI, Ra);
+    Vec8<T>::load(rowB + (int64_t)x1 * CI, Rc);
+  }
+  for (int cx = cxs; cx < cxe; ++cx) {
+    float Na[VEC], Nc[VEC];
+    {
+      const int x2 = cx + 2 < IW ? cx + 2 : IW - 1;   // requested now, consumed as the next cell's right-hand corners
+      Vec8<T>::load(rowT + (int64_t)x2 * CI, Na);
+      Vec8<T>::load(rowB + (int64_t)x2 * CI, Nc);
+    }
+    const int ox0 = __builtin_amdgcn_readlane(xf_l, cx), nx = __builtin_amdgcn_readlane(xn_l, cx);
+    float lxs[MAXO];
+#pragma unroll
+    for (int k = 0; k < MAXO; ++k) lxs[k] = readlane_f(xfr_l[k], cx);
+    if (nx != 0) {
+      for (int j = 0; j < ny; ++j) {
+        const float ly = j == 0 ? lys[0] : j == 1 ? lys[1] : j == 2 ? lys[2] : lys[3], hy = 1.f - ly;
+        f32x2_v t[VEC / 2], u[VEC / 2];
+#pragma unroll
+        for (int e = 0; e < VEC / 2; ++e) {
+          t[e] = __builtin_elementwise_fma((f32x2_v)(hy), f32x2_v{La[2 * e], La[2 * e + 1]}, (f32x2_v)(ly) * f32x2_v{Lc[2 * e], Lc[2 * e + 1]});
+          u[e] = __builtin_elementwise_fma((f32x2_v)(hy), f32x2_v{Ra[2 * e], Ra[2 * e + 1]}, (f32x2_v)(ly) * f32x2_v{Rc[2 * e], Rc[2 * e + 1]});
+        }
+        T* orow = obase + (int64_t)(2 * (oy0 + j)) * orow_pitch + (int64_t)(2 * ox0) * C;
+#pragma unroll
+        for (int i = 0; i < MAXO; ++i) {
+          if (i < nx) {
+            const float lx = lxs[i], hx = 1.f - lx;
+            float o[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC / 2; ++e) {
+              const f32x2_v v = __builtin_elementwise_fma((f32x2_v)(hx), t[e], __builtin_elementwise_fma((f32x2_v)(lx), u[e], bv[e]));
+              o[2 * e] = v.x;
+              o[2 * e + 1] = v.y;
+            }
+            act_apply_n<VEC>(o, ACT);
+#ifdef ESAM3_DEV
+            if ((abl & 2) && o[0] + o[1] + o[2] + o[3] + o[4] + o[5] + o[6] + o[7] != 12345.678f) continue;  // ablation: no stores
+            if (abl & 8) {   // ablation: the same bytes, each wave into its own contiguous run (wrapped into the tensor)
+              const int64_t npx = (int64_t)(nrows / IH) * (FH + 2 * P) * (FW + 2 * P) * C / 512;
+              Vec8<T>::store(out + (((int64_t)unit * 216 + (lin++)) % npx) * 512 + lane * VEC, o);
+              continue;
+            }
+#endif
+            Vec8<T>::store(orow + 2 * i * C, o);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { La[e] = Ra[e]; Lc[e] = Rc[e]; Ra[e] = Na[e]; Rc[e] = Nc[e]; }
+  }
+}
+// host side of the tables: area_pixel_compute_source_index's float arithmetic (ATen UpSample.h, align_corners = False)
+static bool rs_build_tables(RsAxisTables& t, int IH, int IW, int OH, int OW) {
+  if (IH > RsAxisTables::MAX_IN || IW > RsAxisTables::MAX_IN || OH > RsAxisTables::MAX_OUT || OW > RsAxisTables::MAX_OUT) return false;
+  const int in[2] = {IH, IW}, on[2] = {OH, OW};
+  for (int ax = 0; ax < 2; ++ax) {
+    for (int c = 0; c < RsAxisTables::MAX_IN; ++c) t.first[ax][c] = t.count[ax][c] = 0;
+    for (int o = 0; o < RsAxisTables::MAX_OUT; ++o) t.frac[ax][o] = 0.f;
+    const float scale = (float)in[ax] / (float)on[ax];
+    int prev = -1;
+    for (int o = 0; o < on[ax]; ++o) {
+      volatile float f = ((float)o + 0.5f) * scale;   // two roundings, as the CPU ATen kernel does
+      f = f - 0.5f;
+      if (f < 0.f) f = 0.f;
+      int s0 = (int)f;
+      if (s0 > in[ax] - 1) s0 = in[ax] - 1;
+      t.frac[ax][o] = f - (float)s0;
+      if (s0 != prev) { t.first[ax][s0] = o; prev = s0; }
+      if (++t.count[ax][s0] > 4) return false;   // the kernel unrolls four columns per cell
+    }
+  }
+  return true;
+}
+
 // ------------------------------------------------------------------------------------
 // LayerNorm over the last dim (nn.LayerNorm, transformer.py:136-146; LayerNorm2d in NHWC,
 // sam/common.py:27-39), optional residual add before and activation after.
@@ -2812,7 +3034,35 @@ int esam3_launch_resize_shuffle(int dtype, const void* in, const float* bias, vo
   // one thread per source cell, tap and 8-channel group; grid.y = image x source row
   const dim3 grid((unsigned)(((int64_t)IW * taps * CG + 255) / 256), (unsigned)(B * IH));
   static const bool rows_first = esam3_dev_flag("ESAM3_RS_ROWS_FIRST") != 0;  // A/B: 2 FMAs per output element
-  if (rows_first)
+  static const bool lds_tables = esam3_dev_flag("ESAM3_RS_LDS_TABLES") != 0;  // A/B: the table form
+  // up-scaling by r: a cell owns at most ceil(r) + 1 outputs per axis; the direct form unrolls 4 columns
+  const bool direct_ok = (int64_t)OW <= 3 * (int64_t)IW;
+  static const bool no_wave = esam3_dev_flag("ESAM3_RS_NO_WAVE") != 0;        // A/B: the per-thread direct form
+  RsAxisTables tab;
+  // bf16 engine only: the row form blends rows first (fp32 rounding differs from ATen's order, far below a bf16 output step);
+  // the fp32 engine keeps ATen's operation order to the letter
+  if (dtype == 1 && direct_ok && !lds_tables && !rows_first && !no_wave && taps == 4 && (C == 512 || C == 256) &&
+      (act == ACT_NONE || act == ACT_GELU) && rs_build_tables(tab, IH, IW, OH, OW)) {
+    // one wave per (image, source row, 512-channel unit, column run): about 4 waves per SIMD over the whole chip
+    const int upc = 4 * C / 512;
+    int split = 1;
+    while ((int64_t)B * IH * upc * split < 4096 && split * 2 <= IW) split *= 2;
+    static const int split_env = esam3_dev_flag("ESAM3_RS_SPLIT");
+    if (split_env > 0) split = split_env;
+    const int64_t units = (int64_t)B * IH * upc * split;
+    const dim3 wgrid((unsigned)((units + 3) / 4));
+#define ESAM3_RS_ROW(L2, A)                                                                                                              \
+  DISPATCH_T(dtype, hipLaunchKernelGGL((resize_shuffle_row_kernel<T, L2, A>), wgrid, dim3(256), 0, s, (const T*)in, bias, (T*)out, B * IH, \
+                                       IH, IW, OH, OW, out_pad ? 1 : 0, split, tab, esam3_dev_flag("ESAM3_RS_ABL")))
+    if (C == 512 && act == ACT_GELU) ESAM3_RS_ROW(6, ACT_GELU);
+    else if (C == 512) ESAM3_RS_ROW(6, ACT_NONE);
+    else if (act == ACT_GELU) ESAM3_RS_ROW(5, ACT_GELU);
+    else ESAM3_RS_ROW(5, ACT_NONE);
+#undef ESAM3_RS_ROW
+  } else if (direct_ok && !lds_tables && !rows_first)
+    DISPATCH_T(dtype, hipLaunchKernelGGL((resize_shuffle_direct_kernel<T>), grid, dim3(256), 0, s, (const T*)in, bias, (T*)out, IH,
+                                         IW, OH, OW, C, taps, act, out_pad ? 1 : 0, cg_shift, tap_shift, esam3_dev_flag("ESAM3_RS_ABL")));
+  else if (rows_first)
     DISPATCH_T(dtype, hipLaunchKernelGGL((resize_shuffle_kernel<T, true>), grid, dim3(256), lds, s, (const T*)in, bias, (T*)out, IH,
                                          IW, OH, OW, C, taps, act, out_pad ? 1 : 0, cg_shift, tap_shift));
   else

@@ -966,6 +966,14 @@ int64_t esam3_attn_scratch_floats(int B, int Nq, int Nk, int heads, int hd) {
   return (int64_t)B * t2i_chunks(B, Nk) * 2 * T2I_MAXQ * T2I_HEADS * T2I_PART;
 }
 
+// merge of per-chunk (max, sum, acc[16]) partials [B][nparts][16 tokens][8 heads][18] -> o [B][Nq][128]
+int esam3_launch_attn_t2i_merge(int dtype, const float* parts, void* o, int B, int Nq, int nparts, hipStream_t s) {
+  const int total = B * Nq * T2I_HEADS;
+  DISPATCH_T(dtype, hipLaunchKernelGGL((attn_t2i_merge_kernel<T>), dim3(blocks_for(total, 128)), dim3(128), 0, s, parts, (T*)o, B, Nq, nparts));
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
 int esam3_launch_attn(int dtype, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                       void* o, int ldo, int B, int Nq, int Nk, int heads, int hd, float* scratch, hipStream_t s) {
   if (scratch && esam3_attn_scratch_floats(B, Nq, Nk, heads, hd) > 0 && ldq == T2I_D && ldk == T2I_D && ldv == T2I_D &&

@@ -109,7 +109,10 @@ int esam3_op_resize_shuffle(int dtype, const void* in, const float* bias, void* 
   Tmp t;
   const float* db = bias ? static_cast<const float*>(t.up(bias, (size_t)C * 4)) : nullptr;
   if (bias && !db) return fail("op_resize_shuffle");
-  if (esam3_launch_resize_shuffle(dtype, in, db, out, B, IH, IW, OH, OW, C, taps, act, out_pad, (hipStream_t)stream)) return -1;
+  if (op_timed("resize_shuffle", (hipStream_t)stream, [&]() {
+        return esam3_launch_resize_shuffle(dtype, in, db, out, B, IH, IW, OH, OW, C, taps, act, out_pad, (hipStream_t)stream);
+      }))
+    return -1;
   HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
@@ -383,6 +386,35 @@ int esam3_op_lite_mla_block(const void* x, const float* wqkv, const float* wdw, 
   return 0;
 }
 
+int esam3_op_i2t_block(const void* x, const float* wq, const float* bq, const float* peq, const float* wo, const float* bo,
+                       const float* gamma, const float* beta, const float* tk, const float* tv, void* out, int Bp, int P, int T,
+                       void* stream) {
+  Tmp t;
+  if (!esam3_i2t_fused_ok(1, P, T, 8, 16, 256)) { esam3_set_error("op_i2t_block: P = %d, T = %d unsupported", P, T); return -1; }
+  const int Kpq = esam3_gemm_pad_k(256, 2), Kpo = esam3_gemm_pad_k(128, 2);
+  std::vector<float> pq((size_t)128 * Kpq, 0.f), po((size_t)256 * Kpo, 0.f);
+  for (int n = 0; n < 128; ++n)
+    for (int k = 0; k < 256; ++k) pq[(size_t)n * Kpq + k] = wq[(size_t)n * 256 + k];
+  for (int n = 0; n < 256; ++n)
+    for (int k = 0; k < 128; ++k) po[(size_t)n * Kpo + k] = wo[(size_t)n * 128 + k];
+  void* dq = t.upT(1, pq);
+  void* d_o = t.upT(1, po);
+  void* dpe = t.upT(1, std::vector<float>(peq, peq + (size_t)P * 128));
+  void* dk = t.upT(1, std::vector<float>(tk, tk + (size_t)Bp * T * 128));
+  void* dv = t.upT(1, std::vector<float>(tv, tv + (size_t)Bp * T * 128));
+  float* dbq = (float*)t.up(bq, 128 * 4);
+  float* dbo = (float*)t.up(bo, 256 * 4);
+  float* dg = (float*)t.up(gamma, 256 * 4);
+  float* db = (float*)t.up(beta, 256 * 4);
+  if (!dq || !d_o || !dpe || !dk || !dv || !dbq || !dbo || !dg || !db) return fail("op_i2t_block");
+  if (op_timed("i2t_block", (hipStream_t)stream, [&]() {
+        return esam3_launch_i2t_fused(x, out, dq, Kpq, dbq, dpe, d_o, Kpo, dbo, dg, db, 1e-5f, dk, 128, dv, 128, Bp, P, T, (hipStream_t)stream);
+      }))
+    return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
 int esam3_op_dwconv(int dtype, const void* x, const float* w, const float* bias, void* out, int B, int H, int W,
                     int C, int ks, int stride, int act, void* stream) {
   Tmp t;
@@ -456,7 +488,16 @@ int esam3_op_attention(int dtype, const void* q, const void* k, const void* v, v
   const int D = heads * hd;
   int rc;
   Tmp t;
-  if (few_keys) {
+  if (few_keys == 2 || few_keys == 3) {   // token -> image attention on the matrix cores; 3: k_dev holds [k | v] rows of 2 D
+    if (!esam3_t2i_mfma_ok(dtype, Nq, Nk, heads, hd)) { esam3_set_error("op_attention: the MFMA token -> image path does not take this shape"); return -1; }
+    float* scratch = (float*)t.raw((size_t)esam3_t2i_mfma_scratch_floats(B, Nq, Nk) * sizeof(float));
+    if (!scratch) return fail("op_attention");
+    const int ld = few_keys == 3 ? 2 * D : D;
+    const void* vp = few_keys == 3 ? (const void*)((const char*)k + (size_t)D * 2) : v;
+    rc = op_timed("attn_t2i_mfma", (hipStream_t)stream, [&]() {
+      return esam3_launch_t2i_mfma(q, D, k, ld, vp, ld, out, B, Nq, Nk, scratch, (hipStream_t)stream);
+    });
+  } else if (few_keys) {
     rc = esam3_launch_attn_fewkeys(dtype, q, D, k, D, v, D, out, D, B, Nq, Nk, heads, hd, (hipStream_t)stream);
   } else {
     float* scratch = nullptr;  // the engine hands the tiled token -> image kernel its workspace; do the same here
@@ -464,7 +505,9 @@ int esam3_op_attention(int dtype, const void* q, const void* k, const void* v, v
       scratch = (float*)t.raw((size_t)nf * sizeof(float));
       if (!scratch) return fail("op_attention");
     }
-    rc = esam3_launch_attn(dtype, q, D, k, D, v, D, out, D, B, Nq, Nk, heads, hd, scratch, (hipStream_t)stream);
+    rc = op_timed("attn", (hipStream_t)stream, [&]() {
+      return esam3_launch_attn(dtype, q, D, k, D, v, D, out, D, B, Nq, Nk, heads, hd, scratch, (hipStream_t)stream);
+    });
   }
   if (rc) return -1;
   HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));

@@ -417,6 +417,14 @@ int esam3_op_mbconv3(const void* x_dev, const float* w1_host, const float* b1_ho
 int esam3_op_lite_mla_block(const void* x_dev, const float* wqkv_host, const float* wdw_host, const float* wgrp_host,
                             const float* wproj_host, const float* bproj_host, void* out_dev, int B, int H, int W, int C,
                             void* hip_stream);
+/* "image attends to the tokens" block of the two-way transformer on the bf16 engine (csrc/decoder_fused.hip), one kernel:
+ * q = (x + pe) Wq^T + bq, 8 heads x 16 attention over the T <= 16 prompt tokens (k / v already projected), out_proj, + x, LayerNorm.
+ * x_dev / out_dev bf16 [Bp][P][256] (P % 16 == 0); wq [128][256], bq [128], peq [P][128] (= pe Wq^T), wo [256][128], bo [256],
+ * gamma / beta [256], tk / tv [Bp][T][128]: host fp32.  Reference: sam3/sam/transformer.py:177-182 (cross_attn_image_to_token + norm4),
+ * :185-253 (Attention) */
+int esam3_op_i2t_block(const void* x_dev, const float* wq_host, const float* bq_host, const float* peq_host, const float* wo_host,
+                       const float* bo_host, const float* gamma_host, const float* beta_host, const float* tk_host,
+                       const float* tv_host, void* out_dev, int Bp, int P, int T, void* hip_stream);
 /* depthwise k x k (3|5), stride 1|2; w_host PyTorch [C][1][k][k] */
 int esam3_op_dwconv(int dtype, const void* x_dev, const float* w_host, const float* bias_host,
                     void* out_dev, int B, int H, int W, int C, int ksize, int stride, int act,
@@ -434,6 +442,9 @@ int esam3_op_resize_bilinear(int dtype, const void* x_dev, void* out_dev, int B,
 int esam3_op_layernorm(int dtype, const void* x_dev, const void* res_dev, const float* gamma_host,
                        const float* beta_host, void* out_dev, int64_t rows, int C, float eps,
                        int act, void* hip_stream);
+/* few_keys: 0 generic / LDS-tiled token -> image kernel, 1 image -> token kernel (<= 64 keys), 2 token -> image attention on the
+ * matrix cores (bf16, 8 heads x 16, Nq <= 16; csrc/decoder_fused.hip), 3 the same with k_dev holding [k | v] rows of 2 x heads x
+ * head_dim (the merged projection the engine writes; v_dev ignored) */
 int esam3_op_attention(int dtype, const void* q_dev, const void* k_dev, const void* v_dev,
                        void* out_dev, int B, int Nq, int Nk, int heads, int head_dim,
                        int few_keys, void* hip_stream);

@@ -750,3 +750,78 @@ def test_lite_mla_block(B, H, W, C):
     assert torch.isfinite(got).all()
     assert _rel_l2(got, ref) < 8e-3, _rel_l2(got, ref)
     U.assert_close(got, ref, "bf16", f"lite_mla_block C={C} {H}x{W}", scale=1.0)
+
+
+def _i2t_block_ref(x, wq, bq, peq, wo, bo, gamma, beta, tk, tv):
+    """sam/transformer.py:177-182 (cross_attn_image_to_token + norm4) in fp64 with the kernel's rounding points: bf16 inputs and
+    weights, q and the attention output rounded to bf16, the probabilities rounded to bf16 for the P.V product."""
+    r = lambda t: t.to(torch.bfloat16).double()
+    Bp, P, _ = x.shape
+    T = tk.shape[1]
+    xq = r(x)
+    q = r((xq @ r(wq).T + bq.double() + r(peq)[None]).float())
+    qh = q.reshape(Bp, P, 8, 16).permute(0, 2, 1, 3)
+    kh = r(tk).reshape(Bp, T, 8, 16).permute(0, 2, 1, 3)
+    vh = r(tv).reshape(Bp, T, 8, 16).permute(0, 2, 1, 3)
+    s = (qh @ kh.transpose(-1, -2)) * 0.25
+    e = r(torch.exp(s - s.max(dim=-1, keepdim=True).values).float())
+    o = (e @ vh) / e.sum(dim=-1, keepdim=True)
+    o = r(o.permute(0, 2, 1, 3).reshape(Bp, P, 128).float())
+    y = o @ r(wo).T + bo.double() + xq
+    return F.layer_norm(y, (256,), gamma.double(), beta.double(), 1e-5).float()
+
+
+@pytest.mark.parametrize("Bp,P,T", [
+    (1, 16, 7),        # one group of 16 rows
+    (2, 5184, 10),     # the real 72 x 72 map, point + box prompt
+    (3, 144, 16),      # the most tokens the kernel takes
+    (5, 80, 1),        # a single key: softmax = 1
+    (37, 48, 9),       # more prompts than a wave's run of groups: the token operands are reloaded inside a run
+])
+def test_i2t_block(Bp, P, T):
+    """Fused image-to-token block of the two-way transformer (csrc/decoder_fused.hip) against the reference formula in fp64."""
+    tdt = torch.bfloat16
+    x = _rand(Bp, P, 256, seed=1)
+    wq, bq = _rand(128, 256, seed=2) / 16.0, _rand(128, seed=3) * 0.1
+    peq = _rand(P, 128, seed=4) * 0.5
+    wo, bo = _rand(256, 128, seed=5) / 128 ** 0.5, _rand(256, seed=6) * 0.1
+    gamma, beta = torch.rand(256, generator=torch.Generator().manual_seed(7)) + 0.5, _rand(256, seed=8) * 0.1
+    tk, tv = _rand(Bp, T, 128, seed=9), _rand(Bp, T, 128, seed=10)
+    ref = _i2t_block_ref(x, wq, bq, peq, wo, bo, gamma, beta, tk, tv)
+    x_d = x.to("cuda", tdt).contiguous()
+    out = torch.full((Bp, P, 256), float("nan"), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_i2t_block(U.P(x_d), U.H(U.np32(wq)), U.H(U.np32(bq)), U.H(U.np32(peq)), U.H(U.np32(wo)), U.H(U.np32(bo)),
+                                       U.H(U.np32(gamma)), U.H(U.np32(beta)), U.H(U.np32(tk)), U.H(U.np32(tv)), U.P(out), Bp, P, T, None),
+            "op_i2t_block")
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    assert _rel_l2(got, ref) < 6e-3, _rel_l2(got, ref)
+    U.assert_close(got, ref, "bf16", f"i2t_block Bp={Bp} P={P} T={T}", scale=1.0)
+    # in place, as the engine runs it
+    U.check(U.lib().esam3_op_i2t_block(U.P(x_d), U.H(U.np32(wq)), U.H(U.np32(bq)), U.H(U.np32(peq)), U.H(U.np32(wo)), U.H(U.np32(bo)),
+                                       U.H(U.np32(gamma)), U.H(U.np32(beta)), U.H(U.np32(tk)), U.H(U.np32(tv)), U.P(x_d), Bp, P, T, None),
+            "op_i2t_block in place")
+    assert torch.equal(x_d.float().cpu(), got)
+
+
+@pytest.mark.parametrize("B,Nq,Nk,merged", [(32, 10, 5184, 1), (1, 16, 2001, 0), (3, 1, 1100, 1), (2, 7, 64, 0), (1, 9, 65, 1), (2, 10, 3, 0)])
+def test_attention_t2i_mfma(B, Nq, Nk, merged):
+    """token -> image attention on the matrix cores (csrc/decoder_fused.hip: t2i_mfma_kernel + the fixed-order merge), with k / v as
+    separate tensors and as the two halves of the merged [k | v] projection rows"""
+    tdt = torch.bfloat16
+    heads, hd, D = 8, 16, 128
+    q, k, v = _rand(B, Nq, D, seed=1), _rand(B, Nk, D, seed=2), _rand(B, Nk, D, seed=3)
+
+    def split(t):
+        return _q(t, "bf16").reshape(t.shape[0], t.shape[1], heads, hd).transpose(1, 2)
+
+    ref = F.scaled_dot_product_attention(split(q), split(k), split(v)).transpose(1, 2).reshape(B, Nq, D)
+    o_d = torch.full((B, Nq, D), float("nan"), dtype=tdt, device="cuda")
+    q_d = q.to("cuda", tdt)
+    if merged:
+        kv_d = torch.cat([k, v], dim=-1).to("cuda", tdt).contiguous()
+        U.check(U.lib().esam3_op_attention(1, U.P(q_d), U.P(kv_d), None, U.P(o_d), B, Nq, Nk, heads, hd, 3, None), "op_attention 3")
+    else:
+        k_d, v_d = k.to("cuda", tdt), v.to("cuda", tdt)
+        U.check(U.lib().esam3_op_attention(1, U.P(q_d), U.P(k_d), U.P(v_d), U.P(o_d), B, Nq, Nk, heads, hd, 2, None), "op_attention 2")
+    U.assert_close(o_d.float().cpu(), ref, "bf16", "attention t2i mfma")

@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from efficientsam3_amd import schema, synth
+from tests.util import pcs_bf16_yard
 
 SAMPLE = 8192
 BF16_FACTOR = 1.5  # engine-bf16 error allowed as a multiple of the reference's own bf16 error (tests/util.py)
@@ -86,8 +87,7 @@ def test_pcs_engine_vs_golden(pcs_gold, pcs_sd, mode):
     proc = Sam3Processor(model, confidence_threshold=man["confidence_threshold"])
     img = synth.smooth_image_u8(seed=1)
     state = proc.set_image(torch.from_numpy(np.ascontiguousarray(np.moveaxis(img, -1, 0))))
-    with open(os.path.join(os.path.dirname(__file__), "golden", "pcs_ev_m", "bf16ref_manifest.json")) as f:
-        yard = json.load(f)["cases"]  # the reference's own bf16-autocast-vs-fp32 distance per output (gen_golden_pcs_bf16ref.py)
+    yard = pcs_bf16_yard("pcs_ev_m")  # the reference's own bf16-autocast-vs-fp32 distance per output, worst over 1 + 6 seeded images
     for pi in range(len(man["prompts"])):
         y = yard[man["prompts"][pi]]
         lim = dict(logits=1e-4, boxes=1e-4, presence=1e-4, masks=2e-3) if mode == "f32" else \
@@ -177,8 +177,7 @@ def test_pcs_engine_geometric_prompts_vs_golden(pcs_gold, pcs_sd, mode):
     img = synth.smooth_image_u8(seed=1)
     state = proc.set_image(torch.from_numpy(np.ascontiguousarray(np.moveaxis(img, -1, 0))))
     # bf16: the geometric cases have no reference-bf16 run of their own: 2 x the model's yardstick on the text cases (same image)
-    with open(os.path.join(os.path.dirname(__file__), "golden", "pcs_ev_m", "bf16ref_manifest.json")) as f:
-        yard = json.load(f)["cases"]
+    yard = pcs_bf16_yard("pcs_ev_m")
     ymax = {k: max(c[k] for c in yard.values()) for k in ("pred_logits", "pred_boxes", "presence_logit_dec", "pred_masks")}
     lim = dict(f32=dict(logits=1e-4, boxes=1e-4, presence=1e-4, masks=2e-3),
                bf16=dict(logits=PCS_OTHER_INPUTS_FACTOR * ymax["pred_logits"], boxes=PCS_OTHER_INPUTS_FACTOR * ymax["pred_boxes"],

@@ -234,3 +234,27 @@ def tie_reference_bits(name, ref_bits, flipped, ties):
         bits = np.unpackbits(arr[f"{name}/alt_mask_bits/{i}/{k}"])[: tgt.size].reshape(tgt.shape).astype(bool)
         tgt[...] = bits
     return out
+
+
+PCS_KEYS = ("pred_logits", "pred_boxes", "presence_logit_dec", "pred_masks")
+
+
+def pcs_bf16_yard(model_dir: str) -> dict:
+    """the reference's own bf16-autocast-vs-fp32 distance on the text-grounding path, per prompt and output of forward_grounding:
+    the worst over the fixture image (bf16ref_manifest.json) and the further seeded images of bf16ref_draws.json when the model
+    has them (oracle/gen_golden_pcs_bf16ref.py --draws N) -- one draw is a noisy estimate of that distance."""
+    import json
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", model_dir)
+    with open(os.path.join(gdir, "bf16ref_manifest.json")) as f:
+        cases = json.load(f)["cases"]
+    yard = {name: {k: float(c[k]) for k in PCS_KEYS} for name, c in cases.items()}
+    dpath = os.path.join(gdir, "bf16ref_draws.json")
+    if os.path.exists(dpath):
+        with open(dpath) as f:
+            draws = json.load(f)["cases"]
+        for name, ds in draws.items():
+            for d in ds:
+                for k in PCS_KEYS:
+                    yard[name][k] = max(yard[name][k], float(d[k]))
+    return yard
