@@ -307,6 +307,403 @@ __global__ __launch_bounds__(512) void t2i_mfma_kernel(const T2iParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// TOKEN side of the two-way transformer and the output heads (sam/transformer.py:143-182, mask_decoder.py:224-242) in five
+// launches instead of fifty-seven.  The token stream of a prompt is T <= 16 rows x 256 channels: every Linear on it is
+// launch-bound as a GEMM of its own (7-9 us per launch, 0.5 ms per step at 32 prompts).  Here one workgroup owns one prompt
+// and keeps its fp32 stream, the positional tokens and every intermediate in LDS; a Linear is the transposed product
+// Y^T[N x 16] = W[N x K] X^T[K x 16] on v_mfma_f32_16x16x32_bf16 with the packed weight rows read straight from L2 as the A
+// operand (16 bytes per lane) and X^T out of LDS as the B operand; a wave takes 16-channel output blocks round-robin and its
+// C layout (4 consecutive channels of one token per lane) goes back to LDS as one 8-byte store per block.  The stages are
+// cut where the image side has to run:
+//   tok_a   self-attention block + norm1, then q of the token -> image attention            (per layer)
+//   tok_b   token -> image out_proj + norm2, MLP + norm3, k / v of the image -> token attention (+ q of the final attention)
+//   tok_d   final out_proj + norm, hypernetwork MLPs, IoU head, object-score head
+// Rounding points are those of the layer-by-layer path: Linear outputs that were bf16 tensors there are rounded to bf16 here,
+// the stream and its LayerNorms stay fp32, `queries` (the bf16 copy that feeds the GEMMs) is bf16(stream).
+constexpr int TOK_XP = 528;           // bytes per row of a [16][256] bf16 operand in LDS (256 * 2 + 16)
+constexpr int TOK_HP = 2048 * 2 + 16; // MLP hidden
+constexpr int TOK_AP = 128 * 2 + 16;  // [16][128] operand (attention output of the image-side kernels)
+
+struct TokLin { const bf16_t* w; const float* b; int ldw; };
+
+__device__ __forceinline__ bf16x8_v ld_a16(const bf16_t* p) { return __builtin_bit_cast(bf16x8_v, *reinterpret_cast<const uint4*>(p)); }
+__device__ __forceinline__ bf16x8_v ld_b16(const char* p) { return __builtin_bit_cast(bf16x8_v, *reinterpret_cast<const uint4*>(p)); }
+
+// One 16-channel output block of a Linear: where its weight rows, its bias and its X operand are, how many of its channels exist
+struct TokBlk {
+  const bf16_t* w;     // packed weight row of channel 0 of the block
+  const float* bias;   // bias of channel 0 of the block, or null
+  const char* sx;      // X operand (row-major bf16 in LDS)
+  int ldw, nvalid;     // weight row pitch (elements); channels of the block that exist (bias reads are guarded by it)
+};
+// Y^T block by block over a LIST of blocks (several Linears that share K can run as one list): blk(i) describes block i,
+// epi(i, acc) receives its channels 4 g + j (j = 0..3) of token m = lane & 15, bias included.  A wave takes blocks wave, wave + 8,
+// ...; the weight rows are the A operand straight from L2, 16 bytes per lane and k-step, fetched ONE CHUNK (8 k-steps) AHEAD of
+// the products that consume them -- the first version waited for every chunk it had just requested and ran at the latency of
+// one L2 round trip per 16 x 256 block (0.093 ms for the MLP stage at 32 prompts instead of the 0.015 ms its 2.2 MB of weights
+// take through one CU's 64-byte / clock L1).
+template <int K, typename Blk, typename Epi>
+__device__ __forceinline__ void tok_linear_list(int nblocks, Blk blk, int xp, int wave, int lane, Epi epi) {
+  constexpr int KB = K / 32, CH = KB < 8 ? KB : 8, NCH = KB / CH;
+  static_assert(KB % CH == 0, "K must be a multiple of 256 or at most 256");
+  const int m = lane & 15, g = lane >> 4;
+  const int nmine = nblocks > wave ? (nblocks - wave + 7) / 8 : 0;
+  const int total = nmine * NCH;
+  if (total == 0) return;
+  bf16x8_v bufA[CH], bufB[CH];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](bf16x8_v (&buf)[CH], int it) {
+    const TokBlk d = blk(wave + 8 * (it / NCH));
+    const bf16_t* wr = d.w + (int64_t)m * d.ldw + 8 * g + 32 * CH * (it % NCH);
+#pragma unroll
+    for (int j = 0; j < CH; ++j) buf[j] = ld_a16(wr + 32 * j);
+  };
+  auto compute = [&](const bf16x8_v (&buf)[CH], int it) {
+    const int bi = wave + 8 * (it / NCH), c = it % NCH;
+    const TokBlk d = blk(bi);
+    if (c == 0) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* xr = d.sx + m * xp + (32 * CH * c + 8 * g) * 2;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(buf[j], ld_b16(xr + 64 * j), acc, 0, 0, 0);
+    if (c == NCH - 1) {
+      f32x4 r = acc;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r[i] += (d.bias && 4 * g + i < d.nvalid) ? d.bias[4 * g + i] : 0.f;
+      epi(bi, r);
+    }
+  };
+  fetch(bufA, 0);
+#pragma unroll 1
+  for (int it = 0; it < total; it += 2) {
+    if (it + 1 < total) fetch(bufB, it + 1);
+    compute(bufA, it);
+    if (it + 2 < total) fetch(bufA, it + 2);
+    if (it + 1 < total) compute(bufB, it + 1);
+  }
+}
+// a single Linear as a list: block nb = channels [16 nb, 16 nb + 16)
+template <int K, typename Epi>
+__device__ __forceinline__ void tok_linear(const TokLin L, int N, const char* sX, int xp, int wave, int lane, Epi epi) {
+  tok_linear_list<K>((N + 15) / 16, [&](int nb) {
+    return TokBlk{L.w + (int64_t)16 * nb * L.ldw, L.b ? L.b + 16 * nb : nullptr, sX, L.ldw, N - 16 * nb};
+  }, xp, wave, lane, epi);
+}
+// store a C-layout block as bf16 into a row-major LDS operand
+__device__ __forceinline__ void st_block_bf16(char* sY, int yp, int nb, int lane, const f32x4& v, bool relu = false) {
+  const int m = lane & 15, g = lane >> 4;
+  f32x4 r = v;
+  if (relu) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = fmaxf(r[i], 0.f);
+  }
+  *reinterpret_cast<s16x4*>(sY + m * yp + (16 * nb + 4 * g) * 2) = pack4(r[0], r[1], r[2], r[3]);
+}
+// LayerNorm of the 16 x 256 fp32 stream in LDS, in place (rows >= T hold zeros and stay finite); 512 threads, 2 rows per wave
+__device__ __forceinline__ void tok_layernorm(float* sS, const float* gamma, const float* beta, float eps, int wave, int lane) {
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    float* row = sS + (2 * wave + rr) * 256;
+    const float4 v = *reinterpret_cast<const float4*>(row + 4 * lane);
+    float s = v.x + v.y + v.z + v.w;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off);
+    const float mean = s * (1.f / 256.f);
+    const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+    float q = d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) q += __shfl_xor(q, off);
+    const float rstd = rsqrtf(q * (1.f / 256.f) + eps);
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + 4 * lane), bt = *reinterpret_cast<const float4*>(beta + 4 * lane);
+    *reinterpret_cast<float4*>(row + 4 * lane) = make_float4(d0 * rstd * gm.x + bt.x, d1 * rstd * gm.y + bt.y, d2 * rstd * gm.z + bt.z,
+                                                             d3 * rstd * gm.w + bt.w);
+  }
+}
+// bf16 operand rows from the stream: X = bf16(S (+ T)), rows >= T zero; thread = (row, 8 channels)
+__device__ __forceinline__ void tok_make_x(char* sX, const float* sS, const float* sT, int T, int tid) {
+  const int r = tid >> 5, c = (tid & 31) * 8;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = r < T ? sS[r * 256 + c + e] + (sT ? sT[r * 256 + c + e] : 0.f) : 0.f;
+  *reinterpret_cast<uint4*>(sX + r * TOK_XP + c * 2) =
+      make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+}
+__device__ __forceinline__ void tok_load_stream(float* sS, const float* g, int T, int tid) {   // [T][256] fp32 -> LDS, rows >= T zero
+  for (int i = tid; i < 16 * 64; i += 512) {
+    const int r = i >> 6;
+    *reinterpret_cast<float4*>(sS + 4 * i) = r < T ? *reinterpret_cast<const float4*>(g + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+__device__ __forceinline__ void tok_store_stream(float* g, const float* sS, int T, int tid) {
+  for (int i = tid; i < T * 64; i += 512) *reinterpret_cast<float4*>(g + 4 * i) = *reinterpret_cast<const float4*>(sS + 4 * i);
+}
+// [T][128] bf16 rows (global, contiguous) -> a row-major LDS operand, rows >= T zero
+__device__ __forceinline__ void tok_load_a128(char* sA, const bf16_t* g, int T, int tid) {
+  if (tid < 256) {
+    const int r = tid >> 4, sl = tid & 15;
+    *reinterpret_cast<uint4*>(sA + r * TOK_AP + sl * 16) =
+        r < T ? *reinterpret_cast<const uint4*>(g + r * 128 + sl * 8) : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+// store a C-layout block of an N = 128 projection to global [T][128] bf16
+__device__ __forceinline__ void st_block_g128(bf16_t* gy, int T, int nb, int lane, const f32x4& v) {
+  const int m = lane & 15, g = lane >> 4;
+  if (m < T) *reinterpret_cast<s16x4*>(gy + m * 128 + 16 * nb + 4 * g) = pack4(v[0], v[1], v[2], v[3]);
+}
+
+struct TokAParams {
+  float* q32;          // [Bp][T][256] fp32 stream, in / out
+  const float* t32;    // [Bp][T][256] positional tokens
+  bf16_t* tq;          // out: q of the token -> image attention [Bp][T][128]
+  TokLin sq, sk, sv, so, xq;
+  const float *g1, *b1;
+  int T, first;        // first layer: q / k take no positional tokens and the attention output REPLACES the stream
+  float eps;
+};
+
+__global__ __launch_bounds__(512) void tok_a_kernel(const TokAParams p) {
+  __shared__ __attribute__((aligned(16))) float sS[16 * 256], sT[16 * 256];
+  __shared__ __attribute__((aligned(16))) char sXa[16 * TOK_XP], sXb[16 * TOK_XP], sQ[16 * TOK_XP], sK[16 * TOK_XP], sV[16 * TOK_XP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t b = blockIdx.x;
+  const int T = p.T;
+  tok_load_stream(sS, p.q32 + b * T * 256, T, tid);
+  tok_load_stream(sT, p.t32 + b * T * 256, T, tid);
+  __syncthreads();
+  tok_make_x(sXa, sS, p.first ? nullptr : sT, T, tid);
+  tok_make_x(sXb, sS, nullptr, T, tid);
+  __syncthreads();
+  tok_linear_list<256>(48, [&](int i) {   // q | k | v: 3 x 16 blocks in one list
+    const int which = i >> 4, nb = i & 15;
+    const TokLin& L = which == 0 ? p.sq : (which == 1 ? p.sk : p.sv);
+    return TokBlk{L.w + (int64_t)16 * nb * L.ldw, L.b ? L.b + 16 * nb : nullptr, which == 2 ? sXb : sXa, L.ldw, 16};
+  }, TOK_XP, wave, lane, [&](int i, const f32x4& a) {
+    const int which = i >> 4;
+    st_block_bf16(which == 0 ? sQ : (which == 1 ? sK : sV), TOK_XP, i & 15, lane, a);
+  });
+  __syncthreads();
+  // self-attention, 8 heads x 32: thread = (token t, head h, dim quarter dq); fp32 from the bf16 rows, as attn_kernel
+  {
+    const int t = tid >> 5, h = (tid >> 2) & 7, dq = tid & 3;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (t < T) {
+      const float scale = rsqrtf(32.f);
+      float sc[16], mx = -3.0e38f;
+      const bf16_t* qr = reinterpret_cast<const bf16_t*>(sQ + t * TOK_XP) + 32 * h;
+      for (int j = 0; j < T; ++j) {
+        const bf16_t* kr = reinterpret_cast<const bf16_t*>(sK + j * TOK_XP) + 32 * h;
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) a = fmaf(bf16_to_f32(qr[d]) * scale, bf16_to_f32(kr[d]), a);
+        sc[j] = a;
+        mx = fmaxf(mx, a);
+      }
+      float l = 0.f;
+      for (int j = 0; j < T; ++j) {
+        const float e = __expf(sc[j] - mx);
+        l += e;
+        const bf16_t* vr = reinterpret_cast<const bf16_t*>(sV + j * TOK_XP) + 32 * h + 8 * dq;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) o[d] = fmaf(e, bf16_to_f32(vr[d]), o[d]);
+      }
+      const float inv = 1.f / l;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) o[d] *= inv;
+    }
+    // sXa's readers (the q / k projections) finished before the barrier above: the attention output reuses it
+    *reinterpret_cast<uint4*>(sXa + t * TOK_XP + (32 * h + 8 * dq) * 2) =
+        make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+  }
+  __syncthreads();
+  tok_linear<256>(p.so, 256, sXa, TOK_XP, wave, lane, [&](int nb, const f32x4& a) {
+    const int m = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* s = sS + m * 256 + 16 * nb + 4 * g + i;
+      *s = m < T ? (p.first ? 0.f : *s) + a[i] : 0.f;
+    }
+  });
+  __syncthreads();
+  tok_layernorm(sS, p.g1, p.b1, p.eps, wave, lane);
+  __syncthreads();
+  tok_make_x(sXa, sS, sT, T, tid);
+  tok_store_stream(p.q32 + b * T * 256, sS, T, tid);
+  __syncthreads();
+  tok_linear<256>(p.xq, 128, sXa, TOK_XP, wave, lane, [&](int nb, const f32x4& a) { st_block_g128(p.tq + b * T * 128, T, nb, lane, a); });
+}
+
+constexpr int TOK_B_SPLIT = 8;   // workgroups per prompt in tok_b: 256 hidden channels of the MLP each
+
+struct TokBParams {
+  float* q32;
+  const float* t32;
+  const bf16_t* ta;    // [Bp][T][128] output of the token -> image attention
+  bf16_t *tk, *tv;     // out: k / v of the image -> token attention [Bp][T][128]
+  bf16_t* tq;          // out (last layer): q of the final token -> image attention, or null
+  TokLin xo, l1, l2, ik, iv, fq;
+  const float *g2, *b2, *g3, *b3;
+  float* part;         // scratch [Bp][TOK_B_SPLIT][16][256] fp32: the slices' shares of mlp.lin2's output
+  float* mid;          // scratch [Bp][16][256] fp32: the stream after norm2 (written by slice 0 of tok_b1, read by tok_b2)
+  int T;
+  float eps;
+};
+
+// tok_b1, grid (prompt, slice).  The MLP's 2 MB of weights through ONE compute unit's L1 (64 bytes / clock) is 15 us at best and
+// was 80 us in practice, so a prompt is spread over TOK_B_SPLIT workgroups: each recomputes the cheap prefix (out_proj + norm2,
+// 64 KB of weights), takes 256 of the 2048 hidden channels through lin1 AND through the matching K slice of lin2, and leaves its
+// share of lin2's output in `part`.  tok_b2, grid (prompt): adds the shares in slice order (bit-reproducible: no floating-point
+// atomics), applies norm3 and projects k / v for the image -> token attention.  (A single launch in which the last slice to
+// arrive finishes the prompt was slower than the one-workgroup form: the device-scope release fence in front of the arrival
+// counter writes back the XCD's whole L2 -- 256 times per launch.)
+__global__ __launch_bounds__(512) void tok_b1_kernel(const TokBParams p) {
+  __shared__ __attribute__((aligned(16))) float sS[16 * 256];
+  __shared__ __attribute__((aligned(16))) char sXb[16 * TOK_XP], sH[16 * TOK_XP], sA[16 * TOK_AP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  const int64_t b = blockIdx.x;
+  const int sl = blockIdx.y;
+  const int T = p.T;
+  tok_load_stream(sS, p.q32 + b * T * 256, T, tid);
+  tok_load_a128(sA, p.ta + b * T * 128, T, tid);
+  __syncthreads();
+  tok_linear<128>(p.xo, 256, sA, TOK_AP, wave, lane, [&](int nb, const f32x4& a) {
+    if (m < T) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sS[m * 256 + 16 * nb + 4 * g + i] += a[i];
+    }
+  });
+  __syncthreads();
+  tok_layernorm(sS, p.g2, p.b2, p.eps, wave, lane);
+  __syncthreads();
+  tok_make_x(sXb, sS, nullptr, T, tid);
+  if (sl == 0) tok_store_stream(p.mid + b * 16 * 256, sS, T, tid);
+  __syncthreads();
+  // hidden channels [256 sl, 256 sl + 256) = relu(lin1), then their share of lin2 (the K slice at column 256 sl of its weight)
+  tok_linear_list<256>(16, [&](int i) {
+    const int nb = 16 * sl + i;
+    return TokBlk{p.l1.w + (int64_t)16 * nb * p.l1.ldw, p.l1.b + 16 * nb, sXb, p.l1.ldw, 16};
+  }, TOK_XP, wave, lane, [&](int i, const f32x4& a) { st_block_bf16(sH, TOK_XP, i & 15, lane, a, true); });
+  __syncthreads();
+  float* mine = p.part + ((b * TOK_B_SPLIT + sl) * 16) * 256;
+  tok_linear_list<256>(16, [&](int nb) {
+    return TokBlk{p.l2.w + (int64_t)16 * nb * p.l2.ldw + 256 * sl, nullptr, sH, p.l2.ldw, 16};
+  }, TOK_XP, wave, lane, [&](int nb, const f32x4& a) {
+    *reinterpret_cast<float4*>(mine + m * 256 + 16 * nb + 4 * g) = make_float4(a[0], a[1], a[2], a[3]);
+  });
+}
+
+__global__ __launch_bounds__(512) void tok_b2_kernel(const TokBParams p) {
+  __shared__ __attribute__((aligned(16))) float sS[16 * 256], sT[16 * 256];
+  __shared__ __attribute__((aligned(16))) char sXa[16 * TOK_XP], sXb[16 * TOK_XP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t b = blockIdx.x;
+  const int T = p.T;
+  tok_load_stream(sT, p.t32 + b * T * 256, T, tid);
+  for (int i = tid; i < 16 * 64; i += 512) {   // stream = norm2 output + lin2 bias + the shares in slice order; rows >= T zero
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < T * 64) {
+      const float4 base = *reinterpret_cast<const float4*>(p.mid + b * 16 * 256 + 4 * i);
+      const float4 bb = *reinterpret_cast<const float4*>(p.l2.b + 4 * (i & 63));
+      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < TOK_B_SPLIT; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(p.part + ((b * TOK_B_SPLIT + k) * 16) * 256 + 4 * i);
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+      }
+      out = make_float4(base.x + bb.x + sum.x, base.y + bb.y + sum.y, base.z + bb.z + sum.z, base.w + bb.w + sum.w);
+    }
+    *reinterpret_cast<float4*>(sS + 4 * i) = out;
+  }
+  __syncthreads();
+  tok_layernorm(sS, p.g3, p.b3, p.eps, wave, lane);
+  __syncthreads();
+  tok_make_x(sXa, sS, sT, T, tid);
+  tok_make_x(sXb, sS, nullptr, T, tid);
+  tok_store_stream(p.q32 + b * T * 256, sS, T, tid);
+  __syncthreads();
+  tok_linear_list<256>(p.tq ? 24 : 16, [&](int i) {   // k | v (| q of the final attention): 8 blocks each
+    const int which = i >> 3, nb = i & 7;
+    const TokLin& L = which == 0 ? p.ik : (which == 1 ? p.iv : p.fq);
+    return TokBlk{L.w + (int64_t)16 * nb * L.ldw, L.b ? L.b + 16 * nb : nullptr, which == 1 ? sXb : sXa, L.ldw, 16};
+  }, TOK_XP, wave, lane, [&](int i, const f32x4& a) {
+    const int which = i >> 3;
+    st_block_g128((which == 0 ? p.tk : (which == 1 ? p.tv : p.tq)) + b * T * 128, T, i & 7, lane, a);
+  });
+}
+
+struct TokDParams {
+  const float* q32;    // in: stream before the final attention's residual
+  const bf16_t* ta;
+  bf16_t* hs;          // out: bf16(hs) [Bp][T][256] (the layer-by-layer path's `queries`), or null
+  TokLin xo;
+  const float *gf, *bf;
+  TokLin mlp[6][3];    // 0-3 hypernetwork MLPs (mask tokens 2 + i), 4 IoU head (token 1), 5 object-score head (token 0)
+  bf16_t* hyper;       // [Bp][4][32]
+  float* iou;          // [Bp][8] fp32, sigmoid applied, 4 used
+  bf16_t* obj;         // [Bp][8], 1 used
+  int T;
+  float eps;
+};
+
+// grid (prompt, MLP r): the six heads are independent after the final attention's out_proj + norm, which every workgroup of a
+// prompt recomputes (64 KB of weights) instead of waiting for a sibling -- 192 workgroups of 0.3 MB each instead of 32 of 1.7 MB
+__global__ __launch_bounds__(512) void tok_d_kernel(const TokDParams p) {
+  __shared__ __attribute__((aligned(16))) float sS[16 * 256];
+  __shared__ __attribute__((aligned(16))) char sX[16 * TOK_XP], sY[16 * TOK_XP], sA[16 * TOK_AP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, g = lane >> 4;
+  const int64_t b = blockIdx.x;
+  const int r = blockIdx.y;                                   // 0-3 hypernetwork MLPs, 4 IoU head, 5 object-score head
+  const int tok = r < 4 ? 2 + r : (r == 4 ? 1 : 0);           // the token it reads (mask_decoder.py:224-242)
+  const int T = p.T;
+  tok_load_stream(sS, p.q32 + b * T * 256, T, tid);
+  tok_load_a128(sA, p.ta + b * T * 128, T, tid);
+  __syncthreads();
+  tok_linear<128>(p.xo, 256, sA, TOK_AP, wave, lane, [&](int nb, const f32x4& a) {
+    if (m < T) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sS[m * 256 + 16 * nb + 4 * g + i] += a[i];
+    }
+  });
+  __syncthreads();
+  tok_layernorm(sS, p.gf, p.bf, p.eps, wave, lane);
+  __syncthreads();
+  tok_make_x(sX, sS, nullptr, T, tid);   // = bf16(hs)
+  __syncthreads();
+  if (p.hs && r == 0)
+    for (int i = tid; i < T * 32; i += 512) {
+      const int rr = i >> 5, c = (i & 31) * 8;
+      *reinterpret_cast<uint4*>(p.hs + (b * T + rr) * 256 + c) = *reinterpret_cast<const uint4*>(sX + rr * TOK_XP + c * 2);
+    }
+  // the 3-layer MLP on ONE token: every product runs over all 16 columns of the operand (the matrix cores are idle anyway) and
+  // only the column of the token is kept -- it becomes row 0 of the next layer's operand
+  for (int i = tid; i < 16 * TOK_XP / 16; i += 512) reinterpret_cast<uint4*>(sY)[i] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  tok_linear<256>(p.mlp[r][0], 256, sX, TOK_XP, wave, lane, [&](int nb, const f32x4& a) {
+    if (m == tok) *reinterpret_cast<s16x4*>(sY + (16 * nb + 4 * g) * 2) = pack4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
+  });
+  __syncthreads();
+  tok_linear<256>(p.mlp[r][1], 256, sY, TOK_XP, wave, lane, [&](int nb, const f32x4& a) {
+    if (m == 0) *reinterpret_cast<s16x4*>(sX + (16 * nb + 4 * g) * 2) = pack4(fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(a[2], 0.f), fmaxf(a[3], 0.f));
+  });
+  __syncthreads();
+  // layer 2: 32 hypernetwork outputs of a mask token (bf16), 4 IoU scores (fp32 accumulators + sigmoid, never rounded to bf16:
+  // they pick the single-mask fallback by argmax, mask_decoder.py:236-242), 1 object score
+  tok_linear<256>(p.mlp[r][2], r < 4 ? 32 : (r == 4 ? 4 : 1), sX, TOK_XP, wave, lane, [&](int nb, const f32x4& a) {
+    if (m != 0) return;
+    if (r < 4) {
+      *reinterpret_cast<s16x4*>(p.hyper + (b * 4 + r) * 32 + 16 * nb + 4 * g) = pack4(a[0], a[1], a[2], a[3]);
+    } else if (r == 4) {
+      if (g == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p.iou[b * 8 + j] = 1.f / (1.f + expf(-a[j]));
+      }
+    } else if (g == 0) {
+      p.obj[b * 8] = f32_to_bf16(a[0]);
+    }
+  });
+}
+
 }  // namespace
 
 bool esam3_i2t_fused_ok(int dtype, int P, int T, int heads, int hd, int C) {
@@ -363,4 +760,50 @@ int esam3_launch_t2i_mfma(const void* q, int ldq, const void* k, int ldk, const 
   hipLaunchKernelGGL(t2i_mfma_kernel, dim3((unsigned)p.nchunks, (unsigned)Bp), dim3(512), 0, s, p);
   HIP_CHECK_RET(hipGetLastError());
   return esam3_launch_attn_t2i_merge(1, scratch, o, Bp, Nq, p.nchunks, s);
+}
+
+// ---- token side ------------------------------------------------------------------------------------------------------------
+bool esam3_tok_fused_ok(int dtype, int T) { return dtype == 1 && T >= 6 && T <= 16; }
+
+static TokLin tl(const esam3_tok_lin& l) { return TokLin{(const bf16_t*)l.w, l.bias, l.ldw}; }
+
+int esam3_launch_tok_a(float* q32, const float* t32, void* tq, const esam3_tok_lin lin[5], const float* g1, const float* b1, float eps,
+                       int Bp, int T, int first, hipStream_t s) {
+  if (!esam3_tok_fused_ok(1, T)) { esam3_set_error("tok_a: T = %d unsupported", T); return -1; }
+  TokAParams p;
+  p.q32 = q32; p.t32 = t32; p.tq = (bf16_t*)tq;
+  p.sq = tl(lin[0]); p.sk = tl(lin[1]); p.sv = tl(lin[2]); p.so = tl(lin[3]); p.xq = tl(lin[4]);
+  p.g1 = g1; p.b1 = b1; p.T = T; p.first = first; p.eps = eps;
+  hipLaunchKernelGGL(tok_a_kernel, dim3((unsigned)Bp), dim3(512), 0, s, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int64_t esam3_tok_b_scratch_bytes(int Bp) { return (int64_t)Bp * (TOK_B_SPLIT + 1) * 16 * 256 * 4; }
+int esam3_launch_tok_b(float* q32, const float* t32, const void* ta, void* tk, void* tv, void* tq_final, const esam3_tok_lin lin[6],
+                       const float* g2, const float* b2, const float* g3, const float* b3, float eps, void* scratch, int Bp, int T,
+                       hipStream_t s) {
+  if (!esam3_tok_fused_ok(1, T) || !scratch) { esam3_set_error("tok_b: T = %d unsupported", T); return -1; }
+  TokBParams p;
+  p.q32 = q32; p.t32 = t32; p.ta = (const bf16_t*)ta; p.tk = (bf16_t*)tk; p.tv = (bf16_t*)tv; p.tq = (bf16_t*)tq_final;
+  p.xo = tl(lin[0]); p.l1 = tl(lin[1]); p.l2 = tl(lin[2]); p.ik = tl(lin[3]); p.iv = tl(lin[4]); p.fq = tl(lin[5]);
+  p.g2 = g2; p.b2 = b2; p.g3 = g3; p.b3 = b3; p.T = T; p.eps = eps;
+  p.part = (float*)scratch;
+  p.mid = p.part + (int64_t)Bp * TOK_B_SPLIT * 16 * 256;
+  hipLaunchKernelGGL(tok_b1_kernel, dim3((unsigned)Bp, (unsigned)TOK_B_SPLIT), dim3(512), 0, s, p);
+  HIP_CHECK_RET(hipGetLastError());
+  hipLaunchKernelGGL(tok_b2_kernel, dim3((unsigned)Bp), dim3(512), 0, s, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+int esam3_launch_tok_d(float* q32, const void* ta, void* hs, const esam3_tok_lin& xo, const float* gf, const float* bf, float eps,
+                       const esam3_tok_lin mlp[18], void* hyper, float* iou, void* obj, int Bp, int T, hipStream_t s) {
+  if (!esam3_tok_fused_ok(1, T)) { esam3_set_error("tok_d: T = %d unsupported", T); return -1; }
+  TokDParams p;
+  p.q32 = q32; p.ta = (const bf16_t*)ta; p.hs = (bf16_t*)hs; p.xo = tl(xo); p.gf = gf; p.bf = bf;
+  for (int r = 0; r < 6; ++r)
+    for (int l = 0; l < 3; ++l) p.mlp[r][l] = tl(mlp[r * 3 + l]);
+  p.hyper = (bf16_t*)hyper; p.iou = iou; p.obj = (bf16_t*)obj; p.T = T; p.eps = eps;
+  hipLaunchKernelGGL(tok_d_kernel, dim3((unsigned)Bp, 6u), dim3(512), 0, s, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
 }

@@ -2472,6 +2472,75 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
     return tok_ln(norm);
   };
 
+  // bf16 engine, <= 16 tokens: the token side runs as three per-prompt kernels per stage (decoder_fused.hip) between the fused
+  // image-side kernels -- 5 token-side launches instead of 57
+  static const bool no_tok_fused = esam3_dev_flag("ESAM3_NO_TOK_FUSED") != 0;  // A/B: the layer-by-layer token path
+  const bool tok_fused = tok32 && !no_tok_fused && t2i_mfma && esam3_tok_fused_ok(dtype, T) && esam3_i2t_fused_ok(dtype, (int)P, T, 8, 16, DM) &&
+                         !esam3_dev_flag("ESAM3_NO_I2T_FUSED");
+  void* hyper = allocb((size_t)Bp * 4 * 32 * esz);
+  float* iou4 = (float*)allocb((size_t)Bp * 8 * sizeof(float));  // the four predicted IoUs stay fp32 (see the IoU head below)
+  void* obj = allocb((size_t)Bp * 8 * esz);
+  if (!ok(hyper) || !ok(iou4) || !ok(obj)) return -1;
+  void* tokb_scratch = nullptr;
+  if (tok_fused) {
+    const size_t nb = (size_t)esam3_tok_b_scratch_bytes(Bp);
+    tokb_scratch = allocb(nb);
+    if (!ok(tokb_scratch)) return -1;
+  }
+  if (tok_fused) {
+    auto TL = [&](const std::string& prefix, esam3_tok_lin* o) -> int {
+      PackedGemm* g = pk_linear(prefix);
+      if (!g) return -1;
+      o->w = g->w; o->bias = g->bias; o->ldw = g->Kp;
+      return 0;
+    };
+    auto kv_and_attn = [&](const std::string& ap) -> int {   // [k | v] rows of the image tokens, then tq -> ta
+      PackedGemm* gkv = pk_kv_cat(ap);
+      if (!gkv) return -1;
+      CK(gemm(gkv, keys, DM, Bp * P, 1, 1, ikv, 256, ACT_NONE, tbufs[ap + "kv_proj#pe"], 256, 1, (int)P));
+      if (!dry) CK(prof_launch("attn_t2i", 4.0 * Bp * T * (double)P * 128, 2.0 * (double)Bp * P * 128 * (double)esz, [&]() {
+        return esam3_launch_t2i_mfma(tq, 128, ikv, 256, (const char*)ikv + 128 * esz, 256, ta, Bp, T, (int)P, t2i_scratch, st); }));
+      return 0;
+    };
+    const std::string fa = tp + "final_attn_token_to_image.";
+    for (int li = 0; li < 2; ++li) {
+      const std::string lp = tp + "layers." + std::to_string(li) + ".";
+      const std::string ap = lp + "cross_attn_token_to_image.", ip = lp + "cross_attn_image_to_token.";
+      esam3_tok_lin la[5], lb[6];
+      CK(TL(lp + "self_attn.q_proj", &la[0])); CK(TL(lp + "self_attn.k_proj", &la[1])); CK(TL(lp + "self_attn.v_proj", &la[2]));
+      CK(TL(lp + "self_attn.out_proj", &la[3])); CK(TL(ap + "q_proj", &la[4]));
+      CK(TL(ap + "out_proj", &lb[0])); CK(TL(lp + "mlp.lin1", &lb[1])); CK(TL(lp + "mlp.lin2", &lb[2]));
+      CK(TL(ip + "k_proj", &lb[3])); CK(TL(ip + "v_proj", &lb[4])); CK(TL(fa + "q_proj", &lb[5]));
+      float *g1 = fvec(lp + "norm1.weight"), *b1 = fvec(lp + "norm1.bias"), *g2 = fvec(lp + "norm2.weight"), *b2 = fvec(lp + "norm2.bias"),
+            *g3 = fvec(lp + "norm3.weight"), *b3 = fvec(lp + "norm3.bias"), *g4 = fvec(lp + "norm4.weight"), *b4 = fvec(lp + "norm4.bias");
+      PackedGemm *gq = pk_linear(ip + "q_proj"), *go = pk_linear(ip + "out_proj");
+      if (!g1 || !b1 || !g2 || !b2 || !g3 || !b3 || !g4 || !b4 || !gq || !go) return -1;
+      if (!dry) CK(prof_launch("tok_a", 0.0, 0.0, [&]() { return esam3_launch_tok_a(q32, t32, tq, la, g1, b1, 1e-5f, Bp, T, li == 0, st); }));
+      CK(kv_and_attn(ap));
+      if (!dry) CK(prof_launch("tok_b", 0.0, 0.0, [&]() {
+        return esam3_launch_tok_b(q32, t32, ta, tk, tv, li == 1 ? tq : nullptr, lb, g2, b2, g3, b3, 1e-5f, tokb_scratch, Bp, T, st); }));
+      if (!dry) {
+        const double rows = (double)Bp * P;
+        CK(prof_launch("i2t_fused", 2.0 * rows * (2.0 * DM * 128 + 2.0 * T * 128), 2.0 * rows * DM * (double)esz, [&]() {
+          return esam3_launch_i2t_fused(keys, keys, gq->w, gq->Kp, gq->bias, tbufs[ip + "q_proj#pe"], go->w, go->Kp, go->bias, g4, b4,
+                                        1e-5f, tk, 128, tv, 128, Bp, (int)P, T, st);
+        }));
+      }
+    }
+    CK(kv_and_attn(fa));
+    esam3_tok_lin xo, mlps[18];
+    CK(TL(fa + "out_proj", &xo));
+    for (int r = 0; r < 6; ++r)
+      for (int l = 0; l < 3; ++l) {
+        const std::string hp = r < 4 ? MD + "output_hypernetworks_mlps." + std::to_string(r) + ".layers."
+                                     : (r == 4 ? MD + "iou_prediction_head.layers." : MD + "pred_obj_score_head.layers.");
+        CK(TL(hp + std::to_string(l), &mlps[r * 3 + l]));
+      }
+    float *gf = fvec(tp + "norm_final_attn.weight"), *bfin = fvec(tp + "norm_final_attn.bias");
+    if (!gf || !bfin) return -1;
+    if (!dry) CK(prof_launch("tok_d", 0.0, 0.0, [&]() {
+      return esam3_launch_tok_d(q32, ta, queries, xo, gf, bfin, 1e-5f, mlps, hyper, iou4, obj, Bp, T, st); }));
+  } else {
   for (int li = 0; li < 2; ++li) {
     const std::string lp = tp + "layers." + std::to_string(li) + ".";
     // (1) token self attention (transformer.py:155-163)
@@ -2515,6 +2584,7 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
     }
   }
   CK(t2i(tp + "final_attn_token_to_image.", tp + "norm_final_attn"));
+  }
   // queries == hs [Bp][T][256]; keys == src [Bp][72*72][256]
 
   // ---- upscaling with high-res features (mask_decoder.py:213-222) -------------------------
@@ -2529,15 +2599,13 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
   if (!fused_up) CK(convT(MD + "output_upscaling.3", u1, ACT_GELU, &u2, pr->sam2_fpn_dev[0], 32, 0, pr->prompt_image_dev));
 
   // ---- hypernetwork MLPs, IoU head, object-score head (mask_decoder.py:224-242) ------------
-  void* hyper = allocb((size_t)Bp * 4 * 32 * esz);
   void* h1 = allocb((size_t)Bp * DM * esz);
   void* h2 = allocb((size_t)Bp * DM * esz);
-  float* iou4 = (float*)allocb((size_t)Bp * 8 * sizeof(float));  // the four predicted IoUs stay fp32 (see the IoU head below)
-  void* obj = allocb((size_t)Bp * 8 * esz);
   float* all_masks = (float*)allocb(sizeof(float) * (size_t)Bp * 4 * 16 * P);
   int* counters = (int*)allocb(sizeof(int) * 2 * (size_t)Bp);
-  if (!ok(hyper) || !ok(h1) || !ok(h2) || !ok(iou4) || !ok(obj) || !ok(all_masks) || !ok(counters)) return -1;
+  if (!ok(h1) || !ok(h2) || !ok(all_masks) || !ok(counters)) return -1;
   const size_t tok_stride = (size_t)DM * esz;
+  if (!tok_fused) {
   for (int i = 0; i < 4; ++i) {
     const std::string hp = MD + "output_hypernetworks_mlps." + std::to_string(i) + ".layers.";
     const char* tok = (const char*)queries + (size_t)(2 + i) * tok_stride;  // mask token i of every prompt
@@ -2565,6 +2633,7 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
     CK(linear(hp + "0", queries, T * DM, Bp, h1, DM, ACT_RELU));
     CK(linear(hp + "1", h1, DM, Bp, h2, DM, ACT_RELU));
     CK(linear(hp + "2", h2, DM, Bp, obj, 8, ACT_NONE));
+  }
   }
   const int64_t P4 = 16 * P;  // 288 * 288
   PackedGemm* gu = nullptr;  // packed in the dry pass too: weight uploads must not happen while a graph is being captured

@@ -12,6 +12,22 @@ void esam3_note_gemm_kernel(const char* name);
 int esam3_allow_dyn_lds(const void* kernel, int bytes);
 // decoder_fused.hip: "image attends to the tokens" of the two-way transformer in one kernel (q_proj + attention over T <= 16
 // prompt tokens + out_proj + residual + LayerNorm), bf16, 8 heads x 16
+// token side of the two-way transformer + the output heads as three per-prompt kernels (decoder_fused.hip); a Linear is
+// {packed bf16 weight [N][ldw], fp32 bias or null, ldw}
+struct esam3_tok_lin { const void* w; const float* bias; int ldw; };
+bool esam3_tok_fused_ok(int dtype, int T);
+// lin: self_attn q, k, v, out_proj, cross_attn_token_to_image.q_proj
+int esam3_launch_tok_a(float* q32, const float* t32, void* tq, const esam3_tok_lin lin[5], const float* g1, const float* b1, float eps,
+                       int Bp, int T, int first, hipStream_t s);
+// lin: cross_attn_token_to_image.out_proj, mlp.lin1, mlp.lin2, cross_attn_image_to_token.k_proj, .v_proj, final_attn q_proj (or unused)
+// scratch: esam3_tok_b_scratch_bytes(Bp) (two launches: the MLP spread over 8 workgroups per prompt, then the tail)
+int64_t esam3_tok_b_scratch_bytes(int Bp);
+int esam3_launch_tok_b(float* q32, const float* t32, const void* ta, void* tk, void* tv, void* tq_final, const esam3_tok_lin lin[6],
+                       const float* g2, const float* b2, const float* g3, const float* b3, float eps, void* scratch, int Bp, int T,
+                       hipStream_t s);
+// xo: final_attn out_proj; mlp[r * 3 + layer]: r = 0..3 hypernetwork MLPs, 4 IoU head, 5 object-score head
+int esam3_launch_tok_d(float* q32, const void* ta, void* hs, const esam3_tok_lin& xo, const float* gf, const float* bf, float eps,
+                       const esam3_tok_lin mlp[18], void* hyper, float* iou, void* obj, int Bp, int T, hipStream_t s);
 // token -> image attention (<= 16 queries, 8 heads x 16) on the matrix cores; k / v may be the two halves of one [rows][256] tensor
 bool esam3_t2i_mfma_ok(int dtype, int Nq, int Nk, int heads, int hd);
 int64_t esam3_t2i_mfma_scratch_floats(int Bp, int Nq, int Nk);

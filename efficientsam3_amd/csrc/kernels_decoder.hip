@@ -26,6 +26,30 @@ __global__ void gather_add_kernel(const T* __restrict__ in, const int* __restric
     out[i] = from_f32<T>(v);
   }
 }
+constexpr int VEC = 8;
+// the same on 8-element vectors (C % 8 == 0, 16-byte aligned rows): grid.y = prompt, a thread owns 8 channels of one token
+template <typename T>
+__global__ __launch_bounds__(256) void gather_add_vec_kernel(const T* __restrict__ in, const int* __restrict__ src_img,
+                                                             const float* __restrict__ cbias, const T* __restrict__ dense,
+                                                             T* __restrict__ out, int64_t PC8, int C8) {
+  const int64_t bp = blockIdx.y;
+  const T* src = in + (int64_t)src_img[bp] * PC8 * VEC;
+  const T* dn = dense ? dense + bp * PC8 * VEC : nullptr;
+  T* dst = out + bp * PC8 * VEC;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < PC8; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    float v[VEC], d[VEC];
+    Vec8<T>::load(src + i * VEC, v);
+    const float4 b0 = *reinterpret_cast<const float4*>(cbias + c8 * VEC), b1 = *reinterpret_cast<const float4*>(cbias + c8 * VEC + 4);
+    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    if (dn) {
+      Vec8<T>::load(dn + i * VEC, d);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] += d[e];
+    }
+    Vec8<T>::store(dst + i * VEC, v);
+  }
+}
 
 // ------------------------------------------------------------------------------------
 // Softmax attention with few queries and many keys (token -> image cross attention and
@@ -802,6 +826,14 @@ __global__ void clamp_kernel(float* x, int64_t n, float lo, float hi) {
 int esam3_launch_gather_add(int dtype, const void* in, const int* src_img, const float* cbias,
                             const void* dense, void* out, int Bp, int64_t P, int C, hipStream_t s) {
   const int64_t total = (int64_t)Bp * P * C;
+  if (C % VEC == 0 && Bp <= 65535 && !((uintptr_t)in & 15) && !((uintptr_t)out & 15) && !((uintptr_t)dense & 15) && !((uintptr_t)cbias & 15)) {
+    const int64_t pc8 = P * C / VEC;
+    const dim3 grid((unsigned)min((int64_t)256, (pc8 + 255) / 256), (unsigned)Bp);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(gather_add_vec_kernel<T>, grid, dim3(256), 0, s, (const T*)in, src_img, cbias, (const T*)dense,
+                                         (T*)out, pc8, C / VEC));
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
   const unsigned g = (unsigned)min((int64_t)8192, (total + 255) / 256);
   DISPATCH_T(dtype, hipLaunchKernelGGL(gather_add_kernel<T>, dim3(g), dim3(256), 0, s, (const T*)in,
                                        src_img, cbias, (const T*)dense, (T*)out, Bp, P, C));
