@@ -1,0 +1,61 @@
+"""Stage-1 training step on one MI355X: EfficientViT-B1 student (backbone + head) at 1008^2, synthetic images / teacher embeddings,
+forward + masked MSE / cosine loss + backward + clip + AdamW (efficientsam3_amd.stage1_train.Stage1Trainer; the step the reference runs in
+stage1/train_image_encoder_stage1.py:165-226).  Prints ONE JSON line; the roofline leg prices the whole step's algorithmic FLOPs
+(forward graph of SURVEY.md 8(d): backbone 20.3 + head 19.9 GFLOP / image; a training step is forward + input gradients + weight
+gradients = 3 x) against the dense bf16 MFMA peak.
+
+    python tools/bench_stage1_step.py [--batch 8] [--steps 5] [--warmup 2] [--dtype bf16|f32]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from efficientsam3_amd import schema  # noqa: E402
+from efficientsam3_amd.stage1_train import Stage1Trainer  # noqa: E402
+
+PREFIX = "backbone.vision_backbone.trunk.model."
+FWD_GFLOP_PER_IMAGE = 20.3 + 19.9
+PEAK_BF16_TFLOPS = 2500.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    a = ap.parse_args()
+    sd = schema.synthetic_state_dict("efficientvit", "b1", seed=0)
+    sd = {k[len(PREFIX):]: v.clone() for k, v in sd.items() if k.startswith(PREFIX)}
+    tr = Stage1Trainer(sd, "b1", embed_size=72, dtype=a.dtype, lr=1e-4, weight_decay=0.05, clip_grad=5.0, cosine_weight=0.5)
+    g = torch.Generator().manual_seed(0)
+    imgs = torch.randn((a.batch, 3, 1008, 1008), generator=g).cuda()
+    teacher = (torch.randn((a.batch, 72, 72, 1024), generator=g) * 0.5).to("cuda", torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+    sizes = [(1008, 1008)] * a.batch
+    for _ in range(a.warmup):
+        tr.step(imgs, teacher, sizes)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = tr.step(imgs, teacher, sizes)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    flops = 3.0 * FWD_GFLOP_PER_IMAGE * 1e9 * a.batch
+    print(json.dumps({"metric": "images/sec stage-1 distillation training step @1008^2 (EfficientViT-B1 student)", "value": round(a.batch / dt, 2),
+                      "unit": "images/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt * 1e3, 2), "dtype": a.dtype,
+                      "data": "synthetic", "config": {"workload": "forward + loss + backward + clip + AdamW, device-resident fp32 master weights",
+                                                       "batch": a.batch, "loss": float(out["loss"]), "grad_norm": float(out["grad_norm"])},
+                      "roofline": {"bound": "mfma", "achieved": round(flops / dt / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(flops / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                                   "note": "whole step: 3 x the forward graph's algorithmic FLOPs / wall time of a step"}}))
+
+
+if __name__ == "__main__":
+    main()
