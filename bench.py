@@ -83,6 +83,32 @@ def cpu_baseline(sample_images: int = 5):
                       f"fp32 oracle, set_image + predict_inst(point+box), torch CPU {threads} threads"}
 
 
+def bind_to_gpu_numa_node(local_rank: int):
+    """Pin this rank's host threads to the CPUs next to its GPU (sysfs: /sys/bus/pci/devices/<bdf>/local_cpulist): the per-rank
+    staging copies and worker threads of an N-rank job then stay on the socket the GPU hangs off (host IO, not
+    xGMI, is the scaling risk).  Returns a short description for the JSON line, or None where the topology is not exposed."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as f:
+            spec = f.read().strip()
+        cpus = set()
+        for part in spec.split(","):
+            if "-" in part:
+                a, b = part.split("-")
+                cpus.update(range(int(a), int(b) + 1))
+            elif part:
+                cpus.add(int(part))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return f"{bdf}: {len(cpus)} cpus ({spec})"
+    except Exception:  # noqa: BLE001  (no sysfs entry in a container, attribute missing): run unbound
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +155,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    affinity = bind_to_gpu_numa_node(local_rank) if world > 1 else None
     dry_coll = args.dry_collective and world == 1
     esdist.init_process_group("nccl", dev, force=dry_coll)
 
@@ -238,8 +265,8 @@ def main():
     # ---- PCIe-inclusive leg (reported in config, never `value`): B uint8 1024x1024 HWC images in pinned host
     # memory -> one H2D copy -> device antialiased resize to 1008^2 + normalise (P1) -> the same step
     host_incl = None
-    if rank == 0 and world == 1 and not text:
-        u8 = torch.from_numpy(np.random.default_rng(0).integers(0, 256, (B, 1024, 1024, 3), dtype=np.uint8)).pin_memory()
+    if not text:   # every rank runs it (N ranks pull their shards over their own PCIe links at the same time)
+        u8 = torch.from_numpy(np.random.default_rng(rank).integers(0, 256, (B, 1024, 1024, 3), dtype=np.uint8)).pin_memory()
         u8_d = torch.empty_like(u8, device=dev)
         x_keep = x
 
@@ -256,7 +283,12 @@ def main():
         for _ in range(reps):
             step_from_host()
         sync()
-        host_incl = B * reps / (time.perf_counter() - t1)
+        el1 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([el1], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el1 = float(t.item())
+        host_incl = world * B * reps / el1
         x = x_keep
 
     # ---- API-level leg (reported in config, never `value`): the reference-shaped Python calls a user makes --
@@ -353,6 +385,9 @@ def main():
                                      "window_attn", "vit_", "patchify"))
                    else "decode+post")
             stage_ms[key] = stage_ms.get(key, 0.0) + p_["ms"]
+        if world > 1:   # an N-rank line without a live process group behind it is not a scaling number
+            assert dist.is_initialized() and dist.get_world_size() == world and dist.get_backend() == "nccl", \
+                "multi-GPU run without an RCCL process group of WORLD_SIZE ranks"
         out = {
             "metric": "images/sec encode+decode @1024^2 (EV-M bf16)" if (args.backbone, args.model, text) == ("efficientvit", "b1", False)
             else (f"images/sec text-prompted encode+ground @1024^2 ({args.backbone}-{args.model} + MobileCLIP-S0-16 {args.dtype})" if text
@@ -373,6 +408,7 @@ def main():
                        "collective_error": coll_err[0],
                        "ranks_in_process_group": (dist.get_world_size() if dist.is_initialized() else 1),
                        "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
+                       "cpu_affinity_rank0": affinity,
                        "graph": ("reference layer list" if args.no_fuse else
                                  "linear chains composed at load time (ConvT∘1x1, 3x3∘conv_s0/s1): same outputs, fewer FLOPs"),
                        "gflop_per_image_executed": round(gf_img, 1), "gflop_per_image_reference_graph": None if gf_ref is None else round(gf_ref, 1),
@@ -384,7 +420,8 @@ def main():
                                          "timed region; in the timed steps only the dominant launch carries HIP events",
                        "pcie_inclusive_images_per_s": None if host_incl is None else round(host_incl, 1),
                        "pcie_inclusive_note": "uint8 1024x1024 HWC batch in pinned host memory -> H2D -> device resize to 1008^2 "
-                                              "+ normalise -> the same step; measured after the timed region, not `value`",
+                                              "+ normalise -> the same step, on every rank at once (aggregate over the ranks, "
+                                              "slowest rank's clock); measured after the timed region, not `value`",
                        "api_level_images_per_s": None if api_ips is None else round(api_ips, 1),
                        "api_level_note": "Sam3Processor.set_image_batch(32 PIL 1024x1024 images) + model.predict_inst_batch(point+box) -> "
                                          "numpy float32 masks at 1024x1024, IoU scores, low-res logits (the reference's return contract, D2H "

@@ -479,7 +479,10 @@ __global__ void update_save_inv_scale_kernel(const float* __restrict__ state, in
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int BN_SPLITS = 512;
 
-// partial[split][2][C]: (sum a, sum b) per channel with  FWD: a = x, b = x^2;  BWD: a = dy, b = dy (x - mean) rstd
+// partial[split][2][C]: (sum a, sum b) per channel with  FWD: a = x - p, b = (x - p)^2;  BWD: a = dy, b = dy (x - mean) rstd.
+// p is a per-channel PIVOT, the tensor's first row (stored after the partials, partial[splits][2][C] .. + C): E[x^2] - E[x]^2 on the
+// raw values cancels catastrophically when |mean| >> std (a large conv bias in front of the norm); shifted by a sample of the
+// channel, the two sums are of the order of the spread, not of the offset, and the fp64 finalize loses nothing.
 template <int DT, bool BWD>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const typename Elem<DT>::type* __restrict__ x,
                                                         const typename Elem<DT>::type* __restrict__ dy, int64_t rows, int C,
@@ -490,12 +493,19 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const typename Elem<DT>:
   const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
   const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
-  float a[8], b[8], mu[8], rs[8];
+  float a[8], b[8], mu[8], rs[8], pv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    a[e] = 0.f; b[e] = 0.f;
+    a[e] = 0.f; b[e] = 0.f; pv[e] = 0.f;
     mu[e] = BWD ? mean[cg * 8 + e] : 0.f;
     rs[e] = BWD ? rstd[cg * 8 + e] : 0.f;
+  }
+  if constexpr (!BWD) {
+    if (rl < RL) Elem<DT>::load8(x + cg * 8, pv);   // row 0
+    if (blockIdx.x == 0 && rl == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) partial[(int64_t)gridDim.x * 2 * C + cg * 8 + e] = pv[e];
+    }
   }
   if (rl < RL)
     for (int64_t r = r0 + rl; r < r1; r += RL) {
@@ -512,8 +522,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const typename Elem<DT>:
       } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          a[e] += v[e];
-          b[e] = fmaf(v[e], v[e], b[e]);
+          const float d = v[e] - pv[e];
+          a[e] += d;
+          b[e] = fmaf(d, d, b[e]);
         }
       }
     }
@@ -548,8 +559,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     o0[c] = (float)s1;  // dgamma
     o1[c] = (float)s0;  // dbeta
   } else {
-    const double n = (double)rows, mean = s0 / n;
-    double var = s1 / n - mean * mean;
+    const double n = (double)rows, shift = s0 / n, mean = (double)partial[(int64_t)splits * 2 * C + c] + shift;
+    double var = s1 / n - shift * shift;   // sums of (x - pivot): see bn_reduce_kernel
     var = var > 0.0 ? var : 0.0;
     o0[c] = (float)mean;
     o1[c] = (float)(1.0 / sqrt(var + eps));
@@ -705,7 +716,7 @@ int esam3_stage1_update(float* params, float* grads, float* exp_avg, float* exp_
   return 0;
 }
 
-int64_t esam3_bn_train_workspace(int C) { return (int64_t)sizeof(float) * 2 * BN_SPLITS * (int64_t)(C > 0 ? C : 0); }
+int64_t esam3_bn_train_workspace(int C) { return (int64_t)sizeof(float) * (2 * BN_SPLITS + 1) * (int64_t)(C > 0 ? C : 0); }  // + the pivots
 
 int esam3_bn_train_forward(int dtype, const void* x, void* y, int64_t rows, int C, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, double momentum, double eps, float* save_mean, float* save_rstd,

@@ -27,21 +27,17 @@ def init_process_group(backend: Optional[str] = None, device: Optional[torch.dev
     """Join the job described by the environment (no-op for a single process unless ``force``: a one-rank group, which
     is how the collectives of this module are exercised on RCCL with device tensors on a single-GPU box)."""
     rank, local_rank, world = env_ranks()
-    if force and world == 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if "MASTER_PORT" not in os.environ:
-            import socket
-            with socket.socket() as s_:
-                s_.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this platform
         if backend is None:
             backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
         kw = {"device_id": device} if backend == "nccl" and device is not None else {}
-        dist.init_process_group(backend, **kw)
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            # a forced one-rank group needs no rendezvous over TCP: an in-process store (picking a free port by bind-then-close
+            # would leave a window in which another process can take it)
+            dist.init_process_group(backend, store=dist.HashStore(), rank=0, world_size=1, **kw)
+        else:
+            dist.init_process_group(backend, **kw)
     return rank, local_rank, world
 
 

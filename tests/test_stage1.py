@@ -478,3 +478,27 @@ def test_bn_train_forward_backward_vs_torch(mode, shape):
     assert torch.allclose(dgamma.cpu(), gr.grad, rtol=1e-4, atol=1e-4 * float(gr.grad.abs().max()))
     with pytest.raises(RuntimeError):   # C not a multiple of 8
         stage1.bn_train_forward(torch.zeros((4, 12), device=dev), torch.ones(12, device=dev), torch.zeros(12, device=dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,offset", [((2, 20, 12, 64), 1.0e3), ((4, 63, 63, 128), 3.0e3), ((1, 5, 5, 8), 1.0e4)])
+def test_bn_train_statistics_with_a_large_offset(shape, offset):
+    """|mean| >> std (a large conv bias in front of the norm): E[x^2] - E[x]^2 on raw fp32 sums loses the variance entirely at
+    offset / std = 1e3 (relative precision 2^-24 x 1e6 of the square); the kernels accumulate sums shifted by a per-channel pivot,
+    so mean, rstd and the normalised output still match a float64 reference."""
+    g = torch.Generator().manual_seed(7)
+    c = shape[-1]
+    std = 0.5 + torch.rand(c, generator=g)
+    x = torch.randn(shape, generator=g) * std + offset * (1.0 + torch.rand(c, generator=g))
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    dev = "cuda"
+    y, mean, rstd = stage1.bn_train_forward(x.to(dev).contiguous(), gamma.to(dev), beta.to(dev), None, None, momentum=0.1, eps=1e-5)
+    xd = x.double().reshape(-1, c)
+    m64, v64 = xd.mean(0), xd.var(0, unbiased=False)
+    r64 = 1.0 / torch.sqrt(v64 + 1e-5)
+    assert torch.allclose(mean.cpu().double(), m64, rtol=1e-6, atol=0)
+    assert torch.allclose(rstd.cpu().double(), r64, rtol=1e-3, atol=0), float(((rstd.cpu().double() - r64) / r64).abs().max())
+    y64 = ((xd - m64) * r64 * gamma.double() + beta.double()).reshape(shape)
+    # the input itself is fp32: x - mean carries an absolute error of 2^-24 |x| ~ 6e-5 x (offset / 1e3), times rstd
+    tol = 4.0 * offset * 2.0 ** -24 * float(r64.max()) * float(gamma.max()) + 1e-5
+    assert float((y.cpu().double() - y64).abs().max()) <= tol
