@@ -52,6 +52,20 @@ def _nchw_view(t_nhwc: torch.Tensor) -> torch.Tensor:
     return t_nhwc.permute(0, 3, 1, 2)
 
 
+
+_WIDEN_POOL = None
+
+
+def _widen_pool():
+    """a few long-lived worker threads for host-side copies (numpy releases the GIL inside them)"""
+    global _WIDEN_POOL
+    if _WIDEN_POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _WIDEN_POOL = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1), thread_name_prefix="esam3-widen")
+    return _WIDEN_POOL
+
+
 class _Trunk:
     """``model.backbone.vision_backbone.trunk(x) -> [Tensor[B,1024,72,72]]`` (stage1/model.py:237)."""
 
@@ -381,7 +395,18 @@ class Sam3Image:
             if len(pool) > 3:                            # `out = step()` loops need two, a consumer one step behind three
                 pool.pop(0)
         torch.cuda.current_stream(masks.device).synchronize()
-        ent[0].copy_(pin)                   # uint8 -> float32 (or float32 -> float32) with every host core
+        # uint8 -> float32 (or float32 -> float32) on a few worker threads.  NOT torch's copy_: its OpenMP team (128 threads on the
+        # GPU host) keeps spinning after the copy, and the NEXT wait on the device -- the small synchronous prompt upload of the
+        # following call -- then returned 50-70 ms late in about every third step (tools/api_stall_probe.py,
+        # profiles/r04/api_stall_probe.txt: 17 ms steps with 65-80 ms outliers; the device itself was idle).
+        src, dst = pin.numpy().reshape(-1), ent[1].reshape(-1)
+        n = src.size
+        if n < (1 << 22):
+            np.copyto(dst, src, casting="unsafe")
+        else:
+            parts = 16
+            step = -(-n // parts)
+            list(_widen_pool().map(lambda i: np.copyto(dst[i * step:(i + 1) * step], src[i * step:(i + 1) * step], casting="unsafe"), range(parts)))
         return ent[1]
 
     def predict_inst_batch(self, inference_state, point_coords_batch=None, point_labels_batch=None,
@@ -429,7 +454,9 @@ class Sam3Image:
                 for k, j in enumerate(js):
                     masks_out[idxs[j]] = m[k].squeeze(0) if bpi == 1 else m[k]
             self.engine.clamp_(low, -32.0, 32.0)
-            low_np, iou_np = low_g.cpu().numpy(), iou_g.cpu().numpy()
+            # the low-res logits (10 MB at 32 prompts) take the pinned route too: a pageable D2H copy of that size costs 1-2 ms
+            low_np = self._masks_to_host(low_g) if low_g.is_cuda and low_g.numel() >= (1 << 20) else low_g.cpu().numpy()
+            iou_np = iou_g.cpu().numpy()
             for j, i in enumerate(idxs):
                 low_out[i] = low_np[j].squeeze(0) if bpi == 1 else low_np[j]
                 iou_out[i] = iou_np[j].squeeze(0) if bpi == 1 else iou_np[j]

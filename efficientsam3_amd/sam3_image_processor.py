@@ -28,6 +28,10 @@ class Sam3Processor:
         self.confidence_threshold = confidence_threshold
         self._stage = {}   # (B, H, W) -> pinned uint8 [B, H, W, 3] staging buffer of set_image_batch, allocated once
         self._pool = None  # worker threads that convert PIL images into the staging buffer
+        # A/B switch: stage Pillow's 4-byte pixels with torch's copy_ instead of np.copyto from the pool.  Measured on the GPU host
+        # (256 cores): both stage 32 images in 1.7-1.8 ms, but torch's 128 spinning OpenMP threads then starve the HIP runtime's
+        # own threads -- the step went from 40 to 58 ms (profiles/r04/api_level_probe.txt).  Off.
+        self.rgbx_torch_copy = False
         self._stage_busy = {}  # staging buffer key -> event recorded after the last H2D copy out of it
 
     @staticmethod
@@ -66,6 +70,17 @@ class Sam3Processor:
         if ev is not None:
             ev.synchronize()     # the host-to-device copy that last read this buffer must be done before it is refilled
         view = buf.numpy()
+
+        if ch == 4 and self.rgbx_torch_copy:
+            # Pillow's own 4-byte pixels: plain copies.  torch's copy_ splits every 4 MB image over the host cores itself;
+            # np.copyto from a thread pool did NOT run in parallel (25 ms for 32 images on 8 cores against 3.7 ms this way,
+            # measured on the host alone) and was the longest piece of an API-level step.
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")       # the Arrow-backed views are read-only: they are only read
+                for i in range(b):
+                    buf[i].copy_(torch.from_numpy(views[i]))
+            return buf
 
         def fill(i):
             if ch == 4:
