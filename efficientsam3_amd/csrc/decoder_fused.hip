@@ -80,7 +80,7 @@ __global__ __launch_bounds__(512) void i2t_block_kernel(const I2tParams p) {
   const s16x4 ones = {(short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80};
   const unsigned aq = (unsigned)(m * I2T_WQ_PITCH + g * 8), ao = (unsigned)(m * I2T_WO_PITCH + g * 8);
   int cur_b = -1;
-  s16x4 kA[8], vA[8];
+  s16x4 kA[8], vA[8], xf[16], xn[16];
   for (int64_t gg = g_begin; gg < g_end; ++gg) {
     const int b = (int)(gg / gpp), p0 = (int)(gg - (int64_t)b * gpp) * 16;
     if (b != cur_b) {   // wave-uniform: the token-side operands of this prompt
@@ -101,10 +101,13 @@ __global__ __launch_bounds__(512) void i2t_block_kernel(const I2tParams p) {
       }
     }
     const int64_t row = (int64_t)b * p.P + p0 + m;
-    const bf16_t* xr = p.x + row * 256 + 4 * g;
-    s16x4 xf[16];   // B = X^T: column = pixel m, k = channels 16 kb + 4 g ..  (also the residual, in the C layout of Y^T)
+    // B = X^T: column = pixel m, k = channels 16 kb + 4 g ..  (also the residual, in the C layout of Y^T); the first group's rows are
+    // loaded here, every later group's were requested during the previous group's output projection
+    if (gg == g_begin) {
+      const bf16_t* xr = p.x + row * 256 + 4 * g;
 #pragma unroll
-    for (int kb = 0; kb < 16; ++kb) xf[kb] = *reinterpret_cast<const s16x4*>(xr + 16 * kb);
+      for (int kb = 0; kb < 16; ++kb) xf[kb] = *reinterpret_cast<const s16x4*>(xr + 16 * kb);
+    }
     const bf16_t* per = p.peq + (int64_t)(p0 + m) * 128 + 4 * g;
     s16x4 pef[8];
 #pragma unroll
@@ -114,12 +117,14 @@ __global__ __launch_bounds__(512) void i2t_block_kernel(const I2tParams p) {
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
       // ---- Q_h^T = Wq[16 h .. 16 h + 16) X^T  (+ bias + pe) -------------------------------------------------------------
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      // four partial sums: sixteen products chained on ONE accumulator run at the matrix pipe's latency, not its rate
+      f32x4 part[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int kb = 0; kb < 16; ++kb) {
         const s16x4 a = *reinterpret_cast<const s16x4*>(sWq + aq + h * 16 * I2T_WQ_PITCH + kb * 32);
-        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, xf[kb], acc, 0, 0, 0);
+        part[kb & 3] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, xf[kb], part[kb & 3], 0, 0, 0);
       }
+      const f32x4 acc = (part[0] + part[1]) + (part[2] + part[3]);
       float q[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)   // rounded to bf16 where the layer-by-layer path stored q, then the 1 / sqrt(16) scale (exact)
@@ -144,23 +149,34 @@ __global__ __launch_bounds__(512) void i2t_block_kernel(const I2tParams p) {
       const f32x4 den = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ones, pb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       const float inv = 1.f / den[0];
       ob[h] = pack4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
-      __builtin_amdgcn_sched_barrier(0);   // one head at a time: hoisting the next heads' LDS reads spills
+      if (h & 1) __builtin_amdgcn_sched_barrier(0);   // two heads at a time (their chains interleave); hoisting more LDS reads spills
     }
     // ---- Y^T = Wo O^T + bo + x, LayerNorm over the 256 channels of a pixel (= 64 values in the lane x 4 lane groups) --------
     float y[16][4];
     float sum = 0.f;
+    if (gg + 1 < g_end) {   // the next group's rows (contiguous: the groups of a wave are consecutive 16-row blocks of the stream)
+      const bf16_t* xr = p.x + (row + 16) * 256 + 4 * g;
 #pragma unroll
-    for (int mb = 0; mb < 16; ++mb) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int kb = 0; kb < 16; ++kb) xn[kb] = *reinterpret_cast<const s16x4*>(xr + 16 * kb);
+    }
 #pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        const s16x4 a = *reinterpret_cast<const s16x4*>(sWo + ao + mb * 16 * I2T_WO_PITCH + h * 32);
-        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, ob[h], acc, 0, 0, 0);
-      }
+    for (int mq = 0; mq < 4; ++mq) {   // four output blocks at a time: four independent accumulation chains
+      f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        y[mb][i] = acc[i] + sBo[16 * mb + 4 * g + i] + bf16_bits_to_f32(xf[mb][i]);
-        sum += y[mb][i];
+      for (int h = 0; h < 8; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const s16x4 a = *reinterpret_cast<const s16x4*>(sWo + ao + (4 * mq + j) * 16 * I2T_WO_PITCH + h * 32);
+          acc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, ob[h], acc[j], 0, 0, 0);
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int mb = 4 * mq + j;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          y[mb][i] = acc[j][i] + sBo[16 * mb + 4 * g + i] + bf16_bits_to_f32(xf[mb][i]);
+          sum += y[mb][i];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -186,6 +202,8 @@ __global__ __launch_bounds__(512) void i2t_block_kernel(const I2tParams p) {
       for (int i = 0; i < 4; ++i) r[i] = (y[mb][i] - mean) * rstd * sG[16 * mb + 4 * g + i] + sBt[16 * mb + 4 * g + i];
       *reinterpret_cast<s16x4*>(orow + 16 * mb) = pack4(r[0], r[1], r[2], r[3]);
     }
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) xf[kb] = xn[kb];
   }
 }
 
@@ -308,6 +326,93 @@ __global__ __launch_bounds__(512) void t2i_mfma_kernel(const T2iParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+//   rowlin256_kernel   out[r] = x[r] W^T + bias + table[r mod P]  for 256 -> 256 channels over hundreds of thousands of rows: the merged
+//                      [k | v] projection of the image tokens.  As a 256 x 256 x 64 tile GEMM this shape has a K loop of four steps:
+//                      every tile pays the pipeline fill and a 128 KB epilogue for 33 MFLOP, and the launch ran at 0.3 of the HBM
+//                      roof (0.07 ms for 170 MB).  Here the 128 KB of weights stay in LDS for the persistent workgroup, a wave owns
+//                      32 rows: their fragments come straight from global memory in the B layout of v_mfma_f32_32x32x16_bf16
+//                      (Y^T = W X^T, channels = M), the eight 32-channel blocks accumulate side by side (eight independent chains),
+//                      and the C layout leaves 4 consecutive channels of a row per lane for the bias / table add and the store.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ bf16x8_v ld_a16(const bf16_t* p) { return __builtin_bit_cast(bf16x8_v, *reinterpret_cast<const uint4*>(p)); }
+__device__ __forceinline__ bf16x8_v ld_b16(const char* p) { return __builtin_bit_cast(bf16x8_v, *reinterpret_cast<const uint4*>(p)); }
+
+constexpr int RL_PITCH = 528;   // bytes per weight row in LDS (512 + 16: the 16-lane groups of a ds_read_b128 hit 64 distinct banks)
+constexpr int RL_LDS = 256 * RL_PITCH + 256 * 4;
+
+struct RowLinParams {
+  const bf16_t *x, *w, *table;
+  const float* bias;
+  bf16_t* out;
+  int64_t rows;
+  int kp, P, abl;
+};
+
+__global__ __launch_bounds__(512) void rowlin256_kernel(const RowLinParams p) {
+  extern __shared__ __attribute__((aligned(16))) char rl_smem[];
+  char* sW = rl_smem;
+  float* sB = reinterpret_cast<float*>(rl_smem + 256 * RL_PITCH);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 256 * 32; i += 512) {
+    const int row = i >> 5, c = i & 31;
+    *reinterpret_cast<uint4*>(sW + row * RL_PITCH + c * 16) = *reinterpret_cast<const uint4*>(p.w + (int64_t)row * p.kp + c * 8);
+  }
+  if (tid < 256) sB[tid] = p.bias ? p.bias[tid] : 0.f;
+  __syncthreads();
+  const int m = lane & 31, hk = lane >> 5;
+  const int64_t G = p.rows >> 5, NW = (int64_t)gridDim.x * 8, w = (int64_t)blockIdx.x * 8 + wave;
+  const int64_t g_begin = w * G / NW, g_end = (w + 1) * G / NW;
+  const unsigned aw = (unsigned)(m * RL_PITCH + hk * 16);
+  for (int64_t gg = g_begin; gg < g_end; ++gg) {
+    const int64_t row = gg * 32 + m;
+    const bf16_t* xr = p.x + row * 256 + 8 * hk;
+    bf16x8_v xf[16];   // B = X^T: column = row m, k = 16 kb + 8 hk ..
+#ifdef ESAM3_DEV
+    if (p.abl & 2) {   // ablation: no row loads
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) xf[kb] = __builtin_bit_cast(bf16x8_v, make_uint4((unsigned)(row + kb), 0x3f803f80u, (unsigned)lane, 0x3f003f00u));
+    } else
+#endif
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) xf[kb] = ld_a16(xr + 16 * kb);
+    f32x16 acc[8];
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][i] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb) {
+#pragma unroll
+      for (int mb = 0; mb < 8; ++mb)
+        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_b16(sW + aw + mb * 32 * RL_PITCH + kb * 32), xf[kb], acc[mb], 0, 0, 0);
+      if ((kb & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // keep the weight reads four k-steps deep at most
+    }
+    // C layout: value 4 j + i of block mb = channel 32 mb + 8 j + 4 hk + i of row m
+    const int prow = p.table ? (int)(row % p.P) : 0;
+    const bf16_t* tr = p.table ? p.table + (int64_t)prow * 256 + 4 * hk : nullptr;
+    bf16_t* orow = p.out + row * 256 + 4 * hk;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c0 = 32 * mb + 8 * j;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[mb][4 * j + i] + sB[c0 + 4 * hk + i];
+        if (tr) {
+          const s16x4 t4 = *reinterpret_cast<const s16x4*>(tr + c0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] += bf16_bits_to_f32(t4[i]);
+        }
+#ifdef ESAM3_DEV
+        if ((p.abl & 1) && v[0] + v[1] + v[2] + v[3] != 12345.678f) continue;   // ablation: no stores
+#endif
+        *reinterpret_cast<s16x4*>(orow + c0) = pack4(v[0], v[1], v[2], v[3]);
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // TOKEN side of the two-way transformer and the output heads (sam/transformer.py:143-182, mask_decoder.py:224-242) in five
 // launches instead of fifty-seven.  The token stream of a prompt is T <= 16 rows x 256 channels: every Linear on it is
 // launch-bound as a GEMM of its own (7-9 us per launch, 0.5 ms per step at 32 prompts).  Here one workgroup owns one prompt
@@ -327,8 +432,6 @@ constexpr int TOK_AP = 128 * 2 + 16;  // [16][128] operand (attention output of 
 
 struct TokLin { const bf16_t* w; const float* b; int ldw; };
 
-__device__ __forceinline__ bf16x8_v ld_a16(const bf16_t* p) { return __builtin_bit_cast(bf16x8_v, *reinterpret_cast<const uint4*>(p)); }
-__device__ __forceinline__ bf16x8_v ld_b16(const char* p) { return __builtin_bit_cast(bf16x8_v, *reinterpret_cast<const uint4*>(p)); }
 
 // One 16-channel output block of a Linear: where its weight rows, its bias and its X operand are, how many of its channels exist
 struct TokBlk {
@@ -804,6 +907,29 @@ int esam3_launch_tok_d(float* q32, const void* ta, void* hs, const esam3_tok_lin
     for (int l = 0; l < 3; ++l) p.mlp[r][l] = tl(mlp[r * 3 + l]);
   p.hyper = (bf16_t*)hyper; p.iou = iou; p.obj = (bf16_t*)obj; p.T = T; p.eps = eps;
   hipLaunchKernelGGL(tok_d_kernel, dim3((unsigned)Bp, 6u), dim3(512), 0, s, p);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// ---- 256 -> 256 row-wise linear with a position table -------------------------------------------------------------------------
+bool esam3_rowlin256_ok(int dtype, int64_t rows, int N, int K, int P) {
+  return dtype == 1 && N == 256 && K == 256 && rows > 0 && rows % 32 == 0 && (P <= 0 || P % 32 == 0);
+}
+int esam3_launch_rowlin256(const void* x, const void* w, int kp, const float* bias, const void* table, int P, void* out, int64_t rows,
+                           hipStream_t s) {
+  if (!esam3_rowlin256_ok(1, rows, 256, 256, table ? P : 0) || kp < 256 || (kp % 8)) {
+    esam3_set_error("rowlin256: unsupported shape (rows=%lld kp=%d P=%d)", (long long)rows, kp, P);
+    return -1;
+  }
+  static const int ok = esam3_allow_dyn_lds((const void*)rowlin256_kernel, RL_LDS);
+  if (ok) return -1;
+  RowLinParams p;
+  p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.table = (const bf16_t*)table; p.bias = bias; p.out = (bf16_t*)out; p.rows = rows;
+  p.kp = kp; p.P = P; p.abl = esam3_dev_flag("ESAM3_RL_ABL");
+  const int64_t G = rows / 32;
+  int grid = (int)((G + 7) / 8);
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(rowlin256_kernel, dim3(grid), dim3(512), RL_LDS, s, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -2430,6 +2430,20 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
     }
   }
 
+  // [k | v] rows of the image tokens = keys . Wkv^T + bias + position table: the weights-resident row kernel where the shape fits
+  // (256 -> 256, bf16), the tile GEMM otherwise
+  // (measured at parity with the tile GEMM, 0.066-0.069 against 0.064-0.073 ms at 32 prompts: 39 us of it are MFMA + LDS + epilogue, 18 us
+  // its 16-byte-per-row stores, 8 us its 32-byte-per-row loads -- profiles/r04/rowlin256_abl.txt; the tile GEMM stays the default)
+  static const bool use_rowlin = esam3_dev_flag("ESAM3_ROWLIN") != 0;  // A/B
+  auto kv_rows = [&](PackedGemm* gkv, const void* table) -> int {
+    if (use_rowlin && esam3_rowlin256_ok(dtype, Bp * P, gkv->N, gkv->K, (int)P)) {
+      if (dry) return 0;
+      const double rows = (double)Bp * P;
+      return prof_launch(gkv->tag, 2.0 * rows * gkv->N * gkv->K, (2.0 * rows * 256 + (double)gkv->N * gkv->K) * (double)esz, [&]() {
+        return esam3_launch_rowlin256(keys, gkv->w, gkv->Kp, gkv->bias, table, (int)P, ikv, Bp * P, st); });
+    }
+    return gemm(gkv, keys, DM, Bp * P, 1, 1, ikv, 256, ACT_NONE, table, 256, 1, (int)P);
+  };
   auto add = [&](const void* a, const void* b, void* o, int64_t n) -> int {
     if (dry) return 0;
     return esam3_launch_add(dtype, a, b, o, n, st);
@@ -2459,7 +2473,7 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
       // one N = 256 GEMM writes [k | v] rows; the attention runs on the matrix cores out of the two halves
       PackedGemm* gkv = pk_kv_cat(ap);
       if (!gkv) return -1;
-      CK(gemm(gkv, keys, DM, Bp * P, 1, 1, ikv, 256, ACT_NONE, tbufs[ap + "kv_proj#pe"], 256, 1, (int)P));
+      CK(kv_rows(gkv, tbufs[ap + "kv_proj#pe"]));
       if (!dry) CK(prof_launch("attn_t2i", 4.0 * Bp * T * (double)P * 128, 2.0 * (double)Bp * P * 128 * (double)esz, [&]() {
         return esam3_launch_t2i_mfma(tq, 128, ikv, 256, (const char*)ikv + 128 * esz, 256, ta, Bp, T, (int)P, t2i_scratch, st); }));
     } else {
@@ -2497,7 +2511,7 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
     auto kv_and_attn = [&](const std::string& ap) -> int {   // [k | v] rows of the image tokens, then tq -> ta
       PackedGemm* gkv = pk_kv_cat(ap);
       if (!gkv) return -1;
-      CK(gemm(gkv, keys, DM, Bp * P, 1, 1, ikv, 256, ACT_NONE, tbufs[ap + "kv_proj#pe"], 256, 1, (int)P));
+      CK(kv_rows(gkv, tbufs[ap + "kv_proj#pe"]));
       if (!dry) CK(prof_launch("attn_t2i", 4.0 * Bp * T * (double)P * 128, 2.0 * (double)Bp * P * 128 * (double)esz, [&]() {
         return esam3_launch_t2i_mfma(tq, 128, ikv, 256, (const char*)ikv + 128 * esz, 256, ta, Bp, T, (int)P, t2i_scratch, st); }));
       return 0;

@@ -12,6 +12,10 @@ void esam3_note_gemm_kernel(const char* name);
 int esam3_allow_dyn_lds(const void* kernel, int bytes);
 // decoder_fused.hip: "image attends to the tokens" of the two-way transformer in one kernel (q_proj + attention over T <= 16
 // prompt tokens + out_proj + residual + LayerNorm), bf16, 8 heads x 16
+// out[r] = x[r] W^T + bias + table[r mod P] for 256 -> 256 channels, bf16, weights resident in LDS (decoder_fused.hip)
+bool esam3_rowlin256_ok(int dtype, int64_t rows, int N, int K, int P);
+int esam3_launch_rowlin256(const void* x, const void* w, int kp, const float* bias, const void* table, int P, void* out, int64_t rows,
+                           hipStream_t s);
 // token side of the two-way transformer + the output heads as three per-prompt kernels (decoder_fused.hip); a Linear is
 // {packed bf16 weight [N][ldw], fp32 bias or null, ldw}
 struct esam3_tok_lin { const void* w; const float* bias; int ldw; };

@@ -386,6 +386,23 @@ int esam3_op_lite_mla_block(const void* x, const float* wqkv, const float* wdw, 
   return 0;
 }
 
+int esam3_op_rowlin256(const void* x, const float* w, const float* bias, const float* table, int P, void* out, int64_t rows, void* stream) {
+  Tmp t;
+  if (!esam3_rowlin256_ok(1, rows, 256, 256, table ? P : 0)) { esam3_set_error("op_rowlin256: rows = %lld, P = %d unsupported", (long long)rows, P); return -1; }
+  const int Kp = esam3_gemm_pad_k(256, 2);
+  std::vector<float> pk((size_t)256 * Kp, 0.f);
+  for (int n = 0; n < 256; ++n)
+    for (int k = 0; k < 256; ++k) pk[(size_t)n * Kp + k] = w[(size_t)n * 256 + k];
+  void* dw = t.upT(1, pk);
+  float* db = bias ? (float*)t.up(bias, 256 * 4) : nullptr;
+  void* dt = table ? t.upT(1, std::vector<float>(table, table + (size_t)P * 256)) : nullptr;
+  if (!dw || (bias && !db) || (table && !dt)) return fail("op_rowlin256");
+  if (op_timed("rowlin256", (hipStream_t)stream, [&]() { return esam3_launch_rowlin256(x, dw, Kp, db, dt, P, out, rows, (hipStream_t)stream); }))
+    return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
 int esam3_op_i2t_block(const void* x, const float* wq, const float* bq, const float* peq, const float* wo, const float* bo,
                        const float* gamma, const float* beta, const float* tk, const float* tv, void* out, int Bp, int P, int T,
                        void* stream) {

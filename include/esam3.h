@@ -417,6 +417,11 @@ int esam3_op_mbconv3(const void* x_dev, const float* w1_host, const float* b1_ho
 int esam3_op_lite_mla_block(const void* x_dev, const float* wqkv_host, const float* wdw_host, const float* wgrp_host,
                             const float* wproj_host, const float* bproj_host, void* out_dev, int B, int H, int W, int C,
                             void* hip_stream);
+/* out[r] = x[r] W^T + bias + table[r mod P] for 256 -> 256 channels on the bf16 engine with the weights resident in LDS
+ * (csrc/decoder_fused.hip: the merged k | v projection of the image tokens, sam/transformer.py:165-170,226-253).  x_dev / out_dev bf16
+ * [rows][256], rows % 32 == 0; w [256][256], bias [256] or NULL, table [P][256] or NULL (P % 32 == 0): host fp32 */
+int esam3_op_rowlin256(const void* x_dev, const float* w_host, const float* bias_host, const float* table_host, int P, void* out_dev,
+                       int64_t rows, void* hip_stream);
 /* "image attends to the tokens" block of the two-way transformer on the bf16 engine (csrc/decoder_fused.hip), one kernel:
  * q = (x + pe) Wq^T + bq, 8 heads x 16 attention over the T <= 16 prompt tokens (k / v already projected), out_proj, + x, LayerNorm.
  * x_dev / out_dev bf16 [Bp][P][256] (P % 16 == 0); wq [128][256], bq [128], peq [P][128] (= pe Wq^T), wo [256][128], bo [256],

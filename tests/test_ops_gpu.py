@@ -825,3 +825,25 @@ def test_attention_t2i_mfma(B, Nq, Nk, merged):
         k_d, v_d = k.to("cuda", tdt), v.to("cuda", tdt)
         U.check(U.lib().esam3_op_attention(1, U.P(q_d), U.P(k_d), U.P(v_d), U.P(o_d), B, Nq, Nk, heads, hd, 2, None), "op_attention 2")
     U.assert_close(o_d.float().cpu(), ref, "bf16", "attention t2i mfma")
+
+
+@pytest.mark.parametrize("rows,P,bias,table", [(32, 32, True, True), (5184 * 2, 5184, True, True), (96, 0, False, False), (64 * 37, 64, True, False),
+                                              (5184 * 3 + 0, 5184, False, True)])
+def test_rowlin256(rows, P, bias, table):
+    """256 -> 256 row-wise linear with a position table (csrc/decoder_fused.hip: rowlin256_kernel, the merged k | v projection)"""
+    tdt = torch.bfloat16
+    x = _rand(rows, 256, seed=1)
+    w = _rand(256, 256, seed=2) / 16.0
+    b = _rand(256, seed=3) * 0.2 if bias else None
+    tb = _rand(P, 256, seed=4) * 0.5 if table else None
+    q = lambda t: t.to(tdt).double()  # noqa: E731
+    ref = q(x) @ q(w).T
+    if bias:
+        ref = ref + b.double()
+    if table:
+        ref = ref + q(tb).repeat(rows // P, 1)
+    x_d = x.to("cuda", tdt)
+    out = torch.full((rows, 256), float("nan"), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_rowlin256(U.P(x_d), U.H(U.np32(w)), U.H(U.np32(b)) if bias else None, U.H(U.np32(tb)) if table else None, P, U.P(out),
+                                       rows, None), "op_rowlin256")
+    U.assert_close(out.float().cpu(), ref.float(), "bf16", f"rowlin256 rows={rows}")

@@ -45,3 +45,11 @@ if __name__ == "__main__":
     sys.stderr.write("attn_t2i MFMA: "); sys.stderr.flush()
     lib.esam3_op_attention(1, P(q), P(kv), None, P(o), Bp, T, Pn, 8, 16, 3, None)
     torch.cuda.synchronize()
+
+    # the merged k | v projection: weights-resident row kernel
+    xr = torch.randn(Bp * Pn, 256, generator=torch.Generator().manual_seed(5)).to("cuda", torch.bfloat16)
+    orow = torch.empty_like(xr)
+    sys.stderr.write("rowlin256 (kv projection, 170 MB in + out): "); sys.stderr.flush()
+    lib.esam3_op_rowlin256(P(xr), H(rnd(256, 256, seed=6, scale=1 / 16)), H(rnd(256, seed=7, scale=0.1)), H(rnd(Pn, 256, seed=8, scale=0.5)), Pn, P(orow),
+                           C.c_int64(Bp * Pn), None)
+    torch.cuda.synchronize()
