@@ -129,6 +129,7 @@ SIGNATURES = {
     "esam3_op_mbconv_fused": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_mbconv3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_lite_mla_block": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "esam3_resize_axis_tables": (_I, [_I, _I, _P, _P, _P]),
     "esam3_op_rowlin256": (_I, [_P, _P, _P, _P, _I, _P, _L, _P]),
     "esam3_op_i2t_block": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "esam3_op_dwconv": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

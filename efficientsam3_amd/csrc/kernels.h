@@ -99,6 +99,7 @@ int esam3_launch_resize_bilinear(int dtype, const void* in, void* out, int B, in
 // the same interpolation applied to the output of a neck level's first layer computed on the un-resized map: in
 // [B][IH][IW][taps*C] (taps = 4: ConvT k2s2 tap-major blocks, pixel-shuffled to a 2x larger map; taps = 1: 1x1 conv) + bias
 // + activation -> out [B][s*OH (+2)][s*OW (+2)][C], optionally inside a 1-pixel zero border
+int esam3_resize_axis_tables_host(int in_size, int out_size, int* first, int* count, float* frac);  // host-only: the row kernel's axis maps
 int esam3_launch_resize_shuffle(int dtype, const void* in, const float* bias, void* out, int B, int IH, int IW, int OH, int OW,
                                 int C, int taps, int act, int out_pad, hipStream_t s);
 

@@ -3016,6 +3016,19 @@ int esam3_launch_resize_bilinear(int dtype, const void* in, void* out, int B, in
   return 0;
 }
 
+// host-only: the per-axis maps the row-persistent resize_shuffle kernel receives in its kernel arguments (test hook, no device work)
+int esam3_resize_axis_tables_host(int in_size, int out_size, int* first, int* count, float* frac) {
+  RsAxisTables t;
+  if (in_size < 1 || out_size < 1 || !first || !count || !frac || !rs_build_tables(t, in_size, in_size, out_size, out_size)) {
+    esam3_set_error("resize_axis_tables: %d -> %d is outside the row kernel's range (<= %d source, <= %d output indices, <= 4 outputs per cell)",
+                    in_size, out_size, RsAxisTables::MAX_IN, RsAxisTables::MAX_OUT);
+    return -1;
+  }
+  for (int c = 0; c < in_size; ++c) { first[c] = t.first[0][c]; count[c] = t.count[0][c]; }
+  for (int o = 0; o < out_size; ++o) frac[o] = t.frac[0][o];
+  return 0;
+}
+
 int esam3_launch_resize_shuffle(int dtype, const void* in, const float* bias, void* out, int B, int IH, int IW, int OH, int OW,
                                 int C, int taps, int act, int out_pad, hipStream_t s) {
   const int CG = C / VEC;

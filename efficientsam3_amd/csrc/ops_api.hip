@@ -104,6 +104,10 @@ int esam3_op_fused_mlp(const void* x, const float* w1, const float* b1, const fl
   return 0;
 }
 
+int esam3_resize_axis_tables(int in_size, int out_size, int* first, int* count, float* frac) {
+  return esam3_resize_axis_tables_host(in_size, out_size, first, count, frac);
+}
+
 int esam3_op_resize_shuffle(int dtype, const void* in, const float* bias, void* out, int B, int IH, int IW, int OH, int OW, int C, int taps,
                             int act, int out_pad, void* stream) {
   Tmp t;

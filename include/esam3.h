@@ -351,6 +351,11 @@ int esam3_op_fused_mlp(const void* x_dev, const float* w1_host, const float* b1_
  * (taps = 1) layer's output computed on the un-resized map: in [B][IH][IW][taps*C] -> out [B][s*OH(+2)][s*OW(+2)][C], + bias[C]
  * (host fp32 or NULL), activation, optional 1-pixel zero border (the caller zeroes it).  The commuted front end of the necks:
  * F.interpolate of model_builder.py:779-786 applied after the first layer of necks.py:42-92 instead of before it. */
+/* host-only test hook: the per-axis interpolation maps of a bilinear (align_corners = False) resize in_size -> out_size as the
+ * resize_shuffle row kernel receives them: first[c] / count[c] = the run of output indices whose source cell is c (c < in_size),
+ * frac[o] = interpolation fraction of output o.  Same float arithmetic as ATen's area_pixel_compute_source_index
+ * (the head's F.interpolate, model_builder.py:779-786).  Returns -1 outside the kernel's range. */
+int esam3_resize_axis_tables(int in_size, int out_size, int* first_host, int* count_host, float* frac_host);
 int esam3_op_resize_shuffle(int dtype, const void* in_dev, const float* bias_host, void* out_dev, int B, int IH, int IW, int OH, int OW,
                             int C, int taps, int act, int out_pad, void* hip_stream);
 /* dense 3x3/s1/p1 or 1x1 conv, NHWC; w_host is the PyTorch [Cout][Cin][k][k] fp32 weight */

@@ -489,3 +489,32 @@ def test_pil_rgbx_view_is_the_image_and_staging_falls_back():
     assert wide.shape[-1] == (4 if v is not None else 3) and torch.equal(wide[..., :3], packed)
     mixed = proc._stage_pil_batch(ims[:4] + [ims[4].convert("L")], slot=1, rgbx=True)  # one image cannot export: whole batch packs
     assert mixed.shape[-1] == 3 and torch.equal(mixed[:4], packed[:4])
+
+
+@pytest.mark.parametrize("n_in,n_out", [(32, 72), (16, 16), (9, 20), (64, 192), (20, 9), (1, 3), (33, 34)])
+def test_resize_axis_tables_match_aten(n_in, n_out):
+    """the per-axis maps the row-persistent resize_shuffle kernel gets from its launcher (csrc/kernels_backbone.hip: rs_build_tables) against
+    torch's own bilinear resize (align_corners=False, the head's F.interpolate) on the CPU: every output index belongs to exactly one source
+    cell's run, and (1 - frac) x[cell] + frac x[cell + 1] reproduces F.interpolate on random signals"""
+    import ctypes as C
+
+    import torch.nn.functional as F
+
+    from efficientsam3_amd import _lib
+    lib = _lib.load()
+    first, count, frac = (C.c_int * n_in)(), (C.c_int * n_in)(), (C.c_float * n_out)()
+    _lib.check(lib.esam3_resize_axis_tables(n_in, n_out, first, count, frac), "esam3_resize_axis_tables")
+    owner = np.full(n_out, -1)
+    for c in range(n_in):
+        assert 0 <= count[c] <= 4
+        for o in range(first[c], first[c] + count[c]):
+            assert owner[o] == -1
+            owner[o] = c
+    assert (owner >= 0).all() and (np.diff(owner) >= 0).all()
+    x = torch.randn(3, n_in, generator=torch.Generator().manual_seed(n_in * 131 + n_out))
+    ref = F.interpolate(x[None, :, :, None], size=(n_out, 1), mode="bilinear", align_corners=False)[0, :, :, 0].numpy()
+    fr = np.asarray(list(frac), dtype=np.float32)
+    nxt = np.minimum(owner + 1, n_in - 1)
+    got = (1.0 - fr) * x.numpy()[:, owner] + fr * x.numpy()[:, nxt]
+    assert np.abs(got - ref).max() <= 5e-6      # the blend itself is rounded differently (fused multiply-adds in ATen's vectorised kernel)
+    assert lib.esam3_resize_axis_tables(65, 72, first, count, frac) != 0     # more source cells than the kernel's tables hold
