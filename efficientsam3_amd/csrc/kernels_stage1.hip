@@ -543,18 +543,38 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const typename Elem<DT>:
   }
 }
 
-// FWD: mean, rstd, running statistics.  BWD: dgamma, dbeta.  One thread per channel, splits summed in order in fp64.
+// FWD: mean, rstd, running statistics.  BWD: dgamma, dbeta.  A workgroup owns 64 channels; its four waves sum contiguous quarters of the
+// splits in fp64, two interleaved chains each, and the partial sums are combined in one fixed order (deterministic).  The first version
+// -- one thread per channel walking all 512 splits -- took 128 us per call, 9 ms of a 54 ms stage-1 step over its 70 calls
+// (profiles/r04/stage1_step_kernel_stats.csv): a chain of 1024 dependent loads + fp64 adds on a handful of lanes.
 template <bool BWD>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int splits, int C, int64_t rows, double eps,
                                                           double momentum, float* __restrict__ o0, float* __restrict__ o1,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int s_ = 0; s_ < splits; ++s_) {
-    s0 += (double)partial[(int64_t)s_ * 2 * C + c];
-    s1 += (double)partial[(int64_t)s_ * 2 * C + C + c];
+  __shared__ double sq[2][4][64];
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + e;
+  const int per = (splits + 3) / 4, z0 = q * per, z1 = splits < z0 + per ? splits : z0 + per;
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+  if (c < C) {
+    int z = z0;
+    for (; z + 1 < z1; z += 2) {
+      a0 += (double)partial[(int64_t)z * 2 * C + c];
+      b0 += (double)partial[(int64_t)z * 2 * C + C + c];
+      a1 += (double)partial[(int64_t)(z + 1) * 2 * C + c];
+      b1 += (double)partial[(int64_t)(z + 1) * 2 * C + C + c];
+    }
+    if (z < z1) {
+      a0 += (double)partial[(int64_t)z * 2 * C + c];
+      b0 += (double)partial[(int64_t)z * 2 * C + C + c];
+    }
   }
+  sq[0][q][e] = a0 + a1;
+  sq[1][q][e] = b0 + b1;
+  __syncthreads();
+  if (q != 0 || c >= C) return;
+  const double s0 = (sq[0][0][e] + sq[0][1][e]) + (sq[0][2][e] + sq[0][3][e]);
+  const double s1 = (sq[1][0][e] + sq[1][1][e]) + (sq[1][2][e] + sq[1][3][e]);
   if constexpr (BWD) {
     o0[c] = (float)s1;  // dgamma
     o1[c] = (float)s0;  // dbeta
@@ -614,7 +634,7 @@ int bn_forward_t(const void* x, void* y, int64_t rows, int C, const float* gamma
   const int splits = (int)(rows < BN_SPLITS ? rows : BN_SPLITS);
   hipLaunchKernelGGL((bn_reduce_kernel<DT, false>), dim3((unsigned)splits), dim3(256), sizeof(float) * 2 * (size_t)RL * C, s, (const T*)x,
                      (const T*)nullptr, rows, C, (const float*)nullptr, (const float*)nullptr, partial);
-  hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, partial, splits, C, rows, eps, momentum,
+  hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, partial, splits, C, rows, eps, momentum,
                      save_mean, save_rstd, rm, rv);
   const int64_t total = rows * (C / 8);
   const unsigned grid = (unsigned)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
@@ -632,7 +652,7 @@ int bn_backward_t(const void* x, const void* dy, void* dx, int64_t rows, int C, 
   const int splits = (int)(rows < BN_SPLITS ? rows : BN_SPLITS);
   hipLaunchKernelGGL((bn_reduce_kernel<DT, true>), dim3((unsigned)splits), dim3(256), sizeof(float) * 2 * (size_t)RL * C, s, (const T*)x,
                      (const T*)dy, rows, C, save_mean, save_rstd, partial);
-  hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, s, partial, splits, C, rows, 0.0, 0.0, dgamma,
+  hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, partial, splits, C, rows, 0.0, 0.0, dgamma,
                      dbeta, (float*)nullptr, (float*)nullptr);
   const int64_t total = rows * (C / 8);
   const unsigned grid = (unsigned)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);

@@ -186,12 +186,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::ty
   }
 }
 
+// Sum of partial[z][i] over the splits in a FIXED order that is not one dependent chain: the splits are dealt to the four waves of the
+// workgroup in contiguous quarters, every wave keeps four interleaved partial sums, and the sixteen sums are added in one written-down
+// order.  (The one-thread-per-element loop over up to 512 splits ran at one memory latency per few adds: 65 us per call, 5 ms of a
+// stage-1 step over its 80 calls -- profiles/r04/stage1_step_kernel_stats.csv.)  Deterministic: the order depends on (splits) only.
+__device__ __forceinline__ float fixed_order_sum(const float* __restrict__ p, int z0, int z1, int64_t stride) {
+  float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+  int z = z0;
+  for (; z + 3 < z1; z += 4) {
+    a += p[(int64_t)z * stride];
+    b += p[(int64_t)(z + 1) * stride];
+    c += p[(int64_t)(z + 2) * stride];
+    d += p[(int64_t)(z + 3) * stride];
+  }
+  for (; z < z1; ++z) a += p[(int64_t)z * stride];
+  return (a + b) + (c + d);
+}
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int64_t n, float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * n + i];  // fixed order
-  out[i] = s;
+  __shared__ float sq[4][64];
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
+  const int per = (splits + 3) / 4, z0 = q * per, z1 = min(splits, z0 + per);
+  sq[q][e] = i < n ? fixed_order_sum(partial + i, z0, z1, n) : 0.f;
+  __syncthreads();
+  if (q == 0 && i < n) out[i] = (sq[0][e] + sq[1][e]) + (sq[2][e] + sq[3][e]);
 }
 
 // dbias[N] = sum over the rows of dy: [splits][N] partials then the same reduce kernel
@@ -303,13 +321,17 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const typename TElem<DT>:
 }
 
 // [k k][C] (tap-major) -> PyTorch's [C][1][k][k]
-__global__ void dw_wgrad_finalize_kernel(const float* __restrict__ partial, int splits, int C, int taps, float* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= taps * C) return;
-  const int t = i / C, c = i - t * C;
-  float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * taps * C + i];
-  out[c * taps + t] = s;
+__global__ __launch_bounds__(256) void dw_wgrad_finalize_kernel(const float* __restrict__ partial, int splits, int C, int taps, float* __restrict__ out) {
+  __shared__ float sq[4][64];
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e, n = taps * C;
+  const int per = (splits + 3) / 4, z0 = q * per, z1 = min(splits, z0 + per);
+  sq[q][e] = i < n ? fixed_order_sum(partial + i, z0, z1, n) : 0.f;
+  __syncthreads();
+  if (q == 0 && i < n) {
+    const int t = i / C, c = i - t * C;
+    out[c * taps + t] = (sq[0][e] + sq[1][e]) + (sq[2][e] + sq[3][e]);
+  }
 }
 
 // ---- LiteMLA's ReLU linear attention, backward (backbones/efficientvit/nn/ops.py:584-621 relu_linear_att) ---------------------------
@@ -512,13 +534,13 @@ int esam3_linear_wgrad(int dtype, const void* dy, const void* x, int64_t M, int 
   if (dtype == 0) hipLaunchKernelGGL(wgrad_kernel<0>, grid, dim3(256), 0, s, (const float*)dy, N, (const float*)x, K, M, N, K, rps, partial);
   else hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, s, (const uint16_t*)dy, N, (const uint16_t*)x, K, M, N, K, rps, partial);
   const int64_t nk = (int64_t)N * K;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, partial, zs, nk, dw);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk + 63) / 64)), dim3(256), 0, s, partial, zs, nk, dw);
   if (dbias) {
     float* pb = partial + (int64_t)splits * nk;
     const dim3 g2((unsigned)((N + 255) / 256), (unsigned)zs);
     if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<0>, g2, dim3(256), 0, s, (const float*)dy, N, M, N, rps, pb);
     else hipLaunchKernelGGL(colsum_kernel<1>, g2, dim3(256), 0, s, (const uint16_t*)dy, N, M, N, rps, pb);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, pb, zs, (int64_t)N, dbias);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, pb, zs, (int64_t)N, dbias);
   }
   HIP_CHECK_RET(hipGetLastError());
   return 0;
@@ -541,7 +563,7 @@ int esam3_colsum(int dtype, const void* dy, int64_t M, int N, float* out, void* 
   const dim3 g2((unsigned)((N + 255) / 256), (unsigned)zs);
   if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<0>, g2, dim3(256), 0, s, (const float*)dy, N, M, N, rps, pb);
   else hipLaunchKernelGGL(colsum_kernel<1>, g2, dim3(256), 0, s, (const uint16_t*)dy, N, M, N, rps, pb);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, pb, zs, (int64_t)N, out);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, pb, zs, (int64_t)N, out);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -573,7 +595,7 @@ int esam3_dwconv_wgrad(int dtype, const void* x, const void* dy, int B, int H, i
   else if (ksize == 3) ESAM3_DWW(1, 3, uint16_t);
   else ESAM3_DWW(1, 5, uint16_t);
 #undef ESAM3_DWW
-  hipLaunchKernelGGL(dw_wgrad_finalize_kernel, dim3((unsigned)((ksize * ksize * C + 255) / 256)), dim3(256), 0, s, partial, splits, C,
+  hipLaunchKernelGGL(dw_wgrad_finalize_kernel, dim3((unsigned)((ksize * ksize * C + 63) / 64)), dim3(256), 0, s, partial, splits, C,
                      ksize * ksize, dw);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
