@@ -648,12 +648,17 @@ __global__ void select_masks_kernel(const float* __restrict__ all_masks, const T
 // living in global memory (324 KB per 288x288 mask -> L2 resident).  Only component
 // *areas* are consumed, so label values need not match any other implementation.
 // ------------------------------------------------------------------------------------
+// find with path halving: a visited node is re-pointed at its grandparent with atomicMin (parents only ever decrease, an ancestor is
+// always a valid parent, and atomicMin cannot undo a concurrent re-hooking to something smaller).  Without it the walks of the one
+// huge background component -- most pixels of a mask -- stayed as long as cc_merge's hooks had left them.
 __device__ inline int uf_find(int* lab, int x) {
   int r = x;
   while (true) {
     const int p = __hip_atomic_load(lab + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (p == r) break;
-    r = p;
+    const int gp = __hip_atomic_load(lab + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gp != p) atomicMin(lab + r, gp);
+    r = gp;
   }
   return r;
 }
@@ -733,8 +738,17 @@ __global__ void cc_count_kernel(int* __restrict__ labels, int* __restrict__ area
     const int64_t n = gi / HW;
     const int i = (int)(gi - n * HW);
     int* lab = labels + n * HW;
-    if (__hip_atomic_load(lab + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0) {
-      const int r = uf_find(lab, i);
+    const int v = __hip_atomic_load(lab + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v >= 0) {
+      // cc_init pointed every pixel of a horizontal run (inside this wavefront's 64-pixel segment) at the run's first pixel, so most
+      // labels name a pixel that another lane of this wave holds.  A pixel and its label are in one set: a lane whose label points
+      // into the wave takes the root THAT lane found instead of walking itself; a lane that is its own label, whose label lies
+      // outside the wave, or whose source did not walk, walks itself.
+      const bool walk = v == i || i - v > lane;
+      int r = walk ? uf_find(lab, i) : 0;
+      const int src = walk ? lane : lane - (i - v);
+      const int r_src = __shfl(r, src), src_walked = __shfl(walk ? 1 : 0, src);
+      if (!walk) r = src_walked ? r_src : uf_find(lab, i);
       __hip_atomic_store(lab + i, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // path compression
       key = n * HW + r;
     }

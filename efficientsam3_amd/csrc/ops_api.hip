@@ -541,7 +541,8 @@ int esam3_op_fill_holes(const float* in, float* out, int n, int H, int W, float 
   int* labels = (int*)t.raw((size_t)n * H * W * 4);
   int* areas = (int*)t.raw((size_t)n * H * W * 4);
   if (!labels || !areas) return fail("op_fill_holes");
-  if (esam3_launch_fill_holes(in, out, labels, areas, n, H, W, thr, max_area, (hipStream_t)stream)) return -1;
+  if (op_timed("fill_holes", (hipStream_t)stream, [&]() { return esam3_launch_fill_holes(in, out, labels, areas, n, H, W, thr, max_area, (hipStream_t)stream); }))
+    return -1;
   HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }

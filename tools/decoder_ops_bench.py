@@ -53,3 +53,18 @@ if __name__ == "__main__":
     lib.esam3_op_rowlin256(P(xr), H(rnd(256, 256, seed=6, scale=1 / 16)), H(rnd(256, seed=7, scale=0.1)), H(rnd(Pn, 256, seed=8, scale=0.5)), Pn, P(orow),
                            C.c_int64(Bp * Pn), None)
     torch.cuda.synchronize()
+    # hole filling on the low-res logits of 32 prompts (realistic masks: smooth blobs, a few small holes)
+    yy, xx = np.mgrid[0:288, 0:288]
+    rng = np.random.default_rng(3)
+    m = np.full((Bp, 288, 288), -4.0, np.float32)
+    for i in range(Bp):
+        cy, cx, r = rng.integers(80, 200), rng.integers(80, 200), rng.integers(30, 90)
+        m[i][(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 4.0
+        for _ in range(12):
+            hy, hx, hr = rng.integers(0, 288), rng.integers(0, 288), rng.integers(1, 7)
+            m[i][(yy - hy) ** 2 + (xx - hx) ** 2 <= hr * hr] *= -1.0
+    m_d = torch.from_numpy(m).to("cuda")
+    o_d = torch.empty_like(m_d)
+    sys.stderr.write("fill_holes 32 x 288^2: "); sys.stderr.flush()
+    lib.esam3_op_fill_holes(P(m_d), P(o_d), Bp, 288, 288, C.c_float(0.0), C.c_float(256.0), None)
+    torch.cuda.synchronize()
