@@ -83,6 +83,18 @@ def cpu_baseline(sample_images: int = 5):
                       f"fp32 oracle, set_image + predict_inst(point+box), torch CPU {threads} threads"}
 
 
+def parse_cpulist(spec: str) -> set:
+    """sysfs cpulist syntax ("0-63,128-191", "5", "") -> set of cpu numbers"""
+    cpus = set()
+    for part in spec.strip().split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            cpus.update(range(int(a), int(b) + 1))
+        elif part:
+            cpus.add(int(part))
+    return cpus
+
+
 def bind_to_gpu_numa_node(local_rank: int):
     """Pin this rank's host threads to the CPUs next to its GPU (sysfs: /sys/bus/pci/devices/<bdf>/local_cpulist): the per-rank
     staging copies and worker threads of an N-rank job then stay on the socket the GPU hangs off (host IO, not
@@ -93,14 +105,7 @@ def bind_to_gpu_numa_node(local_rank: int):
         bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
         with open(f"/sys/bus/pci/devices/{bdf}/local_cpulist") as f:
             spec = f.read().strip()
-        cpus = set()
-        for part in spec.split(","):
-            if "-" in part:
-                a, b = part.split("-")
-                cpus.update(range(int(a), int(b) + 1))
-            elif part:
-                cpus.add(int(part))
-        cpus &= os.sched_getaffinity(0)
+        cpus = parse_cpulist(spec) & os.sched_getaffinity(0)
         if not cpus:
             return None
         os.sched_setaffinity(0, cpus)

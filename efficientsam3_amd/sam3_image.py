@@ -56,6 +56,19 @@ def _nchw_view(t_nhwc: torch.Tensor) -> torch.Tensor:
 _WIDEN_POOL = None
 
 
+def _widen_into(dst: np.ndarray, src: np.ndarray, parts: int = 16, serial_below: int = 1 << 22) -> None:
+    """dst[...] = src (same shape, any dtypes numpy can cast: the uint8 masks become the float32 array the reference's contract returns);
+    large arrays are split into `parts` contiguous ranges copied by the worker threads."""
+    assert dst.shape == src.shape and dst.flags.c_contiguous and src.flags.c_contiguous
+    d, s_ = dst.reshape(-1), src.reshape(-1)
+    n = s_.size
+    if n < serial_below:
+        np.copyto(d, s_, casting="unsafe")
+        return
+    step = -(-n // parts)
+    list(_widen_pool().map(lambda i: np.copyto(d[i * step:(i + 1) * step], s_[i * step:(i + 1) * step], casting="unsafe"), range(parts)))
+
+
 def _widen_pool():
     """a few long-lived worker threads for host-side copies (numpy releases the GIL inside them)"""
     global _WIDEN_POOL
@@ -399,14 +412,7 @@ class Sam3Image:
         # GPU host) keeps spinning after the copy, and the NEXT wait on the device -- the small synchronous prompt upload of the
         # following call -- then returned 50-70 ms late in about every third step (tools/api_stall_probe.py,
         # profiles/r04/api_stall_probe.txt: 17 ms steps with 65-80 ms outliers; the device itself was idle).
-        src, dst = pin.numpy().reshape(-1), ent[1].reshape(-1)
-        n = src.size
-        if n < (1 << 22):
-            np.copyto(dst, src, casting="unsafe")
-        else:
-            parts = 16
-            step = -(-n // parts)
-            list(_widen_pool().map(lambda i: np.copyto(dst[i * step:(i + 1) * step], src[i * step:(i + 1) * step], casting="unsafe"), range(parts)))
+        _widen_into(ent[1], pin.numpy())
         return ent[1]
 
     def predict_inst_batch(self, inference_state, point_coords_batch=None, point_labels_batch=None,

@@ -518,3 +518,29 @@ def test_resize_axis_tables_match_aten(n_in, n_out):
     got = (1.0 - fr) * x.numpy()[:, owner] + fr * x.numpy()[:, nxt]
     assert np.abs(got - ref).max() <= 5e-6      # the blend itself is rounded differently (fused multiply-adds in ATen's vectorised kernel)
     assert lib.esam3_resize_axis_tables(65, 72, first, count, frac) != 0     # more source cells than the kernel's tables hold
+
+
+def test_widen_into_matches_numpy_on_every_split():
+    """the host-side widening of the uint8 masks into the float32 result array (sam3_image._widen_into): serial and worker-thread paths,
+    sizes that do not divide by the number of parts, float32 -> float32 for return_logits"""
+    from efficientsam3_amd.sam3_image import _widen_into
+    rng = np.random.default_rng(0)
+    for shape, parts, below in (((3, 5, 7), 16, 1 << 22), ((2, 1, 257, 129), 16, 1000), ((1, 1, 1000, 1003), 7, 1000), ((5,), 16, 1)):
+        src = rng.integers(0, 2, shape, dtype=np.uint8)
+        dst = np.full(shape, -1.0, np.float32)
+        _widen_into(dst, src, parts=parts, serial_below=below)
+        assert dst.dtype == np.float32 and np.array_equal(dst, src.astype(np.float32))
+        srcf = rng.standard_normal(shape).astype(np.float32)
+        _widen_into(dst, srcf, parts=parts, serial_below=below)
+        assert np.array_equal(dst, srcf)
+
+
+def test_bench_cpulist_parser():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.parse_cpulist("0-3,8-9\n") == {0, 1, 2, 3, 8, 9}
+    assert bench.parse_cpulist("5") == {5} and bench.parse_cpulist("") == set()
+    assert bench.bind_to_gpu_numa_node(0) is None or isinstance(bench.bind_to_gpu_numa_node(0), str)   # no GPU here: unbound, no exception
