@@ -852,7 +852,7 @@ int64_t esam3_t2i_mfma_scratch_floats(int Bp, int Nq, int Nk) {
 }
 int esam3_launch_t2i_mfma(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* o, int Bp, int Nq, int Nk,
                           float* scratch, hipStream_t s) {
-  if (!esam3_t2i_mfma_ok(1, Nq, Nk, 8, 16) || (ldq % 4) || (ldk % 8) || (ldv % 8) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || !scratch) {
+  if (!esam3_t2i_mfma_ok(1, Nq, Nk, 8, 16) || Bp < 1 || Bp > 65535 || (ldq % 4) || (ldk % 8) || (ldv % 8) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || !scratch) {
     esam3_set_error("t2i_mfma: unsupported shape (Nq=%d Nk=%d ldq=%d ldk=%d ldv=%d)", Nq, Nk, ldq, ldk, ldv);
     return -1;
   }
@@ -900,7 +900,7 @@ int esam3_launch_tok_b(float* q32, const float* t32, const void* ta, void* tk, v
 }
 int esam3_launch_tok_d(float* q32, const void* ta, void* hs, const esam3_tok_lin& xo, const float* gf, const float* bf, float eps,
                        const esam3_tok_lin mlp[18], void* hyper, float* iou, void* obj, int Bp, int T, hipStream_t s) {
-  if (!esam3_tok_fused_ok(1, T)) { esam3_set_error("tok_d: T = %d unsupported", T); return -1; }
+  if (!esam3_tok_fused_ok(1, T) || Bp < 1) { esam3_set_error("tok_d: T = %d, Bp = %d unsupported", T, Bp); return -1; }
   TokDParams p;
   p.q32 = q32; p.ta = (const bf16_t*)ta; p.hs = (bf16_t*)hs; p.xo = tl(xo); p.gf = gf; p.bf = bf;
   for (int r = 0; r < 6; ++r)

@@ -2419,7 +2419,7 @@ int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
   void* ik = ikv;
   void* iv = (char*)ikv + (size_t)Bp * P * 128 * esz;
   static const bool no_t2i_mfma = esam3_dev_flag("ESAM3_NO_T2I_MFMA") != 0;  // A/B: separate k / v GEMMs + the VALU attention
-  const bool t2i_mfma = !no_t2i_mfma && esam3_t2i_mfma_ok(dtype, T, (int)P, 8, 16);
+  const bool t2i_mfma = !no_t2i_mfma && Bp <= 65535 && esam3_t2i_mfma_ok(dtype, T, (int)P, 8, 16);   // grid.y = prompt
   float* t2i_scratch = nullptr;  // per-chunk softmax partials of the token -> image attention
   {
     int64_t nf = esam3_attn_scratch_floats(Bp, T, (int)P, 8, 16);
