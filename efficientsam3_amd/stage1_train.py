@@ -268,3 +268,43 @@ def adamw_state_dict(updater: Stage1Updater, names: Sequence[str]) -> dict:
     groups = [dict(common, weight_decay=updater.weight_decay, params=list(range(n_decay))),
               dict(common, weight_decay=0.0, params=list(range(n_decay, len(order))))]
     return {"state": state, "param_groups": groups, "param_names": order}
+
+
+def load_adamw_state_dict(updater: Stage1Updater, names: Sequence[str], sd: dict) -> None:
+    """the inverse of ``adamw_state_dict``: resume the arena's moments and step count from ``torch.optim.AdamW.state_dict()`` of the optimizer
+    ``stage1/optimizer.py: build_optimizer`` builds (what ``save_checkpoint`` stores under "optimizer", stage1/utils.py:86-101).  Parameter i of
+    the state is the i-th name of [has_decay ..., no_decay ...] in ``named_parameters`` order; the groups' lr / betas / eps / weight_decay become
+    the updater's hyper-parameters (the scheduler overrides lr per iteration anyway)."""
+    from .stage1 import weight_decay_groups
+    shapes = dict(updater.layout.named_shapes)
+    decay = weight_decay_groups([(n, shapes[n]) for n in names])
+    order = [n for n in names if decay[n]] + [n for n in names if not decay[n]]
+    groups = sd["param_groups"]
+    flat = [i for g_ in groups for i in g_["params"]]
+    if len(flat) != len(order):
+        raise ValueError(f"optimizer state holds {len(flat)} parameters, the model has {len(order)}")
+    n_decay = sum(1 for n in names if decay[n])
+    if len(groups) >= 2 and len(groups[0]["params"]) != n_decay:
+        raise ValueError(f"first group holds {len(groups[0]['params'])} parameters, {n_decay} take weight decay here")
+    steps = set()
+    for pos, idx in enumerate(flat):
+        st = sd["state"].get(idx)
+        name = order[pos]
+        ea, es = updater.view(updater.exp_avg, name), updater.view(updater.exp_avg_sq, name)
+        if st is None:          # a parameter that never received a gradient
+            ea.zero_()
+            es.zero_()
+            continue
+        if tuple(st["exp_avg"].shape) != tuple(ea.shape):
+            raise ValueError(f"{name}: moment shape {tuple(st['exp_avg'].shape)} != parameter shape {tuple(ea.shape)}")
+        ea.copy_(torch.as_tensor(st["exp_avg"], dtype=torch.float32))
+        es.copy_(torch.as_tensor(st["exp_avg_sq"], dtype=torch.float32))
+        steps.add(int(float(st["step"])))
+    if len(steps) > 1:
+        raise ValueError(f"parameters with different step counts {sorted(steps)}: the arena keeps one")
+    state = updater.state.cpu()
+    state[4] = float(steps.pop()) if steps else 0.0
+    updater.state.copy_(state)
+    g0 = groups[0]
+    updater.lr, updater.betas, updater.eps = float(g0["lr"]), tuple(g0["betas"]), float(g0["eps"])
+    updater.weight_decay = float(g0["weight_decay"])

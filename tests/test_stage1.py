@@ -502,3 +502,45 @@ def test_bn_train_statistics_with_a_large_offset(shape, offset):
     # the input itself is fp32: x - mean carries an absolute error of 2^-24 |x| ~ 6e-5 x (offset / 1e3), times rstd
     tol = 4.0 * offset * 2.0 ** -24 * float(r64.max()) * float(gamma.max()) + 1e-5
     assert float((y.cpu().double() - y64).abs().max()) <= tol
+
+
+def test_adamw_state_round_trips_through_torch_optim():
+    """Resume in both directions (host logic, no device work): the state of a REAL torch.optim.AdamW with the two parameter groups of
+    stage1/optimizer.py:32-46 (has_decay first, then no_decay: 1-D tensors and biases) after three steps -> `load_adamw_state_dict` into the
+    arena -> `adamw_state_dict` back out: moments, step count and groups identical, and torch's own `load_state_dict` accepts the export."""
+    from efficientsam3_amd.stage1 import ArenaLayout, Stage1Updater
+    from efficientsam3_amd.stage1_train import adamw_state_dict, load_adamw_state_dict
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, bias=False), torch.nn.BatchNorm2d(8), torch.nn.Conv2d(8, 5, 1, bias=True), torch.nn.Linear(5, 4))
+    named = list(net.named_parameters())
+    no_decay = lambda n, p: p.ndim == 1 or n.endswith(".bias")  # noqa: E731   (set_weight_decay, stage1/optimizer.py:36-44)
+    groups = [{"params": [p for n, p in named if not no_decay(n, p)]}, {"params": [p for n, p in named if no_decay(n, p)], "weight_decay": 0.0}]
+    opt = torch.optim.AdamW(groups, lr=3e-4, betas=(0.9, 0.95), eps=1e-7, weight_decay=0.05)
+    for step in range(3):
+        for _, p in named:
+            p.grad = torch.randn_like(p) * (step + 1)
+        opt.step()
+    sd = opt.state_dict()
+    names = [n for n, _ in named]
+    up = Stage1Updater(ArenaLayout([(n, p.shape) for n, p in named]), "cpu", amp=False)
+    load_adamw_state_dict(up, names, sd)
+    assert up.lr == 3e-4 and tuple(up.betas) == (0.9, 0.95) and up.eps == 1e-7 and up.weight_decay == 0.05 and int(up.state[4]) == 3
+    out = adamw_state_dict(up, names)
+    order = [n for n, p in named if not no_decay(n, p)] + [n for n, p in named if no_decay(n, p)]
+    assert out["param_names"] == order
+    assert [g_["params"] for g_ in out["param_groups"]] == [g_["params"] for g_ in sd["param_groups"]]
+    assert out["param_groups"][0]["weight_decay"] == 0.05 and out["param_groups"][1]["weight_decay"] == 0.0
+    for i in sd["state"]:
+        assert torch.equal(out["state"][i]["exp_avg"], sd["state"][i]["exp_avg"]) and torch.equal(out["state"][i]["exp_avg_sq"], sd["state"][i]["exp_avg_sq"])
+        assert float(out["state"][i]["step"]) == float(sd["state"][i]["step"]) == 3.0
+    # the padding between parameters stays zero (AdamW leaves zero-gradient elements with zero moments at zero)
+    used = torch.zeros(up.layout.n, dtype=torch.bool)
+    for n in names:
+        s0, num = up.layout.offsets[n]
+        used[s0:s0 + num] = True
+    assert float(up.exp_avg[~used].abs().max()) == 0.0 and float(up.exp_avg_sq[~used].abs().max()) == 0.0
+    opt2 = torch.optim.AdamW(groups, lr=1.0)
+    opt2.load_state_dict({"state": out["state"], "param_groups": [{k: v for k, v in g_.items()} for g_ in out["param_groups"]]})
+    assert opt2.state_dict()["param_groups"][0]["lr"] == 3e-4
+    with pytest.raises(ValueError):
+        load_adamw_state_dict(up, names[:-1], sd)
