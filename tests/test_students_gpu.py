@@ -184,11 +184,16 @@ def test_tinyvit_full_shard_32_is_image_independent(golden_dir):
         assert torch.equal(out["trunk"][i], out["trunk"][i % 4]) and torch.equal(low[i], low[i % 4]) and torch.equal(iou[i], iou[i % 4]), i
     assert torch.isfinite(low).all() and float(low.std()) > 0.1
     lim = U.bf16_worst_case_limits(U.bf16_yardstick(os.path.join(golden_dir, "tinyvit_11m")), os.path.join(golden_dir, "tinyvit_11m"))
-    # the yardstick was taken on the smooth fixture image; two of these four inputs are uniform-noise images, whose masks
-    # are speckle (mask IoU 0.9754 and 0.9639 measured on image 1 by two builds that differ in one bias summation order,
-    # against a floor of 0.9778): 0.95 for the inputs without a fixture
-    lim = (lim[0], lim[1], min(lim[2], 0.95))
+    # The model's yardstick was taken on smooth images; two of these four inputs are uniform-noise images, whose masks are speckle and
+    # move more under ANY change of precision.  tests/golden/tinyvit_11m/shard_yard.json (oracle/gen_golden_shard_yard.py) holds the REAL
+    # reference's own bf16-autocast-vs-fp32 distance on exactly these four (image, prompt) pairs -- mask IoU 0.989 / 0.962 / 0.993 / 0.973 --
+    # and every image is held to 1.5 x ITS OWN distance (never stricter than the model-wide rule needs, never a flat number).
+    with open(os.path.join(golden_dir, "tinyvit_11m", "shard_yard.json")) as f:
+        shard_yard = json.load(f)["images"]
+    model_lim = lim
     for i in range(4):
+        floor_i = 1.0 - (U.BF16_FACTOR * (1.0 - shard_yard[i]["mask_iou"]) + 2e-3)
+        lim = (model_lim[0], model_lim[1], min(model_lim[2], floor_i))
         with torch.inference_mode():
             ost = ref_model.set_image(sd, torch.from_numpy(base[i])[None], (1008, 1008), "11m")
             m_o, iou_o, low_o = ref_model.predict_inst(sd, ost, point_coords=pts[i], point_labels=labels[i], box=boxes[i],
