@@ -2241,7 +2241,9 @@ PackedGemm* E::pk_kv_cat(const std::string& ap) {
     cb.shape = {(int64_t)(kbias->d.size() + vbias->d.size())};
     cb.d = kbias->d;
     cb.d.insert(cb.d.end(), vbias->d.begin(), vbias->d.end());
-    mark_packed(kw); mark_packed(vw); mark_packed(kbias); mark_packed(vbias);   // consumed: the concatenation is what gets packed
+    // the separate projections stay available to the fallback t2i() (T > 16 tokens or Bp > 65535: more than ~10 points per
+    // prompt): pack them now, while the host weights exist -- after esam3_release_host_weights() a cache miss would be fatal
+    if (!pk_linear(ap + "k_proj") || !pk_linear(ap + "v_proj")) return nullptr;
     raw[key + ".weight"] = std::move(cw);
     raw[key + ".bias"] = std::move(cb);
   }

@@ -1385,6 +1385,9 @@ int launch_mb3(Mb3Params p, hipStream_t stream) {
 // shapes the round-4 fused MBConv is instantiated for (bf16): EfficientViT-B1 / B0 widths
 bool esam3_mbconv3_ok(int dtype, int Cin, int Cmid, int Cout, int stride) {
   if (dtype != 1 || Cmid % 64) return false;
+  // the launcher's own limits (esam3_launch_mbconv3): the persistent Cin <= 64 kernels stage per-channel vectors for Cmid <= 256;
+  // the engine falls back to the layer-by-layer path for anything else (e.g. a checkpoint with a larger expand ratio)
+  if (Cin <= 64 && Cmid > 256 && !(stride == 2 && Cin == 64)) return false;
   if (stride == 2)
     return (Cin == 16 && Cout == 32) || (Cin == 32 && Cout == 64) || (Cin == 64 && Cout == 128) || (Cin == 128 && Cout == 256);
   if (stride == 1)

@@ -32,9 +32,10 @@ def init_process_group(backend: Optional[str] = None, device: Optional[torch.dev
         if backend is None:
             backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"
         kw = {"device_id": device} if backend == "nccl" and device is not None else {}
-        if world == 1 and "MASTER_PORT" not in os.environ:
+        if world == 1 and ("MASTER_PORT" not in os.environ or "RANK" not in os.environ):
             # a forced one-rank group needs no rendezvous over TCP: an in-process store (picking a free port by bind-then-close
-            # would leave a window in which another process can take it)
+            # would leave a window in which another process can take it).  Also taken when MASTER_PORT is exported but RANK is
+            # not (a plain `python` run inside a job's environment): env:// would raise "RANK expected, but not set"
             dist.init_process_group(backend, store=dist.HashStore(), rank=0, world_size=1, **kw)
         else:
             dist.init_process_group(backend, **kw)

@@ -13,9 +13,12 @@ Everything that is a tensor lives on the GPU for the whole step:
   re-uploaded, re-packed on the host or synchronised (``train_blocks``: the ``esam3_train_*`` entry points pack on the device);
 * BatchNorm running statistics are device buffers loaded from / exported to the state dict under the reference's names
   (``...norm.running_mean``, ``...running_var``, ``...num_batches_tracked``);
-* every gradient is written into its view of the gradient arena the moment it exists (last layer first) and handed to
-  ``dist.GradientAllReducer.push`` -- the bucketed averaging all-reduce over RCCL that ``DistributedDataParallel`` performs for the
-  reference (``train_image_encoder_stage1.py:67-72``) -- before ``Stage1Updater.step`` un-scales, clips and applies AdamW.
+* every gradient is written into its view of the gradient arena the moment it exists (last layer first).  On an updating
+  micro-step the backward pass's sink hands it to ``dist.GradientAllReducer.push`` right there -- the bucketed averaging
+  all-reduce over RCCL that ``DistributedDataParallel`` performs for the reference (``train_image_encoder_stage1.py:67-72``):
+  a bucket goes on the wire while the layers in front of it are still in their backward pass.  (The very first updating step
+  learns the arrival order -- the bucket order -- and pushes after its backward pass; every later one overlaps.)
+  ``Stage1Updater.step`` then un-scales, clips and applies AdamW.
 
 The module owns no arithmetic: it sequences kernels (``train_blocks``, ``stage1``) and moves views around."""
 from __future__ import annotations
@@ -167,6 +170,8 @@ class Stage1Trainer:
         self.names = [n for n, _ in named_shapes]
         # gradients arrive head first, then the trunk from its last layer to the stem: the bucket order of the all-reduce
         self._arrival = None
+        self._arrival_index = None
+        self._pushed = False
         self._reducer_cls, self._group, self._force = GradientAllReducer, group, force_collective
         self.reducer = None
         self._micro = 0   # micro-steps accumulated since the last update
@@ -178,10 +183,13 @@ class Stage1Trainer:
         feats = self.trunk.forward(images_nchw_f32)
         return self.head.forward(feats)
 
-    def backward(self, d_preds: torch.Tensor) -> None:
-        """fills the gradient arena (accumulating: ``+=`` into the views, as autograd accumulates into ``.grad``)"""
+    def backward(self, d_preds: torch.Tensor, push: bool = False) -> None:
+        """fills the gradient arena (accumulating: ``+=`` into the views, as autograd accumulates into ``.grad``); with ``push`` (an
+        updating micro-step in a multi-rank job, arrival order known) every finished gradient goes to the all-reduce at once"""
         order = []
         first = self._micro == 0   # first micro-step after an update: the arena was zeroed -> plain copies; later ones accumulate
+        push = push and self.reducer is not None and self._arrival_index is not None
+        self._pushed = push
 
         def sink(name, gval):
             dst = self.updater.grad(name)
@@ -190,11 +198,14 @@ class Stage1Trainer:
             else:
                 dst.add_(gval.to(torch.float32))
             order.append(name)
+            if push:
+                self.reducer.push(self._arrival_index[name], dst)
 
         d_feats, _ = self.head.backward(d_preds, sink=sink)
         self.trunk.backward(d_feats, sink=lambda n, gv: sink("backbone.model." + n, gv))
         if self._arrival is None:
             self._arrival = order
+            self._arrival_index = {n: i for i, n in enumerate(order)}
             assert sorted(order) == sorted(self.names), (set(self.names) ^ set(order))
 
     def step(self, images_nchw_f32: torch.Tensor, teacher: torch.Tensor, sizes_before_pad: Sequence[Tuple[int, int]], lr: Optional[float] = None,
@@ -214,7 +225,7 @@ class Stage1Trainer:
         # (loss.item(), torch.cuda.synchronize(): train_image_encoder_stage1.py:206,226)
         scale = float(self.updater.loss_scale) if self.updater.amp else 1.0
         d = distill_loss_backward(p2, t2, valid, cosine_weight=self.cosine_weight, grad_scale=scale / self.accumulation_steps)
-        self.backward(d.reshape(b, s, s, e))
+        self.backward(d.reshape(b, s, s, e), push=update_grad and self._collective())
         for k in self.batches_tracked:
             self.batches_tracked[k] += 1
         out = {"loss": loss, "grad_norm": None}
@@ -226,15 +237,19 @@ class Stage1Trainer:
         self.last = out
         return out
 
-    def _allreduce(self) -> None:
+    def _collective(self) -> bool:
         import torch.distributed as dist
-        if not (dist.is_initialized() and (dist.get_world_size(self._group) > 1 or self._force)):
+        return bool(dist.is_initialized() and (dist.get_world_size(self._group) > 1 or self._force))
+
+    def _allreduce(self) -> None:
+        if not self._collective():
             return
         grads = [self.updater.grad(n) for n in self._arrival]
         if self.reducer is None:
             self.reducer = self._reducer_cls(grads, group=self._group, force_collective=self._force)
-        for i, g_ in enumerate(grads):
-            self.reducer.push(i, g_)
+        if not self._pushed:   # the first updating step (order unknown until its backward pass ended)
+            for i, g_ in enumerate(grads):
+                self.reducer.push(i, g_)
         self.reducer.finish(grads)
 
     # ---- state ----------------------------------------------------------------------------------------------------------------
@@ -265,8 +280,9 @@ def adamw_state_dict(updater: Stage1Updater, names: Sequence[str]) -> dict:
     n_decay = sum(1 for n in names if decay[n])
     common = dict(lr=updater.lr, betas=tuple(updater.betas), eps=updater.eps, amsgrad=False, maximize=False, foreach=None, capturable=False,
                   differentiable=False, fused=None)
-    groups = [dict(common, weight_decay=updater.weight_decay, params=list(range(n_decay))),
-              dict(common, weight_decay=0.0, params=list(range(n_decay, len(order))))]
+    # lr_scale: the key divide_param_groups_by_lr_scale adds to every group (stage1/utils.py:557-620; 1.0 without layer decay)
+    groups = [dict(common, weight_decay=updater.weight_decay, lr_scale=1.0, params=list(range(n_decay))),
+              dict(common, weight_decay=0.0, lr_scale=1.0, params=list(range(n_decay, len(order))))]
     return {"state": state, "param_groups": groups, "param_names": order}
 
 

@@ -592,3 +592,26 @@ def test_video_grounding_matches_reference_trace():
                     else:
                         assert m["shape"] == d["shape"] and m["dtype"] == d["dtype"], (k, m, d)
                         assert abs(m["sum"] - d["sum"]) <= 1e-9 * max(1.0, d["abs_sum"]) and abs(m["abs_sum"] - d["abs_sum"]) <= 1e-9 * max(1.0, d["abs_sum"]), (k, m, d)
+
+
+def _forced_group_without_rank_worker(q):
+    # a plain `python` run inside a job's environment: MASTER_PORT exported, RANK / WORLD_SIZE not
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR"):
+        os.environ.pop(k, None)
+    os.environ["MASTER_PORT"] = "29999"
+    try:
+        esdist.init_process_group("gloo", torch.device("cpu"), force=True)
+        q.put(bool(dist.is_initialized() and dist.get_world_size() == 1))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_forced_one_rank_group_with_master_port_but_no_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_group_without_rank_worker, args=(q,))
+    p.start()
+    assert q.get(timeout=120) is True
+    p.join(timeout=60)
+    assert p.exitcode == 0
