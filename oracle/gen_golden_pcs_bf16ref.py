@@ -13,7 +13,10 @@ distance between the two runs is recorded per output of `forward_grounding`.  Tw
 `--draws N` adds N further seeded images (seeds 2 ..): the yardstick of a test is then the worst distance over the fixture image and
 the draws, not one sample of it (a single draw is a noisy estimate of the reference's own bf16 distance).
 
-Output: tests/golden/pcs_<model>/bf16ref_manifest.json (+ bf16ref_draws.json)
+`--geo N` measures the same distance for the two GEOMETRIC-prompt cases of oracle/gen_golden_pcs.py on image seeds 1..N and writes only
+bf16ref_geo.json (round 5: the geometric cases used to borrow 2 x the text cases' figure).
+
+Output: tests/golden/pcs_<model>/bf16ref_manifest.json (+ bf16ref_draws.json, bf16ref_geo.json)
 """
 from __future__ import annotations
 
@@ -42,6 +45,7 @@ def main():
     ap.add_argument("--model", default="ev_m", choices=["ev_m", "vit_h"])
     ap.add_argument("--draws", type=int, default=0)
     ap.add_argument("--draws-only", action="store_true", help="leave bf16ref_manifest.json as it is")
+    ap.add_argument("--geo", type=int, default=0, help="N images (seeds 1..N) of the geometric-prompt cases -> bf16ref_geo.json, nothing else")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 8)
@@ -92,6 +96,36 @@ def main():
         return res
 
     t0 = time.time()
+    if args.geo:
+        # the two geometric-prompt cases of oracle/gen_golden_pcs.py (add_geometric_prompt / add_point_prompt,
+        # sam3_image_processor.py:130-190) in fp32 and under bf16 autocast: image seed 1 (the fixture image) first, then --geo - 1 draws
+        def run_geo(amp: bool, chw):
+            ctx = torch.autocast("cpu", dtype=torch.bfloat16) if amp else torch.autocast("cpu", enabled=False)
+            res = {}
+            with torch.inference_mode(), ctx:
+                state = proc.set_image(chw)
+                proc.reset_all_prompts(state)
+                state = proc.set_text_prompt("dog", state)
+                state = proc.add_geometric_prompt([0.45, 0.5, 0.3, 0.4], True, state)
+                res["geo_text_box"] = {k: captured["out"][k].float().clone() for k in KEYS}
+                proc.reset_all_prompts(state)
+                state = proc.add_point_prompt([300.0, 420.0], 1, state)
+                state = proc.add_geometric_prompt([0.6, 0.4, 0.2, 0.25], False, state)
+                state = proc.add_point_prompt([700.5, 200.0], 0, state)
+                state = proc.add_geometric_prompt([0.25, 0.7, 0.45, 0.5], True, state)
+                res["geo_visual_mixed"] = {k: captured["out"][k].float().clone() for k in KEYS}
+            return res
+        geo = {"model": f"pcs_{args.model}", "seeds": list(range(1, 1 + args.geo)), "cases": {"geo_text_box": [], "geo_visual_mixed": []}}
+        for seed in geo["seeds"]:
+            a32, a16 = run_geo(False, image(seed)), run_geo(True, image(seed))
+            for name in geo["cases"]:
+                e = {k: float((a32[name][k] - a16[name][k]).abs().max()) for k in KEYS}
+                e["seed"] = seed
+                geo["cases"][name].append(e)
+                print("geo", seed, name, e, f"[{time.time() - t0:.0f}s]", flush=True)
+            with open(os.path.join(gold, "bf16ref_geo.json"), "w") as f:
+                json.dump(geo, f, indent=1, sort_keys=True)
+        return
     if args.draws:
         draws = {"model": f"pcs_{args.model}", "seeds": list(range(2, 2 + args.draws)), "cases": {t: [] for t in PROMPTS}}
         for seed in draws["seeds"]:

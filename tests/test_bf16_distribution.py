@@ -1,0 +1,134 @@
+"""The bf16 engine against the reference's own bf16 behaviour as a DISTRIBUTION test ("What's weak" 1 / "Next" 2b).
+
+tests/golden[/<model>]/bf16ref_manifest.json + bf16ref_draws.json hold, per prompt case, how far the REAL reference under
+torch.autocast(bfloat16) is from its own fp32 run on the fixture image and on further seeded images (oracle/gen_golden_bf16ref.py,
+oracle/gen_golden_bf16ref_draws.py).  Here the ENGINE's bf16 mode runs on the SAME images and prompts; its distance to the fp32
+outputs (the pinned oracle, run live on the host) is taken on every image, and per case and quantity
+
+    median(engine) <= 1.25 x median(reference)      and      max(engine) <= 1.5 x max(reference)
+
+(tests/util.py: distribution_verdict).  The single-image tests (test_e2e_gpu.py, test_students_gpu.py) keep bounding their one
+sample by 1.5 x the reference's worst draw -- the "max" half of this rule; the median half lives here.  Images on which the
+reference's own bf16 run picked another mask candidate are left out of the REFERENCE's samples only; the engine is excused on a
+prompt only where the fp32 oracle itself says the choice is a tie (tests/util.py: live_case_errors).
+
+CPU part: the rule's bookkeeping on the committed fixtures, and `live_case_errors` on the oracle against itself."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from efficientsam3_amd import schema, synth
+from tests import util as U
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# (backbone, model, oracle model name, golden dir, draws used): every draw for the headline model, three for the other students
+# (their decoder is shared; the oracle's fp32 run of every image is host time on the GPU box), two for the ViT-H teacher
+MODELS = [("efficientvit", "b1", "b1", GOLD, None), ("efficientvit", "b0", "b0", os.path.join(GOLD, "efficientvit_b0"), 3),
+          ("efficientvit", "b2", "b2", os.path.join(GOLD, "efficientvit_b2"), 3),
+          ("repvit", "m0.9", "m0.9", os.path.join(GOLD, "repvit_m0.9"), 3), ("repvit", "m1.1", "m1.1", os.path.join(GOLD, "repvit_m1.1"), 3),
+          ("repvit", "m2.3", "m2.3", os.path.join(GOLD, "repvit_m2.3"), 3), ("tinyvit", "5m", "5m", os.path.join(GOLD, "tinyvit_5m"), 3),
+          ("tinyvit", "11m", "11m", os.path.join(GOLD, "tinyvit_11m"), 3), ("tinyvit", "21m", "21m", os.path.join(GOLD, "tinyvit_21m"), 3),
+          ("sam3", "vit_h", "vit_h", os.path.join(GOLD, "sam3_vit_h"), 2)]
+
+
+def _cases(gdir):
+    """prompt cases that have reference draws, with the kwargs / original size of the golden manifest (the EV-M manifest holds all)"""
+    with open(os.path.join(GOLD, "manifest.json")) as f:
+        man = json.load(f)["cases"]
+    yard = U.bf16_yardstick(gdir)
+    draws = U.bf16_draws(gdir)
+    names = [n for n in yard["cases"] if draws is not None and n in draws["cases"] and n in man and man[n].get("image") is None]
+    return {n: man[n] for n in names}
+
+
+def test_reference_samples_bookkeeping():
+    """fixture image first, flips of the reference's own bf16 run dropped, seeds aligned with the samples"""
+    r = U.reference_draw_samples(GOLD, "two_boxes_batched")
+    assert len(r) == 7 and r[0] is not None and sum(x is None for x in r) == 2          # draws 2 and 5 are selection flips
+    assert U.draw_image_seeds(GOLD) == [1, 101, 102, 103, 104, 105, 106] and U.draw_image_seeds(GOLD, 2) == [1, 101, 102]
+    assert len(U.reference_draw_samples(os.path.join(GOLD, "tinyvit_11m"), "point_multimask", 3)) == 4
+    ok, _ = U.distribution_verdict([1.0, 1.2, 1.1], [1.0, 1.0, 1.0, None])
+    assert ok
+    ok, text = U.distribution_verdict([1.0, 1.6, 1.1], [1.0, 1.0, 1.0])          # one sample past 1.5 x the reference's worst
+    assert not ok and "max" in text
+    ok, _ = U.distribution_verdict([1.3, 1.3, 1.3], [1.0, 1.0, 1.0])            # systematically 30 % worse: the median rule
+    assert not ok
+    for _, _, _, gdir, _ in MODELS:
+        assert _cases(gdir), gdir
+
+
+def test_live_case_errors_of_the_oracle_against_itself():
+    """zero distance, and a deliberately swapped candidate is accepted only where the oracle calls the prompt a tie"""
+    from oracle import ref_model
+    sd = schema.synthetic_state_dict("efficientvit", "b0", seed=0)
+    x = torch.from_numpy(synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=1)))[None]
+    with torch.inference_mode():
+        ost = ref_model.set_image(sd, x, (1008, 1008), "b0")
+    cases = _cases(os.path.join(GOLD, "efficientvit_b0"))
+    for name, case in cases.items():
+        kw = U.case_kwargs(case)
+        hw = tuple(case["hw"])
+        st = dict(ost)
+        st["original_height"], st["original_width"] = hw
+        taps = {}
+        with torch.inference_mode():
+            out = ref_model.predict_inst(sd, st, taps=taps, **kw)
+        e_low, e_iou, miou, took = U.live_case_errors(sd, "b0", ost, out, kw, hw)
+        assert e_low == 0.0 and e_iou == 0.0 and miou == 1.0 and not took, (name, e_low, e_iou, miou, took)
+        if not kw.get("multimask_output", True):
+            # hand the checker candidate 2 of prompt 0 instead of the selected one: a huge distance unless candidate 2 is a
+            # plausible tie outcome for this prompt (it is not, on these fixtures)
+            masks, iou, low = (a.copy() for a in out)
+            lowb = low if low.ndim == 4 else low[None]
+            lowb[0, 0] = torch.clamp(taps["all_masks"][0, 2], -32.0, 32.0).numpy()
+            e_low, _, _, took = U.live_case_errors(sd, "b0", ost, (masks, iou, lowb if low.ndim == 4 else lowb[0]), kw, hw)
+            assert e_low > 1.0 and not took, (name, e_low, took)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bt,mn,oname,gdir,n_draws", MODELS, ids=[f"{m[0]}-{m[1]}" for m in MODELS])
+def test_bf16_engine_distribution_vs_reference_draws(bt, mn, oname, gdir, n_draws):
+    from efficientsam3_amd import Sam3Processor, build_efficientsam3_image_model, build_sam3_image_model
+    from oracle import ref_model
+    sd = schema.synthetic_state_dict(bt, mn, seed=0)
+    if bt == "sam3":
+        model = build_sam3_image_model(device="cuda", enable_inst_interactivity=True, dtype="bf16", state_dict=sd)
+    else:
+        model = build_efficientsam3_image_model(device="cuda", enable_inst_interactivity=True, backbone_type=bt, model_name=mn,
+                                                dtype="bf16", state_dict=sd)
+    proc = Sam3Processor(model)
+    cases = _cases(gdir)
+    seeds = U.draw_image_seeds(gdir, n_draws)
+    eng = {n: dict(low_res=[], iou=[], mask=[]) for n in cases}
+    peaks = {n: 0.0 for n in cases}
+    ties = []
+    for seed in seeds:
+        img = synth.smooth_image_u8(seed=seed)
+        state = proc.set_image(torch.from_numpy(np.ascontiguousarray(np.moveaxis(img, -1, 0))))
+        with torch.inference_mode():
+            ost = ref_model.set_image(sd, torch.from_numpy(synth.normalise_to_chw_f32(img))[None], (1008, 1008), oname)
+        for name, case in cases.items():
+            kw, hw = U.case_kwargs(case), tuple(case["hw"])
+            state["original_height"], state["original_width"] = hw
+            out = model.predict_inst(state, **kw)
+            e_low, e_iou, miou, took = U.live_case_errors(sd, oname, ost, out, kw, hw)
+            eng[name]["low_res"].append(e_low); eng[name]["iou"].append(e_iou); eng[name]["mask"].append(1.0 - miou)
+            peaks[name] = max(peaks[name], float(np.abs(out[1]).max()))
+            if took:
+                ties.append((seed, name, took))
+    failures = []
+    for name in cases:
+        ref = U.reference_draw_samples(gdir, name, n_draws)
+        assert len(ref) == len(seeds)
+        for q, rq, extra in (("low_res", "low_res", 0.0), ("iou", "iou", U.bf16_half_ulp(peaks[name])), ("mask", "mask_iou", 2e-3)):
+            r = [None if s is None else (1.0 - s[rq] if q == "mask" else s[rq]) for s in ref]
+            ok, text = U.distribution_verdict(eng[name][q], r, extra)
+            print(f"[dist {bt}-{mn}] {name:30s} {q:8s} {'ok  ' if ok else 'FAIL'} {text}")
+            if not ok:
+                failures.append((name, q, text))
+    if ties:
+        print(f"[dist {bt}-{mn}] prompts that took another plausible candidate of the fp32 oracle (seed, case, {{prompt: candidate}}): {ties}")
+    assert not failures, failures

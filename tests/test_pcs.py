@@ -16,11 +16,10 @@ from tests.util import pcs_bf16_yard
 SAMPLE = 8192
 BF16_FACTOR = 1.5  # engine-bf16 error allowed as a multiple of the reference's own bf16 error (tests/util.py)
 # Since the detector's 200-query decoder stream is kept in fp32 (as the reference's autocast keeps it), the fixture cases
-# (same image and prompts as the yardstick run) are inside the 1.5 x rule on every output: class logits 0.010-0.011
-# against 0.013 for the reference's own bf16 run, boxes 0.014-0.017 / 0.012-0.014, mask logits 0.50-0.55 / 0.93-1.06.
-# The config-4 batch-8 test compares four OTHER image / prompt pairs with a yardstick that was measured on one image:
-# its limit is 2 x that figure (measured 0.011-0.017 / 0.010 on the class logits, 0.016-0.019 / 0.015 on the boxes).
-PCS_OTHER_INPUTS_FACTOR = 2.0
+# (same image and prompts as the yardstick run) are inside the 1.5 x rule on every output.  Round 5: NO flat factor on inputs the
+# yardstick was not measured on remains -- the geometric-prompt cases have their own reference-bf16 runs (bf16ref_geo.json,
+# oracle/gen_golden_pcs_bf16ref.py --geo), the config-4 batch-8 test runs on the yardstick's own (image, prompt) pairs, and both are
+# held to the DISTRIBUTION rule of tests/util.py (median <= 1.25 x the reference's median, max <= 1.5 x its max, same images).
 PRESENCE_BF16_ULP = 2.0 ** -6  # the presence logit is ONE number per image (about -2): one bf16 ulp at that magnitude
 
 
@@ -176,13 +175,16 @@ def test_pcs_engine_geometric_prompts_vs_golden(pcs_gold, pcs_sd, mode):
     proc = Sam3Processor(model, confidence_threshold=man["confidence_threshold"])
     img = synth.smooth_image_u8(seed=1)
     state = proc.set_image(torch.from_numpy(np.ascontiguousarray(np.moveaxis(img, -1, 0))))
-    # bf16: the geometric cases have no reference-bf16 run of their own: 2 x the model's yardstick on the text cases (same image)
-    yard = pcs_bf16_yard("pcs_ev_m")
-    ymax = {k: max(c[k] for c in yard.values()) for k in ("pred_logits", "pred_boxes", "presence_logit_dec", "pred_masks")}
-    lim = dict(f32=dict(logits=1e-4, boxes=1e-4, presence=1e-4, masks=2e-3),
-               bf16=dict(logits=PCS_OTHER_INPUTS_FACTOR * ymax["pred_logits"], boxes=PCS_OTHER_INPUTS_FACTOR * ymax["pred_boxes"],
-                         presence=PCS_OTHER_INPUTS_FACTOR * ymax["presence_logit_dec"] + PRESENCE_BF16_ULP,
-                         masks=PCS_OTHER_INPUTS_FACTOR * ymax["pred_masks"]))[mode]
+    # bf16, fixture image: 1.5 x the worst of the reference's own bf16 runs of THESE cases (bf16ref_geo.json: seven images) -- the
+    # "max" half of the distribution rule on one sample; test_pcs_bf16_distribution_vs_reference_draws holds both halves
+    with open(os.path.join(os.path.dirname(__file__), "golden", "pcs_ev_m", "bf16ref_geo.json")) as f:
+        geo_yard = json.load(f)["cases"]
+    gmax = lambda name, k: max(d[k] for d in geo_yard[name])  # noqa: E731
+    lims = {name: dict(logits=BF16_FACTOR * gmax(name, "pred_logits"), boxes=BF16_FACTOR * gmax(name, "pred_boxes"),
+                       presence=BF16_FACTOR * gmax(name, "presence_logit_dec") + PRESENCE_BF16_ULP,
+                       masks=BF16_FACTOR * gmax(name, "pred_masks")) for name in man["geometric_cases"]}
+    if mode == "f32":
+        lims = {name: dict(logits=1e-4, boxes=1e-4, presence=1e-4, masks=2e-3) for name in man["geometric_cases"]}
     fpn = state["backbone_out"]["_esam3_nhwc_sam3"]
     for name in man["geometric_cases"]:
         lf = torch.from_numpy(g[f"{name}_language_features"]).to("cuda")
@@ -192,7 +194,8 @@ def test_pcs_engine_geometric_prompts_vs_golden(pcs_gold, pcs_sd, mode):
                  boxes=float(np.abs(out["pred_boxes"].cpu().numpy() - g[f"{name}_pred_boxes"]).max()),
                  presence=float(np.abs(out["presence_logit_dec"].cpu().numpy() - g[f"{name}_presence_logit_dec"]).max()),
                  masks=float(np.abs(_sample(out["pred_masks"]) - g[f"{name}_pred_masks_sample"]).max()))
-        print(f"[pcs geo {mode}] {name}: {e}")
+        lim = lims[name]
+        print(f"[pcs geo {mode}] {name}: err {e} allowed {lim}")
         for k, v in e.items():
             assert v <= lim[k], (name, k, v, lim[k])
     # a padded batch: image 0 = the mixed case, image 1 = the same prompt with one extra (masked) entry of junk
@@ -206,6 +209,7 @@ def test_pcs_engine_geometric_prompts_vs_golden(pcs_gold, pcs_sd, mode):
         pad[k] = torch.cat([pad[k], torch.ones((2, 1), dtype=torch.bool)], 1)
     fpn2 = [torch.cat([t, t], 0).contiguous() for t in fpn]
     name = "geo_visual_mixed"
+    lim = lims[name]
     lf = torch.from_numpy(g[f"{name}_language_features"]).to("cuda").expand(-1, 2, -1)
     lm = torch.from_numpy(g[f"{name}_language_mask"]).to("cuda").expand(2, -1)
     out2 = model.engine.ground(fpn2, lf, lm, geo=pad)
@@ -230,61 +234,141 @@ def test_pcs_engine_geometric_prompts_vs_golden(pcs_gold, pcs_sd, mode):
         assert abs(state["scores"].numel() - n_ref) <= max(4, n_ref // 10)
 
 
+# token ids of the yardstick's prompts (oracle/gen_golden_pcs_bf16ref.py: PROMPTS) as the reference's tokenizer produces them at context
+# length 16 (tokenizer_ve.py:128-253; the BPE merge table is a reference asset that does not travel to the GPU box; tests/test_text_encoder.py
+# pins the tokenizer itself): <start_of_text> ... <end_of_text>, zero padding
+YARD_TOKENS = {"dog": [49406, 1929, 49407], "traffic light": [49406, 3399, 1395, 49407]}
+PCS_OUT = ("pred_logits", "pred_boxes", "presence_logit_dec", "pred_masks")
+
+
+def _pcs_verdicts(tag, eng, ref, failures):
+    """eng / ref: {case: {key: [distance per image]}} on the same images -> the distribution rule per case and output"""
+    from tests.util import distribution_verdict
+    for case in eng:
+        for k in PCS_OUT:
+            ok, text = distribution_verdict(eng[case][k], ref[case][k], PRESENCE_BF16_ULP if k == "presence_logit_dec" else 0.0)
+            print(f"[dist {tag}] {case:18s} {k:20s} {'ok  ' if ok else 'FAIL'} {text}")
+            if not ok:
+                failures.append((tag, case, k, text))
+
+
 @pytest.mark.gpu
-def test_config4_batch_8_is_image_independent():
-    """BASELINE config 4 at its full size (ViT-H + MobileCLIP-S0-16 + detector, batch 8): four distinct (image, text)
-    pairs tiled twice.  Both copies must give bit-identical logits, boxes, presence and mask logits, and the four
-    distinct results must match the ORACLE (oracle/ref_model.py ViT-H + text student, oracle/ref_pcs.py detector) run
-    on CPU per pair: f32 within the f32 limits of test_pcs_engine_vs_golden, bf16 within the reference's own bf16
-    yardstick for this model (tests/golden/pcs_vit_h/bf16ref_manifest.json) under the same rule as the EV-M test."""
+def test_pcs_bf16_distribution_vs_reference_draws(pcs_gold, pcs_sd):
+    """EV-M detector, bf16 engine, on the images the reference's own bf16 runs were taken on (fixture image seed 1 + seeds 2..7): the
+    two text prompts (bf16ref_manifest.json + bf16ref_draws.json) and the two geometric-prompt cases (bf16ref_geo.json), every output
+    against the fp32 oracle run live; median <= 1.25 x the reference's median and max <= 1.5 x its max per case and output (every
+    element of the 200 x 288 x 288 mask logits, as the reference's figures are)."""
+    from efficientsam3_amd import Sam3Processor, build_efficientsam3_image_model
+    from oracle import ref_model, ref_pcs
+    man, g = pcs_gold
+    gdir = os.path.join(os.path.dirname(__file__), "golden", "pcs_ev_m")
+    with open(os.path.join(gdir, "bf16ref_manifest.json")) as f:
+        fix = json.load(f)["cases"]
+    with open(os.path.join(gdir, "bf16ref_draws.json")) as f:
+        draws = json.load(f)
+    with open(os.path.join(gdir, "bf16ref_geo.json")) as f:
+        geo_yard = json.load(f)
+    seeds = [1] + list(draws["seeds"])
+    assert geo_yard["seeds"] == seeds, (geo_yard["seeds"], seeds)
+    texts = man["prompts"]
+    ref = {t: {k: [fix[t][k]] + [d[k] for d in draws["cases"][t]] for k in PCS_OUT} for t in texts}
+    ref.update({n: {k: [d[k] for d in geo_yard["cases"][n]] for k in PCS_OUT} for n in man["geometric_cases"]})
+    model = build_efficientsam3_image_model(device="cuda", enable_inst_interactivity=False, backbone_type="efficientvit",
+                                            model_name="b1", dtype="bf16", state_dict=pcs_sd, text_encoder_type="MobileCLIP-S0",
+                                            text_encoder_context_length=16)
+    proc = Sam3Processor(model, confidence_threshold=man["confidence_threshold"])
+    runs = [(t, f"{pi}", None) for pi, t in enumerate(texts)] + [(n, n, n) for n in man["geometric_cases"]]
+    eng = {c: {k: [] for k in PCS_OUT} for c, _, _ in runs}
+    for seed in seeds:
+        img = synth.smooth_image_u8(seed=seed)
+        state = proc.set_image(torch.from_numpy(np.ascontiguousarray(np.moveaxis(img, -1, 0))))
+        fpn = state["backbone_out"]["_esam3_nhwc_sam3"]
+        with torch.inference_mode():
+            bo = ref_model.set_image(pcs_sd, torch.from_numpy(synth.normalise_to_chw_f32(img))[None], (1008, 1008), "b1")["backbone_out"]
+        for case, key, geo_name in runs:
+            lf, lm = torch.from_numpy(g[f"{key}_language_features"]), torch.from_numpy(g[f"{key}_language_mask"])
+            geo = _geo_case(g, geo_name) if geo_name else None
+            out = model.engine.ground(fpn, lf.to("cuda"), lm.to("cuda"), geo=geo)
+            with torch.inference_mode():
+                o = ref_pcs.forward_grounding(pcs_sd, bo["backbone_fpn"], bo["vision_pos_enc"][-1], lf, lm, None, geo)
+            for k in PCS_OUT:
+                eng[case][k].append(float((out[k].float().cpu() - o[k].float()).abs().max()))
+    failures = []
+    _pcs_verdicts("pcs ev_m bf16", eng, ref, failures)
+    assert not failures, failures
+
+
+@pytest.mark.gpu
+def test_config4_batch_8_on_the_yardstick_pairs():
+    """BASELINE config 4 at its full size (ViT-H + MobileCLIP-S0-16 + detector, batch 8): the eight (image, text) pairs are the ones the
+    reference's own bf16 runs of this model were taken on (tests/golden/pcs_vit_h/bf16ref_draws.json: image seeds 2..5 x the prompts
+    "dog" / "traffic light"), so the bf16 engine is held to the DISTRIBUTION rule on exactly the yardstick's inputs (median <= 1.25 x,
+    max <= 1.5 x the reference's, per prompt and output; no flat factor).  The engine runs its own text encoder on the prompts' token
+    ids.  f32: every pair within the f32 limits of test_pcs_engine_vs_golden against the ORACLE (oracle/ref_model.py ViT-H + text
+    student, oracle/ref_pcs.py detector) run on the host.  Image independence: the two batch entries that share an image have
+    bit-identical features, entries that share a prompt bit-identical text memory, and a batch of two of the pairs reproduces their
+    batch-8 results bit for bit."""
     from efficientsam3_amd import build_sam3_image_model
     from oracle import ref_model, ref_pcs
     sd = schema.synthetic_state_dict("sam3", "vit_h", seed=0, enable_inst_interactivity=False)
     sd.update(schema.synthetic_text_state_dict("MobileCLIP-S0", 16, seed=0))
     sd.update(schema.synthetic_pcs_state_dict(seed=0))
-    base = [synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=1)), synth.normalise_to_chw_f32(synth.noise_image_u8(seed=2)),
-            synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=3)), synth.normalise_to_chw_f32(synth.noise_image_u8(seed=4))]
-    rng = np.random.default_rng(5)
+    with open(os.path.join(os.path.dirname(__file__), "golden", "pcs_vit_h", "bf16ref_draws.json")) as f:
+        draws = json.load(f)
+    seeds, texts = list(draws["seeds"]), list(YARD_TOKENS)
+    assert len(seeds) == 4 and set(draws["cases"]) == set(texts)
+    base = [synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=s_)) for s_ in seeds]
+    pairs = [(i, t) for i in range(4) for t in texts]                    # batch entry 2 i + j = (image i, prompt j)
     tok = np.zeros((8, 16), dtype=np.int64)
-    for i in range(4):
-        n = int(rng.integers(1, 5))
-        tok[i, 0], tok[i, 1:1 + n], tok[i, 1 + n] = 49406, rng.integers(300, 40000, size=n), 49407
-    tok[4:] = tok[:4]
-    keys = ("pred_logits", "pred_boxes", "presence_logit_dec", "pred_masks")
+    for e, (_, t) in enumerate(pairs):
+        tok[e, :len(YARD_TOKENS[t])] = YARD_TOKENS[t]
     oracle = []
     with torch.inference_mode():
-        for i in range(4):
-            fo = ref_model.forward_image(sd, torch.from_numpy(base[i])[None], "vit_h")
-            mask, mem, _ = ref_model.text_encoder_student(sd, torch.from_numpy(tok[i:i + 1]))
-            o = ref_pcs.forward_grounding(sd, fo["backbone_fpn"], fo["vision_pos_enc"][-1], mem, mask)
-            oracle.append({k: o[k].float().numpy() for k in keys})
-    with open(os.path.join(os.path.dirname(__file__), "golden", "pcs_vit_h", "bf16ref_manifest.json")) as f:
-        yard = json.load(f)["cases"]
-    y = {k: max(c[k] for c in yard.values()) for k in keys}
-    lims = dict(f32=dict(pred_logits=1e-4, pred_boxes=1e-4, presence_logit_dec=1e-4, pred_masks=4e-3),
-                bf16=dict(pred_logits=PCS_OTHER_INPUTS_FACTOR * y["pred_logits"], pred_boxes=PCS_OTHER_INPUTS_FACTOR * y["pred_boxes"],
-                          presence_logit_dec=PCS_OTHER_INPUTS_FACTOR * y["presence_logit_dec"] + PRESENCE_BF16_ULP,
-                          pred_masks=PCS_OTHER_INPUTS_FACTOR * y["pred_masks"]))
+        feats = [ref_model.forward_image(sd, torch.from_numpy(base[i])[None], "vit_h") for i in range(4)]
+        txt = {t: ref_model.text_encoder_student(sd, torch.from_numpy(tok[j:j + 1])) for j, t in enumerate(texts)}
+        for i, t in pairs:
+            mask, mem, _ = txt[t]
+            o = ref_pcs.forward_grounding(sd, feats[i]["backbone_fpn"], feats[i]["vision_pos_enc"][-1], mem, mask)
+            oracle.append({k: o[k].float().numpy() for k in PCS_OUT})
+    ref = {t: {k: [d[k] for d in draws["cases"][t]] for k in PCS_OUT} for t in texts}
+    f32_lim = dict(pred_logits=1e-4, pred_boxes=1e-4, presence_logit_dec=1e-4, pred_masks=4e-3)
+    failures = []
     for mode in ("bf16", "f32"):
         model = build_sam3_image_model(device="cuda", enable_inst_interactivity=False, dtype=mode, state_dict=sd,
                                        text_encoder_type="MobileCLIP-S0", text_encoder_context_length=16)
         eng = model.engine
-        x = torch.from_numpy(np.stack([base[i % 4] for i in range(8)])).to("cuda")
+        x = torch.from_numpy(np.stack([base[i] for i, _ in pairs])).to("cuda")
         tok_d = torch.from_numpy(tok).to("cuda")
         out = eng.encode(x, want_sam3=True, want_sam2=False)
         mem, _ = eng.encode_text(tok_d)
-        g = eng.ground(out["sam3_fpn"], mem, tok_d == 0)
-        for k in keys:
-            assert torch.equal(g[k][:4], g[k][4:]), (mode, k)
-            assert torch.isfinite(g[k]).all(), (mode, k)
-        assert g["pred_masks"].shape == (8, 200, 288, 288) and float(g["pred_boxes"].min()) >= 0.0 and float(g["pred_boxes"].max()) <= 1.0
-        for i in range(4):
-            e = {k: float(np.abs(g[k][i].float().cpu().numpy() - oracle[i][k][0]).max()) for k in keys}
-            print(f"[cfg4 {mode}] pair {i} vs oracle: err {e} allowed {lims[mode]}")
-            for k in keys:
-                assert e[k] <= lims[mode][k], (mode, i, k, e[k], lims[mode][k])
-        del model, eng, out, g, x
+        gr = eng.ground(out["sam3_fpn"], mem, tok_d == 0)
+        for lvl in out["sam3_fpn"]:
+            for i in range(4):
+                assert torch.equal(lvl[2 * i], lvl[2 * i + 1]), (mode, i)
+        for j in range(2):
+            for i in range(1, 4):
+                assert torch.equal(mem[:, j], mem[:, 2 * i + j]), (mode, i, j)
+        sub = [1, 6]
+        gr2 = eng.ground([lvl[sub].contiguous() for lvl in out["sam3_fpn"]], mem[:, sub].contiguous(), (tok_d == 0)[sub].contiguous())
+        for k in PCS_OUT:
+            assert torch.isfinite(gr[k]).all(), (mode, k)
+            assert torch.equal(gr2[k], gr[k][sub]), (mode, k)
+        assert gr["pred_masks"].shape == (8, 200, 288, 288) and float(gr["pred_boxes"].min()) >= 0.0 and float(gr["pred_boxes"].max()) <= 1.0
+        err = {t: {k: [] for k in PCS_OUT} for t in texts}
+        for e, (i, t) in enumerate(pairs):
+            for k in PCS_OUT:
+                err[t][k].append(float(np.abs(gr[k][e].float().cpu().numpy() - oracle[e][k][0]).max()))
+        if mode == "f32":
+            for t in texts:
+                for k in PCS_OUT:
+                    print(f"[cfg4 f32] {t:14s} {k:20s} worst of 4 images {max(err[t][k]):.3g} (allowed {f32_lim[k]:.3g})")
+                    if max(err[t][k]) > f32_lim[k]:
+                        failures.append(("f32", t, k, max(err[t][k])))
+        else:
+            _pcs_verdicts("cfg4 vit_h bf16", err, ref, failures)
+        del model, eng, out, gr, gr2, x
         torch.cuda.empty_cache()
+    assert not failures, failures
 
 
 # ---- SURVEY.md 8(f).4: the video path's multi-GPU entry around the REAL detector ---------------------------------------------

@@ -105,6 +105,8 @@ def test_student_predict_inst_vs_golden(student, mode):
             per_prompt = " per prompt " + ", ".join(f"{_iou(masks[i], rb[i]):.4f} (fg {int(rb[i].sum())})" for i in range(masks.shape[0]))
         print(f"[{student['bt']} {mode}] {name}: low_res err {e_low:.3e} (allowed {lim[0]:.3e}) iou err {e_iou:.3e} ({lim[1]:.3e}) "
               f"mask IoU {miou:.6f} (floor {lim[2]:.6f})" + per_prompt)
+        if mode == "bf16":
+            U.report_if_beyond_single_draw(f"[{student['bt']} bf16]", yard, name, e_low, e_iou, miou, float(np.abs(g["iou"]).max()))
         for what, v, ok in (("low_res", e_low, e_low <= lim_low), ("iou", e_iou, e_iou <= lim[1]),
                             ("mask_iou", miou, miou >= lim[2])):
             if not ok:

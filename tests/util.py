@@ -164,6 +164,24 @@ def bf16_case_limits(yard, name, gdir=None, score_peak=1.0):
     return tuple(lim)
 
 
+def bf16_single_draw_limits(yard, name, score_peak=1.0):
+    """the same three limits from the fixture image's draw ALONE (the round-2/3 rule).  Not asserted any more -- a single draw of
+    the reference is a noisy yardstick -- but every single-image test reports when its sample is inside the worst-of-draws cap
+    (`bf16_case_limits`) and outside this one, so a result that leans on the wider cap is visible in the log; whether the engine's
+    DISTRIBUTION matches the reference's is decided by tests/test_bf16_distribution.py."""
+    c = yard["cases"][name]
+    return (BF16_FACTOR * c["low_res"], BF16_FACTOR * c["iou"] + bf16_half_ulp(score_peak), 1.0 - (BF16_FACTOR * (1.0 - c["mask_iou"]) + 2e-3))
+
+
+def report_if_beyond_single_draw(tag, yard, name, e_low, e_iou, miou, score_peak=1.0):
+    s = bf16_single_draw_limits(yard, name, score_peak)
+    over = [f"{q} {v:.4g} > {l:.4g}" if q != "mask_iou" else f"{q} {v:.5f} < {l:.5f}"
+            for q, v, l, bad in (("low_res", e_low, s[0], e_low > s[0]), ("iou", e_iou, s[1], e_iou > s[1]), ("mask_iou", miou, s[2], miou < s[2])) if bad]
+    if over:
+        print(f"{tag} {name}: inside 1.5 x the reference's WORST draw but outside 1.5 x its fixture-image draw: " + "; ".join(over))
+    return over
+
+
 def bf16_worst_case_limits(yard, gdir=None):
     """limits for inputs that have no fixture of their own: the loosest case of the model's yardstick (all draws, `gdir` given)"""
     lims = [bf16_case_limits(yard, n, gdir) for n in yard["cases"]]
@@ -258,3 +276,105 @@ def pcs_bf16_yard(model_dir: str) -> dict:
                 for k in PCS_KEYS:
                     yard[name][k] = max(yard[name][k], float(d[k]))
     return yard
+
+
+# ---- the bf16 yardstick as a DISTRIBUTION test (round 5; VERDICT round 4 "What's weak" 1) ------------------------------------
+# `bf16_case_limits` above bounds ONE engine sample by the worst of the reference's draws: that is the "max" half of a
+# distribution test applied to a single sample, and a maximum over N draws only grows with N.  The rule that decides is this
+# one: the ENGINE is run on the same images the reference's draws were taken on (fixture image + the seeded images of
+# bf16ref_draws.json), its distance to the fp32 outputs (the pinned oracle, run live) is measured on every one of them, and
+#     median(engine) <= MEDIAN_FACTOR x median(reference)   and   max(engine) <= MAX_FACTOR x max(reference)
+# must hold per prompt case and per quantity.  A faithful bf16 implementation has the reference's distribution; a kernel that
+# is systematically worse moves the median, and a rare large error moves the maximum.
+DIST_MEDIAN_FACTOR = 1.25
+DIST_MAX_FACTOR = 1.5
+TIE_STAB, TIE_IOU, STAB_THRESH = 5e-3, 1e-2, 0.98     # oracle/gen_golden_ties.py
+
+
+def reference_draw_samples(gdir, name, n_draws=None):
+    """the reference's own bf16-vs-fp32 distances of prompt case `name`, one entry per image: index 0 = the fixture image
+    (bf16ref_manifest.json), then the images of bf16ref_draws.json in order (the first `n_draws` of them).  An image on which
+    the reference's OWN bf16 run selected another mask candidate (distance > FLIP_FACTOR x the fixture's) is None."""
+    yard, draws = bf16_yardstick(gdir), bf16_draws(gdir)
+    c = yard["cases"][name]
+    out = [dict(low_res=c["low_res"], iou=c["iou"], mask_iou=c["mask_iou"])]
+    if draws is not None and name in draws["cases"]:
+        d = draws["cases"][name]
+        n = len(d["low_res"]) if n_draws is None else min(n_draws, len(d["low_res"]))
+        for i in range(n):
+            flip = d["low_res"][i] > FLIP_FACTOR * c["low_res"]
+            out.append(None if flip else dict(low_res=d["low_res"][i], iou=d["iou"][i], mask_iou=d["mask_iou"][i]))
+    return out
+
+
+def draw_image_seeds(gdir, n_draws=None):
+    """seeds of synth.smooth_image_u8 for `reference_draw_samples`' entries: the fixture image (seed 1) first"""
+    draws = bf16_draws(gdir)
+    seeds = list(draws["image_seeds"]) if draws is not None else []
+    return [1] + (seeds if n_draws is None else seeds[:n_draws])
+
+
+def distribution_verdict(engine, reference, extra=0.0):
+    """engine / reference: lists of non-negative distances (None entries dropped).  Returns (ok, text)."""
+    e = np.asarray([v for v in engine if v is not None], dtype=np.float64)
+    r = np.asarray([v for v in reference if v is not None], dtype=np.float64)
+    med_ok = float(np.median(e)) <= DIST_MEDIAN_FACTOR * float(np.median(r)) + extra
+    max_ok = float(e.max()) <= DIST_MAX_FACTOR * float(r.max()) + extra
+    text = (f"median {np.median(e):.4g} vs {np.median(r):.4g} (x{np.median(e) / max(np.median(r), 1e-30):.2f}, allowed x{DIST_MEDIAN_FACTOR}"
+            f"{'' if not extra else f' + {extra:.2g}'}) max {e.max():.4g} vs {r.max():.4g} (x{e.max() / max(r.max(), 1e-30):.2f}, allowed x{DIST_MAX_FACTOR}) "
+            f"n {e.size}/{r.size}")
+    return med_ok and max_ok, text
+
+
+def live_case_errors(sd, model_name, oracle_state, engine_out, kw, hw):
+    """(low-res max-abs-err, IoU-head max-abs-err, thresholded-mask IoU, {prompt: candidate taken}) of one engine result against the
+    fp32 ORACLE run live on the same state -- with the stability-tie rule of oracle/gen_golden_ties.py evaluated live: for a
+    single-mask prompt whose fp32 stability score of mask 0 is within TIE_STAB of the 0.98 threshold, or whose fallback argmax is
+    decided by predicted IoUs less than TIE_IOU apart (mask_decoder.py:256-290), the engine's output may match any of those
+    plausible candidates of the oracle, and is compared with the candidate it is closest to."""
+    import torch
+    from oracle import ref_model
+    masks, iou, low = engine_out
+    taps = {}
+    st = dict(oracle_state)
+    st["original_height"], st["original_width"] = hw
+    with torch.inference_mode():
+        m_o, iou_o, low_o = ref_model.predict_inst(sd, st, taps=taps, **kw)
+    assert masks.shape == m_o.shape and low.shape == low_o.shape and iou.shape == iou_o.shape, (masks.shape, m_o.shape)
+    batched = low.ndim == 4
+    lo_e, lo_o = (low if batched else low[None]), (low_o if batched else low_o[None]).copy()
+    io_e, io_o = (iou if batched else iou[None]), (iou_o if batched else iou_o[None]).copy()
+    mk_o = (m_o if batched else m_o[None]).copy()
+    bp = lo_e.shape[0]
+    e_low = np.abs(lo_e - lo_o).reshape(bp, -1).max(axis=1)
+    e_iou = np.abs(io_e - io_o).reshape(bp, -1).max(axis=1)
+    took = {}
+    if not kw.get("multimask_output", True):
+        all_m, all_i = taps["all_masks"].float(), taps["all_iou"].float().numpy()
+        for i in range(bp):
+            flat = all_m[i, 0].flatten()
+            au = float((flat > -0.05).sum())
+            stab = float((flat > 0.05).sum()) / au if au > 0 else 1.0
+            best = 1 + int(np.argmax(all_i[i, 1:]))
+            chosen = 0 if stab >= STAB_THRESH else best
+            near = abs(stab - STAB_THRESH) < TIE_STAB
+            plausible = set()
+            if stab >= STAB_THRESH or near:
+                plausible.add(0)
+            if stab < STAB_THRESH or near:
+                plausible.update(k for k in range(1, 4) if all_i[i, k] >= all_i[i, 1:].max() - TIE_IOU)
+            plausible.discard(chosen)
+            for k in sorted(plausible):
+                cand = torch.clamp(all_m[i, k], -32.0, 32.0).numpy()
+                a_low = float(np.abs(lo_e[i, 0] - cand).max())
+                if a_low < e_low[i]:
+                    e_low[i], e_iou[i] = a_low, float(np.abs(io_e[i].reshape(-1)[0] - all_i[i, k]))
+                    took[i] = k
+                    with torch.inference_mode():
+                        full = ref_model.postprocess_masks(all_m[i:i + 1, k:k + 1].clone(), tuple(hw))
+                    mk_o[i] = full[0].numpy() if kw.get("return_logits") else (full[0] > 0).float().numpy()
+    mk_e = masks if batched else masks[None]
+    a, b = mk_e > 0, mk_o > 0
+    u = np.logical_or(a, b).sum()
+    miou = 1.0 if u == 0 else float(np.logical_and(a, b).sum() / u)
+    return float(e_low.max()), float(e_iou.max()), miou, took
