@@ -343,12 +343,16 @@ def main():
             gbs = dom["algorithmic_bytes"] / (avg_ms * 1e-3) / 1e9
             mfma_bound = dom["algorithmic_flops"] / (PEAK_BF16_TFLOPS * 1e12) >= dom["algorithmic_bytes"] / (PEAK_HBM_GBS * 1e9)
             traffic = None
+            traffic_source = None   # `traffic` is NOT measured in this run: PMC counters need rocprofv3 around the process
             pmc_path = os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")
             if os.path.exists(pmc_path):
                 try:  # the committed PMC pass covers the headline config's dominant launch (its tag is recorded in the file)
                     pmc = json.load(open(pmc_path))
                     if dom["tag"] == pmc.get("tag") and B == BATCH and not text:
                         traffic = pmc.get("hbm_bytes_per_launch")
+                        traffic_source = (f"committed rocprofv3 --pmc pass profiles/pmc_dominant_kernel.json (round {pmc.get('round')}, "
+                                          f"{pmc.get('command', 'tools/gpu_profile_round.sh')}): FETCH_SIZE x 2 + WRITE_SIZE per launch of this "
+                                          "kernel and shape, not a counter read in this run")
                 except Exception:
                     traffic = None
             if mfma_bound:
@@ -367,6 +371,7 @@ def main():
                         roof["frac_of_peak_at_that_clock"] = round(tflops / dvd["dense_bf16_peak_at_that_clock_tflops"], 4)
                 except Exception:
                     pass
+            roof["traffic_source"] = traffic_source
             roof.update(kernel=dom.get("kernel", dom["tag"]), tag=dom["tag"], launches_per_step=dom["launches"] // args.steps,
                         timed_launches=dom["launches"],
                         avg_launch_ms=round(avg_ms, 4), algorithmic_flops_per_launch=dom["algorithmic_flops"],

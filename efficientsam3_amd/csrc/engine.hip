@@ -2092,33 +2092,47 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
     return ds32 ? lin(g, A, lda, R, xs, DM, ACT_NONE, xs, DM, 0, 1) : lin(g, A, lda, R, x, DM, ACT_NONE, x, DM);
   };
   if (ds32 && !dry) CK(esam3_launch_cast_to_f32(dtype, x, xs, R * DM, st));
+  // Round 5: two more rounding points of the query stream removed in the bf16 engine (tests/test_pcs.py's distribution test showed
+  // the boxes' median distance to fp32 at 1.32 - 1.36 x the reference's own bf16 run while logits and masks sat at 0.8 x): the
+  // conditional position is kept in fp32 and added to the fp32 stream BEFORE the one rounding to the GEMM input (the reference adds
+  // `tgt + query_pos` in fp32 under autocast; x + qpos on the bf16 view rounded twice), and the box delta of bbox_embed's last
+  // layer is read in fp32 by the refinement (six accumulated logit-space deltas per box).
+  float* qpos32 = ds32 ? (float*)allocb(sizeof(float) * (size_t)R * DM) : nullptr;
+  float* dl32 = ds32 ? (float*)allocb(sizeof(float) * (size_t)R * 8) : nullptr;
+  if (ds32 && (!ok(qpos32) || !ok(dl32))) return -1;
+  auto add_pos = [&]() -> int {  // xp = stream + query_pos, in the GEMM input type
+    if (!ds32) return addk(x, qpos, xp, R * DM);
+    return dry ? 0 : esam3_launch_add_f32_to_bf16(xs, qpos32, xp, R * DM, st);
+  };
   for (int i = 0; i < 6; ++i) {
     const std::string p = t + "layers." + std::to_string(i) + ".";
     // conditional query position: MLP(sine(reference box)); zero for the presence token
     if (!dry) CK(esam3_launch_box_sine(dtype, ref, sine, R, QR, st));
     CK(lin(pk_linear(t + "ref_point_head.layers.0"), sine, 2 * DM, R, da, DM, ACT_RELU));
-    CK(lin(pk_linear(t + "ref_point_head.layers.1"), da, DM, R, qpos, DM, ACT_NONE));
+    if (ds32) CK(lin(pk_linear(t + "ref_point_head.layers.1"), da, DM, R, qpos32, DM, ACT_NONE, nullptr, 0, 0, 1));
+    else CK(lin(pk_linear(t + "ref_point_head.layers.1"), da, DM, R, qpos, DM, ACT_NONE));
     if (!dry) {
-      CK(esam3_launch_bcast_rows(dtype, fbufs["pcs_zero_row"], 1, qpos, QR, 0, B, DM, st));
+      if (ds32) CK(esam3_launch_bcast_rows(0, fbufs["pcs_zero_row"], 1, qpos32, QR, 0, B, DM, st));
+      else CK(esam3_launch_bcast_rows(dtype, fbufs["pcs_zero_row"], 1, qpos, QR, 0, B, DM, st));
       CK(prof_launch("pcs_rpb", 0.0, 0.0, [&]() { return esam3_launch_rpb_mlp(ref, rpbx, rpby, by, bx, R, QR, EMB, EMB, HEADS, st); }));
     }
     // self-attention among presence + queries: q = k = x + pos, v = x
     const std::string sa = p + "self_attn.", ct = p + "ca_text.", ci = p + "cross_attn.";
-    CK(addk(x, qpos, xp, R * DM));
+    CK(add_pos());
     CK(lin(L(sa + "in_proj_weight", sa + "in_proj_bias", 0, 2 * DM, sa + "#qk"), xp, DM, R, dq, 3 * DM, ACT_NONE));
     CK(lin(L(sa + "in_proj_weight", sa + "in_proj_bias", 2 * DM, DM, sa + "#v"), x, DM, R, (char*)dq + 2 * DM * esz, 3 * DM, ACT_NONE));
     CK(attn(dq, 3 * DM, 0, dq, 3 * DM, DM, 2 * DM, da, QR, QR, nullptr));
     CK(linres(pk_linear(sa + "out_proj"), da, DM));
     CK(LNs(p + "norm2"));
     // cross-attention to the prompt tokens
-    CK(addk(x, qpos, xp, R * DM));
+    CK(add_pos());
     CK(lin(L(ct + "in_proj_weight", ct + "in_proj_bias", 0, DM, ct + "#q"), xp, DM, R, dq, DM, ACT_NONE));
     CK(lin(L(ct + "in_proj_weight", ct + "in_proj_bias", DM, 2 * DM, ct + "#kv"), prompt, DM, B * Sp, pkv, 2 * DM, ACT_NONE));
     CK(attn(dq, DM, 0, pkv, 2 * DM, 0, DM, da, QR, Sp, pmask));
     CK(linres(pk_linear(ct + "out_proj"), da, DM));
     CK(LNs(p + "catext_norm"));
     // cross-attention to the image memory with the box-relative position bias (none for the presence token)
-    CK(addk(x, qpos, xp, R * DM));
+    CK(add_pos());
     CK(lin(L(ci + "in_proj_weight", ci + "in_proj_bias", 0, DM, ci + "#q"), xp, DM, R, dq, DM, ACT_NONE));
     CK(lin(L(ci + "in_proj_weight", ci + "in_proj_bias", DM, DM, ci + "#k"), mem, DM, B * P, mkv, 2 * DM, ACT_NONE, tbufs[ci + "#posk"], DM, (int)P));
     CK(lin(L(ci + "in_proj_weight", ci + "in_proj_bias", 2 * DM, DM, ci + "#v"), mem, DM, B * P, (char*)mkv + DM * esz, 2 * DM, ACT_NONE));
@@ -2132,8 +2146,13 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
     CK(LNout(t + "norm", hs));
     CK(lin(pk_linear(t + "bbox_embed.layers.0"), hs, DM, R, da, DM, ACT_RELU));
     CK(lin(pk_linear(t + "bbox_embed.layers.1"), da, DM, R, dq, DM, ACT_RELU));
-    CK(lin(pk_linear(t + "bbox_embed.layers.2"), dq, DM, R, da, 8, ACT_NONE));
-    if (!dry) CK(esam3_launch_box_refine(dtype, da, 8, ref, R, st));
+    if (ds32) {
+      CK(lin(pk_linear(t + "bbox_embed.layers.2"), dq, DM, R, dl32, 8, ACT_NONE, nullptr, 0, 0, 1));
+      if (!dry) CK(esam3_launch_box_refine(0, dl32, 8, ref, R, st));
+    } else {
+      CK(lin(pk_linear(t + "bbox_embed.layers.2"), dq, DM, R, da, 8, ACT_NONE));
+      if (!dry) CK(esam3_launch_box_refine(dtype, da, 8, ref, R, st));
+    }
   }
   // presence logit of the last layer: MLP(LN(presence token)) (row 0 of every image)
   {

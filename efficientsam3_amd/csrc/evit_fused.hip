@@ -45,17 +45,37 @@ __device__ __forceinline__ f32x2_v hsw2(f32x2_v x) {
   t = __builtin_elementwise_min(__builtin_elementwise_max(t, (f32x2_v)(0.f)), (f32x2_v)(1.f));
   return x * t;
 }
-template <int N> __device__ __forceinline__ void hsw_n(float (&v)[N]) {
+// Round 5: the clamp as the VOP3P clamp modifier of the packed fma (result clamped to [0, 1]): v_pk_fma_f32 ... clamp + v_pk_mul_f32 =
+// ONE VALU instruction per element instead of two (hipcc has no pattern that folds a clamp into a packed f32 op: it emits a
+// v_max_f32 ... clamp per element after the v_pk_fma_f32).  The fused MBConv kernels are VALU-issue bound (457 VALU instructions
+// per tile and wave in mbconv3s<2,16,32>, 96 of them these clamps: profiles/r05/isa_mbconv3s.txt).  An inline-assembly reader of an
+// MFMA result gets no hazard padding from the compiler (cdna_hip_programming.md 5.7), so the asm form is only used BEHIND a
+// compiler-generated VALU reader of the same accumulator: `guard` is a value that reader produced, named as an (unused) input, so
+// the statement cannot be scheduled above it; once that reader has issued (with the compiler's wait states), the accumulator
+// is readable by everybody.
+__device__ __forceinline__ f32x2_v hsw2_after(f32x2_v x, float guard) {
+#ifdef ESAM3_HSW_C   // A/B builds (tools/dev_variants.sh): the round-4 C form
+  return hsw2(x);
+#endif
+  f32x2_v t;
+  const f32x2_v k6 = {1.f / 6.f, 1.f / 6.f}, k05 = {0.5f, 0.5f};
+  asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(t) : "v"(x), "v"(k6), "v"(k05), "v"(guard));
+  return x * t;
+}
+template <int N> __device__ __forceinline__ void hsw_n(float (&v)[N]) {   // v: the registers of ONE accumulator
   static_assert(N % 2 == 0, "pairs");
+  const f32x2_v r0 = hsw2(f32x2_v{v[0], v[1]});   // the compiler's reader of the accumulator (hazard padding)
 #pragma unroll
-  for (int i = 0; i < N; i += 2) {
-    const f32x2_v r = hsw2(f32x2_v{v[i], v[i + 1]});
+  for (int i = 2; i < N; i += 2) {
+    const f32x2_v r = hsw2_after(f32x2_v{v[i], v[i + 1]}, r0.x);
     v[i] = r.x;
     v[i + 1] = r.y;
   }
+  v[0] = r0.x;
+  v[1] = r0.y;
 }
 __device__ __forceinline__ uint2 hsw_pack4(const f32x4& a) {   // 4 accumulators -> Hardswish -> 4 bf16
-  const f32x2_v lo = hsw2(f32x2_v{a[0], a[1]}), hi = hsw2(f32x2_v{a[2], a[3]});
+  const f32x2_v lo = hsw2(f32x2_v{a[0], a[1]}), hi = hsw2_after(f32x2_v{a[2], a[3]}, lo.x);
   return make_uint2(pack_bf16x2(lo.x, lo.y), pack_bf16x2(hi.x, hi.y));
 }
 
@@ -821,6 +841,166 @@ __global__ __launch_bounds__(NW * 64, 2) void mla2_kernel(Mla2Params p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// mla2d (round 5): pass 2 rebuilt around what its counters showed (profiles/r04/pmc_c_summary.txt: 84 % of the wave cycles parked at
+// s_waitcnt, 0.16 TB/s -- a chain of L2 round trips, two per 64-channel chunk: the kv operands in front of the attention MFMAs and
+// the projection's weight fragments in front of the projection MFMAs; the weight fragments were 16-byte pieces of 32 different
+// rows per instruction, i.e. a quarter of every cache line fetched, through a 32 KB L1 that a chunk's 64 - 128 KB of lines
+// thrashes).  Same arithmetic, same token / chunk order, same rounding points as mla2_kernel (bit-identical results); what changed:
+//   * the chunk's projection weights [C rows][64 att channels] go global -> LDS by LDS-DMA (whole 128-byte rows, the GEMM swizzle
+//     applied to the source address), double-buffered: chunk c+1's are requested right after chunk c's barrier and land under its
+//     projection phase and the next attention phase -- no phase starts by waiting for a load it has just issued;
+//   * the kv / ksum operands of chunk c+1 and the q fragments of chunk c+2 are requested into registers at the top of chunk c;
+//   * 8 waves for both widths (a wave = one 16-token block x the chunk's 4 groups in the attention phase, one 32-token tile x half of
+//     the output channel tiles in the projection), ONE barrier per chunk.
+// LDS: att 2 x 16 KB + weights 2 x 16 / 32 KB = 64 / 96 KB.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512, C == 128 ? 2 : 1) void mla2d_kernel(Mla2Params p) {
+  typedef bf16_t T;
+  constexpr int HEADS = C / 16, G = 2 * HEADS, NCH = (2 * C) / 64, NT = C / 32;
+  constexpr int NW = 8, CW = NW / 4, NTW = NT / CW;
+  constexpr int WB = C * 128;   // bytes of one chunk's weights in LDS
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* atl = smem;               // [2][128 tokens][128 B] GEMM swizzle
+  char* wpl = smem + 2 * 16384;   // [2][C rows][128 B] GEMM swizzle
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, g = lane >> 5, l15 = lane & 15, kg = lane >> 4;
+  const unsigned bid = xcd_contig(blockIdx.x, gridDim.x);
+  const unsigned tpi = (unsigned)(p.tiles_x * p.tiles_y);
+  const unsigned b = bid / tpi;
+  const unsigned ti = bid - b * tpi;
+  const int oy0 = (int)(ti / (unsigned)p.tiles_x) * 8, ox0 = (int)(ti % (unsigned)p.tiles_x) * 16;
+  const T* __restrict__ gq = reinterpret_cast<const T*>(p.qms);
+  const T* __restrict__ gt = reinterpret_cast<const T*>(p.tab);
+  const T* __restrict__ gw = reinterpret_cast<const T*>(p.wp);
+  const T* __restrict__ gx = reinterpret_cast<const T*>(p.x);
+  T* __restrict__ go = reinterpret_cast<T*>(p.out);
+
+  // ---- weights of chunk ch -> wpl[buf]: C x 128 B = C / 8 DMA pieces, wave w issues pieces w, w + 8, ...; LDS slot s of row r holds
+  //      the row's logical slot s ^ ((r >> 1) & 7) = (group kc of the chunk, half) = 8 columns of Wproj at gnat(kc) * 16 + half * 8
+  const uint32_t wp_lds = lds_addr(wpl);
+  auto dma_w = [&](int ch, int buf) {
+#pragma unroll
+    for (int j = 0; j < WB / 8192; ++j) {
+      const int piece = wave + 8 * j;
+      const int byte = piece * 1024 + lane * 16;
+      const int row = byte >> 7, ls = ((byte & 127) >> 4) ^ ((row >> 1) & 7);
+      const int kc = ls >> 1;
+      const int gnat = (kc >> 1) * HEADS + 2 * ch + (kc & 1);
+      const uint32_t voff = (uint32_t)((row * p.Kpp + gnat * 16 + (ls & 1) * 8) * 2);
+      dma_piece(gw, voff, wp_lds + (uint32_t)(buf * WB + piece * 1024));
+    }
+  };
+  // kv hi / lo, ksum hi / lo operands of the chunk's 4 groups (this lane's 8 bytes of each 512-byte operand block)
+  auto load_tab = [&](int ch, s16x4 (&t)[4][4]) {
+#pragma unroll
+    for (int gl = 0; gl < 4; ++gl) {
+      const int gnat = (gl >> 1) * HEADS + 2 * ch + (gl & 1);
+      const T* tb = gt + ((int64_t)b * G + gnat) * 1024 + lane * 4;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) t[gl][o] = *reinterpret_cast<const s16x4*>(tb + 256 * o);
+    }
+  };
+  // relu(q) of token block `wave`, the chunk's 4 groups (pass 1's layout: [chunk][group][tile row][16 px][16 ch])
+  auto load_q = [&](int ch, s16x4 (&q)[4]) {
+#pragma unroll
+    for (int gl = 0; gl < 4; ++gl)
+      q[gl] = *reinterpret_cast<const s16x4*>(gq + (((int64_t)b * tpi + ti) * NCH + ch) * 8192 + ((gl * 8 + wave) * 16 + l15) * 16 + 4 * kg);
+  };
+
+  f32x16_v accp[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accp[t][r] = 0.f;
+  const int ppt = wave & 3, pnt0 = wave >> 2;
+
+  dma_w(0, 0);
+  s16x4 qf[3][4], tabf[2][4][4];
+  load_q(0, qf[0]);
+  if (NCH > 1) load_q(1, qf[1]);
+  load_tab(0, tabf[0]);
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    char* at = atl + (ch & 1) * 16384;
+    // this wave's DMA pieces of W(ch) (issued one chunk ago) have landed; the barrier below publishes everybody's
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ch + 1 < NCH) load_tab(ch + 1, tabf[(ch + 1) & 1]);
+    if (ch + 2 < NCH) load_q(ch + 2, qf[(ch + 2) % 3]);
+    // ---- A: att[token block = wave][4 groups x 16 channels] -> LDS ----
+#pragma unroll
+    for (int gl = 0; gl < 4; ++gl) {
+      const s16x4 q = qf[ch % 3][gl];
+      const s16x4(&t)[4] = tabf[ch & 1][gl];
+      f32x4 num = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(t[0], q, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      num = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(t[1], q, num, 0, 0, 0);
+      f32x4 den = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(t[2], q, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      den = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(t[3], q, den, 0, 0, 0);
+      float a[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = num[i] / (den[i] + 1e-15f);
+      const int row = wave * 16 + l15;
+      *reinterpret_cast<uint2*>(at + row * 128 + swz(row, gl * 2 + (kg >> 1)) + (kg & 1) * 8) =
+          make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]));
+    }
+    __syncthreads();   // att(ch) and W(ch) complete; everybody is past P(ch - 1): the other weight / att buffers are free
+    if (ch + 1 < NCH) dma_w(ch + 1, (ch + 1) & 1);
+    // ---- P: acc += Wproj[:, chunk] . att ----
+    {
+      const char* wb = wpl + (ch & 1) * WB;
+      const int prow = ppt * 32 + l31;
+      u32x4 fd[4];
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) fd[kc] = *reinterpret_cast<const u32x4*>(at + prow * 128 + swz(prow, kc * 2 + g));
+#pragma unroll
+      for (int t = 0; t < NTW; ++t) {
+        const int wr = (pnt0 + t * CW) * 32 + l31;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+          const u32x4 fw2 = *reinterpret_cast<const u32x4*>(wb + wr * 128 + swz(wr, kc * 2 + g));
+          MmaOps<T>::mma(fw2, fd[kc], accp[t]);
+        }
+      }
+    }
+  }
+  // ---- out = acc + b + x ----
+  {
+    const int op = ppt * 32 + l31;
+    const int oy = oy0 + (op >> 4), ox = ox0 + (op & 15);
+    const bool ok = oy < p.H && ox < p.W;
+    const int64_t row = ((int64_t)b * p.H + oy) * p.W + ox;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int nt = pnt0 + t * CW;
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bp + nt * 32 + 8 * q + 4 * g);
+        v[4 * q + 0] = accp[t][4 * q + 0] + bb.x; v[4 * q + 1] = accp[t][4 * q + 1] + bb.y;
+        v[4 * q + 2] = accp[t][4 * q + 2] + bb.z; v[4 * q + 3] = accp[t][4 * q + 3] + bb.w;
+        if (ok) {
+          const uint2 u = *reinterpret_cast<const uint2*>(gx + row * C + nt * 32 + 8 * q + 4 * g);
+          v[4 * q + 0] += __uint_as_float(u.x << 16); v[4 * q + 1] += __uint_as_float(u.x & 0xffff0000u);
+          v[4 * q + 2] += __uint_as_float(u.y << 16); v[4 * q + 3] += __uint_as_float(u.y & 0xffff0000u);
+        }
+      }
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
+        const uint32_t c0_ = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]), c1_ = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
+        auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0_, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
+        if (ok) {
+          const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+          *reinterpret_cast<u32x4*>(go + row * C + nt * 32 + 16 * qp + 8 * g) = o;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // mbconv3s: the same three phases for Cin <= 64 (the six high-resolution MBConvs), rebuilt around what the phase ablation of
 // mbconv3 showed (profiles/r04/evit_fused_bench_b.txt: every phase's cost ADDS UP -- the workgroup is a chain of memory / LDS
 // latencies, not a throughput problem):
@@ -991,9 +1171,15 @@ __global__ __launch_bounds__(256, 2) void mbconv3s_kernel(Mb3Params p) {
           auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
           o[qp] = u32x4{s0[0], s1[0], s0[1], s1[1]};  // channels ejt*32 + 16qp + 8g .. +8 of halo pixel hp
         }
-        // lanes whose pixel index has bit 1 set write the qp = 1 piece first: the 8 lanes of a ds_write_b128 group then hit
-        // 4 distinct 16-byte bank slots instead of 2 (pixel pitch 192 B = 64 mod 128, pieces 32 B apart)
+        // S = 1: lanes whose pixel index has bit 1 set write the qp = 1 piece first: the 8 lanes of a ds_write_b128 group then hit
+        // 4 distinct 16-byte bank slots instead of 2 (pixel pitch 192 B = 64 mod 128, pieces 32 B apart).  S = 2 (pitch 160 B =
+        // 32 mod 128): consecutive pixels already land on 4 distinct slots, and the swap made it WORSE (lanes 0, 3, 4, 7 on one slot:
+        // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.60, profiles/r04/pmc_c_summary.txt) -- no swap, and 8 selects fewer per unit
+#ifdef ESAM3_HSW_C
         const bool flip = (l31 >> 1) & 1;
+#else
+        const bool flip = S == 1 && ((l31 >> 1) & 1);
+#endif
         const u32x4 w0 = flip ? o[1] : o[0], w1v = flip ? o[0] : o[1];
         char* rowp = mid + hp * PITCH + ((ejt * 4 + g) << 4);
         *reinterpret_cast<u32x4*>(rowp + (flip ? 32 : 0)) = w0;
@@ -1471,8 +1657,19 @@ int esam3_launch_mla_fused(const void* x, void* out, const void* wqkv, int Kpq, 
   Mla2Params q{};
   q.qms = qms; q.tab = tab; q.wp = wproj; q.bp = bproj; q.x = x; q.out = out;
   q.B = B; q.H = H; q.W = W; q.Kpp = Kpp; q.tiles_x = a.tiles_x; q.tiles_y = a.tiles_y;
-  if (C == 128) hipLaunchKernelGGL((mla2_kernel<128, 4>), dim3((unsigned)(B * tiles)), dim3(256), 0, stream, q);
-  else hipLaunchKernelGGL((mla2_kernel<256, 8>), dim3((unsigned)(B * tiles)), dim3(512), 0, stream, q);
+  if (esam3_dev_flag("ESAM3_MLA2_OLD")) {   // A/B (dev builds): the round-4 kernel, bit-identical output
+    if (C == 128) hipLaunchKernelGGL((mla2_kernel<128, 4>), dim3((unsigned)(B * tiles)), dim3(256), 0, stream, q);
+    else hipLaunchKernelGGL((mla2_kernel<256, 8>), dim3((unsigned)(B * tiles)), dim3(512), 0, stream, q);
+  } else {
+    const size_t lds2 = (size_t)2 * 16384 + (size_t)2 * C * 128;
+    if (C == 128) {
+      if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(mla2d_kernel<128>), (int)lds2)) return -1;
+      hipLaunchKernelGGL((mla2d_kernel<128>), dim3((unsigned)(B * tiles)), dim3(512), lds2, stream, q);
+    } else {
+      if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(mla2d_kernel<256>), (int)lds2)) return -1;
+      hipLaunchKernelGGL((mla2d_kernel<256>), dim3((unsigned)(B * tiles)), dim3(512), lds2, stream, q);
+    }
+  }
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

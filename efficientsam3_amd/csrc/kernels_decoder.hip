@@ -782,6 +782,163 @@ __global__ void cc_apply_kernel(const float* __restrict__ in, float* __restrict_
   out[gi] = v;
 }
 
+// ------------------------------------------------------------------------------------
+// Tiled hole filling (round 5; SURVEY.md 2.2 asked for labelling per tile in LDS with a seam merge; the reference's own GPU
+// algorithm is the block-local + merge scheme of perflib/triton/connected_components.py:203-394; plan checked against scipy by
+// tools/cc_tiled_prototype.py).  The grid-wide union-find above spends its time on the ONE huge background component of a
+// mask: every walk and every count atomically converges on its root in L2 (cc_merge + cc_count = 0.28 ms of a 1 ms decode).
+// Here a workgroup owns one full-width STRIP of TH rows (TH x W <= 9216 pixels: 288 x 32) and does the same union-find on LDS
+// words; strips only meet at horizontal seams:
+//   cc_tile : labels = first pixel of the horizontal run (wave-local), unions with W (at 64-lane seams) / N / NW / NE inside the
+//             strip, flatten, per-root areas (run-length aggregated LDS atomics, saturating) -> labels[pixel] = mask-local index
+//             of the strip-local root, areas[pixel] = local area at roots, 0 elsewhere;
+//   cc_seam : the first row of every strip but the first: the same N / NW / NE rule across the seam, as unions of strip-local
+//             roots in global memory -- a few hundred components per mask instead of 83 k pixels;
+//   cc_sum  : every strip-local root that is no longer a global root adds its area to its global root's (saturating);
+//   cc_apply_tiled : pixel -> strip root -> global root (read-only walk) -> fill when the merged area <= max_area.
+// Integer work, order-independent results (areas are sums; only `area <= max_area` is consumed): bit-exact against scipy.
+// ------------------------------------------------------------------------------------
+constexpr int CC_TPX = 9216;   // pixels per strip: two int arrays in LDS = 72 KB, two workgroups per CU
+
+__device__ inline int uf_find_ro(const int* lab, int x) {   // no compression: chains are pixel -> strip root -> a few hooks
+  while (true) {
+    const int p = __hip_atomic_load(lab + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (p == x) return x;
+    x = p;
+  }
+}
+
+__global__ __launch_bounds__(1024) void cc_tile_kernel(const float* __restrict__ in, int* __restrict__ labels, int* __restrict__ areas,
+                                                        int W, int H, int TH, int strips, float thr, int sat) {
+  extern __shared__ int cc_lds[];
+  int* lab = cc_lds;             // [CC_TPX] parent pointers (strip-local pixel index), -1 = foreground
+  int* area = cc_lds + CC_TPX;   // [CC_TPX]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int n = blockIdx.x / strips, st = blockIdx.x - n * strips;
+  const int y0 = st * TH, rows = min(TH, H - y0), npx = rows * W;
+  const int64_t base = (int64_t)n * H * W + (int64_t)y0 * W;
+  const float* src = in + base;
+  const int iters = (npx + 1023) / 1024;
+  // ---- a: run-start labels (every lane of a wave takes part in the ballot) ----
+  for (int k = 0; k < iters; ++k) {
+    const int i = k * 1024 + tid;
+    const bool valid = i < npx;
+    const bool bg = valid && src[i] <= thr;
+    const unsigned long long m = __ballot(bg);
+    if (valid) {
+      int v = -1;
+      if (bg) {
+        const unsigned long long below = ~m & ((1ull << lane) - 1ull);
+        int start = below ? 64 - __clzll(below) : 0;   // first lane of this run inside the wave's 64-pixel segment
+        const int x = i % W;
+        if (lane - x > start) start = lane - x;          // runs do not cross the row start
+        v = i - (lane - start);
+      }
+      lab[i] = v;
+      area[i] = 0;
+    }
+  }
+  __syncthreads();
+  // ---- b: unions inside the strip (cc_merge_kernel's rule) ----
+  for (int k = 0; k < iters; ++k) {
+    const int i = k * 1024 + tid;
+    if (i >= npx || lab[i] < 0) continue;
+    const int y = i / W, x = i - y * W;
+    const bool w_bg = x > 0 && lab[i - 1] >= 0;
+    if (w_bg && (i & 63) == 0) uf_union(lab, i, i - 1);   // runs were merged inside one 64-lane segment only
+    if (y > 0) {
+      const bool n_bg = lab[i - W] >= 0;
+      const bool nw_bg = x > 0 && lab[i - W - 1] >= 0;
+      const bool ne_bg = x < W - 1 && lab[i - W + 1] >= 0;
+      if (n_bg) {
+        if (!(w_bg && nw_bg)) uf_union(lab, i, i - W);
+      } else {
+        if (nw_bg && !w_bg) uf_union(lab, i, i - W - 1);
+        if (ne_bg) uf_union(lab, i, i - W + 1);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- c: flatten + areas (one LDS atomic per run of equal roots inside a wave) ----
+  for (int k = 0; k < iters; ++k) {
+    const int i = k * 1024 + tid;
+    int key = -1;
+    if (i < npx && lab[i] >= 0) {
+      key = uf_find(lab, i);
+      lab[i] = key;   // a root is always a valid parent: plain store
+    }
+    const int prev = __shfl_up(key, 1);
+    const bool brk = lane == 0 || prev != key;
+    const unsigned long long bm = __ballot(brk);
+    if (key >= 0 && brk) {
+      const unsigned long long above = lane == 63 ? 0ull : (bm >> (lane + 1));
+      const int len = above ? __ffsll((long long)above) : 64 - lane;
+      if (area[key] <= sat) atomicAdd(area + key, len);   // only `area <= max_area` is consumed
+    }
+  }
+  __syncthreads();
+  // ---- d: strip-local roots as mask-local pixel indices; areas at roots, 0 elsewhere ----
+  const int off = y0 * W;
+  for (int i = tid; i < npx; i += 1024) {
+    const int l = lab[i];
+    labels[base + i] = l < 0 ? -1 : off + l;
+    areas[base + i] = l == i ? area[i] : 0;
+  }
+}
+
+__global__ void cc_seam_kernel(int* __restrict__ labels, int W, int H, int TH, int strips, int n_masks) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per = (strips - 1) * W;
+  if (t >= n_masks * per) return;
+  const int n = t / per, r = t - n * per;
+  const int st = 1 + r / W, x = r - (st - 1) * W;
+  int* lab = labels + (int64_t)n * H * W;
+  const int i = st * TH * W + x;   // first row of strip st; the row above belongs to strip st - 1
+  if (lab[i] < 0) return;           // (lab >= 0 <=> background: unions only ever write non-negative parents)
+  const bool w_bg = x > 0 && __hip_atomic_load(lab + i - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0;
+  const bool n_bg = __hip_atomic_load(lab + i - W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0;
+  const bool nw_bg = x > 0 && __hip_atomic_load(lab + i - W - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0;
+  const bool ne_bg = x < W - 1 && __hip_atomic_load(lab + i - W + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0;
+  if (n_bg) {
+    if (!(w_bg && nw_bg)) uf_union(lab, i, i - W);
+  } else {
+    if (nw_bg && !w_bg) uf_union(lab, i, i - W - 1);
+    if (ne_bg) uf_union(lab, i, i - W + 1);
+  }
+}
+
+__global__ void cc_sum_kernel(int* __restrict__ labels, int* __restrict__ areas, int HW, int64_t total, int sat) {
+  const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= total) return;
+  const int a = areas[gi];   // > 0 exactly at the strip-local roots (cc_tile); nobody adds to a root that is not a global root
+  if (a <= 0) return;
+  const int64_t n = gi / HW;
+  const int i = (int)(gi - n * HW);
+  const int r = uf_find_ro(labels + n * HW, i);
+  if (r == i) return;
+  int* dst = areas + n * HW + r;
+  if (__hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= sat) atomicAdd(dst, a);
+}
+
+__global__ void cc_apply_tiled_kernel(const float* __restrict__ in, float* __restrict__ out, const int* __restrict__ labels,
+                                      const int* __restrict__ areas, int HW, int64_t total, float thr, float max_area) {
+  const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gi >= total) return;
+  float v = in[gi];
+  if (v <= thr) {
+    const int64_t n = gi / HW;
+    const int* lab = labels + n * HW;
+    int r = labels[gi];
+    while (true) {   // kernel boundary = all unions done: plain loads
+      const int p = lab[r];
+      if (p == r) break;
+      r = p;
+    }
+    if ((float)areas[n * HW + r] <= max_area) v = thr + 10.f;
+  }
+  out[gi] = v;
+}
+
 // bilinear upsample (align_corners=False) of fp32 masks, optional > thr -> u8
 __global__ void upsample_masks_kernel(const float* __restrict__ in, float* __restrict__ out_f32,
                                       uint8_t* __restrict__ out_u8, int IH, int IW, int OH, int OW,
@@ -1188,6 +1345,21 @@ int esam3_launch_fill_holes(const float* in, float* out, int* labels, int* areas
   const int HW = H * W;
   const int64_t total = (int64_t)n * HW;
   const dim3 grid(blocks_for(total, 256)), blk(256);
+  if (W <= CC_TPX && (int64_t)n * H < (1ll << 30) && !esam3_dev_flag("ESAM3_CC_OLD")) {   // strips in LDS + seam merge
+    const int TH = CC_TPX / W < H ? CC_TPX / W : H, strips = (H + TH - 1) / TH;
+    const int lds = 2 * CC_TPX * (int)sizeof(int);
+    static const int ok = esam3_allow_dyn_lds((const void*)cc_tile_kernel, lds);
+    if (ok) return -1;
+    hipLaunchKernelGGL(cc_tile_kernel, dim3((unsigned)(n * strips)), dim3(1024), lds, s, in, labels, areas, W, H, TH, strips, thr, (int)max_area);
+    if (strips > 1) {
+      const int nt = n * (strips - 1) * W;
+      hipLaunchKernelGGL(cc_seam_kernel, dim3((unsigned)((nt + 255) / 256)), blk, 0, s, labels, W, H, TH, strips, n);
+      hipLaunchKernelGGL(cc_sum_kernel, grid, blk, 0, s, labels, areas, HW, total, (int)max_area);
+    }
+    hipLaunchKernelGGL(cc_apply_tiled_kernel, grid, blk, 0, s, in, out, labels, areas, HW, total, thr, max_area);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(cc_init_kernel, grid, blk, 0, s, in, labels, areas, W, HW, total, thr);
   hipLaunchKernelGGL(cc_merge_kernel, grid, blk, 0, s, in, labels, W, H, HW, total, thr);
   hipLaunchKernelGGL(cc_count_kernel, grid, blk, 0, s, labels, areas, HW, total, (int)max_area);

@@ -14,8 +14,12 @@ exactly representable in bf16 and every fp32 accumulation is exact in any order:
   * the one inexact operation of LiteMLA (the fp32 division) is IEEE in the kernel and in torch, on exact integer operands.
 
 The kernel's output must then equal the fp64 formula BIT FOR BIT (torch.equal): a single swapped lane, tap or channel
-anywhere in a fused graph changes an integer somewhere.  The i2t block ends in a LayerNorm (a reduction whose fp32 result depends
-on the order): there every element must be within one bf16 ulp and >= 99.5 % of them bit-equal.
+anywhere in a fused graph changes an integer somewhere.  Where a vanishing term exists (the e^-40 tails of a one-hot softmax, GELU's
+-6e-9 at -6) it is absorbed by every non-zero integer it is added to but survives next to an exact ZERO: there `_same_integers`
+asks for bit equality of every non-zero expected value and |got| <= 1e-6 where zero is expected (first GPU run of round 5: exactly the
+1 / 17 of the one-hot attention outputs whose selected value is 0 came back as 1e-17).  The i2t block ends in a LayerNorm (a
+reduction whose fp32 result depends on the order): there every element must be within one bf16 ulp (or 1e-5 near zero) and >= 99.5 %
+of them bit-equal.
 
 These tests complement, not replace, the random-data tests of test_ops_gpu.py (which exercise rounding) and the end-to-end
 fixtures (which exercise the composition)."""
@@ -50,6 +54,15 @@ def _sparse_pm1(rows, cols, nnz, seed):
 
 def _bf16_exact(t):
     return torch.equal(t.to(torch.bfloat16).float(), t.float())
+
+
+def _same_integers(got, ref, what=""):
+    """bit equality where the expected integer is non-zero, |got| <= 1e-6 where it is zero (module docstring)"""
+    ref = ref.float()
+    nz = ref != 0
+    bad = (nz & (got != ref)) | (~nz & (got.abs() > 1e-6))
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} elements differ on exact data; first at {tuple(bad.nonzero()[0].tolist())}: "
+                           f"got {float(got[tuple(bad.nonzero()[0].tolist())])!r}, expected {float(ref[tuple(bad.nonzero()[0].tolist())])!r}")
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cmid,Cout,stride,res", [
@@ -165,9 +178,7 @@ def test_attention_t2i_mfma_is_a_gather_on_one_hot_scores(B, Nq, Nk, merged):
     else:
         k_d, v_d = k.to("cuda", torch.bfloat16), v.to("cuda", torch.bfloat16)
         U.check(U.lib().esam3_op_attention(1, U.P(q_d), U.P(k_d), U.P(v_d), U.P(o_d), B, Nq, Nk, heads, hd, 2, None), "op_attention 2")
-    got = o_d.float().cpu()
-    bad = got != ref
-    assert not bad.any(), f"{int(bad.sum())}/{bad.numel()} elements differ; first at {tuple(bad.nonzero()[0].tolist())}"
+    _same_integers(o_d.float().cpu(), ref, "t2i one-hot attention")
 
 
 def t2i_lattice(B, Nq, Nk):
@@ -203,7 +214,7 @@ def test_i2t_block_on_one_hot_scores(Bp, P, T, q_from):
     got = out.float().cpu().double()
     assert torch.isfinite(got).all()
     refb = ref.to(torch.bfloat16).double()
-    ulp = 2.0 ** (torch.floor(torch.log2(ref.abs().clamp_min(2.0 ** -20))) - 7)
+    ulp = (2.0 ** (torch.floor(torch.log2(ref.abs().clamp_min(2.0 ** -20))) - 7)).clamp_min(1e-5)   # near zero: the fp32 reduction's own noise
     far = (got - ref).abs() > ulp
     assert not far.any(), f"{int(far.sum())} elements beyond one bf16 ulp; worst {float(((got - ref).abs() / ulp).max()):.2f} ulp"
     assert float((got == refb).double().mean()) >= 0.995, float((got == refb).double().mean())
@@ -260,9 +271,7 @@ def test_fused_mlp_exact_on_the_lattice(M, Cin, Hid, Cout, res):
     out = torch.full((M, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
     U.check(U.lib().esam3_op_fused_mlp(U.P(x_d), U.H(U.np32(w1)), U.H(U.np32(b1)), U.H(U.np32(w2)), U.H(U.np32(b2)), U.P(r_d), U.P(out),
                                        M, Cin, Hid, Cout, U.ACT["gelu"], None), "op_fused_mlp")
-    got = out.float().cpu()
-    bad = got != ref.float()
-    assert not bad.any(), f"{int(bad.sum())}/{bad.numel()} elements differ on exact data; first at {tuple(bad.nonzero()[0].tolist())}"
+    _same_integers(out.float().cpu(), ref, "fused_mlp")
 
 
 @pytest.mark.parametrize("rows,P", [(32, 32), (5184 * 2, 5184), (64 * 37, 64)])

@@ -17,6 +17,11 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden", "stage1")
 PREFIX = "backbone.vision_backbone.trunk.model."
 DTS = {"f32": torch.float32, "bf16": torch.bfloat16}
 
+# step-1 gradient limits of the fp32 run: max-abs-err <= GRAD_REL x the tensor's largest gradient + GRAD_ABS x the network's largest
+# (the values are set from the achieved margins x 3, profiles/r05/parity_margins.txt; VERDICT round 4 "Next" 2d)
+GRAD_REL, GRAD_ABS = 2.5e-2, 1e-4
+
+
 
 def _rand(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
@@ -182,17 +187,25 @@ def test_two_training_steps_match_the_reference_run(step_gold):
         # pinned by the loss (1e-3), by the recurrence on our own gradients (tight) and statistically against the reference's parameters.
         assert abs(norm - ref["grad_norms"][step]) <= (2e-3 if step == 0 else 0.15) * ref["grad_norms"][step]
         if step == 0:
-            worst = 0.0
+            # Achieved margins (profiles/r05/parity_margins.txt keeps the printed line): tensors whose own gradient is above 1e-3 of the
+            # network's largest are judged relative to THEIR maximum, the rest (shifts feeding a training-mode BatchNorm: analytically
+            # zero gradient, rounding noise on both sides) relative to the network's largest gradient
+            worst_rel, worst_rel_n, worst_abs, worst_abs_n, used = 0.0, "", 0.0, "", 0.0
             for n in ref["names"]:
                 got = grads[n] * clip                 # the fixture's gradients are the clipped ones (what AdamW saw)
                 want = g[f"grad1/{n}"]
                 tmax = float(g[f"gradmax1/{n}"])
                 err = float(np.abs(got - want).max())
-                # relative to the tensor's own gradient scale, with a floor at 1e-4 of the largest gradient of the network: a shift
-                # that feeds straight into a training-mode BatchNorm has an analytically zero gradient (rounding noise on both sides)
-                assert err <= 2.5e-2 * tmax + 1e-4 * gmax, (n, err, tmax, gmax)
-                worst = max(worst, err / max(tmax, 1e-30))
-            print(f"  gradients: worst max-abs-err / tensor max = {worst:.3e}")
+                if tmax >= 1e-3 * gmax:
+                    if err / tmax > worst_rel:
+                        worst_rel, worst_rel_n = err / tmax, n
+                elif err / gmax > worst_abs:
+                    worst_abs, worst_abs_n = err / gmax, n
+                used = max(used, err / (GRAD_REL * tmax + GRAD_ABS * gmax))
+                assert err <= GRAD_REL * tmax + GRAD_ABS * gmax, (n, err, tmax, gmax)
+            print(f"  gradients: worst max-abs-err / tensor max = {worst_rel:.3e} ({worst_rel_n}) over the tensors with a gradient; "
+                  f"worst max-abs-err / network max = {worst_abs:.3e} ({worst_abs_n}) over the noise-only tensors; "
+                  f"largest fraction of the allowance ({GRAD_REL:g} x tensor max + {GRAD_ABS:g} x network max) used = {used:.3f}")
         params = {n: _sample(v, ns) for n, v in tr.state_dict().items() if n in ref["shapes"]}
         own.append({n: grads[n].astype(np.float64) * clip for n in ref["names"]})
         # (1) the update itself: torch.optim.AdamW's recurrence (decoupled decay, bias-corrected moments) on OUR clipped gradients of

@@ -314,16 +314,58 @@ def draw_image_seeds(gdir, n_draws=None):
     return [1] + (seeds if n_draws is None else seeds[:n_draws])
 
 
-def distribution_verdict(engine, reference, extra=0.0):
+def distribution_verdict(engine, reference, extra=0.0, median=True, maximum=True):
     """engine / reference: lists of non-negative distances (None entries dropped).  Returns (ok, text)."""
     e = np.asarray([v for v in engine if v is not None], dtype=np.float64)
     r = np.asarray([v for v in reference if v is not None], dtype=np.float64)
-    med_ok = float(np.median(e)) <= DIST_MEDIAN_FACTOR * float(np.median(r)) + extra
-    max_ok = float(e.max()) <= DIST_MAX_FACTOR * float(r.max()) + extra
-    text = (f"median {np.median(e):.4g} vs {np.median(r):.4g} (x{np.median(e) / max(np.median(r), 1e-30):.2f}, allowed x{DIST_MEDIAN_FACTOR}"
-            f"{'' if not extra else f' + {extra:.2g}'}) max {e.max():.4g} vs {r.max():.4g} (x{e.max() / max(r.max(), 1e-30):.2f}, allowed x{DIST_MAX_FACTOR}) "
-            f"n {e.size}/{r.size}")
-    return med_ok and max_ok, text
+    med_ok = (not median) or float(np.median(e)) <= DIST_MEDIAN_FACTOR * float(np.median(r)) + extra
+    max_ok = (not maximum) or float(e.max()) <= DIST_MAX_FACTOR * float(r.max()) + extra
+    text = ""
+    if median:
+        text += (f"median {np.median(e):.4g} vs {np.median(r):.4g} (x{np.median(e) / max(np.median(r), 1e-30):.2f}, allowed x{DIST_MEDIAN_FACTOR}"
+                 f"{'' if not extra else f' + {extra:.2g}'}) ")
+    if maximum:
+        text += f"max {e.max():.4g} vs {r.max():.4g} (x{e.max() / max(r.max(), 1e-30):.2f}, allowed x{DIST_MAX_FACTOR}{'' if not extra else f' + {extra:.2g}'}) "
+    return med_ok and max_ok, text + f"n {e.size}/{r.size}"
+
+
+PER_CASE_MEDIAN_MIN_N = 7
+
+
+def distribution_report(tag, eng, ref, extra=None, pooled_only=()):
+    """The rule, applied to eng / ref = {case: {quantity: [one distance per image, None = excluded]}} measured on the same images:
+
+      * per QUANTITY, pooled over the cases and images of the model: median(engine) <= 1.25 x median(reference) and
+        max(engine) <= 1.5 x max(reference) -- a systematic loss of precision anywhere moves the pooled median;
+      * per CASE and quantity: the max rule always; the median rule too where the case has >= PER_CASE_MEDIAN_MIN_N images (the
+        headline model and the EV-M detector: 7) -- the median of 3 or 4 draws of a maximum is not a statistic;
+      * quantities in `pooled_only` (the thresholded-mask IoU) get the pooled rules only: it is a DISCRETE function of the logits
+        (threshold + hole filling: one <= 256-pixel hole toggling moves it by more than all of the reference's noise, and the
+        reference's own per-case values scatter between 4e-5 and 1.5e-2); the logits and scores carry the per-case rules.
+
+    `extra` = {case: {quantity: additive allowance}} (half a bf16 ulp of a stored score; the 2e-3 zero-crossing floor of a mask).
+    Prints one line per check; returns the list of failed checks."""
+    extra = extra or {}
+    failures = []
+    quantities = list(next(iter(eng.values())))
+    for q in quantities:
+        e_all = [v for c in eng for v in eng[c][q]]
+        r_all = [v for c in ref for v in ref[c][q]]
+        ex = max((extra.get(c, {}).get(q, 0.0) for c in eng), default=0.0)
+        ok, text = distribution_verdict(e_all, r_all, ex)
+        print(f"[dist {tag}] {'(all cases)':30s} {q:20s} {'ok  ' if ok else 'FAIL'} {text}")
+        if not ok:
+            failures.append((tag, "(all cases)", q, text))
+    for c in eng:
+        for q in quantities:
+            if q in pooled_only:
+                continue
+            n = sum(v is not None for v in eng[c][q])
+            ok, text = distribution_verdict(eng[c][q], ref[c][q], extra.get(c, {}).get(q, 0.0), median=n >= PER_CASE_MEDIAN_MIN_N)
+            print(f"[dist {tag}] {c:30s} {q:20s} {'ok  ' if ok else 'FAIL'} {text}")
+            if not ok:
+                failures.append((tag, c, q, text))
+    return failures
 
 
 def live_case_errors(sd, model_name, oracle_state, engine_out, kw, hw):
