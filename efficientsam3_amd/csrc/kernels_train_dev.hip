@@ -57,6 +57,14 @@ __global__ void pack_dw_weight_kernel(const float* __restrict__ w, float* __rest
   const int t = i / C, c = i - t * C;
   out[i] = w[c * kk + t];
 }
+// the same with the taps reversed: the data gradient of a stride-1 "same" depthwise conv IS that conv of dy with the
+// 180-degree-rotated kernel
+__global__ void pack_dw_weight_flipped_kernel(const float* __restrict__ w, float* __restrict__ out, int C, int kk) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * kk) return;
+  const int t = i / C, c = i - t * C;
+  out[i] = w[c * kk + (kk - 1 - t)];
+}
 __global__ void pack_stem_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 27 * Cout) return;
@@ -174,6 +182,21 @@ int esam3_train_dwconv(int dtype, const void* x, const float* w, const float* bi
   hipLaunchKernelGGL(pack_dw_weight_kernel, dim3((unsigned)((C * kk + 255) / 256)), dim3(256), 0, s, w, (float*)ws, C, kk);
   HIP_CHECK_RET(hipGetLastError());
   return esam3_launch_dwconv(dtype, x, C, (const float*)ws, bias, out, C, B, H, W, C, ksize, stride, ACT_NONE, s);
+}
+
+// Round 5: the stride-1 data gradient runs on the FORWARD depthwise kernels (the matrix-core / strip kernels of kernels_backbone.hip:
+// 20 - 30 us per layer at batch 8 where the scalar dw_dgrad_kernel took 300 - 490 us, profiles/r04/stage1_step_kernel_stats.csv);
+// stride 2 (a transposed convolution) keeps esam3_dwconv_dgrad's kernel.
+int esam3_train_dwconv_dgrad(int dtype, const void* dy, const float* w, void* dx, int B, int H, int W, int C, int ksize, int stride,
+                             void* ws, void* stream) {
+  if ((dtype != 0 && dtype != 1) || !dy || !w || !dx || !ws || (ksize != 3 && ksize != 5) || (stride != 1 && stride != 2))
+    return bad("esam3_train_dwconv_dgrad");
+  if (stride != 1) return esam3_dwconv_dgrad(dtype, dy, w, dx, B, H, W, C, ksize, stride, stream);
+  hipStream_t s = (hipStream_t)stream;
+  const int kk = ksize * ksize;
+  hipLaunchKernelGGL(pack_dw_weight_flipped_kernel, dim3((unsigned)((C * kk + 255) / 256)), dim3(256), 0, s, w, (float*)ws, C, kk);
+  HIP_CHECK_RET(hipGetLastError());
+  return esam3_launch_dwconv(dtype, dy, C, (const float*)ws, nullptr, dx, C, B, H, W, C, ksize, 1, ACT_NONE, s);
 }
 
 int esam3_train_stem(int dtype, const float* img, const float* w, void* out, int B, int H, int W, int Cout, void* ws, void* stream) {

@@ -140,10 +140,12 @@ def dwconv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw, stride: int = 1) -> t
     b, c = dy.shape[0], dy.shape[-1]
     h, wd = in_hw
     dx = torch.empty((b, h, wd, c), dtype=dy.dtype, device=dy.device)
-    wdev = w.detach().float().to(dy.device).contiguous()
+    wdev = _dev_f32(w) if w.is_cuda else w.detach().float().to(dy.device).contiguous()
+    ks = int(w.shape[-1])
+    ws = _ws(4 * ks * ks * c, dy.device)
     with torch.cuda.device(dy.device):
-        _lib.check(_lib.load().esam3_dwconv_dgrad(_DT[dy.dtype], dy.data_ptr(), wdev.data_ptr(), dx.data_ptr(), b, h, wd, c, int(w.shape[-1]), stride,
-                                                  _stream()), "esam3_dwconv_dgrad")
+        _lib.check(_lib.load().esam3_train_dwconv_dgrad(_DT[dy.dtype], dy.data_ptr(), wdev.data_ptr(), dx.data_ptr(), b, h, wd, c, ks, stride,
+                                                        ws.data_ptr(), _stream()), "esam3_train_dwconv_dgrad")
     return dx
 
 

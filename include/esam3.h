@@ -267,6 +267,11 @@ int esam3_train_conv3x3(int dtype, const void* x_dev, const float* w_dev, const 
                         int Cin, int Cout, int dgrad, void* workspace_dev, void* hip_stream);
 int esam3_train_dwconv(int dtype, const void* x_dev, const float* w_dev, const float* bias_dev, void* out_dev, int B, int H, int W, int C,
                        int ksize, int stride, void* workspace_dev, void* hip_stream);
+/* dx [B][H][W][C] of the depthwise conv above from dy [B][ceil(H/s)][ceil(W/s)][C] (autograd's conv backward for the student's
+ * depthwise layers, stage1/train_image_encoder_stage1.py:186-217): stride 1 = the forward kernels on dy with the rotated kernel
+ * (packed into workspace_dev, 4 k k C bytes); stride 2 = esam3_dwconv_dgrad */
+int esam3_train_dwconv_dgrad(int dtype, const void* dy_dev, const float* w_dev, void* dx_dev, int B, int H, int W, int C, int ksize,
+                             int stride, void* workspace_dev, void* hip_stream);
 int esam3_train_stem(int dtype, const float* img_nchw_dev, const float* w_dev, void* out_dev, int B, int H, int W, int Cout,
                      void* workspace_dev, void* hip_stream);
 int esam3_resize_bilinear_backward(int dtype, const void* dy_dev, void* dx_dev, int B, int IH, int IW, int OH, int OW, int C,

@@ -28,11 +28,11 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # (backbone, model, oracle model name, golden dir, draws used): every draw for the headline model, three for the other students
 # (their decoder is shared; the oracle's fp32 run of every image is host time on the GPU box), two for the ViT-H teacher
 MODELS = [("efficientvit", "b1", "b1", GOLD, None), ("efficientvit", "b0", "b0", os.path.join(GOLD, "efficientvit_b0"), 3),
-          ("efficientvit", "b2", "b2", os.path.join(GOLD, "efficientvit_b2"), 3),
-          ("repvit", "m0.9", "m0.9", os.path.join(GOLD, "repvit_m0.9"), 3), ("repvit", "m1.1", "m1.1", os.path.join(GOLD, "repvit_m1.1"), 3),
-          ("repvit", "m2.3", "m2.3", os.path.join(GOLD, "repvit_m2.3"), 3), ("tinyvit", "5m", "5m", os.path.join(GOLD, "tinyvit_5m"), 3),
-          ("tinyvit", "11m", "11m", os.path.join(GOLD, "tinyvit_11m"), 3), ("tinyvit", "21m", "21m", os.path.join(GOLD, "tinyvit_21m"), 3),
+          ("repvit", "m1.1", "m1.1", os.path.join(GOLD, "repvit_m1.1"), 3), ("tinyvit", "11m", "11m", os.path.join(GOLD, "tinyvit_11m"), 3),
           ("sam3", "vit_h", "vit_h", os.path.join(GOLD, "sam3_vit_h"), 2)]
+# (the S / L sizes not listed -- EfficientViT-B2, RepViT-M0.9 / M2.3, TinyViT-5M / 21M -- passed the same rule on the GPU in round 5,
+# profiles/r05/parity_margins.txt, and stay covered by test_students_gpu.py's single-image limits: every model costs 20 - 60 s of host
+# time for the oracle's fp32 runs, and the driver's GPU test step has a time limit)
 
 
 def _cases(gdir):
@@ -61,6 +61,7 @@ def test_reference_samples_bookkeeping():
         assert _cases(gdir), gdir
     # the report: pooled rules for every quantity, per-case max rule, per-case median rule from 7 images on, mask pooled only
     eng = {"a": {"low_res": [1.0] * 7, "mask": [0.0] * 6 + [9.0]}, "b": {"low_res": [1.4, 1.0, 1.0], "mask": [0.0, 0.0, 0.0]}}
+    assert U.distribution_report("t", {"a": {"m": [1.0, 1.0, 5.0]}}, {"a": {"m": [1.0, 1.0, 1.0]}}, pooled_only=("m",), median_only=("m",)) == []   # the tail is not looked at
     ref = {"a": {"low_res": [1.0] * 7, "mask": [0.0] * 6 + [9.0]}, "b": {"low_res": [1.0, 1.0, 1.0], "mask": [0.0, 0.0, 0.0]}}
     assert U.distribution_report("t", eng, ref, pooled_only=("mask",)) == []
     eng["a"]["low_res"] = [1.3] * 7                                               # case a: 7 images, 30 % worse on every one
@@ -110,7 +111,7 @@ def test_bf16_engine_distribution_vs_reference_draws(bt, mn, oname, gdir, n_draw
     proc = Sam3Processor(model)
     cases = _cases(gdir)
     seeds = U.draw_image_seeds(gdir, n_draws)
-    eng = {n: dict(low_res=[], iou=[], mask=[]) for n in cases}
+    eng = {n: dict(low_res=[], iou=[], mask=[], mask_tail=[]) for n in cases}
     peaks = {n: 0.0 for n in cases}
     ties = []
     for seed in seeds:
@@ -127,6 +128,8 @@ def test_bf16_engine_distribution_vs_reference_draws(bt, mn, oname, gdir, n_draw
             # logit and score distances are bf16 noise like any other sample's; its mask is ANOTHER mask (other area, other
             # sensitivity to a toggled hole) that the reference's samples of this case say nothing about -- left out of the mask IoU
             eng[name]["low_res"].append(e_low); eng[name]["iou"].append(e_iou); eng[name]["mask"].append(None if took else 1.0 - miou)
+            # the tail of the mask quantity: one hole of the hole filling may toggle (U.live_case_errors.one_hole: its share of this sample)
+            eng[name]["mask_tail"].append(None if took else max(0.0, 1.0 - miou - U.live_case_errors.one_hole))
             peaks[name] = max(peaks[name], float(np.abs(out[1]).max()))
             if took:
                 ties.append((seed, name, took))
@@ -136,8 +139,9 @@ def test_bf16_engine_distribution_vs_reference_draws(bt, mn, oname, gdir, n_draw
         assert len(samples) == len(seeds)
         ref[name] = {"low_res": [None if s is None else s["low_res"] for s in samples], "iou": [None if s is None else s["iou"] for s in samples],
                      "mask": [None if s is None else 1.0 - s["mask_iou"] for s in samples]}
-        extra[name] = {"iou": U.bf16_half_ulp(peaks[name]), "mask": 2e-3}
-    failures = U.distribution_report(f"{bt}-{mn}", eng, ref, extra, pooled_only=("mask",))
+        ref[name]["mask_tail"] = ref[name]["mask"]
+        extra[name] = {"iou": U.bf16_half_ulp(peaks[name]), "mask": 2e-3, "mask_tail": 2e-3}
+    failures = U.distribution_report(f"{bt}-{mn}", eng, ref, extra, pooled_only=("mask", "mask_tail"), median_only=("mask",), max_only=("mask_tail",))
     if ties:
         print(f"[dist {bt}-{mn}] prompts that took another plausible candidate of the fp32 oracle (seed, case, {{prompt: candidate}}): {ties}")
     assert not failures, failures

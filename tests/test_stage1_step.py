@@ -17,9 +17,12 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden", "stage1")
 PREFIX = "backbone.vision_backbone.trunk.model."
 DTS = {"f32": torch.float32, "bf16": torch.bfloat16}
 
-# step-1 gradient limits of the fp32 run: max-abs-err <= GRAD_REL x the tensor's largest gradient + GRAD_ABS x the network's largest
-# (the values are set from the achieved margins x 3, profiles/r05/parity_margins.txt; VERDICT round 4 "Next" 2d)
-GRAD_REL, GRAD_ABS = 2.5e-2, 1e-4
+# step-1 gradient limits of the fp32 run: max-abs-err <= GRAD_REL x the tensor's largest gradient + GRAD_ABS x the network's largest.
+# Achieved on the MI355X (round 5, profiles/r05/parity_margins.txt): the worst tensor WITH a gradient is the stem's depthwise weight --
+# 1.66e-2 of its own maximum (nine sums of 2 M products each at 504 x 504, heavy cancellation, another summation order than torch's);
+# the five next-worst tensors are printed by the test.  The noise-only tensors (analytically zero gradient) reach 7.1e-6 of the network's
+# largest gradient: GRAD_ABS = 3.5 x that (it was 1e-4).  GRAD_REL stays at 1.5 x the achieved worst.
+GRAD_REL, GRAD_ABS = 2.5e-2, 2.5e-5
 
 
 
@@ -191,6 +194,7 @@ def test_two_training_steps_match_the_reference_run(step_gold):
             # network's largest are judged relative to THEIR maximum, the rest (shifts feeding a training-mode BatchNorm: analytically
             # zero gradient, rounding noise on both sides) relative to the network's largest gradient
             worst_rel, worst_rel_n, worst_abs, worst_abs_n, used = 0.0, "", 0.0, "", 0.0
+            ranked = []
             for n in ref["names"]:
                 got = grads[n] * clip                 # the fixture's gradients are the clipped ones (what AdamW saw)
                 want = g[f"grad1/{n}"]
@@ -202,10 +206,15 @@ def test_two_training_steps_match_the_reference_run(step_gold):
                 elif err / gmax > worst_abs:
                     worst_abs, worst_abs_n = err / gmax, n
                 used = max(used, err / (GRAD_REL * tmax + GRAD_ABS * gmax))
+                if tmax >= 1e-3 * gmax:
+                    ranked.append((err / tmax, n))
                 assert err <= GRAD_REL * tmax + GRAD_ABS * gmax, (n, err, tmax, gmax)
             print(f"  gradients: worst max-abs-err / tensor max = {worst_rel:.3e} ({worst_rel_n}) over the tensors with a gradient; "
                   f"worst max-abs-err / network max = {worst_abs:.3e} ({worst_abs_n}) over the noise-only tensors; "
                   f"largest fraction of the allowance ({GRAD_REL:g} x tensor max + {GRAD_ABS:g} x network max) used = {used:.3f}")
+            ranked.sort(reverse=True)
+            print("  gradients, the six worst tensors (max-abs-err / tensor max): " + "; ".join(f"{r:.2e} {n}" for r, n in ranked[:6])
+                  + f"; median over {len(ranked)} tensors {ranked[len(ranked) // 2][0]:.2e}")
         params = {n: _sample(v, ns) for n, v in tr.state_dict().items() if n in ref["shapes"]}
         own.append({n: grads[n].astype(np.float64) * clip for n in ref["names"]})
         # (1) the update itself: torch.optim.AdamW's recurrence (decoupled decay, bias-corrected moments) on OUR clipped gradients of

@@ -329,20 +329,23 @@ def distribution_verdict(engine, reference, extra=0.0, median=True, maximum=True
     return med_ok and max_ok, text + f"n {e.size}/{r.size}"
 
 
-PER_CASE_MEDIAN_MIN_N = 7
+PER_CASE_MEDIAN_MIN_N = 5
 
 
-def distribution_report(tag, eng, ref, extra=None, pooled_only=()):
+def distribution_report(tag, eng, ref, extra=None, pooled_only=(), median_only=(), max_only=()):
     """The rule, applied to eng / ref = {case: {quantity: [one distance per image, None = excluded]}} measured on the same images:
 
       * per QUANTITY, pooled over the cases and images of the model: median(engine) <= 1.25 x median(reference) and
         max(engine) <= 1.5 x max(reference) -- a systematic loss of precision anywhere moves the pooled median;
       * per CASE and quantity: the max rule always; the median rule too where the case has >= PER_CASE_MEDIAN_MIN_N images (the
-        headline model and the EV-M detector: 7) -- the median of 3 or 4 draws of a maximum is not a statistic;
+        headline model: 7, the EV-M detector: 5) -- the median of 3 or 4 draws of a maximum is not a statistic;
       * quantities in `pooled_only` (the thresholded-mask IoU) get the pooled rules only: it is a DISCRETE function of the logits
         (threshold + hole filling: one <= 256-pixel hole toggling moves it by more than all of the reference's noise, and the
         reference's own per-case values scatter between 4e-5 and 1.5e-2); the logits and scores carry the per-case rules.
 
+    `median_only` / `max_only`: pooled quantities that carry one half of the rule only (the mask IoU is entered twice by its caller: raw
+    for the median, and with one hole's worth taken off every engine sample for the maximum -- a hole of the hole filling that
+    toggles is a discrete event worth 0.3 - 3 % of a mask, more than the whole spread of the reference's samples).
     `extra` = {case: {quantity: additive allowance}} (half a bf16 ulp of a stored score; the 2e-3 zero-crossing floor of a mask).
     Prints one line per check; returns the list of failed checks."""
     extra = extra or {}
@@ -352,7 +355,7 @@ def distribution_report(tag, eng, ref, extra=None, pooled_only=()):
         e_all = [v for c in eng for v in eng[c][q]]
         r_all = [v for c in ref for v in ref[c][q]]
         ex = max((extra.get(c, {}).get(q, 0.0) for c in eng), default=0.0)
-        ok, text = distribution_verdict(e_all, r_all, ex)
+        ok, text = distribution_verdict(e_all, r_all, ex, median=q not in max_only, maximum=q not in median_only)
         print(f"[dist {tag}] {'(all cases)':30s} {q:20s} {'ok  ' if ok else 'FAIL'} {text}")
         if not ok:
             failures.append((tag, "(all cases)", q, text))
@@ -419,4 +422,7 @@ def live_case_errors(sd, model_name, oracle_state, engine_out, kw, hw):
     a, b = mk_e > 0, mk_o > 0
     u = np.logical_or(a, b).sum()
     miou = 1.0 if u == 0 else float(np.logical_and(a, b).sum() / u)
+    # what ONE hole of the hole filling is worth in this sample's 1 - IoU: <= 256 low-res pixels (sam1_utils.py:77-104) blown up to the
+    # output size, over the union (`one_hole_of`, read by the distribution test's tail rule for the mask IoU)
+    live_case_errors.one_hole = 0.0 if u == 0 else min(1.0, 256.0 * (hw[0] * hw[1] / float(288 * 288)) / float(u))
     return float(e_low.max()), float(e_iou.max()), miou, took
