@@ -93,6 +93,7 @@ SIGNATURES = {
     "esam3_rle_scratch_bytes": (_L, [_I, _I, _I, _L]),
     "esam3_rle_encode": (_I, [_P, _I, _I, _I, _P, _L, _P, _P, _L, _P]),
     "esam3_rle_to_string": (_L, [_P, _L, _P, _L]),
+    "esam3_host_widen_u8_f32": (_I, [_P, _P, C.c_int64]),
     "esam3_rle_from_string": (_L, [_P, _L, _P, _L]),
     "esam3_stage1_preprocess_shape": (None, [_I, _I, _I, _P, _P]),
     "esam3_stage1_preprocess_u8": (_I, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P]),

@@ -2,6 +2,9 @@
 // weights exactly like the engine does and launch the same kernels, so unit parity tests
 // can compare one operator at a time against the oracle.  Test-sized: every call uploads
 // its weights, synchronises and frees them.
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#endif
 #include <algorithm>
 #include <cstdio>
 #include <vector>
@@ -670,6 +673,31 @@ int esam3_rle_encode(const uint8_t* masks_dev, int n, int H, int W, uint32_t* co
 // cocoapi's compressed string form of the counts (maskApi.c rleToString / rleFrString: every count after the third is
 // stored as the difference to the count two places before; 5 payload bits per character with a continuation bit,
 // sign-extended, + 48).  Host code, no device work.  Returns the string length (without a terminator) or -1.
+// Host side of the mask return path (sam1_task_predictor.py:293-295: the reference hands back float32 numpy masks): uint8 0 / 1 masks in
+// a pinned staging buffer -> the caller's float32 array.  Plain C so that a few Python worker threads can run it concurrently through
+// ctypes (the GIL is released for the call); the loop vectorises, the stores are the cost (4 bytes written per byte read).
+int esam3_host_widen_u8_f32(const uint8_t* src_host, float* dst_host, int64_t n) {
+  if (!src_host || !dst_host || n < 0) { esam3_set_error("esam3_host_widen_u8_f32: bad argument"); return -1; }
+  int64_t i = 0;
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SSE2__)
+  // non-temporal stores: the 4 n bytes written are not read back by this thread, and a write-allocate would fetch every line first
+  // (half of the memory traffic of the plain loop)
+  for (; i < n && ((uintptr_t)(dst_host + i) & 15); ++i) dst_host[i] = (float)src_host[i];
+  const __m128i zero = _mm_setzero_si128();
+  for (; i + 16 <= n; i += 16) {
+    const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src_host + i));
+    const __m128i lo = _mm_unpacklo_epi8(b, zero), hi = _mm_unpackhi_epi8(b, zero);
+    _mm_stream_ps(dst_host + i, _mm_cvtepi32_ps(_mm_unpacklo_epi16(lo, zero)));
+    _mm_stream_ps(dst_host + i + 4, _mm_cvtepi32_ps(_mm_unpackhi_epi16(lo, zero)));
+    _mm_stream_ps(dst_host + i + 8, _mm_cvtepi32_ps(_mm_unpacklo_epi16(hi, zero)));
+    _mm_stream_ps(dst_host + i + 12, _mm_cvtepi32_ps(_mm_unpackhi_epi16(hi, zero)));
+  }
+  _mm_sfence();
+#endif
+  for (; i < n; ++i) dst_host[i] = (float)src_host[i];
+  return 0;
+}
+
 int64_t esam3_rle_to_string(const uint32_t* counts_host, int64_t n_counts, char* out, int64_t capacity) {
   if (!counts_host || !out || n_counts < 0) { esam3_set_error("esam3_rle_to_string: bad argument"); return -1; }
   int64_t p = 0;

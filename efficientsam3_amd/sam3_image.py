@@ -24,7 +24,7 @@ import sys
 import numpy as np
 import torch
 
-from . import schema
+from . import _lib, schema
 from .engine import EMB, LOW_RES, NET_RES, HipEngine
 
 
@@ -54,18 +54,32 @@ def _nchw_view(t_nhwc: torch.Tensor) -> torch.Tensor:
 
 
 _WIDEN_POOL = None
+D2H_CHUNKS = 4   # pieces of the device-to-host mask copy that the host widens while the next one is in flight
 
 
 def _widen_into(dst: np.ndarray, src: np.ndarray, parts: int = 16, serial_below: int = 1 << 22) -> None:
     """dst[...] = src (same shape, any dtypes numpy can cast: the uint8 masks become the float32 array the reference's contract returns);
-    large arrays are split into `parts` contiguous ranges copied by the worker threads."""
+    large arrays are split into `parts` contiguous ranges copied by the worker threads.  uint8 -> float32 (the thresholded masks) runs
+    in the library's C loop (esam3_host_widen_u8_f32: numpy's casting copy reached 37 GB/s of stores on 16 threads, 3.6 ms per 32
+    masks of 1024 x 1024 -- the longest host-side piece of an API-level step, profiles/r04/api_level_probe.txt)."""
     assert dst.shape == src.shape and dst.flags.c_contiguous and src.flags.c_contiguous
     d, s_ = dst.reshape(-1), src.reshape(-1)
     n = s_.size
+    native = None
+    if src.dtype == np.uint8 and dst.dtype == np.float32:
+        fn = _lib.load().esam3_host_widen_u8_f32
+        sp, dp = s_.ctypes.data, d.ctypes.data
+        native = lambda a, b: fn(sp + a, dp + 4 * a, b - a)  # noqa: E731
     if n < serial_below:
-        np.copyto(d, s_, casting="unsafe")
+        if native is not None:
+            native(0, n)
+        else:
+            np.copyto(d, s_, casting="unsafe")
         return
     step = -(-n // parts)
+    if native is not None:
+        list(_widen_pool().map(lambda i: native(i * step, min(n, (i + 1) * step)), range(parts)))
+        return
     list(_widen_pool().map(lambda i: np.copyto(d[i * step:(i + 1) * step], s_[i * step:(i + 1) * step], casting="unsafe"), range(parts)))
 
 
@@ -194,6 +208,7 @@ class Sam3Image:
             self._schema.update(schema.pcs_schema())  # the grounding detector the text prompts feed
         self._sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
         self._pos_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._copy_stream = None                           # side stream of the chunked device-to-host mask copies
         self._host_stage: Dict[tuple, torch.Tensor] = {}   # pinned D2H staging buffers of predict_inst_batch, by (shape, dtype)
         self._host_out: Dict[tuple, list] = {}             # per shape: up to three result buffers (tensor, ndarray), each handed out again only once the caller dropped it
         self.training = False
@@ -391,7 +406,23 @@ class Sam3Image:
             if len(self._host_stage) >= 4:
                 self._host_stage.clear()
             pin = self._host_stage[key] = torch.empty(masks.shape, dtype=masks.dtype).pin_memory()
-        pin.copy_(masks, non_blocking=True)
+        # The device-to-host copy runs in D2H_CHUNKS pieces on a side stream, an event behind each: the host widens piece k into the
+        # result array while piece k + 1 is still on the wire (round 5: one copy, one wait, then 3.6 ms of widening with the device and
+        # the link idle before).
+        n0 = masks.shape[0]
+        nch = D2H_CHUNKS if (masks.dim() >= 2 and n0 >= 2 * D2H_CHUNKS and masks.is_contiguous()) else 1
+        bounds = [(n0 * k // nch, n0 * (k + 1) // nch) for k in range(nch)]
+        cur = torch.cuda.current_stream(masks.device)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=masks.device)
+        self._copy_stream.wait_stream(cur)
+        events = []
+        with torch.cuda.stream(self._copy_stream):
+            for a, e in bounds:
+                pin[a:e].copy_(masks[a:e], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self._copy_stream)
+                events.append(ev)
         # The result array is the caller's (the reference returns fresh arrays), but 134 MB of never-touched pages cost
         # ~30 ms of page faults per call: the previous result tensor of this shape is handed out again ONLY if nothing
         # outside this object references it any more (a caller that kept its arrays keeps them untouched).
@@ -407,12 +438,15 @@ class Sam3Image:
             pool.append(ent)
             if len(pool) > 3:                            # `out = step()` loops need two, a consumer one step behind three
                 pool.pop(0)
-        torch.cuda.current_stream(masks.device).synchronize()
         # uint8 -> float32 (or float32 -> float32) on a few worker threads.  NOT torch's copy_: its OpenMP team (128 threads on the
         # GPU host) keeps spinning after the copy, and the NEXT wait on the device -- the small synchronous prompt upload of the
         # following call -- then returned 50-70 ms late in about every third step (tools/api_stall_probe.py,
         # profiles/r04/api_stall_probe.txt: 17 ms steps with 65-80 ms outliers; the device itself was idle).
-        _widen_into(ent[1], pin.numpy())
+        pin_np = pin.numpy()
+        for (a, e), ev in zip(bounds, events):
+            ev.synchronize()
+            _widen_into(ent[1][a:e], pin_np[a:e])
+        cur.wait_stream(self._copy_stream)      # `masks` may be freed / reused by the caller's stream only after the copies
         return ent[1]
 
     def predict_inst_batch(self, inference_state, point_coords_batch=None, point_labels_batch=None,

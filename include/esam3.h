@@ -193,6 +193,9 @@ int esam3_rle_encode(const uint8_t* masks_dev, int n, int H, int W, uint32_t* co
 /* cocoapi's compressed "counts" string (maskApi.c rleToString / rleFrString; what pycocotools returns as bytes):
  * host buffers, returns the number of characters / counts written, -1 on error */
 int64_t esam3_rle_to_string(const uint32_t* counts_host, int64_t n_counts, char* out, int64_t capacity);
+/* dst_host[i] = (float) src_host[i], i < n: the uint8 -> float32 widening of thresholded masks on the host (the reference returns
+ * float32 numpy masks, sam3/model/sam1_task_predictor.py:293-295); thread-safe on disjoint ranges */
+int esam3_host_widen_u8_f32(const uint8_t* src_host, float* dst_host, int64_t n);
 int64_t esam3_rle_from_string(const char* s, int64_t len, uint32_t* counts_host, int64_t capacity);
 
 /* Stage-1 distillation loss, forward (stage1/train_image_encoder_stage1.py:271-307 masked_mse and
