@@ -2198,8 +2198,22 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
     if (!ok(pm) || !ok(p1) || !ok(pool) || !ok(hp)) return -1;
     CK(lin(pk_linear(d + "prompt_mlp.layers.0"), prompt, DM, B * Sp, pm, FF, ACT_RELU));
     CK(lin(pk_linear(d + "prompt_mlp.layers.1"), pm, FF, B * Sp, p1, DM, ACT_NONE, prompt, DM));
-    CK(LN(d + "prompt_mlp.out_norm", p1, p1, B * Sp));
-    if (!dry) CK(esam3_launch_masked_mean(dtype, p1, pmask, pool, B, Sp, DM, st));
+    if (dtype == 1) {
+      // bf16 engine: the normed prompt stays fp32 up to the pooled vector (LayerNorm returns fp32 under the reference's autocast and
+      // mean_pool_text averages it in fp32, model_misc.py:60-81): ONE rounding, at prompt_proj's input, instead of three.  The pooled
+      // vector enters every one of the 200 class logits of an image (config 4's logits sat at 1.4 x the reference's own bf16 distance)
+      float* p1f = (float*)allocb(sizeof(float) * (size_t)B * Sp * DM);
+      float* poolf = (float*)allocb(sizeof(float) * (size_t)B * DM);
+      if (!ok(p1f) || !ok(poolf)) return -1;
+      CK(layernorm_io(dtype, 0, d + "prompt_mlp.out_norm", p1, p1f, B * Sp, DM, 1e-5f));
+      if (!dry) {
+        CK(esam3_launch_masked_mean(0, p1f, pmask, poolf, B, Sp, DM, st));
+        CK(esam3_launch_cast_from_f32(dtype, poolf, pool, (int64_t)B * DM, st));
+      }
+    } else {
+      CK(LN(d + "prompt_mlp.out_norm", p1, p1, B * Sp));
+      if (!dry) CK(esam3_launch_masked_mean(dtype, p1, pmask, pool, B, Sp, DM, st));
+    }
     CK(lin(pk_linear(d + "prompt_proj"), pool, DM, B, ph, DM, ACT_NONE));
     CK(lin(pk_linear(d + "hs_proj"), hs, DM, R, hp, DM, ACT_NONE));
     if (!dry) CK(esam3_launch_dot_score(dtype, hp, QR, 1, Q, ph, out->pred_logits_dev, B, DM, 1.0f / 16.0f, 12.0f, st));

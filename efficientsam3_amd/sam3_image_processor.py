@@ -32,6 +32,7 @@ class Sam3Processor:
         # (256 cores): both stage 32 images in 1.7-1.8 ms, but torch's 128 spinning OpenMP threads then starve the HIP runtime's
         # own threads -- the step went from 40 to 58 ms (profiles/r04/api_level_probe.txt).  Off.
         self.rgbx_torch_copy = False
+        self.first_chunk_fraction = 0.25   # share of a batch in the first of the two pipelined encode chunks (set_image_batch)
         self._stage_busy = {}  # staging buffer key -> event recorded after the last H2D copy out of it
 
     @staticmethod
@@ -205,7 +206,7 @@ class Sam3Processor:
                 full["sam2_fpn"] = [torch.empty((b, h, h, c), dtype=dt, device=dev) for h, c in ((288, 32), (144, 64), (72, 256))]
             # uneven chunks: the device idles until the first chunk is staged and copied (1.3 + 1.25 ms for 16 images), so the first
             # one is a quarter of the batch; the rest travels under its encode
-            first = max(4, b // 4)
+            first = min(b - 1, max(4, int(b * self.first_chunk_fraction)))
             for ci, (a, e) in enumerate(((0, first), (first, b))):
                 batch = self._stage_to_device(images[a:e], slot=ci)
                 if tuple(batch.shape[1:3]) == (r, r):

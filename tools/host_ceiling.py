@@ -112,6 +112,16 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=30)
     a = ap.parse_args()
     print(f"host: {len(os.sched_getaffinity(0))} cpus; batch 32 x 1024 x 1024 PIL images per rank and step; device step (not run) = 10.3 - 10.6 ms")
+    for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"):
+        try:
+            print(f"  {f}: {open(f).read().strip()}")     # a CPU quota below ranks x 16 worker threads throttles the N-rank run
+        except OSError:
+            pass
+    try:
+        import subprocess
+        print("  " + subprocess.run(["lscpu"], capture_output=True, text=True).stdout.replace("\n", " | ")[:600])
+    except Exception:  # noqa: BLE001
+        pass
     for world in (1, a.ranks):
         res = run(world, a.steps)
         worst = max(r[2] for r in res)
