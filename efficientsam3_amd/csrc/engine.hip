@@ -1712,8 +1712,26 @@ int E::encode_text(const int64_t* tokens, int B, int S, float* memory_sbd, float
     CK(text_repmixer(e + "transformer.0.", x, B, S, D, y));
     std::swap(x, y);
   }
+  // Round 5, bf16 engine: the pre-norm transformer layers keep their residual stream in fp32 (`xs`), as the reference's autocast does
+  // (`x = x + dropout(mha(norm(x)))` adds a bf16 branch to an fp32 tensor, mobile_clip.py TransformerEncoder): the text memory enters
+  // every class logit of the detector, and config 4's logits were the last output above the reference's own bf16 distance
+  // (tests/test_pcs.py::test_config4_batch_8_on_the_yardstick_pairs: "dog" 1.68 x the reference's worst draw).
+  const bool ts32 = dtype == 1;
+  float* xs = ts32 ? (float*)allocb(sizeof(float) * (size_t)rows * D) : nullptr;
+  if (ts32 && !ok(xs)) return -1;
+  if (ts32 && !dry) CK(esam3_launch_cast_to_f32(dtype, x, xs, rows * D, st));
   for (int i = first; i < n_layers + first; ++i) {
     const std::string q = e + "transformer." + std::to_string(i) + ".";
+    if (ts32) {
+      CK(layernorm_io(0, dtype, q + "pre_norm_mha.0", xs, ln, rows, D, 1e-5f));
+      CK(linear(q + "pre_norm_mha.1.qkv_proj", ln, D, rows, qkv, 3 * D, ACT_NONE));
+      if (!dry) CK(prof_launch("text_attn", 0.0, 0.0, [&]() { return esam3_launch_text_attn(dtype, qkv, att, B, S, heads, 64, text_causal ? 1 : 0, st); }));
+      CK(linear(q + "pre_norm_mha.1.out_proj", att, D, rows, xs, D, ACT_NONE, xs, D, 0, 1));
+      CK(layernorm_io(0, dtype, q + "pre_norm_ffn.0", xs, ln, rows, D, 1e-5f));
+      CK(linear(q + "pre_norm_ffn.1", ln, D, rows, hid, 4 * D, ACT_GELU));
+      CK(linear(q + "pre_norm_ffn.4", hid, 4 * D, rows, xs, D, ACT_NONE, xs, D, 0, 1));
+      continue;
+    }
     CK(layernorm(q + "pre_norm_mha.0", x, ln, rows, D, 1e-5f));
     CK(linear(q + "pre_norm_mha.1.qkv_proj", ln, D, rows, qkv, 3 * D, ACT_NONE));
     if (!dry) CK(prof_launch("text_attn", 0.0, 0.0, [&]() { return esam3_launch_text_attn(dtype, qkv, att, B, S, heads, 64, text_causal ? 1 : 0, st); }));
@@ -1722,6 +1740,7 @@ int E::encode_text(const int64_t* tokens, int B, int S, float* memory_sbd, float
     CK(linear(q + "pre_norm_ffn.1", ln, D, rows, hid, 4 * D, ACT_GELU));
     CK(linear(q + "pre_norm_ffn.4", hid, 4 * D, rows, x, D, ACT_NONE, y, D));
   }
+  if (ts32 && !dry) CK(esam3_launch_cast_from_f32(dtype, xs, x, rows * D, st));   // the closing RepMixer / final norm read the GEMM type
   if (mct) {
     CK(text_repmixer(e + "transformer." + std::to_string(n_layers + 1) + ".", x, B, S, D, y));
   } else {

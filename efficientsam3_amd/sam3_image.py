@@ -54,7 +54,7 @@ def _nchw_view(t_nhwc: torch.Tensor) -> torch.Tensor:
 
 
 _WIDEN_POOL = None
-D2H_CHUNKS = 4   # pieces of the device-to-host mask copy that the host widens while the next one is in flight
+D2H_CHUNKS = 1   # pieces of the device-to-host mask copy (an event behind each; the host widens piece k while piece k + 1 is in flight).  Measured on the MI355X box (tools/api_ab.py, profiles/r05/api_ab.txt): 4 pieces cost 1.6 ms MORE per 32 masks than one copy + one wait (event wake-ups and four pool dispatches outweigh 0.7 ms of copy), so the default is 1
 
 
 def _widen_into(dst: np.ndarray, src: np.ndarray, parts: int = 16, serial_below: int = 1 << 22) -> None:

@@ -33,7 +33,10 @@ from . import train_blocks as tb
 from .stage1 import ArenaLayout, Stage1Updater, distill_loss, distill_loss_backward, valid_mask
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
-EFFICIENTVIT = {"b0": ([8, 16, 32, 64, 128], [1, 2, 2, 2, 2], 16), "b1": ([16, 32, 64, 128, 256], [1, 2, 3, 3, 4], 16)}
+# EfficientViT-B0 / B1 / B2 = the EV-S / EV-M / EV-L students (backbones/efficientvit/efficientvit/backbone.py:169-190: width_list,
+# depth_list, dim of the LiteMLA heads)
+EFFICIENTVIT = {"b0": ([8, 16, 32, 64, 128], [1, 2, 2, 2, 2], 16), "b1": ([16, 32, 64, 128, 256], [1, 2, 3, 3, 4], 16),
+                "b2": ([24, 48, 96, 192, 384], [1, 3, 4, 4, 6], 32)}
 
 
 def _stream():

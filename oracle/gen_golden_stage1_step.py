@@ -21,7 +21,7 @@ from itself).
     PYTHONDONTWRITEBYTECODE=1 CUDA_VISIBLE_DEVICES="" HIP_VISIBLE_DEVICES="" \
     PYTHONPATH=oracle/shims:/root/reference:. python oracle/gen_golden_stage1_step.py     (the OUTER sam3 package: stage1/model.py imports sam3.sam3.*)
 
-Output: tests/golden/stage1/step.npz + step_manifest.json
+Output: tests/golden/stage1/step.npz + step_manifest.json (`--model b2`: step_b2.npz + step_b2_manifest.json, round 5)
 """
 from __future__ import annotations
 
@@ -52,8 +52,11 @@ IMAGE_SEEDS, TEACHER_SEED = (11, 12), 7
 NSAMP = 256
 
 
+MODEL = "b1"          # --model b0 | b1 | b2 (the default b1 writes step.npz / step_manifest.json, the others step_<model>.*)
+
+
 def student_state_dict():
-    sd = schema.synthetic_state_dict("efficientvit", "b1", seed=0)
+    sd = schema.synthetic_state_dict("efficientvit", MODEL, seed=0)
     return {k[len(PREFIX):]: v.clone() for k, v in sd.items() if k.startswith(PREFIX)}
 
 
@@ -86,7 +89,7 @@ def run(amp: bool):
     import model as ref_model            # stage1/model.py
     import optimizer as ref_optimizer    # stage1/optimizer.py
     ref = reference_functions()
-    cfg = SimpleNamespace(MODEL=SimpleNamespace(BACKBONE="efficientvit_b1"), DATA=SimpleNamespace(IMG_SIZE=IMG),
+    cfg = SimpleNamespace(MODEL=SimpleNamespace(BACKBONE=f"efficientvit_{MODEL}"), DATA=SimpleNamespace(IMG_SIZE=IMG),
                           DISTILL=SimpleNamespace(EMBED_DIM=EMBED_DIM, EMBED_SIZE=EMBED_SIZE, COSINE=HYPER["cosine"]),
                           TRAIN=SimpleNamespace(OPTIMIZER=SimpleNamespace(NAME="adamw", EPS=HYPER["eps"], BETAS=HYPER["betas"], MOMENTUM=0.9),
                                                 BASE_LR=HYPER["lr"], WEIGHT_DECAY=HYPER["weight_decay"], CLIP_GRAD=HYPER["clip_grad"],
@@ -136,17 +139,23 @@ def run(amp: bool):
 
 
 def main():
+    global MODEL
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="b1", choices=["b0", "b1", "b2"])
+    MODEL = ap.parse_args().model
+    suffix = "" if MODEL == "b1" else f"_{MODEL}"
     os.makedirs(GOLD, exist_ok=True)
     fp32, arrays = run(False)
     bf16, _ = run(True)
     man = {"source": "stage1/train_image_encoder_stage1.py:165-226, stage1/model.py:28-37,188-211, stage1/optimizer.py:6-46, stage1/utils.py:341-368",
            "hyper": HYPER, "img_size": IMG, "embed_dim": EMBED_DIM, "embed_size": EMBED_SIZE, "sizes_before_pad": SIZES,
            "image_seeds": list(IMAGE_SEEDS), "teacher_seed": TEACHER_SEED, "samples_per_tensor": NSAMP, "torch": torch.__version__,
-           "fp32": fp32, "bf16_autocast": bf16}
-    np.savez_compressed(os.path.join(GOLD, "step.npz"), **arrays)
-    with open(os.path.join(GOLD, "step_manifest.json"), "w") as f:
+           "fp32": fp32, "bf16_autocast": bf16, "model": MODEL}
+    np.savez_compressed(os.path.join(GOLD, f"step{suffix}.npz"), **arrays)
+    with open(os.path.join(GOLD, f"step{suffix}_manifest.json"), "w") as f:
         json.dump(man, f, indent=1, sort_keys=True)
-    print("wrote", GOLD, "step.npz", os.path.getsize(os.path.join(GOLD, "step.npz")) // 1024, "KB")
+    print("wrote", GOLD, f"step{suffix}.npz", os.path.getsize(os.path.join(GOLD, f"step{suffix}.npz")) // 1024, "KB")
 
 
 if __name__ == "__main__":
