@@ -476,6 +476,167 @@ __global__ __launch_bounds__(256) void mla_backward_kernel(const typename TElem<
   }
 }
 
+// Round 5: the same three passes with the TOKENS split over P workgroups per (image, head group) -- B x G = 128 - 256 workgroups walking
+// up to 3969 tokens three times were 24 % of a training step (profiles/r04/stage1_step_kernel_stats.csv).  MODE 0 writes the partial S of
+// its token range, MODE 1 (with the reduced S) the partial dS and Y, MODE 2 (with S and dS) the per-token gradients; the partial
+// matrices are summed in range order by mla_backward_reduce_kernel: deterministic, same arithmetic per token as the one-workgroup form.
+template <int DT, int DIM, int MODE>
+__global__ __launch_bounds__(256) void mla_backward_part_kernel(const typename TElem<DT>::type* __restrict__ ms,
+                                                           const typename TElem<DT>::type* __restrict__ dout,
+                                                           typename TElem<DT>::type* __restrict__ dms,
+                                                           typename TElem<DT>::type* __restrict__ y, int N, int G, float eps, int P, int span,
+                                                                const float* __restrict__ Sg, const float* __restrict__ dSg, float* __restrict__ part) {
+  constexpr int TT = 64, D1 = DIM + 1, SE = D1 * DIM;  // tokens per tile, rows of S, elements of S
+  __shared__ float tq[TT][DIM + 1], tk[TT][DIM + 1], tv[TT][D1 + 1];  // relu(q), relu(k), [v; 1] of the tile (+1: bank skew)
+  __shared__ float tdo[TT][D1 + 1];                                   // dO of the tile
+  __shared__ float S[SE], dS[SE];
+  typedef typename TElem<DT>::type T;
+  const int g = blockIdx.x % G;
+  const int64_t b = blockIdx.x / G;
+  const int nb = blockIdx.y * span, ne = min(N, nb + span);   // this workgroup's token range
+  const int tid = threadIdx.x;
+  const int C3 = G * 3 * DIM, CO = G * DIM;
+  const T* base = ms + b * N * (int64_t)C3 + g * 3 * DIM;
+  auto ldf = [](const T* p) -> float {
+    if constexpr (DT == 0) return *p; else return __uint_as_float((uint32_t)*p << 16);
+  };
+  auto stage = [&](int n0) {  // tile of tokens n0 .. n0 + TT - 1 (zeros past N: they add nothing to S / dS)
+    for (int i = tid; i < TT * 3 * DIM; i += 256) {
+      const int n = i / (3 * DIM), c = i - n * 3 * DIM;
+      float v = 0.f;
+      if (n0 + n < ne) v = ldf(base + (int64_t)(n0 + n) * C3 + c);
+      if (c < DIM) tq[n][c] = v > 0.f ? v : 0.f;
+      else if (c < 2 * DIM) tk[n][c - DIM] = v > 0.f ? v : 0.f;
+      else tv[n][c - 2 * DIM] = v;
+    }
+    for (int n = tid; n < TT; n += 256) tv[n][DIM] = n0 + n < ne ? 1.f : 0.f;
+  };
+  // acc[j] += sum over the tile of X[n][a] Z[n][c]  for this thread's elements e = tid + 256 j = a DIM + c
+  constexpr int NJ = (SE + 255) / 256;
+  auto outer = [&](const float (*X)[D1 + 1], const float (*Z)[DIM + 1], float* acc) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int e = tid + 256 * j;
+      if (e < SE) {
+        const int a = e / DIM, c = e - a * DIM;
+        float s_ = acc[j];
+        for (int n = 0; n < TT; ++n) s_ = fmaf(X[n][a], Z[n][c], s_);
+        acc[j] = s_;
+      }
+    }
+  };
+  // per-token dO from S (in LDS) and dY; also returns D and writes Y
+  auto token_dO = [&](int n0, int n, float* dO) {
+    float O[D1];
+#pragma unroll
+    for (int a = 0; a < D1; ++a) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) s_ = fmaf(S[a * DIM + c], tq[n][c], s_);
+      O[a] = s_;
+    }
+    const float D = O[DIM] + eps, inv = 1.f / D;
+    float dD = 0.f;
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+      const float yv = O[c] * inv;
+      const float dyv = ldf(dout + ((b * N + n0 + n) * (int64_t)CO) + g * DIM + c);
+      dO[c] = dyv * inv;
+      dD = fmaf(-dyv, yv, dD);
+      if (MODE == 1 && y) {
+        if constexpr (DT == 0) y[(b * N + n0 + n) * (int64_t)CO + g * DIM + c] = yv;
+        else y[(b * N + n0 + n) * (int64_t)CO + g * DIM + c] = f32_to_bf16(yv);
+      }
+    }
+    dO[DIM] = dD * inv;
+  };
+
+  float acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
+  float* mine = part + ((int64_t)blockIdx.x * P + blockIdx.y) * SE;
+  if constexpr (MODE == 0) {   // ---- S partial = Vp Kr^T over this range ----
+    for (int n0 = nb; n0 < ne; n0 += TT) {
+      __syncthreads();
+      stage(n0);
+      __syncthreads();
+      outer(tv, tk, acc);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      if (tid + 256 * j < SE) mine[tid + 256 * j] = acc[j];
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    if (tid + 256 * j < SE) {
+      S[tid + 256 * j] = Sg[(int64_t)blockIdx.x * SE + tid + 256 * j];
+      if constexpr (MODE == 2) dS[tid + 256 * j] = dSg[(int64_t)blockIdx.x * SE + tid + 256 * j];
+    }
+  if constexpr (MODE == 1) {   // ---- dS partial = dO Qr^T over this range (also writes Y) ----
+  for (int n0 = nb; n0 < ne; n0 += TT) {
+    __syncthreads();
+    stage(n0);
+    __syncthreads();
+    if (tid < TT) {
+      float dO[D1];
+#pragma unroll
+      for (int a = 0; a < D1; ++a) dO[a] = 0.f;
+      if (n0 + tid < ne) token_dO(n0, tid, dO);
+#pragma unroll
+      for (int a = 0; a < D1; ++a) tdo[tid][a] = dO[a];
+    }
+    __syncthreads();
+    outer(tdo, tq, acc);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+    if (tid + 256 * j < SE) mine[tid + 256 * j] = acc[j];
+  return;
+  }
+  // ---- MODE 2: per-token gradients of this range ----
+  for (int n0 = nb; n0 < ne; n0 += TT) {
+    __syncthreads();
+    stage(n0);
+    __syncthreads();
+    if (tid < TT && n0 + tid < ne) {
+      const int n = tid;
+      float dO[D1];
+      token_dO(n0, n, dO);
+      T* o = dms + (b * N + n0 + n) * (int64_t)C3 + g * 3 * DIM;
+      auto stf = [&](int c, float v) {
+        if constexpr (DT == 0) o[c] = v; else o[c] = f32_to_bf16(v);
+      };
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) {
+        float dq = 0.f, dk = 0.f, dv = 0.f;
+#pragma unroll
+        for (int a = 0; a < D1; ++a) {
+          dq = fmaf(S[a * DIM + c], dO[a], dq);        // dQr = S^T dO
+          dk = fmaf(dS[a * DIM + c], tv[n][a], dk);    // dKr = dS^T Vp
+        }
+#pragma unroll
+        for (int c2 = 0; c2 < DIM; ++c2) dv = fmaf(dS[c * DIM + c2], tk[n][c2], dv);  // dV = (dS Kr)[:DIM], row c
+        stf(c, tq[n][c] > 0.f ? dq : 0.f);
+        stf(DIM + c, tk[n][c] > 0.f ? dk : 0.f);
+        stf(2 * DIM + c, dv);
+      }
+    }
+  }
+}
+
+
+// sum of P partial (DIM + 1) x DIM matrices per (image, head group) in a fixed order (deterministic)
+__global__ void mla_backward_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int P, int SE, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (bg, e)
+  if (i >= total) return;
+  const int64_t bg = i / SE;
+  const int e = (int)(i - bg * SE);
+  float s_ = 0.f;
+  for (int p_ = 0; p_ < P; ++p_) s_ += part[(bg * P + p_) * SE + e];
+  out[i] = s_;
+}
+
 constexpr int TRAIN_SPLITS_MAX = 256;
 int wgrad_splits(int64_t M) {  // every split a whole number of 64-row tiles
   int64_t tiles = (M + WG_ROWS - 1) / WG_ROWS;
@@ -616,6 +777,52 @@ int esam3_lite_mla_backward(int dtype, const void* ms, const void* dout, void* d
   else if (dim == 16) ESAM3_MLA_BWD(1, 16, uint16_t);
   else ESAM3_MLA_BWD(1, 32, uint16_t);
 #undef ESAM3_MLA_BWD
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+static int mla_bw_parts(int N) { int p_ = (N + 255) / 256; return p_ < 1 ? 1 : (p_ > 64 ? 64 : p_); }
+
+int64_t esam3_lite_mla_backward_workspace(int B, int N, int groups, int dim) {
+  if (B <= 0 || N <= 0 || groups <= 0 || (dim != 16 && dim != 32)) return 0;
+  const int64_t SE = (int64_t)(dim + 1) * dim;
+  return (int64_t)sizeof(float) * B * groups * SE * (mla_bw_parts(N) + 2);
+}
+
+int esam3_lite_mla_backward_ws(int dtype, const void* ms, const void* dout, void* dms, void* y, int B, int N, int groups, int dim, float eps,
+                               void* workspace, void* stream) {
+  if ((dtype != 0 && dtype != 1) || !ms || !dout || !dms || !workspace || B <= 0 || N <= 0 || groups <= 0 || (dim != 16 && dim != 32)) {
+    esam3_set_error("esam3_lite_mla_backward_ws: bad argument (head dim 16 or 32, workspace of esam3_lite_mla_backward_workspace bytes)");
+    return -1;
+  }
+  const int P = mla_bw_parts(N);
+  if (P == 1) return esam3_lite_mla_backward(dtype, ms, dout, dms, y, B, N, groups, dim, eps, stream);
+  const int TT = 64;
+  const int span = ((N + P - 1) / P + TT - 1) / TT * TT;   // whole 64-token tiles per workgroup
+  const int64_t BG = (int64_t)B * groups, SE = (int64_t)(dim + 1) * dim;
+  float* part = (float*)workspace;
+  float* Sg = part + BG * P * SE;
+  float* dSg = Sg + BG * SE;
+  const dim3 grid((unsigned)BG, (unsigned)P);
+  const unsigned rgrid = (unsigned)((BG * SE + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+#define ESAM3_MLA_PART(DT_, DIM_, T_, MODE_) \
+  hipLaunchKernelGGL((mla_backward_part_kernel<DT_, DIM_, MODE_>), grid, dim3(256), 0, s, (const T_*)ms, (const T_*)dout, (T_*)dms, (T_*)y, N, groups, eps, \
+                     P, span, Sg, dSg, part)
+#define ESAM3_MLA_ALL(DT_, DIM_, T_)                                                                                  \
+  do {                                                                                                               \
+    ESAM3_MLA_PART(DT_, DIM_, T_, 0);                                                                                \
+    hipLaunchKernelGGL(mla_backward_reduce_kernel, dim3(rgrid), dim3(256), 0, s, part, Sg, P, (int)SE, BG * SE);     \
+    ESAM3_MLA_PART(DT_, DIM_, T_, 1);                                                                                \
+    hipLaunchKernelGGL(mla_backward_reduce_kernel, dim3(rgrid), dim3(256), 0, s, part, dSg, P, (int)SE, BG * SE);    \
+    ESAM3_MLA_PART(DT_, DIM_, T_, 2);                                                                                \
+  } while (0)
+  if (dtype == 0 && dim == 16) ESAM3_MLA_ALL(0, 16, float);
+  else if (dtype == 0) ESAM3_MLA_ALL(0, 32, float);
+  else if (dim == 16) ESAM3_MLA_ALL(1, 16, uint16_t);
+  else ESAM3_MLA_ALL(1, 32, uint16_t);
+#undef ESAM3_MLA_ALL
+#undef ESAM3_MLA_PART
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

@@ -34,6 +34,7 @@ class Sam3Processor:
         self.rgbx_torch_copy = False
         self.first_chunk_fraction = 0.25   # share of a batch in the first of the two pipelined encode chunks (set_image_batch)
         self._stage_busy = {}  # staging buffer key -> event recorded after the last H2D copy out of it
+        self._h2d_stream = None  # side stream of the staged host-to-device copies (_stage_to_device)
 
     @staticmethod
     def _rgbx_view(im):
@@ -128,11 +129,21 @@ class Sam3Processor:
         b, (w, h) = len(images), images[0].size
         rgbx = (h, w) != (self.resolution, self.resolution) and hasattr(self.model.engine, "preprocess_resize_u8_batch")
         host = self._stage_pil_batch(images, slot, rgbx=rgbx)
-        dev_t = host.to(self.device, non_blocking=True)
-        if self.device.type == "cuda":
+        if self.device.type != "cuda":
+            return host.to(self.device, non_blocking=True)
+        # The copy goes out on a SIDE stream (round 5): issued on the compute stream it queued behind the previous chunk's encode, and
+        # the device then sat idle for the 2 ms the second chunk's pixels took to arrive (tools/api_level_probe.py: 10.8 ms of device
+        # tail per step against 9.6 ms for the same step with resident inputs).  The compute stream waits for the copy's event only.
+        cur = torch.cuda.current_stream(self.device)
+        if self._h2d_stream is None:
+            self._h2d_stream = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(self._h2d_stream):
+            dev_t = host.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            self._stage_busy[(b, h, w, slot, host.shape[-1])] = ev
+            ev.record(self._h2d_stream)
+        self._stage_busy[(b, h, w, slot, host.shape[-1])] = ev     # the pinned buffer is refilled only after the copy has run
+        cur.wait_event(ev)
+        dev_t.record_stream(cur)                                   # allocated on the side stream, consumed on the compute stream
         return dev_t
 
     def _preprocess(self, hwc_u8_list: List[torch.Tensor]) -> torch.Tensor:

@@ -263,9 +263,11 @@ def lite_mla_backward(ms: torch.Tensor, dout: torch.Tensor, groups: int, dim: in
     b, n, c3 = ms.shape
     assert c3 == groups * 3 * dim and tuple(dout.shape) == (b, n, groups * dim) and ms.is_contiguous() and dout.is_contiguous()
     dms, y = torch.empty_like(ms), torch.empty_like(dout)
+    lib = _lib.load()
+    ws = _ws(lib.esam3_lite_mla_backward_workspace(b, n, groups, dim), ms.device)   # tokens split over workgroups, fixed-order sums (round 5)
     with torch.cuda.device(ms.device):
-        _lib.check(_lib.load().esam3_lite_mla_backward(_DT[ms.dtype], ms.data_ptr(), dout.data_ptr(), dms.data_ptr(), y.data_ptr(), b, n, groups,
-                                                       dim, float(eps), _stream()), "esam3_lite_mla_backward")
+        _lib.check(lib.esam3_lite_mla_backward_ws(_DT[ms.dtype], ms.data_ptr(), dout.data_ptr(), dms.data_ptr(), y.data_ptr(), b, n, groups,
+                                                  dim, float(eps), ws.data_ptr(), _stream()), "esam3_lite_mla_backward_ws")
     return dms, y
 
 

@@ -244,6 +244,12 @@ int esam3_dwconv_wgrad(int dtype, const void* x_dev, const void* dy_dev, int B, 
  * dim 16 or 32; fp32 arithmetic; one workgroup per (image, head group), deterministic. */
 int esam3_lite_mla_backward(int dtype, const void* ms_dev, const void* dout_dev, void* dms_dev, void* y_dev, int B, int N, int groups,
                             int dim, float eps, void* hip_stream);
+/* the same with the tokens split over several workgroups per (image, head group) and the two small matrices summed in a fixed order
+ * (round 5: 128 - 256 workgroups walking up to 3969 tokens three times were 24 % of a training step); workspace_dev holds
+ * esam3_lite_mla_backward_workspace(B, N, groups, dim) bytes; results as esam3_lite_mla_backward up to the summation order of S / dS */
+int64_t esam3_lite_mla_backward_workspace(int B, int N, int groups, int dim);
+int esam3_lite_mla_backward_ws(int dtype, const void* ms_dev, const void* dout_dev, void* dms_dev, void* y_dev, int B, int N, int groups,
+                               int dim, float eps, void* workspace_dev, void* hip_stream);
 /* dx [B][H][W][C] of the same depthwise conv from dy [B][ceil(H/s)][ceil(W/s)][C]; w_dev fp32 [C][1][k][k] ON THE DEVICE */
 int esam3_dwconv_dgrad(int dtype, const void* dy_dev, const float* w_dev, void* dx_dev, int B, int H, int W, int C, int ksize,
                        int stride, void* hip_stream);

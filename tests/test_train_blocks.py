@@ -204,7 +204,7 @@ def test_dsconv_block_forward_backward_vs_autograd(mode):
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
-@pytest.mark.parametrize("B,N,G,dim", [(2, 100, 4, 16), (1, 1024, 16, 16), (2, 77, 2, 32), (1, 3969, 2, 16)])
+@pytest.mark.parametrize("B,N,G,dim", [(2, 100, 4, 16), (1, 1024, 16, 16), (2, 77, 2, 32), (1, 3969, 2, 16), (2, 1100, 3, 32), (1, 257, 2, 16)])
 def test_lite_mla_backward_vs_autograd(mode, B, N, G, dim):
     """esam3_lite_mla_backward against autograd through the reference's formula (LiteMLA.relu_linear_att, ops.py:584-621: ReLU kernels,
     v padded with a row of ones, vk = v k^T, out = vk q, normalised by its last row + 1e-15), fp32 on the (bf16-quantised) inputs."""
