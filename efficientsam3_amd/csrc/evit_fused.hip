@@ -23,6 +23,8 @@
 //                    bf16 hi + lo MFMA operands.
 //   mla2_kernel      second pass: att = (kv . relu(q)) / (ksum . relu(q) + eps) per head on the matrix cores (fp32 divide),
 //                    proj 1x1 + BN + identity shortcut (ops.py:663-671,740-770) accumulated over 64-channel chunks of att.
+#include <type_traits>
+
 #include "gemm_common.h"
 #include "kernels.h"
 
@@ -1145,46 +1147,64 @@ __global__ __launch_bounds__(256, 2) void mbconv3s_kernel(Mb3Params p) {
         const float4 bb = *reinterpret_cast<const float4*>(sb1 + c0 + ejt * 32 + 8 * q + 4 * g);
         binit[4 * q + 0] = bb.x; binit[4 * q + 1] = bb.y; binit[4 * q + 2] = bb.z; binit[4 * q + 3] = bb.w;
       }
+      // Round 5: ONE basic block per expand phase.  Every wave owns exactly UPW units here (2 NPT is a multiple of the four waves for both
+      // tile shapes), so the per-unit "pt >= NPT" exit is gone, and the border zeroing picks one of two straight-line versions of the loop
+      // instead of branching inside every unit: the scheduler can put unit u + 1's MFMA under unit u's Hardswish / pack / store chain
+      // (each unit used to be MFMA -> wait -> 30 dependent VALU instructions -> two LDS stores, back to back).
+      static_assert((2 * NPT) % NW == 0, "every wave owns the same number of expand units");
+      auto expand_units = [&](auto zero_border) {
+        // software pipeline by hand: unit u + 1's MFMAs are ISSUED before unit u's VALU chain (left to itself the register allocator
+        // reuses one accumulator and serialises MFMA -> wait -> VALU per unit); the scheduling barrier keeps the order
+        f32x16_v accs[2];
+        accs[0] = binit;
 #pragma unroll
-      for (int u = 0; u < UPW; ++u) {
-        const int pt = (wave + NW * u) >> 1;
-        if (pt >= NPT) continue;  // wave-uniform
-        const int hp = pt * 32 + l31;
-        f32x16_v acc = binit;
+        for (int ks = 0; ks < KS; ++ks) MmaOps<T>::mma(fw[ks], xf[0][ks], accs[0]);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) MmaOps<T>::mma(fw[ks], xf[u][ks], acc);
-        float v[16];
+        for (int u = 0; u < UPW; ++u) {
+          const int pt = (wave + NW * u) >> 1;
+          const int hp = pt * 32 + l31;
+          if (u + 1 < UPW) {
+            accs[(u + 1) & 1] = binit;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = acc[e];
-        hsw_n<16>(v);
-        if (any_out) {
-          const bool in = (xin_t >> u) & 1u;
+            for (int ks = 0; ks < KS; ++ks) MmaOps<T>::mma(fw[ks], xf[u + 1][ks], accs[(u + 1) & 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x16_v acc = accs[u & 1];
+          float v[16];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] = in ? v[e] : 0.f;
-        }
-        u32x4 o[2];
+          for (int e = 0; e < 16; ++e) v[e] = acc[e];
+          hsw_n<16>(v);
+          if constexpr (decltype(zero_border)::value) {
+            const bool in = (xin_t >> u) & 1u;
 #pragma unroll
-        for (int qp = 0; qp < 2; ++qp) {
-          const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
-          const uint32_t c0_ = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]), c1_ = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
-          auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0_, false, false);
-          auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
-          o[qp] = u32x4{s0[0], s1[0], s0[1], s1[1]};  // channels ejt*32 + 16qp + 8g .. +8 of halo pixel hp
-        }
-        // S = 1: lanes whose pixel index has bit 1 set write the qp = 1 piece first: the 8 lanes of a ds_write_b128 group then hit
-        // 4 distinct 16-byte bank slots instead of 2 (pixel pitch 192 B = 64 mod 128, pieces 32 B apart).  S = 2 (pitch 160 B =
-        // 32 mod 128): consecutive pixels already land on 4 distinct slots, and the swap made it WORSE (lanes 0, 3, 4, 7 on one slot:
-        // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.60, profiles/r04/pmc_c_summary.txt) -- no swap, and 8 selects fewer per unit
+            for (int e = 0; e < 16; ++e) v[e] = in ? v[e] : 0.f;
+          }
+          u32x4 o[2];
+#pragma unroll
+          for (int qp = 0; qp < 2; ++qp) {
+            const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
+            const uint32_t c0_ = pack_bf16x2(v[8 * qp + 4], v[8 * qp + 5]), c1_ = pack_bf16x2(v[8 * qp + 6], v[8 * qp + 7]);
+            auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0_, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
+            o[qp] = u32x4{s0[0], s1[0], s0[1], s1[1]};  // channels ejt*32 + 16qp + 8g .. +8 of halo pixel hp
+          }
+          // S = 1: lanes whose pixel index has bit 1 set write the qp = 1 piece first: the 8 lanes of a ds_write_b128 group then hit
+          // 4 distinct 16-byte bank slots instead of 2 (pixel pitch 192 B = 64 mod 128, pieces 32 B apart).  S = 2 (pitch 160 B =
+          // 32 mod 128): consecutive pixels already land on 4 distinct slots, and the swap made it WORSE (lanes 0, 3, 4, 7 on one slot:
+          // SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.60, profiles/r04/pmc_c_summary.txt) -- no swap, and 8 selects fewer per unit
 #ifdef ESAM3_HSW_C
-        const bool flip = (l31 >> 1) & 1;
+          const bool flip = (l31 >> 1) & 1;
 #else
-        const bool flip = S == 1 && ((l31 >> 1) & 1);
+          const bool flip = S == 1 && ((l31 >> 1) & 1);
 #endif
-        const u32x4 w0 = flip ? o[1] : o[0], w1v = flip ? o[0] : o[1];
-        char* rowp = mid + hp * PITCH + ((ejt * 4 + g) << 4);
-        *reinterpret_cast<u32x4*>(rowp + (flip ? 32 : 0)) = w0;
-        *reinterpret_cast<u32x4*>(rowp + (flip ? 0 : 32)) = w1v;
-      }
+          const u32x4 w0 = flip ? o[1] : o[0], w1v = flip ? o[0] : o[1];
+          char* rowp = mid + hp * PITCH + ((ejt * 4 + g) << 4);
+          *reinterpret_cast<u32x4*>(rowp + (flip ? 32 : 0)) = w0;
+          *reinterpret_cast<u32x4*>(rowp + (flip ? 0 : 32)) = w1v;
+        }
+      };
+      if (any_out) expand_units(std::true_type{});
+      else expand_units(std::false_type{});
       __syncthreads();
       // next chunk's W1 fragments + bias (chunk 0 again for the next tile); after the last expand phase of this tile the next
       // tile's pixel fragments

@@ -573,6 +573,31 @@ __global__ __launch_bounds__(256) void mla_backward_part_kernel(const typename T
       S[tid + 256 * j] = Sg[(int64_t)blockIdx.x * SE + tid + 256 * j];
       if constexpr (MODE == 2) dS[tid + 256 * j] = dSg[(int64_t)blockIdx.x * SE + tid + 256 * j];
     }
+  if constexpr (MODE == 3) {   // ---- forward only: Y = O[:DIM] / (O[DIM] + eps) of this range (dout is not read) ----
+    for (int n0 = nb; n0 < ne; n0 += TT) {
+      __syncthreads();
+      stage(n0);
+      __syncthreads();
+      if (tid < TT && n0 + tid < ne) {
+        float O[D1];
+#pragma unroll
+        for (int a = 0; a < D1; ++a) {
+          float s_ = 0.f;
+#pragma unroll
+          for (int c = 0; c < DIM; ++c) s_ = fmaf(S[a * DIM + c], tq[tid][c], s_);
+          O[a] = s_;
+        }
+        const float inv = 1.f / (O[DIM] + eps);
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+          const float yv = O[c] * inv;
+          if constexpr (DT == 0) y[(b * N + n0 + tid) * (int64_t)CO + g * DIM + c] = yv;
+          else y[(b * N + n0 + tid) * (int64_t)CO + g * DIM + c] = f32_to_bf16(yv);
+        }
+      }
+    }
+    return;
+  }
   if constexpr (MODE == 1) {   // ---- dS partial = dO Qr^T over this range (also writes Y) ----
   for (int n0 = nb; n0 < ne; n0 += TT) {
     __syncthreads();
@@ -786,16 +811,18 @@ static int mla_bw_parts(int N) { int p_ = (N + 255) / 256; return p_ < 1 ? 1 : (
 int64_t esam3_lite_mla_backward_workspace(int B, int N, int groups, int dim) {
   if (B <= 0 || N <= 0 || groups <= 0 || (dim != 16 && dim != 32)) return 0;
   const int64_t SE = (int64_t)(dim + 1) * dim;
-  return (int64_t)sizeof(float) * B * groups * SE * (mla_bw_parts(N) + 2);
+  return (int64_t)sizeof(float) * B * groups * SE * ((mla_bw_parts(N) > 2 ? mla_bw_parts(N) : 2) + 2);
 }
 
 int esam3_lite_mla_backward_ws(int dtype, const void* ms, const void* dout, void* dms, void* y, int B, int N, int groups, int dim, float eps,
                                void* workspace, void* stream) {
-  if ((dtype != 0 && dtype != 1) || !ms || !dout || !dms || !workspace || B <= 0 || N <= 0 || groups <= 0 || (dim != 16 && dim != 32)) {
+  const bool fwd_only = !dout;   // dout_dev NULL: the forward output y only (dms_dev is not written)
+  if ((dtype != 0 && dtype != 1) || !ms || (!fwd_only && !dms) || (fwd_only && !y) || !workspace || B <= 0 || N <= 0 || groups <= 0 ||
+      (dim != 16 && dim != 32)) {
     esam3_set_error("esam3_lite_mla_backward_ws: bad argument (head dim 16 or 32, workspace of esam3_lite_mla_backward_workspace bytes)");
     return -1;
   }
-  const int P = mla_bw_parts(N);
+  const int P = fwd_only ? (mla_bw_parts(N) > 1 ? mla_bw_parts(N) : 2) : mla_bw_parts(N);
   if (P == 1) return esam3_lite_mla_backward(dtype, ms, dout, dms, y, B, N, groups, dim, eps, stream);
   const int TT = 64;
   const int span = ((N + P - 1) / P + TT - 1) / TT * TT;   // whole 64-token tiles per workgroup
@@ -813,6 +840,7 @@ int esam3_lite_mla_backward_ws(int dtype, const void* ms, const void* dout, void
   do {                                                                                                               \
     ESAM3_MLA_PART(DT_, DIM_, T_, 0);                                                                                \
     hipLaunchKernelGGL(mla_backward_reduce_kernel, dim3(rgrid), dim3(256), 0, s, part, Sg, P, (int)SE, BG * SE);     \
+    if (fwd_only) { ESAM3_MLA_PART(DT_, DIM_, T_, 3); break; }                                                      \
     ESAM3_MLA_PART(DT_, DIM_, T_, 1);                                                                                \
     hipLaunchKernelGGL(mla_backward_reduce_kernel, dim3(rgrid), dim3(256), 0, s, part, dSg, P, (int)SE, BG * SE);    \
     ESAM3_MLA_PART(DT_, DIM_, T_, 2);                                                                                \

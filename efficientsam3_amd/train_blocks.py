@@ -271,6 +271,20 @@ def lite_mla_backward(ms: torch.Tensor, dout: torch.Tensor, groups: int, dim: in
     return dms, y
 
 
+def lite_mla_forward(ms: torch.Tensor, groups: int, dim: int, eps: float = 1e-15) -> torch.Tensor:
+    """LiteMLA.relu_linear_att (ops.py:584-621) forward only: y [B, N, groups * dim] (the backward kernels with dout = NULL: the S pass and
+    one pass over the tokens; round 5 -- the training forward used to run the whole backward with a zero upstream gradient)"""
+    b, n, c3 = ms.shape
+    assert c3 == groups * 3 * dim and ms.is_contiguous()
+    y = torch.empty((b, n, groups * dim), dtype=ms.dtype, device=ms.device)
+    lib = _lib.load()
+    ws = _ws(lib.esam3_lite_mla_backward_workspace(b, n, groups, dim), ms.device)
+    with torch.cuda.device(ms.device):
+        _lib.check(lib.esam3_lite_mla_backward_ws(_DT[ms.dtype], ms.data_ptr(), None, None, y.data_ptr(), b, n, groups, dim, float(eps),
+                                                  ws.data_ptr(), _stream()), "esam3_lite_mla_backward_ws (forward only)")
+    return y
+
+
 def _blockdiag(wg: torch.Tensor, gs: int) -> torch.Tensor:
     """grouped 1x1 weight [C, gs, 1, 1] (group size gs) -> the dense block-diagonal [C, C] matrix the engine's GEMM runs; pure data
     movement, on the weight's own device (a device-resident weight changes every step: rebuilt per forward)"""
@@ -309,8 +323,7 @@ class LiteMLATrain:
         agg2 = linear_forward(self.agg1, self.wg_dense)                          # grouped 1x1 as a block-diagonal GEMM
         self.ms = torch.cat([self.qkv, agg2], dim=-1).reshape(b, h * w, 6 * c).contiguous()
         self.groups = 2 * (c // self.dim)
-        zeros = torch.zeros((b, h * w, 2 * c), dtype=x.dtype, device=x.device)
-        _, att = lite_mla_backward(self.ms, zeros, self.groups, self.dim, self.eps)   # the kernel's forward output
+        att = lite_mla_forward(self.ms, self.groups, self.dim, self.eps)
         self.att = att.reshape(b, h, w, 2 * c)
         y = self.proj.forward(self.att)
         return (x.float() + y.float()).to(x.dtype)

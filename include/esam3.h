@@ -246,7 +246,8 @@ int esam3_lite_mla_backward(int dtype, const void* ms_dev, const void* dout_dev,
                             int dim, float eps, void* hip_stream);
 /* the same with the tokens split over several workgroups per (image, head group) and the two small matrices summed in a fixed order
  * (round 5: 128 - 256 workgroups walking up to 3969 tokens three times were 24 % of a training step); workspace_dev holds
- * esam3_lite_mla_backward_workspace(B, N, groups, dim) bytes; results as esam3_lite_mla_backward up to the summation order of S / dS */
+ * esam3_lite_mla_backward_workspace(B, N, groups, dim) bytes; results as esam3_lite_mla_backward up to the summation order of S / dS.
+ * dout_dev == NULL: forward only -- y_dev receives relu_linear_att(ms), dms_dev is not touched (the training-mode forward of LiteMLA) */
 int64_t esam3_lite_mla_backward_workspace(int B, int N, int groups, int dim);
 int esam3_lite_mla_backward_ws(int dtype, const void* ms_dev, const void* dout_dev, void* dms_dev, void* y_dev, int B, int N, int groups,
                                int dim, float eps, void* workspace_dev, void* hip_stream);

@@ -221,6 +221,8 @@ def test_lite_mla_backward_vs_autograd(mode, B, N, G, dim):
     yr.backward(dout.float().permute(0, 2, 1).contiguous())
     dref = qkv.grad.reshape(B, G * 3 * dim, N).permute(0, 2, 1)
     dms, y = tb.lite_mla_backward(ms.cuda().contiguous(), dout.cuda().contiguous(), G, dim)
+    y_fwd = tb.lite_mla_forward(ms.cuda().contiguous(), G, dim)          # the forward-only entry (dout = NULL)
+    _close(y_fwd, y.float().cpu(), mode, "forward-only y vs the backward kernels' y", 1e-5, 1e-5) if mode == "f32" else _close_l2(y_fwd, y.float().cpu(), "y fwd", 1e-2)
     if mode == "f32":
         _close(y, yr.detach().permute(0, 2, 1), mode, "y", 2e-4)
         _close(dms, dref, mode, "d_ms", 5e-4)

@@ -81,6 +81,7 @@ def cpu_kernels(monkeypatch):
     monkeypatch.setattr(tb, "bn_train_forward", bn_fwd)
     monkeypatch.setattr(tb, "bn_train_backward", bn_bwd)
     monkeypatch.setattr(tb, "lite_mla_backward", mla_bwd)
+    monkeypatch.setattr(tb, "lite_mla_forward", lambda ms, groups, dim, eps=1e-15: mla_bwd(ms, torch.zeros(ms.shape[0], ms.shape[1], groups * dim), groups, dim, eps)[1])
 
 
 def _bn(h, gamma, beta):
