@@ -1,5 +1,5 @@
 """A/B of the API-level step's host pipeline in ONE process (box-to-box spread is larger than the effects): first encode chunk
-(half / quarter of the batch) x device-to-host mask copy in 1 / 4 pieces.   python tools/api_ab.py"""
+(half / quarter of the batch) x device-to-host mask copy in 1 / 4 pieces.  (Round 5 also tried the second chunk's staged H2D in pieces of 8 images, each sent as soon as it was staged: no difference, 15.8 vs 15.8 ms -- profiles/r05/api_ab_h2d_pieces.txt.)   python tools/api_ab.py"""
 import os
 import sys
 import time
@@ -31,8 +31,8 @@ def step():
 
 ref = None
 for rnd in range(2):
-    for frac in (0.5, 0.25, 0.125):
-        for chunks in (1, 4):
+    for frac in (0.5, 0.25):
+        for chunks, piece in ((1, 0), (4, 0)):
             proc.first_chunk_fraction, SI.D2H_CHUNKS = frac, chunks
             for _ in range(3):
                 out = step()
@@ -45,4 +45,4 @@ for rnd in range(2):
                 out = step()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 8
-            print(f"round {rnd}: first chunk {frac:5.3f}, D2H pieces {chunks}: {dt * 1e3:6.2f} ms = {B / dt:5.0f} images/s", flush=True)
+            print(f"round {rnd}: first chunk {frac:5.3f}, D2H pieces {chunks}, H2D piece {piece}: {dt * 1e3:6.2f} ms = {B / dt:5.0f} images/s", flush=True)
