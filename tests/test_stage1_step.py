@@ -301,17 +301,18 @@ def test_bf16_training_step_inside_the_reference_autocast_yardstick(step_gold):
         assert abs(loss - r32["losses"][step]) <= lim_l and abs(norm - r32["grad_norms"][step]) <= lim_n
 
 
-@pytest.mark.xfail(strict=False, reason="OPEN (round 5): EfficientViT-B2 runs through the trainer, but the seeded random-init B2 at 1008^2 is an ILL-CONDITIONED "
-                                        "fixture: the fp32 HIP trunk and the same composition on torch stand-ins (tools/trunk_train_layer_diff.py, "
-                                        "profiles/r05/layer_diff_b2.txt) agree to 1e-6 after the stem and drift apart by 2 - 3 x per stage-4 block to 2.7e-3 after "
-                                        "the last one (loss 601.9367 vs 602.0063, total gradient norm 346 695 vs 232 970); the host emulation reproduces the "
-                                        "reference only because it runs the reference's own CPU kernels.  A B2 fixture needs a better-conditioned initialisation")
 def test_b2_training_step_matches_the_reference_run():
     """EfficientViT-B2 (EV-L: widths 24 .. 384, LiteMLA heads of dim 32, 1 + 3 + 4 + 4 + 6 blocks) through the same trainer: the first
     iteration of the REAL reference stack (oracle/gen_golden_stage1_step.py --model b2 -> tests/golden/stage1/step_b2.*) -- loss,
     total gradient norm, every parameter's clipped gradient (samples) and every parameter after the update.  (A randomly initialised
     B2 at 1008^2 has a gradient norm of 2.3e5 that its own bf16-autocast run moves to 1.1e6: the second step of that run is not a
-    fixture worth holding anything to, see the B1 test's note on step 2.)"""
+    fixture worth holding anything to, see the B1 test's note on step 2.)
+
+    History (round 5): with the one-workgroup LiteMLA backward -- every element of S and dS one fp32 chain over all 1024 - 3969 tokens --
+    this test FAILED (loss 601.9367 vs 602.0063, gradient norm 346 695 vs 232 970) and tools/trunk_train_layer_diff.py showed the forward
+    drifting from a torch stand-in run by 2 - 3 x per stage-4 block (profiles/r05/layer_diff_b2.txt): B2 at random initialisation
+    amplifies summation error.  The token-split kernels (256-token partial sums combined in a fixed order, a shorter and more accurate
+    summation) brought it inside the limits; the margins are printed."""
     from efficientsam3_amd.stage1_train import Stage1Trainer
     with open(os.path.join(GOLD, "step_b2_manifest.json")) as f:
         man = json.load(f)
