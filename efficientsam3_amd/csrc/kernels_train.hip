@@ -12,6 +12,8 @@
 //   esam3_dwconv_wgrad                 depthwise 3x3 | 5x5 weight gradient, stride 1 | 2, padding k / 2
 //   esam3_dwconv_dgrad                 depthwise 3x3 | 5x5 data gradient, stride 1 | 2 (for stride 2 a transposed convolution)
 //   esam3_lite_mla_backward            backward of LiteMLA's ReLU linear attention core (and its forward output for free)
+//   esam3_channel_scale / esam3_batched_coldot   the per-channel scale / shift and the per-image channel reductions RepViT's RepVGGDW and
+//                                      SqueezeExcite need forwards and backwards (sam3/backbones/repvit.py:84-161; timm SqueezeExcite)
 // The data gradient of a 1x1 conv needs no new kernel: it is esam3_op_linear with the transposed weight.
 #include <hip/hip_runtime.h>
 
@@ -60,6 +62,7 @@ __device__ __forceinline__ float act_fwd(float x, int act) {
     case ACT_RELU: return x > 0.f ? x : 0.f;
     case ACT_GELU: return gelu_fast(x);
     case ACT_HSWISH: return x * fminf(fmaxf(x + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    case ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
     default: return x;
   }
 }
@@ -74,6 +77,10 @@ __device__ __forceinline__ float act_grad(float x, int act) {
     // torch (ATen cpu/Activation.cpp hardswish_backward): 0 for x <= -3, x / 3 + 1 / 2 inside, 1 for x >= 3 (the CUDA kernel puts
     // the two boundary points on the other side; a set of measure zero)
     case ACT_HSWISH: return x <= -3.f ? 0.f : (x >= 3.f ? 1.f : (2.f * x + 3.f) * (1.f / 6.f));
+    case ACT_SIGMOID: {
+      const float sg = 1.f / (1.f + __expf(-x));
+      return sg * (1.f - sg);
+    }
     default: return 1.f;
   }
 }
@@ -225,6 +232,92 @@ __global__ __launch_bounds__(256) void colsum_kernel(const typename TElem<DT>::t
     else s += __uint_as_float((uint32_t)dy[r * ldy + c] << 16);
   }
   partial[(int64_t)blockIdx.y * N + c] = s;
+}
+
+// ---- per-channel scale / shift of an NHWC tensor, the elementwise half of RepViT's RepVGGDW and SqueezeExcite (round 5) ------------------
+//   out[b][p][c] = add[b][p][c] + x[b][p][c] * (mul[b * mul_bs + c] + plus_one) + bias[b * bias_bs + c] * bias_scale
+// mul / bias fp32, per channel (batch stride 0) or per (image, channel) (batch stride C); add and bias optional.  What it stands for:
+//   RepVGGDW forward   (repvit.py:92-93)  s = conv_bn(x) + conv1(x) + x          add = conv_bn(x), mul = conv1.weight, +1, bias = conv1.bias
+//   RepVGGDW backward                     dx = dx_conv + ds * (conv1.weight + 1)
+//   SqueezeExcite forward (timm)          y = x * gate[b][c]
+//   SqueezeExcite backward                dx = dy * gate[b][c] + d_mean[b][c] / HW  (the mean's share of every pixel)
+template <int DT>
+__global__ __launch_bounds__(256) void channel_scale_kernel(const typename TElem<DT>::type* __restrict__ x, const float* __restrict__ mul, int mul_bs,
+                                                            float plus_one, const float* __restrict__ bias, int bias_bs, float bias_scale,
+                                                            const typename TElem<DT>::type* __restrict__ add,
+                                                            typename TElem<DT>::type* __restrict__ out, int64_t per_image8, int C8, int64_t total8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / per_image8;
+    const int c = (int)(i % C8) * 8;
+    float v[8], a[8], o[8];
+    TElem<DT>::load8(x + i * 8, v);
+    if (add) TElem<DT>::load8(add + i * 8, a);
+    const float* m = mul + b * mul_bs + c;
+    const float* bi = bias ? bias + b * bias_bs + c : nullptr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float r = v[e] * (m[e] + plus_one);
+      if (add) r += a[e];
+      if (bi) r += bi[e] * bias_scale;
+      o[e] = r;
+    }
+    TElem<DT>::store8(out + i * 8, o);
+  }
+}
+
+// ---- out[b][c] = scale * sum over the HW pixels of image b of a[b][p][c] * (b2 ? b2[b][p][c] : 1) -----------------------------------------
+// SqueezeExcite's global mean (b2 = NULL, scale = 1 / HW), the gradient of its gate (sum of dy * x), and with B = 1 the gradient of
+// RepVGGDW's depthwise 1x1 weight (sum over all rows of ds * x).  grid = (splits, B); a workgroup = (256 / C8) row lanes x C8 groups of 8
+// channels; row lanes are summed through LDS and the splits by coldot_reduce_kernel, both in a fixed order (deterministic).
+template <int DT>
+__global__ __launch_bounds__(256) void batched_coldot_kernel(const typename TElem<DT>::type* __restrict__ a,
+                                                             const typename TElem<DT>::type* __restrict__ b2, int64_t HW, int C,
+                                                             int64_t rows_per_split, float* __restrict__ partial /* [split][B][C] */) {
+  __shared__ float red[256 * 8];
+  const int C8 = C / 8, RL = 256 / C8;
+  const int cg = threadIdx.x % C8, rl = threadIdx.x / C8;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_split, r1 = r0 + rows_per_split < HW ? r0 + rows_per_split : HW;
+  const int64_t base = (int64_t)blockIdx.y * HW;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rl < RL) {
+    for (int64_t r = r0 + rl; r < r1; r += RL) {
+      float u[8], w[8];
+      TElem<DT>::load8(a + ((base + r) * C8 + cg) * 8, u);
+      if (b2) {
+        TElem<DT>::load8(b2 + ((base + r) * C8 + cg) * 8, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += u[e] * w[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += u[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(rl * C8 + cg) * 8 + e] = s[e];
+  }
+  __syncthreads();
+  if (rl == 0) {
+    float* dst = partial + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * C + cg * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = 0.f;
+      for (int q = 0; q < RL; ++q) t += red[(q * C8 + cg) * 8 + e];
+      dst[e] = t;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void coldot_reduce_kernel(const float* __restrict__ partial, int splits, int64_t n, float scale, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = fixed_order_sum(partial + i, 0, splits, n) * scale;
+}
+constexpr int COLDOT_SPLITS_MAX = 64;
+int coldot_splits(int B, int64_t HW, int C) {
+  const int RL = 256 / (C / 8);
+  const int64_t want = 1024 / B > 1 ? 1024 / B : 1;                   // >= ~1024 workgroups over the chip when the image allows it
+  const int64_t most = (HW + (int64_t)RL * 8 - 1) / ((int64_t)RL * 8);  // a split has at least 8 rows per row lane
+  int64_t sp = want < most ? want : most;
+  if (sp > COLDOT_SPLITS_MAX) sp = COLDOT_SPLITS_MAX;
+  return (int)(sp < 1 ? 1 : sp);
 }
 
 // ---- depthwise k x k weight gradient (k = 3 | 5, padding k / 2):
@@ -674,8 +767,8 @@ int wgrad_splits(int64_t M) {  // every split a whole number of 64-row tiles
 extern "C" {
 
 int esam3_act_forward(int dtype, const void* x, void* y, int64_t n, int act, void* stream) {
-  if ((dtype != 0 && dtype != 1) || !x || !y || n <= 0 || n % 8 || act < 0 || act > ACT_HSWISH) {
-    esam3_set_error("esam3_act_forward: bad argument (n a multiple of 8; act none | relu | gelu | hswish)");
+  if ((dtype != 0 && dtype != 1) || !x || !y || n <= 0 || n % 8 || act < 0 || act > ACT_SIGMOID) {
+    esam3_set_error("esam3_act_forward: bad argument (n a multiple of 8; act none | relu | gelu | hswish | sigmoid)");
     return -1;
   }
   const int64_t n8 = n / 8;
@@ -687,8 +780,8 @@ int esam3_act_forward(int dtype, const void* x, void* y, int64_t n, int act, voi
 }
 
 int esam3_act_backward(int dtype, const void* x, const void* dy, void* dx, int64_t n, int act, void* stream) {
-  if ((dtype != 0 && dtype != 1) || !x || !dy || !dx || n <= 0 || n % 8 || act < 0 || act > ACT_HSWISH) {
-    esam3_set_error("esam3_act_backward: bad argument (n a multiple of 8; act none | relu | gelu | hswish)");
+  if ((dtype != 0 && dtype != 1) || !x || !dy || !dx || n <= 0 || n % 8 || act < 0 || act > ACT_SIGMOID) {
+    esam3_set_error("esam3_act_backward: bad argument (n a multiple of 8; act none | relu | gelu | hswish | sigmoid)");
     return -1;
   }
   const int64_t n8 = n / 8;
@@ -750,6 +843,48 @@ int esam3_colsum(int dtype, const void* dy, int64_t M, int N, float* out, void* 
   if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<0>, g2, dim3(256), 0, s, (const float*)dy, N, M, N, rps, pb);
   else hipLaunchKernelGGL(colsum_kernel<1>, g2, dim3(256), 0, s, (const uint16_t*)dy, N, M, N, rps, pb);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, pb, zs, (int64_t)N, out);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_channel_scale(int dtype, const void* x, const float* mul, int mul_per_image, float plus_one, const float* bias, int bias_per_image,
+                        float bias_scale, const void* add, void* out, int B, int64_t HW, int C, void* stream) {
+  if ((dtype != 0 && dtype != 1) || !x || !mul || !out || B <= 0 || HW <= 0 || C <= 0 || C % 8) {
+    esam3_set_error("esam3_channel_scale: bad argument (fp32 / bf16; C a multiple of 8)");
+    return -1;
+  }
+  const int C8 = C / 8;
+  const int64_t per_image8 = HW * C8, total8 = per_image8 * B;
+  const unsigned grid = (unsigned)(total8 / 256 + 1 < 16384 ? total8 / 256 + 1 : 16384);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == 0)
+    hipLaunchKernelGGL(channel_scale_kernel<0>, dim3(grid), dim3(256), 0, s, (const float*)x, mul, mul_per_image ? C : 0, plus_one, bias,
+                       bias_per_image ? C : 0, bias_scale, (const float*)add, (float*)out, per_image8, C8, total8);
+  else
+    hipLaunchKernelGGL(channel_scale_kernel<1>, dim3(grid), dim3(256), 0, s, (const uint16_t*)x, mul, mul_per_image ? C : 0, plus_one, bias,
+                       bias_per_image ? C : 0, bias_scale, (const uint16_t*)add, (uint16_t*)out, per_image8, C8, total8);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int64_t esam3_batched_coldot_workspace(int B, int C) { return B > 0 && C > 0 ? (int64_t)sizeof(float) * COLDOT_SPLITS_MAX * B * C : 0; }
+
+int esam3_batched_coldot(int dtype, const void* a, const void* b2, int B, int64_t HW, int C, float scale, float* out, void* workspace,
+                         void* stream) {
+  if ((dtype != 0 && dtype != 1) || !a || !out || !workspace || B <= 0 || B > 65535 || HW <= 0 || C <= 0 || C % 8 || C > 2048) {
+    esam3_set_error("esam3_batched_coldot: bad argument (fp32 / bf16; C a multiple of 8, at most 2048; B at most 65535)");
+    return -1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int splits = coldot_splits(B, HW, C);
+  const int64_t rps = (HW + splits - 1) / splits;
+  const int used = (int)((HW + rps - 1) / rps);
+  float* partial = (float*)workspace;
+  const dim3 grid((unsigned)used, (unsigned)B);
+  if (dtype == 0) hipLaunchKernelGGL(batched_coldot_kernel<0>, grid, dim3(256), 0, s, (const float*)a, (const float*)b2, HW, C, rps, partial);
+  else hipLaunchKernelGGL(batched_coldot_kernel<1>, grid, dim3(256), 0, s, (const uint16_t*)a, (const uint16_t*)b2, HW, C, rps, partial);
+  const int64_t n = (int64_t)B * C;
+  hipLaunchKernelGGL(coldot_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, partial, used, n, scale, out);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

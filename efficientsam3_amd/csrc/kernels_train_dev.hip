@@ -8,6 +8,7 @@
 //   esam3_train_linear     1x1 conv / Linear (and its data gradient: `transpose`), esam3_launch_gemm
 //   esam3_train_conv3x3    dense 3x3 conv, padding 1 (the student head's second conv, stage1/model.py:197-200) and its data
 //                          gradient (the same conv with the 180-degree-rotated, channel-transposed weight)
+//   esam3_train_conv3x3_s2 the same conv with stride 2 (RepViT patch embedding, forward only; see there)
 //   esam3_train_dwconv     depthwise k x k
 //   esam3_train_stem       the 3 -> C0 stride-2 stem conv on the fp32 NCHW image
 //   esam3_resize_bilinear_backward   adjoint of F.interpolate(bilinear, align_corners=False) (stage1/model.py:205-210)
@@ -170,6 +171,25 @@ int esam3_train_conv3x3(int dtype, const void* x, const float* w, const float* b
   p.A = x; p.Wt = ws; p.bias = bias; p.out = out; p.M = (int64_t)B * H * W; p.N = Cout; p.K = K; p.Kp = esam3_gemm_pad_k(K, esz);
   p.H = H; p.W = W; p.Cin = Cin; p.ksize = 3; p.lda = Cin; p.ldc = Cout; p.ldr = Cout; p.act = ACT_NONE; p.res_after_act = 1;
   p.korder = esam3_conv_korder(Cin, 3, esz);
+  return esam3_launch_gemm(dtype, p, s);
+}
+
+// Round 5 (RepViT students): the patch embedding's second conv is a dense 3x3 with STRIDE 2 (repvit.py:229-230 Conv2d_BN(C/2, C, 3, 2, 1)):
+// the same implicit GEMM with GemmParams::stride = 2; out [B][ceil(H/2)][ceil(W/2)][Cout].  Its data gradient is esam3_train_conv3x3
+// (dgrad = 1) on dy spread over the even pixels of a zero H x W grid, its weight gradient nine esam3_linear_wgrad calls on strided views
+// (efficientsam3_amd/train_blocks.py: Conv3x3S2Train).
+int esam3_train_conv3x3_s2(int dtype, const void* x, const float* w, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
+                           void* ws, void* stream) {
+  if ((dtype != 0 && dtype != 1) || !x || !w || !out || !ws || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0)
+    return bad("esam3_train_conv3x3_s2");
+  hipStream_t s = (hipStream_t)stream;
+  const int esz = dtype == 0 ? 4 : 2;
+  const int K = Cin * 9;
+  if (pack_gemm(dtype, w, ws, Cout, K, 2, Cin, s)) return -1;
+  GemmParams p{};
+  p.A = x; p.Wt = ws; p.bias = bias; p.out = out; p.M = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2); p.N = Cout; p.K = K;
+  p.Kp = esam3_gemm_pad_k(K, esz); p.H = H; p.W = W; p.Cin = Cin; p.ksize = 3; p.lda = Cin; p.ldc = Cout; p.ldr = Cout; p.act = ACT_NONE;
+  p.res_after_act = 1; p.korder = esam3_conv_korder(Cin, 3, esz); p.stride = 2;
   return esam3_launch_gemm(dtype, p, s);
 }
 

@@ -1,4 +1,4 @@
-"""One stage-1 distillation TRAINING STEP of an EfficientViT student on the HIP kernels.
+"""One stage-1 distillation TRAINING STEP of an EfficientViT or RepViT student on the HIP kernels.
 
 Reference: ``stage1/train_image_encoder_stage1.py:165-226`` (``train_one_epoch``: ``model.train()`` -> forward of
 ``ImageStudentEncoder`` (``stage1/model.py:188-211``: backbone -> Conv1x1 + BatchNorm + GELU -> Conv3x3 -> bilinear resize to the
@@ -37,6 +37,11 @@ _DT = {torch.float32: 0, torch.bfloat16: 1}
 # depth_list, dim of the LiteMLA heads)
 EFFICIENTVIT = {"b0": ([8, 16, 32, 64, 128], [1, 2, 2, 2, 2], 16), "b1": ([16, 32, 64, 128, 256], [1, 2, 3, 3, 4], 16),
                 "b2": ([24, 48, 96, 192, 384], [1, 3, 4, 4, 6], 32)}
+
+
+# the RepViT students RV-S / RV-M / RV-L (stage1/model.py:386-395: MODEL.BACKBONE repvit_m0_9 | repvit_m1_1 | repvit_m2_3) -> the key of
+# schema.REPVIT_CFG; layers in train_repvit.py
+REPVIT = {"repvit_m0_9": "m0.9", "repvit_m1_1": "m1.1", "repvit_m2_3": "m2.3"}
 
 
 def _stream():
@@ -139,7 +144,7 @@ class HeadTrain:
 
 
 class Stage1Trainer:
-    """A stage-1 student (EfficientViT-B0 / B1 backbone + head) that trains: ``step(images, teacher, sizes_before_pad)`` is one
+    """A stage-1 student (EfficientViT-B0 / B1 / B2 or RepViT-M0.9 / M1.1 / M2.3 backbone + head) that trains: ``step(images, teacher, sizes_before_pad)`` is one
     iteration of ``train_one_epoch`` (module docstring).  ``state_dict`` is the reference ``ImageStudentEncoder``'s
     (``backbone.model.<EfficientViTBackbone keys>``, ``head.*``), BatchNorm buffers included; ``state_dict()`` returns it back (fp32, host)."""
 
@@ -151,7 +156,10 @@ class Stage1Trainer:
         self.device = torch.device(device)
         tb.DEVICE = str(self.device)
         self.tdtype = {"f32": torch.float32, "bf16": torch.bfloat16}[dtype]
-        self.widths, self.depths, self.dim = EFFICIENTVIT[model_name]
+        if model_name not in EFFICIENTVIT and model_name not in REPVIT:
+            raise ValueError(f"stage-1 student {model_name!r}: the trainer covers {sorted(EFFICIENTVIT) + sorted(REPVIT)} "
+                             "(the TinyViT students are not built)")
+        self.model_name = model_name
         self.embed_size, self.cosine_weight, self.accumulation_steps = embed_size, float(cosine_weight), int(accumulation_steps)
         is_buffer = lambda k: k.endswith(("running_mean", "running_var", "num_batches_tracked"))  # noqa: E731
         named_shapes = [(k, tuple(v.shape)) for k, v in state_dict.items() if not is_buffer(k)]
@@ -165,7 +173,12 @@ class Stage1Trainer:
         self.batches_tracked = {k: int(v) for k, v in state_dict.items() if k.endswith("num_batches_tracked")}
         views = {name: self.updater.param(name) for name, _ in named_shapes}
         views.update(self.buffers)
-        self.trunk = tb.EfficientViTTrunkTrain(views, self.widths, self.depths, self.dim, dtype=self.tdtype, prefix="backbone.model.")
+        if model_name in EFFICIENTVIT:
+            self.widths, self.depths, self.dim = EFFICIENTVIT[model_name]
+            self.trunk = tb.EfficientViTTrunkTrain(views, self.widths, self.depths, self.dim, dtype=self.tdtype, prefix="backbone.model.")
+        else:
+            from .train_repvit import RepViTTrunkTrain
+            self.trunk = RepViTTrunkTrain(views, REPVIT[model_name], dtype=self.tdtype, prefix="backbone.model.")
         for _, layer in self.trunk.norm_layers():
             layer.momentum = bn_momentum
         self.head = HeadTrain(views, embed_size)

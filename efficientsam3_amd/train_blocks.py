@@ -18,7 +18,7 @@ import torch
 from . import _lib
 from .stage1 import bn_train_backward, bn_train_forward
 
-ACT = {None: 0, "relu": 1, "gelu": 2, "hswish": 3}
+ACT = {None: 0, "relu": 1, "gelu": 2, "hswish": 3, "sigmoid": 4}
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 DEVICE = "cuda"   # where the block classes keep their BatchNorm parameters (the host-logic test runs the compositions on "cpu" doubles)
 
@@ -132,6 +132,40 @@ def colsum(dy: torch.Tensor) -> torch.Tensor:
     ws = torch.empty(int(lib.esam3_colsum_workspace(m, n)), dtype=torch.uint8, device=dy.device)
     with torch.cuda.device(dy.device):
         _lib.check(lib.esam3_colsum(_DT[dy.dtype], dy.data_ptr(), m, n, out.data_ptr(), ws.data_ptr(), _stream()), "esam3_colsum")
+    return out
+
+
+def channel_scale(x: torch.Tensor, mul: torch.Tensor, bias: torch.Tensor = None, add: torch.Tensor = None, plus_one: bool = False,
+                  bias_scale: float = 1.0) -> torch.Tensor:
+    """out = add + x * (mul [+ 1]) + bias * bias_scale on x [B, ..., C]; mul / bias device fp32, [C] (per channel) or [B, C] (per image and
+    channel); the elementwise half of RepVGGDW and SqueezeExcite, forwards and backwards (``esam3_channel_scale``)"""
+    b, c = x.shape[0], x.shape[-1]
+    hw = x.numel() // (b * c)
+    assert x.is_contiguous() and (add is None or (add.shape == x.shape and add.dtype == x.dtype and add.is_contiguous()))
+    for t in (mul, bias):
+        assert t is None or (tuple(t.shape) in ((c,), (b, c)) and _dev_f32(t) is t)
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().esam3_channel_scale(_DT[x.dtype], x.data_ptr(), mul.data_ptr(), int(mul.dim() == 2), 1.0 if plus_one else 0.0,
+                                                   None if bias is None else bias.data_ptr(), int(bias is not None and bias.dim() == 2),
+                                                   float(bias_scale), None if add is None else add.data_ptr(), out.data_ptr(), b, hw, c, _stream()),
+                   "esam3_channel_scale")
+    return out
+
+
+def batched_coldot(a: torch.Tensor, b2: torch.Tensor = None, scale: float = 1.0, per_image: bool = True) -> torch.Tensor:
+    """[B, C] fp32 (``per_image``) or [C]: scale * the sum over the pixels (of each image | of all images) of a * b2 (of a when ``b2`` is
+    None) for a [B, ..., C] (``esam3_batched_coldot``)"""
+    c = a.shape[-1]
+    b = a.shape[0] if per_image else 1
+    hw = a.numel() // (b * c)
+    assert a.is_contiguous() and (b2 is None or (b2.shape == a.shape and b2.dtype == a.dtype and b2.is_contiguous()))
+    lib = _lib.load()
+    out = torch.empty((b, c) if per_image else (c,), dtype=torch.float32, device=a.device)
+    ws = torch.empty(int(lib.esam3_batched_coldot_workspace(b, c)), dtype=torch.uint8, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.esam3_batched_coldot(_DT[a.dtype], a.data_ptr(), None if b2 is None else b2.data_ptr(), b, hw, c, float(scale), out.data_ptr(),
+                                            ws.data_ptr(), _stream()), "esam3_batched_coldot")
     return out
 
 

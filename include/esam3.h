@@ -219,7 +219,8 @@ int esam3_distill_loss_backward(int preds_dtype, const void* preds_dev, int teac
  * 264-360: Conv2d without bias -> BatchNorm2d -> activation), NHWC rows, dtype 0 fp32 / 1 bf16 activations and gradients, fp32
  * weight gradients.  Building blocks of the student-trunk backward of stage 1 (stage1/train_image_encoder_stage1.py:196-217), which as a
  * whole is not built; tests/test_train_blocks.py composes them into an MBConv block and checks every gradient against autograd.
- *   esam3_act_forward / _backward: y = act(x), dx = dy * act'(x); act 0 none, 1 ReLU, 2 GELU (erf), 3 Hardswish; n % 8 == 0.
+ *   esam3_act_forward / _backward: y = act(x), dx = dy * act'(x); act 0 none, 1 ReLU, 2 GELU (erf), 3 Hardswish, 4 sigmoid
+ *     (the SqueezeExcite gate of the RepViT students); n % 8 == 0.
  *   esam3_linear_wgrad: dw[N][K] = sum_rows dy[row][n] * x[row][k] (the weight gradient of a 1x1 conv / Linear with weight
  *     [N][K]; the M rows are the reduction: split over the rows, fp32 partial tiles summed in a fixed order), dbias[N] = sum_rows dy
  *     (NULL to skip).  N % 8 == 0, K % 8 == 0.  workspace: esam3_linear_wgrad_workspace(M, N, K) bytes.
@@ -235,6 +236,20 @@ int esam3_linear_wgrad(int dtype, const void* dy_dev, const void* x_dev, int64_t
  * EfficientViTBlock, ops.py:704-711 use_bias=(True, True, False), norm=(None, None, bn2d)); workspace: esam3_colsum_workspace(M, N) bytes */
 int64_t esam3_colsum_workspace(int64_t M, int N);
 int esam3_colsum(int dtype, const void* dy_dev, int64_t M, int N, float* out_dev, void* workspace_dev, void* hip_stream);
+/* Per-channel scale / shift and per-image channel reductions: the elementwise and reduction halves of the two RepViT layers that are not
+ * plain convolutions, forwards and backwards (round 5: RepViT students of stage 1, stage1/model.py:386-395) --
+ * RepVGGDW (sam3/backbones/repvit.py:84-93: bn(conv_bn(x) + conv1(x) + x), conv1 a depthwise 1x1 with bias) and timm's SqueezeExcite
+ * (repvit.py:136,150: x * sigmoid(fc2(relu(fc1(mean_hw(x)))))).  x / add / out [B][HW][C] in dtype, mul / bias / out of the reduction fp32.
+ *   esam3_channel_scale: out = add + x * (mul[(b,) c] + plus_one) + bias[(b,) c] * bias_scale; mul / bias are [C], or [B][C] when
+ *     mul_per_image / bias_per_image; add and bias may be NULL.  C % 8 == 0.
+ *   esam3_batched_coldot: out[b][c] = scale * sum over the HW pixels of a[b][p][c] * (b2 ? b2[b][p][c] : 1): the SE mean (b2 NULL,
+ *     scale 1 / HW), the gate's gradient (sum dy x), and with B = 1 the depthwise-1x1 weight gradient (sum over all rows of ds x).
+ *     Fixed summation order (deterministic).  C % 8 == 0, C <= 2048; workspace: esam3_batched_coldot_workspace(B, C) bytes. */
+int esam3_channel_scale(int dtype, const void* x_dev, const float* mul_dev, int mul_per_image, float plus_one, const float* bias_dev,
+                        int bias_per_image, float bias_scale, const void* add_dev, void* out_dev, int B, int64_t HW, int C, void* hip_stream);
+int64_t esam3_batched_coldot_workspace(int B, int C);
+int esam3_batched_coldot(int dtype, const void* a_dev, const void* b2_dev, int B, int64_t HW, int C, float scale, float* out_dev,
+                         void* workspace_dev, void* hip_stream);
 int64_t esam3_dwconv_wgrad_workspace(int C);
 int esam3_dwconv_wgrad(int dtype, const void* x_dev, const void* dy_dev, int B, int H, int W, int C, int ksize, int stride,
                        float* dw_dev, void* workspace_dev, void* hip_stream);
@@ -275,6 +290,11 @@ int esam3_train_linear(int dtype, const void* x_dev, const float* w_dev, const f
                        int transpose, void* workspace_dev, void* hip_stream);
 int esam3_train_conv3x3(int dtype, const void* x_dev, const float* w_dev, const float* bias_dev, void* out_dev, int B, int H, int W,
                         int Cin, int Cout, int dgrad, void* workspace_dev, void* hip_stream);
+/* the dense 3x3 (padding 1) with STRIDE 2: the second conv of RepViT's patch embedding (sam3/backbones/repvit.py:229-230), forward only
+ * -- out [B][ceil(H/2)][ceil(W/2)][Cout]; workspace esam3_train_pack_bytes(dtype, Cout, 9 Cin).  Its data gradient is
+ * esam3_train_conv3x3(dgrad = 1) on dy spread over the even pixels of a zero H x W grid, its weight gradient esam3_linear_wgrad per tap. */
+int esam3_train_conv3x3_s2(int dtype, const void* x_dev, const float* w_dev, const float* bias_dev, void* out_dev, int B, int H, int W,
+                           int Cin, int Cout, void* workspace_dev, void* hip_stream);
 int esam3_train_dwconv(int dtype, const void* x_dev, const float* w_dev, const float* bias_dev, void* out_dev, int B, int H, int W, int C,
                        int ksize, int stride, void* workspace_dev, void* hip_stream);
 /* dx [B][H][W][C] of the depthwise conv above from dy [B][ceil(H/s)][ceil(W/s)][C] (autograd's conv backward for the student's

@@ -21,7 +21,8 @@ from itself).
     PYTHONDONTWRITEBYTECODE=1 CUDA_VISIBLE_DEVICES="" HIP_VISIBLE_DEVICES="" \
     PYTHONPATH=oracle/shims:/root/reference:. python oracle/gen_golden_stage1_step.py     (the OUTER sam3 package: stage1/model.py imports sam3.sam3.*)
 
-Output: tests/golden/stage1/step.npz + step_manifest.json (`--model b2`: step_b2.npz + step_b2_manifest.json, round 5)
+Output: tests/golden/stage1/step.npz + step_manifest.json (`--model b2`: step_b2.npz + step_b2_manifest.json, round 5;
+`--model repvit_m0_9` / `repvit_m1_1`: step_repvit_m0_9.* / step_repvit_m1_1.*, the RepViT students of stage1/model.py:386-395)
 """
 from __future__ import annotations
 
@@ -53,10 +54,19 @@ NSAMP = 256
 
 
 MODEL = "b1"          # --model b0 | b1 | b2 (the default b1 writes step.npz / step_manifest.json, the others step_<model>.*)
+                      # | repvit_m0_9 | repvit_m1_1 | repvit_m2_3 (round 5: the RepViT students, stage1/model.py:386-395)
+
+
+def _family():
+    """(schema backbone type, schema model name, MODEL.BACKBONE of the reference's config)"""
+    if MODEL.startswith("repvit_"):
+        return "repvit", MODEL[len("repvit_"):].replace("_", "."), MODEL
+    return "efficientvit", MODEL, f"efficientvit_{MODEL}"
 
 
 def student_state_dict():
-    sd = schema.synthetic_state_dict("efficientvit", MODEL, seed=0)
+    family, name, _ = _family()
+    sd = schema.synthetic_state_dict(family, name, seed=0)
     return {k[len(PREFIX):]: v.clone() for k, v in sd.items() if k.startswith(PREFIX)}
 
 
@@ -89,7 +99,7 @@ def run(amp: bool):
     import model as ref_model            # stage1/model.py
     import optimizer as ref_optimizer    # stage1/optimizer.py
     ref = reference_functions()
-    cfg = SimpleNamespace(MODEL=SimpleNamespace(BACKBONE=f"efficientvit_{MODEL}"), DATA=SimpleNamespace(IMG_SIZE=IMG),
+    cfg = SimpleNamespace(MODEL=SimpleNamespace(BACKBONE=_family()[2]), DATA=SimpleNamespace(IMG_SIZE=IMG),
                           DISTILL=SimpleNamespace(EMBED_DIM=EMBED_DIM, EMBED_SIZE=EMBED_SIZE, COSINE=HYPER["cosine"]),
                           TRAIN=SimpleNamespace(OPTIMIZER=SimpleNamespace(NAME="adamw", EPS=HYPER["eps"], BETAS=HYPER["betas"], MOMENTUM=0.9),
                                                 BASE_LR=HYPER["lr"], WEIGHT_DECAY=HYPER["weight_decay"], CLIP_GRAD=HYPER["clip_grad"],
@@ -142,7 +152,7 @@ def main():
     global MODEL
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="b1", choices=["b0", "b1", "b2"])
+    ap.add_argument("--model", default="b1", choices=["b0", "b1", "b2", "repvit_m0_9", "repvit_m1_1", "repvit_m2_3"])
     MODEL = ap.parse_args().model
     suffix = "" if MODEL == "b1" else f"_{MODEL}"
     os.makedirs(GOLD, exist_ok=True)

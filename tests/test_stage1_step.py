@@ -23,6 +23,7 @@ DTS = {"f32": torch.float32, "bf16": torch.bfloat16}
 # the five next-worst tensors are printed by the test.  The noise-only tensors (analytically zero gradient) reach 7.1e-6 of the network's
 # largest gradient: GRAD_ABS = 3.5 x that (it was 1e-4).  GRAD_REL stays at 1.5 x the achieved worst.
 GRAD_REL, GRAD_ABS = 2.5e-2, 2.5e-5
+RV_GRAD_REL, RV_GRAD_ABS = 5e-2, 1e-4      # the RepViT students (round 5): the B2 allowance until their margins are on record (printed)
 B2_GRAD_REL, B2_GRAD_ABS = 5e-2, 1e-4      # EfficientViT-B2: 35 x larger gradients through a deeper chain of training-mode BatchNorms
 
 
@@ -301,6 +302,69 @@ def test_bf16_training_step_inside_the_reference_autocast_yardstick(step_gold):
         assert abs(loss - r32["losses"][step]) <= lim_l and abs(norm - r32["grad_norms"][step]) <= lim_n
 
 
+def _first_step_vs_reference(model, suffix, sd, grad_rel, grad_abs, second_step=None, check_buffers=False):
+    """the first iteration of the trainer (fp32) against the reference stack's own run (tests/golden/stage1/step_<suffix>.*): loss, total
+    gradient norm, every parameter's clipped gradient (samples), every parameter after the update; ``second_step`` = (loss rel, norm rel):
+    also the loss and gradient norm of a second iteration"""
+    from efficientsam3_amd.stage1_train import Stage1Trainer
+    with open(os.path.join(GOLD, f"step_{suffix}_manifest.json")) as f:
+        man = json.load(f)
+    g = np.load(os.path.join(GOLD, f"step_{suffix}.npz"))
+    hy, ref, ns = man["hyper"], man["fp32"], man["samples_per_tensor"]
+    assert set(ref["names"]) == {k for k in sd if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+    tr = Stage1Trainer(sd, model, embed_size=man["embed_size"], dtype="f32", lr=hy["lr"], weight_decay=hy["weight_decay"], betas=tuple(hy["betas"]),
+                       eps=hy["eps"], clip_grad=hy["clip_grad"], amp=False, cosine_weight=hy["cosine"], accumulation_steps=hy["accumulation_steps"])
+    imgs, teacher = _inputs(man)
+    imgs, teacher = imgs.cuda(), teacher.cuda()
+    sizes = [tuple(s_) for s_ in man["sizes_before_pad"]]
+    out = tr.step(imgs, teacher, sizes, update_grad=False)
+    grads = {n: _sample(v, ns) for n, v in tr.gradients().items()}
+    tr._allreduce()
+    norm = float(tr.updater.step())
+    tr._micro = 0
+    loss = float(out["loss"])
+    clip = min(1.0, hy["clip_grad"] / (norm + 1e-6))
+    print(f"[stage-1 {model} step 1] loss {loss:.6f} (reference {ref['losses'][0]:.6f})  grad norm {norm:.3f} ({ref['grad_norms'][0]:.3f})")
+    assert abs(loss - ref["losses"][0]) <= 1e-4 * abs(ref["losses"][0])
+    assert abs(norm - ref["grad_norms"][0]) <= 1e-2 * ref["grad_norms"][0]
+    gmax = max(float(g[f"gradmax1/{n}"]) for n in ref["names"])
+    ranked, used = [], 0.0
+    for n in ref["names"]:
+        err = float(np.abs(grads[n] * clip - g[f"grad1/{n}"]).max())
+        tmax = float(g[f"gradmax1/{n}"])
+        used = max(used, err / (grad_rel * tmax + grad_abs * gmax))
+        if tmax >= 1e-3 * gmax:
+            ranked.append((err / tmax, n))
+    ranked.sort(reverse=True)
+    print(f"  gradients: largest fraction of the allowance ({grad_rel:g} x tensor max + {grad_abs:g} x network max) used = {used:.3f}; six worst "
+          "tensors (max-abs-err / tensor max): " + "; ".join(f"{r:.2e} {n}" for r, n in ranked[:6]))
+    assert used <= 1.0
+    lr, nbad, nconf = hy["lr"], 0, 0
+    params = {n: _sample(v, ns) for n, v in tr.state_dict().items() if n in ref["shapes"]}
+    for n in ref["names"]:
+        conf = np.abs(g[f"grad1/{n}"]) > 1e-3 * float(g[f"gradmax1/{n}"]) + 1e-6 * gmax
+        d = np.abs(params[n] - g[f"param1/{n}"])
+        assert d.max() <= 2.5 * lr + 1e-6, n
+        nconf += int(conf.sum()); nbad += int((d[conf] > 2e-2 * lr).sum())
+    print(f"  parameters after step 1: {nbad} of {nconf} confident samples outside 0.02 lr")
+    assert nbad <= 5e-3 * nconf, (nbad, nconf)
+    bufs = {k: v for k, v in tr.state_dict().items() if k.endswith(("running_mean", "running_var"))} if check_buffers else {}
+    worst_buf = 0.0
+    for k, v in bufs.items():
+        want = g[f"buffer1/{k}"]
+        worst_buf = max(worst_buf, float(np.abs(_sample(v, ns) - want).max()) / max(1.0, float(np.abs(want).max())))
+    print(f"  BatchNorm running statistics after step 1 ({len(bufs)} buffers): worst |diff| / max(1, |ref|) = {worst_buf:.2e}")
+    assert worst_buf <= 1e-3
+    if second_step is not None:
+        out = tr.step(imgs, teacher, sizes)
+        loss2, norm2 = float(out["loss"]), float(out["grad_norm"])
+        print(f"[stage-1 {model} step 2] loss {loss2:.6f} (reference {ref['losses'][1]:.6f}, allowed {second_step[0]:g} rel)  "
+              f"grad norm {norm2:.3f} ({ref['grad_norms'][1]:.3f}, allowed {second_step[1]:g} rel)")
+        assert abs(loss2 - ref["losses"][1]) <= second_step[0] * abs(ref["losses"][1])
+        assert abs(norm2 - ref["grad_norms"][1]) <= second_step[1] * ref["grad_norms"][1]
+    return man
+
+
 def test_b2_training_step_matches_the_reference_run():
     """EfficientViT-B2 (EV-L: widths 24 .. 384, LiteMLA heads of dim 32, 1 + 3 + 4 + 4 + 6 blocks) through the same trainer: the first
     iteration of the REAL reference stack (oracle/gen_golden_stage1_step.py --model b2 -> tests/golden/stage1/step_b2.*) -- loss,
@@ -313,44 +377,46 @@ def test_b2_training_step_matches_the_reference_run():
     drifting from a torch stand-in run by 2 - 3 x per stage-4 block (profiles/r05/layer_diff_b2.txt): B2 at random initialisation
     amplifies summation error.  The token-split kernels (256-token partial sums combined in a fixed order, a shorter and more accurate
     summation) brought it inside the limits; the margins are printed."""
-    from efficientsam3_amd.stage1_train import Stage1Trainer
-    with open(os.path.join(GOLD, "step_b2_manifest.json")) as f:
-        man = json.load(f)
-    g = np.load(os.path.join(GOLD, "step_b2.npz"))
-    hy, ref, ns = man["hyper"], man["fp32"], man["samples_per_tensor"]
     sd = schema.synthetic_state_dict("efficientvit", "b2", seed=0)
     sd = {k[len(PREFIX):]: v.clone() for k, v in sd.items() if k.startswith(PREFIX)}
-    assert set(ref["names"]) == {k for k in sd if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
-    tr = Stage1Trainer(sd, "b2", embed_size=man["embed_size"], dtype="f32", lr=hy["lr"], weight_decay=hy["weight_decay"], betas=tuple(hy["betas"]),
-                       eps=hy["eps"], clip_grad=hy["clip_grad"], amp=False, cosine_weight=hy["cosine"], accumulation_steps=hy["accumulation_steps"])
+    _first_step_vs_reference("b2", "b2", sd, B2_GRAD_REL, B2_GRAD_ABS)
+
+
+def _repvit_sd(name):
+    sd = schema.synthetic_state_dict("repvit", name, seed=0)
+    return {k[len(PREFIX):]: v.clone() for k, v in sd.items() if k.startswith(PREFIX)}
+
+
+@pytest.mark.parametrize("model,name", [("repvit_m0_9", "m0.9"), ("repvit_m1_1", "m1.1")])
+def test_repvit_training_steps_match_the_reference_run(model, name):
+    """The RepViT students (RV-S / RV-M: stage1/model.py:386-395 -> RepViTAdapter over sam3/backbones/repvit.py) through the same trainer --
+    patch embedding with its dense stride-2 3x3, RepVGGDW token mixers, SqueezeExcite in every other block, stride-2 blocks, GELU channel
+    mixers, every BatchNorm in training mode -- against the REAL reference stack's run (oracle/gen_golden_stage1_step.py --model repvit_m0_9 |
+    repvit_m1_1): first iteration as for B2 (loss, norm, every clipped gradient, every updated parameter, every running statistic), and the
+    loss and gradient norm of the second iteration (these nets are well conditioned: the reference's own bf16-autocast run moves its
+    loss by 4e-4 and its norm by 3e-4)."""
+    _first_step_vs_reference(model, model, _repvit_sd(name), RV_GRAD_REL, RV_GRAD_ABS, second_step=(2e-3, 2e-2), check_buffers=True)
+
+
+@pytest.mark.parametrize("model,name", [("repvit_m0_9", "m0.9"), ("repvit_m1_1", "m1.1")])
+def test_repvit_bf16_training_step_inside_the_reference_autocast_yardstick(model, name):
+    """the same two iterations with bf16 activations: loss and gradient norm against the reference's fp32 run, allowed 1.5 x the distance of
+    the reference's own bf16-autocast run + 1 % (loss) / 5 % (norm) of the value -- the rule of the EfficientViT-B1 test"""
+    from efficientsam3_amd.stage1_train import Stage1Trainer
+    with open(os.path.join(GOLD, f"step_{model}_manifest.json")) as f:
+        man = json.load(f)
+    hy = man["hyper"]
+    tr = Stage1Trainer(_repvit_sd(name), model, embed_size=man["embed_size"], dtype="bf16", lr=hy["lr"], weight_decay=hy["weight_decay"],
+                       betas=tuple(hy["betas"]), eps=hy["eps"], clip_grad=hy["clip_grad"], amp=False, cosine_weight=hy["cosine"])
     imgs, teacher = _inputs(man)
-    out = tr.step(imgs.cuda(), teacher.cuda(), [tuple(s) for s in man["sizes_before_pad"]], update_grad=False)
-    grads = {n: _sample(v, ns) for n, v in tr.gradients().items()}
-    tr._allreduce()
-    norm = float(tr.updater.step())
-    loss = float(out["loss"])
-    clip = min(1.0, hy["clip_grad"] / (norm + 1e-6))
-    print(f"[stage-1 B2 step 1] loss {loss:.6f} (reference {ref['losses'][0]:.6f})  grad norm {norm:.3f} ({ref['grad_norms'][0]:.3f})")
-    assert abs(loss - ref["losses"][0]) <= 1e-4 * abs(ref["losses"][0])
-    assert abs(norm - ref["grad_norms"][0]) <= 1e-2 * ref["grad_norms"][0]
-    gmax = max(float(g[f"gradmax1/{n}"]) for n in ref["names"])
-    ranked, used = [], 0.0
-    for n in ref["names"]:
-        err = float(np.abs(grads[n] * clip - g[f"grad1/{n}"]).max())
-        tmax = float(g[f"gradmax1/{n}"])
-        used = max(used, err / (B2_GRAD_REL * tmax + B2_GRAD_ABS * gmax))
-        if tmax >= 1e-3 * gmax:
-            ranked.append((err / tmax, n))
-    ranked.sort(reverse=True)
-    print(f"  gradients: largest fraction of the allowance ({B2_GRAD_REL:g} x tensor max + {B2_GRAD_ABS:g} x network max) used = {used:.3f}; six worst "
-          "tensors (max-abs-err / tensor max): " + "; ".join(f"{r:.2e} {n}" for r, n in ranked[:6]))
-    assert used <= 1.0
-    lr, nbad, nconf = hy["lr"], 0, 0
-    params = {n: _sample(v, ns) for n, v in tr.state_dict().items() if n in ref["shapes"]}
-    for n in ref["names"]:
-        conf = np.abs(g[f"grad1/{n}"]) > 1e-3 * float(g[f"gradmax1/{n}"]) + 1e-6 * gmax
-        d = np.abs(params[n] - g[f"param1/{n}"])
-        assert d.max() <= 2.5 * lr + 1e-6, n
-        nconf += int(conf.sum()); nbad += int((d[conf] > 2e-2 * lr).sum())
-    print(f"  parameters after step 1: {nbad} of {nconf} confident samples outside 0.02 lr")
-    assert nbad <= 5e-3 * nconf, (nbad, nconf)
+    imgs, teacher = imgs.cuda(), teacher.cuda().to(torch.bfloat16)
+    for step in range(2):
+        out = tr.step(imgs, teacher, [tuple(s_) for s_ in man["sizes_before_pad"]])
+        loss, norm = float(out["loss"]), float(out["grad_norm"])
+        r32, r16 = man["fp32"], man["bf16_autocast"]
+        lim_l = 1.5 * abs(r16["losses"][step] - r32["losses"][step]) + 1e-2 * abs(r32["losses"][step])
+        lim_n = 1.5 * abs(r16["grad_norms"][step] - r32["grad_norms"][step]) + 5e-2 * r32["grad_norms"][step]
+        print(f"[stage-1 {model} bf16 step {step + 1}] loss {loss:.5f} (fp32 ref {r32['losses'][step]:.5f}, ref bf16 {r16['losses'][step]:.5f}, "
+              f"allowed +-{lim_l:.4f}) grad norm {norm:.4f} ({r32['grad_norms'][step]:.4f} / {r16['grad_norms'][step]:.4f}, +-{lim_n:.4f})")
+        assert np.isfinite(loss) and np.isfinite(norm)
+        assert abs(loss - r32["losses"][step]) <= lim_l and abs(norm - r32["grad_norms"][step]) <= lim_n

@@ -1,0 +1,132 @@
+"""CPU: the HOST LOGIC of efficientsam3_amd/stage1_train.py (``Stage1Trainer``: arena views handed to the layers, head and trunk sequencing,
+gradient sink and arrival order, state-dict names, BatchNorm buffers, the update) with a RepViT student, every kernel wrapper replaced by a
+plain torch / numpy stand-in of the same contract (tests/test_train_blocks_host.py, tests/test_train_repvit_host.py, the oracle's loss and
+update), against the REAL reference stack's run of the same two iterations (tests/golden/stage1/step_repvit_m0_9.*, made by
+oracle/gen_golden_stage1_step.py --model repvit_m0_9).  The GPU twin, with the HIP kernels in place of the stand-ins, is
+tests/test_stage1_step.py::test_repvit_training_steps_match_the_reference_run."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from efficientsam3_amd import schema, stage1, stage1_train, synth
+from oracle import ref_stage1
+from tests.test_train_blocks_host import _to_nchw, _to_nhwc, cpu_kernels  # noqa: F401
+from tests.test_train_repvit_host import repvit_kernels  # noqa: F401
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stage1")
+PREFIX = "backbone.vision_backbone.trunk.model."
+
+
+class HostUpdater(stage1.Stage1Updater):
+    """the arena of Stage1Updater on the CPU; ``step`` = the oracle's update (oracle/ref_stage1.py: update_step) on views of it"""
+
+    def __init__(self, layout, device, lr=5e-4, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, clip_grad=5.0, amp=False, **_):
+        self.layout, self.device = layout, torch.device("cpu")
+        self.lr, self.weight_decay, self.betas, self.eps, self.clip_grad, self.amp = float(lr), float(weight_decay), betas, float(eps), clip_grad, False
+        z = lambda: torch.zeros(layout.n, dtype=torch.float32)  # noqa: E731
+        self.params, self.grads, self.exp_avg, self.exp_avg_sq = z(), z(), z(), z()
+        self.state = torch.zeros(16, dtype=torch.float32)
+        self.state[0] = 1.0
+        self._st = {"scale": 1.0, "tracker": 0, "step": 0}
+
+    def step(self, lr=None, zero_grads=True):
+        names = [n for n, _ in self.layout.named_shapes]
+        as_np = lambda buf: {n: self.view(buf, n).numpy() for n in names}  # noqa: E731  (views: updated in place)
+        decay = stage1.weight_decay_groups(self.layout.named_shapes)
+        norm, _ = ref_stage1.update_step(as_np(self.params), as_np(self.grads), as_np(self.exp_avg), as_np(self.exp_avg_sq), self._st, decay, {},
+                                         self.lr if lr is None else lr, self.weight_decay, self.betas, self.eps, self.clip_grad, amp=False)
+        if zero_grads:
+            self.grads.zero_()
+        self.state[3], self.state[4] = float(norm), self._st["step"]
+        return self.state[3].clone()
+
+
+@pytest.fixture
+def host_trainer(repvit_kernels, monkeypatch):  # noqa: F811
+    def loss(p2, t2, valid):          # [B, HW, C] rows -> the reference's NCHW functions on [B, C, HW, 1]
+        p, t, m = p2.permute(0, 2, 1)[..., None].float(), t2.permute(0, 2, 1)[..., None].float(), valid[:, None, :, None].float()
+        return ref_stage1.masked_mse(p, t, m), ref_stage1.masked_cosine_loss(p, t, m), None
+
+    def loss_backward(p2, t2, valid, cosine_weight=0.0, grad_scale=1.0):
+        pr = p2.clone().float().requires_grad_(True)
+        mse, cos, _ = loss(pr, t2, valid)
+        ((mse + cosine_weight * cos) * grad_scale).backward()
+        return pr.grad
+
+    def conv3x3_wgrad(dy, x):
+        wr = torch.zeros((dy.shape[-1], x.shape[-1], 3, 3), requires_grad=True)
+        F.conv2d(_to_nchw(x), wr, None, padding=1).backward(_to_nchw(dy))
+        return wr.grad
+
+    def resize_backward(dy, in_hw):
+        xr = torch.zeros((dy.shape[0], dy.shape[-1]) + tuple(in_hw), requires_grad=True)
+        F.interpolate(xr, size=tuple(dy.shape[1:3]), mode="bilinear", align_corners=False).backward(_to_nchw(dy))
+        return _to_nhwc(xr.grad)
+
+    st = stage1_train
+    monkeypatch.setattr(st, "Stage1Updater", HostUpdater)
+    monkeypatch.setattr(st, "distill_loss", loss)
+    monkeypatch.setattr(st, "distill_loss_backward", loss_backward)
+    monkeypatch.setattr(st, "conv3x3_forward", lambda x, w, bias: _to_nhwc(F.conv2d(_to_nchw(x), w, bias, padding=1)))
+    monkeypatch.setattr(st, "conv3x3_dgrad", lambda dy, w: _to_nhwc(F.conv_transpose2d(_to_nchw(dy), w, None, padding=1)))
+    monkeypatch.setattr(st, "conv3x3_wgrad", conv3x3_wgrad)
+    monkeypatch.setattr(st, "resize_forward", lambda x, size: _to_nhwc(F.interpolate(_to_nchw(x), size=(size, size), mode="bilinear", align_corners=False)))
+    monkeypatch.setattr(st, "resize_backward", resize_backward)
+
+
+def _sample(t, n):
+    flat = t.detach().float().reshape(-1)
+    step = max(1, flat.numel() // n)
+    return flat[::step][:n].numpy()
+
+
+def test_repvit_trainer_host_logic_vs_the_reference_run(host_trainer):
+    with open(os.path.join(GOLD, "step_repvit_m0_9_manifest.json")) as f:
+        man = json.load(f)
+    g = np.load(os.path.join(GOLD, "step_repvit_m0_9.npz"))
+    hy, ref, ns = man["hyper"], man["fp32"], man["samples_per_tensor"]
+    sd = schema.synthetic_state_dict("repvit", "m0.9", seed=0)
+    sd = {k[len(PREFIX):]: v.clone() for k, v in sd.items() if k.startswith(PREFIX)}
+    tr = stage1_train.Stage1Trainer(sd, "repvit_m0_9", embed_size=man["embed_size"], dtype="f32", device="cpu", lr=hy["lr"], weight_decay=hy["weight_decay"],
+                                    betas=tuple(hy["betas"]), eps=hy["eps"], clip_grad=hy["clip_grad"], amp=False, cosine_weight=hy["cosine"],
+                                    accumulation_steps=hy["accumulation_steps"])
+    imgs = torch.stack([torch.from_numpy(synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=s))) for s in man["image_seeds"]])
+    for i, (h, w) in enumerate(man["sizes_before_pad"]):
+        imgs[i, :, h:, :] = 0
+        imgs[i, :, :, w:] = 0
+    gen = torch.Generator().manual_seed(man["teacher_seed"])
+    teacher = (torch.randn((len(man["sizes_before_pad"]), man["embed_dim"], man["embed_size"], man["embed_size"]), generator=gen) * 0.5).permute(0, 2, 3, 1).contiguous()
+    sizes = [tuple(s) for s in man["sizes_before_pad"]]
+
+    out = tr.step(imgs, teacher, sizes, update_grad=False)
+    grads = {n: _sample(v, ns) for n, v in tr.gradients().items()}
+    norm = float(tr.updater.step())
+    tr._micro = 0
+    loss = float(out["loss"])
+    assert abs(loss - ref["losses"][0]) <= 1e-5 * abs(ref["losses"][0]), (loss, ref["losses"][0])
+    assert abs(norm - ref["grad_norms"][0]) <= 1e-3 * ref["grad_norms"][0], (norm, ref["grad_norms"][0])
+    clip = min(1.0, hy["clip_grad"] / (norm + 1e-6))
+    gmax = max(float(g[f"gradmax1/{n}"]) for n in ref["names"])
+    assert sorted(grads) == sorted(ref["names"])
+    for n in ref["names"]:
+        err = float(np.abs(grads[n] * clip - g[f"grad1/{n}"]).max())
+        assert err <= 5e-3 * float(g[f"gradmax1/{n}"]) + 1e-5 * gmax, (n, err, float(g[f"gradmax1/{n}"]))
+    state = tr.state_dict()
+    for n in ref["names"]:
+        assert tuple(state[n].shape) == tuple(ref["shapes"][n]), n
+        assert float(np.abs(_sample(state[n], ns) - g[f"param1/{n}"]).max()) <= 2.5 * hy["lr"] + 1e-6, n
+    for k in [k for k in state if k.endswith(("running_mean", "running_var"))]:
+        want = g[f"buffer1/{k}"]
+        assert float(np.abs(_sample(state[k], ns) - want).max()) <= 1e-4 * max(1.0, float(np.abs(want).max())), k
+    assert all(int(v) == int(sd[k]) + 1 for k, v in state.items() if k.endswith("num_batches_tracked"))
+    # the arrival order of the gradients (= the bucket order of the all-reduce): head first, then the trunk from its last block to the stem
+    assert tr._arrival[0].startswith("head.") and tr._arrival[-1] == "backbone.model.features.0.0.bn.bias"
+
+    out = tr.step(imgs, teacher, sizes)
+    loss2, norm2 = float(out["loss"]), float(out["grad_norm"])
+    assert abs(loss2 - ref["losses"][1]) <= 1e-3 * abs(ref["losses"][1]), (loss2, ref["losses"][1])
+    assert abs(norm2 - ref["grad_norms"][1]) <= 1e-2 * ref["grad_norms"][1], (norm2, ref["grad_norms"][1])

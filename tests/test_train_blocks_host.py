@@ -18,7 +18,7 @@ def _to_nhwc(t):
 
 
 def _act(x, act):
-    return {None: lambda t: t, "relu": F.relu, "gelu": F.gelu, "hswish": F.hardswish}[act](x)
+    return {None: lambda t: t, "relu": F.relu, "gelu": F.gelu, "hswish": F.hardswish, "sigmoid": torch.sigmoid}[act](x)
 
 
 @pytest.fixture
@@ -68,6 +68,23 @@ def cpu_kernels(monkeypatch):
         y.backward(dout.permute(0, 2, 1).contiguous())
         return qkv.grad.reshape(b, groups * 3 * dim, n).permute(0, 2, 1).contiguous(), y.detach().permute(0, 2, 1).contiguous()
 
+    def channel_scale(x, mul, bias=None, add=None, plus_one=False, bias_scale=1.0):
+        b, c = x.shape[0], x.shape[-1]
+        shape = lambda t: t.reshape((b,) + (1,) * (x.dim() - 2) + (c,)) if t.dim() == 2 else t  # noqa: E731
+        out = x * (shape(mul) + (1.0 if plus_one else 0.0))
+        if add is not None:
+            out = out + add
+        if bias is not None:
+            out = out + shape(bias) * bias_scale
+        return out
+
+    def batched_coldot(a, b2=None, scale=1.0, per_image=True):
+        prod = a if b2 is None else a * b2
+        c = a.shape[-1]
+        return prod.reshape(a.shape[0], -1, c).sum(1) * scale if per_image else prod.reshape(-1, c).sum(0) * scale
+
+    monkeypatch.setattr(tb, "channel_scale", channel_scale)
+    monkeypatch.setattr(tb, "batched_coldot", batched_coldot)
     monkeypatch.setattr(tb, "DEVICE", "cpu")
     monkeypatch.setattr(tb, "act_forward", lambda x, act: _act(x, act))
     monkeypatch.setattr(tb, "act_backward", act_backward)
