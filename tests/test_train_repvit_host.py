@@ -167,51 +167,46 @@ def test_repvit_trunk_composition_and_names(repvit_kernels):
 REFERENCE = "/root/reference"
 
 
-@pytest.mark.skipif(not __import__("os").path.isdir(REFERENCE + "/stage1"), reason="the reference tree is only present in the build container")
+@pytest.mark.skipif(not __import__("os").path.isdir(REFERENCE + "/sam3"), reason="the reference tree is only present in the build container")
 def test_repvit_trunk_vs_the_reference_module(repvit_kernels):
-    """where the reference is present (this container, never the GPU box): the same comparison against the REAL module --
-    stage1/model.py:_build_backbone("repvit_m0_9") = RepViTAdapter(repvit_m0_9(...)) in train mode, loaded with the synthetic state dict --
+    """where the reference is present (this container, never the GPU box): the same comparison against the REAL module -- repvit_m0_9 of
+    sam3/backbones/repvit.py as stage1/model.py:386-395 builds it (num_classes 0, no distillation head), run layer by layer over
+    ``model.features`` as RepViTAdapter.forward does (stage1/model.py:293-296), in train mode, loaded with the synthetic state dict --
     instead of this file's own restatement of it"""
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    added = [os.path.join(root, "oracle", "shims"), REFERENCE, REFERENCE + "/stage1"]
-    sys.path[:0] = added
-    before = set(sys.modules)
-    try:
-        import model as ref_model                                       # stage1/model.py
-        backbone, out_channels = ref_model._build_backbone("repvit_m0_9", 1008)
-    finally:
-        for a in added:
-            sys.path.remove(a)
-        for name in set(sys.modules) - before:                           # leave no reference / shim module behind for the other tests
-            if name.split(".")[0] in ("model", "sam3", "timm", "torchvision", "iopath", "cv2", "ftfy", "omegaconf", "pycocotools", "skimage"):
-                del sys.modules[name]
+    for pth in (os.path.join(root, "oracle", "shims"), REFERENCE + "/sam3"):      # as tests/test_train_blocks_host.py imports the EfficientViT module
+        if pth not in sys.path:
+            sys.path.insert(0, pth)
+    from sam3.backbones.repvit import repvit_m0_9
+    model = repvit_m0_9(pretrained=False, num_classes=0, distillation=False)
     full = schema.synthetic_state_dict("repvit", "m0.9", seed=4)
-    pre = "backbone.vision_backbone.trunk.model.backbone."
+    pre = "backbone.vision_backbone.trunk.model.backbone.model."
     sd = {k[len(pre):]: v.float() for k, v in full.items() if k.startswith(pre)}
-    backbone.load_state_dict(sd, strict=True)
-    backbone.train()
+    model.load_state_dict(sd, strict=True)
+    model.train()
     g = torch.Generator().manual_seed(8)
     img = torch.randn(2, 3, 128, 96, generator=g)
-    yr = backbone(img)
-    assert yr.shape[1] == out_channels
+    yr = img
+    for layer in model.features:
+        yr = layer(yr)
     dy = torch.randn(yr.shape, generator=g)
     yr.backward(dy)
-    ref_grads = {n: p.grad for n, p in backbone.named_parameters()}
-    trunk = tr.RepViTTrunkTrain({k: v.clone() for k, v in sd.items()}, "m0.9", dtype=torch.float32, prefix="model.")
+    ref_grads = {n: p.grad for n, p in model.named_parameters()}
+    trunk = tr.RepViTTrunkTrain({k: v.clone() for k, v in sd.items()}, "m0.9", dtype=torch.float32)
     y = trunk.forward(img)
     grads = trunk.backward(_to_nhwc(dy))
-    assert sorted("model." + k for k in grads) == sorted(ref_grads)
+    assert sorted(grads) == sorted(ref_grads)
     d, m = float((y - _to_nhwc(yr.detach())).abs().max()), float(yr.detach().abs().max())
     assert d <= 1e-3 * m, (d, m)
     typical = float(torch.stack([v.abs().max() for v in ref_grads.values()]).median())
-    worst = max((float((grads[k] - ref_grads["model." + k]).abs().max()) / max(float(ref_grads["model." + k].abs().max()), 1e-2 * typical), k) for k in grads)
+    worst = max((float((grads[k] - ref_grads[k]).abs().max()) / max(float(ref_grads[k].abs().max()), 1e-2 * typical), k) for k in grads)
     print("worst relative gradient error against the reference module", worst)
     assert worst[0] <= 5e-3, worst
     # BatchNorm buffers after one training-mode forward: the module's own running statistics
-    ref_buf = {k: v for k, v in backbone.state_dict().items() if k.endswith(("running_mean", "running_var"))}
+    ref_buf = {k: v for k, v in model.state_dict().items() if k.endswith(("running_mean", "running_var"))}
     for name, layer in trunk.norm_layers():
         for stat in ("running_mean", "running_var"):
-            got, want = getattr(layer, stat), ref_buf[f"model.{name}.{stat}"]
+            got, want = getattr(layer, stat), ref_buf[f"{name}.{stat}"]
             assert float((got - want).abs().max()) <= 1e-4 * max(float(want.abs().max()), 1.0), (name, stat)
