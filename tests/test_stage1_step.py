@@ -23,7 +23,8 @@ DTS = {"f32": torch.float32, "bf16": torch.bfloat16}
 # the five next-worst tensors are printed by the test.  The noise-only tensors (analytically zero gradient) reach 7.1e-6 of the network's
 # largest gradient: GRAD_ABS = 3.5 x that (it was 1e-4).  GRAD_REL stays at 1.5 x the achieved worst.
 GRAD_REL, GRAD_ABS = 2.5e-2, 2.5e-5
-RV_GRAD_REL, RV_GRAD_ABS = 5e-2, 1e-4      # the RepViT students (round 5): the B2 allowance until their margins are on record (printed)
+RV_GRAD_REL, RV_GRAD_ABS = 2.5e-3, 5e-6    # the RepViT students (round 5): first run used 0.015 - 0.018 of (5e-2, 1e-4), worst tensor 4.6e-4 of its
+                                           # maximum (profiles/r05/parity_margins_repvit_steps.txt); this allowance is 1 / 20 of that one
 B2_GRAD_REL, B2_GRAD_ABS = 5e-2, 1e-4      # EfficientViT-B2: 35 x larger gradients through a deeper chain of training-mode BatchNorms
 
 
@@ -302,7 +303,7 @@ def test_bf16_training_step_inside_the_reference_autocast_yardstick(step_gold):
         assert abs(loss - r32["losses"][step]) <= lim_l and abs(norm - r32["grad_norms"][step]) <= lim_n
 
 
-def _first_step_vs_reference(model, suffix, sd, grad_rel, grad_abs, second_step=None, check_buffers=False):
+def _first_step_vs_reference(model, suffix, sd, grad_rel, grad_abs, second_step=None, check_buffers=False, loss_rel=1e-4, norm_rel=1e-2):
     """the first iteration of the trainer (fp32) against the reference stack's own run (tests/golden/stage1/step_<suffix>.*): loss, total
     gradient norm, every parameter's clipped gradient (samples), every parameter after the update; ``second_step`` = (loss rel, norm rel):
     also the loss and gradient norm of a second iteration"""
@@ -325,8 +326,8 @@ def _first_step_vs_reference(model, suffix, sd, grad_rel, grad_abs, second_step=
     loss = float(out["loss"])
     clip = min(1.0, hy["clip_grad"] / (norm + 1e-6))
     print(f"[stage-1 {model} step 1] loss {loss:.6f} (reference {ref['losses'][0]:.6f})  grad norm {norm:.3f} ({ref['grad_norms'][0]:.3f})")
-    assert abs(loss - ref["losses"][0]) <= 1e-4 * abs(ref["losses"][0])
-    assert abs(norm - ref["grad_norms"][0]) <= 1e-2 * ref["grad_norms"][0]
+    assert abs(loss - ref["losses"][0]) <= loss_rel * abs(ref["losses"][0])
+    assert abs(norm - ref["grad_norms"][0]) <= norm_rel * ref["grad_norms"][0]
     gmax = max(float(g[f"gradmax1/{n}"]) for n in ref["names"])
     ranked, used = [], 0.0
     for n in ref["names"]:
@@ -354,7 +355,7 @@ def _first_step_vs_reference(model, suffix, sd, grad_rel, grad_abs, second_step=
         want = g[f"buffer1/{k}"]
         worst_buf = max(worst_buf, float(np.abs(_sample(v, ns) - want).max()) / max(1.0, float(np.abs(want).max())))
     print(f"  BatchNorm running statistics after step 1 ({len(bufs)} buffers): worst |diff| / max(1, |ref|) = {worst_buf:.2e}")
-    assert worst_buf <= 1e-3
+    assert worst_buf <= 1e-5          # measured 1.5e-7
     if second_step is not None:
         out = tr.step(imgs, teacher, sizes)
         loss2, norm2 = float(out["loss"]), float(out["grad_norm"])
@@ -395,7 +396,8 @@ def test_repvit_training_steps_match_the_reference_run(model, name):
     repvit_m1_1): first iteration as for B2 (loss, norm, every clipped gradient, every updated parameter, every running statistic), and the
     loss and gradient norm of the second iteration (these nets are well conditioned: the reference's own bf16-autocast run moves its
     loss by 4e-4 and its norm by 3e-4)."""
-    _first_step_vs_reference(model, model, _repvit_sd(name), RV_GRAD_REL, RV_GRAD_ABS, second_step=(2e-3, 2e-2), check_buffers=True)
+    # measured (first run): loss 2e-7 / 1e-7 rel, norm 3.4e-4 / 3.9e-4 rel in step 1; 1.3e-7 and 3.0e-4 in step 2
+    _first_step_vs_reference(model, model, _repvit_sd(name), RV_GRAD_REL, RV_GRAD_ABS, second_step=(5e-6, 2e-3), check_buffers=True, loss_rel=5e-6, norm_rel=2e-3)
 
 
 @pytest.mark.parametrize("model,name", [("repvit_m0_9", "m0.9"), ("repvit_m1_1", "m1.1")])
