@@ -107,6 +107,12 @@ SIGNATURES = {
     "esam3_batched_coldot_workspace": (_L, [_I, _I]),
     "esam3_batched_coldot": (_I, [_I, _P, _P, _I, _L, _I, C.c_float, _P, _P, _P]),
     "esam3_train_conv3x3_s2": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "esam3_ln_train_forward": (_I, [_I, _P, _P, _L, _I, _P, _P, C.c_float, _P, _P, _P]),
+    "esam3_ln_train_workspace": (_L, [_I]),
+    "esam3_ln_train_backward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "esam3_win_attn_train_forward": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, C.c_float, _P]),
+    "esam3_win_attn_train_backward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, C.c_float, _P]),
+    "esam3_attn_bias_gather_sum": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "esam3_dwconv_wgrad_workspace": (_L, [_I]),
     "esam3_dwconv_wgrad": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "esam3_lite_mla_backward": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),

@@ -1,0 +1,459 @@
+// Stage-1 training path, the TinyViT students (stage1/model.py:397-406 -> TinyViTAdapter over
+// sam3/backbones/tiny_vit.py under model.train(), stage1/train_image_encoder_stage1.py:165-226).  What a TinyViTBlock needs beyond the
+// convolution / BatchNorm / activation kernels of kernels_train.hip:
+//   esam3_ln_train_forward / _backward     nn.LayerNorm over the channels of [M][C] rows (Attention.norm, Mlp.norm: tiny_vit.py:201,236):
+//                                          y, saved mean / rstd; dx, dgamma, dbeta (per-row statistics on one wavefront, the two column
+//                                          sums over fixed row partitions: deterministic)
+//   esam3_win_attn_train_forward / _backward   Attention.forward without its Linear layers (tiny_vit.py:271-293): per window and head
+//                                          softmax(q k^T scale + bias) v on [windows][N][heads * 96] qkv rows (per head q | k | v of 32
+//                                          channels), N = 49 | 196 tokens; backward gives d(qkv) and dS = the gradient of the bias-added
+//                                          logits per window (the bias gradient is its sum over the windows, esam3_colsum)
+//   esam3_attn_bias_gather_sum             d(attention_biases)[h][o] = sum of dBias[h][i][j] over the (i, j) with
+//                                          attention_bias_idxs[i][j] = o (tiny_vit.py:240-254), fixed order
+// All arithmetic fp32; activations / gradients fp32 or bf16.  One workgroup per (window, head): q / dO rows live in registers, the other
+// operand's rows are read from LDS as broadcasts (every lane the same address), so there are no bank conflicts by construction.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/esam3.h"
+#include "esam3_common.h"
+#include "kernels.h"
+
+namespace {
+
+template <int DT> struct VElem;  // 0 f32, 1 bf16
+template <> struct VElem<0> {
+  using type = float;
+  static __device__ inline void load8(const float* p, float* v) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ inline void store8(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+template <> struct VElem<1> {
+  using type = uint16_t;
+  static __device__ inline void load8(const uint16_t* p, float* v) {
+    const uint4 q = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ inline void store8(uint16_t* p, const float* v) {
+    uint4 o;
+    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = o;
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---- LayerNorm -----------------------------------------------------------------------------------------------------------------------------
+// one wavefront per row; a lane holds the 8-channel groups lane, lane + 64 (C <= 1024).  Two-pass statistics (mean, then the centred
+// second moment), biased variance, as torch.nn.functional.layer_norm.
+constexpr int LN_G = 2;
+template <int DT>
+__global__ __launch_bounds__(256) void ln_forward_kernel(const typename VElem<DT>::type* __restrict__ x, typename VElem<DT>::type* __restrict__ y,
+                                                         int64_t M, int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float eps, float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, C8 = C / 8;
+  const float inv_c = 1.f / (float)C;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+    float v[LN_G][8];
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < LN_G; ++g) {
+      const int cg = lane + 64 * g;
+      if (cg < C8) {
+        VElem<DT>::load8(x + row * C + cg * 8, v[g]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[g][e];
+      }
+    }
+    const float mean = wave_sum(s) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int g = 0; g < LN_G; ++g)
+      if (lane + 64 * g < C8) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[g][e] - mean;
+          q += d * d;
+        }
+      }
+    const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
+#pragma unroll
+    for (int g = 0; g < LN_G; ++g) {
+      const int cg = lane + 64 * g;
+      if (cg < C8) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[g][e] - mean) * rstd * gamma[cg * 8 + e] + beta[cg * 8 + e];
+        VElem<DT>::store8(y + row * C + cg * 8, o);
+      }
+    }
+    if (lane == 0) {
+      mean_out[row] = mean;
+      rstd_out[row] = rstd;
+    }
+  }
+}
+
+// dx = rstd (g - mean_c(g) - xhat mean_c(g xhat)), g = dy gamma; dgamma = sum_rows dy xhat, dbeta = sum_rows dy.
+// A wave walks the rows (wave index + k * waves of the grid): the set of rows a lane sums is a function of (M, grid) only.
+// partial [block][2][C]; ln_reduce_kernel adds the blocks in a fixed order.
+constexpr int LN_BLOCKS_MAX = 512;
+template <int DT>
+__global__ __launch_bounds__(256) void ln_backward_kernel(const typename VElem<DT>::type* __restrict__ x, const typename VElem<DT>::type* __restrict__ dy,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                          const float* __restrict__ rstd_in, typename VElem<DT>::type* __restrict__ dx, int64_t M,
+                                                          int C, float* __restrict__ partial) {
+  __shared__ float red[4][2][LN_G * 64 * 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, C8 = C / 8;
+  const float inv_c = 1.f / (float)C;
+  float ag[LN_G][8], ab[LN_G][8];
+#pragma unroll
+  for (int g = 0; g < LN_G; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ag[g][e] = ab[g][e] = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float xh[LN_G][8], gg[LN_G][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int g = 0; g < LN_G; ++g) {
+      const int cg = lane + 64 * g;
+      if (cg < C8) {
+        float xv[8], dv[8];
+        VElem<DT>::load8(x + row * C + cg * 8, xv);
+        VElem<DT>::load8(dy + row * C + cg * 8, dv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[g][e] = (xv[e] - mean) * rstd;
+          gg[g][e] = dv[e] * gamma[cg * 8 + e];
+          s1 += gg[g][e];
+          s2 += gg[g][e] * xh[g][e];
+          ag[g][e] += dv[e] * xh[g][e];
+          ab[g][e] += dv[e];
+        }
+      }
+    }
+    const float a = wave_sum(s1) * inv_c, b = wave_sum(s2) * inv_c;
+#pragma unroll
+    for (int g = 0; g < LN_G; ++g) {
+      const int cg = lane + 64 * g;
+      if (cg < C8) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rstd * (gg[g][e] - a - xh[g][e] * b);
+        VElem<DT>::store8(dx + row * C + cg * 8, o);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < LN_G; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[wave][0][(g * 64 + lane) * 8 + e] = ag[g][e];
+      red[wave][1][(g * 64 + lane) * 8 + e] = ab[g][e];
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, c = i - which * C;
+    const int cg = c / 8, e = c & 7, g = cg / 64, ln = cg - g * 64;
+    const int idx = (g * 64 + ln) * 8 + e;
+    partial[(int64_t)blockIdx.x * 2 * C + i] = (red[0][which][idx] + red[1][which][idx]) + (red[2][which][idx] + red[3][which][idx]);
+  }
+}
+__global__ __launch_bounds__(256) void ln_reduce_kernel(const float* __restrict__ partial, int blocks, int n, float* __restrict__ out_a, float* __restrict__ out_b,
+                                                        int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < blocks; b += 4) {
+    s0 += partial[(int64_t)b * n + i];
+    s1 += partial[(int64_t)(b + 1) * n + i];
+    s2 += partial[(int64_t)(b + 2) * n + i];
+    s3 += partial[(int64_t)(b + 3) * n + i];
+  }
+  for (; b < blocks; ++b) s0 += partial[(int64_t)b * n + i];
+  const float t = (s0 + s1) + (s2 + s3);
+  if (i < C) out_a[i] = t;
+  else out_b[i - C] = t;
+}
+int ln_blocks(int64_t M) {
+  const int64_t want = (M + 3) / 4;
+  return (int)(want < LN_BLOCKS_MAX ? want : LN_BLOCKS_MAX);
+}
+
+// ---- window attention, head dim 32 ---------------------------------------------------------------------------------------------------------
+constexpr int HD = 32;
+
+// stage rows [N][32] of one (window, head) operand into LDS as fp32: `src` points at the operand's first channel of token 0, rows `ld` apart
+template <int DT>
+__device__ __forceinline__ void stage_rows(const typename VElem<DT>::type* __restrict__ src, int ld, int N, float* __restrict__ dst) {
+  for (int c = threadIdx.x; c < N * 4; c += blockDim.x) {
+    const int r = c >> 2, part = c & 3;
+    float v[8];
+    VElem<DT>::load8(src + (int64_t)r * ld + part * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[r * HD + part * 8 + e] = v[e];
+  }
+}
+template <int DT>
+__device__ __forceinline__ void load_row(const typename VElem<DT>::type* __restrict__ src, float (&v)[HD]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) VElem<DT>::load8(src + p * 8, &v[p * 8]);
+}
+template <int DT>
+__device__ __forceinline__ void store_row(typename VElem<DT>::type* __restrict__ dst, const float (&v)[HD]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) VElem<DT>::store8(dst + p * 8, &v[p * 8]);
+}
+__device__ __forceinline__ float dot32(const float (&a)[HD], const float* __restrict__ b) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    const float4 w = *reinterpret_cast<const float4*>(b + c);
+    s0 += a[c] * w.x; s1 += a[c + 1] * w.y; s2 += a[c + 2] * w.z; s3 += a[c + 3] * w.w;
+  }
+  return (s0 + s1) + (s2 + s3);
+}
+
+// forward: thread i owns query row i; K, V of the (window, head) in LDS; online softmax over the N keys.
+// The bias table is symmetric (offsets are |p1 - p2|, tiny_vit.py:245): row i is read as column i, coalesced over the threads.
+template <int DT>
+__global__ __launch_bounds__(256) void win_attn_forward_kernel(const typename VElem<DT>::type* __restrict__ qkv, const float* __restrict__ bias,
+                                                               typename VElem<DT>::type* __restrict__ out, float* __restrict__ lse, int N, int heads,
+                                                               float scale) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sk = lds;
+  float* sv = lds + N * HD;
+  const int w = blockIdx.x, h = blockIdx.y, ld = heads * 3 * HD;
+  const typename VElem<DT>::type* base = qkv + (int64_t)w * N * ld + h * 3 * HD;
+  stage_rows<DT>(base + HD, ld, N, sk);
+  stage_rows<DT>(base + 2 * HD, ld, N, sv);
+  __syncthreads();
+  const int i = threadIdx.x;
+  if (i >= N) return;
+  float q[HD], o[HD];
+  load_row<DT>(base + (int64_t)i * ld, q);
+#pragma unroll
+  for (int c = 0; c < HD; ++c) {
+    q[c] *= scale;
+    o[c] = 0.f;
+  }
+  const float* brow = bias + (int64_t)h * N * N + i;   // bias[h][j][i] = bias[h][i][j]
+  float m = -3.0e38f, l = 0.f;
+  for (int j = 0; j < N; ++j) {
+    const float s = dot32(q, sk + j * HD) + brow[(int64_t)j * N];
+    const float mn = fmaxf(m, s);
+    const float corr = __expf(m - mn), p = __expf(s - mn);
+    l = l * corr + p;
+    const float* vj = sv + j * HD;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) o[c] = o[c] * corr + p * vj[c];
+    m = mn;
+  }
+  const float inv = 1.f / l;
+#pragma unroll
+  for (int c = 0; c < HD; ++c) o[c] *= inv;
+  store_row<DT>(out + ((int64_t)w * N + i) * (heads * HD) + h * HD, o);
+  lse[((int64_t)w * heads + h) * N + i] = m + __logf(l);
+}
+
+// backward.  P_ij = exp(s_ij - lse_i); dP_ij = dO_i . v_j; D_i = dO_i . O_i (= sum_j P_ij dP_ij); dS_ij = P_ij (dP_ij - D_i);
+//   dq_i = scale sum_j dS_ij k_j     (phase A, thread = query row i, K / V rows broadcast from LDS)
+//   dk_j = scale sum_i dS_ij q_i,  dv_j = sum_i P_ij dO_i,  dS written [window][head][i][j]   (phase B, thread = key row j, Q / dO rows
+//   broadcast from LDS; the store of dS_i. is coalesced over j)
+template <int DT>
+__global__ __launch_bounds__(256) void win_attn_backward_kernel(const typename VElem<DT>::type* __restrict__ qkv, const float* __restrict__ bias,
+                                                                const typename VElem<DT>::type* __restrict__ out, const float* __restrict__ lse,
+                                                                const typename VElem<DT>::type* __restrict__ dout,
+                                                                typename VElem<DT>::type* __restrict__ dqkv, float* __restrict__ ds_out, int N, int heads,
+                                                                float scale) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* sq = lds;
+  float* sk = sq + N * HD;
+  float* sv = sk + N * HD;
+  float* sdo = sv + N * HD;
+  float* slse = sdo + N * HD;
+  float* sd = slse + N;
+  const int w = blockIdx.x, h = blockIdx.y, ld = heads * 3 * HD, ldo = heads * HD;
+  const typename VElem<DT>::type* base = qkv + (int64_t)w * N * ld + h * 3 * HD;
+  const typename VElem<DT>::type* dobase = dout + (int64_t)w * N * ldo + h * HD;
+  stage_rows<DT>(base, ld, N, sq);
+  stage_rows<DT>(base + HD, ld, N, sk);
+  stage_rows<DT>(base + 2 * HD, ld, N, sv);
+  stage_rows<DT>(dobase, ldo, N, sdo);
+  const int t = threadIdx.x;
+  float mine[HD], other[HD];      // phase A: q_i (scaled), dO_i; phase B: k_j (scaled), v_j
+  if (t < N) {
+    load_row<DT>(dobase + (int64_t)t * ldo, other);
+    load_row<DT>(out + ((int64_t)w * N + t) * ldo + h * HD, mine);
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) d += other[c] * mine[c];
+    sd[t] = d;
+    slse[t] = lse[((int64_t)w * heads + h) * N + t];
+  }
+  __syncthreads();
+  const float* bcol = bias + (int64_t)h * N * N + t;     // bias[h][.][t]: symmetric table, coalesced over the threads
+  if (t < N) {   // ---- phase A ----
+    load_row<DT>(base + (int64_t)t * ld, mine);
+#pragma unroll
+    for (int c = 0; c < HD; ++c) mine[c] *= scale;
+    float dq[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) dq[c] = 0.f;
+    const float lse_i = slse[t], d_i = sd[t];
+    for (int j = 0; j < N; ++j) {
+      const float* kj = sk + j * HD;
+      const float s = dot32(mine, kj) + bcol[(int64_t)j * N];
+      const float p = __expf(s - lse_i);
+      const float dsv = p * (dot32(other, sv + j * HD) - d_i) * scale;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) dq[c] += dsv * kj[c];
+    }
+    store_row<DT>(dqkv + ((int64_t)w * N + t) * ld + h * 3 * HD, dq);
+    // ---- phase B ----
+    load_row<DT>(base + (int64_t)t * ld + HD, mine);        // k_j
+    load_row<DT>(base + (int64_t)t * ld + 2 * HD, other);   // v_j
+#pragma unroll
+    for (int c = 0; c < HD; ++c) mine[c] *= scale;
+    float dk[HD], dv[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) dk[c] = dv[c] = 0.f;
+    float* dsrow = ds_out + ((int64_t)w * heads + h) * N * N + t;
+    for (int i = 0; i < N; ++i) {
+      const float* qi = sq + i * HD;
+      const float* doi = sdo + i * HD;
+      const float s = dot32(mine, qi) + bcol[(int64_t)i * N];     // scale q_i . k_j + bias[h][i][j]
+      const float p = __expf(s - slse[i]);
+      const float dsv = p * (dot32(other, doi) - sd[i]);
+      dsrow[(int64_t)i * N] = dsv;
+      const float dss = dsv * scale;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) {
+        dv[c] += p * doi[c];
+        dk[c] += dss * qi[c];
+      }
+    }
+    store_row<DT>(dqkv + ((int64_t)w * N + t) * ld + h * 3 * HD + HD, dk);
+    store_row<DT>(dqkv + ((int64_t)w * N + t) * ld + h * 3 * HD + 2 * HD, dv);
+  }
+}
+
+// out[h][o] = sum over the items of offset o (CSR: start[o] .. start[o + 1]) of full[h][item], in list order
+__global__ __launch_bounds__(256) void bias_gather_sum_kernel(const float* __restrict__ full, const int* __restrict__ start, const int* __restrict__ items,
+                                                              float* __restrict__ out, int heads, int NN, int n_off) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= heads * n_off) return;
+  const int h = i / n_off, o = i - h * n_off;
+  float s = 0.f;
+  for (int k = start[o]; k < start[o + 1]; ++k) s += full[(int64_t)h * NN + items[k]];
+  out[i] = s;
+}
+
+int bad(const char* what) {
+  esam3_set_error("%s: bad argument", what);
+  return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int esam3_ln_train_forward(int dtype, const void* x, void* y, int64_t M, int C, const float* gamma, const float* beta, float eps, float* mean,
+                           float* rstd, void* stream) {
+  if ((dtype != 0 && dtype != 1) || !x || !y || !gamma || !beta || !mean || !rstd || M <= 0 || C <= 0 || C % 8 || C > LN_G * 64 * 8)
+    return bad("esam3_ln_train_forward (fp32 / bf16; C a multiple of 8, at most 1024)");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((M + 3) / 4 < 65535 ? (M + 3) / 4 : 65535);
+  if (dtype == 0) hipLaunchKernelGGL(ln_forward_kernel<0>, dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, M, C, gamma, beta, eps, mean, rstd);
+  else hipLaunchKernelGGL(ln_forward_kernel<1>, dim3(grid), dim3(256), 0, s, (const uint16_t*)x, (uint16_t*)y, M, C, gamma, beta, eps, mean, rstd);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int64_t esam3_ln_train_workspace(int C) { return C > 0 ? (int64_t)sizeof(float) * LN_BLOCKS_MAX * 2 * C : 0; }
+
+int esam3_ln_train_backward(int dtype, const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd, void* dx,
+                            float* dgamma, float* dbeta, int64_t M, int C, void* workspace, void* stream) {
+  if ((dtype != 0 && dtype != 1) || !x || !dy || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !workspace || M <= 0 || C <= 0 || C % 8 ||
+      C > LN_G * 64 * 8)
+    return bad("esam3_ln_train_backward (fp32 / bf16; C a multiple of 8, at most 1024)");
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = ln_blocks(M);
+  float* partial = (float*)workspace;
+  if (dtype == 0)
+    hipLaunchKernelGGL(ln_backward_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, (const float*)dy, gamma, mean, rstd, (float*)dx, M, C,
+                       partial);
+  else
+    hipLaunchKernelGGL(ln_backward_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)x, (const uint16_t*)dy, gamma, mean, rstd,
+                       (uint16_t*)dx, M, C, partial);
+  hipLaunchKernelGGL(ln_reduce_kernel, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, s, partial, blocks, 2 * C, dgamma, dbeta, C);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_win_attn_train_forward(int dtype, const void* qkv, const float* bias, void* out, float* lse, int windows, int N, int heads, float scale,
+                                 void* stream) {
+  if ((dtype != 0 && dtype != 1) || !qkv || !bias || !out || !lse || windows <= 0 || N <= 0 || N > 256 || heads <= 0 || heads > 65535)
+    return bad("esam3_win_attn_train_forward (fp32 / bf16; at most 256 tokens per window; head dim 32)");
+  hipStream_t s = (hipStream_t)stream;
+  const int threads = (N + 63) / 64 * 64, lds = 2 * N * HD * (int)sizeof(float);
+  if (dtype == 0) {
+    if (esam3_allow_dyn_lds((const void*)win_attn_forward_kernel<0>, 2 * 256 * HD * (int)sizeof(float))) return -1;
+    hipLaunchKernelGGL(win_attn_forward_kernel<0>, dim3((unsigned)windows, (unsigned)heads), dim3(threads), lds, s, (const float*)qkv, bias, (float*)out, lse, N,
+                       heads, scale);
+  } else {
+    if (esam3_allow_dyn_lds((const void*)win_attn_forward_kernel<1>, 2 * 256 * HD * (int)sizeof(float))) return -1;
+    hipLaunchKernelGGL(win_attn_forward_kernel<1>, dim3((unsigned)windows, (unsigned)heads), dim3(threads), lds, s, (const uint16_t*)qkv, bias, (uint16_t*)out,
+                       lse, N, heads, scale);
+  }
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_win_attn_train_backward(int dtype, const void* qkv, const float* bias, const void* out, const float* lse, const void* dout, void* dqkv,
+                                  float* ds, int windows, int N, int heads, float scale, void* stream) {
+  if ((dtype != 0 && dtype != 1) || !qkv || !bias || !out || !lse || !dout || !dqkv || !ds || windows <= 0 || N <= 0 || N > 256 || heads <= 0 ||
+      heads > 65535)
+    return bad("esam3_win_attn_train_backward (fp32 / bf16; at most 256 tokens per window; head dim 32)");
+  hipStream_t s = (hipStream_t)stream;
+  const int threads = (N + 63) / 64 * 64, lds = (4 * N * HD + 2 * N) * (int)sizeof(float);
+  const int lds_max = (4 * 256 * HD + 2 * 256) * (int)sizeof(float);
+  if (dtype == 0) {
+    if (esam3_allow_dyn_lds((const void*)win_attn_backward_kernel<0>, lds_max)) return -1;
+    hipLaunchKernelGGL(win_attn_backward_kernel<0>, dim3((unsigned)windows, (unsigned)heads), dim3(threads), lds, s, (const float*)qkv, bias, (const float*)out,
+                       lse, (const float*)dout, (float*)dqkv, ds, N, heads, scale);
+  } else {
+    if (esam3_allow_dyn_lds((const void*)win_attn_backward_kernel<1>, lds_max)) return -1;
+    hipLaunchKernelGGL(win_attn_backward_kernel<1>, dim3((unsigned)windows, (unsigned)heads), dim3(threads), lds, s, (const uint16_t*)qkv, bias,
+                       (const uint16_t*)out, lse, (const uint16_t*)dout, (uint16_t*)dqkv, ds, N, heads, scale);
+  }
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+int esam3_attn_bias_gather_sum(const float* full, const int* start, const int* items, float* out, int heads, int NN, int n_off, void* stream) {
+  if (!full || !start || !items || !out || heads <= 0 || NN <= 0 || n_off <= 0) return bad("esam3_attn_bias_gather_sum");
+  const int n = heads * n_off;
+  hipLaunchKernelGGL(bias_gather_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, full, start, items, out, heads, NN, n_off);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -1,4 +1,5 @@
-"""One stage-1 distillation TRAINING STEP of an EfficientViT or RepViT student on the HIP kernels.
+"""One stage-1 distillation TRAINING STEP of an EfficientViT, RepViT or TinyViT student on the HIP kernels: the nine
+students of stage1/model.py:386-420.
 
 Reference: ``stage1/train_image_encoder_stage1.py:165-226`` (``train_one_epoch``: ``model.train()`` -> forward of
 ``ImageStudentEncoder`` (``stage1/model.py:188-211``: backbone -> Conv1x1 + BatchNorm + GELU -> Conv3x3 -> bilinear resize to the
@@ -42,6 +43,9 @@ EFFICIENTVIT = {"b0": ([8, 16, 32, 64, 128], [1, 2, 2, 2, 2], 16), "b1": ([16, 3
 # the RepViT students RV-S / RV-M / RV-L (stage1/model.py:386-395: MODEL.BACKBONE repvit_m0_9 | repvit_m1_1 | repvit_m2_3) -> the key of
 # schema.REPVIT_CFG; layers in train_repvit.py
 REPVIT = {"repvit_m0_9": "m0.9", "repvit_m1_1": "m1.1", "repvit_m2_3": "m2.3"}
+# the TinyViT students TV-S / TV-M / TV-L (stage1/model.py:397-406: tiny_vit_5m | tiny_vit_11m | tiny_vit_21m) -> the key of
+# schema.TINYVIT_CFG; layers in train_tinyvit.py
+TINYVIT = {"tiny_vit_5m": "5m", "tiny_vit_11m": "11m", "tiny_vit_21m": "21m"}
 
 
 def _stream():
@@ -144,21 +148,20 @@ class HeadTrain:
 
 
 class Stage1Trainer:
-    """A stage-1 student (EfficientViT-B0 / B1 / B2 or RepViT-M0.9 / M1.1 / M2.3 backbone + head) that trains: ``step(images, teacher, sizes_before_pad)`` is one
+    """A stage-1 student (EfficientViT-B0 / B1 / B2, RepViT-M0.9 / M1.1 / M2.3 or TinyViT-5M / 11M / 21M backbone + head) that trains: ``step(images, teacher, sizes_before_pad)`` is one
     iteration of ``train_one_epoch`` (module docstring).  ``state_dict`` is the reference ``ImageStudentEncoder``'s
     (``backbone.model.<EfficientViTBackbone keys>``, ``head.*``), BatchNorm buffers included; ``state_dict()`` returns it back (fp32, host)."""
 
     def __init__(self, state_dict: Dict[str, torch.Tensor], model_name: str = "b1", embed_size: int = 72, dtype: str = "f32", device="cuda",
                  lr: float = 5e-4, weight_decay: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8, clip_grad: float = 5.0, amp: bool = False,
                  cosine_weight: float = 0.0, accumulation_steps: int = 1, init_scale: float = 65536.0, growth_interval: int = 2000,
-                 bn_momentum: float = 0.1, group=None, force_collective: bool = False):
+                 bn_momentum: float = 0.1, group=None, force_collective: bool = False, drop_path_sampler=None, seed: int = 0):
         from .dist import GradientAllReducer
         self.device = torch.device(device)
         tb.DEVICE = str(self.device)
         self.tdtype = {"f32": torch.float32, "bf16": torch.bfloat16}[dtype]
-        if model_name not in EFFICIENTVIT and model_name not in REPVIT:
-            raise ValueError(f"stage-1 student {model_name!r}: the trainer covers {sorted(EFFICIENTVIT) + sorted(REPVIT)} "
-                             "(the TinyViT students are not built)")
+        if model_name not in EFFICIENTVIT and model_name not in REPVIT and model_name not in TINYVIT:
+            raise ValueError(f"stage-1 student {model_name!r}: the trainer covers {sorted(EFFICIENTVIT) + sorted(REPVIT) + sorted(TINYVIT)}")
         self.model_name = model_name
         self.embed_size, self.cosine_weight, self.accumulation_steps = embed_size, float(cosine_weight), int(accumulation_steps)
         is_buffer = lambda k: k.endswith(("running_mean", "running_var", "num_batches_tracked"))  # noqa: E731
@@ -176,9 +179,13 @@ class Stage1Trainer:
         if model_name in EFFICIENTVIT:
             self.widths, self.depths, self.dim = EFFICIENTVIT[model_name]
             self.trunk = tb.EfficientViTTrunkTrain(views, self.widths, self.depths, self.dim, dtype=self.tdtype, prefix="backbone.model.")
-        else:
+        elif model_name in REPVIT:
             from .train_repvit import RepViTTrunkTrain
             self.trunk = RepViTTrunkTrain(views, REPVIT[model_name], dtype=self.tdtype, prefix="backbone.model.")
+        else:
+            from .train_tinyvit import TinyViTTrunkTrain
+            self.trunk = TinyViTTrunkTrain(views, TINYVIT[model_name], dtype=self.tdtype, prefix="backbone.model.", drop_path_sampler=drop_path_sampler,
+                                           seed=seed)
         for _, layer in self.trunk.norm_layers():
             layer.momentum = bn_momentum
         self.head = HeadTrain(views, embed_size)

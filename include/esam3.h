@@ -307,6 +307,31 @@ int esam3_train_stem(int dtype, const float* img_nchw_dev, const float* w_dev, v
 int esam3_resize_bilinear_backward(int dtype, const void* dy_dev, void* dx_dev, int B, int IH, int IW, int OH, int OW, int C,
                                    void* hip_stream);
 
+/* What a TinyViTBlock needs in training mode beyond the kernels above (csrc/kernels_train_vit.hip; round 5: the TinyViT students of stage 1,
+ * stage1/model.py:397-406 -> TinyViTAdapter over sam3/backbones/tiny_vit.py).  fp32 arithmetic, fp32 / bf16 rows.
+ *   esam3_ln_train_forward / _backward: nn.LayerNorm over the C channels of [M][C] rows (Attention.norm, Mlp.norm: tiny_vit.py:201,236) with
+ *     the saved per-row mean / rstd; backward = (dx, dgamma, dbeta), the two column sums over fixed row partitions (deterministic).
+ *     C % 8 == 0, C <= 1024; workspace esam3_ln_train_workspace(C) bytes.
+ *   esam3_win_attn_train_forward / _backward: the attention of Attention.forward between its two Linear layers (tiny_vit.py:271-293), per window
+ *     and head: out = softmax(q k^T scale + bias) v on qkv [windows][N][heads * 96] (per head q | k | v, 32 channels each), bias
+ *     [heads][N][N] fp32 = attention_biases[:, attention_bias_idxs] (symmetric in (i, j)), out [windows][N][heads * 32], lse
+ *     [windows][heads][N] fp32 (log-sum-exp of every row, kept for the backward).  Backward: dqkv like qkv, and ds
+ *     [windows][heads][N][N] fp32 = the gradient of the bias-added logits -- summed over the windows (esam3_colsum) it is the gradient of
+ *     `bias`.  N <= 256.
+ *   esam3_attn_bias_gather_sum: out[h][o] = sum of full[h][item] over the items (flattened (i, j)) whose attention_bias_idxs is o, given as
+ *     CSR lists (start [n_off + 1], items [NN]) on the device: the gradient of attention_biases [heads][n_off] from that of the gathered table. */
+int esam3_ln_train_forward(int dtype, const void* x_dev, void* y_dev, int64_t M, int C, const float* gamma_dev, const float* beta_dev, float eps,
+                           float* mean_dev, float* rstd_dev, void* hip_stream);
+int64_t esam3_ln_train_workspace(int C);
+int esam3_ln_train_backward(int dtype, const void* x_dev, const void* dy_dev, const float* gamma_dev, const float* mean_dev, const float* rstd_dev,
+                            void* dx_dev, float* dgamma_dev, float* dbeta_dev, int64_t M, int C, void* workspace_dev, void* hip_stream);
+int esam3_win_attn_train_forward(int dtype, const void* qkv_dev, const float* bias_dev, void* out_dev, float* lse_dev, int windows, int N, int heads,
+                                 float scale, void* hip_stream);
+int esam3_win_attn_train_backward(int dtype, const void* qkv_dev, const float* bias_dev, const void* out_dev, const float* lse_dev,
+                                  const void* dout_dev, void* dqkv_dev, float* ds_dev, int windows, int N, int heads, float scale, void* hip_stream);
+int esam3_attn_bias_gather_sum(const float* full_dev, const int* start_dev, const int* items_dev, float* out_dev, int heads, int NN, int n_off,
+                               void* hip_stream);
+
 /* Update half of the stage-1 training step: AMP loss scaler + gradient-norm clipping + AdamW on ONE flat fp32 arena.
  * Replaces, for a student whose trainable parameters live in `params` (each tensor padded to a multiple of 256 elements),
  *   NativeScalerWithGradNormCount.__call__ after backward (stage1/utils.py:347-362): GradScaler.unscale_ (non-finite

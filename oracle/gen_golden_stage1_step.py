@@ -22,7 +22,8 @@ from itself).
     PYTHONPATH=oracle/shims:/root/reference:. python oracle/gen_golden_stage1_step.py     (the OUTER sam3 package: stage1/model.py imports sam3.sam3.*)
 
 Output: tests/golden/stage1/step.npz + step_manifest.json (`--model b2`: step_b2.npz + step_b2_manifest.json, round 5;
-`--model repvit_m0_9` / `repvit_m1_1`: step_repvit_m0_9.* / step_repvit_m1_1.*, the RepViT students of stage1/model.py:386-395)
+`--model repvit_m0_9` / `repvit_m1_1`: step_repvit_m0_9.* / step_repvit_m1_1.*, the RepViT students of stage1/model.py:386-395;
+`--model tiny_vit_5m` / `tiny_vit_11m`: step_tiny_vit_5m.* / step_tiny_vit_11m.*, the TinyViT students of stage1/model.py:397-406)
 """
 from __future__ import annotations
 
@@ -55,12 +56,16 @@ NSAMP = 256
 
 MODEL = "b1"          # --model b0 | b1 | b2 (the default b1 writes step.npz / step_manifest.json, the others step_<model>.*)
                       # | repvit_m0_9 | repvit_m1_1 | repvit_m2_3 (round 5: the RepViT students, stage1/model.py:386-395)
+                      # | tiny_vit_5m | tiny_vit_11m | tiny_vit_21m (the TinyViT students, stage1/model.py:397-406; 11m / 21m train with
+                      #   stochastic depth: the per-sample keep masks every DropPath drew are part of the fixture)
 
 
 def _family():
     """(schema backbone type, schema model name, MODEL.BACKBONE of the reference's config)"""
     if MODEL.startswith("repvit_"):
         return "repvit", MODEL[len("repvit_"):].replace("_", "."), MODEL
+    if MODEL.startswith("tiny_vit_"):
+        return "tinyvit", MODEL[len("tiny_vit_"):], MODEL
     return "efficientvit", MODEL, f"efficientvit_{MODEL}"
 
 
@@ -108,14 +113,38 @@ def run(amp: bool):
     net = ref_model.build_image_student_model(cfg)
     missing, unexpected = net.load_state_dict(student_state_dict(), strict=True)
     net.train()
+    drawn = []           # (module name, call index within the forward pass, per-sample factor) of every DropPath call, in call order
+    calls = {}
+
+    def recording(name, mod):
+        def forward(x):
+            if mod.drop_prob == 0.0 or not mod.training:
+                return x
+            keep = 1 - mod.drop_prob                       # timm.layers.drop_path (scale_by_keep=True), as the shim restates it
+            # drawn in fp32 whatever the activation dtype, so that the fp32 and the bf16-autocast run drop the same branches
+            mask = torch.empty((x.shape[0],) + (1,) * (x.ndim - 1), dtype=torch.float32).bernoulli_(keep)
+            if keep > 0.0:
+                mask.div_(keep)
+            k = calls.get(name, 0)
+            calls[name] = k + 1
+            drawn.append((name, k, mask.reshape(-1).clone()))
+            return x * mask.to(x.dtype)
+        return forward
+
+    for name, mod in net.named_modules():
+        if type(mod).__name__ == "DropPath":
+            mod.forward = recording(name, mod)
     opt = ref_optimizer.build_optimizer(cfg, net)
     opt.zero_grad()
     imgs, teacher = inputs()
     named = dict(net.named_parameters())
     rec = {"losses": [], "mse": [], "cosine": [], "grad_norms": []}
     arrays = {}
+    torch.manual_seed(1234)      # the stream the DropPath masks are drawn from (the same in the fp32 and the bf16 run)
     for step in range(2):
         t0 = time.time()
+        calls.clear()
+        del drawn[:]
         ctx = torch.autocast("cpu", dtype=torch.bfloat16) if amp else torch.autocast("cpu", enabled=False)
         with ctx:
             preds = net(imgs)
@@ -126,6 +155,8 @@ def run(amp: bool):
         # NativeScalerWithGradNormCount.__call__ with the GradScaler disabled (AMP off): backward, clip_grad_norm_, step
         loss.backward()
         norm = torch.nn.utils.clip_grad_norm_(net.parameters(), cfg.TRAIN.CLIP_GRAD)
+        for name, k, mask in drawn:
+            arrays[f"droppath{step + 1}/{name}/{k}"] = mask.numpy()
         if step == 0 and not amp:
             for n, p in named.items():
                 arrays[f"grad1/{n}"] = sample(p.grad)    # after clipping: what AdamW sees
@@ -152,12 +183,14 @@ def main():
     global MODEL
     import argparse
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="b1", choices=["b0", "b1", "b2", "repvit_m0_9", "repvit_m1_1", "repvit_m2_3"])
+    ap.add_argument("--model", default="b1", choices=["b0", "b1", "b2", "repvit_m0_9", "repvit_m1_1", "repvit_m2_3", "tiny_vit_5m", "tiny_vit_11m", "tiny_vit_21m"])
     MODEL = ap.parse_args().model
     suffix = "" if MODEL == "b1" else f"_{MODEL}"
     os.makedirs(GOLD, exist_ok=True)
     fp32, arrays = run(False)
-    bf16, _ = run(True)
+    bf16, arrays16 = run(True)
+    for k in [k for k in arrays if k.startswith("droppath")]:
+        assert np.array_equal(arrays[k], arrays16[k]), k      # both runs dropped the same residual branches
     man = {"source": "stage1/train_image_encoder_stage1.py:165-226, stage1/model.py:28-37,188-211, stage1/optimizer.py:6-46, stage1/utils.py:341-368",
            "hyper": HYPER, "img_size": IMG, "embed_dim": EMBED_DIM, "embed_size": EMBED_SIZE, "sizes_before_pad": SIZES,
            "image_seeds": list(IMAGE_SEEDS), "teacher_seed": TEACHER_SEED, "samples_per_tensor": NSAMP, "torch": torch.__version__,

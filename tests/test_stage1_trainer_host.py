@@ -1,9 +1,9 @@
 """CPU: the HOST LOGIC of efficientsam3_amd/stage1_train.py (``Stage1Trainer``: arena views handed to the layers, head and trunk sequencing,
-gradient sink and arrival order, state-dict names, BatchNorm buffers, the update) with a RepViT student, every kernel wrapper replaced by a
+gradient sink and arrival order, state-dict names, BatchNorm buffers, the update) with a RepViT or TinyViT student, every kernel wrapper replaced by a
 plain torch / numpy stand-in of the same contract (tests/test_train_blocks_host.py, tests/test_train_repvit_host.py, the oracle's loss and
-update), against the REAL reference stack's run of the same two iterations (tests/golden/stage1/step_repvit_m0_9.*, made by
-oracle/gen_golden_stage1_step.py --model repvit_m0_9).  The GPU twin, with the HIP kernels in place of the stand-ins, is
-tests/test_stage1_step.py::test_repvit_training_steps_match_the_reference_run."""
+update), against the REAL reference stack's run of the same two iterations (tests/golden/stage1/step_repvit_m0_9.*, step_tiny_vit_5m.*,
+step_tiny_vit_11m.*, made by oracle/gen_golden_stage1_step.py --model ...).  The GPU twins, with the HIP kernels in place of the stand-ins, are
+tests/test_stage1_step.py::test_repvit_training_steps_match_the_reference_run and ::test_tinyvit_training_steps_match_the_reference_run."""
 import json
 import os
 
@@ -16,6 +16,7 @@ from efficientsam3_amd import schema, stage1, stage1_train, synth
 from oracle import ref_stage1
 from tests.test_train_blocks_host import _to_nchw, _to_nhwc, cpu_kernels  # noqa: F401
 from tests.test_train_repvit_host import repvit_kernels  # noqa: F401
+from tests.test_train_tinyvit_host import tinyvit_kernels  # noqa: F401
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stage1")
 PREFIX = "backbone.vision_backbone.trunk.model."
@@ -46,7 +47,7 @@ class HostUpdater(stage1.Stage1Updater):
 
 
 @pytest.fixture
-def host_trainer(repvit_kernels, monkeypatch):  # noqa: F811
+def host_trainer(tinyvit_kernels, monkeypatch):  # noqa: F811
     def loss(p2, t2, valid):          # [B, HW, C] rows -> the reference's NCHW functions on [B, C, HW, 1]
         p, t, m = p2.permute(0, 2, 1)[..., None].float(), t2.permute(0, 2, 1)[..., None].float(), valid[:, None, :, None].float()
         return ref_stage1.masked_mse(p, t, m), ref_stage1.masked_cosine_loss(p, t, m), None
@@ -84,16 +85,29 @@ def _sample(t, n):
     return flat[::step][:n].numpy()
 
 
-def test_repvit_trainer_host_logic_vs_the_reference_run(host_trainer):
-    with open(os.path.join(GOLD, "step_repvit_m0_9_manifest.json")) as f:
+@pytest.mark.parametrize("model,family,name", [("repvit_m0_9", "repvit", "m0.9"), ("tiny_vit_5m", "tinyvit", "5m"), ("tiny_vit_11m", "tinyvit", "11m")])
+def test_trainer_host_logic_vs_the_reference_run(host_trainer, model, family, name):
+    """RepViT-M0.9; TinyViT-5M (no stochastic depth); TinyViT-11M with the DropPath factors of the reference's run (part of the fixture) fed
+    through ``drop_path_sampler``"""
+    with open(os.path.join(GOLD, f"step_{model}_manifest.json")) as f:
         man = json.load(f)
-    g = np.load(os.path.join(GOLD, "step_repvit_m0_9.npz"))
+    g = np.load(os.path.join(GOLD, f"step_{model}.npz"))
     hy, ref, ns = man["hyper"], man["fp32"], man["samples_per_tensor"]
-    sd = schema.synthetic_state_dict("repvit", "m0.9", seed=0)
+    sd = schema.synthetic_state_dict(family, name, seed=0)
     sd = {k[len(PREFIX):]: v.clone() for k, v in sd.items() if k.startswith(PREFIX)}
-    tr = stage1_train.Stage1Trainer(sd, "repvit_m0_9", embed_size=man["embed_size"], dtype="f32", device="cpu", lr=hy["lr"], weight_decay=hy["weight_decay"],
+    step_no = [1]
+    used = []
+
+    def sampler(mod, call, batch, keep):
+        key = f"droppath{step_no[0]}/backbone.model.{mod}/{call}"
+        used.append(key)
+        f = g[key]
+        assert f.shape == (batch,) and set(np.round(f * keep, 5).tolist()) <= {0.0, 1.0}, (key, f, keep)
+        return torch.from_numpy(f)
+
+    tr = stage1_train.Stage1Trainer(sd, model, embed_size=man["embed_size"], dtype="f32", device="cpu", lr=hy["lr"], weight_decay=hy["weight_decay"],
                                     betas=tuple(hy["betas"]), eps=hy["eps"], clip_grad=hy["clip_grad"], amp=False, cosine_weight=hy["cosine"],
-                                    accumulation_steps=hy["accumulation_steps"])
+                                    accumulation_steps=hy["accumulation_steps"], drop_path_sampler=sampler)
     imgs = torch.stack([torch.from_numpy(synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=s))) for s in man["image_seeds"]])
     for i, (h, w) in enumerate(man["sizes_before_pad"]):
         imgs[i, :, h:, :] = 0
@@ -103,6 +117,7 @@ def test_repvit_trainer_host_logic_vs_the_reference_run(host_trainer):
     sizes = [tuple(s) for s in man["sizes_before_pad"]]
 
     out = tr.step(imgs, teacher, sizes, update_grad=False)
+    assert sorted(used) == sorted(k for k in g.files if k.startswith("droppath1/"))          # every factor the reference drew was asked for
     grads = {n: _sample(v, ns) for n, v in tr.gradients().items()}
     norm = float(tr.updater.step())
     tr._micro = 0
@@ -124,8 +139,10 @@ def test_repvit_trainer_host_logic_vs_the_reference_run(host_trainer):
         assert float(np.abs(_sample(state[k], ns) - want).max()) <= 1e-4 * max(1.0, float(np.abs(want).max())), k
     assert all(int(v) == int(sd[k]) + 1 for k, v in state.items() if k.endswith("num_batches_tracked"))
     # the arrival order of the gradients (= the bucket order of the all-reduce): head first, then the trunk from its last block to the stem
-    assert tr._arrival[0].startswith("head.") and tr._arrival[-1] == "backbone.model.features.0.0.bn.bias"
+    first = {"repvit": "backbone.model.features.0.0.bn.bias", "tinyvit": "backbone.model.patch_embed.seq.0.bn.bias"}[family]
+    assert tr._arrival[0].startswith("head.") and tr._arrival[-1] == first
 
+    step_no[0] = 2
     out = tr.step(imgs, teacher, sizes)
     loss2, norm2 = float(out["loss"]), float(out["grad_norm"])
     assert abs(loss2 - ref["losses"][1]) <= 1e-3 * abs(ref["losses"][1]), (loss2, ref["losses"][1])
