@@ -25,6 +25,7 @@ DTS = {"f32": torch.float32, "bf16": torch.bfloat16}
 GRAD_REL, GRAD_ABS = 2.5e-2, 2.5e-5
 RV_GRAD_REL, RV_GRAD_ABS = 2.5e-3, 5e-6    # the RepViT students (round 5): first run used 0.015 - 0.018 of (5e-2, 1e-4), worst tensor 4.6e-4 of its
                                            # maximum (profiles/r05/parity_margins_repvit_steps.txt); this allowance is 1 / 20 of that one
+TV_GRAD_REL, TV_GRAD_ABS = 2.5e-2, 2.5e-5    # the TinyViT students (round 5): the EfficientViT-B1 allowance until their margins are on record
 B2_GRAD_REL, B2_GRAD_ABS = 5e-2, 1e-4      # EfficientViT-B2: 35 x larger gradients through a deeper chain of training-mode BatchNorms
 
 
@@ -303,6 +304,14 @@ def test_bf16_training_step_inside_the_reference_autocast_yardstick(step_gold):
         assert abs(loss - r32["losses"][step]) <= lim_l and abs(norm - r32["grad_norms"][step]) <= lim_n
 
 
+def _fixture_drop_path(g, step_no):
+    """the DropPath factors the reference's run drew (oracle/gen_golden_stage1_step.py records them per module and call), as the trainer's
+    ``drop_path_sampler``; None for fixtures of students without stochastic depth"""
+    if not any(k.startswith("droppath") for k in g.files):
+        return None
+    return lambda mod, call, batch, keep: torch.from_numpy(g[f"droppath{step_no[0]}/backbone.model.{mod}/{call}"])
+
+
 def _first_step_vs_reference(model, suffix, sd, grad_rel, grad_abs, second_step=None, check_buffers=False, loss_rel=1e-4, norm_rel=1e-2):
     """the first iteration of the trainer (fp32) against the reference stack's own run (tests/golden/stage1/step_<suffix>.*): loss, total
     gradient norm, every parameter's clipped gradient (samples), every parameter after the update; ``second_step`` = (loss rel, norm rel):
@@ -313,8 +322,10 @@ def _first_step_vs_reference(model, suffix, sd, grad_rel, grad_abs, second_step=
     g = np.load(os.path.join(GOLD, f"step_{suffix}.npz"))
     hy, ref, ns = man["hyper"], man["fp32"], man["samples_per_tensor"]
     assert set(ref["names"]) == {k for k in sd if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))}
+    step_no = [1]
     tr = Stage1Trainer(sd, model, embed_size=man["embed_size"], dtype="f32", lr=hy["lr"], weight_decay=hy["weight_decay"], betas=tuple(hy["betas"]),
-                       eps=hy["eps"], clip_grad=hy["clip_grad"], amp=False, cosine_weight=hy["cosine"], accumulation_steps=hy["accumulation_steps"])
+                       eps=hy["eps"], clip_grad=hy["clip_grad"], amp=False, cosine_weight=hy["cosine"], accumulation_steps=hy["accumulation_steps"],
+                       drop_path_sampler=_fixture_drop_path(g, step_no))
     imgs, teacher = _inputs(man)
     imgs, teacher = imgs.cuda(), teacher.cuda()
     sizes = [tuple(s_) for s_ in man["sizes_before_pad"]]
@@ -357,6 +368,7 @@ def _first_step_vs_reference(model, suffix, sd, grad_rel, grad_abs, second_step=
     print(f"  BatchNorm running statistics after step 1 ({len(bufs)} buffers): worst |diff| / max(1, |ref|) = {worst_buf:.2e}")
     assert worst_buf <= 1e-5          # measured 1.5e-7
     if second_step is not None:
+        step_no[0] = 2
         out = tr.step(imgs, teacher, sizes)
         loss2, norm2 = float(out["loss"]), float(out["grad_norm"])
         print(f"[stage-1 {model} step 2] loss {loss2:.6f} (reference {ref['losses'][1]:.6f}, allowed {second_step[0]:g} rel)  "
@@ -413,6 +425,49 @@ def test_repvit_bf16_training_step_inside_the_reference_autocast_yardstick(model
     imgs, teacher = _inputs(man)
     imgs, teacher = imgs.cuda(), teacher.cuda().to(torch.bfloat16)
     for step in range(2):
+        out = tr.step(imgs, teacher, [tuple(s_) for s_ in man["sizes_before_pad"]])
+        loss, norm = float(out["loss"]), float(out["grad_norm"])
+        r32, r16 = man["fp32"], man["bf16_autocast"]
+        lim_l = 1.5 * abs(r16["losses"][step] - r32["losses"][step]) + 1e-2 * abs(r32["losses"][step])
+        lim_n = 1.5 * abs(r16["grad_norms"][step] - r32["grad_norms"][step]) + 5e-2 * r32["grad_norms"][step]
+        print(f"[stage-1 {model} bf16 step {step + 1}] loss {loss:.5f} (fp32 ref {r32['losses'][step]:.5f}, ref bf16 {r16['losses'][step]:.5f}, "
+              f"allowed +-{lim_l:.4f}) grad norm {norm:.4f} ({r32['grad_norms'][step]:.4f} / {r16['grad_norms'][step]:.4f}, +-{lim_n:.4f})")
+        assert np.isfinite(loss) and np.isfinite(norm)
+        assert abs(loss - r32["losses"][step]) <= lim_l and abs(norm - r32["grad_norms"][step]) <= lim_n
+
+
+def _tinyvit_sd(name):
+    sd = schema.synthetic_state_dict("tinyvit", name, seed=0)
+    return {k[len(PREFIX):]: v.clone() for k, v in sd.items() if k.startswith(PREFIX)}
+
+
+@pytest.mark.parametrize("model,name", [("tiny_vit_5m", "5m"), ("tiny_vit_11m", "11m")])
+def test_tinyvit_training_steps_match_the_reference_run(model, name):
+    """The TinyViT students (TV-S / TV-M: stage1/model.py:397-406 -> TinyViTAdapter over sam3/backbones/tiny_vit.py) through the same trainer --
+    MBConv stage, PatchMerging, window attention over zero-padded windows (63 -> 70 for the 14-token windows, 32 -> 35 for the last stage)
+    with its learned bias table, LayerNorm, MLP, and for 11m stochastic depth with the per-sample factors of the reference's own run --
+    against the REAL reference stack's run (oracle/gen_golden_stage1_step.py --model tiny_vit_5m | tiny_vit_11m): first iteration (loss,
+    norm, every clipped gradient, every updated parameter, every running statistic), loss and gradient norm of the second."""
+    _first_step_vs_reference(model, model, _tinyvit_sd(name), TV_GRAD_REL, TV_GRAD_ABS, second_step=(1e-4, 1e-2), check_buffers=True, loss_rel=2e-5, norm_rel=5e-3)
+
+
+@pytest.mark.parametrize("model,name", [("tiny_vit_5m", "5m"), ("tiny_vit_11m", "11m")])
+def test_tinyvit_bf16_training_step_inside_the_reference_autocast_yardstick(model, name):
+    """the same two iterations with bf16 activations: loss and gradient norm against the reference's fp32 run, allowed 1.5 x the distance of
+    the reference's own bf16-autocast run + 1 % (loss) / 5 % (norm) of the value -- the rule of the EfficientViT-B1 test"""
+    from efficientsam3_amd.stage1_train import Stage1Trainer
+    with open(os.path.join(GOLD, f"step_{model}_manifest.json")) as f:
+        man = json.load(f)
+    g = np.load(os.path.join(GOLD, f"step_{model}.npz"))
+    hy = man["hyper"]
+    step_no = [1]
+    tr = Stage1Trainer(_tinyvit_sd(name), model, embed_size=man["embed_size"], dtype="bf16", lr=hy["lr"], weight_decay=hy["weight_decay"],
+                       betas=tuple(hy["betas"]), eps=hy["eps"], clip_grad=hy["clip_grad"], amp=False, cosine_weight=hy["cosine"],
+                       drop_path_sampler=_fixture_drop_path(g, step_no))
+    imgs, teacher = _inputs(man)
+    imgs, teacher = imgs.cuda(), teacher.cuda().to(torch.bfloat16)
+    for step in range(2):
+        step_no[0] = step + 1
         out = tr.step(imgs, teacher, [tuple(s_) for s_ in man["sizes_before_pad"]])
         loss, norm = float(out["loss"]), float(out["grad_norm"])
         r32, r16 = man["fp32"], man["bf16_autocast"]
