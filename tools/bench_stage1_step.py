@@ -1,12 +1,13 @@
 """Stage-1 training step on one MI355X: a student (backbone + head; default EfficientViT-B1, --model b0 | b1 | b2 | repvit_m0_9 | repvit_m1_1 |
-repvit_m2_3) at 1008^2, synthetic images / teacher embeddings,
+repvit_m2_3 | tiny_vit_5m | tiny_vit_11m | tiny_vit_21m) at 1008^2, synthetic images / teacher embeddings,
 forward + masked MSE / cosine loss + backward + clip + AdamW (efficientsam3_amd.stage1_train.Stage1Trainer; the step the reference runs in
 stage1/train_image_encoder_stage1.py:165-226).  Prints ONE JSON line; the roofline leg prices the whole step's algorithmic FLOPs
 (forward graph of SURVEY.md 8(d): backbone 20.3 + head 19.9 GFLOP / image; a training step is forward + input gradients + weight
 gradients = 3 x) against the dense bf16 MFMA peak.
 
 For the other students the forward FLOPs are COUNTED from the layers after a forward pass (2 x output elements x weight elements per output
-channel of every convolution of trunk and head; the SqueezeExcite MLPs and LiteMLA's attention products are left out).
+channel of every convolution of trunk and head; the SqueezeExcite MLPs, LiteMLA's attention products and, for TinyViT, the Linear layers
+and attention products are left out: its figure is a lower bound).
 
     python tools/bench_stage1_step.py [--batch 8] [--steps 5] [--warmup 2] [--dtype bf16|f32] [--model b1]
 """
@@ -56,13 +57,18 @@ def counted_forward_flops(obj, seen=None) -> float:
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--model", default="b1", choices=["b0", "b1", "b2", "repvit_m0_9", "repvit_m1_1", "repvit_m2_3"])
+    ap.add_argument("--model", default="b1", choices=["b0", "b1", "b2", "repvit_m0_9", "repvit_m1_1", "repvit_m2_3", "tiny_vit_5m", "tiny_vit_11m", "tiny_vit_21m"])
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     a = ap.parse_args()
-    family, name = ("repvit", a.model[len("repvit_"):].replace("_", ".")) if a.model.startswith("repvit_") else ("efficientvit", a.model)
+    if a.model.startswith("repvit_"):
+        family, name = "repvit", a.model[len("repvit_"):].replace("_", ".")
+    elif a.model.startswith("tiny_vit_"):
+        family, name = "tinyvit", a.model[len("tiny_vit_"):]
+    else:
+        family, name = "efficientvit", a.model
     sd = schema.synthetic_state_dict(family, name, seed=0)
     sd = {k[len(PREFIX):]: v.clone() for k, v in sd.items() if k.startswith(PREFIX)}
     tr = Stage1Trainer(sd, a.model, embed_size=72, dtype=a.dtype, lr=1e-4, weight_decay=0.05, clip_grad=5.0, cosine_weight=0.5)
