@@ -274,9 +274,11 @@ __global__ __launch_bounds__(256) void win_attn_forward_kernel(const typename VE
 }
 
 // backward.  P_ij = exp(s_ij - lse_i); dP_ij = dO_i . v_j; D_i = dO_i . O_i (= sum_j P_ij dP_ij); dS_ij = P_ij (dP_ij - D_i);
-//   dq_i = scale sum_j dS_ij k_j     (phase A, thread = query row i, K / V rows broadcast from LDS)
-//   dk_j = scale sum_i dS_ij q_i,  dv_j = sum_i P_ij dO_i,  dS written [window][head][i][j]   (phase B, thread = key row j, Q / dO rows
-//   broadcast from LDS; the store of dS_i. is coalesced over j)
+//   phase 0 (blockIdx.z = 0, thread = query row i, K / V rows broadcast from LDS):   dq_i = scale sum_j dS_ij k_j
+//   phase 1 (blockIdx.z = 1, thread = key row j, Q / dO rows broadcast from LDS):    dk_j = scale sum_i dS_ij q_i,  dv_j = sum_i P_ij dO_i,
+//                                                                                    dS written [window][head][i][j] (coalesced over j)
+// The two phases are separate workgroups: each stages only the two operands it broadcasts (2 N 32 floats: three workgroups fit a CU where
+// one with all four did not -- the single-workgroup form spent 15 ms of a 54 ms TinyViT-11M step, profiles/r05/stage1_step_tiny_vit_11m_kernel_stats.csv).
 template <int DT>
 __global__ __launch_bounds__(256) void win_attn_backward_kernel(const typename VElem<DT>::type* __restrict__ qkv, const float* __restrict__ bias,
                                                                 const typename VElem<DT>::type* __restrict__ out, const float* __restrict__ lse,
@@ -284,21 +286,22 @@ __global__ __launch_bounds__(256) void win_attn_backward_kernel(const typename V
                                                                 typename VElem<DT>::type* __restrict__ dqkv, float* __restrict__ ds_out, int N, int heads,
                                                                 float scale) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* sq = lds;
-  float* sk = sq + N * HD;
-  float* sv = sk + N * HD;
-  float* sdo = sv + N * HD;
-  float* slse = sdo + N * HD;
+  float* sa = lds;                 // phase 0: K      phase 1: Q
+  float* sb = sa + N * HD;         // phase 0: V      phase 1: dO
+  float* slse = sb + N * HD;
   float* sd = slse + N;
-  const int w = blockIdx.x, h = blockIdx.y, ld = heads * 3 * HD, ldo = heads * HD;
+  const int w = blockIdx.x, h = blockIdx.y, phase = blockIdx.z, ld = heads * 3 * HD, ldo = heads * HD;
   const typename VElem<DT>::type* base = qkv + (int64_t)w * N * ld + h * 3 * HD;
   const typename VElem<DT>::type* dobase = dout + (int64_t)w * N * ldo + h * HD;
-  stage_rows<DT>(base, ld, N, sq);
-  stage_rows<DT>(base + HD, ld, N, sk);
-  stage_rows<DT>(base + 2 * HD, ld, N, sv);
-  stage_rows<DT>(dobase, ldo, N, sdo);
+  if (phase == 0) {
+    stage_rows<DT>(base + HD, ld, N, sa);
+    stage_rows<DT>(base + 2 * HD, ld, N, sb);
+  } else {
+    stage_rows<DT>(base, ld, N, sa);
+    stage_rows<DT>(dobase, ldo, N, sb);
+  }
   const int t = threadIdx.x;
-  float mine[HD], other[HD];      // phase A: q_i (scaled), dO_i; phase B: k_j (scaled), v_j
+  float mine[HD], other[HD];      // phase 0: q_i (scaled), dO_i; phase 1: k_j (scaled), v_j
   if (t < N) {
     load_row<DT>(dobase + (int64_t)t * ldo, other);
     load_row<DT>(out + ((int64_t)w * N + t) * ldo + h * HD, mine);
@@ -309,9 +312,10 @@ __global__ __launch_bounds__(256) void win_attn_backward_kernel(const typename V
     slse[t] = lse[((int64_t)w * heads + h) * N + t];
   }
   __syncthreads();
+  if (t >= N) return;
   const float* bcol = bias + (int64_t)h * N * N + t;     // bias[h][.][t]: symmetric table, coalesced over the threads
-  if (t < N) {   // ---- phase A ----
-    load_row<DT>(base + (int64_t)t * ld, mine);
+  if (phase == 0) {
+    load_row<DT>(base + (int64_t)t * ld, mine);           // q_i; `other` still holds dO_i
 #pragma unroll
     for (int c = 0; c < HD; ++c) mine[c] *= scale;
     float dq[HD];
@@ -319,15 +323,15 @@ __global__ __launch_bounds__(256) void win_attn_backward_kernel(const typename V
     for (int c = 0; c < HD; ++c) dq[c] = 0.f;
     const float lse_i = slse[t], d_i = sd[t];
     for (int j = 0; j < N; ++j) {
-      const float* kj = sk + j * HD;
+      const float* kj = sa + j * HD;
       const float s = dot32(mine, kj) + bcol[(int64_t)j * N];
       const float p = __expf(s - lse_i);
-      const float dsv = p * (dot32(other, sv + j * HD) - d_i) * scale;
+      const float dsv = p * (dot32(other, sb + j * HD) - d_i) * scale;
 #pragma unroll
       for (int c = 0; c < HD; ++c) dq[c] += dsv * kj[c];
     }
     store_row<DT>(dqkv + ((int64_t)w * N + t) * ld + h * 3 * HD, dq);
-    // ---- phase B ----
+  } else {
     load_row<DT>(base + (int64_t)t * ld + HD, mine);        // k_j
     load_row<DT>(base + (int64_t)t * ld + 2 * HD, other);   // v_j
 #pragma unroll
@@ -337,8 +341,8 @@ __global__ __launch_bounds__(256) void win_attn_backward_kernel(const typename V
     for (int c = 0; c < HD; ++c) dk[c] = dv[c] = 0.f;
     float* dsrow = ds_out + ((int64_t)w * heads + h) * N * N + t;
     for (int i = 0; i < N; ++i) {
-      const float* qi = sq + i * HD;
-      const float* doi = sdo + i * HD;
+      const float* qi = sa + i * HD;
+      const float* doi = sb + i * HD;
       const float s = dot32(mine, qi) + bcol[(int64_t)i * N];     // scale q_i . k_j + bias[h][i][j]
       const float p = __expf(s - slse[i]);
       const float dsv = p * (dot32(other, doi) - sd[i]);
@@ -355,15 +359,17 @@ __global__ __launch_bounds__(256) void win_attn_backward_kernel(const typename V
   }
 }
 
-// out[h][o] = sum over the items of offset o (CSR: start[o] .. start[o + 1]) of full[h][item], in list order
+// out[h][o] = sum over the items of offset o (CSR: start[o] .. start[o + 1]) of full[h][item]: one wavefront per (head, offset), lane l adds
+// the items l, l + 64, ... in list order, the 64 lane sums are added by the butterfly of wave_sum -- a fixed order (deterministic)
 __global__ __launch_bounds__(256) void bias_gather_sum_kernel(const float* __restrict__ full, const int* __restrict__ start, const int* __restrict__ items,
                                                               float* __restrict__ out, int heads, int NN, int n_off) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= heads * n_off) return;
   const int h = i / n_off, o = i - h * n_off;
   float s = 0.f;
-  for (int k = start[o]; k < start[o + 1]; ++k) s += full[(int64_t)h * NN + items[k]];
-  out[i] = s;
+  for (int k = start[o] + lane; k < start[o + 1]; k += 64) s += full[(int64_t)h * NN + items[k]];
+  s = wave_sum(s);
+  if (lane == 0) out[i] = s;
 }
 
 int bad(const char* what) {
@@ -433,15 +439,15 @@ int esam3_win_attn_train_backward(int dtype, const void* qkv, const float* bias,
       heads > 65535)
     return bad("esam3_win_attn_train_backward (fp32 / bf16; at most 256 tokens per window; head dim 32)");
   hipStream_t s = (hipStream_t)stream;
-  const int threads = (N + 63) / 64 * 64, lds = (4 * N * HD + 2 * N) * (int)sizeof(float);
-  const int lds_max = (4 * 256 * HD + 2 * 256) * (int)sizeof(float);
+  const int threads = (N + 63) / 64 * 64, lds = (2 * N * HD + 2 * N) * (int)sizeof(float);
+  const int lds_max = (2 * 256 * HD + 2 * 256) * (int)sizeof(float);
   if (dtype == 0) {
     if (esam3_allow_dyn_lds((const void*)win_attn_backward_kernel<0>, lds_max)) return -1;
-    hipLaunchKernelGGL(win_attn_backward_kernel<0>, dim3((unsigned)windows, (unsigned)heads), dim3(threads), lds, s, (const float*)qkv, bias, (const float*)out,
+    hipLaunchKernelGGL(win_attn_backward_kernel<0>, dim3((unsigned)windows, (unsigned)heads, 2), dim3(threads), lds, s, (const float*)qkv, bias, (const float*)out,
                        lse, (const float*)dout, (float*)dqkv, ds, N, heads, scale);
   } else {
     if (esam3_allow_dyn_lds((const void*)win_attn_backward_kernel<1>, lds_max)) return -1;
-    hipLaunchKernelGGL(win_attn_backward_kernel<1>, dim3((unsigned)windows, (unsigned)heads), dim3(threads), lds, s, (const uint16_t*)qkv, bias,
+    hipLaunchKernelGGL(win_attn_backward_kernel<1>, dim3((unsigned)windows, (unsigned)heads, 2), dim3(threads), lds, s, (const uint16_t*)qkv, bias,
                        (const uint16_t*)out, lse, (const uint16_t*)dout, (uint16_t*)dqkv, ds, N, heads, scale);
   }
   HIP_CHECK_RET(hipGetLastError());
@@ -451,7 +457,7 @@ int esam3_win_attn_train_backward(int dtype, const void* qkv, const float* bias,
 int esam3_attn_bias_gather_sum(const float* full, const int* start, const int* items, float* out, int heads, int NN, int n_off, void* stream) {
   if (!full || !start || !items || !out || heads <= 0 || NN <= 0 || n_off <= 0) return bad("esam3_attn_bias_gather_sum");
   const int n = heads * n_off;
-  hipLaunchKernelGGL(bias_gather_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, full, start, items, out, heads, NN, n_off);
+  hipLaunchKernelGGL(bias_gather_sum_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, full, start, items, out, heads, NN, n_off);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

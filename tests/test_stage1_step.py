@@ -25,7 +25,8 @@ DTS = {"f32": torch.float32, "bf16": torch.bfloat16}
 GRAD_REL, GRAD_ABS = 2.5e-2, 2.5e-5
 RV_GRAD_REL, RV_GRAD_ABS = 2.5e-3, 5e-6    # the RepViT students (round 5): first run used 0.015 - 0.018 of (5e-2, 1e-4), worst tensor 4.6e-4 of its
                                            # maximum (profiles/r05/parity_margins_repvit_steps.txt); this allowance is 1 / 20 of that one
-TV_GRAD_REL, TV_GRAD_ABS = 2.5e-2, 2.5e-5    # the TinyViT students (round 5): the EfficientViT-B1 allowance until their margins are on record
+TV_GRAD_REL, TV_GRAD_ABS = 2.5e-3, 2.5e-6    # the TinyViT students (round 5): first run used 0.011 of (2.5e-2, 2.5e-5), worst tensor 3.0e-4 of its maximum
+                                             # (profiles/r05/parity_margins_tinyvit_steps.txt); this allowance is 1 / 10 of that one
 B2_GRAD_REL, B2_GRAD_ABS = 5e-2, 1e-4      # EfficientViT-B2: 35 x larger gradients through a deeper chain of training-mode BatchNorms
 
 
@@ -304,6 +305,12 @@ def test_bf16_training_step_inside_the_reference_autocast_yardstick(step_gold):
         assert abs(loss - r32["losses"][step]) <= lim_l and abs(norm - r32["grad_norms"][step]) <= lim_n
 
 
+# Note on the gradient-norm column of the RepViT / TinyViT fixtures: this trainer's norm is 2.8e-4 - 3.4e-4 ABOVE the fixture's in every model and
+# step, on the GPU and in the CPU emulation alike.  The fixture holds what the reference's loop logs, torch.nn.utils.clip_grad_norm_'s fp32
+# value; the float64 norm of the reference's own gradients (computed when the offset was chased: 673.4554 for repvit_m0_9 against the logged
+# 673.2244) equals this trainer's (673.4554): clip_grad_norm_ sums the 9.4 M squares of head.3.weight in fp32.  Hence norm limits of 2e-3, not 1e-5.
+
+
 def _fixture_drop_path(g, step_no):
     """the DropPath factors the reference's run drew (oracle/gen_golden_stage1_step.py records them per module and call), as the trainer's
     ``drop_path_sampler``; None for fixtures of students without stochastic depth"""
@@ -448,7 +455,8 @@ def test_tinyvit_training_steps_match_the_reference_run(model, name):
     with its learned bias table, LayerNorm, MLP, and for 11m stochastic depth with the per-sample factors of the reference's own run --
     against the REAL reference stack's run (oracle/gen_golden_stage1_step.py --model tiny_vit_5m | tiny_vit_11m): first iteration (loss,
     norm, every clipped gradient, every updated parameter, every running statistic), loss and gradient norm of the second."""
-    _first_step_vs_reference(model, model, _tinyvit_sd(name), TV_GRAD_REL, TV_GRAD_ABS, second_step=(1e-4, 1e-2), check_buffers=True, loss_rel=2e-5, norm_rel=5e-3)
+    # measured (first run): loss equal to all printed digits in step 1, 1e-7 rel in step 2; norm + 2.8e-4 rel in both (see the note below)
+    _first_step_vs_reference(model, model, _tinyvit_sd(name), TV_GRAD_REL, TV_GRAD_ABS, second_step=(5e-6, 2e-3), check_buffers=True, loss_rel=5e-6, norm_rel=2e-3)
 
 
 @pytest.mark.parametrize("model,name", [("tiny_vit_5m", "5m"), ("tiny_vit_11m", "11m")])

@@ -123,6 +123,7 @@ def test_trainer_host_logic_vs_the_reference_run(host_trainer, model, family, na
     tr._micro = 0
     loss = float(out["loss"])
     assert abs(loss - ref["losses"][0]) <= 1e-5 * abs(ref["losses"][0]), (loss, ref["losses"][0])
+    print(f"[host {model}] loss {loss:.6f} ({ref['losses'][0]:.6f}) grad norm {norm:.4f} ({ref['grad_norms'][0]:.4f})")
     assert abs(norm - ref["grad_norms"][0]) <= 1e-3 * ref["grad_norms"][0], (norm, ref["grad_norms"][0])
     clip = min(1.0, hy["clip_grad"] / (norm + 1e-6))
     gmax = max(float(g[f"gradmax1/{n}"]) for n in ref["names"])

@@ -167,21 +167,22 @@ def test_repvit_trunk_composition_and_names(repvit_kernels):
 REFERENCE = "/root/reference"
 
 
+@pytest.mark.parametrize("name", ["m0.9", "m1.1", "m2.3"])
 @pytest.mark.skipif(not __import__("os").path.isdir(REFERENCE + "/sam3"), reason="the reference tree is only present in the build container")
-def test_repvit_trunk_vs_the_reference_module(repvit_kernels):
+def test_repvit_trunk_vs_the_reference_module(repvit_kernels, name):
     """where the reference is present (this container, never the GPU box): the same comparison against the REAL module -- repvit_m0_9 of
     sam3/backbones/repvit.py as stage1/model.py:386-395 builds it (num_classes 0, no distillation head), run layer by layer over
     ``model.features`` as RepViTAdapter.forward does (stage1/model.py:293-296), in train mode, loaded with the synthetic state dict --
-    instead of this file's own restatement of it"""
+    instead of this file's own restatement of it (all three students: 26 / 24 / 58 blocks)"""
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for pth in (os.path.join(root, "oracle", "shims"), REFERENCE + "/sam3"):      # as tests/test_train_blocks_host.py imports the EfficientViT module
         if pth not in sys.path:
             sys.path.insert(0, pth)
-    from sam3.backbones.repvit import repvit_m0_9
-    model = repvit_m0_9(pretrained=False, num_classes=0, distillation=False)
-    full = schema.synthetic_state_dict("repvit", "m0.9", seed=4)
+    from sam3.backbones import repvit as ref_repvit
+    model = getattr(ref_repvit, "repvit_" + name.replace(".", "_"))(pretrained=False, num_classes=0, distillation=False)
+    full = schema.synthetic_state_dict("repvit", name, seed=4)
     pre = "backbone.vision_backbone.trunk.model.backbone.model."
     sd = {k[len(pre):]: v.float() for k, v in full.items() if k.startswith(pre)}
     model.load_state_dict(sd, strict=True)
@@ -194,7 +195,7 @@ def test_repvit_trunk_vs_the_reference_module(repvit_kernels):
     dy = torch.randn(yr.shape, generator=g)
     yr.backward(dy)
     ref_grads = {n: p.grad for n, p in model.named_parameters()}
-    trunk = tr.RepViTTrunkTrain({k: v.clone() for k, v in sd.items()}, "m0.9", dtype=torch.float32)
+    trunk = tr.RepViTTrunkTrain({k: v.clone() for k, v in sd.items()}, name, dtype=torch.float32)
     y = trunk.forward(img)
     grads = trunk.backward(_to_nhwc(dy))
     assert sorted(grads) == sorted(ref_grads)

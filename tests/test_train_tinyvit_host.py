@@ -214,21 +214,22 @@ def test_tinyvit_trunk_composition_and_names(tinyvit_kernels):
 REFERENCE = "/root/reference"
 
 
+@pytest.mark.parametrize("name", ["5m", "11m", "21m"])
 @pytest.mark.skipif(not os.path.isdir(REFERENCE + "/sam3"), reason="the reference tree is only present in the build container")
-def test_tinyvit_trunk_vs_the_reference_module(tinyvit_kernels):
+def test_tinyvit_trunk_vs_the_reference_module(tinyvit_kernels, name):
     """where the reference is present (this container, never the GPU box): against the REAL module -- tiny_vit_5m_224(img_size=...) of
     sam3/backbones/tiny_vit.py run as TinyViTAdapter.forward does (stage1/model.py:310-318: patch_embed, the four layers, tokens back to a
-    map), in train mode (5m has no stochastic depth), loaded with the synthetic state dict"""
+    map), in train mode with drop_path_rate 0 (stochastic depth is covered by the training-step fixtures), loaded with the synthetic state dict; all three students"""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for pth in (os.path.join(root, "oracle", "shims"), REFERENCE + "/sam3"):
         if pth not in sys.path:
             sys.path.insert(0, pth)
-    from sam3.backbones.tiny_vit import tiny_vit_5m_224
+    from sam3.backbones import tiny_vit as ref_tiny_vit
     H, W = 160, 160
-    model = tiny_vit_5m_224(pretrained=False, img_size=H)
+    model = getattr(ref_tiny_vit, f"tiny_vit_{name}_224")(pretrained=False, img_size=H, drop_path_rate=0.0)   # stochastic depth: the fixture tests
     model.head, model.norm_head = torch.nn.Identity(), torch.nn.Identity()
-    full = schema.synthetic_state_dict("tinyvit", "5m", seed=4)
+    full = schema.synthetic_state_dict("tinyvit", name, seed=4)
     pre = "backbone.vision_backbone.trunk.model.backbone.model."
     sd = {k[len(pre):]: v.float() for k, v in full.items() if k.startswith(pre)}
     model.load_state_dict(sd, strict=True)
@@ -245,7 +246,7 @@ def test_tinyvit_trunk_vs_the_reference_module(tinyvit_kernels):
     dy = torch.randn(yr.shape, generator=g)
     yr.backward(dy)
     ref_grads = {n: p.grad for n, p in model.named_parameters()}
-    trunk = tt.TinyViTTrunkTrain({k: v.clone() for k, v in sd.items()}, "5m", dtype=torch.float32)
+    trunk = tt.TinyViTTrunkTrain({k: v.clone() for k, v in sd.items()}, name, dtype=torch.float32, drop_path_sampler=lambda n, c, b, keep: torch.ones(b))
     y = trunk.forward(img)
     grads = trunk.backward(dy.contiguous())
     assert sorted(grads) == sorted(ref_grads)
