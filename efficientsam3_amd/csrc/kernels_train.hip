@@ -583,6 +583,7 @@ __global__ __launch_bounds__(256) void mla_backward_part_kernel(const typename T
   __shared__ float tq[TT][DIM + 1], tk[TT][DIM + 1], tv[TT][D1 + 1];  // relu(q), relu(k), [v; 1] of the tile (+1: bank skew)
   __shared__ float tdo[TT][D1 + 1];                                   // dO of the tile
   __shared__ float S[SE], dS[SE];
+  __shared__ float pdd[4][TT];                                         // the four shares of a token's dD (token_dO)
   typedef typename TElem<DT>::type T;
   const int g = blockIdx.x % G;
   const int64_t b = blockIdx.x / G;
@@ -618,31 +619,36 @@ __global__ __launch_bounds__(256) void mla_backward_part_kernel(const typename T
       }
     }
   };
-  // per-token dO from S (in LDS) and dY; also returns D and writes Y
-  auto token_dO = [&](int n0, int n, float* dO) {
-    float O[D1];
+  // dO of token n (from S in LDS and dY) -> tdo[n][0 .. DIM]; writes Y in MODE 1.  Nothing is kept in an indexed register array: with
+  // DIM = 32 the fully unrolled form (O[33], dO[33], then 32 x 65 multiply-adds per token in one thread) spilled 12 KB of scratch per thread
+  // and MODE 2 alone was 74 ms of a 133 ms EfficientViT-B2 step (profiles/r05/stage1_step_b2_kernel_stats.csv).  Same operations in the
+  // same order per element as before.
+  // Four threads per token (thread = (n = tid & 63, quarter q = tid >> 6)): every one recomputes D (32 multiply-adds), handles the DIM / 4
+  // channels a of its quarter and leaves its share of dD in pdd[q][n]; token_dD adds the four shares in quarter order (deterministic).
+  auto token_dO = [&](int n0, int n, int q) {
+    float od = 0.f;
 #pragma unroll
-    for (int a = 0; a < D1; ++a) {
+    for (int c = 0; c < DIM; ++c) od = fmaf(S[DIM * DIM + c], tq[n][c], od);
+    const float D = od + eps, inv = 1.f / D;
+    float dD = 0.f;
+#pragma unroll 2
+    for (int k = 0; k < DIM / 4; ++k) {
+      const int a = q * (DIM / 4) + k;
       float s_ = 0.f;
 #pragma unroll
       for (int c = 0; c < DIM; ++c) s_ = fmaf(S[a * DIM + c], tq[n][c], s_);
-      O[a] = s_;
-    }
-    const float D = O[DIM] + eps, inv = 1.f / D;
-    float dD = 0.f;
-#pragma unroll
-    for (int c = 0; c < DIM; ++c) {
-      const float yv = O[c] * inv;
-      const float dyv = ldf(dout + ((b * N + n0 + n) * (int64_t)CO) + g * DIM + c);
-      dO[c] = dyv * inv;
+      const float yv = s_ * inv;
+      const float dyv = ldf(dout + ((b * N + n0 + n) * (int64_t)CO) + g * DIM + a);
+      tdo[n][a] = dyv * inv;
       dD = fmaf(-dyv, yv, dD);
       if (MODE == 1 && y) {
-        if constexpr (DT == 0) y[(b * N + n0 + n) * (int64_t)CO + g * DIM + c] = yv;
-        else y[(b * N + n0 + n) * (int64_t)CO + g * DIM + c] = f32_to_bf16(yv);
+        if constexpr (DT == 0) y[(b * N + n0 + n) * (int64_t)CO + g * DIM + a] = yv;
+        else y[(b * N + n0 + n) * (int64_t)CO + g * DIM + a] = f32_to_bf16(yv);
       }
     }
-    dO[DIM] = dD * inv;
+    pdd[q][n] = dD * inv;
   };
+  auto token_dD = [&](int n) { tdo[n][DIM] = (pdd[0][n] + pdd[1][n]) + (pdd[2][n] + pdd[3][n]); };
 
   float acc[NJ];
 #pragma unroll
@@ -671,21 +677,21 @@ __global__ __launch_bounds__(256) void mla_backward_part_kernel(const typename T
       __syncthreads();
       stage(n0);
       __syncthreads();
-      if (tid < TT && n0 + tid < ne) {
-        float O[D1];
+      const int n = tid & (TT - 1), q = tid >> 6;      // four threads per token, a quarter of the output channels each
+      if (n0 + n < ne) {
+        float od = 0.f;
 #pragma unroll
-        for (int a = 0; a < D1; ++a) {
+        for (int c = 0; c < DIM; ++c) od = fmaf(S[DIM * DIM + c], tq[n][c], od);
+        const float inv = 1.f / (od + eps);
+#pragma unroll 2
+        for (int k = 0; k < DIM / 4; ++k) {
+          const int a = q * (DIM / 4) + k;
           float s_ = 0.f;
 #pragma unroll
-          for (int c = 0; c < DIM; ++c) s_ = fmaf(S[a * DIM + c], tq[tid][c], s_);
-          O[a] = s_;
-        }
-        const float inv = 1.f / (O[DIM] + eps);
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-          const float yv = O[c] * inv;
-          if constexpr (DT == 0) y[(b * N + n0 + tid) * (int64_t)CO + g * DIM + c] = yv;
-          else y[(b * N + n0 + tid) * (int64_t)CO + g * DIM + c] = f32_to_bf16(yv);
+          for (int c = 0; c < DIM; ++c) s_ = fmaf(S[a * DIM + c], tq[n][c], s_);
+          const float yv = s_ * inv;
+          if constexpr (DT == 0) y[(b * N + n0 + n) * (int64_t)CO + g * DIM + a] = yv;
+          else y[(b * N + n0 + n) * (int64_t)CO + g * DIM + a] = f32_to_bf16(yv);
         }
       }
     }
@@ -696,14 +702,16 @@ __global__ __launch_bounds__(256) void mla_backward_part_kernel(const typename T
     __syncthreads();
     stage(n0);
     __syncthreads();
-    if (tid < TT) {
-      float dO[D1];
-#pragma unroll
-      for (int a = 0; a < D1; ++a) dO[a] = 0.f;
-      if (n0 + tid < ne) token_dO(n0, tid, dO);
-#pragma unroll
-      for (int a = 0; a < D1; ++a) tdo[tid][a] = dO[a];
+    {
+      const int n = tid & (TT - 1), q = tid >> 6;
+      if (n0 + n < ne) token_dO(n0, n, q);
+      else {
+        for (int k = 0; k < DIM / 4; ++k) tdo[n][q * (DIM / 4) + k] = 0.f;
+        pdd[q][n] = 0.f;
+      }
     }
+    __syncthreads();
+    if (tid < TT) token_dD(tid);
     __syncthreads();
     outer(tdo, tq, acc);
   }
@@ -713,24 +721,31 @@ __global__ __launch_bounds__(256) void mla_backward_part_kernel(const typename T
   return;
   }
   // ---- MODE 2: per-token gradients of this range ----
+  // first the token's dO (into LDS, four threads per token), then the gradients with the same thread layout: thread = (token n = tid & 63,
+  // channel quarter tid >> 6), so S / dS reads stay wave-uniform (broadcasts) and each thread streams its operands from LDS instead of
+  // holding a 33-vector
+  constexpr int CPT = DIM / 4;
   for (int n0 = nb; n0 < ne; n0 += TT) {
     __syncthreads();
     stage(n0);
     __syncthreads();
-    if (tid < TT && n0 + tid < ne) {
-      const int n = tid;
-      float dO[D1];
-      token_dO(n0, n, dO);
+    const int n = tid & (TT - 1), c0 = (tid >> 6) * CPT;
+    if (n0 + n < ne) token_dO(n0, n, tid >> 6);
+    __syncthreads();
+    if (tid < TT && n0 + tid < ne) token_dD(tid);
+    __syncthreads();
+    if (n0 + n < ne) {
       T* o = dms + (b * N + n0 + n) * (int64_t)C3 + g * 3 * DIM;
       auto stf = [&](int c, float v) {
         if constexpr (DT == 0) o[c] = v; else o[c] = f32_to_bf16(v);
       };
-#pragma unroll
-      for (int c = 0; c < DIM; ++c) {
+#pragma unroll 2
+      for (int k = 0; k < CPT; ++k) {
+        const int c = c0 + k;
         float dq = 0.f, dk = 0.f, dv = 0.f;
 #pragma unroll
         for (int a = 0; a < D1; ++a) {
-          dq = fmaf(S[a * DIM + c], dO[a], dq);        // dQr = S^T dO
+          dq = fmaf(S[a * DIM + c], tdo[n][a], dq);    // dQr = S^T dO
           dk = fmaf(dS[a * DIM + c], tv[n][a], dk);    // dKr = dS^T Vp
         }
 #pragma unroll
