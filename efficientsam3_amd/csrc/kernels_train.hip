@@ -777,6 +777,17 @@ int wgrad_splits(int64_t M) {  // every split a whole number of 64-row tiles
   return (int)(s < 1 ? 1 : s);
 }
 
+// Splits of the weight gradient's row reduction: enough workgroups to fill the chip (about 2048 with the N x K tiles), not one per 64-row
+// tile -- with 128 - 256 splits of a 1024 x 256 weight the fp32 partial tiles were 128 x the size of dW, and wgrad_reduce_kernel alone 8 %
+// of a training step (profiles/r05/stage1_step_b2_kernel_stats_mla4.csv).  A function of (M, N, K) only: the summation order stays fixed.
+int wgrad_splits_nk(int64_t M, int N, int K) {
+  const int64_t tiles_nk = (int64_t)((N + WG_TILE - 1) / WG_TILE) * ((K + WG_TILE - 1) / WG_TILE);
+  int64_t want = 2048 / tiles_nk;
+  if (want < 1) want = 1;
+  const int64_t most = wgrad_splits(M);
+  return (int)(want < most ? want : most);
+}
+
 }  // namespace
 
 extern "C" {
@@ -809,7 +820,7 @@ int esam3_act_backward(int dtype, const void* x, const void* dy, void* dx, int64
 
 int64_t esam3_linear_wgrad_workspace(int64_t M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return (int64_t)sizeof(float) * wgrad_splits(M) * ((int64_t)N * K + N);
+  return (int64_t)sizeof(float) * wgrad_splits_nk(M, N, K) * ((int64_t)N * K + N);
 }
 
 int esam3_linear_wgrad(int dtype, const void* dy, const void* x, int64_t M, int N, int K, float* dw, float* dbias, void* workspace,
@@ -819,7 +830,7 @@ int esam3_linear_wgrad(int dtype, const void* dy, const void* x, int64_t M, int 
     return -1;
   }
   hipStream_t s = (hipStream_t)stream;
-  const int splits = wgrad_splits(M);
+  const int splits = wgrad_splits_nk(M, N, K);
   const int64_t tiles = (M + WG_ROWS - 1) / WG_ROWS;
   const int64_t rps = (tiles + splits - 1) / splits * WG_ROWS;
   const int zs = (int)((M + rps - 1) / rps);  // splits actually used

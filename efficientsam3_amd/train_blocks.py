@@ -153,6 +153,19 @@ def channel_scale(x: torch.Tensor, mul: torch.Tensor, bias: torch.Tensor = None,
     return out
 
 
+_ONES = {}
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a + b (same shape and dtype; fp32 sum, rounded once): the residual additions of the blocks, as ``esam3_channel_scale`` with a unit
+    multiplier -- one launch where the torch form (two casts, an add, a cast) was four"""
+    c = a.shape[-1]
+    key = (c, str(a.device))
+    if key not in _ONES:
+        _ONES[key] = torch.ones(c, dtype=torch.float32, device=a.device)
+    return channel_scale(a.contiguous(), _ONES[key], add=b.contiguous())
+
+
 def batched_coldot(a: torch.Tensor, b2: torch.Tensor = None, scale: float = 1.0, per_image: bool = True) -> torch.Tensor:
     """[B, C] fp32 (``per_image``) or [C]: scale * the sum over the pixels (of each image | of all images) of a * b2 (of a when ``b2`` is
     None) for a [B, ..., C] (``esam3_batched_coldot``)"""
@@ -259,13 +272,13 @@ class MBConvTrain:
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y = self.pw.forward(self.dw.forward(self.inv.forward(x)))
-        return (x.float() + y.float()).to(x.dtype) if self.residual else y
+        return add(x, y) if self.residual else y
 
     def backward(self, dy: torch.Tensor):
         d, g_pw = self.pw.backward(dy)
         d, g_dw = self.dw.backward(d)
         d, g_inv = self.inv.backward(d)
-        dx = (d.float() + dy.float()).to(dy.dtype) if self.residual else d
+        dx = add(d, dy) if self.residual else d
         grads = {f"{n}.{k}": v for n, g in (("inverted", g_inv), ("depth", g_dw), ("point", g_pw)) for k, v in g.items()}
         return dx, grads
 
@@ -282,12 +295,12 @@ class DSConvTrain:
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         y = self.pw.forward(self.dw.forward(x))
-        return (x.float() + y.float()).to(x.dtype) if self.residual else y
+        return add(x, y) if self.residual else y
 
     def backward(self, dy: torch.Tensor):
         d, g_pw = self.pw.backward(dy)
         d, g_dw = self.dw.backward(d)
-        dx = (d.float() + dy.float()).to(dy.dtype) if self.residual else d
+        dx = add(d, dy) if self.residual else d
         return dx, {f"{n}.{k}": v for n, g in (("depth", g_dw), ("point", g_pw)) for k, v in g.items()}
 
 
@@ -360,7 +373,7 @@ class LiteMLATrain:
         att = lite_mla_forward(self.ms, self.groups, self.dim, self.eps)
         self.att = att.reshape(b, h, w, 2 * c)
         y = self.proj.forward(self.att)
-        return (x.float() + y.float()).to(x.dtype)
+        return add(x, y)
 
     def backward(self, dy: torch.Tensor):
         b, h, w, c = self.x.shape
@@ -372,9 +385,9 @@ class LiteMLATrain:
         dwg = _blockdiag_extract(dense, self.dim)
         d_agg1 = linear_dgrad(d_agg2, self.wg_dense)
         dwd = dwconv_wgrad(self.qkv, d_agg1, 1, 5)
-        d_qkv = (d_qkv_direct.float() + dwconv_dgrad(d_agg1, self.p["aggreg.dw.weight"], (h, w), 1).float()).to(dy.dtype)
+        d_qkv = add(d_qkv_direct, dwconv_dgrad(d_agg1, self.p["aggreg.dw.weight"], (h, w), 1))
         dwq = linear_wgrad(d_qkv, self.x)
-        dx = (linear_dgrad(d_qkv, self.p["qkv.weight"]).float() + dy.float()).to(dy.dtype)
+        dx = add(linear_dgrad(d_qkv, self.p["qkv.weight"]), dy)
         grads = {"qkv.weight": dwq, "aggreg.dw.weight": dwd, "aggreg.pw.weight": dwg, "proj.weight": g_proj["weight"],
                  "proj.gamma": g_proj["gamma"], "proj.beta": g_proj["beta"]}
         return dx, grads

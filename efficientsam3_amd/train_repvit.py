@@ -11,7 +11,7 @@ layers are ``sam3/backbones/repvit.py``:
   ``Residual(1x1 C -> 2C, GELU, 1x1 2C -> C)`` (``:51-63``; drop 0)                                       -> ``RepViTBlockTrain``;
 * ``:226-231`` the patch embedding: ``Conv2d_BN(3, C/2, 3, 2, 1)``, GELU, ``Conv2d_BN(C/2, C, 3, 2, 1)``        -> ``StemConvTrain`` + ``Conv3x3S2Train``.
 
-Like ``train_blocks`` this module owns no arithmetic beyond the residual additions: it sequences kernels (``esam3_train_*``,
+Like ``train_blocks`` this module owns no arithmetic: it sequences kernels (``esam3_train_*``,
 ``esam3_bn_train_*``, ``esam3_channel_scale``, ``esam3_batched_coldot``, the gradient kernels) on NHWC tensors; parameters are fp32 device views
 of the optimizer's arena.  The tiny SqueezeExcite MLP ([B, C] rows) runs in fp32 whatever the activation dtype.  The composition is checked
 against torch.autograd on the CPU with kernel stand-ins (tests/test_train_repvit_host.py), the kernels and blocks against autograd on the
@@ -215,7 +215,7 @@ class RepViTBlockTrain:
         for layer, _ in self.parts:
             x = layer.forward(x)
         h = self.mixer[1][0].forward(self.mixer[0][0].forward(x))
-        return (x.float() + h.float()).to(x.dtype)                       # Residual (repvit.py:57-63, drop 0)
+        return tb.add(x, h)                                              # Residual (repvit.py:57-63, drop 0)
 
     def backward(self, dy: torch.Tensor):
         grads = {}
@@ -227,7 +227,7 @@ class RepViTBlockTrain:
 
         d = through(*self.mixer[1], dy)
         d = through(*self.mixer[0], d)
-        d = (d.float() + dy.float()).to(dy.dtype)
+        d = tb.add(d, dy)
         for layer, back in reversed(self.parts):
             d = through(layer, back, d)
         return d, grads

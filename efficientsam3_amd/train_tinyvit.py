@@ -235,7 +235,7 @@ class _Residual:
 
 
 def _sum(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    return (a.float() + b.float()).to(a.dtype)
+    return tb.add(a, b)
 
 
 class MBConvTrain:
