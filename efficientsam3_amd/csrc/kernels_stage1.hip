@@ -550,7 +550,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const typename Elem<DT>:
 template <bool BWD>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int splits, int C, int64_t rows, double eps,
                                                           double momentum, float* __restrict__ o0, float* __restrict__ o1,
-                                                          float* __restrict__ running_mean, float* __restrict__ running_var) {
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          float* __restrict__ var_out = nullptr) {
   __shared__ double sq[2][4][64];
   const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + e;
@@ -584,6 +585,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     var = var > 0.0 ? var : 0.0;
     o0[c] = (float)mean;
     o1[c] = (float)(1.0 / sqrt(var + eps));
+    if (var_out) var_out[c] = (float)var;   // the biased variance itself: what a SyncBatchNorm gathers from every rank
     if (running_mean) running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
     if (running_var) running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * var * (n > 1.0 ? n / (n - 1.0) : 1.0));
   }
@@ -596,10 +598,9 @@ __global__ __launch_bounds__(256) void bn_map_kernel(const typename Elem<DT>::ty
                                                      typename Elem<DT>::type* __restrict__ out, int64_t rows, int C,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta) {
+                                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta, float invn) {
   const int CG = C >> 3;
-  const int64_t total = rows * CG;
-  const float invn = 1.f / (float)rows;
+  const int64_t total = rows * CG;   // invn = 1 / (rows of the whole batch): `rows` of this rank, or of all ranks under SyncBatchNorm
   const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
   int cg = (int)(i0 % CG);
   const int dcg = (int)(stride % CG);  // the channel group advances by a fixed amount per iteration: no 64-bit modulo in the loop
@@ -639,7 +640,7 @@ int bn_forward_t(const void* x, void* y, int64_t rows, int C, const float* gamma
   const int64_t total = rows * (C / 8);
   const unsigned grid = (unsigned)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
   hipLaunchKernelGGL((bn_map_kernel<DT, false>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)nullptr, (T*)y, rows, C, gamma, beta,
-                     save_mean, save_rstd, (const float*)nullptr, (const float*)nullptr);
+                     save_mean, save_rstd, (const float*)nullptr, (const float*)nullptr, 0.f);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -657,7 +658,58 @@ int bn_backward_t(const void* x, const void* dy, void* dx, int64_t rows, int C, 
   const int64_t total = rows * (C / 8);
   const unsigned grid = (unsigned)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
   hipLaunchKernelGGL((bn_map_kernel<DT, true>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)dy, (T*)dx, rows, C, gamma,
-                     (const float*)nullptr, save_mean, save_rstd, dgamma, dbeta);
+                     (const float*)nullptr, save_mean, save_rstd, dgamma, dbeta, 1.f / (float)rows);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+// The four halves of the two calls above, for SyncBatchNorm (train_image_encoder_stage1.py:62-63 --use-sync-bn): between the statistics and
+// the elementwise map the host combines the ranks' (mean, biased variance, rows) (forward) or sums their (sum dy, sum dy xhat, rows)
+// (backward) with one collective each -- torch.nn.SyncBatchNorm's own protocol (efficientsam3_amd/train_blocks.py: bn_train_forward).
+template <int DT>
+int bn_stats_t(const void* x, int64_t rows, int C, double eps, float* mean, float* rstd, float* var, float* partial, hipStream_t s) {
+  typedef typename Elem<DT>::type T;
+  const int RL = 256 / (C / 8);
+  const int splits = (int)(rows < BN_SPLITS ? rows : BN_SPLITS);
+  hipLaunchKernelGGL((bn_reduce_kernel<DT, false>), dim3((unsigned)splits), dim3(256), sizeof(float) * 2 * (size_t)RL * C, s, (const T*)x,
+                     (const T*)nullptr, rows, C, (const float*)nullptr, (const float*)nullptr, partial);
+  hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, partial, splits, C, rows, eps, 0.0, mean, rstd,
+                     (float*)nullptr, (float*)nullptr, var);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <int DT>
+int bn_apply_t(const void* x, void* y, int64_t rows, int C, const float* gamma, const float* beta, const float* mean, const float* rstd,
+               hipStream_t s) {
+  typedef typename Elem<DT>::type T;
+  const int64_t total = rows * (C / 8);
+  const unsigned grid = (unsigned)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
+  hipLaunchKernelGGL((bn_map_kernel<DT, false>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)nullptr, (T*)y, rows, C, gamma, beta, mean, rstd,
+                     (const float*)nullptr, (const float*)nullptr, 0.f);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <int DT>
+int bn_backward_sums_t(const void* x, const void* dy, int64_t rows, int C, const float* mean, const float* rstd, float* sum_dy_xhat, float* sum_dy,
+                       float* partial, hipStream_t s) {
+  typedef typename Elem<DT>::type T;
+  const int RL = 256 / (C / 8);
+  const int splits = (int)(rows < BN_SPLITS ? rows : BN_SPLITS);
+  hipLaunchKernelGGL((bn_reduce_kernel<DT, true>), dim3((unsigned)splits), dim3(256), sizeof(float) * 2 * (size_t)RL * C, s, (const T*)x, (const T*)dy, rows,
+                     C, mean, rstd, partial);
+  hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, partial, splits, C, rows, 0.0, 0.0, sum_dy_xhat, sum_dy,
+                     (float*)nullptr, (float*)nullptr);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+template <int DT>
+int bn_backward_apply_t(const void* x, const void* dy, void* dx, int64_t rows, int C, const float* gamma, const float* mean, const float* rstd,
+                        const float* sum_dy_xhat, const float* sum_dy, double total_rows, hipStream_t s) {
+  typedef typename Elem<DT>::type T;
+  const int64_t total = rows * (C / 8);
+  const unsigned grid = (unsigned)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
+  hipLaunchKernelGGL((bn_map_kernel<DT, true>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)dy, (T*)dx, rows, C, gamma, (const float*)nullptr, mean,
+                     rstd, sum_dy_xhat, sum_dy, (float)(1.0 / total_rows));
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -750,6 +802,50 @@ int esam3_bn_train_forward(int dtype, const void* x, void* y, int64_t rows, int 
                                       (float*)workspace, (hipStream_t)stream)
                     : bn_forward_t<1>(x, y, rows, C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd,
                                       (float*)workspace, (hipStream_t)stream);
+}
+
+int esam3_bn_train_stats(int dtype, const void* x, int64_t rows, int C, double eps, float* mean, float* rstd, float* var, void* workspace,
+                         void* stream) {
+  if (!bn_args_ok("esam3_bn_train_stats", dtype, rows, C)) return -1;
+  if (!x || !mean || !rstd || !var || !workspace || !(eps >= 0.0)) {
+    esam3_set_error("esam3_bn_train_stats: bad argument");
+    return -1;
+  }
+  return dtype == 0 ? bn_stats_t<0>(x, rows, C, eps, mean, rstd, var, (float*)workspace, (hipStream_t)stream)
+                    : bn_stats_t<1>(x, rows, C, eps, mean, rstd, var, (float*)workspace, (hipStream_t)stream);
+}
+
+int esam3_bn_train_apply(int dtype, const void* x, void* y, int64_t rows, int C, const float* gamma, const float* beta, const float* mean,
+                         const float* rstd, void* stream) {
+  if (!bn_args_ok("esam3_bn_train_apply", dtype, rows, C)) return -1;
+  if (!x || !y || !gamma || !beta || !mean || !rstd) {
+    esam3_set_error("esam3_bn_train_apply: bad argument");
+    return -1;
+  }
+  return dtype == 0 ? bn_apply_t<0>(x, y, rows, C, gamma, beta, mean, rstd, (hipStream_t)stream)
+                    : bn_apply_t<1>(x, y, rows, C, gamma, beta, mean, rstd, (hipStream_t)stream);
+}
+
+int esam3_bn_train_backward_sums(int dtype, const void* x, const void* dy, int64_t rows, int C, const float* mean, const float* rstd,
+                                 float* sum_dy_xhat, float* sum_dy, void* workspace, void* stream) {
+  if (!bn_args_ok("esam3_bn_train_backward_sums", dtype, rows, C)) return -1;
+  if (!x || !dy || !mean || !rstd || !sum_dy_xhat || !sum_dy || !workspace) {
+    esam3_set_error("esam3_bn_train_backward_sums: bad argument");
+    return -1;
+  }
+  return dtype == 0 ? bn_backward_sums_t<0>(x, dy, rows, C, mean, rstd, sum_dy_xhat, sum_dy, (float*)workspace, (hipStream_t)stream)
+                    : bn_backward_sums_t<1>(x, dy, rows, C, mean, rstd, sum_dy_xhat, sum_dy, (float*)workspace, (hipStream_t)stream);
+}
+
+int esam3_bn_train_backward_apply(int dtype, const void* x, const void* dy, void* dx, int64_t rows, int C, const float* gamma, const float* mean,
+                                  const float* rstd, const float* sum_dy_xhat, const float* sum_dy, double total_rows, void* stream) {
+  if (!bn_args_ok("esam3_bn_train_backward_apply", dtype, rows, C)) return -1;
+  if (!x || !dy || !dx || !gamma || !mean || !rstd || !sum_dy_xhat || !sum_dy || !(total_rows > 0.0)) {
+    esam3_set_error("esam3_bn_train_backward_apply: bad argument (total_rows > 0: the rows of all ranks, or 1 when the sums are already divided by it)");
+    return -1;
+  }
+  return dtype == 0 ? bn_backward_apply_t<0>(x, dy, dx, rows, C, gamma, mean, rstd, sum_dy_xhat, sum_dy, total_rows, (hipStream_t)stream)
+                    : bn_backward_apply_t<1>(x, dy, dx, rows, C, gamma, mean, rstd, sum_dy_xhat, sum_dy, total_rows, (hipStream_t)stream);
 }
 
 int esam3_bn_train_backward(int dtype, const void* x, const void* dy, void* dx, int64_t rows, int C, const float* gamma,

@@ -414,3 +414,52 @@ def bn_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, sa
                                                save_mean.data_ptr(), save_rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                                ws.data_ptr(), torch.cuda.current_stream().cuda_stream), "esam3_bn_train_backward")
     return dx, dgamma, dbeta
+
+
+# ---- the halves of the two calls above, for SyncBatchNorm (train_blocks.bn_train_forward / bn_train_backward) -----------------------------------
+def bn_stats(x: torch.Tensor, eps: float = 1e-5):
+    """this rank's (mean, rstd, biased variance) per channel of an NHWC tensor [..., C] (``esam3_bn_train_stats``)"""
+    rows, c = _bn_rows(x)
+    lib = _lib.load()
+    mean, rstd, var = (torch.empty(c, dtype=torch.float32, device=x.device) for _ in range(3))
+    ws = torch.empty(int(lib.esam3_bn_train_workspace(c)), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.esam3_bn_train_stats(_DT[x.dtype], x.data_ptr(), rows, c, float(eps), mean.data_ptr(), rstd.data_ptr(), var.data_ptr(), ws.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream), "esam3_bn_train_stats")
+    return mean, rstd, var
+
+
+def bn_apply(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor) -> torch.Tensor:
+    """y = (x - mean) rstd gamma + beta with given statistics (``esam3_bn_train_apply``)"""
+    rows, c = _bn_rows(x)
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().esam3_bn_train_apply(_DT[x.dtype], x.data_ptr(), y.data_ptr(), rows, c, gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
+                                                    rstd.data_ptr(), torch.cuda.current_stream().cuda_stream), "esam3_bn_train_apply")
+    return y
+
+
+def bn_backward_sums(x: torch.Tensor, dy: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor):
+    """this rank's (sum dy xhat, sum dy) per channel (``esam3_bn_train_backward_sums``): its dgamma and dbeta"""
+    rows, c = _bn_rows(x)
+    assert dy.shape == x.shape and dy.dtype == x.dtype and dy.is_contiguous()
+    lib = _lib.load()
+    sdyx, sdy = (torch.empty(c, dtype=torch.float32, device=x.device) for _ in range(2))
+    ws = torch.empty(int(lib.esam3_bn_train_workspace(c)), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.esam3_bn_train_backward_sums(_DT[x.dtype], x.data_ptr(), dy.data_ptr(), rows, c, mean.data_ptr(), rstd.data_ptr(), sdyx.data_ptr(),
+                                                    sdy.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream), "esam3_bn_train_backward_sums")
+    return sdyx, sdy
+
+
+def bn_backward_apply(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, mean_dy_xhat: torch.Tensor,
+                      mean_dy: torch.Tensor) -> torch.Tensor:
+    """dx = gamma rstd (dy - mean_dy - xhat mean_dy_xhat) with the all-rank sums ALREADY divided by the all-rank row count
+    (``esam3_bn_train_backward_apply`` with total_rows = 1)"""
+    rows, c = _bn_rows(x)
+    dx = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().esam3_bn_train_backward_apply(_DT[x.dtype], x.data_ptr(), dy.data_ptr(), dx.data_ptr(), rows, c, gamma.data_ptr(), mean.data_ptr(),
+                                                             rstd.data_ptr(), mean_dy_xhat.data_ptr(), mean_dy.data_ptr(), 1.0,
+                                                             torch.cuda.current_stream().cuda_stream), "esam3_bn_train_backward_apply")
+    return dx

@@ -155,10 +155,14 @@ class Stage1Trainer:
     def __init__(self, state_dict: Dict[str, torch.Tensor], model_name: str = "b1", embed_size: int = 72, dtype: str = "f32", device="cuda",
                  lr: float = 5e-4, weight_decay: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8, clip_grad: float = 5.0, amp: bool = False,
                  cosine_weight: float = 0.0, accumulation_steps: int = 1, init_scale: float = 65536.0, growth_interval: int = 2000,
-                 bn_momentum: float = 0.1, group=None, force_collective: bool = False, drop_path_sampler=None, seed: int = 0):
+                 bn_momentum: float = 0.1, group=None, force_collective: bool = False, drop_path_sampler=None, seed: int = 0,
+                 sync_bn: bool = False):
         from .dist import GradientAllReducer
         self.device = torch.device(device)
         tb.DEVICE = str(self.device)
+        # --use-sync-bn (train_image_encoder_stage1.py:62-63): every BatchNorm of trunk and head uses the statistics of all ranks of `group`
+        import torch.distributed as _dist
+        tb.SYNC_BN = (group if group is not None else True) if (sync_bn and _dist.is_initialized()) else None
         self.tdtype = {"f32": torch.float32, "bf16": torch.bfloat16}[dtype]
         if model_name not in EFFICIENTVIT and model_name not in REPVIT and model_name not in TINYVIT:
             raise ValueError(f"stage-1 student {model_name!r}: the trainer covers {sorted(EFFICIENTVIT) + sorted(REPVIT) + sorted(TINYVIT)}")

@@ -16,11 +16,67 @@ import numpy as np
 import torch
 
 from . import _lib
-from .stage1 import bn_train_backward, bn_train_forward
+from . import stage1 as _s1
+from .stage1 import bn_apply, bn_backward_apply, bn_backward_sums, bn_stats
 
 ACT = {None: 0, "relu": 1, "gelu": 2, "hswish": 3, "sigmoid": 4}
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 DEVICE = "cuda"   # where the block classes keep their BatchNorm parameters (the host-logic test runs the compositions on "cpu" doubles)
+
+
+# SyncBatchNorm (stage1/train_image_encoder_stage1.py:62-63 `--use-sync-bn`: torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)): None = every
+# rank normalises with its own batch statistics (nn.BatchNorm2d); a torch.distributed process group (or True for the default group) = the
+# statistics of all its ranks, torch.nn.SyncBatchNorm's protocol with one collective each way.  Set by ``Stage1Trainer(sync_bn=True)``.
+SYNC_BN = None
+
+
+def _sync_group():
+    return None if SYNC_BN is True else SYNC_BN
+
+
+def bn_train_forward(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: torch.Tensor = None, running_var: torch.Tensor = None,
+                     momentum: float = 0.1, eps: float = 1e-5):
+    """training-mode BatchNorm2d on NHWC rows -> (y, mean, rstd).  Under ``SYNC_BN``: every rank's (mean, biased variance, rows) are gathered
+    (one all_gather of 2 C + 1 doubles), combined as torch's batch_norm_gather_stats_with_counts does -- the count-weighted mean, and the
+    count-weighted mean of var + (mean_r - mean)^2 --, the running statistics take the all-rank values (unbiased variance with the all-rank
+    count), and the map runs with them"""
+    if SYNC_BN is None:
+        return _s1.bn_train_forward(x, gamma, beta, running_mean, running_var, momentum, eps)
+    import torch.distributed as dist
+    c = x.shape[-1]
+    mean_l, _, var_l = bn_stats(x, eps)
+    rows = torch.full((1,), float(x.numel() // c), dtype=torch.float64, device=x.device)
+    packed = torch.cat([mean_l.double(), var_l.double(), rows])
+    gathered = [torch.empty_like(packed) for _ in range(dist.get_world_size(_sync_group()))]
+    dist.all_gather(gathered, packed, group=_sync_group())
+    g = torch.stack(gathered)
+    cnt = g[:, -1:]
+    n = cnt.sum()
+    mean = (g[:, :c] * cnt).sum(0) / n
+    var = ((g[:, c:2 * c] + (g[:, :c] - mean) ** 2) * cnt).sum(0) / n
+    rstd = torch.rsqrt(var + eps)
+    if running_mean is not None:
+        running_mean.mul_(1.0 - momentum).add_((momentum * mean).float())
+        running_var.mul_(1.0 - momentum).add_((momentum * var * n / (n - 1.0).clamp(min=1.0)).float())
+    mean32, rstd32 = mean.float(), rstd.float()
+    return bn_apply(x, gamma, beta, mean32, rstd32), mean32, rstd32
+
+
+def bn_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, save_mean: torch.Tensor, save_rstd: torch.Tensor):
+    """its autograd backward -> (dx, dgamma, dbeta).  Under ``SYNC_BN``: the ranks' (sum dy xhat, sum dy, rows) are summed (one all_reduce),
+    dx uses the all-rank means, dgamma / dbeta stay THIS rank's sums (the gradient all-reduce averages them like every other gradient), as
+    torch.nn.SyncBatchNorm's backward does"""
+    if SYNC_BN is None:
+        return _s1.bn_train_backward(x, dy, gamma, save_mean, save_rstd)
+    import torch.distributed as dist
+    c = x.shape[-1]
+    sdyx, sdy = bn_backward_sums(x, dy, save_mean, save_rstd)
+    rows = torch.full((1,), float(x.numel() // c), dtype=torch.float64, device=x.device)
+    packed = torch.cat([sdyx.double(), sdy.double(), rows])
+    dist.all_reduce(packed, group=_sync_group())
+    means = (packed[:2 * c] / packed[-1]).float()
+    dx = bn_backward_apply(x, dy, gamma, save_mean, save_rstd, means[:c].contiguous(), means[c:].contiguous())
+    return dx, sdyx, sdy
 
 
 def _stream():

@@ -371,6 +371,23 @@ int esam3_bn_train_forward(int dtype, const void* x_dev, void* y_dev, int64_t ro
 int esam3_bn_train_backward(int dtype, const void* x_dev, const void* dy_dev, void* dx_dev, int64_t rows, int C,
                             const float* gamma_dev, const float* save_mean_dev, const float* save_rstd_dev, float* dgamma_dev,
                             float* dbeta_dev, void* workspace_dev, void* hip_stream);
+/* The same two operations in halves, for SyncBatchNorm (stage1/train_image_encoder_stage1.py:62-63 `--use-sync-bn`:
+ * torch.nn.SyncBatchNorm.convert_sync_batchnorm): between the statistics and the elementwise map the host combines the ranks' values with ONE
+ * collective each way, as torch's SyncBatchNorm does (efficientsam3_amd/train_blocks.py: bn_train_forward / bn_train_backward).
+ *   esam3_bn_train_stats: this rank's mean, rstd = (var + eps)^-1/2 and biased variance per channel (no map, running statistics untouched);
+ *   esam3_bn_train_apply: y = (x - mean) rstd gamma + beta with the (all-rank) mean / rstd given;
+ *   esam3_bn_train_backward_sums: this rank's sum dy xhat (= its dgamma) and sum dy (= its dbeta) with the all-rank mean / rstd;
+ *   esam3_bn_train_backward_apply: dx = gamma rstd (dy - sum_dy / n - xhat sum_dy_xhat / n) with the ALL-RANK sums and n = total_rows (pass
+ *     total_rows = 1 with sums the host already divided by the all-rank row count: no read-back of the count is needed then). */
+int esam3_bn_train_stats(int dtype, const void* x_dev, int64_t rows, int C, double eps, float* mean_dev, float* rstd_dev, float* var_dev,
+                         void* workspace_dev, void* hip_stream);
+int esam3_bn_train_apply(int dtype, const void* x_dev, void* y_dev, int64_t rows, int C, const float* gamma_dev, const float* beta_dev,
+                         const float* mean_dev, const float* rstd_dev, void* hip_stream);
+int esam3_bn_train_backward_sums(int dtype, const void* x_dev, const void* dy_dev, int64_t rows, int C, const float* mean_dev,
+                                 const float* rstd_dev, float* sum_dy_xhat_dev, float* sum_dy_dev, void* workspace_dev, void* hip_stream);
+int esam3_bn_train_backward_apply(int dtype, const void* x_dev, const void* dy_dev, void* dx_dev, int64_t rows, int C, const float* gamma_dev,
+                                  const float* mean_dev, const float* rstd_dev, const float* sum_dy_xhat_dev, const float* sum_dy_dev,
+                                  double total_rows, void* hip_stream);
 
 /* Stage-1 input pipeline (BASELINE config 5): what SA1BDataset.__getitem__ does to an image before the trunks see it
  * (stage1/data/sa1b_dataset.py:163,170-171,217-228; stage1/data/transforms.py:48-55,81-88): ResizeLongestSide(img_size)

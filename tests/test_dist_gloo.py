@@ -615,3 +615,150 @@ def test_forced_one_rank_group_with_master_port_but_no_rank():
     assert q.get(timeout=120) is True
     p.join(timeout=60)
     assert p.exitcode == 0
+
+
+# ---- SyncBatchNorm (train_image_encoder_stage1.py:62-63) -------------------------------------------------------------------------------------
+def _bn_case():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(8, 5, 6, 16, generator=g) * 2.0 + torch.randn(16, generator=g)     # NHWC, 8 samples
+    dy = torch.randn(8, 5, 6, 16, generator=g)
+    gamma, beta = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.2
+    return x, dy, gamma, beta
+
+
+_BN_SPLIT = (3, 5)      # samples per rank: unequal, so the combination has to weight by the row counts
+
+
+def _bn_standins(tb):
+    """torch stand-ins of the four kernel wrappers behind the SyncBatchNorm path (same contracts)"""
+    def stats(x, eps=1e-5):
+        x2 = x.reshape(-1, x.shape[-1]).double()
+        mean, var = x2.mean(0), x2.var(0, unbiased=False)
+        return mean.float(), (1.0 / torch.sqrt(var + eps)).float(), var.float()
+
+    def sums(x, dy, mean, rstd):
+        xh = (x - mean) * rstd
+        c = x.shape[-1]
+        return (dy * xh).reshape(-1, c).sum(0), dy.reshape(-1, c).sum(0)
+
+    tb.bn_stats = stats
+    tb.bn_apply = lambda x, gamma, beta, mean, rstd: (x - mean) * rstd * gamma + beta
+    tb.bn_backward_sums = sums
+    tb.bn_backward_apply = lambda x, dy, gamma, mean, rstd, m_dyx, m_dy: gamma * rstd * (dy - m_dy - (x - mean) * rstd * m_dyx)
+
+
+def _sync_bn_worker(rank, world, port, backend, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    esdist.init_process_group(backend)
+    from efficientsam3_amd import train_blocks as tb
+    dev = torch.device("cuda", rank) if backend == "nccl" else torch.device("cpu")
+    if backend == "nccl":
+        torch.cuda.set_device(dev)
+    else:
+        _bn_standins(tb)
+    try:
+        x, dy, gamma, beta = _bn_case()
+        lo = sum(_BN_SPLIT[:rank])
+        xs, dys = x[lo:lo + _BN_SPLIT[rank]].contiguous().to(dev), dy[lo:lo + _BN_SPLIT[rank]].contiguous().to(dev)
+        rm, rv = torch.zeros(16, device=dev), torch.ones(16, device=dev)
+        tb.SYNC_BN = True
+        y, mean, rstd = tb.bn_train_forward(xs, gamma.to(dev), beta.to(dev), rm, rv, 0.1, 1e-5)
+        dx, dgamma, dbeta = tb.bn_train_backward(xs, dys, gamma.to(dev), mean, rstd)
+        q.put((rank, [t.cpu().numpy() for t in (y, dx, dgamma, dbeta, rm, rv)]))
+    finally:
+        tb.SYNC_BN = None
+        dist.destroy_process_group()
+
+
+def _run_sync_bn(backend):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_bn_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # the reference: ONE BatchNorm2d over the whole batch (what SyncBatchNorm is defined to equal), torch autograd
+    x, dy, gamma, beta = _bn_case()
+    xr, gr, br = x.permute(0, 3, 1, 2).contiguous().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(16), torch.ones(16)
+    yr = torch.nn.functional.batch_norm(xr, rm, rv, gr, br, training=True, momentum=0.1, eps=1e-5)
+    yr.backward(dy.permute(0, 3, 1, 2).contiguous())
+    y_full, dx_full = yr.detach().permute(0, 2, 3, 1).numpy(), xr.grad.permute(0, 2, 3, 1).numpy()
+    lo = 0
+    dgamma_sum, dbeta_sum = 0.0, 0.0
+    for rank in range(world):
+        y, dx, dgamma, dbeta, rm_r, rv_r = results[rank]
+        n = _BN_SPLIT[rank]
+        np.testing.assert_allclose(y, y_full[lo:lo + n], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(dx, dx_full[lo:lo + n], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(rm_r, rm.numpy(), rtol=1e-5, atol=1e-6)          # every rank holds the all-rank running statistics
+        np.testing.assert_allclose(rv_r, rv.numpy(), rtol=1e-5, atol=1e-6)
+        dgamma_sum, dbeta_sum = dgamma_sum + dgamma, dbeta_sum + dbeta
+        lo += n
+    np.testing.assert_allclose(dgamma_sum, gr.grad.numpy(), rtol=2e-4, atol=2e-4)    # the ranks' own sums add up to the whole batch's gradient
+    np.testing.assert_allclose(dbeta_sum, br.grad.numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_sync_batchnorm_two_ranks_equal_one_big_batch_gloo():
+    """``Stage1Trainer(sync_bn=True)``'s BatchNorm on two ranks holding 3 and 5 samples = nn.BatchNorm2d over the 8 (forward, running statistics,
+    input gradient; the weight / bias gradients are each rank's own sums, as torch.nn.SyncBatchNorm leaves them to the gradient all-reduce)"""
+    _run_sync_bn("gloo")
+
+
+@pytest.mark.gpu
+def test_sync_batchnorm_two_ranks_equal_one_big_batch_rccl():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    _run_sync_bn("nccl")
+
+
+def _sync_bn_one_rank_worker(q):
+    """one GPU, a one-rank RCCL group: the SyncBatchNorm path (split kernels + all_gather / all_reduce on device tensors) against the plain path
+    (the fused two-call kernels) on the same tensors, fp32 and bf16"""
+    port = _free_port()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    esdist.init_process_group("nccl", dev, force=True)
+    from efficientsam3_amd import train_blocks as tb
+    rep = {}
+    try:
+        for dtype in (torch.float32, torch.bfloat16):
+            g = torch.Generator().manual_seed(11)
+            x = (torch.randn(4, 33, 31, 48, generator=g) * 2.0 + 3.0).to(dtype).to(dev)
+            dy = torch.randn(4, 33, 31, 48, generator=g).to(dtype).to(dev)
+            gamma, beta = (torch.rand(48, generator=g) + 0.5).to(dev), torch.randn(48, generator=g).to(dev)
+            outs = []
+            for sync in (None, True):
+                tb.SYNC_BN = sync
+                rm, rv = torch.zeros(48, device=dev), torch.ones(48, device=dev)
+                y, mean, rstd = tb.bn_train_forward(x, gamma, beta, rm, rv, 0.1, 1e-5)
+                dx, dgamma, dbeta = tb.bn_train_backward(x, dy, gamma, mean, rstd)
+                outs.append([t.float().cpu() for t in (y, mean, rstd, rm, rv, dx, dgamma, dbeta)])
+            rep[str(dtype)] = [float((a - b).abs().max()) / max(1e-6, float(a.abs().max())) for a, b in zip(*outs)]
+        q.put(rep)
+    finally:
+        tb.SYNC_BN = None
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sync_batchnorm_path_equals_the_plain_path_on_one_rank_rccl():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_sync_bn_one_rank_worker, args=(q,))
+    p.start()
+    rep = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    names = ("y", "mean", "rstd", "running_mean", "running_var", "dx", "dgamma", "dbeta")
+    for dtype, errs in rep.items():
+        print(f"[sync-bn one rank {dtype}] relative max differences to the plain path: " + ", ".join(f"{n} {e:.1e}" for n, e in zip(names, errs)))
+        for n, e in zip(names, errs):
+            assert e <= (1e-5 if n not in ("y", "dx") or "float32" in dtype else 8e-3), (dtype, n, e)
