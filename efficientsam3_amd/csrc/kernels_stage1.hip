@@ -548,14 +548,17 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const typename Elem<DT>:
 // -- one thread per channel walking all 512 splits -- took 128 us per call, 9 ms of a 54 ms stage-1 step over its 70 calls
 // (profiles/r04/stage1_step_kernel_stats.csv): a chain of 1024 dependent loads + fp64 adds on a handful of lanes.
 template <bool BWD>
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int splits, int C, int64_t rows, double eps,
-                                                          double momentum, float* __restrict__ o0, float* __restrict__ o1,
-                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                          float* __restrict__ var_out = nullptr) {
-  __shared__ double sq[2][4][64];
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ partial, int splits, int C, int64_t rows, double eps,
+                                                           double momentum, float* __restrict__ o0, float* __restrict__ o1,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                           float* __restrict__ var_out = nullptr) {
+  // 64 channels x 16 wavefronts: each wave sums a contiguous sixteenth of the splits (round 5: four waves of 128 splits were 20 us per call,
+  // 1.5 ms of a 21.6 ms B1 step over its 70 calls, profiles/r05/stage1_step_b1_kernel_stats_final.csv)
+  constexpr int Q = 16;
+  __shared__ double sq[2][Q][64];
   const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + e;
-  const int per = (splits + 3) / 4, z0 = q * per, z1 = splits < z0 + per ? splits : z0 + per;
+  const int per = (splits + Q - 1) / Q, z0 = q * per, z1 = splits < z0 + per ? splits : z0 + per;
   double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
   if (c < C) {
     int z = z0;
@@ -574,8 +577,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   sq[1][q][e] = b0 + b1;
   __syncthreads();
   if (q != 0 || c >= C) return;
-  const double s0 = (sq[0][0][e] + sq[0][1][e]) + (sq[0][2][e] + sq[0][3][e]);
-  const double s1 = (sq[1][0][e] + sq[1][1][e]) + (sq[1][2][e] + sq[1][3][e]);
+  double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < Q; k += 4) {   // one written-down order
+    s0 += (sq[0][k][e] + sq[0][k + 1][e]) + (sq[0][k + 2][e] + sq[0][k + 3][e]);
+    s1 += (sq[1][k][e] + sq[1][k + 1][e]) + (sq[1][k + 2][e] + sq[1][k + 3][e]);
+  }
   if constexpr (BWD) {
     o0[c] = (float)s1;  // dgamma
     o1[c] = (float)s0;  // dbeta
@@ -635,7 +642,7 @@ int bn_forward_t(const void* x, void* y, int64_t rows, int C, const float* gamma
   const int splits = (int)(rows < BN_SPLITS ? rows : BN_SPLITS);
   hipLaunchKernelGGL((bn_reduce_kernel<DT, false>), dim3((unsigned)splits), dim3(256), sizeof(float) * 2 * (size_t)RL * C, s, (const T*)x,
                      (const T*)nullptr, rows, C, (const float*)nullptr, (const float*)nullptr, partial);
-  hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, partial, splits, C, rows, eps, momentum,
+  hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, s, partial, splits, C, rows, eps, momentum,
                      save_mean, save_rstd, rm, rv);
   const int64_t total = rows * (C / 8);
   const unsigned grid = (unsigned)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
@@ -653,7 +660,7 @@ int bn_backward_t(const void* x, const void* dy, void* dx, int64_t rows, int C, 
   const int splits = (int)(rows < BN_SPLITS ? rows : BN_SPLITS);
   hipLaunchKernelGGL((bn_reduce_kernel<DT, true>), dim3((unsigned)splits), dim3(256), sizeof(float) * 2 * (size_t)RL * C, s, (const T*)x,
                      (const T*)dy, rows, C, save_mean, save_rstd, partial);
-  hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, partial, splits, C, rows, 0.0, 0.0, dgamma,
+  hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, s, partial, splits, C, rows, 0.0, 0.0, dgamma,
                      dbeta, (float*)nullptr, (float*)nullptr);
   const int64_t total = rows * (C / 8);
   const unsigned grid = (unsigned)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
@@ -673,7 +680,7 @@ int bn_stats_t(const void* x, int64_t rows, int C, double eps, float* mean, floa
   const int splits = (int)(rows < BN_SPLITS ? rows : BN_SPLITS);
   hipLaunchKernelGGL((bn_reduce_kernel<DT, false>), dim3((unsigned)splits), dim3(256), sizeof(float) * 2 * (size_t)RL * C, s, (const T*)x,
                      (const T*)nullptr, rows, C, (const float*)nullptr, (const float*)nullptr, partial);
-  hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, partial, splits, C, rows, eps, 0.0, mean, rstd,
+  hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, s, partial, splits, C, rows, eps, 0.0, mean, rstd,
                      (float*)nullptr, (float*)nullptr, var);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
@@ -697,7 +704,7 @@ int bn_backward_sums_t(const void* x, const void* dy, int64_t rows, int C, const
   const int splits = (int)(rows < BN_SPLITS ? rows : BN_SPLITS);
   hipLaunchKernelGGL((bn_reduce_kernel<DT, true>), dim3((unsigned)splits), dim3(256), sizeof(float) * 2 * (size_t)RL * C, s, (const T*)x, (const T*)dy, rows,
                      C, mean, rstd, partial);
-  hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, partial, splits, C, rows, 0.0, 0.0, sum_dy_xhat, sum_dy,
+  hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, s, partial, splits, C, rows, 0.0, 0.0, sum_dy_xhat, sum_dy,
                      (float*)nullptr, (float*)nullptr);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
