@@ -101,6 +101,8 @@ SIGNATURES = {
     "esam3_act_backward": (_I, [_I, _P, _P, _P, _L, _I, _P]),
     "esam3_linear_wgrad_workspace": (_L, [_L, _I, _I]),
     "esam3_linear_wgrad": (_I, [_I, _P, _P, _L, _I, _I, _P, _P, _P, _P]),
+    "esam3_conv3x3_wgrad_workspace": (_L, [_I, _I, _I, _I, _I, _I]),
+    "esam3_conv3x3_wgrad": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "esam3_colsum_workspace": (_L, [_L, _I]),
     "esam3_colsum": (_I, [_I, _P, _L, _I, _P, _P, _P]),
     "esam3_channel_scale": (_I, [_I, _P, _P, _I, C.c_float, _P, _I, C.c_float, _P, _P, _I, _L, _I, _P]),

@@ -114,16 +114,36 @@ constexpr int WG_VS = WG_ROWS * 32 + 128;  // bf16 sub-tile [64 rows][16 ch] + s
 typedef short ts16x4_v __attribute__((ext_vector_type(4)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
+// GATHER (round 5): the weight gradient of a dense 3x3 conv (padding 1, stride 1 | 2) in ONE launch -- grid.z = 9 taps x splits; for tap
+// (ky, kx) the x operand of output pixel (b, oy, ox) is the input pixel (oy s + ky - 1, ox s + kx - 1), zeros outside the image (the nine
+// shifted, zero-padded copies the host made before: stage1_train.conv3x3_wgrad of round 4).  partial [tap][split][N][K].
+struct WgradGather {
+  int on, zs, OH, OW, IH, IW, stride;
+};
 template <int DT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::type* __restrict__ dy, int ldy,
                                                     const typename TElem<DT>::type* __restrict__ x, int ldx, int64_t M, int N, int K,
-                                                    int64_t rows_per_split, float* __restrict__ partial /* [splits][N][K] */) {
+                                                    int64_t rows_per_split, float* __restrict__ partial /* [splits][N][K] */,
+                                                    WgradGather gt = WgradGather{0, 0, 0, 0, 0, 0, 0}) {
   // fp32: plain [row][64 ch] (+1 float pad); bf16: 4 sub-tiles per operand
   __shared__ __attribute__((aligned(16))) char sA[DT == 0 ? WG_ROWS * 65 * 4 : 4 * WG_VS];
   __shared__ __attribute__((aligned(16))) char sB[DT == 0 ? WG_ROWS * 65 * 4 : 4 * WG_VS];
   const int n0 = blockIdx.y * WG_TILE, k0 = blockIdx.x * WG_TILE;
-  const int64_t r_begin = (int64_t)blockIdx.z * rows_per_split;
+  const int zsplit = gt.on ? (int)blockIdx.z % gt.zs : (int)blockIdx.z, tap = gt.on ? (int)blockIdx.z / gt.zs : 0;
+  const int64_t r_begin = (int64_t)zsplit * rows_per_split;
   const int64_t r_end = r_begin + rows_per_split < M ? r_begin + rows_per_split : M;
+  const int gky = tap / 3 - 1, gkx = tap % 3 - 1;
+  // row of the x operand for output row r: the row itself, or (GATHER) the tap's input pixel (-1: outside the image)
+  auto xrow = [&](int64_t r) -> int64_t {
+    if (!gt.on) return r;
+    const int64_t hw = (int64_t)gt.OH * gt.OW;
+    const int64_t b = r / hw;
+    const int rem = (int)(r - b * hw);
+    const int oy = rem / gt.OW, ox = rem - oy * gt.OW;
+    const int iy = oy * gt.stride + gky, ix = ox * gt.stride + gkx;
+    if (iy < 0 || iy >= gt.IH || ix < 0 || ix >= gt.IW) return -1;
+    return (b * gt.IH + iy) * (int64_t)gt.IW + ix;
+  };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
   const int wn = wave >> 1, wk = wave & 1;  // this wave's quadrant: dW rows n0 + 32 wn .., columns k0 + 32 wk ..
   f32x16_t acc;
@@ -139,7 +159,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::ty
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
         if (r0 + row < r_end) {
           if (n0 + ch < N) a = *reinterpret_cast<const float4*>(dy + (r0 + row) * ldy + n0 + ch);   // N, K multiples of 8
-          if (k0 + ch < K) b = *reinterpret_cast<const float4*>(x + (r0 + row) * ldx + k0 + ch);
+          const int64_t xr = xrow(r0 + row);
+          if (k0 + ch < K && xr >= 0) b = *reinterpret_cast<const float4*>(x + xr * ldx + k0 + ch);
         }
         float* pa = reinterpret_cast<float*>(sA) + row * 65 + ch;
         float* pb = reinterpret_cast<float*>(sB) + row * 65 + ch;
@@ -152,7 +173,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::ty
         uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a;
         if (r0 + row < r_end) {
           if (n0 + ch8 * 8 < N) a = *reinterpret_cast<const uint4*>(dy + (r0 + row) * ldy + n0 + ch8 * 8);
-          if (k0 + ch8 * 8 < K) b = *reinterpret_cast<const uint4*>(x + (r0 + row) * ldx + k0 + ch8 * 8);
+          const int64_t xr = xrow(r0 + row);
+          if (k0 + ch8 * 8 < K && xr >= 0) b = *reinterpret_cast<const uint4*>(x + xr * ldx + k0 + ch8 * 8);
         }
         const int off = (ch8 >> 1) * WG_VS + row * 32 + (ch8 & 1) * 16;
         *reinterpret_cast<uint4*>(sA + off) = a;
@@ -217,6 +239,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   sq[q][e] = i < n ? fixed_order_sum(partial + i, z0, z1, n) : 0.f;
   __syncthreads();
   if (q == 0 && i < n) out[i] = (sq[0][e] + sq[1][e]) + (sq[2][e] + sq[3][e]);
+}
+
+// the 3x3 conv's nine taps: out[(n K + k) 9 + tap] = sum over the splits of partial[tap][split][n K + k] (fixed order): dw [N][K][3][3]
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int64_t nk, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int tap = blockIdx.y;
+  if (i >= nk) return;
+  out[i * 9 + tap] = fixed_order_sum(partial + (int64_t)tap * splits * nk + i, 0, splits, nk);
 }
 
 // dbias[N] = sum over the rows of dy: [splits][N] partials then the same reduce kernel
@@ -847,6 +877,51 @@ int esam3_linear_wgrad(int dtype, const void* dy, const void* x, int64_t M, int 
     else hipLaunchKernelGGL(colsum_kernel<1>, g2, dim3(256), 0, s, (const uint16_t*)dy, N, M, N, rps, pb);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, pb, zs, (int64_t)N, dbias);
   }
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
+}
+
+static int conv3x3_wgrad_splits(int64_t M, int N, int K) {
+  const int64_t tiles_nk = 9 * (int64_t)((N + WG_TILE - 1) / WG_TILE) * ((K + WG_TILE - 1) / WG_TILE);
+  int64_t want = 2048 / tiles_nk;
+  if (want < 1) want = 1;
+  const int64_t most = wgrad_splits(M);
+  return (int)(want < most ? want : most);
+}
+
+int64_t esam3_conv3x3_wgrad_workspace(int B, int IH, int IW, int Cin, int Cout, int stride) {
+  if (B <= 0 || IH <= 0 || IW <= 0 || Cin <= 0 || Cout <= 0 || (stride != 1 && stride != 2)) return 0;
+  const int64_t M = (int64_t)B * ((IH + stride - 1) / stride) * ((IW + stride - 1) / stride);
+  return (int64_t)sizeof(float) * 9 * conv3x3_wgrad_splits(M, Cout, Cin) * (int64_t)Cout * Cin;
+}
+
+// dw [Cout][Cin][3][3] fp32 of a dense 3x3 conv (padding 1, stride 1 | 2): x [B][IH][IW][Cin], dy [B][ceil(IH/s)][ceil(IW/s)][Cout]
+int esam3_conv3x3_wgrad(int dtype, const void* dy, const void* x, int B, int IH, int IW, int Cin, int Cout, int stride, float* dw, void* workspace,
+                        void* stream) {
+  if ((dtype != 0 && dtype != 1) || !dy || !x || !dw || !workspace || B <= 0 || IH <= 0 || IW <= 0 || Cin <= 0 || Cout <= 0 || Cin % 8 || Cout % 8 ||
+      (stride != 1 && stride != 2)) {
+    esam3_set_error("esam3_conv3x3_wgrad: bad argument (fp32 / bf16; Cin and Cout multiples of 8; stride 1 | 2)");
+    return -1;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int OH = (IH + stride - 1) / stride, OW = (IW + stride - 1) / stride;
+  const int64_t M = (int64_t)B * OH * OW;
+  const int N = Cout, K = Cin;
+  const int splits = conv3x3_wgrad_splits(M, N, K);
+  const int64_t tiles = (M + WG_ROWS - 1) / WG_ROWS;
+  const int64_t rps = (tiles + splits - 1) / splits * WG_ROWS;
+  const int zs = (int)((M + rps - 1) / rps);
+  if (9 * zs > 65535) {
+    esam3_set_error("esam3_conv3x3_wgrad: %d splits", zs);
+    return -1;
+  }
+  float* partial = (float*)workspace;
+  const WgradGather gt{1, zs, OH, OW, IH, IW, stride};
+  const dim3 grid((unsigned)((K + WG_TILE - 1) / WG_TILE), (unsigned)((N + WG_TILE - 1) / WG_TILE), (unsigned)(9 * zs));
+  if (dtype == 0) hipLaunchKernelGGL(wgrad_kernel<0>, grid, dim3(256), 0, s, (const float*)dy, N, (const float*)x, K, M, N, K, rps, partial, gt);
+  else hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, s, (const uint16_t*)dy, N, (const uint16_t*)x, K, M, N, K, rps, partial, gt);
+  const int64_t nk = (int64_t)N * K;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((nk + 255) / 256), 9), dim3(256), 0, s, partial, zs, nk, dw);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }

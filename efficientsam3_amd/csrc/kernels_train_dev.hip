@@ -8,7 +8,7 @@
 //   esam3_train_linear     1x1 conv / Linear (and its data gradient: `transpose`), esam3_launch_gemm
 //   esam3_train_conv3x3    dense 3x3 conv, padding 1 (the student head's second conv, stage1/model.py:197-200) and its data
 //                          gradient (the same conv with the 180-degree-rotated, channel-transposed weight)
-//   esam3_train_conv3x3_s2 the same conv with stride 2 (RepViT patch embedding, forward only; see there)
+//   esam3_train_conv3x3_s2 the same conv with stride 2 (RepViT / TinyViT patch embedding, forward only; see there)
 //   esam3_train_dwconv     depthwise k x k
 //   esam3_train_stem       the 3 -> C0 stride-2 stem conv on the fp32 NCHW image
 //   esam3_resize_bilinear_backward   adjoint of F.interpolate(bilinear, align_corners=False) (stage1/model.py:205-210)

@@ -78,17 +78,19 @@ def conv3x3_dgrad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return dx
 
 
-def conv3x3_wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dw [Cout, Cin, 3, 3] fp32: tap (ky, kx) is the 1x1 weight gradient of dy against x shifted by (ky - 1, kx - 1) (zero outside the image):
-    nine launches of the row-reduction GEMM ``esam3_linear_wgrad`` on shifted copies (data movement only)"""
+def conv3x3_wgrad(dy: torch.Tensor, x: torch.Tensor, stride: int = 1) -> torch.Tensor:
+    """dw [Cout, Cin, 3, 3] fp32 of the dense 3x3 conv (padding 1, stride 1 | 2): tap (ky, kx) is the 1x1 weight gradient of dy against x shifted
+    by (ky - 1, kx - 1) (zero outside the image) -- ``esam3_conv3x3_wgrad``: ONE launch of the weight-gradient GEMM with the nine taps on
+    grid.z and the shifted operand gathered in the kernel (round 4 made nine shifted, zero-padded copies and nine launches here)"""
     b, h, wd, cin = x.shape
     cout = dy.shape[-1]
-    xp = torch.zeros((b, h + 2, wd + 2, cin), dtype=x.dtype, device=x.device)
-    xp[:, 1:h + 1, 1:wd + 1] = x
+    assert x.is_contiguous() and dy.is_contiguous() and dy.dtype == x.dtype
+    lib = _lib.load()
     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
-    for ky in range(3):
-        for kx in range(3):
-            dw[:, :, ky, kx] = tb.linear_wgrad(dy, xp[:, ky:ky + h, kx:kx + wd].contiguous())
+    ws = tb._ws(lib.esam3_conv3x3_wgrad_workspace(b, h, wd, cin, cout, stride), x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.esam3_conv3x3_wgrad(_DT[x.dtype], dy.data_ptr(), x.data_ptr(), b, h, wd, cin, cout, stride, dw.data_ptr(), ws.data_ptr(), _stream()),
+                   "esam3_conv3x3_wgrad")
     return dw
 
 

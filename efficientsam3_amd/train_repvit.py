@@ -65,16 +65,17 @@ def conv3x3_s2_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw) -> torch.Tensor:
 
 
 def conv3x3_s2_wgrad(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """dw [Cout, Cin, 3, 3] fp32: tap (ky, kx) is the 1x1 weight gradient of dy against the input pixels (2 oy + ky - 1, 2 ox + kx - 1)
-    (zero outside the image): nine launches of ``esam3_linear_wgrad`` on strided copies of the zero-bordered input (data movement only)"""
+    """dw [Cout, Cin, 3, 3] fp32: tap (ky, kx) is the 1x1 weight gradient of dy against the input pixels (2 oy + ky - 1, 2 ox + kx - 1) (zero
+    outside the image): ``esam3_conv3x3_wgrad`` with stride 2, one launch (the operand gathered in the kernel)"""
     b, h, wd, cin = x.shape
-    _, oh, ow, cout = dy.shape
-    xp = torch.zeros((b, 2 * oh + 1, 2 * ow + 1, cin), dtype=x.dtype, device=x.device)
-    xp[:, 1:h + 1, 1:wd + 1] = x
+    cout = dy.shape[-1]
+    assert x.is_contiguous() and dy.is_contiguous() and dy.dtype == x.dtype
+    lib = _lib.load()
     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
-    for ky in range(3):
-        for kx in range(3):
-            dw[:, :, ky, kx] = tb.linear_wgrad(dy, xp[:, ky:ky + 2 * oh - 1:2, kx:kx + 2 * ow - 1:2].contiguous())
+    ws = tb._ws(lib.esam3_conv3x3_wgrad_workspace(b, h, wd, cin, cout, 2), x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.esam3_conv3x3_wgrad(_DT[x.dtype], dy.data_ptr(), x.data_ptr(), b, h, wd, cin, cout, 2, dw.data_ptr(), ws.data_ptr(), tb._stream()),
+                   "esam3_conv3x3_wgrad")
     return dw
 
 

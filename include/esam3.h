@@ -232,6 +232,13 @@ int esam3_act_backward(int dtype, const void* x_dev, const void* dy_dev, void* d
 int64_t esam3_linear_wgrad_workspace(int64_t M, int N, int K);
 int esam3_linear_wgrad(int dtype, const void* dy_dev, const void* x_dev, int64_t M, int N, int K, float* dw_dev, float* dbias_dev,
                        void* workspace_dev, void* hip_stream);
+/* dw [Cout][Cin][3][3] fp32 of a dense 3x3 conv with padding 1 and stride 1 | 2 (the student head's second conv, stage1/model.py:197-200; the
+ * second conv of the RepViT / TinyViT patch embedding, repvit.py:230, tiny_vit.py:80) in ONE launch of the weight-gradient GEMM: grid.z = 9 taps x
+ * row splits, the x operand of tap (ky, kx) gathered from the input pixel (oy s + ky - 1, ox s + kx - 1), zeros outside the image.
+ * x [B][IH][IW][Cin], dy [B][ceil(IH/s)][ceil(IW/s)][Cout]; Cin % 8 == 0, Cout % 8 == 0; workspace esam3_conv3x3_wgrad_workspace(...) bytes. */
+int64_t esam3_conv3x3_wgrad_workspace(int B, int IH, int IW, int Cin, int Cout, int stride);
+int esam3_conv3x3_wgrad(int dtype, const void* dy_dev, const void* x_dev, int B, int IH, int IW, int Cin, int Cout, int stride, float* dw_dev,
+                        void* workspace_dev, void* hip_stream);
 /* out[N] = sum over the M rows of dy[M][N] (the bias gradient of a conv / Linear whose BatchNorm is absent: the local MBConv of an
  * EfficientViTBlock, ops.py:704-711 use_bias=(True, True, False), norm=(None, None, bn2d)); workspace: esam3_colsum_workspace(M, N) bytes */
 int64_t esam3_colsum_workspace(int64_t M, int N);

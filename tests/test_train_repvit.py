@@ -275,3 +275,21 @@ def test_repvit_block_forward_backward_vs_autograd(mode, B, H, W, C, Cout, strid
     # running statistics of every BatchNorm of the block: one training-mode forward from (0, 1)
     names = dict(blk.norm_layers())
     assert set(names) == {k[:-len(".weight")] for k in sd if k.endswith("bn.weight")}
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("B,IH,IW,Cin,Cout,stride", [(2, 9, 7, 16, 24, 1), (1, 32, 32, 64, 64, 1), (8, 32, 32, 256, 128, 1), (2, 12, 10, 24, 48, 2),
+                                                      (1, 13, 11, 40, 80, 2), (3, 1, 5, 8, 8, 1), (2, 64, 64, 32, 64, 2)])
+def test_conv3x3_weight_gradient_one_launch(mode, B, IH, IW, Cin, Cout, stride):
+    """``esam3_conv3x3_wgrad``: the nine taps of a dense 3x3 conv's weight gradient in one gathered launch (padding 1, stride 1 | 2, odd sizes,
+    images smaller than a 64-row tile, several row splits) against autograd"""
+    from efficientsam3_amd import stage1_train as st
+    g = torch.Generator().manual_seed(B + IH + Cin)
+    x = torch.randn(B, IH, IW, Cin, generator=g).to(TDT[mode])
+    dy = torch.randn(B, (IH + stride - 1) // stride, (IW + stride - 1) // stride, Cout, generator=g).to(TDT[mode])
+    wr = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    F.conv2d(_to_nchw(x.float()), wr, None, stride=stride, padding=1).backward(_to_nchw(dy.float()))
+    dw = st.conv3x3_wgrad(dy.cuda().contiguous(), x.cuda().contiguous(), stride)
+    assert dw.shape == wr.grad.shape and dw.dtype == torch.float32
+    _close(dw, wr.grad, "f32", f"conv3x3 wgrad s{stride}", f32=2e-5 if mode == "f32" else 2e-5)
+    assert torch.equal(st.conv3x3_wgrad(dy.cuda().contiguous(), x.cuda().contiguous(), stride), dw)      # fixed summation order
