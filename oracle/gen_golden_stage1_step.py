@@ -183,8 +183,11 @@ def main():
     global MODEL
     import argparse
     ap = argparse.ArgumentParser()
+    ap.add_argument("--samples", type=int, default=NSAMP, help="strided samples kept per tensor (256; the fixtures of the largest students keep 64)")
     ap.add_argument("--model", default="b1", choices=["b0", "b1", "b2", "repvit_m0_9", "repvit_m1_1", "repvit_m2_3", "tiny_vit_5m", "tiny_vit_11m", "tiny_vit_21m"])
-    MODEL = ap.parse_args().model
+    a_ = ap.parse_args()
+    MODEL = a_.model
+    globals()["NSAMP"] = a_.samples
     suffix = "" if MODEL == "b1" else f"_{MODEL}"
     os.makedirs(GOLD, exist_ok=True)
     fp32, arrays = run(False)

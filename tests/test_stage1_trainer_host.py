@@ -85,10 +85,13 @@ def _sample(t, n):
     return flat[::step][:n].numpy()
 
 
-@pytest.mark.parametrize("model,family,name", [("repvit_m0_9", "repvit", "m0.9"), ("tiny_vit_5m", "tinyvit", "5m"), ("tiny_vit_11m", "tinyvit", "11m")])
+@pytest.mark.parametrize("model,family,name", [("repvit_m0_9", "repvit", "m0.9"), ("tiny_vit_5m", "tinyvit", "5m"), ("tiny_vit_11m", "tinyvit", "11m"),
+                                               ("tiny_vit_21m", "tinyvit", "21m"), ("b0", "efficientvit", "b0")])
 def test_trainer_host_logic_vs_the_reference_run(host_trainer, model, family, name):
-    """RepViT-M0.9; TinyViT-5M (no stochastic depth); TinyViT-11M with the DropPath factors of the reference's run (part of the fixture) fed
-    through ``drop_path_sampler``"""
+    """RepViT-M0.9; TinyViT-5M (no stochastic depth); TinyViT-11M and 21M with the DropPath factors of the reference's run (part of the fixture)
+    fed through ``drop_path_sampler``; EfficientViT-B0 (the GPU tests hold B1 and B2 to their fixtures) -- with the GPU fixtures that is eight
+    of the nine students of stage1/model.py:386-420 against the reference's own run (RepViT-M2.3, 58 blocks, is checked against the reference
+    MODULE in tests/test_train_repvit_host.py)"""
     with open(os.path.join(GOLD, f"step_{model}_manifest.json")) as f:
         man = json.load(f)
     g = np.load(os.path.join(GOLD, f"step_{model}.npz"))
@@ -128,9 +131,15 @@ def test_trainer_host_logic_vs_the_reference_run(host_trainer, model, family, na
     clip = min(1.0, hy["clip_grad"] / (norm + 1e-6))
     gmax = max(float(g[f"gradmax1/{n}"]) for n in ref["names"])
     assert sorted(grads) == sorted(ref["names"])
+    # EfficientViT at random initialisation amplifies rounding differences between two fp32 implementations (its GPU test allows 2.5e-2 of a
+    # tensor's maximum for the same reason: tests/test_stage1_step.py); the other two families are well conditioned
+    rel, absl = (2.5e-2, 2.5e-5) if family == "efficientvit" else (5e-3, 1e-5)
+    worst = 0.0
     for n in ref["names"]:
         err = float(np.abs(grads[n] * clip - g[f"grad1/{n}"]).max())
-        assert err <= 5e-3 * float(g[f"gradmax1/{n}"]) + 1e-5 * gmax, (n, err, float(g[f"gradmax1/{n}"]))
+        worst = max(worst, err / (rel * float(g[f"gradmax1/{n}"]) + absl * gmax))
+        assert err <= rel * float(g[f"gradmax1/{n}"]) + absl * gmax, (n, err, float(g[f"gradmax1/{n}"]))
+    print(f"[host {model}] largest fraction of the gradient allowance ({rel:g} x tensor max + {absl:g} x network max) used: {worst:.3f}")
     state = tr.state_dict()
     for n in ref["names"]:
         assert tuple(state[n].shape) == tuple(ref["shapes"][n]), n
@@ -140,7 +149,8 @@ def test_trainer_host_logic_vs_the_reference_run(host_trainer, model, family, na
         assert float(np.abs(_sample(state[k], ns) - want).max()) <= 1e-4 * max(1.0, float(np.abs(want).max())), k
     assert all(int(v) == int(sd[k]) + 1 for k, v in state.items() if k.endswith("num_batches_tracked"))
     # the arrival order of the gradients (= the bucket order of the all-reduce): head first, then the trunk from its last block to the stem
-    first = {"repvit": "backbone.model.features.0.0.bn.bias", "tinyvit": "backbone.model.patch_embed.seq.0.bn.bias"}[family]
+    first = {"repvit": "backbone.model.features.0.0.bn.bias", "tinyvit": "backbone.model.patch_embed.seq.0.bn.bias",
+             "efficientvit": "backbone.model.input_stem.op_list.0.norm.bias"}[family]
     assert tr._arrival[0].startswith("head.") and tr._arrival[-1] == first
 
     step_no[0] = 2
