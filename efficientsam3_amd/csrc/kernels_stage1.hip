@@ -11,6 +11,7 @@
 #include "esam3_common.h"
 #include "kernels.h"
 #include "resize_aa.h"
+#include "train_act.h"
 
 namespace {
 
@@ -487,7 +488,10 @@ template <int DT, bool BWD>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const typename Elem<DT>::type* __restrict__ x,
                                                         const typename Elem<DT>::type* __restrict__ dy, int64_t rows, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                        float* __restrict__ partial) {
+                                                        float* __restrict__ partial,
+                                                        const typename Elem<DT>::type* __restrict__ pre = nullptr, int act = 0) {
+  // BWD with `pre` (round 5): dy is the gradient of act(pre), pre = the BatchNorm's own output -- g = dy act'(pre) is formed here instead of
+  // in a separate elementwise pass that wrote it out (the ConvLayer's activation derivative fused into the BatchNorm backward)
   extern __shared__ float red[];  // [RL][2][C]
   const int CG = C >> 3, RL = 256 / CG;
   const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
@@ -514,6 +518,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const typename Elem<DT>:
       if constexpr (BWD) {
         float g[8];
         Elem<DT>::load8(dy + r * C + cg * 8, g);
+        if (pre) {
+          float pv2[8];
+          Elem<DT>::load8(pre + r * C + cg * 8, pv2);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) g[e] *= act_grad(pv2[e], act);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           a[e] += g[e];
@@ -605,7 +615,11 @@ __global__ __launch_bounds__(256) void bn_map_kernel(const typename Elem<DT>::ty
                                                      typename Elem<DT>::type* __restrict__ out, int64_t rows, int C,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta, float invn) {
+                                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta, float invn,
+                                                     const typename Elem<DT>::type* __restrict__ pre = nullptr,
+                                                     typename Elem<DT>::type* __restrict__ out_act = nullptr, int act = 0) {
+  // round 5, the ConvLayer's activation in the same pass.  FWD with `out_act`: also writes act(y) (of the value as stored: rounded to bf16
+  // first in bf16 mode, so the result equals the separate pass's).  BWD with `pre`: dy is the gradient of act(pre), g = dy act'(pre).
   const int CG = C >> 3;
   const int64_t total = rows * CG;   // invn = 1 / (rows of the whole batch): `rows` of this rank, or of all ranks under SyncBatchNorm
   const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
@@ -617,6 +631,12 @@ __global__ __launch_bounds__(256) void bn_map_kernel(const typename Elem<DT>::ty
     if constexpr (BWD) {
       float g[8];
       Elem<DT>::load8(dy + i * 8, g);
+      if (pre) {
+        float pv2[8];
+        Elem<DT>::load8(pre + i * 8, pv2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] *= act_grad(pv2[e], act);
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int c = cg * 8 + e;
@@ -629,6 +649,16 @@ __global__ __launch_bounds__(256) void bn_map_kernel(const typename Elem<DT>::ty
         const int c = cg * 8 + e;
         o[e] = (v[e] - mean[c]) * rstd[c] * gamma[c] + beta[c];
       }
+      if (out_act) {
+        float oa[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float stored = o[e];
+          if constexpr (DT == 1) stored = __uint_as_float(pack_bf16x2(o[e], 0.f) << 16);   // what `out` will hold
+          oa[e] = act_fwd(stored, act);
+        }
+        Store8<DT>::st(out_act + i * 8, oa);
+      }
     }
     Store8<DT>::st(out + i * 8, o);
   }
@@ -636,7 +666,8 @@ __global__ __launch_bounds__(256) void bn_map_kernel(const typename Elem<DT>::ty
 
 template <int DT>
 int bn_forward_t(const void* x, void* y, int64_t rows, int C, const float* gamma, const float* beta, float* rm, float* rv,
-                 double momentum, double eps, float* save_mean, float* save_rstd, float* partial, hipStream_t s) {
+                 double momentum, double eps, float* save_mean, float* save_rstd, float* partial, hipStream_t s, void* y_act = nullptr,
+                 int act = 0) {
   typedef typename Elem<DT>::type T;
   const int RL = 256 / (C / 8);
   const int splits = (int)(rows < BN_SPLITS ? rows : BN_SPLITS);
@@ -647,25 +678,25 @@ int bn_forward_t(const void* x, void* y, int64_t rows, int C, const float* gamma
   const int64_t total = rows * (C / 8);
   const unsigned grid = (unsigned)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
   hipLaunchKernelGGL((bn_map_kernel<DT, false>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)nullptr, (T*)y, rows, C, gamma, beta,
-                     save_mean, save_rstd, (const float*)nullptr, (const float*)nullptr, 0.f);
+                     save_mean, save_rstd, (const float*)nullptr, (const float*)nullptr, 0.f, (const T*)nullptr, (T*)y_act, act);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 
 template <int DT>
 int bn_backward_t(const void* x, const void* dy, void* dx, int64_t rows, int C, const float* gamma, const float* save_mean,
-                  const float* save_rstd, float* dgamma, float* dbeta, float* partial, hipStream_t s) {
+                  const float* save_rstd, float* dgamma, float* dbeta, float* partial, hipStream_t s, const void* pre = nullptr, int act = 0) {
   typedef typename Elem<DT>::type T;
   const int RL = 256 / (C / 8);
   const int splits = (int)(rows < BN_SPLITS ? rows : BN_SPLITS);
   hipLaunchKernelGGL((bn_reduce_kernel<DT, true>), dim3((unsigned)splits), dim3(256), sizeof(float) * 2 * (size_t)RL * C, s, (const T*)x,
-                     (const T*)dy, rows, C, save_mean, save_rstd, partial);
+                     (const T*)dy, rows, C, save_mean, save_rstd, partial, (const T*)pre, act);
   hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, s, partial, splits, C, rows, 0.0, 0.0, dgamma,
                      dbeta, (float*)nullptr, (float*)nullptr);
   const int64_t total = rows * (C / 8);
   const unsigned grid = (unsigned)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
   hipLaunchKernelGGL((bn_map_kernel<DT, true>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)dy, (T*)dx, rows, C, gamma,
-                     (const float*)nullptr, save_mean, save_rstd, dgamma, dbeta, 1.f / (float)rows);
+                     (const float*)nullptr, save_mean, save_rstd, dgamma, dbeta, 1.f / (float)rows, (const T*)pre, (T*)nullptr, act);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -809,6 +840,34 @@ int esam3_bn_train_forward(int dtype, const void* x, void* y, int64_t rows, int 
                                       (float*)workspace, (hipStream_t)stream)
                     : bn_forward_t<1>(x, y, rows, C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd,
                                       (float*)workspace, (hipStream_t)stream);
+}
+
+// The ConvLayer's activation in the BatchNorm's own passes (round 5; ops.py:39-81 Conv2d -> BatchNorm2d -> act): forward also writes
+// y_act = act(y); backward takes dy = the gradient of act(y) with pre = y and forms dy act'(pre) on the fly -- one elementwise pass less each way.
+int esam3_bn_act_train_forward(int dtype, const void* x, void* y, void* y_act, int act, int64_t rows, int C, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, double momentum, double eps, float* save_mean, float* save_rstd,
+                               void* workspace, void* stream) {
+  if (!bn_args_ok("esam3_bn_act_train_forward", dtype, rows, C)) return -1;
+  if (!x || !y || !y_act || !gamma || !beta || !save_mean || !save_rstd || !workspace || !(eps >= 0.0) || act < ACT_RELU || act > ACT_SIGMOID) {
+    esam3_set_error("esam3_bn_act_train_forward: bad argument (act relu | gelu | hswish | sigmoid)");
+    return -1;
+  }
+  return dtype == 0 ? bn_forward_t<0>(x, y, rows, C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd,
+                                      (float*)workspace, (hipStream_t)stream, y_act, act)
+                    : bn_forward_t<1>(x, y, rows, C, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_rstd,
+                                      (float*)workspace, (hipStream_t)stream, y_act, act);
+}
+
+int esam3_bn_act_train_backward(int dtype, const void* x, const void* dy, const void* pre, int act, void* dx, int64_t rows, int C,
+                                const float* gamma, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta, void* workspace,
+                                void* stream) {
+  if (!bn_args_ok("esam3_bn_act_train_backward", dtype, rows, C)) return -1;
+  if (!x || !dy || !pre || !dx || !gamma || !save_mean || !save_rstd || !dgamma || !dbeta || !workspace || act < ACT_RELU || act > ACT_SIGMOID) {
+    esam3_set_error("esam3_bn_act_train_backward: bad argument (act relu | gelu | hswish | sigmoid)");
+    return -1;
+  }
+  return dtype == 0 ? bn_backward_t<0>(x, dy, dx, rows, C, gamma, save_mean, save_rstd, dgamma, dbeta, (float*)workspace, (hipStream_t)stream, pre, act)
+                    : bn_backward_t<1>(x, dy, dx, rows, C, gamma, save_mean, save_rstd, dgamma, dbeta, (float*)workspace, (hipStream_t)stream, pre, act);
 }
 
 int esam3_bn_train_stats(int dtype, const void* x, int64_t rows, int C, double eps, float* mean, float* rstd, float* var, void* workspace,

@@ -79,6 +79,26 @@ def bn_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, sa
     return dx, sdyx, sdy
 
 
+# The ConvLayer's activation inside the BatchNorm kernels' own passes (esam3_bn_act_train_*): one elementwise pass less each way.  Off under
+# SyncBatchNorm (its halves have no fused form) and in the CPU composition tests (they stand in for the unfused kernels).
+FUSE_BN_ACT = True
+
+
+def bn_act_forward(x: torch.Tensor, gamma, beta, running_mean, running_var, momentum: float, eps: float, act):
+    """BatchNorm2d (training mode) then ``act`` -> (pre = the BatchNorm's output, act(pre), mean, rstd)"""
+    if act is not None and FUSE_BN_ACT and SYNC_BN is None:
+        return _s1.bn_act_train_forward(x, gamma, beta, running_mean, running_var, momentum, eps, act)
+    pre, mean, rstd = bn_train_forward(x, gamma, beta, running_mean, running_var, momentum, eps)
+    return pre, (act_forward(pre, act) if act else pre), mean, rstd
+
+
+def bn_act_backward(x: torch.Tensor, dy: torch.Tensor, pre: torch.Tensor, act, gamma, mean, rstd):
+    """its backward: dy = the gradient of act(pre) -> (dx, dgamma, dbeta)"""
+    if act is not None and FUSE_BN_ACT and SYNC_BN is None:
+        return _s1.bn_act_train_backward(x, dy, pre, act, gamma, mean, rstd)
+    return bn_train_backward(x, act_backward(pre, dy, act) if act else dy, gamma, mean, rstd)
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -285,20 +305,19 @@ class ConvLayerTrain:
         self.x = x
         self.conv_out = linear_forward(x, self.w, self.bias) if self.kind == "pw" else dwconv_forward(x, self.w, self.stride, self.bias)
         if self.norm:
-            self.pre, self.mean, self.rstd = bn_train_forward(self.conv_out, self.gamma, self.beta, self.running_mean, self.running_var,
-                                                              self.momentum, self.eps)
-        else:
-            self.pre = self.conv_out
+            self.pre, y, self.mean, self.rstd = bn_act_forward(self.conv_out, self.gamma, self.beta, self.running_mean, self.running_var,
+                                                               self.momentum, self.eps, self.act)
+            return y
+        self.pre = self.conv_out
         return act_forward(self.pre, self.act) if self.act else self.pre
 
     def backward(self, dy: torch.Tensor):
         """-> (dx, {"weight": dw, "gamma" / "beta" or "bias": ...})"""
-        d_pre = act_backward(self.pre, dy, self.act) if self.act else dy
         grads = {}
         if self.norm:
-            d_conv, grads["gamma"], grads["beta"] = bn_train_backward(self.conv_out, d_pre, self.gamma, self.mean, self.rstd)
+            d_conv, grads["gamma"], grads["beta"] = bn_act_backward(self.conv_out, dy, self.pre, self.act, self.gamma, self.mean, self.rstd)
         else:
-            d_conv = d_pre
+            d_conv = act_backward(self.pre, dy, self.act) if self.act else dy
         if self.bias is not None:
             grads["bias"] = colsum(d_conv)
         if self.kind == "pw":
@@ -510,13 +529,12 @@ class StemConvTrain:
     def forward(self, img: torch.Tensor) -> torch.Tensor:
         self.img = img
         self.conv_out = stem_forward(img, self.w, self.dtype)
-        self.pre, self.mean, self.rstd = bn_train_forward(self.conv_out, self.gamma, self.beta, self.running_mean, self.running_var, self.momentum,
-                                                          self.eps)
-        return act_forward(self.pre, self.act)
+        self.pre, y, self.mean, self.rstd = bn_act_forward(self.conv_out, self.gamma, self.beta, self.running_mean, self.running_var, self.momentum,
+                                                           self.eps, self.act)
+        return y
 
     def backward(self, dy: torch.Tensor):
-        d_pre = act_backward(self.pre, dy, self.act)
-        d_conv, dgamma, dbeta = bn_train_backward(self.conv_out, d_pre, self.gamma, self.mean, self.rstd)
+        d_conv, dgamma, dbeta = bn_act_backward(self.conv_out, dy, self.pre, self.act, self.gamma, self.mean, self.rstd)
         dw = linear_wgrad(d_conv, stem_im2col(self.img, self.dtype))[:, :27].reshape(self.w.shape)
         return None, {"weight": dw, "gamma": dgamma, "beta": dbeta}
 

@@ -358,3 +358,27 @@ def test_trunk_train_vs_autograd_f32(size, fwd, worst, median):
                    for n, v in p.items()), reverse=True)
     print(f"[trunk f32 @{size}] output rel L2 {e_y:.3e}; {len(rows)} gradients: worst {rows[0][0]:.3e} ({rows[0][1]}), median {rows[len(rows) // 2][0]:.3e}")
     assert e_y <= fwd and rows[0][0] <= worst and rows[len(rows) // 2][0] <= median
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("act", ["hswish", "gelu", "relu"])
+def test_bn_act_fused_passes_equal_the_separate_ones(mode, act):
+    """``esam3_bn_act_train_forward / _backward`` (the ConvLayer's activation inside the BatchNorm kernels' passes) against BatchNorm then
+    activation as separate kernels: same y, same act(y) bit for bit; gradients equal up to the one rounding the separate form spends on
+    storing dy act'(pre) (none in fp32)"""
+    from efficientsam3_amd import stage1, train_blocks as tb
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(3, 17, 19, 48, generator=g) * 2.0 + 1.0).to(TDT[mode]).cuda()
+    dy = torch.randn(3, 17, 19, 48, generator=g).to(TDT[mode]).cuda()
+    gamma, beta = (torch.rand(48, generator=g) + 0.5).cuda(), (torch.randn(48, generator=g) * 0.5).cuda()
+    rm1, rv1, rm2, rv2 = torch.zeros(48).cuda(), torch.ones(48).cuda(), torch.zeros(48).cuda(), torch.ones(48).cuda()
+    y1, m1, r1 = stage1.bn_train_forward(x, gamma, beta, rm1, rv1, 0.1, 1e-5)
+    a1 = tb.act_forward(y1, act)
+    y2, a2, m2, r2 = stage1.bn_act_train_forward(x, gamma, beta, rm2, rv2, 0.1, 1e-5, act)
+    assert torch.equal(y1, y2) and torch.equal(a1, a2) and torch.equal(m1, m2) and torch.equal(r1, r2) and torch.equal(rm1, rm2) and torch.equal(rv1, rv2)
+    dx1, dg1, db1 = stage1.bn_train_backward(x, tb.act_backward(y1, dy, act), gamma, m1, r1)
+    dx2, dg2, db2 = stage1.bn_act_train_backward(x, dy, y2, act, gamma, m2, r2)
+    tol = 2e-6 if mode == "f32" else 1.5e-2
+    for got, ref, what in ((dx2, dx1, "dx"), (dg2, dg1, "dgamma"), (db2, db1, "dbeta")):
+        d, m = float((got.float() - ref.float()).abs().max()), float(ref.float().abs().max())
+        assert d <= tol * m, (what, mode, act, d, m)

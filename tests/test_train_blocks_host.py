@@ -85,6 +85,7 @@ def cpu_kernels(monkeypatch):
 
     monkeypatch.setattr(tb, "channel_scale", channel_scale)
     monkeypatch.setattr(tb, "batched_coldot", batched_coldot)
+    monkeypatch.setattr(tb, "FUSE_BN_ACT", False)       # the compositions are checked with the unfused BatchNorm / activation stand-ins
     monkeypatch.setattr(tb, "DEVICE", "cpu")
     monkeypatch.setattr(tb, "act_forward", lambda x, act: _act(x, act))
     monkeypatch.setattr(tb, "act_backward", act_backward)
