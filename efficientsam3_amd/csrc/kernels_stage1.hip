@@ -469,8 +469,8 @@ __global__ void update_save_inv_scale_kernel(const float* __restrict__ state, in
 // BatchNorm2d in TRAINING mode, forward and backward, on NHWC rows [rows = B H W][C]: every ConvLayer of the
 // EfficientViT / RepViT / TinyViT students normalises with batch statistics while stage 1 trains
 // (backbones/efficientvit/nn/ops.py:69-77 norm="bn2d" = nn.BatchNorm2d, nn/norm.py:47; stage1/train_image_encoder_stage1.py:165
-// model.train(), :310-314 EVAL_BN_WHEN_TRAINING False in every shipped config).  Building blocks of the trunk backward, which is
-// not built: these kernels are checked against torch's batch_norm + autograd, nothing in the engine calls them yet.
+// model.train(), :310-314 EVAL_BN_WHEN_TRAINING False in every shipped config).  Every ConvLayer / Conv2d_BN of the stage-1 trainer runs them
+// (efficientsam3_amd/train_blocks.py: ConvLayerTrain); checked against torch's batch_norm + autograd.  The inference engine folds BN instead.
 //   forward : mean_c, biased var_c over the rows; y = (x - mean) rstd gamma + beta; running_mean / running_var updated with
 //             `momentum` (running_var takes the UNBIASED variance, as torch does); mean and rstd saved for the backward
 //   backward: dbeta = sum dy, dgamma = sum dy xhat, dx = gamma rstd (dy - dbeta / n - xhat dgamma / n)

@@ -3,8 +3,8 @@
 // (backbones/efficientvit/nn/ops.py:39-81 ConvLayer = Conv2d (no bias) -> BatchNorm2d -> activation; :264-360 DSConv / MBConv), on NHWC
 // rows like the rest of the engine.  Together with esam3_bn_train_forward / _backward (kernels_stage1.hip) and the forward operators
 // (esam3_op_linear, esam3_op_dwconv) they are enough to run one such block forwards and backwards; tests/test_train_blocks.py composes
-// them and checks every gradient against torch.autograd.  Nothing in the inference engine calls them; the backward of a whole trunk
-// (LiteMLA, the necks, activation bookkeeping) is not built.
+// them and checks every gradient against torch.autograd; efficientsam3_amd/stage1_train.py sequences them into the training step of every
+// stage-1 student (round 4: EfficientViT; round 5: RepViT, TinyViT).  Nothing in the inference engine calls them.
 //   esam3_act_forward / _backward      Hardswish | ReLU | GELU (erf) | identity and dx = dy * act'(x)
 //   esam3_linear_wgrad                 dW[N][K] = dy[M][N]^T x[M][K]   (1x1 conv / Linear weight gradient; M = pixels is the
 //                                      reduction dimension: a "TN" GEMM), optionally dbias[N] = sum_rows dy

@@ -1,5 +1,6 @@
 """Forward AND backward of the layers an EfficientViT MBConv block is made of, on the HIP kernels (building
-blocks of the stage-1 student-trunk backward, which as a whole is not built).  The reference's block is
+blocks of the stage-1 student-trunk backward; ``stage1_train.Stage1Trainer`` composes them, with ``train_repvit`` / ``train_tinyvit``, into the
+training step of all nine students).  The reference's block is
 ``backbones/efficientvit/nn/ops.py:39-81`` (ConvLayer: Conv2d without bias -> BatchNorm2d -> activation) and ``:310-360`` (MBConv:
 1x1 expand + Hardswish, depthwise 3x3 + Hardswish, 1x1 project, BatchNorm after each; ResidualBlock adds the input), run under
 ``model.train()`` by ``stage1/train_image_encoder_stage1.py:165``.  Everything is NHWC on the GPU; weight gradients come back fp32.

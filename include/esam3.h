@@ -217,8 +217,9 @@ int esam3_distill_loss_backward(int preds_dtype, const void* preds_dev, int teac
 
 /* Gradient kernels of the layers an EfficientViT ConvLayer / DSConv / MBConv is made of (backbones/efficientvit/nn/ops.py:39-81,
  * 264-360: Conv2d without bias -> BatchNorm2d -> activation), NHWC rows, dtype 0 fp32 / 1 bf16 activations and gradients, fp32
- * weight gradients.  Building blocks of the student-trunk backward of stage 1 (stage1/train_image_encoder_stage1.py:196-217), which as a
- * whole is not built; tests/test_train_blocks.py composes them into an MBConv block and checks every gradient against autograd.
+ * weight gradients.  Building blocks of the student-trunk backward of stage 1 (stage1/train_image_encoder_stage1.py:196-217):
+ * efficientsam3_amd/stage1_train.py sequences them into the training step of every student; tests/test_train_blocks.py composes them into an
+ * MBConv block and checks every gradient against autograd.
  *   esam3_act_forward / _backward: y = act(x), dx = dy * act'(x); act 0 none, 1 ReLU, 2 GELU (erf), 3 Hardswish, 4 sigmoid
  *     (the SqueezeExcite gate of the RepViT students); n % 8 == 0.
  *   esam3_linear_wgrad: dw[N][K] = sum_rows dy[row][n] * x[row][k] (the weight gradient of a 1x1 conv / Linear with weight
@@ -365,7 +366,7 @@ int esam3_stage1_update(float* params_dev, float* grads_dev, float* exp_avg_dev,
 /* BatchNorm2d in TRAINING mode on NHWC rows [rows = B H W][C] (dtype 0 fp32 / 1 bf16 activations and gradients; C % 8 == 0,
  * C <= 2048): what every ConvLayer's nn.BatchNorm2d does while stage 1 trains (backbones/efficientvit/nn/ops.py:69-77,
  * nn/norm.py:47; stage1/train_image_encoder_stage1.py:165 model.train(), :310-314) and its autograd backward.  Building blocks of
- * the student-trunk backward (not built): nothing in the engine calls them.
+ * the student-trunk backward (efficientsam3_amd/train_blocks.py: ConvLayerTrain); the inference engine folds BatchNorm instead.
  * forward : y = (x - mean_c) / sqrt(var_c + eps) * gamma_c + beta_c with the batch mean and BIASED variance over the rows;
  *           running_mean / running_var (may be NULL) <- (1 - momentum) * old + momentum * (mean, UNBIASED variance);
  *           save_mean / save_rstd [C] fp32 for the backward.
