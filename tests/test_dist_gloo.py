@@ -762,3 +762,109 @@ def test_sync_batchnorm_path_equals_the_plain_path_on_one_rank_rccl():
         print(f"[sync-bn one rank {dtype}] relative max differences to the plain path: " + ", ".join(f"{n} {e:.1e}" for n, e in zip(names, errs)))
         for n, e in zip(names, errs):
             assert e <= (1e-5 if n not in ("y", "dx") or "float32" in dtype else 8e-3), (dtype, n, e)
+
+
+# ---- the stage-1 trainer on two ranks (DDP gradient averaging + SyncBatchNorm) = one rank with the whole batch -----------------------------------
+class _Setter:
+    """what the kernel stand-in installers need of pytest's monkeypatch, for a spawned worker"""
+
+    @staticmethod
+    def setattr(obj, name, value):
+        setattr(obj, name, value)
+
+
+def _install_trainer_standins():
+    """every kernel wrapper of the trainer replaced by its torch stand-in (tests/test_*_host.py), the BatchNorm dispatcher of train_blocks left
+    REAL (so that its SyncBatchNorm path runs) over stand-ins of the local kernels"""
+    import types
+    from efficientsam3_amd import train_blocks as tb
+    from tests.test_stage1_trainer_host import install_host_trainer
+    from tests.test_train_blocks_host import install_cpu_kernels
+    from tests.test_train_repvit_host import install_repvit_kernels
+    from tests.test_train_tinyvit_host import install_tinyvit_kernels
+    real_fwd, real_bwd = tb.bn_train_forward, tb.bn_train_backward
+    for install in (install_cpu_kernels, install_repvit_kernels, install_tinyvit_kernels, install_host_trainer):
+        install(_Setter)
+    tb._s1 = types.SimpleNamespace(bn_train_forward=tb.bn_train_forward, bn_train_backward=tb.bn_train_backward)
+    tb.bn_train_forward, tb.bn_train_backward = real_fwd, real_bwd
+    _bn_standins(tb)
+
+
+def _trainer_case():
+    from efficientsam3_amd import schema
+    pre = "backbone.vision_backbone.trunk.model."
+    sd = {k[len(pre):]: v.clone() for k, v in schema.synthetic_state_dict("repvit", "m0.9", seed=1).items() if k.startswith(pre)}
+    g = torch.Generator().manual_seed(21)
+    imgs = torch.randn(4, 3, 128, 96, generator=g)
+    teacher = torch.randn(4, 8, 8, 1024, generator=g) * 0.5
+    return sd, imgs, teacher
+
+
+def _trainer_grads(sd, imgs, teacher, sync_bn):
+    from efficientsam3_amd import stage1_train
+    tr = stage1_train.Stage1Trainer(sd, "repvit_m0_9", embed_size=8, dtype="f32", device="cpu", lr=1e-3, cosine_weight=0.5, sync_bn=sync_bn)
+    out = tr.step(imgs, teacher, [(128, 96)] * imgs.shape[0], update_grad=False)
+    tr._allreduce()                                             # the bucketed averaging all-reduce (a no-op without a process group)
+    state = tr.state_dict()
+    return float(out["loss"]), {k: v.numpy() for k, v in tr.gradients().items()}, {k: v.numpy() for k, v in state.items() if k.endswith("running_var")}
+
+
+def _trainer_worker(rank, world, port, sync_bn, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    esdist.init_process_group("gloo")
+    try:
+        _install_trainer_standins()
+        sd, imgs, teacher = _trainer_case()
+        lo = 2 * rank
+        q.put((rank,) + _trainer_grads(sd, imgs[lo:lo + 2].contiguous(), teacher[lo:lo + 2].contiguous(), sync_bn))
+    finally:
+        from efficientsam3_amd import train_blocks as tb
+        tb.SYNC_BN = None
+        dist.destroy_process_group()
+
+
+def _run_trainer(sync_bn):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, sync_bn, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {r[0]: r[1:] for r in (q.get(timeout=600) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return results
+
+
+def _one_rank_reference(q):
+    _install_trainer_standins()
+    sd, imgs, teacher = _trainer_case()
+    q.put(_trainer_grads(sd, imgs, teacher, False))
+
+
+def test_stage1_trainer_two_ranks_with_sync_bn_equal_one_rank_with_the_whole_batch():
+    """``Stage1Trainer(sync_bn=True)`` on two gloo ranks with 2 samples each -- DistributedDataParallel's gradient averaging
+    (``GradientAllReducer``) + torch.nn.SyncBatchNorm's statistics -- gives every rank the gradients of ONE rank training on the 4 samples: the
+    identity the reference's ``--use-sync-bn`` multi-GPU run relies on (train_image_encoder_stage1.py:62-72).  Without SyncBatchNorm the two
+    differ (the negative control).  Kernel stand-ins on the CPU; the host logic, the collectives and the BatchNorm dispatcher are the real ones."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_reference, args=(q,))
+    p.start()
+    loss1, grads1, rv1 = q.get(timeout=600)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    synced = _run_trainer(True)
+    gmax = max(float(np.abs(v).max()) for v in grads1.values())
+    assert abs(0.5 * (synced[0][0] + synced[1][0]) - loss1) <= 1e-5 * abs(loss1)           # the mean of the ranks' losses is the batch's loss
+    for rank in (0, 1):
+        _, grads, rv = synced[rank]
+        worst = max(float(np.abs(grads[k] - grads1[k]).max()) / (float(np.abs(grads1[k]).max()) + 1e-3 * gmax) for k in grads1)
+        assert worst <= 2e-3, (rank, worst)
+        for k in rv1:                                                                       # all-rank running statistics on every rank
+            np.testing.assert_allclose(rv[k], rv1[k], rtol=1e-4, atol=1e-6)
+    plain = _run_trainer(False)
+    worst_plain = max(float(np.abs(plain[0][1][k] - grads1[k]).max()) / (float(np.abs(grads1[k]).max()) + 1e-3 * gmax) for k in grads1)
+    assert worst_plain > 2e-2, worst_plain                                                  # per-rank statistics are a different function

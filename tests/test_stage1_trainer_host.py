@@ -46,8 +46,7 @@ class HostUpdater(stage1.Stage1Updater):
         return self.state[3].clone()
 
 
-@pytest.fixture
-def host_trainer(tinyvit_kernels, monkeypatch):  # noqa: F811
+def install_host_trainer(monkeypatch):  # noqa: F811
     def loss(p2, t2, valid):          # [B, HW, C] rows -> the reference's NCHW functions on [B, C, HW, 1]
         p, t, m = p2.permute(0, 2, 1)[..., None].float(), t2.permute(0, 2, 1)[..., None].float(), valid[:, None, :, None].float()
         return ref_stage1.masked_mse(p, t, m), ref_stage1.masked_cosine_loss(p, t, m), None
@@ -77,6 +76,11 @@ def host_trainer(tinyvit_kernels, monkeypatch):  # noqa: F811
     monkeypatch.setattr(st, "conv3x3_wgrad", conv3x3_wgrad)
     monkeypatch.setattr(st, "resize_forward", lambda x, size: _to_nhwc(F.interpolate(_to_nchw(x), size=(size, size), mode="bilinear", align_corners=False)))
     monkeypatch.setattr(st, "resize_backward", resize_backward)
+
+
+@pytest.fixture
+def host_trainer(tinyvit_kernels, monkeypatch):  # noqa: F811
+    install_host_trainer(monkeypatch)
 
 
 def _sample(t, n):

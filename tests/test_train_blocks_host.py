@@ -21,8 +21,7 @@ def _act(x, act):
     return {None: lambda t: t, "relu": F.relu, "gelu": F.gelu, "hswish": F.hardswish, "sigmoid": torch.sigmoid}[act](x)
 
 
-@pytest.fixture
-def cpu_kernels(monkeypatch):
+def install_cpu_kernels(monkeypatch):
     """stand-ins with the kernels' contracts (NHWC tensors, PyTorch-layout weights, fp32 weight gradients)"""
     def act_backward(x, dy, act):
         xr = x.clone().requires_grad_(True)
@@ -100,6 +99,11 @@ def cpu_kernels(monkeypatch):
     monkeypatch.setattr(tb, "bn_train_backward", bn_bwd)
     monkeypatch.setattr(tb, "lite_mla_backward", mla_bwd)
     monkeypatch.setattr(tb, "lite_mla_forward", lambda ms, groups, dim, eps=1e-15: mla_bwd(ms, torch.zeros(ms.shape[0], ms.shape[1], groups * dim), groups, dim, eps)[1])
+
+
+@pytest.fixture
+def cpu_kernels(monkeypatch):
+    install_cpu_kernels(monkeypatch)
 
 
 def _bn(h, gamma, beta):

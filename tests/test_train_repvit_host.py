@@ -13,8 +13,7 @@ from efficientsam3_amd import train_repvit as tr
 from tests.test_train_blocks_host import _bn, _check, _to_nchw, _to_nhwc, cpu_kernels  # noqa: F401
 
 
-@pytest.fixture
-def repvit_kernels(cpu_kernels, monkeypatch):  # noqa: F811
+def install_repvit_kernels(monkeypatch):  # noqa: F811
     def conv_nhwc(x, w, stride):
         return _to_nhwc(F.conv2d(_to_nchw(x), w, None, stride=stride, padding=1))
 
@@ -31,6 +30,11 @@ def repvit_kernels(cpu_kernels, monkeypatch):  # noqa: F811
     monkeypatch.setattr(tr, "conv3x3_s2_forward", lambda x, w: conv_nhwc(x, w, 2))
     monkeypatch.setattr(tr, "_conv3x3", conv3x3)
     monkeypatch.setattr(tb, "stem_forward", lambda img, w, dtype: _to_nhwc(F.conv2d(img, w, None, stride=2, padding=1)).to(dtype))
+
+
+@pytest.fixture
+def repvit_kernels(cpu_kernels, monkeypatch):  # noqa: F811
+    install_repvit_kernels(monkeypatch)
 
 
 def _rand_params(shapes, seed):

@@ -25,8 +25,7 @@ def _attn_core(qkv, bias, heads, scale):
     return (s.softmax(dim=-1) @ v).transpose(1, 2).reshape(nw, n, heads * 32), torch.logsumexp(s, dim=-1)
 
 
-@pytest.fixture
-def tinyvit_kernels(repvit_kernels, monkeypatch):  # noqa: F811
+def install_tinyvit_kernels(monkeypatch):  # noqa: F811
     def ln_fwd(x, gamma, beta, eps=1e-5):
         mean, var = x.mean(-1, keepdim=True), x.var(-1, unbiased=False, keepdim=True)
         rstd = 1.0 / torch.sqrt(var + eps)
@@ -54,6 +53,11 @@ def tinyvit_kernels(repvit_kernels, monkeypatch):  # noqa: F811
     monkeypatch.setattr(tt, "win_attn_forward", _attn_core)
     monkeypatch.setattr(tt, "win_attn_backward", attn_bwd)
     monkeypatch.setattr(tt, "attn_bias_grad", bias_grad)
+
+
+@pytest.fixture
+def tinyvit_kernels(repvit_kernels, monkeypatch):  # noqa: F811
+    install_tinyvit_kernels(monkeypatch)
 
 
 def _ln(x, w, b):
