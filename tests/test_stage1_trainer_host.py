@@ -162,3 +162,84 @@ def test_trainer_host_logic_vs_the_reference_run(host_trainer, model, family, na
     loss2, norm2 = float(out["loss"]), float(out["grad_norm"])
     assert abs(loss2 - ref["losses"][1]) <= 1e-3 * abs(ref["losses"][1]), (loss2, ref["losses"][1])
     assert abs(norm2 - ref["grad_norms"][1]) <= 1e-2 * ref["grad_norms"][1], (norm2, ref["grad_norms"][1])
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE + "/sam3"), reason="the reference tree is only present in the build container")
+def test_trainer_gradient_accumulation_vs_the_reference_loop(host_trainer):
+    """ACCUMULATION_STEPS = 2 (train_image_encoder_stage1.py:186-219): two micro-batches, each loss / 2, gradients accumulated, ONE clip + AdamW
+    step + zero_grad after the second -- ``step(update_grad=False)`` then ``step()`` -- against that loop written out with the real RepViT module,
+    the head of ``ImageStudentEncoder`` (stage1/model.py:193-211), the oracle's loss functions and torch.optim.AdamW in the two groups of
+    ``set_weight_decay`` (stage1/optimizer.py:32-46); then a second accumulation cycle (the arena was zeroed, the BatchNorm buffers moved on)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for pth in (os.path.join(root, "oracle", "shims"), REFERENCE + "/sam3"):
+        if pth not in sys.path:
+            sys.path.insert(0, pth)
+    from sam3.backbones import repvit as ref_repvit
+    E, S, ACC, LR, WD, CLIP, COS = 1024, 8, 2, 1e-3, 0.05, 5.0, 0.5
+    sd = schema.synthetic_state_dict("repvit", "m0.9", seed=2)
+    sd = {k[len(PREFIX):]: v.clone().float() for k, v in sd.items() if k.startswith(PREFIX)}
+
+    class Student(torch.nn.Module):            # ImageStudentEncoder (stage1/model.py:188-211) over RepViTAdapter (:287-296)
+        def __init__(self):
+            super().__init__()
+            self.backbone = torch.nn.Module()
+            self.backbone.model = ref_repvit.repvit_m0_9(pretrained=False, num_classes=0, distillation=False)
+            self.head = torch.nn.Sequential(torch.nn.Conv2d(384, E, 1, bias=False), torch.nn.BatchNorm2d(E), torch.nn.GELU(), torch.nn.Conv2d(E, E, 3, padding=1))
+
+        def forward(self, x):
+            for layer in self.backbone.model.features:
+                x = layer(x)
+            return F.interpolate(self.head(x), size=(S, S), mode="bilinear", align_corners=False)
+
+    net = Student()
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    decay, no_decay = [], []
+    for n, p in net.named_parameters():
+        (no_decay if p.dim() == 1 or n.endswith(".bias") else decay).append(p)
+    opt = torch.optim.AdamW([{"params": decay}, {"params": no_decay, "weight_decay": 0.0}], lr=LR, weight_decay=WD, betas=(0.9, 0.999), eps=1e-8)
+    tr = stage1_train.Stage1Trainer({k: v.clone() for k, v in sd.items()}, "repvit_m0_9", embed_size=S, dtype="f32", device="cpu", lr=LR, weight_decay=WD,
+                                    clip_grad=CLIP, amp=False, cosine_weight=COS, accumulation_steps=ACC)
+    g = torch.Generator().manual_seed(31)
+    sizes = [(128, 96), (100, 96)]
+    for cycle in range(2):
+        norms = []
+        for micro in range(ACC):
+            imgs = torch.randn(2, 3, 128, 128, generator=g)
+            for i, (h, w) in enumerate(sizes):                 # the dataset pads below / right of the resized image with zeros
+                imgs[i, :, h:, :] = 0
+                imgs[i, :, :, w:] = 0
+            teacher = torch.randn(2, E, S, S, generator=g) * 0.5
+            preds = net(imgs)
+            valid = ref_stage1.build_valid_mask(128, sizes, (S, S))
+            loss = (ref_stage1.masked_mse(preds, teacher, valid) + COS * ref_stage1.masked_cosine_loss(preds, teacher, valid)) / ACC
+            loss.backward()
+            out = tr.step(imgs, teacher.permute(0, 2, 3, 1).contiguous(), sizes, update_grad=(micro == ACC - 1))
+            assert abs(float(out["loss"]) - float(loss)) <= 2e-5 * abs(float(loss)), (cycle, micro, float(out["loss"]), float(loss))
+            norms.append(out["grad_norm"])
+        ref_norm = float(torch.nn.utils.clip_grad_norm_(net.parameters(), CLIP))
+        ref_grads = {n: p.grad.clone() for n, p in net.named_parameters()}
+        opt.step()
+        opt.zero_grad()
+        assert norms[0] is None and abs(float(norms[1]) - ref_norm) <= 2e-3 * ref_norm, (cycle, norms, ref_norm)
+        state = tr.state_dict()
+        named = dict(net.named_parameters())
+        worst = max(float((state[n] - p.detach()).abs().max()) for n, p in named.items())
+        assert worst <= (2.1 if cycle == 0 else 4.2) * LR, (cycle, worst)       # AdamW's first steps move by about lr: a sign flip of a noise-level gradient is 2 lr
+        # elements whose gradient is rounding noise (a shift in front of a BatchNorm has none at all) get a noise sign from AdamW in the reference
+        # too: compare where the gradient is confidently non-zero, as the GPU test does
+        gmax = max(float(v.abs().max()) for v in ref_grads.values())
+        bad = conf = 0
+        for n, p in named.items():
+            mask = ref_grads[n].abs() > 1e-3 * float(ref_grads[n].abs().max()) + 1e-6 * gmax
+            conf += int(mask.sum())
+            bad += int((((state[n] - p.detach()).abs() > 2e-2 * LR) & mask).sum())
+        assert conf > 1e6 and bad <= 5e-3 * conf, (cycle, bad, conf)
+        for k, v in net.state_dict().items():
+            if k.endswith(("running_mean", "running_var")):
+                # cycle 2 runs on parameters that already differ by AdamW's noise-sign elements
+                assert float((state[k] - v).abs().max()) <= (1e-4 if cycle == 0 else 5e-3) * max(1.0, float(v.abs().max())), (cycle, k)
