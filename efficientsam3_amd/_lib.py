@@ -147,6 +147,7 @@ SIGNATURES = {
     "esam3_op_vit_rope": (_I, [_I, _P, _P, _L, _I, _I, _I, _I, _P]),
     "esam3_op_squeeze_excite": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "esam3_op_conv3x3_padded": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "esam3_op_upconv": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_conv_transpose2x2": (_I, [_I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_mbconv_fused": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_mbconv3": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

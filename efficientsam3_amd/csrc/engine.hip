@@ -54,6 +54,70 @@ const std::string SAM = "inst_interactive_predictor.model.";
 const std::string MD = SAM + "sam_mask_decoder.";
 const std::string PE = SAM + "sam_prompt_encoder.";
 
+}  // namespace
+
+// The arithmetic of Engine::compose_upconv (see there) on plain host arrays, shared with the single-operator entry esam3_op_upconv:
+// wt [cin][cm][2][2] + bt [cm] = the ConvTranspose2d (already composed with the 1x1 that follows it), w3 [co][cm][3][3] + b3 [co] = the
+// 3x3 conv -> w [class][o][tap = kh*2 + kw][ci], bias [co], corr [class][3: row edge, column edge, both][co].  fp64 accumulation.
+void esam3_compose_upconv_host(const float* wt, const float* bt, const float* w3, const float* b3, int cin, int cm, int co,
+                               std::vector<float>& w, std::vector<float>& bias, std::vector<float>& corr) {
+  w.assign((size_t)4 * co * 4 * cin, 0.f);
+  // Wt as [t][m][ci] (rows contiguous in ci)
+  std::vector<double> wtt((size_t)4 * cm * cin);
+  for (int ci = 0; ci < cin; ++ci)
+    for (int m = 0; m < cm; ++m)
+      for (int t = 0; t < 4; ++t) wtt[((size_t)t * cm + m) * cin + ci] = wt[((size_t)ci * cm + m) * 4 + t];
+  std::vector<double> acc((size_t)4 * cin);  // [kh*2+kw][ci] of one (class, o)
+  for (int cls = 0; cls < 4; ++cls) {
+    const int dy = cls >> 1, dx = cls & 1;
+    for (int o = 0; o < co; ++o) {
+      std::fill(acc.begin(), acc.end(), 0.0);
+      for (int ty = 0; ty < 3; ++ty)
+        for (int tx = 0; tx < 3; ++tx) {
+          const int ay = dy + ty - 1, ax = dx + tx - 1;  // offset of the ConvT output pixel from (2y, 2x): -1 .. 2
+          const int sy = ay < 0 ? -1 : ay >> 1, sx = ax < 0 ? -1 : ax >> 1;  // floor(a / 2)
+          const int kh = sy + 1 - dy, kw = sx + 1 - dx, par = (ay & 1) * 2 + (ax & 1);
+          double* a = &acc[(size_t)(kh * 2 + kw) * cin];
+          for (int m = 0; m < cm; ++m) {
+            const double wv = w3[(((size_t)o * cm + m) * 3 + ty) * 3 + tx];
+            const double* r = &wtt[((size_t)par * cm + m) * cin];
+            for (int ci = 0; ci < cin; ++ci) a[ci] += wv * r[ci];
+          }
+        }
+      float* dst = &w[((size_t)cls * co + o) * 4 * cin];
+      for (size_t i = 0; i < (size_t)4 * cin; ++i) dst[i] = (float)acc[i];
+    }
+  }
+  // bias shares S[ty][tx][o] and the composed bias / ring corrections
+  std::vector<double> S((size_t)9 * co, 0.0);
+  for (int o = 0; o < co; ++o)
+    for (int m = 0; m < cm; ++m)
+      for (int t = 0; t < 9; ++t) S[(size_t)t * co + o] += (double)w3[((size_t)o * cm + m) * 9 + t] * bt[m];
+  bias.resize(co);
+  corr.resize((size_t)4 * 3 * co);
+  for (int o = 0; o < co; ++o) {
+    double a = b3[o];
+    for (int t = 0; t < 9; ++t) a += S[(size_t)t * co + o];
+    bias[o] = (float)a;
+  }
+  for (int cls = 0; cls < 4; ++cls) {
+    const int iy = (cls >> 1) ? 2 : 0, ix = (cls & 1) ? 2 : 0;  // the 3x3 tap row / column that falls outside at that edge
+    for (int o = 0; o < co; ++o) {
+      double r = 0.0, c = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        r += S[(size_t)(iy * 3 + k) * co + o];
+        c += S[(size_t)(k * 3 + ix) * co + o];
+      }
+      const double both = r + c - S[(size_t)(iy * 3 + ix) * co + o];
+      corr[((size_t)cls * 3 + 0) * co + o] = (float)-r;
+      corr[((size_t)cls * 3 + 1) * co + o] = (float)-c;
+      corr[((size_t)cls * 3 + 2) * co + o] = (float)-both;
+    }
+  }
+}
+
+namespace {
+
 struct HostTensor {
   std::vector<float> d;
   std::vector<int64_t> shape;
@@ -391,59 +455,7 @@ struct esam3_engine {
     const int cin = (int)wt->shape[0], cm = (int)wt->shape[1], co = (int)w3->shape[0];
     if ((int)w3->shape[1] != cm || (int)w3->shape[2] != 3) { esam3_set_error("compose_upconv %s: unexpected shape", c3prefix.c_str()); return false; }
     cin_out = cin; co_out = co;
-    w.assign((size_t)4 * co * 4 * cin, 0.f);
-    // Wt as [t][m][ci] (rows contiguous in ci)
-    std::vector<double> wtt((size_t)4 * cm * cin);
-    for (int ci = 0; ci < cin; ++ci)
-      for (int m = 0; m < cm; ++m)
-        for (int t = 0; t < 4; ++t) wtt[((size_t)t * cm + m) * cin + ci] = wt->d[((size_t)ci * cm + m) * 4 + t];
-    std::vector<double> acc((size_t)4 * cin);  // [kh*2+kw][ci] of one (class, o)
-    for (int cls = 0; cls < 4; ++cls) {
-      const int dy = cls >> 1, dx = cls & 1;
-      for (int o = 0; o < co; ++o) {
-        std::fill(acc.begin(), acc.end(), 0.0);
-        for (int ty = 0; ty < 3; ++ty)
-          for (int tx = 0; tx < 3; ++tx) {
-            const int ay = dy + ty - 1, ax = dx + tx - 1;  // offset of the ConvT output pixel from (2y, 2x): -1 .. 2
-            const int sy = ay < 0 ? -1 : ay >> 1, sx = ax < 0 ? -1 : ax >> 1;  // floor(a / 2)
-            const int kh = sy + 1 - dy, kw = sx + 1 - dx, par = (ay & 1) * 2 + (ax & 1);
-            double* a = &acc[(size_t)(kh * 2 + kw) * cin];
-            for (int m = 0; m < cm; ++m) {
-              const double wv = w3->d[(((size_t)o * cm + m) * 3 + ty) * 3 + tx];
-              const double* r = &wtt[((size_t)par * cm + m) * cin];
-              for (int ci = 0; ci < cin; ++ci) a[ci] += wv * r[ci];
-            }
-          }
-        float* dst = &w[((size_t)cls * co + o) * 4 * cin];
-        for (size_t i = 0; i < (size_t)4 * cin; ++i) dst[i] = (float)acc[i];
-      }
-    }
-    // bias shares S[ty][tx][o] and the composed bias / ring corrections
-    std::vector<double> S((size_t)9 * co, 0.0);
-    for (int o = 0; o < co; ++o)
-      for (int m = 0; m < cm; ++m)
-        for (int t = 0; t < 9; ++t) S[(size_t)t * co + o] += (double)w3->d[((size_t)o * cm + m) * 9 + t] * bt->d[m];
-    bias.resize(co);
-    corr.resize((size_t)4 * 3 * co);
-    for (int o = 0; o < co; ++o) {
-      double a = b3->d[o];
-      for (int t = 0; t < 9; ++t) a += S[(size_t)t * co + o];
-      bias[o] = (float)a;
-    }
-    for (int cls = 0; cls < 4; ++cls) {
-      const int iy = (cls >> 1) ? 2 : 0, ix = (cls & 1) ? 2 : 0;  // the 3x3 tap row / column that falls outside at that edge
-      for (int o = 0; o < co; ++o) {
-        double r = 0.0, c = 0.0;
-        for (int k = 0; k < 3; ++k) {
-          r += S[(size_t)(iy * 3 + k) * co + o];
-          c += S[(size_t)(k * 3 + ix) * co + o];
-        }
-        const double both = r + c - S[(size_t)(iy * 3 + ix) * co + o];
-        corr[((size_t)cls * 3 + 0) * co + o] = (float)-r;
-        corr[((size_t)cls * 3 + 1) * co + o] = (float)-c;
-        corr[((size_t)cls * 3 + 2) * co + o] = (float)-both;
-      }
-    }
+    esam3_compose_upconv_host(wt->d.data(), bt->d.data(), w3->d.data(), b3->d.data(), cin, cm, co, w, bias, corr);
     return true;
   }
   // Packed for gemm256p's up-conv gather: N = class * Cout + o, K = (ci / 64) * 256 + (kh * 2 + kw) * 64 + ci % 64.
@@ -463,7 +475,7 @@ struct esam3_engine {
       float* row = &pk[(size_t)n * g.Kp];
       const float* src = &w[(size_t)n * 4 * cin];
       for (int tap = 0; tap < 4; ++tap)
-        for (int ci = 0; ci < cin; ++ci) row[(size_t)(ci / 64) * 256 + tap * 64 + ci % 64] = src[(size_t)tap * cin + ci];
+        for (int ci = 0; ci < cin; ++ci) row[esam3_upconv_kindex(tap, ci)] = src[(size_t)tap * cin + ci];
     }
     g.w = upload_T(pk);
     g.bias = (float*)dev_upload(bias.data(), bias.size() * 4);

@@ -1,6 +1,8 @@
 // Host-callable launchers of the non-GEMM kernels (definitions in *.hip).
 // dtype: 0 = f32 activations, 1 = bf16 activations.  All tensors NHWC / row-major.
 #pragma once
+#include <vector>
+
 #include "esam3_common.h"
 
 int esam3_gemm_pad_n(int N);
@@ -53,6 +55,11 @@ int64_t esam3_conv3x3_narrow_windex(int N, int n, int tap, int c);
 int esam3_launch_conv3x3_narrow(const GemmParams& p, hipStream_t stream);
 // up-conv (ConvT k2s2 composed with the 3x3 + 1x1 that follow) with 32 output channels per parity class, same file:
 // eligibility, weight index of (n, class, tap kh*2+kw, c) in the staged order, launcher (p.convt_cout = 32, p.H / p.W = input size)
+// Up-conv composition (engine.hip): ConvT k2s2 (+ its 1x1) followed by a 3x3 conv as four 2x2 convs on the ConvT's input, on host arrays;
+// and the K position of (tap = kh*2 + kw, input channel ci) in a packed row of gemm256p's up-conv gather (64-channel chunk major).
+void esam3_compose_upconv_host(const float* wt, const float* bt, const float* w3, const float* b3, int cin, int cm, int co,
+                               std::vector<float>& w, std::vector<float>& bias, std::vector<float>& corr);
+inline int64_t esam3_upconv_kindex(int tap, int ci) { return (int64_t)(ci / 64) * 256 + tap * 64 + ci % 64; }
 bool esam3_upconv_narrow_ok(int dtype, int Cout, int Cin, int H, int W);
 int64_t esam3_upconv_narrow_windex(int n, int cls, int tap, int c);
 int esam3_launch_upconv_narrow(const GemmParams& p, hipStream_t stream);

@@ -492,6 +492,14 @@ int esam3_op_vit_rope(int dtype, void* qkv_dev, const float* cos_sin_host, int64
 int esam3_op_squeeze_excite(int dtype, void* x_dev, const float* w1_host, const float* b1_host,
                             const float* w2_host, const float* b2_host, int B, int HW, int C, int R,
                             void* hip_stream);
+/* the composed "up-conv" of neck level 0 (necks.py:74-98: dconv_2x2_1 -> conv_1x1 -> conv_3x3 [-> conv_s0 of mask_decoder.py]), bf16:
+ * ConvTranspose2d k2 s2 (wt_host [Cin][Cmid][2][2] + bt_host [Cmid], the 1x1 already folded in by the caller) followed by a 3x3 / pad 1
+ * conv (w3_host [Cout][Cmid][3][3] + b3_host [Cout]) as four 2x2 convs on the ConvT's INPUT, one per parity class of the output pixel;
+ * the same host composition, packing and kernels as the engine's level-0 launches.  xpad_dev: [B][H+2][W+2][Cin] with a zero border,
+ * out_dev: [B][2H][2W][Cout].  narrow = 0: gemm256p's up-conv gather (the dominant launch; Cout % 256 == 0, Cin % 64 == 0, H, W % 16 == 0),
+ * narrow = 1: upconv_narrow_kernel (Cout == 32: the SAM2-side level 0). */
+int esam3_op_upconv(const void* xpad_dev, const float* wt_host, const float* bt_host, const float* w3_host, const float* b3_host,
+                    void* out_dev, int B, int H, int W, int Cin, int Cmid, int Cout, int narrow, void* hip_stream);
 /* ConvTranspose2d k2 s2, NHWC; w_host is the PyTorch [Cin][Cout][2][2] fp32 weight */
 int esam3_op_conv_transpose2x2(int dtype, const void* x_dev, const float* w_host,
                                const float* bias_host, const void* res_dev, void* out_dev, int B,

@@ -286,3 +286,88 @@ def test_rowlin256_exact_on_the_lattice(rows, P):
     out = torch.full((rows, 256), float("nan"), dtype=torch.bfloat16, device="cuda")
     U.check(U.lib().esam3_op_rowlin256(U.P(x_d), U.H(U.np32(w)), U.H(U.np32(b)), U.H(U.np32(tb)), P, U.P(out), rows, None), "op_rowlin256")
     assert torch.equal(out.float().cpu(), ref.float())
+
+
+# ---- neck level 0: the composed up-conv (the dominant launch of the headline step and its SAM2-side narrow twin) ---------------------------
+def upconv_lattice(B, H, W, Cin, C1, Cmid, Cout, nnz3, seed=0):
+    """necks.py:74-98 level 0 behind the GELU: dconv_2x2_1 (ConvTranspose2d k2 s2, Cin -> C1) -> conv_1x1 (C1 -> Cmid) -> conv_3x3
+    (Cmid -> Cout, pad 1) on integers.  Returns the layer weights, the ConvT with the 1x1 folded in (what the operator entry takes; integer
+    arithmetic, exact) and the fp64 result of running the three layers one after the other."""
+    x = _ints(B, Cin, H, W, lo=-2, hi=2, seed=seed + 1)
+    wt_raw = _sparse_pm1(C1 * 4, Cin, 2, seed=seed + 2).reshape(C1, 4, Cin).permute(2, 0, 1).reshape(Cin, C1, 2, 2).contiguous()
+    bt_raw = _ints(C1, lo=-1, hi=1, seed=seed + 3)
+    w1 = _sparse_pm1(Cmid, C1, 2, seed=seed + 4)
+    b1 = _ints(Cmid, lo=-1, hi=1, seed=seed + 5)
+    w3 = _sparse_pm1(Cout, Cmid * 9, nnz3, seed=seed + 6).reshape(Cout, Cmid, 3, 3).contiguous()
+    b3 = _ints(Cout, lo=-2, hi=2, seed=seed + 7)
+    mid = F.conv_transpose2d(x.double(), wt_raw.double(), bt_raw.double(), stride=2)
+    mid = F.conv2d(mid, w1.double()[:, :, None, None], b1.double())
+    ref = F.conv2d(mid, w3.double(), b3.double(), padding=1)
+    assert float(ref.abs().max()) < 2 ** 15 and float(ref.abs().max()) > 8  # fp32 sums of integers: exact in any order
+    # ConvT o 1x1 (engine.hip: compose_convT_1x1): wt[ci][m][t] = sum_c raw[ci][c][t] * w1[m][c], bt = w1 bt_raw + b1
+    wt = torch.einsum("ictu,mc->imtu", wt_raw.double(), w1.double()).contiguous()
+    bt = w1.double() @ bt_raw.double() + b1.double()
+    assert _bf16_exact(wt)
+    return x, wt.float(), bt.float(), w3, b3, ref
+
+
+def _run_upconv(x, wt, bt, w3, b3, Cout, narrow):
+    B, Cin, H, W = x.shape
+    xp = F.pad(x, (1, 1, 1, 1)).permute(0, 2, 3, 1).contiguous().to("cuda", torch.bfloat16)  # [B][H+2][W+2][Cin], zero border
+    out = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    U.check(U.lib().esam3_op_upconv(U.P(xp), U.H(U.np32(wt)), U.H(U.np32(bt)), U.H(U.np32(w3)), U.H(U.np32(b3)), U.P(out),
+                                    B, H, W, Cin, wt.shape[1], Cout, int(narrow), None), "op_upconv")
+    return U.from_dev_nhwc(out)
+
+
+def _assert_upconv_exact(got, ref, what):
+    exp = ref.to(torch.bfloat16).float()  # the accumulators hold the exact integer: ONE rounding, on the store
+    bad = got != exp
+    if bad.any():
+        i = tuple(bad.nonzero()[0].tolist())
+        H2, W2 = ref.shape[-2:]
+        ring = bad[..., 0, :].sum() + bad[..., H2 - 1, :].sum() + bad[..., :, 0].sum() + bad[..., :, W2 - 1].sum()
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} elements differ on exact data ({int(ring)} of them on the ring of the "
+                             f"output image); first at (b, c, y, x) = {i}: got {float(got[i])!r}, expected {float(exp[i])!r}")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,C1,Cmid,Cout", [
+    (3, 16, 16, 64, 64, 64, 256),       # one pixel tile per image: every pixel tile is an edge tile in both directions
+    (2, 32, 48, 128, 64, 128, 256),     # B > 1, H != W, interior + edge tiles
+    (1, 48, 32, 192, 128, 64, 512),     # two N tiles per parity class (class = n0 / Cout), 3 channel chunks
+    (1, 144, 144, 512, 256, 256, 256),  # the real shape of the dominant launch (one image of the headline batch)
+    (5, 64, 64, 64, 64, 64, 256),       # 80 pixel tiles x 4 classes > 256 workgroups: the persistent loop hands tiles over
+])
+def test_upconv_gather_exact_on_the_lattice(B, H, W, Cin, C1, Cmid, Cout):
+    """gemm256p's up-conv gather (ksize 2): the four parity classes x 2x2 taps of the composed weight, the class shift of the gather on
+    the zero-bordered input, the channel-chunk-major K order, the ConvT pixel-shuffle store with tap = class and the ring-pixel bias
+    correction -- all of it bit for bit against ConvT -> 1x1 -> 3x3 run layer by layer in fp64"""
+    x, wt, bt, w3, b3, ref = upconv_lattice(B, H, W, Cin, C1, Cmid, Cout, nnz3=9)
+    got = _run_upconv(x, wt, bt, w3, b3, Cout, narrow=False)
+    _assert_upconv_exact(got, ref, "upconv_gather")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,C1,Cmid", [
+    (3, 16, 16, 64, 64, 64), (2, 32, 48, 128, 64, 128), (1, 48, 32, 48, 32, 64), (1, 144, 144, 512, 256, 256), (9, 96, 96, 32, 32, 32),
+])
+def test_upconv_narrow_exact_on_the_lattice(B, H, W, Cin, C1, Cmid):
+    """upconv_narrow_kernel (32 output channels per parity class = conv_3x3 o conv_s0 of the SAM2 side, mask_decoder.py): the 18x18
+    halo per 16-channel chunk, the 16 (halo shift, class) pairs, the four accumulator sets and the 2x2 output block store.  w3 here
+    stands for the composed 3x3 o conv_s0 (the same integer lattice; its folding is test_unfused_layer_list_matches_golden's business)"""
+    x, wt, bt, w3, b3, ref = upconv_lattice(B, H, W, Cin, C1, Cmid, 32, nnz3=24, seed=100)
+    got = _run_upconv(x, wt, bt, w3, b3, 32, narrow=True)
+    _assert_upconv_exact(got, ref, "upconv_narrow")
+
+
+def test_upconv_gather_bias_only_ring():
+    """zero input: the output is the composed bias, and on the ring of the output image the shares of the 3x3 taps that fall outside
+    are taken back (GemmParams::border_corr) -- corners included, per parity class"""
+    B, H, W, Cin, C1, Cmid, Cout = 1, 32, 32, 64, 64, 64, 256
+    x, wt, bt, w3, b3, _ = upconv_lattice(B, H, W, Cin, C1, Cmid, Cout, nnz3=9, seed=7)
+    x = torch.zeros_like(x)
+    bt = _ints(Cmid, lo=-3, hi=3, seed=11)
+    mid = bt.double()[None, :, None, None].expand(B, Cmid, 2 * H, 2 * W)
+    ref = F.conv2d(mid, w3.double(), b3.double(), padding=1)
+    assert not torch.equal(ref[..., 0, :], ref[..., 1, :])  # the ring differs from the interior: the correction is exercised
+    got = _run_upconv(x, wt, bt, w3, b3, Cout, narrow=False)
+    _assert_upconv_exact(got, ref, "upconv_gather bias ring")

@@ -35,7 +35,7 @@ for name, B, H, W, Cin, N, ks, ct in SHAPES:
     if only and not any(o in name for o in only.split(',')):
         continue
     ms = C.c_float()
-    rc = lib.esam3_bench_gemm(1, B, H, W, Cin, N, ks, ct, 10, C.byref(ms))
+    rc = lib.esam3_bench_gemm(1, B, H, W, Cin, N, ks, ct, int(os.environ.get("ESAM3_BENCH_ITERS", "10")), C.byref(ms))
     fl = 2.0 * B * H * W * N * Cin * ks * ks
     print(f"{name:34s} rc={rc} {ms.value:8.3f} ms  {fl / ms.value / 1e9:8.1f} TF/s", flush=True)
     if hasattr(lib, "esam3_dev_read_trace"):  # trace build: cycle stamps of the last launch (workgroups 0-7, waves 0 / 4)
