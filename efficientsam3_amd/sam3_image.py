@@ -54,7 +54,6 @@ def _nchw_view(t_nhwc: torch.Tensor) -> torch.Tensor:
 
 
 _WIDEN_POOL = None
-D2H_CHUNKS = 1   # pieces of the device-to-host mask copy (an event behind each; the host widens piece k while piece k + 1 is in flight).  Measured on the MI355X box (tools/api_ab.py, profiles/r05/api_ab.txt): 4 pieces cost 1.6 ms MORE per 32 masks than one copy + one wait (event wake-ups and four pool dispatches outweigh 0.7 ms of copy), so the default is 1
 
 
 def _widen_into(dst: np.ndarray, src: np.ndarray, parts: int = 16, serial_below: int = 1 << 22) -> None:
@@ -81,6 +80,21 @@ def _widen_into(dst: np.ndarray, src: np.ndarray, parts: int = 16, serial_below:
         list(_widen_pool().map(lambda i: native(i * step, min(n, (i + 1) * step)), range(parts)))
         return
     list(_widen_pool().map(lambda i: np.copyto(d[i * step:(i + 1) * step], s_[i * step:(i + 1) * step], casting="unsafe"), range(parts)))
+
+
+def _pool_get(pool: list, make):
+    """One result buffer (tensor, its ndarray) out of `pool`: a buffer that was handed out before comes back ONLY if no view of its
+    ndarray is alive outside the pool (the tuple's slot + getrefcount's argument = 2); otherwise `make()` builds a new one.  At most
+    three are kept per shape: an `out = step()` loop needs two, a consumer one step behind three."""
+    for cand in pool:
+        if sys.getrefcount(cand[1]) <= 2:
+            return cand
+    t = make()
+    ent = (t, t.numpy())                         # views handed to the caller keep the ndarray (their base) alive
+    pool.append(ent)
+    if len(pool) > 3:
+        pool.pop(0)
+    return ent
 
 
 def _widen_pool():
@@ -393,61 +407,58 @@ class Sam3Image:
         masks_np = masks.squeeze(0).float().cpu().numpy()
         return masks_np, iou.squeeze(0).cpu().numpy(), low.squeeze(0).cpu().numpy()
 
-    def _masks_to_host(self, masks: torch.Tensor) -> np.ndarray:
-        """Device masks of one size group -> the float32 numpy array the reference's contract returns
-        (sam1_task_predictor.py:293-295).  Thresholded masks leave the device as the uint8 they are (a quarter of the
-        bytes) through a pinned, reused host buffer and are widened to float32 on the host by torch's multi-threaded copy;
-        logits (return_logits) are float32 on the device already and take the pinned route too."""
-        if not masks.is_cuda:  # an engine double on the host (tests): nothing to stage
-            return masks.float().numpy()
-        key = (tuple(masks.shape), masks.dtype)
-        pin = self._host_stage.get(key)
-        if pin is None:
-            if len(self._host_stage) >= 4:
-                self._host_stage.clear()
-            pin = self._host_stage[key] = torch.empty(masks.shape, dtype=masks.dtype).pin_memory()
-        # The device-to-host copy runs in D2H_CHUNKS pieces on a side stream, an event behind each: the host widens piece k into the
-        # result array while piece k + 1 is still on the wire (round 5: one copy, one wait, then 3.6 ms of widening with the device and
-        # the link idle before).
-        n0 = masks.shape[0]
-        nch = D2H_CHUNKS if (masks.dim() >= 2 and n0 >= 2 * D2H_CHUNKS and masks.is_contiguous()) else 1
-        bounds = [(n0 * k // nch, n0 * (k + 1) // nch) for k in range(nch)]
-        cur = torch.cuda.current_stream(masks.device)
+    def _d2h_begin(self, t: torch.Tensor, slot: int = 0):
+        """Start the device-to-host hand-back of one result tensor on the copy stream and return a handle for _d2h_end.
+
+        uint8 (thresholded masks; the reference's contract returns them as float32, sam1_task_predictor.py:293-295): the bytes leave
+        the device as they are (a quarter of the float32 size) into a pinned staging buffer and are widened on the host in _d2h_end.
+        float32 (mask logits, low-res logits): copied straight into a PINNED result buffer whose numpy view is what the caller gets --
+        no host-side copy at all (round 5 staged them and copied again).  Result buffers come from _pool_get: reused only when
+        nothing outside this object references them."""
+        if not t.is_cuda:  # an engine double on the host (tests): nothing to stage
+            return (None, None, t.float().numpy(), None)
+        t = t.contiguous()
+        widen = t.dtype != torch.float32
+        key = (tuple(t.shape), t.dtype)
+        pin = None
+        if widen:   # `slot`: hand-backs in flight at the same time never share a staging buffer
+            pin = self._host_stage.get(key + (slot,))
+            if pin is None:
+                if len(self._host_stage) >= 6:
+                    self._host_stage.clear()
+                pin = self._host_stage[key + (slot,)] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+        # The result array is the caller's (the reference returns fresh arrays), but 134 MB of never-touched pages cost ~30 ms of page
+        # faults per call: a previous result buffer of this shape is handed out again ONLY if nothing outside this object references
+        # it any more (a caller that kept its arrays keeps them untouched).
+        ent = _pool_get(self._host_out.setdefault(key, []),
+                        lambda: torch.empty(t.shape, dtype=torch.float32, pin_memory=not widen))
+        cur = torch.cuda.current_stream(t.device)
         if self._copy_stream is None:
-            self._copy_stream = torch.cuda.Stream(device=masks.device)
+            self._copy_stream = torch.cuda.Stream(device=t.device)
         self._copy_stream.wait_stream(cur)
-        events = []
         with torch.cuda.stream(self._copy_stream):
-            for a, e in bounds:
-                pin[a:e].copy_(masks[a:e], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(self._copy_stream)
-                events.append(ev)
-        # The result array is the caller's (the reference returns fresh arrays), but 134 MB of never-touched pages cost
-        # ~30 ms of page faults per call: the previous result tensor of this shape is handed out again ONLY if nothing
-        # outside this object references it any more (a caller that kept its arrays keeps them untouched).
-        pool = self._host_out.setdefault(key, [])
-        ent = None
-        for cand in pool:                                # a buffer nobody outside this object references any more
-            if sys.getrefcount(cand[1]) <= 2:            # the tuple's slot + getrefcount's argument: no view of it is alive
-                ent = cand
-                break
-        if ent is None:
-            t = torch.empty(masks.shape, dtype=torch.float32)
-            ent = (t, t.numpy())                         # views handed to the caller keep the ndarray (their base) alive
-            pool.append(ent)
-            if len(pool) > 3:                            # `out = step()` loops need two, a consumer one step behind three
-                pool.pop(0)
-        # uint8 -> float32 (or float32 -> float32) on a few worker threads.  NOT torch's copy_: its OpenMP team (128 threads on the
-        # GPU host) keeps spinning after the copy, and the NEXT wait on the device -- the small synchronous prompt upload of the
-        # following call -- then returned 50-70 ms late in about every third step (tools/api_stall_probe.py,
-        # profiles/r04/api_stall_probe.txt: 17 ms steps with 65-80 ms outliers; the device itself was idle).
-        pin_np = pin.numpy()
-        for (a, e), ev in zip(bounds, events):
-            ev.synchronize()
-            _widen_into(ent[1][a:e], pin_np[a:e])
-        cur.wait_stream(self._copy_stream)      # `masks` may be freed / reused by the caller's stream only after the copies
-        return ent[1]
+            (pin if widen else ent[0]).copy_(t, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._copy_stream)
+        return (ev, pin, ent[1], t)
+
+    def _d2h_end(self, handle) -> np.ndarray:
+        """Wait for one hand-back started by _d2h_begin; uint8 masks are widened to float32 here, on a few worker threads.  NOT torch's
+        copy_: its OpenMP team (128 threads on the GPU host) keeps spinning after the copy, and the NEXT wait on the device then returned
+        50-70 ms late in about every third step (tools/api_stall_probe.py, profiles/r04/api_stall_probe.txt)."""
+        ev, pin, out, src = handle
+        if ev is None:
+            return out
+        ev.synchronize()
+        if pin is not None:
+            _widen_into(out, pin.numpy())
+        # `src` may be freed / reused by the caller's stream only after the copy has run
+        torch.cuda.current_stream(src.device).wait_stream(self._copy_stream)
+        return out
+
+    def _masks_to_host(self, masks: torch.Tensor) -> np.ndarray:
+        """Device masks of one size group -> the float32 numpy array the reference's contract returns, start to finish."""
+        return self._d2h_end(self._d2h_begin(masks))
 
     def predict_inst_batch(self, inference_state, point_coords_batch=None, point_labels_batch=None,
                            box_batch=None, mask_input_batch=None, multimask_output: bool = True,
@@ -488,15 +499,23 @@ class Sam3Image:
                 by_size.setdefault((hs[i], ws[i]), []).append(j)
             low_g = low.view(len(idxs), bpi, *low.shape[1:])
             iou_g = iou.view(len(idxs), bpi, -1)
+            # Every hand-back is STARTED before any of them is waited for (round 5 widened the masks on the host before the clamp and
+            # the low-res copy were even launched: 1.1 ms of idle device per step, profiles/r06/api_timeline_before.txt): the masks of
+            # each size group, then the clamped low-res logits and the scores travel on the copy stream while the host widens.
+            pending = []
             for (h, w), js in by_size.items():
                 sel = low_g[js] if len(js) != len(idxs) else low_g
-                m = self._masks_to_host(self.engine.postprocess(sel.contiguous(), (h, w), return_logits))
+                pending.append((js, self._d2h_begin(self.engine.postprocess(sel.contiguous(), (h, w), return_logits), slot=len(pending))))
+            self.engine.clamp_(low, -32.0, 32.0)
+            big = low_g.is_cuda and low_g.numel() >= (1 << 20)   # 10 MB at 32 prompts: a pageable copy of that size costs 1-2 ms
+            low_h = self._d2h_begin(low_g) if big else None
+            iou_h = self._d2h_begin(iou_g) if big else None
+            for js, hnd in pending:
+                m = self._d2h_end(hnd)
                 for k, j in enumerate(js):
                     masks_out[idxs[j]] = m[k].squeeze(0) if bpi == 1 else m[k]
-            self.engine.clamp_(low, -32.0, 32.0)
-            # the low-res logits (10 MB at 32 prompts) take the pinned route too: a pageable D2H copy of that size costs 1-2 ms
-            low_np = self._masks_to_host(low_g) if low_g.is_cuda and low_g.numel() >= (1 << 20) else low_g.cpu().numpy()
-            iou_np = iou_g.cpu().numpy()
+            low_np = self._d2h_end(low_h) if big else low_g.cpu().numpy()
+            iou_np = self._d2h_end(iou_h) if big else iou_g.cpu().numpy()
             for j, i in enumerate(idxs):
                 low_out[i] = low_np[j].squeeze(0) if bpi == 1 else low_np[j]
                 iou_out[i] = iou_np[j].squeeze(0) if bpi == 1 else iou_np[j]

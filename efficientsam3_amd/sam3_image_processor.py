@@ -35,6 +35,7 @@ class Sam3Processor:
         self.first_chunk_fraction = 0.25   # share of a batch in the first of the two pipelined encode chunks (set_image_batch)
         self._stage_busy = {}  # staging buffer key -> event recorded after the last H2D copy out of it
         self._h2d_stream = None  # side stream of the staged host-to-device copies (_stage_to_device)
+        self._sender = None      # one helper thread that stages and sends the later chunks of a batch (_send_later)
 
     @staticmethod
     def _rgbx_view(im):
@@ -123,18 +124,19 @@ class Sam3Processor:
                 t = t.to(torch.uint8)
         return t.contiguous(), int(height), int(width)
 
-    def _stage_to_device(self, images, slot: int = 0) -> torch.Tensor:
+    def _stage_to_device(self, images, slot: int = 0, wait: bool = True):
         """staged PIL batch -> device (asynchronous copy); an event guards the pinned buffer until the copy has run.  Images that
-        the device will resize anyway travel as Pillow's 4-byte pixels where possible (see _rgbx_view)."""
+        the device will resize anyway travel as Pillow's 4-byte pixels where possible (see _rgbx_view).  ``wait=False`` (the helper
+        thread of set_image_batch): returns (device tensor, event) and leaves the ordering against the compute stream to the caller."""
         b, (w, h) = len(images), images[0].size
         rgbx = (h, w) != (self.resolution, self.resolution) and hasattr(self.model.engine, "preprocess_resize_u8_batch")
         host = self._stage_pil_batch(images, slot, rgbx=rgbx)
         if self.device.type != "cuda":
-            return host.to(self.device, non_blocking=True)
+            dev_t = host.to(self.device, non_blocking=True)
+            return dev_t if wait else (dev_t, None)
         # The copy goes out on a SIDE stream (round 5): issued on the compute stream it queued behind the previous chunk's encode, and
         # the device then sat idle for the 2 ms the second chunk's pixels took to arrive (tools/api_level_probe.py: 10.8 ms of device
         # tail per step against 9.6 ms for the same step with resident inputs).  The compute stream waits for the copy's event only.
-        cur = torch.cuda.current_stream(self.device)
         if self._h2d_stream is None:
             self._h2d_stream = torch.cuda.Stream(device=self.device)
         with torch.cuda.stream(self._h2d_stream):
@@ -142,9 +144,33 @@ class Sam3Processor:
             ev = torch.cuda.Event()
             ev.record(self._h2d_stream)
         self._stage_busy[(b, h, w, slot, host.shape[-1])] = ev     # the pinned buffer is refilled only after the copy has run
-        cur.wait_event(ev)
-        dev_t.record_stream(cur)                                   # allocated on the side stream, consumed on the compute stream
+        if not wait:
+            return dev_t, ev
+        return self._arrived(dev_t, ev)
+
+    def _arrived(self, dev_t: torch.Tensor, ev) -> torch.Tensor:
+        """order the compute stream of THIS thread behind a staged copy"""
+        if ev is not None:
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(ev)
+            dev_t.record_stream(cur)                               # allocated on the side stream, consumed on the compute stream
         return dev_t
+
+    def _send_later(self, images, slot: int):
+        """stage + copy a chunk on the helper thread (round 6): the pixels of chunk k + 1 are converted and put on the wire while the
+        calling thread is inside the engine call that launches chunk k's encode (a ctypes call: the GIL is free).  Round 5 did both on
+        one thread: the second chunk's copy was issued only after the first chunk's ~150 launches, and the device idled for the whole
+        transfer (profiles/r06/api_timeline_before.txt: 1.8 ms per step)."""
+        if self._sender is None:
+            self._sender = ThreadPoolExecutor(max_workers=1, thread_name_prefix="esam3-send")
+
+        def work():
+            if self.device.type == "cuda":
+                with torch.cuda.device(self.device):               # the current device is a per-thread setting
+                    return self._stage_to_device(images, slot=slot, wait=False)
+            return self._stage_to_device(images, slot=slot, wait=False)
+
+        return self._sender.submit(work)
 
     def _preprocess(self, hwc_u8_list: List[torch.Tensor]) -> torch.Tensor:
         """The reference's transform (uint8 -> Resize(1008) -> float/255 -> Normalize(.5,.5)) on
@@ -218,8 +244,16 @@ class Sam3Processor:
             # uneven chunks: the device idles until the first chunk is staged and copied (1.3 + 1.25 ms for 16 images), so the first
             # one is a quarter of the batch; the rest travels under its encode
             first = min(b - 1, max(4, int(b * self.first_chunk_fraction)))
-            for ci, (a, e) in enumerate(((0, first), (first, b))):
-                batch = self._stage_to_device(images[a:e], slot=ci)
+            bounds = ((0, first), (first, b))
+            if self._pool is None:                                 # both threads fill their staging buffers through it
+                self._pool = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1), thread_name_prefix="esam3-stage")
+            if self._h2d_stream is None and dev.type == "cuda":
+                self._h2d_stream = torch.cuda.Stream(device=dev)
+            nxt = self._send_later(images[first:b], slot=1)        # chunk 1 is staged and sent while chunk 0 is staged, sent and launched here
+            batch = self._stage_to_device(images[0:first], slot=0)
+            for ci, (a, e) in enumerate(bounds):
+                if ci:
+                    batch = self._arrived(*nxt.result())
                 if tuple(batch.shape[1:3]) == (r, r):
                     x = eng.preprocess_u8(batch)
                 else:

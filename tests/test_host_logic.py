@@ -429,27 +429,14 @@ def test_selection_tie_fixtures_and_matching_rule():
 
 
 def test_host_result_buffers_are_never_reused_while_referenced():
-    """predict_inst_batch's host result pool (sam3_image._masks_to_host): a buffer is handed out again only when no view of
-    it is alive -- ONE live view (a single-image group of a batch) protects it; an `out = step()` loop settles on two
-    buffers.  The rule is restated here on CPU tensors and the method's source is checked to carry the same threshold (the
-    method itself needs a device tensor)."""
-    import inspect
-    import sys
+    """predict_inst_batch's host result pool (sam3_image._pool_get, used by _d2h_begin for masks, low-res logits and scores): a buffer is
+    handed out again only when no view of it is alive -- ONE live view (a single-image group of a batch) protects it; an
+    `out = step()` loop settles on two buffers; at most three are kept."""
     import torch
     from efficientsam3_amd import sam3_image as S
-    assert "getrefcount(cand[1]) <= 2" in inspect.getsource(S.Sam3Image._masks_to_host)
 
     def get(pool, shape):
-        ent = None
-        for cand in pool:
-            if sys.getrefcount(cand[1]) <= 2:
-                ent = cand
-                break
-        if ent is None:
-            t = torch.empty(shape)
-            ent = (t, t.numpy())
-            pool.append(ent)
-        return ent[1]
+        return S._pool_get(pool, lambda: torch.empty(shape))[1]
 
     pool = []
     a = get(pool, (2, 3))[0]
@@ -464,6 +451,13 @@ def test_host_result_buffers_are_never_reused_while_referenced():
         out = [get(pool, (2, 3))[0]]
         seen.add(id(out[0].base))
     assert len(seen) == 2 and len(pool) <= 3
+    kept = [get(pool, (2, 3)) for _ in range(5)]     # a caller that keeps everything: fresh buffers every time, none shared
+    assert len({id(k) for k in kept}) == 5 and len(pool) <= 3
+    # the engine-double path of the hand-back (a host tensor): begin / end return the values, uint8 widened to float32
+    m = S.Sam3Image.__new__(S.Sam3Image)
+    h = m._d2h_begin(torch.tensor([[0, 1], [1, 0]], dtype=torch.uint8))
+    got = m._d2h_end(h)
+    assert got.dtype == np.float32 and got.tolist() == [[0.0, 1.0], [1.0, 0.0]]
 
 
 def test_pil_rgbx_view_is_the_image_and_staging_falls_back():
