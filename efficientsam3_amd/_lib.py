@@ -72,6 +72,7 @@ SIGNATURES = {
     "esam3_decode": (_I, [_P, C.POINTER(Prompts), C.POINTER(DecodeOut), _P]),
     "esam3_postprocess_masks": (_I, [_P, _P, _I, _I, _I, _F, _F, _P, _P, _P]),
     "esam3_clamp_f32": (_I, [_P, _P, _L, _F, _F, _P]),
+    "esam3_set_scope_hooks": (None, [_P, _P]),
     "esam3_profile_enable": (_I, [_P, _I]),
     "esam3_profile_tag": (_I, [_P, C.c_char_p]),
     "esam3_profile_report": (_I, [_P, C.c_char_p, _L]),
@@ -184,8 +185,43 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
+    _install_scope_hooks(lib)
     _lib = lib
     return lib
+
+
+_SCOPE_PUSH = C.CFUNCTYPE(None, C.c_char_p)
+_SCOPE_POP = C.CFUNCTYPE(None)
+_scope_keep = []     # the ctypes callback objects must outlive the library's pointers to them
+_scope_open = []     # record_function ranges opened by the engine's scopes, innermost last (per process: the engine is not re-entrant)
+
+
+def _install_scope_hooks(lib):
+    """The engine's phase scopes (include/esam3.h, esam3_set_scope_hooks) become torch.profiler.record_function ranges with the
+    reference's names (sam3/model/sam3_image.py:449-479) -- only while a torch profiler is recording; otherwise a callback costs a
+    flag test."""
+    try:
+        import torch
+        from torch.autograd import profiler as _prof
+    except Exception:  # noqa: BLE001  (no torch: nothing to forward to; roctx still sees the scopes)
+        return
+
+    def push(name):
+        if _prof._is_profiler_enabled:
+            rf = torch.profiler.record_function(name.decode())
+            rf.__enter__()
+            _scope_open.append(rf)
+        else:
+            _scope_open.append(None)
+
+    def pop():
+        rf = _scope_open.pop() if _scope_open else None
+        if rf is not None:
+            rf.__exit__(None, None, None)
+
+    cbs = (_SCOPE_PUSH(push), _SCOPE_POP(pop))
+    _scope_keep.extend(cbs)
+    lib.esam3_set_scope_hooks(C.cast(cbs[0], C.c_void_p), C.cast(cbs[1], C.c_void_p))
 
 
 def check(rc: int, what: str = "esam3 call"):

@@ -16,6 +16,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "../../include/esam3.h"
 #include "kernels.h"
 
@@ -55,6 +57,39 @@ const std::string MD = SAM + "sam_mask_decoder.";
 const std::string PE = SAM + "sam_prompt_encoder.";
 
 }  // namespace
+
+// ---- profiler scopes (esam3_common.h) ------------------------------------------------------------------------------------------
+namespace {
+void (*g_scope_push)(const char*) = nullptr;
+void (*g_scope_pop)(void) = nullptr;
+struct Roctx {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    if (void* h = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL)) {
+      push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+      pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+      if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+  }
+};
+Roctx& roctx() {
+  static Roctx r;
+  return r;
+}
+}  // namespace
+void esam3_scope_push(const char* name) {
+  if (g_scope_push) g_scope_push(name);
+  if (roctx().push) roctx().push(name);
+}
+void esam3_scope_pop() {
+  if (roctx().pop) roctx().pop();
+  if (g_scope_pop) g_scope_pop();
+}
+extern "C" void esam3_set_scope_hooks(void (*push)(const char*), void (*pop)(void)) {
+  g_scope_push = push;
+  g_scope_pop = pop;
+}
 
 // The arithmetic of Engine::compose_upconv (see there) on plain host arrays, shared with the single-operator entry esam3_op_upconv:
 // wt [cin][cm][2][2] + bt [cm] = the ConvTranspose2d (already composed with the 1x1 that follows it), w3 [co][cm][3][3] + b3 [co] = the
@@ -1955,6 +1990,8 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
   auto addk = [&](const void* a, const void* b, void* o, int64_t n) -> int { return dry ? 0 : esam3_launch_add(dtype, a, b, o, n, st); };
   auto LN = [&](const std::string& name, const void* x, void* o, int64_t rows) -> int { return layernorm(name, x, o, rows, DM, 1e-5f); };
 
+  ScopeSeq scope;
+  if (!dry) scope.next("SAM3Image._encode_prompt");
   // ---- prompt = [text tokens ; geometry tokens] ------------------------------------------------------
   void* prompt = allocb((size_t)B * Sp * DM * esz);
   uint8_t* pmask = (uint8_t*)allocb((size_t)B * Sp);
@@ -2039,6 +2076,7 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
     if (!dry) CK(esam3_launch_copy_rows(dtype, a, Lg, prompt, Sp, S, B, DM, st));
   }
 
+  if (!dry) scope.next("SAM3Image._run_encoder");
   // ---- fusion encoder (encoder.py:139-201,513-577): 6 pre-norm layers over the 5184 image tokens -------
   // Round 5, bf16 engine: the residual stream of the six layers is kept in fp32 (`ms`), as the reference's autocast keeps it
   // (`tgt = tgt + dropout(tgt2)` adds the bf16 branch to an fp32 tensor: 18 additions that rounded the 5184 x 256 stream to bf16 each
@@ -2078,6 +2116,7 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
   }
   if (es32 && !dry) CK(esam3_launch_cast_from_f32(dtype, ms, mem, (int64_t)B * P * DM, st));
 
+  if (!dry) scope.next("SAM3Image._run_decoder");
   // ---- decoder (decoder.py:33-191,417-618): [presence ; 200 queries] per image, post-norm layers, box refinement
   const std::string t = "transformer.decoder.";
   const int64_t R = (int64_t)B * QR;
@@ -2250,6 +2289,7 @@ int E::ground(const esam3_ground_in* in, const esam3_ground_out* out) {
     if (!dry) CK(esam3_launch_dot_score(dtype, hp, QR, 1, Q, ph, out->pred_logits_dev, B, DM, 1.0f / 16.0f, 12.0f, st));
   }
 
+  if (!dry) scope.next("SAM3Image._run_segmentation_heads");
   // ---- segmentation head (maskformer_segmentation.py:172-323) ------------------------------------------------
   {
     const std::string h = "segmentation_head.";
@@ -2403,6 +2443,8 @@ int E::precompute_pe() {
 // Prompt encoder + MaskDecoder.forward (sam1_task_predictor.py:385-421, mask_decoder.py:107-242)
 int E::decode(const esam3_prompts* pr, const esam3_decode_out* out) {
   arena.top = 0;
+  ScopeSeq scope;
+  if (!dry) scope.next("sam_mask_decoder");   // the reference's scope around the SAM heads (sam3_tracker_base.py:314)
   const int Bp = pr->n_prompts, Np = pr->n_points;
   const int pad = Np > 0 ? 1 : 0;  // _embed_points appends a pad point (prompt_encoder.py:84-88)
   const int T = 6 + Np + pad;      // output tokens + points (boxes are passed as points) + pad

@@ -218,6 +218,23 @@ template <> struct Vec8<float> {
 
 // ---- error handling ---------------------------------------------------------------
 void esam3_set_error(const char* fmt, ...);
+// Profiler scopes with the reference's record_function names (sam3_image.py:449-479, sam3_tracker_base.py:314) around the launches of each
+// phase: forwarded to the hooks of esam3_set_scope_hooks (the Python layer opens torch.profiler.record_function ranges) and to roctx
+// (rocprofv3 --marker-trace) when libroctx64.so is loadable.  ScopeSeq: next(name) closes the previous phase and opens the next one, the
+// destructor closes the last (also on an error return).
+void esam3_scope_push(const char* name);
+void esam3_scope_pop();
+struct ScopeSeq {
+  bool open = false;
+  void next(const char* name) {
+    if (open) esam3_scope_pop();
+    esam3_scope_push(name);
+    open = true;
+  }
+  ~ScopeSeq() {
+    if (open) esam3_scope_pop();
+  }
+};
 #define HIP_CHECK_RET(expr)                                                        \
   do {                                                                             \
     hipError_t _e = (expr);                                                        \

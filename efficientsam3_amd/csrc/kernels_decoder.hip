@@ -1348,8 +1348,7 @@ int esam3_launch_fill_holes(const float* in, float* out, int* labels, int* areas
   if (W <= CC_TPX && (int64_t)n * H < (1ll << 30) && !esam3_dev_flag("ESAM3_CC_OLD")) {   // strips in LDS + seam merge
     const int TH = CC_TPX / W < H ? CC_TPX / W : H, strips = (H + TH - 1) / TH;
     const int lds = 2 * CC_TPX * (int)sizeof(int);
-    static const int ok = esam3_allow_dyn_lds((const void*)cc_tile_kernel, lds);
-    if (ok) return -1;
+    if (esam3_allow_dyn_lds((const void*)cc_tile_kernel, lds)) return -1;   // memoised per (device, kernel): every launch asks, as the other kernels do
     hipLaunchKernelGGL(cc_tile_kernel, dim3((unsigned)(n * strips)), dim3(1024), lds, s, in, labels, areas, W, H, TH, strips, thr, (int)max_area);
     if (strips > 1) {
       const int nt = n * (strips - 1) * W;

@@ -25,10 +25,19 @@ def _concat_padded(seq1, mask1, seq2, mask2):
     return out, mask
 
 
+_NO_MASK_PROMPTS = ("mask prompts of the geometry encoder (SequenceGeometryEncoder._encode_masks, sam3/model/geometry_encoders.py:697-745, "
+                    "815-823) are not built: Sam3Processor never issues them (it appends boxes and points only, "
+                    "sam3_image_processor.py:130-190); pass boxes / points, or use the interactive predictor's mask_input")
+
+
 class Prompt:
     def __init__(self, box_embeddings: Optional[torch.Tensor] = None, box_mask: Optional[torch.Tensor] = None,
                  point_embeddings: Optional[torch.Tensor] = None, point_mask: Optional[torch.Tensor] = None,
-                 box_labels: Optional[torch.Tensor] = None, point_labels: Optional[torch.Tensor] = None):
+                 box_labels: Optional[torch.Tensor] = None, point_labels: Optional[torch.Tensor] = None,
+                 mask_embeddings: Optional[torch.Tensor] = None, mask_mask: Optional[torch.Tensor] = None,
+                 mask_labels: Optional[torch.Tensor] = None):
+        if mask_embeddings is not None or mask_mask is not None or mask_labels is not None:
+            raise NotImplementedError(_NO_MASK_PROMPTS)
         ref = box_embeddings if box_embeddings is not None else point_embeddings
         if ref is None:
             raise ValueError("Prompt needs box_embeddings or point_embeddings (use zero-length tensors for none)")
@@ -67,6 +76,10 @@ class Prompt:
         lab, _ = _concat_padded(self.point_labels.long().unsqueeze(-1), self.point_mask, labels.long().unsqueeze(-1), mask)
         self.point_labels = lab.squeeze(-1)
         self.point_embeddings, self.point_mask = _concat_padded(self.point_embeddings, self.point_mask, points.float(), mask)
+
+    def append_masks(self, masks, labels=None, attn_mask=None) -> None:
+        """geometry_encoders.py:377-400 -- refused by name instead of being dropped silently"""
+        raise NotImplementedError(_NO_MASK_PROMPTS)
 
     def batch_first(self) -> dict:
         """The engine's layout: points [B, Np, 2], labels [B, N] int32, masks [B, N] uint8."""

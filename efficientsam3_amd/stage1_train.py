@@ -157,8 +157,8 @@ class Stage1Trainer:
     def __init__(self, state_dict: Dict[str, torch.Tensor], model_name: str = "b1", embed_size: int = 72, dtype: str = "f32", device="cuda",
                  lr: float = 5e-4, weight_decay: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8, clip_grad: float = 5.0, amp: bool = False,
                  cosine_weight: float = 0.0, accumulation_steps: int = 1, init_scale: float = 65536.0, growth_interval: int = 2000,
-                 bn_momentum: float = 0.1, group=None, force_collective: bool = False, drop_path_sampler=None, seed: int = 0,
-                 sync_bn: bool = False):
+                 bn_momentum: float = 0.1, group=None, force_collective: bool = False, drop_path_sampler=None, seed: Optional[int] = None,
+                 sync_bn: bool = False, bucket_bytes: int = 25 << 20):
         from .dist import GradientAllReducer
         self.device = torch.device(device)
         tb.DEVICE = str(self.device)
@@ -202,6 +202,11 @@ class Stage1Trainer:
         self._arrival_index = None
         self._pushed = False
         self._reducer_cls, self._group, self._force = GradientAllReducer, group, force_collective
+        # DistributedDataParallel's bucket size (25 MB), not the reducer's 64 MB default: gradients arrive head first and head.3.weight alone
+        # is 38 MB -- with 64 MB buckets the head shares a bucket with the last trunk stages (for the small students: with the WHOLE trunk),
+        # which completes only when the stem's gradient arrives, i.e. nothing overlapped.  A gradient larger than a bucket closes the
+        # bucket before it and fills one of its own, so the head goes on the wire while the trunk is still in its backward pass.
+        self._bucket_bytes = int(bucket_bytes)
         self.reducer = None
         self._micro = 0   # micro-steps accumulated since the last update
         self.last = {}
@@ -275,7 +280,7 @@ class Stage1Trainer:
             return
         grads = [self.updater.grad(n) for n in self._arrival]
         if self.reducer is None:
-            self.reducer = self._reducer_cls(grads, group=self._group, force_collective=self._force)
+            self.reducer = self._reducer_cls(grads, bucket_bytes=self._bucket_bytes, group=self._group, force_collective=self._force)
         if not self._pushed:   # the first updating step (order unknown until its backward pass ended)
             for i, g_ in enumerate(grads):
                 self.reducer.push(i, g_)
@@ -290,6 +295,15 @@ class Stage1Trainer:
         for k, v in self.batches_tracked.items():
             sd[k] = torch.tensor(v, dtype=torch.long)
         return sd
+
+    def rng_state(self) -> Optional[torch.Tensor]:
+        """the stochastic-depth generator's state (TinyViT 11M / 21M; None for students without DropPath): save it beside state_dict() and the
+        optimizer state, hand it to ``set_rng_state`` on resume -- otherwise a resumed run replays the mask sequence from its start"""
+        return self.trunk.rng_state() if hasattr(self.trunk, "rng_state") else None
+
+    def set_rng_state(self, state: Optional[torch.Tensor]) -> None:
+        if state is not None and hasattr(self.trunk, "set_rng_state"):
+            self.trunk.set_rng_state(state)
 
     def gradients(self) -> Dict[str, torch.Tensor]:
         return {n: self.updater.grad(n).detach().cpu().clone() for n in self.names}

@@ -359,13 +359,19 @@ class TinyViTTrunkTrain:
     ``layers.1.blocks.0.attn.qkv.weight`` ...).  Same interface as ``train_blocks.EfficientViTTrunkTrain``."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], model_name: str, dtype: torch.dtype = torch.float32, prefix: str = "",
-                 drop_path_sampler: Optional[Callable] = None, seed: int = 0):
+                 drop_path_sampler: Optional[Callable] = None, seed: Optional[int] = None):
         dims, depths, heads, windows = TINYVIT_CFG[model_name]
         get = lambda k: sd[prefix + k]  # noqa: E731
         has = lambda k: (prefix + k) in sd  # noqa: E731
         opt = lambda k: sd.get(prefix + k)  # noqa: E731
         self.shapes = {k[len(prefix):]: tuple(v.shape) for k, v in sd.items() if k.startswith(prefix)}
-        self._gen = torch.Generator().manual_seed(seed)
+        # The reference seeds every rank differently (train_image_encoder_stage1.py:340: seed = config.SEED + dist.get_rank()), so the
+        # data-parallel ranks draw DIFFERENT stochastic-depth masks; `seed` is the base seed, the rank is added here.
+        import torch.distributed as _dist
+        rank = _dist.get_rank() if (_dist.is_available() and _dist.is_initialized()) else 0
+        self._gen = torch.Generator().manual_seed((0 if seed is None else int(seed)) + rank)
+        self._own_sampler = drop_path_sampler is None
+        self._pre = {}        # (name, call) -> device row of this step's factors, drawn and uploaded in ONE piece by forward()
         sampler = drop_path_sampler or self._draw
         rates = np.linspace(0.0, DROP_PATH_RATE[model_name], sum(depths)).tolist()       # tiny_vit.py:491
         self.stem1 = tb.StemConvTrain(get("patch_embed.seq.0.c.weight"), get("patch_embed.seq.0.bn.weight"), get("patch_embed.seq.0.bn.bias"), dtype,
@@ -385,9 +391,39 @@ class TinyViTTrunkTrain:
 
     def _draw(self, name: str, call: int, batch: int, keep: float) -> torch.Tensor:
         """timm.layers.drop_path with scale_by_keep: bernoulli(keep) / keep per sample"""
+        pre = self._pre.pop((name, call), None)
+        if pre is not None and pre.shape[0] == batch:
+            return pre
         return torch.empty(batch, dtype=torch.float32).bernoulli_(keep, generator=self._gen) / keep
 
+    def _predraw(self, batch: int, device) -> None:
+        """All stochastic-depth factors of one step, drawn in forward order from the trunk's generator (the same sequence the per-block
+        draws would consume) and moved to the device in ONE copy: round 5 did a synchronous pageable upload per residual."""
+        self._pre = {}
+        todo = []
+        for blk in self.blocks:
+            res = getattr(blk, "res", None)
+            if res is None or res.rate == 0.0:
+                continue
+            for call in range(2 if isinstance(blk, TinyViTBlockTrain) else 1):
+                todo.append((res.name, call, 1.0 - res.rate))
+        if not todo:
+            return
+        host = torch.stack([torch.empty(batch, dtype=torch.float32).bernoulli_(keep, generator=self._gen) / keep for _, _, keep in todo])
+        dev = host.to(device, non_blocking=True)
+        for i, (name, call, _) in enumerate(todo):
+            self._pre[(name, call)] = dev[i]
+
+    def rng_state(self) -> torch.Tensor:
+        """state of the stochastic-depth generator (checkpoint it next to state_dict(): a resumed run continues the mask sequence)"""
+        return self._gen.get_state()
+
+    def set_rng_state(self, state: torch.Tensor) -> None:
+        self._gen.set_state(state)
+
     def forward(self, img_nchw_f32: torch.Tensor) -> torch.Tensor:
+        if self._own_sampler:
+            self._predraw(img_nchw_f32.shape[0], img_nchw_f32.device)
         x = self.stem2.forward(self.stem1.forward(img_nchw_f32))
         for blk in self.blocks:
             x = blk.forward(x)

@@ -418,6 +418,13 @@ int esam3_stage1_preprocess_u8(const uint8_t* img_hwc_u8_dev, int H, int W, floa
                                const float* pixel_mean3_host, const float* pixel_std3_host, int* new_h, int* new_w,
                                void* hip_stream);
 
+/* Profiler scopes.  The engine brackets the launches of each phase with the reference's own torch.profiler.record_function names --
+ * "SAM3Image._encode_prompt", "SAM3Image._run_encoder", "SAM3Image._run_decoder", "SAM3Image._run_segmentation_heads"
+ * (sam3/model/sam3_image.py:449-479) inside esam3_ground, "sam_mask_decoder" (sam3_tracker_base.py:314) inside esam3_decode -- so that
+ * traces of the two implementations line up.  Every scope is forwarded to roctx (rocprofv3 --marker-trace) when libroctx64.so can be
+ * loaded, and to these process-wide hooks (NULL = none): the Python layer registers callbacks that open / close a
+ * torch.profiler.record_function range while a torch profiler is running.  push / pop are called on the thread inside the engine call. */
+void esam3_set_scope_hooks(void (*push)(const char* name), void (*pop)(void));
 /* Per-launch timing with HIP events on the launch stream (bench.py roofline leg): enable,
  * run encode/decode, then fetch a JSON report (syncs the device, clears the records). */
 int esam3_profile_enable(esam3_engine* e, int on);

@@ -868,3 +868,86 @@ def test_stage1_trainer_two_ranks_with_sync_bn_equal_one_rank_with_the_whole_bat
     plain = _run_trainer(False)
     worst_plain = max(float(np.abs(plain[0][1][k] - grads1[k]).max()) / (float(np.abs(grads1[k]).max()) + 1e-3 * gmax) for k in grads1)
     assert worst_plain > 2e-2, worst_plain                                                  # per-rank statistics are a different function
+
+
+# ---- the in-backward push path of the gradient all-reduce ---------------------------------------------------------------
+def _trainer_updates(sd, imgs, teacher, sync_bn, accumulation_steps, n_updates, bucket_bytes):
+    """`n_updates` updating iterations (each `accumulation_steps` micro-steps on the same samples); returns the gradients the LAST update
+    consumed, the parameters after it, and what the reducer did on that last update"""
+    from efficientsam3_amd import stage1_train
+    tr = stage1_train.Stage1Trainer(sd, "repvit_m0_9", embed_size=8, dtype="f32", device="cpu", lr=1e-3, cosine_weight=0.5, sync_bn=sync_bn,
+                                    accumulation_steps=accumulation_steps, bucket_bytes=bucket_bytes)
+    sizes = [(128, 96)] * imgs.shape[0]
+    pushed, snap = [], {}
+    orig_step = tr.updater.step
+
+    def step_and_snapshot(*a, **k):     # the arena is zeroed by the update: keep what the update consumed (after the all-reduce)
+        snap.update({n: tr.updater.grad(n).detach().cpu().clone().numpy() for n in tr.names})
+        return orig_step(*a, **k)
+
+    tr.updater.step = step_and_snapshot
+    for _ in range(n_updates):
+        for m in range(accumulation_steps):
+            tr.step(imgs, teacher, sizes, update_grad=(m == accumulation_steps - 1))
+        pushed.append(bool(tr._pushed))
+    red = tr.reducer
+    info = None if red is None else dict(n_buckets=red.n_buckets, issue_order=list(red.issue_order), pushed=pushed,
+                                         first_buckets=[[tr._arrival[i] for i in b_["idx"]] for b_ in red.buckets[:2]])
+    return (dict(snap), {k: v.numpy() for k, v in tr.state_dict().items()}, info)
+
+
+def _updates_worker(rank, world, port, acc, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    esdist.init_process_group("gloo")
+    try:
+        _install_trainer_standins()
+        sd, imgs, teacher = _trainer_case()
+        lo = 2 * rank
+        q.put((rank,) + _trainer_updates(sd, imgs[lo:lo + 2].contiguous(), teacher[lo:lo + 2].contiguous(), True, acc, 2, 4 << 20))
+    finally:
+        from efficientsam3_amd import train_blocks as tb
+        tb.SYNC_BN = None
+        dist.destroy_process_group()
+
+
+def _updates_one_rank(acc, q):
+    _install_trainer_standins()
+    sd, imgs, teacher = _trainer_case()
+    q.put(_trainer_updates(sd, imgs, teacher, False, acc, 2, 4 << 20))
+
+
+@pytest.mark.parametrize("acc", [1, 2])
+def test_stage1_trainer_two_ranks_push_gradients_during_backward(acc):
+    """Two UPDATING iterations on two gloo ranks (SyncBatchNorm on): the first learns the arrival order of the gradients and reduces after
+    its backward pass, the second pushes every gradient into the bucketed all-reduce from INSIDE the backward pass (`_pushed`), head
+    bucket first -- with the trainer's DDP-sized buckets the head's 3x3 weight (37.7 MB) closes bucket 0 on its own and goes on the wire
+    while the trunk is still in its backward pass.  Gradients and parameters of the second update equal ONE rank training on all four
+    samples; with ACCUMULATION_STEPS = 2 only the updating micro-step pushes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_updates_one_rank, args=(acc, q))
+    p.start()
+    grads1, params1, info1 = q.get(timeout=900)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and info1 is None
+    world = 2
+    port = _free_port()
+    procs = [ctx.Process(target=_updates_worker, args=(r, world, port, acc, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = {r[0]: r[1:] for r in (q.get(timeout=900) for _ in range(world))}
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    gmax = max(float(np.abs(v).max()) for v in grads1.values())
+    for rank in (0, 1):
+        grads, params, info = results[rank]
+        assert info["pushed"] == [False, True], info["pushed"]                       # order learnt in update 1, pushed in update 2
+        assert info["n_buckets"] >= 3 and info["issue_order"] == list(range(info["n_buckets"])), info
+        big = [b_ for b_ in info["first_buckets"] if "head.3.weight" in b_]
+        assert big and all(n.startswith("head.") for n in big[0]) and len(big[0]) <= 3, info["first_buckets"]   # the head's big weight does not wait for the trunk
+        worst = max(float(np.abs(grads[k] - grads1[k]).max()) / (float(np.abs(grads1[k]).max()) + 1e-3 * gmax) for k in grads1)
+        assert worst <= 5e-3, (rank, worst)
+        moved = [k for k in params1 if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+        far = sum(int((np.abs(params[k] - params1[k]) > 2.5e-3).sum()) for k in moved)   # 2 updates x lr 1e-3: no element may be further
+        assert far == 0, far

@@ -402,12 +402,22 @@ def test_b2_training_step_matches_the_reference_run():
     _first_step_vs_reference("b2", "b2", sd, B2_GRAD_REL, B2_GRAD_ABS)
 
 
+def test_b0_training_step_matches_the_reference_run():
+    """EfficientViT-B0 (EV-S: widths 8 .. 128, 1 + 2 + 2 + 2 + 2 blocks, LiteMLA heads of dim 16) through the same trainer, against the REAL
+    reference stack's run (oracle/gen_golden_stage1_step.py --model b0 -> tests/golden/stage1/step_b0.*): round 5 benchmarked this student
+    (675 img/s) but only held its step to the fixture through the CPU stand-in (tests/test_stage1_trainer_host.py); first iteration as for
+    B1 / B2 -- loss, total gradient norm, every parameter's clipped gradient, every updated parameter, every BatchNorm running statistic."""
+    sd = schema.synthetic_state_dict("efficientvit", "b0", seed=0)
+    sd = {k[len(PREFIX):]: v.clone() for k, v in sd.items() if k.startswith(PREFIX)}
+    _first_step_vs_reference("b0", "b0", sd, GRAD_REL, GRAD_ABS, check_buffers=True)
+
+
 def _repvit_sd(name):
     sd = schema.synthetic_state_dict("repvit", name, seed=0)
     return {k[len(PREFIX):]: v.clone() for k, v in sd.items() if k.startswith(PREFIX)}
 
 
-@pytest.mark.parametrize("model,name", [("repvit_m0_9", "m0.9"), ("repvit_m1_1", "m1.1")])
+@pytest.mark.parametrize("model,name", [("repvit_m0_9", "m0.9"), ("repvit_m1_1", "m1.1"), ("repvit_m2_3", "m2.3")])
 def test_repvit_training_steps_match_the_reference_run(model, name):
     """The RepViT students (RV-S / RV-M: stage1/model.py:386-395 -> RepViTAdapter over sam3/backbones/repvit.py) through the same trainer --
     patch embedding with its dense stride-2 3x3, RepVGGDW token mixers, SqueezeExcite in every other block, stride-2 blocks, GELU channel
@@ -448,7 +458,7 @@ def _tinyvit_sd(name):
     return {k[len(PREFIX):]: v.clone() for k, v in sd.items() if k.startswith(PREFIX)}
 
 
-@pytest.mark.parametrize("model,name", [("tiny_vit_5m", "5m"), ("tiny_vit_11m", "11m")])
+@pytest.mark.parametrize("model,name", [("tiny_vit_5m", "5m"), ("tiny_vit_11m", "11m"), ("tiny_vit_21m", "21m")])
 def test_tinyvit_training_steps_match_the_reference_run(model, name):
     """The TinyViT students (TV-S / TV-M: stage1/model.py:397-406 -> TinyViTAdapter over sam3/backbones/tiny_vit.py) through the same trainer --
     MBConv stage, PatchMerging, window attention over zero-padded windows (63 -> 70 for the 14-token windows, 32 -> 35 for the last stage)

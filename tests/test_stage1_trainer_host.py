@@ -164,6 +164,42 @@ def test_trainer_host_logic_vs_the_reference_run(host_trainer, model, family, na
     assert abs(norm2 - ref["grad_norms"][1]) <= 1e-2 * ref["grad_norms"][1], (norm2, ref["grad_norms"][1])
 
 
+def test_drop_path_factors_one_draw_per_step_same_sequence_and_resumable(host_trainer):
+    """TinyViT-11M's default stochastic depth: the factors of a step are drawn in ONE piece at the start of forward() -- the
+    same generator sequence as per-residual draws in forward order -- so a step costs one upload instead of one synchronous copy per block;
+    ``rng_state`` / ``set_rng_state`` let a resumed run continue the mask sequence; `seed` is the BASE seed (the rank is added: the
+    reference seeds config.SEED + rank, train_image_encoder_stage1.py:340)."""
+    from efficientsam3_amd import train_tinyvit as tv
+    sd = schema.synthetic_state_dict("tinyvit", "11m", seed=0)
+    sd = {k[len(PREFIX):]: v.clone() for k, v in sd.items() if k.startswith(PREFIX)}
+    tr = stage1_train.Stage1Trainer(sd, "tiny_vit_11m", embed_size=8, dtype="f32", device="cpu", seed=5)
+    trunk = tr.trunk
+    gen = torch.Generator().manual_seed(5)          # one rank, no process group: base seed + 0
+    expect = {}
+    for blk in trunk.blocks:
+        res = getattr(blk, "res", None)
+        if res is None or res.rate == 0.0:
+            continue
+        for call in range(2 if isinstance(blk, tv.TinyViTBlockTrain) else 1):
+            keep = 1.0 - res.rate
+            expect[(res.name, call)] = torch.empty(3, dtype=torch.float32).bernoulli_(keep, generator=gen) / keep
+    assert len(expect) >= 10
+    state0 = tr.rng_state()
+    trunk._predraw(3, "cpu")
+    assert set(trunk._pre) == set(expect)
+    for k, v in expect.items():
+        assert torch.equal(trunk._pre[k], v), k
+    first = {k: v.clone() for k, v in trunk._pre.items()}
+    trunk._predraw(3, "cpu")                                               # the next step continues the sequence ...
+    assert any(not torch.equal(trunk._pre[k], first[k]) for k in first)
+    tr.set_rng_state(state0)                                               # ... and a restored state replays it exactly
+    trunk._predraw(3, "cpu")
+    assert all(torch.equal(trunk._pre[k], first[k]) for k in first)
+    # a factor asked for through the sampler interface is the pre-drawn row (consumed once), then fresh draws
+    k0 = next(iter(first))
+    assert torch.equal(trunk._draw(k0[0], k0[1], 3, 0.9), first[k0]) and k0 not in trunk._pre
+
+
 REFERENCE = "/root/reference"
 
 
