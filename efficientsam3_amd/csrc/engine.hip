@@ -1177,8 +1177,14 @@ int E::tv_mbconv(const std::string& p, const T4& x, T4* y) {
       *y = dst;
       if (dry) return 0;
       const double px = (double)x.rows();
+      // round 6: the persistent matrix-core kernel of the EfficientViT MBConvs (evit_fused.hip: mbconv3s) with GELU epilogues; the
+      // round-2 kernel (mbconv_fused.hip v2) was the largest launch of a TinyViT step (2 x 1.18 ms, 0.08 of its floor).  A/B: ESAM3_MB_V2
+      const bool v3 = esam3_mbconv3_ok(dtype, 64, 256, 64, 1) && !esam3_dev_flag("ESAM3_MB_V2");
       return prof_launch("mbconv_fused_gelu:" + p.substr(p.size() > 40 ? p.size() - 40 : 0), 2.0 * px * 256 * (64 + 9 + 64),
                          px * 64 * 3 * (double)esz, [&]() {
+                           if (v3)
+                             return esam3_launch_mbconv3(x.p, y->p, g1->w, g1->Kp, g1->bias, dw->w, dw->bias, g2->w, g2->Kp, g2->bias,
+                                                         x.B, x.H, x.W, 64, 256, 64, 1, /*shortcut + GELU variant*/ 3, st);
                            return esam3_launch_mbconv_fused(dtype, x.p, y->p, g1->w, g1->Kp, g1->bias, dw->w, dw->bias, g2->w, g2->Kp,
                                                             g2->bias, x.B, x.H, x.W, 64, 256, 64, 1, /*shortcut + GELU variant*/ 3, st);
                          });

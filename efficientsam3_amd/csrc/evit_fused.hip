@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(512, C == 128 ? 2 : 1) void mla2d_kernel(Mla2Params
 //   * the expand epilogue writes its two 16-byte pieces in a lane-dependent order (2-way instead of 4-way bank conflicts);
 //   * the depthwise LDS reads run three input rows ahead of the MFMAs (DwRows3).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int S, int CIN, int COUT>
+template <int S, int CIN, int COUT, bool GELU = false>
 __global__ __launch_bounds__(256, 2) void mbconv3s_kernel(Mb3Params p) {
   typedef bf16_t T;
   constexpr int NW = 4;
@@ -1173,7 +1173,8 @@ __global__ __launch_bounds__(256, 2) void mbconv3s_kernel(Mb3Params p) {
           float v[16];
 #pragma unroll
           for (int e = 0; e < 16; ++e) v[e] = acc[e];
-          hsw_n<16>(v);
+          if constexpr (GELU) gelu_fast_n<16>(v);   // TinyViT MBConv (tiny_vit.py:73-108): GELU after conv1 / conv2 and after the shortcut add
+          else hsw_n<16>(v);
           if constexpr (decltype(zero_border)::value) {
             const bool in = (xin_t >> u) & 1u;
 #pragma unroll
@@ -1238,7 +1239,15 @@ __global__ __launch_bounds__(256, 2) void mbconv3s_kernel(Mb3Params p) {
 #pragma unroll
         for (int r = 0; r < DROWS; ++r) {
           const int op = (drow0 + r) * TW + 4 * dq + pi;
-          *reinterpret_cast<uint2*>(dwo + op * 128 + swz(op, blk >> 1) + (blk & 1) * 8) = hsw_pack4(acc[r]);
+          uint2 packed;
+          if constexpr (GELU) {
+            float a4[4] = {acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+            gelu_fast_n<4>(a4);
+            packed = make_uint2(pack_bf16x2(a4[0], a4[1]), pack_bf16x2(a4[2], a4[3]));
+          } else {
+            packed = hsw_pack4(acc[r]);
+          }
+          *reinterpret_cast<uint2*>(dwo + op * 128 + swz(op, blk >> 1) + (blk & 1) * 8) = packed;
         }
       }
       __syncthreads();
@@ -1278,6 +1287,7 @@ __global__ __launch_bounds__(256, 2) void mbconv3s_kernel(Mb3Params p) {
           v[4 * q + 2] += __uint_as_float(u2.y << 16); v[4 * q + 3] += __uint_as_float(u2.y & 0xffff0000u);
         }
       }
+      if constexpr (GELU) gelu_fast_n<16>(v);   // the block's closing activation follows the shortcut add
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp) {
         const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
@@ -1294,7 +1304,7 @@ __global__ __launch_bounds__(256, 2) void mbconv3s_kernel(Mb3Params p) {
   }
 }
 
-template <int S, int CIN, int COUT>
+template <int S, int CIN, int COUT, bool GELU = false>
 int launch_mb3s(Mb3Params p, hipStream_t stream) {
   constexpr int TH = 8, TW = S == 1 ? 16 : 8;
   p.tiles_x = (p.OW + TW - 1) / TW;
@@ -1305,7 +1315,7 @@ int launch_mb3s(Mb3Params p, hipStream_t stream) {
   const int gd = esam3_dev_flag("ESAM3_MB3S_GRID");
   if (gd > 0) grid = (unsigned)gd;
   if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL((mbconv3s_kernel<S, CIN, COUT>), dim3(grid), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((mbconv3s_kernel<S, CIN, COUT, GELU>), dim3(grid), dim3(256), 0, stream, p);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -1613,6 +1623,13 @@ int esam3_launch_mbconv3(const void* x, void* out, const void* w1, int Kp1, cons
   q.B = B; q.H = H; q.W = W; q.OH = (H + stride - 1) / stride; q.OW = (W + stride - 1) / stride;
   q.Cmid = Cmid; q.Kp1 = Kp1; q.Kp2 = Kp2; q.residual = residual & 1;
   q.abl = esam3_dev_flag("ESAM3_MB3_ABL");
+  if (residual & 2) {   // TinyViT MBConv (tiny_vit.py:73-108), round 6: GELU after conv1, conv2 and the shortcut add; one shape, 64 -> 256 -> 64
+    if (Cin != 64 || Cout != 64 || Cmid != 256 || stride != 1 || !(residual & 1)) {
+      esam3_set_error("mbconv3: the GELU variant is built for 64 -> 256 -> 64 channels, stride 1, with the shortcut");
+      return -1;
+    }
+    return launch_mb3s<1, 64, 64, true>(q, stream);
+  }
   if (Cin <= 64 && !esam3_dev_flag("ESAM3_MB3_GENERIC")) {   // persistent + prefetching variant
     if (Cmid > 256) { esam3_set_error("mbconv3s: Cmid %d > 256", Cmid); return -1; }
     if (stride == 2 && Cin == 16) return launch_mb3s<2, 16, 32>(q, stream);

@@ -56,7 +56,7 @@ def _nchw_view(t_nhwc: torch.Tensor) -> torch.Tensor:
 _WIDEN_POOL = None
 
 
-def _widen_into(dst: np.ndarray, src: np.ndarray, parts: int = 16, serial_below: int = 1 << 22) -> None:
+def _widen_into(dst: np.ndarray, src: np.ndarray, parts: int = 0, serial_below: int = 1 << 22) -> None:
     """dst[...] = src (same shape, any dtypes numpy can cast: the uint8 masks become the float32 array the reference's contract returns);
     large arrays are split into `parts` contiguous ranges copied by the worker threads.  uint8 -> float32 (the thresholded masks) runs
     in the library's C loop (esam3_host_widen_u8_f32: numpy's casting copy reached 37 GB/s of stores on 16 threads, 3.6 ms per 32
@@ -75,6 +75,7 @@ def _widen_into(dst: np.ndarray, src: np.ndarray, parts: int = 16, serial_below:
         else:
             np.copyto(d, s_, casting="unsafe")
         return
+    parts = parts or host_threads()
     step = -(-n // parts)
     if native is not None:
         list(_widen_pool().map(lambda i: native(i * step, min(n, (i + 1) * step)), range(parts)))
@@ -97,13 +98,23 @@ def _pool_get(pool: list, make):
     return ent
 
 
+def host_threads() -> int:
+    """worker threads of the host-side copies (PIL staging, mask widening): ESAM3_HOST_THREADS, else min(16, cores) -- measured on the
+    256-core GPU host (profiles/r06/api_host_threads.txt)"""
+    try:
+        n = int(os.environ.get("ESAM3_HOST_THREADS", "0"))
+    except ValueError:
+        n = 0
+    return n if n > 0 else min(16, os.cpu_count() or 1)
+
+
 def _widen_pool():
     """a few long-lived worker threads for host-side copies (numpy releases the GIL inside them)"""
     global _WIDEN_POOL
     if _WIDEN_POOL is None:
         import os
         from concurrent.futures import ThreadPoolExecutor
-        _WIDEN_POOL = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1), thread_name_prefix="esam3-widen")
+        _WIDEN_POOL = ThreadPoolExecutor(max_workers=host_threads(), thread_name_prefix="esam3-widen")
     return _WIDEN_POOL
 
 

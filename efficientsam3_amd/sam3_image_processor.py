@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from .engine import NET_RES
+from .sam3_image import host_threads
 
 try:  # PIL is optional at import time
     import PIL.Image as _PILImage
@@ -94,7 +95,7 @@ class Sam3Processor:
 
         if b >= 4:
             if self._pool is None:
-                self._pool = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1), thread_name_prefix="esam3-stage")
+                self._pool = ThreadPoolExecutor(max_workers=host_threads(), thread_name_prefix="esam3-stage")
             list(self._pool.map(fill, range(b)))
         else:
             for i in range(b):
@@ -246,7 +247,7 @@ class Sam3Processor:
             first = min(b - 1, max(4, int(b * self.first_chunk_fraction)))
             bounds = ((0, first), (first, b))
             if self._pool is None:                                 # both threads fill their staging buffers through it
-                self._pool = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1), thread_name_prefix="esam3-stage")
+                self._pool = ThreadPoolExecutor(max_workers=host_threads(), thread_name_prefix="esam3-stage")
             if self._h2d_stream is None and dev.type == "cuda":
                 self._h2d_stream = torch.cuda.Stream(device=dev)
             nxt = self._send_later(images[first:b], slot=1)        # chunk 1 is staged and sent while chunk 0 is staged, sent and launched here

@@ -708,6 +708,38 @@ def test_mbconv3(B, H, W, Cin, Cmid, Cout, stride, res):
     U.assert_close(got, ref, mode, f"mbconv3 {Cin}->{Cmid}->{Cout} s{stride}", scale=0.7)
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 30, 26), (2, 33, 50), (2, 64, 64), (1, 252, 252)])
+def test_mbconv3_gelu_variant(B, H, W):
+    """Round 6: TinyViT's MBConv (tiny_vit.py:73-108: conv1 + BN -> GELU -> depthwise 3x3 + BN -> GELU -> conv3 + BN -> + x -> GELU,
+    64 -> 256 -> 64) on the persistent matrix-core kernel of the EfficientViT MBConvs (mbconv3s with GELU epilogues) vs the layer-by-layer
+    PyTorch reference with the kernel's rounding points; and against the round-2 kernel it replaces (same formula, same GELU polynomial:
+    the two must agree to bf16 rounding of the intermediates)."""
+    mode = "bf16"
+    d, tdt = U.DT[mode]
+    Cin, Cmid, Cout = 64, 256, 64
+    x = _rand(B, Cin, H, W, seed=1)
+    w1, b1 = _rand(Cmid, Cin, 1, 1, seed=2) * (2.0 / Cin) ** 0.5, _rand(Cmid, seed=3) * 0.1
+    wd, bd = _rand(Cmid, 1, 3, 3, seed=4) * 0.4, _rand(Cmid, seed=5) * 0.1
+    w2, b2 = _rand(Cout, Cmid, 1, 1, seed=6) / Cmid ** 0.5, _rand(Cout, seed=7) * 0.1
+    xq = _q(x, mode)
+    m = _q(F.gelu(F.conv2d(xq, _q(w1, mode), b1)), mode)
+    m = _q(F.gelu(F.conv2d(m, _q(wd, mode), bd, padding=1, groups=Cmid)), mode)
+    ref = F.gelu(F.conv2d(m, _q(w2, mode), b2) + xq)
+    x_d = U.to_dev_nhwc(x, tdt)
+    args = (U.H(U.np32(w1)), U.H(U.np32(b1)), U.H(U.np32(wd)), U.H(U.np32(bd)), U.H(U.np32(w2)), U.H(U.np32(b2)))
+    out = torch.full((B, H, W, Cout), float("nan"), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_mbconv3(U.P(x_d), *args, U.P(out), B, H, W, Cin, Cmid, Cout, 1, 3, None), "op_mbconv3 (GELU)")
+    got = U.from_dev_nhwc(out)
+    assert torch.isfinite(got).all()
+    assert _rel_l2(got, ref) < 6e-3, _rel_l2(got, ref)
+    U.assert_close(got, ref, mode, "mbconv3 GELU 64->256->64", scale=0.7)
+    old = torch.full((B, H, W, Cout), float("nan"), dtype=tdt, device="cuda")
+    U.check(U.lib().esam3_op_mbconv_fused(d, U.P(x_d), *args, U.P(old), B, H, W, Cin, Cmid, Cout, 1, 3, None), "op_mbconv_fused (GELU)")
+    assert _rel_l2(got, U.from_dev_nhwc(old)) < 4e-3, _rel_l2(got, U.from_dev_nhwc(old))
+    with pytest.raises(Exception):   # the variant is one shape: anything else is refused, not run on another kernel
+        U.check(U.lib().esam3_op_mbconv3(U.P(x_d), *args, U.P(out), B, H, W, Cin, Cmid, Cout, 1, 2, None), "no shortcut")
+
+
 def _lite_mla_block_ref(x, wqkv, wdw, wgrp, wproj, bproj, dim=16):
     """ops.py:521-671 + the ResidualBlock shortcut, with the fused kernels' rounding points (bf16 tensors between the layers)."""
     q = lambda t: t.to(torch.bfloat16).float()

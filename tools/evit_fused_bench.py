@@ -23,6 +23,8 @@ MB = {  # name: B, H, W, Cin, Cmid, Cout, stride, res
     "s1.0": (32, 252, 252, 32, 128, 64, 2, 0), "s1.1": (32, 126, 126, 64, 256, 64, 1, 1),
     "s2.0": (32, 126, 126, 64, 256, 128, 2, 0), "s2.loc": (32, 63, 63, 128, 512, 128, 1, 1),
     "s3.0": (32, 63, 63, 128, 512, 256, 2, 0), "s3.loc": (32, 32, 32, 256, 1024, 256, 1, 1),
+    # TinyViT-5M / 11M layer 0 (res = 3: shortcut + the GELU variant, tiny_vit.py:73-108); "tv.hs" = the same shape with Hardswish
+    "tv.0": (32, 252, 252, 64, 256, 64, 1, 3), "tv.hs": (32, 252, 252, 64, 256, 64, 1, 1),
 }
 MLA = {"s2.ctx": (32, 63, 63, 128), "s3.ctx": (32, 32, 32, 256)}
 
