@@ -162,9 +162,15 @@ class Stage1Trainer:
         from .dist import GradientAllReducer
         self.device = torch.device(device)
         tb.DEVICE = str(self.device)
-        # --use-sync-bn (train_image_encoder_stage1.py:62-63): every BatchNorm of trunk and head uses the statistics of all ranks of `group`
+        # --use-sync-bn (train_image_encoder_stage1.py:62-63): every BatchNorm of trunk and head uses the statistics of all ranks of `group`.
+        # The setting is carried by THIS trainer's BatchNorm layers (`layer.sync`, set below next to the momentum), not by a module global:
+        # a second trainer in the process (another group, no SyncBatchNorm, an evaluation copy) does not change this one.
         import torch.distributed as _dist
-        tb.SYNC_BN = (group if group is not None else True) if (sync_bn and _dist.is_initialized()) else None
+        if sync_bn and not _dist.is_initialized():
+            import warnings
+            warnings.warn("Stage1Trainer(sync_bn=True) without an initialised torch.distributed process group: BatchNorm uses this "
+                          "rank's own batch statistics (initialise the process group before building the trainer)")
+        self._sync = (group if group is not None else True) if (sync_bn and _dist.is_initialized()) else None
         self.tdtype = {"f32": torch.float32, "bf16": torch.bfloat16}[dtype]
         if model_name not in EFFICIENTVIT and model_name not in REPVIT and model_name not in TINYVIT:
             raise ValueError(f"stage-1 student {model_name!r}: the trainer covers {sorted(EFFICIENTVIT) + sorted(REPVIT) + sorted(TINYVIT)}")
@@ -194,8 +200,10 @@ class Stage1Trainer:
                                            seed=seed)
         for _, layer in self.trunk.norm_layers():
             layer.momentum = bn_momentum
+            layer.sync = self._sync
         self.head = HeadTrain(views, embed_size)
         self.head.l0.momentum = bn_momentum
+        self.head.l0.sync = self._sync
         self.names = [n for n, _ in named_shapes]
         # gradients arrive head first, then the trunk from its last layer to the stem: the bucket order of the all-reduce
         self._arrival = None

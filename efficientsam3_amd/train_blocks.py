@@ -28,28 +28,35 @@ DEVICE = "cuda"   # where the block classes keep their BatchNorm parameters (the
 # SyncBatchNorm (stage1/train_image_encoder_stage1.py:62-63 `--use-sync-bn`: torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)): None = every
 # rank normalises with its own batch statistics (nn.BatchNorm2d); a torch.distributed process group (or True for the default group) = the
 # statistics of all its ranks, torch.nn.SyncBatchNorm's protocol with one collective each way.  Set by ``Stage1Trainer(sync_bn=True)``.
-SYNC_BN = None
+SYNC_BN = None          # process-wide default (tests, scripts); a trainer sets `sync` on ITS BatchNorm layers instead (round 6), so two
+GLOBAL = object()       # trainers in one process -- with and without SyncBatchNorm, or on different groups -- do not change each other
 
 
-def _sync_group():
-    return None if SYNC_BN is True else SYNC_BN
+def _sync(sync):
+    """a layer's `sync` attribute (or the GLOBAL marker: the module default above) -> None | True | process group"""
+    return SYNC_BN if sync is GLOBAL else sync
+
+
+def _sync_group(sync=GLOBAL):
+    v = _sync(sync)
+    return None if v is True else v
 
 
 def bn_train_forward(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: torch.Tensor = None, running_var: torch.Tensor = None,
-                     momentum: float = 0.1, eps: float = 1e-5):
+                     momentum: float = 0.1, eps: float = 1e-5, sync=GLOBAL):
     """training-mode BatchNorm2d on NHWC rows -> (y, mean, rstd).  Under ``SYNC_BN``: every rank's (mean, biased variance, rows) are gathered
     (one all_gather of 2 C + 1 doubles), combined as torch's batch_norm_gather_stats_with_counts does -- the count-weighted mean, and the
     count-weighted mean of var + (mean_r - mean)^2 --, the running statistics take the all-rank values (unbiased variance with the all-rank
     count), and the map runs with them"""
-    if SYNC_BN is None:
+    if _sync(sync) is None:
         return _s1.bn_train_forward(x, gamma, beta, running_mean, running_var, momentum, eps)
     import torch.distributed as dist
     c = x.shape[-1]
     mean_l, _, var_l = bn_stats(x, eps)
     rows = torch.full((1,), float(x.numel() // c), dtype=torch.float64, device=x.device)
     packed = torch.cat([mean_l.double(), var_l.double(), rows])
-    gathered = [torch.empty_like(packed) for _ in range(dist.get_world_size(_sync_group()))]
-    dist.all_gather(gathered, packed, group=_sync_group())
+    gathered = [torch.empty_like(packed) for _ in range(dist.get_world_size(_sync_group(sync)))]
+    dist.all_gather(gathered, packed, group=_sync_group(sync))
     g = torch.stack(gathered)
     cnt = g[:, -1:]
     n = cnt.sum()
@@ -63,18 +70,18 @@ def bn_train_forward(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, r
     return bn_apply(x, gamma, beta, mean32, rstd32), mean32, rstd32
 
 
-def bn_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, save_mean: torch.Tensor, save_rstd: torch.Tensor):
+def bn_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, save_mean: torch.Tensor, save_rstd: torch.Tensor, sync=GLOBAL):
     """its autograd backward -> (dx, dgamma, dbeta).  Under ``SYNC_BN``: the ranks' (sum dy xhat, sum dy, rows) are summed (one all_reduce),
     dx uses the all-rank means, dgamma / dbeta stay THIS rank's sums (the gradient all-reduce averages them like every other gradient), as
     torch.nn.SyncBatchNorm's backward does"""
-    if SYNC_BN is None:
+    if _sync(sync) is None:
         return _s1.bn_train_backward(x, dy, gamma, save_mean, save_rstd)
     import torch.distributed as dist
     c = x.shape[-1]
     sdyx, sdy = bn_backward_sums(x, dy, save_mean, save_rstd)
     rows = torch.full((1,), float(x.numel() // c), dtype=torch.float64, device=x.device)
     packed = torch.cat([sdyx.double(), sdy.double(), rows])
-    dist.all_reduce(packed, group=_sync_group())
+    dist.all_reduce(packed, group=_sync_group(sync))
     means = (packed[:2 * c] / packed[-1]).float()
     dx = bn_backward_apply(x, dy, gamma, save_mean, save_rstd, means[:c].contiguous(), means[c:].contiguous())
     return dx, sdyx, sdy
@@ -85,19 +92,19 @@ def bn_train_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, sa
 FUSE_BN_ACT = True
 
 
-def bn_act_forward(x: torch.Tensor, gamma, beta, running_mean, running_var, momentum: float, eps: float, act):
+def bn_act_forward(x: torch.Tensor, gamma, beta, running_mean, running_var, momentum: float, eps: float, act, sync=GLOBAL):
     """BatchNorm2d (training mode) then ``act`` -> (pre = the BatchNorm's output, act(pre), mean, rstd)"""
-    if act is not None and FUSE_BN_ACT and SYNC_BN is None:
+    if act is not None and FUSE_BN_ACT and _sync(sync) is None:
         return _s1.bn_act_train_forward(x, gamma, beta, running_mean, running_var, momentum, eps, act)
-    pre, mean, rstd = bn_train_forward(x, gamma, beta, running_mean, running_var, momentum, eps)
+    pre, mean, rstd = bn_train_forward(x, gamma, beta, running_mean, running_var, momentum, eps, sync=sync)
     return pre, (act_forward(pre, act) if act else pre), mean, rstd
 
 
-def bn_act_backward(x: torch.Tensor, dy: torch.Tensor, pre: torch.Tensor, act, gamma, mean, rstd):
+def bn_act_backward(x: torch.Tensor, dy: torch.Tensor, pre: torch.Tensor, act, gamma, mean, rstd, sync=GLOBAL):
     """its backward: dy = the gradient of act(pre) -> (dx, dgamma, dbeta)"""
-    if act is not None and FUSE_BN_ACT and SYNC_BN is None:
+    if act is not None and FUSE_BN_ACT and _sync(sync) is None:
         return _s1.bn_act_train_backward(x, dy, pre, act, gamma, mean, rstd)
-    return bn_train_backward(x, act_backward(pre, dy, act) if act else dy, gamma, mean, rstd)
+    return bn_train_backward(x, act_backward(pre, dy, act) if act else dy, gamma, mean, rstd, sync=sync)
 
 
 def _stream():
@@ -307,7 +314,7 @@ class ConvLayerTrain:
         self.conv_out = linear_forward(x, self.w, self.bias) if self.kind == "pw" else dwconv_forward(x, self.w, self.stride, self.bias)
         if self.norm:
             self.pre, y, self.mean, self.rstd = bn_act_forward(self.conv_out, self.gamma, self.beta, self.running_mean, self.running_var,
-                                                               self.momentum, self.eps, self.act)
+                                                               self.momentum, self.eps, self.act, sync=getattr(self, "sync", GLOBAL))
             return y
         self.pre = self.conv_out
         return act_forward(self.pre, self.act) if self.act else self.pre
@@ -316,7 +323,7 @@ class ConvLayerTrain:
         """-> (dx, {"weight": dw, "gamma" / "beta" or "bias": ...})"""
         grads = {}
         if self.norm:
-            d_conv, grads["gamma"], grads["beta"] = bn_act_backward(self.conv_out, dy, self.pre, self.act, self.gamma, self.mean, self.rstd)
+            d_conv, grads["gamma"], grads["beta"] = bn_act_backward(self.conv_out, dy, self.pre, self.act, self.gamma, self.mean, self.rstd, sync=getattr(self, "sync", GLOBAL))
         else:
             d_conv = act_backward(self.pre, dy, self.act) if self.act else dy
         if self.bias is not None:
@@ -531,11 +538,11 @@ class StemConvTrain:
         self.img = img
         self.conv_out = stem_forward(img, self.w, self.dtype)
         self.pre, y, self.mean, self.rstd = bn_act_forward(self.conv_out, self.gamma, self.beta, self.running_mean, self.running_var, self.momentum,
-                                                           self.eps, self.act)
+                                                           self.eps, self.act, sync=getattr(self, "sync", GLOBAL))
         return y
 
     def backward(self, dy: torch.Tensor):
-        d_conv, dgamma, dbeta = bn_act_backward(self.conv_out, dy, self.pre, self.act, self.gamma, self.mean, self.rstd)
+        d_conv, dgamma, dbeta = bn_act_backward(self.conv_out, dy, self.pre, self.act, self.gamma, self.mean, self.rstd, sync=getattr(self, "sync", GLOBAL))
         dw = linear_wgrad(d_conv, stem_im2col(self.img, self.dtype))[:, :27].reshape(self.w.shape)
         return None, {"weight": dw, "gamma": dgamma, "beta": dbeta}
 

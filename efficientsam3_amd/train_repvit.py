@@ -93,11 +93,11 @@ class Conv3x3S2Train:
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self.x = x
         self.conv_out = conv3x3_s2_forward(x, self.w)
-        y, self.mean, self.rstd = tb.bn_train_forward(self.conv_out, self.gamma, self.beta, self.running_mean, self.running_var, self.momentum, self.eps)
+        y, self.mean, self.rstd = tb.bn_train_forward(self.conv_out, self.gamma, self.beta, self.running_mean, self.running_var, self.momentum, self.eps, sync=getattr(self, "sync", tb.GLOBAL))
         return y
 
     def backward(self, dy: torch.Tensor):
-        d_conv, dgamma, dbeta = tb.bn_train_backward(self.conv_out, dy, self.gamma, self.mean, self.rstd)
+        d_conv, dgamma, dbeta = tb.bn_train_backward(self.conv_out, dy, self.gamma, self.mean, self.rstd, sync=getattr(self, "sync", tb.GLOBAL))
         dw = conv3x3_s2_wgrad(d_conv, self.x)
         dx = conv3x3_s2_dgrad(d_conv, self.w, self.x.shape[1:3])
         return dx, {"weight": dw, "gamma": dgamma, "beta": dbeta}
@@ -124,11 +124,11 @@ class RepVGGDWTrain:
         self.x = x
         a = self.conv.forward(x)
         self.s = tb.channel_scale(x, self.w1.reshape(-1), bias=self.b1, add=a, plus_one=True)        # conv(x) + (w1 x + b1) + x
-        y, self.mean, self.rstd = tb.bn_train_forward(self.s, self.gamma, self.beta, self.running_mean, self.running_var, self.momentum, self.eps)
+        y, self.mean, self.rstd = tb.bn_train_forward(self.s, self.gamma, self.beta, self.running_mean, self.running_var, self.momentum, self.eps, sync=getattr(self, "sync", tb.GLOBAL))
         return y
 
     def backward(self, dy: torch.Tensor):
-        ds, dgamma, dbeta = tb.bn_train_backward(self.s, dy, self.gamma, self.mean, self.rstd)
+        ds, dgamma, dbeta = tb.bn_train_backward(self.s, dy, self.gamma, self.mean, self.rstd, sync=getattr(self, "sync", tb.GLOBAL))
         dx_conv, g = self.conv.backward(ds)
         dw1 = tb.batched_coldot(ds, self.x, per_image=False)                                           # sum over all pixels of ds x
         db1 = tb.colsum(ds)

@@ -83,17 +83,31 @@ def win_attn_forward(qkv: torch.Tensor, bias: torch.Tensor, heads: int, scale: f
     return out, lse
 
 
+DS_CHUNK_BYTES = 256 << 20   # bound on the transient logits-gradient tensor of win_attn_backward
+
+
 def win_attn_backward(qkv: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, lse: torch.Tensor, dout: torch.Tensor, heads: int, scale: float):
     """-> (dqkv like qkv, dbias [heads, N, N] fp32 = the logits' gradient summed over the windows)"""
     nw, n, _ = qkv.shape
     assert dout.shape == out.shape and dout.dtype == qkv.dtype and dout.is_contiguous()
     dqkv = torch.empty_like(qkv)
-    ds = torch.empty((nw, heads * n * n), dtype=torch.float32, device=qkv.device)
+    # The logits' gradient dS [windows, heads N N] fp32 exists only to be summed over the windows (the bias gradient).  For TinyViT-11M at
+    # 1008^2 and batch 32 the whole tensor is 0.98 GB per stage-2 block (1.5 GB for 21M): the windows are walked in chunks of at most
+    # DS_CHUNK_BYTES and the chunk sums added in chunk order (a fixed order: repeats stay bit-identical).  One chunk = the old path.
+    per_window = heads * n * n * 4
+    chunk = max(1, min(nw, DS_CHUNK_BYTES // per_window))
+    ds = torch.empty((chunk, heads * n * n), dtype=torch.float32, device=qkv.device)
+    dbias = None
+    lib = _lib.load()
     with torch.cuda.device(qkv.device):
-        _lib.check(_lib.load().esam3_win_attn_train_backward(_DT[qkv.dtype], qkv.data_ptr(), bias.data_ptr(), out.data_ptr(), lse.data_ptr(), dout.data_ptr(),
-                                                             dqkv.data_ptr(), ds.data_ptr(), nw, n, heads, float(scale), tb._stream()),
-                   "esam3_win_attn_train_backward")
-    return dqkv, tb.colsum(ds).reshape(heads, n, n)
+        for a in range(0, nw, chunk):
+            e = min(nw, a + chunk)
+            _lib.check(lib.esam3_win_attn_train_backward(_DT[qkv.dtype], qkv[a:e].data_ptr(), bias.data_ptr(), out[a:e].data_ptr(), lse[a:e].data_ptr(),
+                                                         dout[a:e].data_ptr(), dqkv[a:e].data_ptr(), ds.data_ptr(), e - a, n, heads, float(scale),
+                                                         tb._stream()), "esam3_win_attn_train_backward")
+            part = tb.colsum(ds[:e - a])
+            dbias = part if dbias is None else dbias.add_(part)
+    return dqkv, dbias.reshape(heads, n, n)
 
 
 def attention_bias_idxs(ws: int) -> np.ndarray:

@@ -28,7 +28,7 @@ def install_cpu_kernels(monkeypatch):
         _act(xr, act).backward(dy)
         return xr.grad
 
-    def bn_fwd(x, gamma, beta, rm, rv, momentum, eps):
+    def bn_fwd(x, gamma, beta, rm, rv, momentum, eps, sync=None):   # `sync`: the layer's SyncBatchNorm setting (None here: one rank)
         c = x.shape[-1]
         x2 = x.reshape(-1, c)
         mean, var = x2.mean(0), x2.var(0, unbiased=False)
@@ -38,7 +38,7 @@ def install_cpu_kernels(monkeypatch):
         rv.mul_(1 - momentum).add_(momentum * var * n / (n - 1))
         return ((x - mean) * rstd * gamma + beta), mean, rstd
 
-    def bn_bwd(x, dy, gamma, mean, rstd):
+    def bn_bwd(x, dy, gamma, mean, rstd, sync=None):
         c = x.shape[-1]
         n = x.numel() // c
         xh = (x - mean) * rstd
