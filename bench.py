@@ -267,6 +267,66 @@ def main():
         elapsed = float(t.item())
     fg = float((masks > 0).float().mean().item()) if text else float(masks.float().mean().item())
 
+    # ---- two batches in flight (reported in config, never `value`): the same step from TWO engine replicas on two HIP streams, one Python
+    # thread each.  `value` above is one stream running its steps back to back (every round's definition); a serving process that keeps two
+    # batches in flight lets one batch's latency-bound backbone / decoder kernels fill the tails and stalls of the other's, and loses
+    # nothing on the power-bound GEMM launches (profiles/r06/two_stream_probe.txt, gemm_grid_cap.txt).  Same work per step, same results.
+    model2 = two_ips = None
+    if rank == 0 and world == 1 and not text and args.backbone != "sam3":
+        import threading
+        model2 = build_efficientsam3_image_model(device=dev, enable_inst_interactivity=True, backbone_type=args.backbone,
+                                                 model_name=args.model, dtype=args.dtype, state_dict=sd,
+                                                 dual_neck=not args.sam2_only, fuse_linear_chains=not args.no_fuse)
+
+        def make_step(mdl):
+            e_, b_ = mdl.engine, {"enc": None, "dec": None, "post": None}
+            x_ = x.clone()
+
+            def one():
+                b_["enc"] = o_ = e_.encode(x_, want_sam3=not args.sam2_only, want_sam2=True, out=b_["enc"])
+                b_["dec"] = lw, _ = e_.decode(o_["sam2_fpn"], pi_d, c_d, l_d, multimask_output=False, out=b_["dec"])
+                b_["post"] = e_.postprocess(lw, (1008, 1008), return_logits=False, out=b_["post"])
+                return b_["post"]
+            return one
+
+        steps2 = [make_step(model), make_step(model2)]
+        per = max(2, args.steps // 2)
+        gate2 = threading.Barrier(3)
+        means, errs2 = [None, None], []
+
+        def flight(i):
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    for _ in range(2):
+                        steps2[i]()
+                    torch.cuda.current_stream(dev).synchronize()
+                    gate2.wait()
+                    o_ = None
+                    for _ in range(per):
+                        o_ = steps2[i]()
+                    torch.cuda.current_stream(dev).synchronize()
+                    gate2.wait()
+                    means[i] = float(o_.float().mean().item())
+            except Exception as e:  # noqa: BLE001
+                errs2.append(f"{type(e).__name__}: {e}"[:200])
+                gate2.abort()
+
+        th2 = [threading.Thread(target=flight, args=(i,), daemon=True) for i in range(2)]
+        for t_ in th2:
+            t_.start()
+        try:
+            gate2.wait()
+            t4 = time.perf_counter()
+            gate2.wait()
+            two_ips = 2 * per * B / (time.perf_counter() - t4)
+        except threading.BrokenBarrierError:
+            two_ips = None
+        for t_ in th2:
+            t_.join(timeout=60)
+        if two_ips is not None and (errs2 or means[0] != means[1] or abs(means[0] - fg) > 1e-6):
+            two_ips = None    # both replicas must reproduce the timed region's masks
+
     # ---- PCIe-inclusive leg (reported in config, never `value`): B uint8 1024x1024 HWC images in pinned host
     # memory -> one H2D copy -> device antialiased resize to 1008^2 + normalise (P1) -> the same step
     host_incl = None
@@ -319,7 +379,7 @@ def main():
     # the ORIGINAL 1024x1024 size, i.e. including PIL -> tensor conversion, H2D, device resize, and the D2H copies of
     # float32 masks / IoU scores / low-res logits that the reference's contract returns
     api_ips = api2_ips = api2_err = None
-    if rank == 0 and world == 1 and not text:
+    if rank == 0 and world == 1 and not text and model2 is not None:
         try:
             from PIL import Image
             from efficientsam3_amd import Sam3Processor
@@ -350,9 +410,6 @@ def main():
             # hand-back with batch k + 1's encode -- two callers do, with the reference's API unchanged.  Reported beside the
             # one-caller figure, never instead of it.
             import threading
-            model2 = build_efficientsam3_image_model(device=dev, enable_inst_interactivity=True, backbone_type=args.backbone,
-                                                     model_name=args.model, dtype=args.dtype, state_dict=sd,
-                                                     dual_neck=not args.sam2_only, fuse_linear_chains=not args.no_fuse)
             callers = [(model, proc), (model2, Sam3Processor(model2))]
             lbl = [labels[i] for i in range(B)]
             reps2, errs = 6, []
@@ -393,7 +450,6 @@ def main():
             for t_ in ths:
                 t_.join(timeout=60)
             api2_err = errs[0] if errs else None
-            del model2
         except ImportError:
             api_ips = None
 
@@ -500,6 +556,9 @@ def main():
                                               "+ normalise -> the same step, on every rank at once (aggregate over the ranks, "
                                               "slowest rank's clock); measured after the timed region, not `value`",
                        "api_level_images_per_s": None if api_ips is None else round(api_ips, 1),
+                       "two_batches_in_flight_images_per_s": None if two_ips is None else round(two_ips, 1),
+                       "two_batches_in_flight_note": "the same step from two engine replicas on two HIP streams (one Python thread each), same "
+                                                     "results; `value` is ONE stream running its steps back to back",
                        "api_level_two_callers_images_per_s": None if api2_ips is None else round(api2_ips, 1),
                        "api_level_two_callers_note": "the same calls from two Python threads, one model replica each on this GPU (the API is "
                                                      "synchronous: one caller cannot overlap a batch's hand-back with the next batch's encode)"

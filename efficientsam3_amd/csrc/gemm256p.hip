@@ -771,7 +771,9 @@ int esam3_launch_gemm256p(const GemmParams& p, hipStream_t stream) {
     HIP_CHECK_RET(hipGetDeviceProperties(&prop, dev));
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  const int64_t grid = tiles < n_cu ? tiles : n_cu;  // persistent: one workgroup per CU
+  int64_t grid = tiles < n_cu ? tiles : n_cu;  // persistent: one workgroup per CU
+  // -DESAM3_DEV builds: ESAM3_P_GRID=n caps the persistent grid (how much of a power-bound launch's time depends on the CU count?)
+  if (const int cap = esam3_dev_flag("ESAM3_P_GRID")) grid = grid < cap ? grid : cap;
   if (p.out_f32) {  // fp32 output / residual stream (esam3_gemm256p_ok has checked: no activation, plain rows)
     void (*k32)(GemmParams, GemmDivs) = p.res ? gemm256p_kernel<ACT_NONE, true, true> : gemm256p_kernel<ACT_NONE, false, true>;
     if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(k32), (int)lds)) return -1;
