@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the legs reported under config (two batches in flight, PCIe-inclusive, API level): profiler passes want one "
+                         "stream and one dominant launch per step")
     ap.add_argument("--workload", default="interactive", choices=["interactive", "text"],
                     help="interactive: set_image_batch + predict_inst (headline, BASELINE configs[1]); text: image encoder + "
                          "MobileCLIP-S0 text encoder + PCS grounding detector, one text prompt per image (configs[3] with "
@@ -272,7 +275,7 @@ def main():
     # batches in flight lets one batch's latency-bound backbone / decoder kernels fill the tails and stalls of the other's, and loses
     # nothing on the power-bound GEMM launches (profiles/r06/two_stream_probe.txt, gemm_grid_cap.txt).  Same work per step, same results.
     model2 = two_ips = None
-    if rank == 0 and world == 1 and not text and args.backbone != "sam3":
+    if rank == 0 and world == 1 and not text and args.backbone != "sam3" and not args.headline_only:
         import threading
         model2 = build_efficientsam3_image_model(device=dev, enable_inst_interactivity=True, backbone_type=args.backbone,
                                                  model_name=args.model, dtype=args.dtype, state_dict=sd,
@@ -330,7 +333,7 @@ def main():
     # ---- PCIe-inclusive leg (reported in config, never `value`): B uint8 1024x1024 HWC images in pinned host
     # memory -> one H2D copy -> device antialiased resize to 1008^2 + normalise (P1) -> the same step
     host_incl = None
-    if not text:   # every rank runs it (N ranks pull their shards over their own PCIe links at the same time)
+    if not text and not args.headline_only:   # every rank runs it (N ranks pull their shards over their own PCIe links at the same time)
         u8 = torch.from_numpy(np.random.default_rng(rank).integers(0, 256, (B, 1024, 1024, 3), dtype=np.uint8)).pin_memory()
         # two device buffers: batch k + 1 crosses the link on a side stream while batch k is resized, encoded and decoded (a
         # streaming caller's pipeline; round 5 issued the copy on the compute stream, so the device idled for every transfer)
