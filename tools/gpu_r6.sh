@@ -1,0 +1,186 @@
+#!/bin/bash
+# Round 6: every gpurun call of the round as a subcommand (usage: gpurun -- "bash tools/gpu_r6.sh <letter>"); outputs under gpurun_out/r06/,
+# the ones quoted in DESIGN.md copied to profiles/r06/ (profiles/README.md names the file -> subcommand).
+O=gpurun_out/r06
+mkdir -p $O
+R=$GRAFT_REPO_ROOT
+case "$1" in
+a)
+  # round 6, GPU call A: (1) the exact-lattice tests of the two up-conv kernels, (2) the dominant launch on random / GELU-shaped / zero
+  # operands with the chip's power and clock sampled beside it (is the 0.53 a schedule limit or the power budget?), (3) the backbone
+  # counter pass BEFORE this round's kernel work, (4) the headline line and the API-level probe on this box.
+  # power / clock beside a sustained run of the dominant shape (400 launches ~ 0.9 s per data mode)
+  # backbone counters, before
+  # headline + API level on this box
+  timeout 600 python -m pytest tests/test_lattice_gpu.py -q -m gpu -k "upconv" --timeout 500 > $O/a_lattice_upconv.txt 2>&1
+  tail -5 $O/a_lattice_upconv.txt | cut -c1-300
+  {
+  for mode in random gelu zeros random; do
+    echo "== operands: $mode"
+    if [ $mode = random ]; then unset ESAM3_BENCH_DATA; else export ESAM3_BENCH_DATA=$mode; fi
+    timeout 200 python tools/bench_gemm.py "up-conv,neck L0 3x3,head.3,ViT-H fc1" 2>&1 | grep -v "amdgpu.ids\|^lib\|^kernel"
+  done
+  unset ESAM3_BENCH_DATA
+  } > $O/a_gemm_operands.txt 2>&1
+  cat $O/a_gemm_operands.txt
+  {
+  for mode in random zeros; do
+    if [ $mode = random ]; then unset ESAM3_BENCH_DATA; else export ESAM3_BENCH_DATA=$mode; fi
+    ESAM3_BENCH_ITERS=1500 timeout 120 python tools/bench_gemm.py "up-conv" > $O/a_sustained_$mode.txt 2>&1 &
+    BP=$!
+    sleep 6
+    for i in 1 2 3 4 5 6 7 8; do
+      echo "-- $mode sample $i"; rocm-smi --showpower --showclocks 2>/dev/null | grep -i "power\|sclk\|mclk" | head -6
+      sleep 0.4
+    done
+    wait $BP
+    grep "up-conv" $O/a_sustained_$mode.txt
+  done
+  unset ESAM3_BENCH_DATA
+  } > $O/a_power_clock.txt 2>&1
+  tail -40 $O/a_power_clock.txt | cut -c1-200
+  cd /tmp && export TMPDIR=/tmp
+  P=$R/$O/pmc_before
+  mkdir -p $P
+  rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace -d $P/sq1 -o a --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES --kernel-trace -d $P/sq2 -o b --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $P/fetch -o f --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $P/write -o w --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  cd $R
+  python tools/pmc_kernels.py --pass $P/sq1 --pass $P/sq2 --pass $P/fetch --pass $P/write \
+    --match mbconv3s,mbconv3b,mla1,mla2d,kvprep,stem_dsconv,gemm256p,upconv_narrow,conv3x3_narrow,resize_shuffle --out $O/pmc_backbone_before.txt > /dev/null 2>&1
+  head -60 $O/pmc_backbone_before.txt | cut -c1-260
+  find $P -name "*.csv" -size +4M -delete
+  ESAM3_BENCH_PROFILE_OUT=$O/a_bench_per_launch.json timeout 400 python bench.py > $O/a_bench.json 2> $O/a_bench.err
+  tail -c 1500 $O/a_bench.json
+  timeout 300 python tools/api_level_probe.py > $O/a_api_probe.txt 2>&1
+  tail -15 $O/a_api_probe.txt | cut -c1-200
+
+  ;;
+b)
+  # round 6, GPU call B: GPU timeline of API-level steps (where the device idles) + the double-buffered PCIe-inclusive leg
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf /tmp/tl && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/tl -o t --output-format csv -- python $R/tools/api_timeline.py run > $R/$O/b_api_timeline_host.txt 2>&1
+  cd $R
+  grep "host step" $O/b_api_timeline_host.txt
+  python tools/api_timeline.py report /tmp/tl > $O/b_api_timeline.txt 2>&1
+  cat $O/b_api_timeline.txt | cut -c1-200
+  timeout 400 python bench.py --no-cpu-baseline > $O/b_bench.json 2> $O/b_bench.err
+  python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r06/b_bench.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], {k: v for k, v in d["config"].items() if k.endswith("images_per_s")})
+PY
+
+  ;;
+c)
+  # round 6, GPU call C: the API path after (1) the helper-thread staging of chunk 2 and (2) hand-backs started before any wait
+  timeout 600 python -m pytest tests/test_e2e_gpu.py -q -m gpu -k "batch or processor or api or host or alias or preprocess" --timeout 500 > $O/c_tests.txt 2>&1
+  tail -4 $O/c_tests.txt | cut -c1-300
+  timeout 300 python tools/api_level_probe.py 2>&1 | grep -v amdgpu > $O/c_api_probe.txt
+  head -12 $O/c_api_probe.txt | cut -c1-200
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf /tmp/tl && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace -d /tmp/tl -o t --output-format csv -- python $R/tools/api_timeline.py run > $R/$O/c_api_timeline_host.txt 2>&1
+  cd $R
+  grep "host step" $O/c_api_timeline_host.txt | tail -3
+  python tools/api_timeline.py report /tmp/tl > $O/c_api_timeline.txt 2>&1
+  tail -30 $O/c_api_timeline.txt | cut -c1-160
+  timeout 500 python bench.py --no-cpu-baseline > $O/c_bench.json 2> $O/c_bench.err
+  tail -3 $O/c_bench.err
+  python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r06/c_bench.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], {k: v for k, v in d["config"].items() if k.endswith("images_per_s") or "FAILED" in str(v)})
+PY
+
+  ;;
+d)
+  # round 6, GPU call D: the new parity pins (three students, scopes), then the whole GPU suite with its slowest tests listed
+  timeout 900 python -m pytest tests/test_stage1_step.py tests/test_e2e_gpu.py tests/test_pcs.py -q -m gpu -rP --timeout 600 \
+    -k "b0_training or repvit_m2_3 or tiny_vit_21m or profiler_scopes or (pcs_engine_vs_golden and bf16)" > $O/d_new_pins.txt 2>&1
+  grep -E "^\[stage-1|gradients:|parameters after|BatchNorm running|passed|failed|^E " $O/d_new_pins.txt | cut -c1-330
+  timeout 1500 python -m pytest tests -q -m gpu -x --durations=60 --timeout 900 > $O/d_full_suite.txt 2>&1
+  tail -75 $O/d_full_suite.txt | cut -c1-200
+
+  ;;
+e)
+  # round 6, GPU call E: idle time between the kernels of a headline step
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf /tmp/kt && timeout 300 rocprofv3 --kernel-trace -d /tmp/kt -o t --output-format csv -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $R/$O/e_bench_traced.json 2>/dev/null
+  cd $R
+  python tools/kernel_gaps.py /tmp/kt --out $O/e_kernel_gaps.txt | cut -c1-200
+
+  ;;
+f)
+  # round 6, GPU call F: TinyViT MBConv on the mbconv3s design with GELU epilogues: op test, TinyViT parity tests, config-3 shard bench
+  timeout 600 python -m pytest tests/test_ops_gpu.py tests/test_students_gpu.py tests/test_bf16_distribution.py -q -m gpu -rP --timeout 500 \
+    -k "mbconv3_gelu or tinyvit" > $O/f_tinyvit_tests.txt 2>&1
+  grep -E "passed|failed|^E |\[dist" $O/f_tinyvit_tests.txt | cut -c1-300
+  ESAM3_BENCH_PROFILE_OUT=$O/f_bench_tinyvit_per_launch.json timeout 400 python bench.py --backbone tinyvit --model 11m --no-cpu-baseline > $O/f_bench_tinyvit.json 2> $O/f_bench_tinyvit.err
+  python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r06/f_bench_tinyvit.json").read().strip().splitlines()[-1])
+print("tinyvit-11m", d["value"], d["ms_per_step"])
+p = json.load(open("gpurun_out/r06/f_bench_tinyvit_per_launch.json"))["per_tag"]
+for r in sorted(p, key=lambda r: -r["ms"])[:12]:
+    print(f"  {r['ms']:.3f} x{r['launches']} {r['tag'][:90]}")
+PY
+
+  ;;
+g)
+  ESAM3_DEV_LIB=build_dev/libesam3_dev.so ESAM3_OP_REPEAT=20 timeout 300 python tools/evit_fused_bench.py tv.0 tv.0:v2 tv.hs s1.1 2>&1 | grep -v amdgpu | tee $O/g_tv_mbconv_ab.txt
+
+  ;;
+h)
+  # round 6, GPU call H: host worker threads of the API path (PIL staging + mask widening): 8 / 16 / 32 / 64
+  for n in 16 8 32 64 16; do
+    echo "== ESAM3_HOST_THREADS=$n"
+    ESAM3_HOST_THREADS=$n timeout 200 python tools/api_level_probe.py 2>&1 | grep -E "api step, results|keep previous|rep 1|stage 32 PIL images, rgbx np" | cut -c1-220
+  done > $O/h_api_host_threads.txt 2>&1
+  cat $O/h_api_host_threads.txt
+
+  ;;
+i)
+  # round 6, GPU call I: per-operator roofline of a B1 batch-32 training step (+ the throughput lines of three students)
+  timeout 400 python tools/stage1_step_roofline.py --model b1 --batch 32 2>&1 | grep -v amdgpu > $O/i_roofline_stage1_step_b1_b32.md
+  head -40 $O/i_roofline_stage1_step_b1_b32.md | cut -c1-220
+  timeout 300 python tools/bench_stage1_step.py --model b1 --batch 32 --steps 5 2>/dev/null | tail -1 > $O/i_bench_stage1_step_b1_b32.json
+  python -c "
+import json; d=json.loads(open('$O/i_bench_stage1_step_b1_b32.json').read()); print(d['value'], d['ms_per_step'], d['roofline']['frac'])"
+
+  ;;
+j)
+  # round 6, GPU call J: two-caller test, chunked window-attention backward, per-layer SyncBatchNorm setting, training steps after those changes
+  timeout 900 python -m pytest tests/test_e2e_gpu.py tests/test_train_tinyvit.py tests/test_stage1_step.py tests/test_dist_gloo.py -q -m gpu --timeout 600 \
+    -k "two_callers or window_attention or training_step or rccl or tinyvit_block" > $O/j_tests.txt 2>&1
+  tail -6 $O/j_tests.txt | cut -c1-300
+
+  ;;
+k)
+  # round 6, GPU call K: does a power-bound GEMM launch need all 256 CUs?  (dev library, persistent grid capped)
+  for g in 256 248 240 224 208 192 160 128 256; do
+    echo "== ESAM3_P_GRID=$g"
+    ESAM3_P_GRID=$g ESAM3_DEV_LIB=build_dev/libesam3_dev.so ESAM3_BENCH_ITERS=40 timeout 120 python tools/bench_gemm.py "up-conv,neck L1 3x3,head.3" 2>&1 | grep "ms"
+  done > $O/k_gemm_grid_cap.txt 2>&1
+  cat $O/k_gemm_grid_cap.txt
+
+  ;;
+l)
+  for g in 0 224 192 160 128; do
+    ESAM3_LIB=build_dev/libesam3_dev.so ESAM3_P_GRID=$g timeout 300 python tools/two_stream_probe.py 2>&1 | grep "streams="
+  done > $O/l_two_stream_probe.txt 2>&1
+  cat $O/l_two_stream_probe.txt | cut -c1-120
+
+  ;;
+m)
+  ( time python bench.py > $O/m_bench.json 2> $O/m_bench.err ) 2>&1 | grep real
+  tail -2 $O/m_bench.err
+  python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r06/m_bench.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["cpu_baseline"]["value"], {k: v for k, v in d["config"].items() if k.endswith("images_per_s") or "FAILED" in str(v)})
+PY
+
+  ;;
+*) echo "usage: $0 {a..m}"; exit 2 ;;
+esac
