@@ -127,6 +127,7 @@ SIGNATURES = {
     "esam3_train_conv3x3": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "esam3_train_dwconv": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "esam3_train_dwconv_dgrad": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "esam3_stem_im2col": (_I, [_I, _P, _P, _I, _I, _I, _P]),
     "esam3_train_stem": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
     "esam3_resize_bilinear_backward": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_bn_train_workspace": (_L, [_I]),

@@ -30,6 +30,11 @@ namespace {
 template <int DT> struct TElem;  // 0 f32, 1 bf16
 template <> struct TElem<0> {
   using type = float;
+  struct vec8 { float4 a, b; };   // 8 elements as loaded (unpacked later: lets a kernel issue many loads before the first use)
+  static __device__ inline vec8 loadraw(const float* p) { return vec8{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)}; }
+  static __device__ inline void unpack(const vec8& q, float* v) {
+    v[0] = q.a.x; v[1] = q.a.y; v[2] = q.a.z; v[3] = q.a.w; v[4] = q.b.x; v[5] = q.b.y; v[6] = q.b.z; v[7] = q.b.w;
+  }
   static __device__ inline void load8(const float* p, float* v) {
     const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -41,6 +46,16 @@ template <> struct TElem<0> {
 };
 template <> struct TElem<1> {
   using type = uint16_t;
+  typedef uint4 vec8;
+  static __device__ inline vec8 loadraw(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ inline void unpack(const vec8& q, float* v) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
   static __device__ inline void load8(const uint16_t* p, float* v) {
     const uint4 q = *reinterpret_cast<const uint4*>(p);
     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
@@ -237,6 +252,50 @@ __global__ __launch_bounds__(256) void colsum_kernel(const typename TElem<DT>::t
   partial[(int64_t)blockIdx.y * N + c] = s;
 }
 
+// Round 6: the same column sums with 16-byte loads.  The kernel above gives a thread ONE column and walks its rows with 2-byte (bf16) loads:
+// 0.3 TB/s on [508 032][256] (profiles/r06/roofline_stage1_step_b1_b32.md: 3.1 ms of a 65 ms step in 19 launches).  Here a workgroup is
+// (N / 8 channel groups) x (256 / (N / 8) row lanes); a thread sums 8 channels of every RL-th row of its split, four rows in flight; the row
+// lanes meet in LDS in lane order; partial [split][N] as before (same reduce kernel, fixed order: deterministic).  N % 8 == 0, N <= 2048.
+template <int DT>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const typename TElem<DT>::type* __restrict__ dy, int64_t M, int N, int64_t rows_per_split,
+                                                         float* __restrict__ partial) {
+  __shared__ float red[256 * 8];
+  const int C8 = N / 8, RL = 256 / C8;
+  const int cg = threadIdx.x % C8, rl = threadIdx.x / C8;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_split, r1 = r0 + rows_per_split < M ? r0 + rows_per_split : M;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rl < RL) {
+    int64_t r = r0 + rl;
+    for (; r + 3 * (int64_t)RL < r1; r += 4 * (int64_t)RL) {
+      float u0[8], u1[8], u2[8], u3[8];
+      TElem<DT>::load8(dy + (r * C8 + cg) * 8, u0);
+      TElem<DT>::load8(dy + ((r + RL) * C8 + cg) * 8, u1);
+      TElem<DT>::load8(dy + ((r + 2 * (int64_t)RL) * C8 + cg) * 8, u2);
+      TElem<DT>::load8(dy + ((r + 3 * (int64_t)RL) * C8 + cg) * 8, u3);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (u0[e] + u1[e]) + (u2[e] + u3[e]);
+    }
+    for (; r < r1; r += RL) {
+      float u[8];
+      TElem<DT>::load8(dy + (r * C8 + cg) * 8, u);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += u[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(rl * C8 + cg) * 8 + e] = s[e];
+  }
+  __syncthreads();
+  if (rl == 0) {
+    float* dst = partial + (int64_t)blockIdx.x * N + cg * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = 0.f;
+      for (int q = 0; q < RL; ++q) t += red[(q * C8 + cg) * 8 + e];
+      dst[e] = t;
+    }
+  }
+}
+
 // ---- per-channel scale / shift of an NHWC tensor, the elementwise half of RepViT's RepVGGDW and SqueezeExcite (round 5) ------------------
 //   out[b][p][c] = add[b][p][c] + x[b][p][c] * (mul[b * mul_bs + c] + plus_one) + bias[b * bias_bs + c] * bias_scale
 // mul / bias fp32, per channel (batch stride 0) or per (image, channel) (batch stride C); add and bias optional.  What it stands for:
@@ -337,30 +396,39 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const typename TElem<DT>:
   const int CG = C >> 3, RL = 256 / CG;
   const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
   const int kh = blockIdx.y;
-  const int64_t npx = (int64_t)B * OH * OW;
-  const int64_t per = (npx + gridDim.x - 1) / gridDim.x;
-  const int64_t p0 = (int64_t)blockIdx.x * per, p1 = p0 + per < npx ? p0 + per : npx;
+  // Round 6: a split is a range of output ROWS (b, oy); the input row iy of this workgroup's kernel row is uniform per output row, and a thread
+  // walks the row's pixels with its lane stride -- no per-pixel index arithmetic (the first version recovered (b, oy, ox) from a flat 64-bit
+  // pixel index with three divisions per pixel and kernel row: 1.0 TB/s on tensors that stream at 3.4, profiles/r06/roofline_stage1_step_*.md).
+  // The summation order inside a split changed with it (rows, then lanes): still fixed, repeats stay bit-identical.
+  const int64_t nrows = (int64_t)B * OH;
+  const int64_t per = (nrows + gridDim.x - 1) / gridDim.x;
+  const int64_t q0 = (int64_t)blockIdx.x * per, q1 = q0 + per < nrows ? q0 + per : nrows;
   float acc[KS][8];
 #pragma unroll
   for (int t = 0; t < KS; ++t)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
   if (rl < RL)
-    for (int64_t p = p0 + rl; p < p1; p += RL) {
-      const int ox = (int)(p % OW), oy = (int)((p / OW) % OH);
-      const int64_t b = p / ((int64_t)OW * OH);
+    for (int64_t q = q0; q < q1; ++q) {
+      const int64_t b = q / OH;
+      const int oy = (int)(q - b * OH);
       const int iy = oy * stride + kh - PAD;
       if (iy < 0 || iy >= H) continue;
-      float g[8];
-      TElem<DT>::load8(dy + p * C + cg * 8, g);
+      const typename TElem<DT>::type* dyr = dy + q * OW * (int64_t)C + cg * 8;
+      const typename TElem<DT>::type* xr = x + (b * H + iy) * (int64_t)W * C + cg * 8;
+#pragma unroll 2
+      for (int ox = rl; ox < OW; ox += RL) {
+        float g[8];
+        TElem<DT>::load8(dyr + (int64_t)ox * C, g);
 #pragma unroll
-      for (int kw = 0; kw < KS; ++kw) {
-        const int ix = ox * stride + kw - PAD;
-        if (ix < 0 || ix >= W) continue;
-        float v[8];
-        TElem<DT>::load8(x + ((b * H + iy) * (int64_t)W + ix) * C + cg * 8, v);
+        for (int kw = 0; kw < KS; ++kw) {
+          const int ix = ox * stride + kw - PAD;
+          if (ix < 0 || ix >= W) continue;
+          float v[8];
+          TElem<DT>::load8(xr + (int64_t)ix * C, v);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[kw][e] = fmaf(g[e], v[e], acc[kw][e]);
+          for (int e = 0; e < 8; ++e) acc[kw][e] = fmaf(g[e], v[e], acc[kw][e]);
+        }
       }
     }
   if (rl < RL)
@@ -373,6 +441,88 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const typename TElem<DT>:
     float s = 0.f;
     for (int l = 0; l < RL; ++l) s += red[l * KS * C + i];
     partial[((int64_t)blockIdx.x * KS + kh) * KS * C + i] = s;
+  }
+}
+
+// Round 6, 3x3 only: ALL nine taps in one workgroup.  The kernel above runs one workgroup per kernel row, so dy and x cross the memory system
+// three times each (1.0 - 1.1 TB/s of algorithmic bytes = 3.2 TB/s of traffic: it was at the streaming rate of what it asked for); here a
+// thread keeps the 9 x 8 sums of its (8-channel group, pixel lane), reads dy once per pixel and the three input rows out of L1 / L2 (the
+// neighbouring output row needs two of them again).  partial [split][9][C], the same layout: the finalize kernel is shared.
+template <int DT>
+__global__ __launch_bounds__(256) void dw_wgrad3_kernel(const typename TElem<DT>::type* __restrict__ x,
+                                                        const typename TElem<DT>::type* __restrict__ dy, int B, int H, int W, int C, int stride,
+                                                        float* __restrict__ partial) {
+  extern __shared__ float red[];  // [RL][C]: the lanes meet tap by tap (8 KB instead of 72: four workgroups per CU -- the walk is latency-bound)
+  const int OH = (H + stride - 1) / stride, OW = (W + stride - 1) / stride;
+  const int CG = C >> 3, RL = 256 / CG;
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+  const int64_t nrows = (int64_t)B * OH;
+  const int64_t per = (nrows + gridDim.x - 1) / gridDim.x;
+  const int64_t q0 = (int64_t)blockIdx.x * per, q1 = q0 + per < nrows ? q0 + per : nrows;
+  float acc[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+  if (rl < RL)
+    for (int64_t q = q0; q < q1; ++q) {
+      const int64_t b = q / OH;
+      const int oy = (int)(q - b * OH);
+      const typename TElem<DT>::type* dyr = dy + q * OW * (int64_t)C + cg * 8;
+      const typename TElem<DT>::type* xb = x + b * H * (int64_t)W * C + cg * 8;
+      const int iy0 = oy * stride - 1;
+      // Branch-free taps: every tap's address is clamped into the image and its contribution multiplied by 0 / 1.  With `continue`s on the
+      // image border every load sat in its own basic block and the nine loads of a pixel were nine serial trips to L2 -- that, not traffic or
+      // occupancy, was what held the first versions of this kernel at 1 TB/s.
+      float rv[3];
+      int iyc[3];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int iy = iy0 + kh;
+        rv[kh] = (iy >= 0 && iy < H) ? 1.f : 0.f;
+        iyc[kh] = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+      }
+      for (int ox = rl; ox < OW; ox += RL) {
+        typename TElem<DT>::vec8 raw[9];
+        float cv[3];
+        int ixc[3];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int ix = ox * stride + kw - 1;
+          cv[kw] = (ix >= 0 && ix < W) ? 1.f : 0.f;
+          ixc[kw] = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+        }
+        const typename TElem<DT>::vec8 graw = TElem<DT>::loadraw(dyr + (int64_t)ox * C);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) raw[kh * 3 + kw] = TElem<DT>::loadraw(xb + ((int64_t)iyc[kh] * W + ixc[kw]) * C);
+        float g[8];
+        TElem<DT>::unpack(graw, g);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            float v[8];
+            TElem<DT>::unpack(raw[kh * 3 + kw], v);
+            const float m = rv[kh] * cv[kw];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[kh * 3 + kw][e] = fmaf(g[e] * m, v[e], acc[kh * 3 + kw][e]);
+          }
+      }
+    }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if (rl < RL)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[rl * C + cg * 8 + e] = acc[t][e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) {
+      float s = 0.f;
+      for (int l = 0; l < RL; ++l) s += red[l * C + i];
+      partial[((int64_t)blockIdx.x * 9 + t) * C + i] = s;
+    }
+    __syncthreads();
   }
 }
 
@@ -413,6 +563,57 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const typename TElem<DT>:
       }
     }
     TElem<DT>::store8(dx + px * C + cg * 8, acc);
+  }
+}
+
+// Round 6: the stride-2 3x3 data gradient (the transposed convolution behind the four stride-2 MBConvs) with the weights in LDS.  The generic
+// kernel above fetched its 8 channels' taps as 72 scalar global loads per thread -- 0.6 TB/s of algorithmic bytes on tensors that stream at
+// 3.4 TB/s through the stride-1 path (profiles/r06/roofline_stage1_step_b1_b32.md: 4.1 ms of a 65 ms step in four launches).  Here a
+// workgroup stages w as [tap][C] once (two 16-byte LDS reads per tap and thread, conflict-free: consecutive threads = consecutive channel
+// groups) and every thread walks input pixels; an input pixel (iy, ix) receives the taps whose parity matches: 1, 2 or 4 of the nine.
+template <int DT>
+__global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const typename TElem<DT>::type* __restrict__ dy, const float* __restrict__ w,
+                                                          typename TElem<DT>::type* __restrict__ dx, int B, int H, int W, int C) {
+  extern __shared__ float sw[];   // [9][C]
+  for (int i = threadIdx.x; i < 9 * C; i += 256) sw[(i % 9) * C + i / 9] = w[i];
+  __syncthreads();
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const unsigned CG = (unsigned)C >> 3;
+  // one workgroup = one input row (b, iy): the row's taps (kh, oy) are workgroup-uniform, the per-item index needs ONE 32-bit division
+  // (the first version of this kernel, like the generic one, spent four 64-bit divisions per item on (b, iy, ix, cg))
+  for (unsigned row = blockIdx.x; row < (unsigned)(B * H); row += gridDim.x) {
+    const unsigned b = row / (unsigned)H, iy = row - b * (unsigned)H;
+    const int nkh = (iy & 1) ? 2 : 1;
+    int khs[2], oys[2];
+    for (int a = 0; a < 2; ++a) {
+      khs[a] = (iy & 1) ? 2 * a : 1;
+      oys[a] = ((int)iy + 1 - khs[a]) >> 1;
+    }
+    const typename TElem<DT>::type* dyb = dy + (int64_t)b * OH * OW * C;
+    typename TElem<DT>::type* dxr = dx + (int64_t)row * W * C;
+    for (unsigned j = threadIdx.x; j < (unsigned)W * CG; j += 256) {
+      const unsigned ix = j / CG, cg = j - ix * CG;
+      float acc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+      const int nkw = (ix & 1) ? 2 : 1;
+      for (int a = 0; a < nkh; ++a) {
+        const int kh = khs[a], oy = oys[a];
+        if (oy >= OH) continue;
+        for (int c2 = 0; c2 < nkw; ++c2) {
+          const int kw = (ix & 1) ? 2 * c2 : 1;
+          const int ox = ((int)ix + 1 - kw) >> 1;
+          if (ox >= OW) continue;
+          float g[8];
+          TElem<DT>::load8(dyb + ((int64_t)oy * OW + ox) * C + cg * 8, g);
+          const float4 w0 = *reinterpret_cast<const float4*>(sw + (kh * 3 + kw) * C + cg * 8);
+          const float4 w1 = *reinterpret_cast<const float4*>(sw + (kh * 3 + kw) * C + cg * 8 + 4);
+          acc[0] = fmaf(g[0], w0.x, acc[0]); acc[1] = fmaf(g[1], w0.y, acc[1]); acc[2] = fmaf(g[2], w0.z, acc[2]); acc[3] = fmaf(g[3], w0.w, acc[3]);
+          acc[4] = fmaf(g[4], w1.x, acc[4]); acc[5] = fmaf(g[5], w1.y, acc[5]); acc[6] = fmaf(g[6], w1.z, acc[6]); acc[7] = fmaf(g[7], w1.w, acc[7]);
+        }
+      }
+      TElem<DT>::store8(dxr + (int64_t)j * 8, acc);
+    }
   }
 }
 
@@ -914,7 +1115,10 @@ int esam3_colsum(int dtype, const void* dy, int64_t M, int N, float* out, void* 
   const int zs = (int)((M + rps - 1) / rps);
   float* pb = (float*)workspace;
   const dim3 g2((unsigned)((N + 255) / 256), (unsigned)zs);
-  if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<0>, g2, dim3(256), 0, s, (const float*)dy, N, M, N, rps, pb);
+  if (N % 8 == 0 && N <= 2048 && (((uintptr_t)dy) & 15) == 0) {   // round 6: 16-byte loads, row lanes (colsum_vec_kernel)
+    if (dtype == 0) hipLaunchKernelGGL(colsum_vec_kernel<0>, dim3((unsigned)zs), dim3(256), 0, s, (const float*)dy, M, N, rps, pb);
+    else hipLaunchKernelGGL(colsum_vec_kernel<1>, dim3((unsigned)zs), dim3(256), 0, s, (const uint16_t*)dy, M, N, rps, pb);
+  } else if (dtype == 0) hipLaunchKernelGGL(colsum_kernel<0>, g2, dim3(256), 0, s, (const float*)dy, N, M, N, rps, pb);
   else hipLaunchKernelGGL(colsum_kernel<1>, g2, dim3(256), 0, s, (const uint16_t*)dy, N, M, N, rps, pb);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, pb, zs, (int64_t)N, out);
   HIP_CHECK_RET(hipGetLastError());
@@ -979,6 +1183,16 @@ int esam3_dwconv_wgrad(int dtype, const void* x, const void* dy, int B, int H, i
   const int RL = 256 / (C / 8);
   const size_t lds = sizeof(float) * (size_t)RL * ksize * C;
   float* partial = (float*)workspace;
+  if (ksize == 3) {   // round 6: all nine taps in one workgroup (dw_wgrad3_kernel)
+    const int64_t nrows = (int64_t)B * OH;
+    const int sp3 = (int)(nrows < 704 ? nrows : 704);   // 704 x 9 x C floats fit the workspace sized for 256 x 25 x C
+    const size_t lds3 = sizeof(float) * (size_t)RL * C;
+    if (dtype == 0) hipLaunchKernelGGL(dw_wgrad3_kernel<0>, dim3((unsigned)sp3), dim3(256), lds3, s, (const float*)x, (const float*)dy, B, H, W, C, stride, partial);
+    else hipLaunchKernelGGL(dw_wgrad3_kernel<1>, dim3((unsigned)sp3), dim3(256), lds3, s, (const uint16_t*)x, (const uint16_t*)dy, B, H, W, C, stride, partial);
+    hipLaunchKernelGGL(dw_wgrad_finalize_kernel, dim3((unsigned)((9 * C + 63) / 64)), dim3(256), 0, s, partial, sp3, C, 9, dw);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
   const dim3 grid((unsigned)splits, (unsigned)ksize);
 #define ESAM3_DWW(DT_, KS_, T_)                                                                                                   \
   do {                                                                                                                            \
@@ -1073,6 +1287,14 @@ int esam3_dwconv_dgrad(int dtype, const void* dy, const float* w, void* dx, int 
   const int64_t total = (int64_t)B * H * W * (C / 8);
   const unsigned grid = (unsigned)(total / 256 + 1 < 32768 ? total / 256 + 1 : 32768);
   hipStream_t s = (hipStream_t)stream;
+  if (stride == 2 && ksize == 3 && (size_t)9 * C * 4 <= 64 * 1024) {   // round 6: weights in LDS
+    const size_t lds = (size_t)9 * C * 4;
+    const unsigned g2 = (unsigned)((int64_t)B * H < 16384 ? (int64_t)B * H : 16384);   // one workgroup per input row (b, iy), strided above that
+    if (dtype == 0) hipLaunchKernelGGL(dw_dgrad_s2_kernel<0>, dim3(g2), dim3(256), lds, s, (const float*)dy, w, (float*)dx, B, H, W, C);
+    else hipLaunchKernelGGL(dw_dgrad_s2_kernel<1>, dim3(g2), dim3(256), lds, s, (const uint16_t*)dy, w, (uint16_t*)dx, B, H, W, C);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
   if (dtype == 0 && ksize == 3) hipLaunchKernelGGL((dw_dgrad_kernel<0, 3>), dim3(grid), dim3(256), 0, s, (const float*)dy, w, (float*)dx, B, H, W, C, stride);
   else if (dtype == 0) hipLaunchKernelGGL((dw_dgrad_kernel<0, 5>), dim3(grid), dim3(256), 0, s, (const float*)dy, w, (float*)dx, B, H, W, C, stride);
   else if (ksize == 3) hipLaunchKernelGGL((dw_dgrad_kernel<1, 3>), dim3(grid), dim3(256), 0, s, (const uint16_t*)dy, w, (uint16_t*)dx, B, H, W, C, stride);

@@ -74,6 +74,41 @@ __global__ void pack_stem_weight_kernel(const float* __restrict__ w, float* __re
   out[i] = w[(co * 3 + c) * 9 + tap];
 }
 
+// Round 6: the `x` operand of the stem's weight gradient, im2col of the 3x3 / stride 2 / padding 1 stem on the NCHW fp32 image: row = output
+// pixel, column k = c * 9 + kh * 3 + kw (torch.nn.functional.unfold's order), columns 27..31 zero, in the activation dtype.  A thread writes 8
+// columns (16 bytes in bf16) of one row; 64 threads = 16 consecutive rows = 1 KB of contiguous output.  Replaces unfold + permute + pad + cast
+// (four ATen passes, 2.1 ms at batch 32, profiles/r06/roofline_stage1_step_b1_b32.md).
+template <typename T>
+__global__ void stem_im2col_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int H, int W, int OH, int OW) {
+  const int64_t total = (int64_t)B * OH * OW * 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 3);
+    const int64_t row = i >> 2;
+    const int ox = (int)(row % OW), oy = (int)((row / OW) % OH);
+    const int64_t b = row / ((int64_t)OW * OH);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = q * 8 + e;
+      float val = 0.f;
+      if (k < 27) {
+        const int c = k / 9, t = k - c * 9, kh = t / 3, kw = t - kh * 3;
+        const int iy = oy * 2 + kh - 1, ix = ox * 2 + kw - 1;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) val = img[((b * 3 + c) * H + iy) * (int64_t)W + ix];
+      }
+      v[e] = val;
+    }
+    if constexpr (sizeof(T) == 2) {
+      uint4 o;
+      o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+      *reinterpret_cast<uint4*>(out + row * 32 + q * 8) = o;
+    } else {
+      *reinterpret_cast<float4*>(out + row * 32 + q * 8) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(out + row * 32 + q * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  }
+}
+
 // dx[b][iy][ix][c] = sum over the output pixels (oy, ox) whose bilinear footprint contains (iy, ix) of weight * dy[b][oy][ox][c]:
 // the exact adjoint of resize_bilinear_kernel (same source coordinate, clamping and fraction arithmetic); gather form, fixed order.
 template <typename T>
@@ -225,6 +260,18 @@ int esam3_train_stem(int dtype, const float* img, const float* w, void* out, int
   hipLaunchKernelGGL(pack_stem_weight_kernel, dim3((unsigned)((27 * Cout + 255) / 256)), dim3(256), 0, s, w, (float*)ws, Cout);
   HIP_CHECK_RET(hipGetLastError());
   return esam3_launch_stem(dtype, img, (const float*)ws, nullptr, out, B, H, W, Cout, ACT_NONE, s);
+}
+
+int esam3_stem_im2col(int dtype, const float* img, void* out, int B, int H, int W, void* stream) {
+  if ((dtype != 0 && dtype != 1) || !img || !out || B <= 0 || H <= 0 || W <= 0) return bad("esam3_stem_im2col");
+  const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+  const int64_t total = (int64_t)B * OH * OW * 4;
+  const unsigned grid = (unsigned)(total / 256 + 1 < 65536 ? total / 256 + 1 : 65536);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == 0) hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(grid), dim3(256), 0, s, img, (float*)out, B, H, W, OH, OW);
+  else hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, img, (bf16_t*)out, B, H, W, OH, OW);
+  HIP_CHECK_RET(hipGetLastError());
+  return 0;
 }
 
 int esam3_resize_bilinear_backward(int dtype, const void* dy, void* dx, int B, int IH, int IW, int OH, int OW, int C, void* stream) {

@@ -518,7 +518,14 @@ def stem_forward(img_nchw_f32: torch.Tensor, w: torch.Tensor, dtype: torch.dtype
 def stem_im2col(img_nchw_f32: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """[B * OH * OW, 32] rows of the 27 image values under each output pixel of the stride-2 3x3 conv (order ci, kh, kw = the weight's), padded to
     32 columns: the `x` operand of the stem's weight gradient.  Pure data movement (torch's unfold)."""
-    cols = torch.nn.functional.unfold(img_nchw_f32, kernel_size=3, padding=1, stride=2)       # [B, 27, OH * OW]
+    if img_nchw_f32.is_cuda and dtype in _DT:   # round 6: one kernel (esam3_stem_im2col) instead of unfold + permute + pad + cast
+        b, _, h, wd = img_nchw_f32.shape
+        img = img_nchw_f32.contiguous()
+        out = torch.empty((b * ((h + 1) // 2) * ((wd + 1) // 2), 32), dtype=dtype, device=img.device)
+        with torch.cuda.device(img.device):
+            _lib.check(_lib.load().esam3_stem_im2col(_DT[dtype], img.data_ptr(), out.data_ptr(), b, h, wd, _stream()), "esam3_stem_im2col")
+        return out
+    cols = torch.nn.functional.unfold(img_nchw_f32, kernel_size=3, padding=1, stride=2)       # [B, 27, OH * OW]  (host doubles of the tests)
     cols = cols.permute(0, 2, 1).reshape(-1, 27)
     return torch.nn.functional.pad(cols, (0, 5)).to(dtype).contiguous()
 

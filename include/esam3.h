@@ -310,6 +310,10 @@ int esam3_train_dwconv(int dtype, const void* x_dev, const float* w_dev, const f
  * (packed into workspace_dev, 4 k k C bytes); stride 2 = esam3_dwconv_dgrad */
 int esam3_train_dwconv_dgrad(int dtype, const void* dy_dev, const float* w_dev, void* dx_dev, int B, int H, int W, int C, int ksize,
                              int stride, void* workspace_dev, void* hip_stream);
+/* the `x` operand of the stem's weight gradient: im2col of the 3 -> C0 3x3 / stride 2 / padding 1 stem conv (backbone.py:50-58) on the NCHW
+ * fp32 image -> out_dev [B * ceil(H/2) * ceil(W/2)][32] in the activation dtype, column c * 9 + kh * 3 + kw (torch.nn.functional.unfold's
+ * order), columns 27..31 zero; dW = esam3_linear_wgrad(d_conv, out)[:, :27] */
+int esam3_stem_im2col(int dtype, const float* img_nchw_dev, void* out_dev, int B, int H, int W, void* hip_stream);
 int esam3_train_stem(int dtype, const float* img_nchw_dev, const float* w_dev, void* out_dev, int B, int H, int W, int Cout,
                      void* workspace_dev, void* hip_stream);
 int esam3_resize_bilinear_backward(int dtype, const void* dy_dev, void* dx_dev, int B, int IH, int IW, int OH, int OW, int C,

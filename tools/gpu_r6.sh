@@ -182,5 +182,17 @@ print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["cpu_baseline"]["va
 PY
 
   ;;
-*) echo "usage: $0 {a..m}"; exit 2 ;;
+p)
+  # round 6, GPU call P: training kernels after the round's changes (stride-2 depthwise dgrad with LDS weights, vectorised colsum, stem im2col
+  # kernel, depthwise wgrad without per-pixel divisions): their tests, the step pins of all students, the per-operator table again
+  timeout 900 python -m pytest tests/test_train_blocks.py tests/test_train_repvit.py tests/test_train_tinyvit.py tests/test_stage1_step.py tests/test_stage1.py -q -m gpu -x --timeout 600 > $O/p_train_tests.txt 2>&1
+  tail -5 $O/p_train_tests.txt | cut -c1-300
+  timeout 400 python tools/stage1_step_roofline.py --model b1 --batch 32 --calls 40 2>&1 | grep -v amdgpu > $O/p_roofline_stage1_step_b1_b32.md
+  head -32 $O/p_roofline_stage1_step_b1_b32.md | cut -c1-200
+  for m in b1 repvit_m1_1 tiny_vit_11m; do
+    timeout 300 python tools/bench_stage1_step.py --model $m --batch 32 --steps 5 2>/dev/null | tail -1 > $O/p_bench_stage1_step_${m}_b32.json
+    python -c "import json; d=json.loads(open('$O/p_bench_stage1_step_${m}_b32.json').read()); print('$m', d['value'], d['ms_per_step'])"
+  done
+  ;;
+*) echo "usage: $0 {a..p}"; exit 2 ;;
 esac

@@ -78,7 +78,8 @@ def wrap(mod, name):
         finally:
             DEPTH[0] -= 1
         e1.record()
-        REC.append((name, e0, e1, _bytes(args) + _bytes(kw) + _bytes(out), _flops(name, list(args) + list(kw.values()), out)))
+        shapes = " ".join("x".join(str(d) for d in t_.shape) for t_ in list(args) + list(kw.values()) if torch.is_tensor(t_))
+        REC.append((name, e0, e1, _bytes(args) + _bytes(kw) + _bytes(out), _flops(name, list(args) + list(kw.values()), out), shapes))
         return out
 
     inner.__name__ = name
@@ -90,6 +91,7 @@ def main():
     ap.add_argument("--model", default="b1")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--calls", type=int, default=0, help="also list the N slowest single calls with their tensor shapes")
     a = ap.parse_args()
     # leaf operators only (a wrapper that calls other wrapped functions would be counted twice): the C-ABI callers of train_blocks /
     # stage1_train, the loss and the update
@@ -143,7 +145,7 @@ def main():
     ON[0] = False
     total = s0.elapsed_time(s1)
     rows = collections.OrderedDict()
-    for nm, e0, e1, by, fl in REC:
+    for nm, e0, e1, by, fl, _shapes in REC:
         r = rows.setdefault(nm, dict(ms=0.0, n=0, by=0.0, fl=0.0))
         r["ms"] += e0.elapsed_time(e1); r["n"] += 1; r["by"] += by; r["fl"] += fl
     n_par = sum(v.numel() for k, v in sd.items() if not k.endswith(("running_mean", "running_var", "num_batches_tracked")))
@@ -163,6 +165,11 @@ def main():
         print(f"| {r['ms']:.3f} | {r['n']} | {r['fl'] / t / 1e12 if t else 0:.0f} | {r['by'] / t / 1e12 if t else 0:.2f} | "
               f"{'mfma' if f_m >= f_h else 'hbm'} | {floor * 1e3:.3f} | {floor / t if t else 0:.2f} | `{nm}` |")
     print(f"\nsum of the floors {fsum * 1e3:.2f} ms = {fsum * 1e3 / total:.3f} of the instrumented step")
+    if a.calls:
+        print(f"\nthe {a.calls} slowest single calls (ms, GB/s of algorithmic bytes, operator, tensor argument shapes):\n")
+        for nm, e0, e1, by, fl, shapes in sorted(REC, key=lambda r: -r[1].elapsed_time(r[2]))[:a.calls]:
+            t = e0.elapsed_time(e1)
+            print(f"    {t:7.3f} ms  {by / t / 1e6:7.0f} GB/s  {nm:20s} {shapes}")
 
 
 if __name__ == "__main__":
