@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "../../include/esam3.h"
 #include "esam3_common.h"
@@ -113,9 +114,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::ty
                                                     const typename TElem<DT>::type* __restrict__ x, int ldx, int64_t M, int N, int K,
                                                     int64_t rows_per_split, float* __restrict__ partial /* [splits][N][K] */,
                                                     WgradGather gt = WgradGather{0, 0, 0, 0, 0, 0, 0}) {
+  // rows per step: 64 in fp32 (two 16.6 KB tiles), 128 in bf16 (round 6: half the barriers per row; a split is any multiple of 64 rows, the
+  // tail of a step past the split's end is staged as zeros)
+  constexpr int ROWS = DT == 0 ? 64 : 128, VS = ROWS * 32 + 128;
   // fp32: plain [row][64 ch] (+1 float pad); bf16: 4 sub-tiles per operand
-  __shared__ __attribute__((aligned(16))) char sA[DT == 0 ? WG_ROWS * 65 * 4 : 4 * WG_VS];
-  __shared__ __attribute__((aligned(16))) char sB[DT == 0 ? WG_ROWS * 65 * 4 : 4 * WG_VS];
+  __shared__ __attribute__((aligned(16))) char sA[DT == 0 ? ROWS * 65 * 4 : 4 * VS];
+  __shared__ __attribute__((aligned(16))) char sB[DT == 0 ? ROWS * 65 * 4 : 4 * VS];
   const int n0 = blockIdx.y * WG_TILE, k0 = blockIdx.x * WG_TILE;
   const int zsplit = gt.on ? (int)blockIdx.z % gt.zs : (int)blockIdx.z, tap = gt.on ? (int)blockIdx.z / gt.zs : 0;
   const int64_t r_begin = (int64_t)zsplit * rows_per_split;
@@ -138,51 +142,74 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::ty
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  for (int64_t r0 = r_begin; r0 < r_end; r0 += WG_ROWS) {
-    __syncthreads();
-    // ---- stage 64 rows x 64 channels of dy and of x (zeros past M / N / K) ----
-    if constexpr (DT == 0) {
-      for (int c = tid; c < WG_ROWS * 16; c += 256) {  // 4-float chunks
+  // Round 6: the global loads of row step s + 1 are issued BEFORE the matrix products of step s (register double buffer).  The loop used to
+  // be load -> LDS -> barrier -> 4 MFMAs per wave -> barrier: one exposed trip to memory per 64 rows (0.7 ms for the 8 M-row layers of the
+  // stem, 6.5 ms of a 55 ms step over 52 calls, profiles/r06/roofline_stage1_step_b1_b32.md); now the trip hides behind the products.
+  constexpr int NCH = DT == 0 ? (ROWS * 16) / 256 : (ROWS * 8) / 256;   // chunks per thread and operand: 4 (fp32) / 4 (bf16)
+  typedef typename std::conditional<DT == 0, float4, uint4>::type chunk_t;
+  chunk_t ra[NCH], rb[NCH];
+  auto fetch = [&](int64_t r0) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + 256 * i;
+      if constexpr (DT == 0) {
         const int row = c >> 4, ch = (c & 15) * 4;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        float4 av = make_float4(0.f, 0.f, 0.f, 0.f), bv = av;
         if (r0 + row < r_end) {
-          if (n0 + ch < N) a = *reinterpret_cast<const float4*>(dy + (r0 + row) * ldy + n0 + ch);   // N, K multiples of 8
+          if (n0 + ch < N) av = *reinterpret_cast<const float4*>(dy + (r0 + row) * ldy + n0 + ch);   // N, K multiples of 8
           const int64_t xr = xrow(r0 + row);
-          if (k0 + ch < K && xr >= 0) b = *reinterpret_cast<const float4*>(x + xr * ldx + k0 + ch);
+          if (k0 + ch < K && xr >= 0) bv = *reinterpret_cast<const float4*>(x + xr * ldx + k0 + ch);
         }
-        float* pa = reinterpret_cast<float*>(sA) + row * 65 + ch;
-        float* pb = reinterpret_cast<float*>(sB) + row * 65 + ch;
-        pa[0] = a.x; pa[1] = a.y; pa[2] = a.z; pa[3] = a.w;
-        pb[0] = b.x; pb[1] = b.y; pb[2] = b.z; pb[3] = b.w;
-      }
-    } else {
-      for (int c = tid; c < WG_ROWS * 8; c += 256) {  // 8-element (16-byte) chunks: row = c / 8, chunk = c % 8
+        ra[i] = av; rb[i] = bv;
+      } else {
         const int row = c >> 3, ch8 = c & 7;
-        uint4 a = make_uint4(0u, 0u, 0u, 0u), b = a;
+        uint4 av = make_uint4(0u, 0u, 0u, 0u), bv = av;
         if (r0 + row < r_end) {
-          if (n0 + ch8 * 8 < N) a = *reinterpret_cast<const uint4*>(dy + (r0 + row) * ldy + n0 + ch8 * 8);
+          if (n0 + ch8 * 8 < N) av = *reinterpret_cast<const uint4*>(dy + (r0 + row) * ldy + n0 + ch8 * 8);
           const int64_t xr = xrow(r0 + row);
-          if (k0 + ch8 * 8 < K && xr >= 0) b = *reinterpret_cast<const uint4*>(x + xr * ldx + k0 + ch8 * 8);
+          if (k0 + ch8 * 8 < K && xr >= 0) bv = *reinterpret_cast<const uint4*>(x + xr * ldx + k0 + ch8 * 8);
         }
-        const int off = (ch8 >> 1) * WG_VS + row * 32 + (ch8 & 1) * 16;
-        *reinterpret_cast<uint4*>(sA + off) = a;
-        *reinterpret_cast<uint4*>(sB + off) = b;
+        ra[i] = av; rb[i] = bv;
       }
     }
+  };
+  auto stash = [&]() {   // ---- 64 rows x 64 channels of dy and of x into LDS (zeros past M / N / K) ----
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = tid + 256 * i;
+      if constexpr (DT == 0) {
+        const int row = c >> 4, ch = (c & 15) * 4;
+        float* pa = reinterpret_cast<float*>(sA) + row * 65 + ch;
+        float* pb = reinterpret_cast<float*>(sB) + row * 65 + ch;
+        pa[0] = ra[i].x; pa[1] = ra[i].y; pa[2] = ra[i].z; pa[3] = ra[i].w;
+        pb[0] = rb[i].x; pb[1] = rb[i].y; pb[2] = rb[i].z; pb[3] = rb[i].w;
+      } else {
+        const int row = c >> 3, ch8 = c & 7;
+        const int off = (ch8 >> 1) * VS + row * 32 + (ch8 & 1) * 16;
+        *reinterpret_cast<uint4*>(sA + off) = ra[i];
+        *reinterpret_cast<uint4*>(sB + off) = rb[i];
+      }
+    }
+  };
+  if (r_begin < r_end) fetch(r_begin);
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += ROWS) {
     __syncthreads();
+    stash();
+    __syncthreads();
+    if (r0 + ROWS < r_end) fetch(r0 + ROWS);   // in flight under the products below
     if constexpr (DT == 0) {
       const float* fa = reinterpret_cast<const float*>(sA) + wn * 32 + l31;
       const float* fb = reinterpret_cast<const float*>(sB) + wk * 32 + l31;
 #pragma unroll 8
-      for (int p = 0; p < WG_ROWS; p += 2)
+      for (int p = 0; p < ROWS; p += 2)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[(p + g) * 65], fb[(p + g) * 65], acc, 0, 0, 0);
     } else {
       typedef __attribute__((address_space(3))) ts16x4_v* lds_v4;
-      const unsigned frag = (unsigned)((l31 >> 4) * WG_VS + (4 * g + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8);
-      const auto pa = (__attribute__((address_space(3))) char*)sA + wn * 2 * WG_VS + frag;
-      const auto pb = (__attribute__((address_space(3))) char*)sB + wk * 2 * WG_VS + frag;
+      const unsigned frag = (unsigned)((l31 >> 4) * VS + (4 * g + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8);
+      const auto pa = (__attribute__((address_space(3))) char*)sA + wn * 2 * VS + frag;
+      const auto pb = (__attribute__((address_space(3))) char*)sB + wk * 2 * VS + frag;
 #pragma unroll
-      for (int s = 0; s < WG_ROWS / 16; ++s) {
+      for (int s = 0; s < ROWS / 16; ++s) {
         const int off = s * 16 * 32;
         const uint2 alo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa + off)));
         const uint2 ahi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa + off + 8 * 32)));
@@ -416,18 +443,24 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const typename TElem<DT>:
       if (iy < 0 || iy >= H) continue;
       const typename TElem<DT>::type* dyr = dy + q * OW * (int64_t)C + cg * 8;
       const typename TElem<DT>::type* xr = x + (b * H + iy) * (int64_t)W * C + cg * 8;
-#pragma unroll 2
-      for (int ox = rl; ox < OW; ox += RL) {
-        float g[8];
-        TElem<DT>::load8(dyr + (int64_t)ox * C, g);
+      for (int ox = rl; ox < OW; ox += RL) {   // branch-free taps, all loads of a pixel issued before the first use (see dw_wgrad3_kernel)
+        typename TElem<DT>::vec8 raw[KS];
+        float cv[KS];
+        const typename TElem<DT>::vec8 graw = TElem<DT>::loadraw(dyr + (int64_t)ox * C);
 #pragma unroll
         for (int kw = 0; kw < KS; ++kw) {
           const int ix = ox * stride + kw - PAD;
-          if (ix < 0 || ix >= W) continue;
-          float v[8];
-          TElem<DT>::load8(xr + (int64_t)ix * C, v);
+          cv[kw] = (ix >= 0 && ix < W) ? 1.f : 0.f;
+          raw[kw] = TElem<DT>::loadraw(xr + (int64_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C);
+        }
+        float g[8];
+        TElem<DT>::unpack(graw, g);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[kw][e] = fmaf(g[e], v[e], acc[kw][e]);
+        for (int kw = 0; kw < KS; ++kw) {
+          float v[8];
+          TElem<DT>::unpack(raw[kw], v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[kw][e] = fmaf(g[e] * cv[kw], v[e], acc[kw][e]);
         }
       }
     }
@@ -591,27 +624,47 @@ __global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const typename TElem<D
     }
     const typename TElem<DT>::type* dyb = dy + (int64_t)b * OH * OW * C;
     typename TElem<DT>::type* dxr = dx + (int64_t)row * W * C;
+    // the row's (up to) two kernel rows, clamped and masked: uniform over the workgroup
+    float rm[2];
+    int oyc[2];
+    for (int a = 0; a < 2; ++a) {
+      rm[a] = (a < nkh && oys[a] < OH) ? 1.f : 0.f;
+      oyc[a] = oys[a] < OH ? (oys[a] < 0 ? 0 : oys[a]) : OH - 1;
+    }
     for (unsigned j = threadIdx.x; j < (unsigned)W * CG; j += 256) {
       const unsigned ix = j / CG, cg = j - ix * CG;
+      // (up to) two kernel columns of this pixel, clamped and masked: four loads issued together, a parity that has one tap per axis re-reads
+      // a cached line with weight 0 (with `continue`s every load was its own trip to L2)
+      const int odd = ix & 1;
+      int kws[2], oxc[2];
+      float cm[2];
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        kws[c2] = odd ? 2 * c2 : 1;
+        const int ox = ((int)ix + 1 - kws[c2]) >> 1;
+        cm[c2] = ((odd || c2 == 0) && ox < OW) ? 1.f : 0.f;
+        oxc[c2] = ox < OW ? ox : OW - 1;
+      }
+      typename TElem<DT>::vec8 raw[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) raw[a * 2 + c2] = TElem<DT>::loadraw(dyb + ((int64_t)oyc[a] * OW + oxc[c2]) * C + cg * 8);
       float acc[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-      const int nkw = (ix & 1) ? 2 : 1;
-      for (int a = 0; a < nkh; ++a) {
-        const int kh = khs[a], oy = oys[a];
-        if (oy >= OH) continue;
-        for (int c2 = 0; c2 < nkw; ++c2) {
-          const int kw = (ix & 1) ? 2 * c2 : 1;
-          const int ox = ((int)ix + 1 - kw) >> 1;
-          if (ox >= OW) continue;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
           float g[8];
-          TElem<DT>::load8(dyb + ((int64_t)oy * OW + ox) * C + cg * 8, g);
-          const float4 w0 = *reinterpret_cast<const float4*>(sw + (kh * 3 + kw) * C + cg * 8);
-          const float4 w1 = *reinterpret_cast<const float4*>(sw + (kh * 3 + kw) * C + cg * 8 + 4);
-          acc[0] = fmaf(g[0], w0.x, acc[0]); acc[1] = fmaf(g[1], w0.y, acc[1]); acc[2] = fmaf(g[2], w0.z, acc[2]); acc[3] = fmaf(g[3], w0.w, acc[3]);
-          acc[4] = fmaf(g[4], w1.x, acc[4]); acc[5] = fmaf(g[5], w1.y, acc[5]); acc[6] = fmaf(g[6], w1.z, acc[6]); acc[7] = fmaf(g[7], w1.w, acc[7]);
+          TElem<DT>::unpack(raw[a * 2 + c2], g);
+          const float m = rm[a] * cm[c2];
+          const float* wp = sw + (khs[a] * 3 + kws[c2]) * C + cg * 8;
+          const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+          acc[0] = fmaf(g[0] * m, w0.x, acc[0]); acc[1] = fmaf(g[1] * m, w0.y, acc[1]); acc[2] = fmaf(g[2] * m, w0.z, acc[2]); acc[3] = fmaf(g[3] * m, w0.w, acc[3]);
+          acc[4] = fmaf(g[4] * m, w1.x, acc[4]); acc[5] = fmaf(g[5] * m, w1.y, acc[5]); acc[6] = fmaf(g[6] * m, w1.z, acc[6]); acc[7] = fmaf(g[7] * m, w1.w, acc[7]);
         }
-      }
       TElem<DT>::store8(dxr + (int64_t)j * 8, acc);
     }
   }
