@@ -673,6 +673,237 @@ __global__ __launch_bounds__(512, 2) void mla1_kernel(Mla1Params p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// mla1v (round 6): pass 1 rebuilt around its phase ablation (profiles/r06/mla1_ablation_before.txt: at 63^2 x 128 the depthwise phase
+// was 44 of the 84 us that the five phases account for and the grouped 1x1 22, the qkv GEMM 10; nothing saturated, every phase a chain of
+// latencies at two waves per SIMD).  Same arithmetic in the same order as mla1_kernel (bit-identical qms / kvp); what changed:
+//   * depthwise 5x5 and grouped 1x1 are ONE phase: lane = (4-channel block c4 of the 16-channel group, pixel column n of 16), so the
+//     depthwise accumulator of a lane (4 channels of one pixel) is, packed to bf16, exactly the B operand of the grouped conv's
+//     v_mfma_f32_16x16x16_bf16 (k = 4 c4 .. + 3 of column n): the dwo tile, its barrier, its 4-way conflicted reads and the two idle waves
+//     are gone.  Work units = (group, output row); the 6 x 8 = 48 of a chunk go to the 8 waves as runs of 6 consecutive rows (a run
+//     crosses at most one group boundary: segments of 6, 2 + 4, 4 + 2, 6 rows -- every loaded operand still feeds up to 5 rows);
+//   * pixel pitch of the LDS tiles 208 B (= 16 mod 256): 16 consecutive pixels x 16 bytes tile the 64 banks exactly, so the depthwise
+//     ds_read_b64, the expand phase's ds_write_b128 and the grouped conv's writes are conflict-free (192 B: 4 distinct residues for 16
+//     pixels; SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.50 - 0.57);
+//   * the 25 depthwise taps of a chunk are staged cooperatively (5 loads per thread, one chunk ahead) as bf16 into a double-buffered LDS
+//     table: the depthwise phase no longer starts with 25 global loads + 300 VALU instructions of operand building per lane;
+//   * relu(q) and the kv partials of scale 0 (which only need the qkv tile) are issued at the start of the depthwise phase; the wait for
+//     the next chunk's weight DMA sits BEFORE the late stores, so no wave ends a chunk waiting for its own stores to be acknowledged.
+// LDS: mid 240 x 208 + ago 128 x 208 + Wqkv chunk 96 x C x 2 + taps 2 x 25 x 96 x 2 = 108 / 132 KB.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512, 2) void mla1v_kernel(Mla1Params p) {
+  typedef bf16_t T;
+  constexpr int HEADS = C / 16, C3 = 3 * C, KS = C / 16, NCH = HEADS / 2;
+  constexpr int TH = 8, TW = 16, HH = TH + 4, HW = TW + 4, HP = HH * HW;   // 12 x 20 halo
+  constexpr int PITCH = 208;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* mid = smem;                    // [240 halo px][208 B]: 96 qkv channels of the chunk
+  char* ago = mid + HP * PITCH;        // [128 px][208 B]: the aggregated (second scale) 96 channels
+  char* wqs = ago + 128 * PITCH;       // this chunk's 96 rows of Wqkv: [96][C] bf16, 16-byte slot ^ (row & 15), filled by LDS-DMA
+  uint16_t* swd = reinterpret_cast<uint16_t*>(wqs + 96 * C * 2);   // [2][25 taps][96 ch] bf16
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, g = lane >> 5, l15 = lane & 15, kg = lane >> 4;
+
+  const unsigned tpi = (unsigned)(p.tiles_x * p.tiles_y);
+  const unsigned bid = xcd_contig(blockIdx.x, gridDim.x);
+  const unsigned b = bid / tpi;
+  const unsigned ti = bid - b * tpi;
+  const int ty = (int)(ti / (unsigned)p.tiles_x), tx = (int)(ti - ty * p.tiles_x);
+  const int oy0 = ty * TH, ox0 = tx * TW;
+
+  const T* __restrict__ gx = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ gwq = reinterpret_cast<const T*>(p.wqkv);
+  const T* __restrict__ gwg = reinterpret_cast<const T*>(p.wgrp);
+  T* __restrict__ gq = reinterpret_cast<T*>(p.qms);
+
+  const uint32_t wq_lds = lds_addr(wqs);
+  auto dma_wq = [&](int ch) {
+#pragma unroll
+    for (int j = 0; j < (96 * C * 2 / 1024 + 7) / 8; ++j) {
+      const int piece = wave + 8 * j;
+      if (piece < 96 * C * 2 / 1024) {   // wave-uniform
+        const int byte = piece * 1024 + lane * 16;
+        const int row = byte / (C * 2), pslot = (byte - row * (C * 2)) >> 4;
+        const uint32_t voff = (uint32_t)(((ch * 96 + row) * p.Kpq + ((pslot ^ (row & 15)) << 3)) * 2);
+        dma_piece(gwq, voff, wq_lds + (uint32_t)piece * 1024u);
+      }
+    }
+  };
+  // depthwise taps of chunk ch: 25 x 96 values, element e = tap * 96 + channel, thread t owns e = t + 512 k
+  float wst[5];
+  auto load_taps = [&](int ch) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int e = tid + 512 * k;
+      const int tap = e / 96, cc = e - tap * 96;
+      wst[k] = e < 2400 ? p.wdw[tap * C3 + ch * 96 + cc] : 0.f;
+    }
+  };
+  auto store_taps = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int e = tid + 512 * k;
+      if (e < 2400) swd[buf * 2400 + e] = f32_to_bf16(wst[k]);
+    }
+  };
+  dma_wq(0);
+  load_taps(0);
+  // ---- x fragments of this wave's halo pixel tile (pixels 32 wave .. + 31), kept for all chunks ----
+  u32x4 fa[KS];
+  const int hp_e = wave * 32 + l31;
+  {
+    const int hy = hp_e / HW, hx = hp_e - hy * HW;
+    const int iy = oy0 - 2 + hy, ix = ox0 - 2 + hx;
+    const bool in = hp_e < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    const T* px = gx + ((int64_t)(b * (unsigned)p.H + (in ? iy : 0)) * p.W + (in ? ix : 0)) * C;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      fa[ks] = u32x4{0u, 0u, 0u, 0u};
+      if (in) fa[ks] = *reinterpret_cast<const u32x4*>(px + (2 * ks + g) * 8);
+    }
+  }
+  // depthwise + grouped phase: lane = (c4 = 4-channel block of a 16-channel group, column n); the wave's run of 6 (group, row) units
+  const int pi = lane & 3;
+  const int wq4 = wave & 3, gi0 = (wave >> 2) * 3;
+  const int giA = gi0 + (wq4 >= 2 ? (wq4 == 2 ? 1 : 2) : 0);   // group of the run's first segment
+  const int giB = gi0 + (wq4 == 1 ? 1 : 2);                    // group of the second segment (waves 1, 2 of a quad)
+  const bool col_in = (ox0 + l15) < p.W;
+
+  store_taps(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // Wqkv chunk 0 and the taps of chunk 0 are in LDS
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c0 = ch * 96;   // first qkv channel of the chunk (heads 2ch, 2ch + 1)
+    // the grouped conv's 16 x 16 weight blocks of this wave's (at most two) groups: requested now, used after the depthwise walk
+    const s16x4 wgaA = *reinterpret_cast<const s16x4*>(gwg + (int64_t)(c0 + giA * 16 + l15) * p.Kpg + 4 * kg);
+    const s16x4 wgaB = *reinterpret_cast<const s16x4*>(gwg + (int64_t)(c0 + giB * 16 + l15) * p.Kpg + 4 * kg);
+    if (ch + 1 < NCH) load_taps(ch + 1);
+    // ================= E: mid[halo px][96] = Wqkv[c0 .. c0+96) . x =================
+    if (!MLA1_ABL(1))
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      f32x16_v acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int wr = j * 32 + l31;
+      const char* wrow = wqs + wr * (C * 2);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const u32x4 fw = *reinterpret_cast<const u32x4*>(wrow + (((2 * ks + g) ^ (wr & 15)) << 4));
+        MmaOps<T>::mma(fw, fa[ks], acc);
+      }
+      u32x4 o[2];
+#pragma unroll
+      for (int qp = 0; qp < 2; ++qp) {
+        const uint32_t a0 = pack_bf16x2(acc[8 * qp + 0], acc[8 * qp + 1]), a1 = pack_bf16x2(acc[8 * qp + 2], acc[8 * qp + 3]);
+        const uint32_t c0_ = pack_bf16x2(acc[8 * qp + 4], acc[8 * qp + 5]), c1_ = pack_bf16x2(acc[8 * qp + 6], acc[8 * qp + 7]);
+        auto s0 = __builtin_amdgcn_permlane32_swap(a0, c0_, false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
+        o[qp] = u32x4{s0[0], s1[0], s0[1], s1[1]};  // channels j*32 + 16qp + 8g .. +8 of halo pixel hp
+      }
+      if (hp_e < HP) {
+        char* rowp = mid + hp_e * PITCH + ((j * 4 + g) << 4);
+        *reinterpret_cast<u32x4*>(rowp) = o[0];
+        *reinterpret_cast<u32x4*>(rowp + 32) = o[1];
+      }
+    }
+    if (ch + 1 < NCH) store_taps((ch + 1) & 1);   // read by the NEXT chunk's depthwise phase (behind two barriers)
+    __syncthreads();
+    if (ch + 1 < NCH) dma_wq(ch + 1);   // the expand phase is done with the buffer; lands under the other phases
+
+    // ================= early KVQ: scale 0 (the qkv tile itself) =================
+    auto q_store = [&](int item) {   // relu(q) -> qms[b][tile][chunk][gl = scale*2 + head][tile row][px][16 ch], item = (gl, row, px, half)
+      const int half = item & 1, pxx = (item >> 1) & 15, py = (item >> 5) & 7, gl = item >> 8;
+      const int scale = gl >> 1, hh = gl & 1;
+      const int px = py * 16 + pxx;
+      const char* src = (scale ? ago + px * PITCH : mid + ((py + 2) * HW + pxx + 2) * PITCH) + hh * 96 + half * 16;
+      const uint4 v = *reinterpret_cast<const uint4*>(src);
+      const s16x4 lo = relu_bf16x4(__builtin_bit_cast(s16x4, make_uint2(v.x, v.y)));
+      const s16x4 hi = relu_bf16x4(__builtin_bit_cast(s16x4, make_uint2(v.z, v.w)));
+      const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+      *reinterpret_cast<uint4*>(gq + (((int64_t)b * tpi + ti) * NCH + ch) * 8192 + item * 8) = make_uint4(l2.x, l2.y, h2.x, h2.y);
+    };
+    auto kv_partial = [&](int scale, int hh, int half) {   // 4 tile rows of 16 pixels each = 4 MFMA steps
+      f32x4 akv = {0.f, 0.f, 0.f, 0.f}, aks = {0.f, 0.f, 0.f, 0.f};
+      const s16x4 ones = {(short)0x3F80, (short)0x3F80, (short)0x3F80, (short)0x3F80};
+      const int jpx = 4 * kg + (l15 >> 2);   // the pixel this lane addresses for the transposing read
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int ry = half * 4 + st;
+        const char* rb = (scale ? ago + (ry * 16 + jpx) * PITCH : mid + ((ry + 2) * HW + 2 + jpx) * PITCH) + hh * 96 + (lane & 3) * 8;
+        const s16x4 kf = relu_bf16x4(lds_tr16(rb + 32));
+        const s16x4 vf = lds_tr16(rb + 64);
+        akv = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vf, kf, akv, 0, 0, 0);
+        aks = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ones, kf, aks, 0, 0, 0);
+      }
+      const int gnat = scale * HEADS + 2 * ch + hh;
+      float* o = p.kvp + (((int64_t)b * tpi + ti) * 2 + half) * (int64_t)(2 * HEADS * 272) + gnat * 272;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[(4 * kg + i) * 16 + l15] = akv[i];
+      if (kg == 0) o[256 + l15] = aks[0];
+    };
+    if (!MLA1_ABL(8)) q_store(tid);
+    if (!MLA1_ABL(16) && wave < 4) kv_partial(0, wave & 1, wave >> 1);
+
+    // ================= DP: ago[px][96] = grouped 1x1 of dw5x5(mid), in registers =================
+    if (!MLA1_ABL(2)) {
+      const uint16_t* tb = swd + (ch & 1) * 2400;
+      auto segment = [&](auto rows_c, int gi, int r0, const s16x4& wga) {
+        constexpr int R = decltype(rows_c)::value;
+        s16x4 wdg[25];
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+          const uint64_t wv = (uint64_t)tb[t * 96 + gi * 16 + 4 * kg + pi] << (16 * pi);
+          wdg[t] = __builtin_bit_cast(s16x4, wv);
+        }
+        f32x4 acc[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        DwRows3<5, R, 1, HW, PITCH, 2>::run(lds_addr(mid + (r0 * HW + l15) * PITCH + gi * 32 + kg * 8), wdg, acc);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          s16x4 xb;
+          if (MLA1_ABL(4)) {
+            xb = s16x4{0, 0, 0, 0};
+          } else {
+            const uint2 pk = make_uint2(pack_bf16x2(acc[r][0], acc[r][1]), pack_bf16x2(acc[r][2], acc[r][3]));
+            xb = __builtin_bit_cast(s16x4, pk);
+          }
+          const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wga, xb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          // channels gi*16 + 4kg .. +4 of pixel (r0 + r, l15); pixels of the tile that lie outside the image must not reach kv
+          const bool p_in = col_in && (oy0 + r0 + r) < p.H;
+          uint2 o;
+          o.x = p_in ? pack_bf16x2(d[0], d[1]) : 0u;
+          o.y = p_in ? pack_bf16x2(d[2], d[3]) : 0u;
+          *reinterpret_cast<uint2*>(ago + ((r0 + r) * 16 + l15) * PITCH + gi * 32 + kg * 8) = o;
+        }
+      };
+      if (wq4 == 0) {
+        segment(std::integral_constant<int, 6>{}, giA, 0, wgaA);
+      } else if (wq4 == 1) {
+        segment(std::integral_constant<int, 2>{}, giA, 6, wgaA);
+        segment(std::integral_constant<int, 4>{}, giB, 0, wgaB);
+      } else if (wq4 == 2) {
+        segment(std::integral_constant<int, 4>{}, giA, 4, wgaA);
+        segment(std::integral_constant<int, 2>{}, giB, 0, wgaB);
+      } else {
+        segment(std::integral_constant<int, 6>{}, giA, 2, wgaA);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next chunk's weights (issued a phase ago) have landed
+    __syncthreads();
+
+    // ================= late KVQ: scale 1 =================
+    if (!MLA1_ABL(8)) q_store(512 + tid);
+    if (!MLA1_ABL(16) && wave >= 4) kv_partial(1, wave & 1, (wave >> 1) & 1);
+    // no barrier here: these reads touch `ago` only, which the next chunk writes behind ITS first barrier; `mid`, the weight buffer and
+    // the tap table the next expand phase writes were last read in front of the barrier above
+  }
+}
+
 // kv[b][g] = sum of the tile partials in a fixed order; written as the bf16 hi / lo MFMA operands of pass 2:
 // tab[b][g][op][lane][4], op 0/1 = kv hi / lo (lane (m = dv, kq): kv[m][4kq .. 4kq+3]), op 2/3 = ksum hi / lo (every row m)
 __global__ __launch_bounds__(256) void mla_kvprep_kernel(const float* __restrict__ kvp, bf16_t* __restrict__ tab, int P, int G) {
@@ -1681,7 +1912,16 @@ int esam3_launch_mla_fused(const void* x, void* out, const void* wqkv, int Kpq, 
   a.abl = esam3_dev_flag("ESAM3_MLA1_ABL");
   const int tiles = a.tiles_x * a.tiles_y, G = 2 * (C / 16);
   const size_t lds1 = (size_t)(256 + 128 + 128) * 192 + (size_t)96 * C * 2;
-  if (C == 128) {
+  const size_t lds1v = (size_t)(240 + 128) * 208 + (size_t)96 * C * 2 + 2 * 2400 * 2;
+  if (!esam3_dev_flag("ESAM3_MLA1_OLD")) {   // round 6: depthwise + grouped conv in registers (A/B in dev builds: the round-4 kernel)
+    if (C == 128) {
+      if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(mla1v_kernel<128>), (int)lds1v)) return -1;
+      hipLaunchKernelGGL((mla1v_kernel<128>), dim3((unsigned)(B * tiles)), dim3(512), lds1v, stream, a);
+    } else {
+      if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(mla1v_kernel<256>), (int)lds1v)) return -1;
+      hipLaunchKernelGGL((mla1v_kernel<256>), dim3((unsigned)(B * tiles)), dim3(512), lds1v, stream, a);
+    }
+  } else if (C == 128) {
     if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(mla1_kernel<128>), (int)lds1)) return -1;
     hipLaunchKernelGGL((mla1_kernel<128>), dim3((unsigned)(B * tiles)), dim3(512), lds1, stream, a);
   } else {

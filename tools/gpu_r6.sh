@@ -194,5 +194,33 @@ p)
     python -c "import json; d=json.loads(open('$O/p_bench_stage1_step_${m}_b32.json').read()); print('$m', d['value'], d['ms_per_step'])"
   done
   ;;
-*) echo "usage: $0 {a..p}"; exit 2 ;;
+q)
+  # round 6, GPU call Q: phase ablation of mla1 (dev library; ESAM3_MLA1_ABL bits: 1 expand, 2 depthwise, 4 grouped, 8 relu(q) stores, 16 kv partials)
+  export ESAM3_DEV_LIB=build_dev/libesam3_dev.so ESAM3_OP_REPEAT=50
+  {
+  for abl in 0 1 2 4 8 16 24 31 0; do
+    echo "== ESAM3_MLA1_ABL=$abl"
+    ESAM3_MLA1_ABL=$abl timeout 120 python tools/evit_fused_bench.py s2.ctx s3.ctx 2>&1 | grep op_timed
+  done
+  } > $O/q_mla1_ablation.txt 2>&1
+  cat $O/q_mla1_ablation.txt
+  ;;
+r)
+  # round 6, GPU call R: mla1v (depthwise + grouped conv in registers) -- exactness tests, then A/B against the round-4 kernel
+  timeout 600 python -m pytest tests/test_lattice_gpu.py tests/test_ops_gpu.py -q -m gpu -k "mla or lite" --timeout 500 > $O/r_mla_tests.txt 2>&1
+  tail -5 $O/r_mla_tests.txt | cut -c1-300
+  export ESAM3_DEV_LIB=build_dev/libesam3_dev.so ESAM3_OP_REPEAT=50
+  {
+  for old in 1 0 1 0; do
+    echo "== ESAM3_MLA1_OLD=$old"
+    ESAM3_MLA1_OLD=$old timeout 120 python tools/evit_fused_bench.py s2.ctx s3.ctx 2>&1 | grep op_timed
+  done
+  for abl in 1 2 4 8 16 31; do
+    echo "== new kernel, ESAM3_MLA1_ABL=$abl"
+    ESAM3_MLA1_ABL=$abl timeout 120 python tools/evit_fused_bench.py s2.ctx s3.ctx 2>&1 | grep op_timed
+  done
+  } > $O/r_mla1_ab.txt 2>&1
+  cat $O/r_mla1_ab.txt
+  ;;
+*) echo "usage: $0 {a..r}"; exit 2 ;;
 esac
