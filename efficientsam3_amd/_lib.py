@@ -159,6 +159,7 @@ SIGNATURES = {
     "esam3_op_i2t_block": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "esam3_op_dwconv": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_op_stem": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "esam3_op_stem_dsconv": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "esam3_op_lite_mla": (_I, [_I, _P, _P, _I, _I, _I, _I, _P]),
     "esam3_op_grouped_pw": (_I, [_I, _P, _P, _P, _L, _I, _I, _P]),
     "esam3_op_resize_bilinear": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -906,26 +906,39 @@ __global__ __launch_bounds__(512, 2) void mla1v_kernel(Mla1Params p) {
 
 // kv[b][g] = sum of the tile partials in a fixed order; written as the bf16 hi / lo MFMA operands of pass 2:
 // tab[b][g][op][lane][4], op 0/1 = kv hi / lo (lane (m = dv, kq): kv[m][4kq .. 4kq+3]), op 2/3 = ksum hi / lo (every row m)
-__global__ __launch_bounds__(256) void mla_kvprep_kernel(const float* __restrict__ kvp, bf16_t* __restrict__ tab, int P, int G) {
+// Round 6: 1024 threads per (image, group): the partials are summed in FOUR interleaved quarters (thread quarter j takes partials
+// j, j + 4, ...), each with up to eight independent loads in flight, and the quarters are combined through LDS in a fixed order -- the
+// 256-thread form walked the 64 partials of a 63 x 63 image in 8 dependent rounds of L2 latency (13.7 us per launch, 90 % of the wave time
+// parked: profiles/r06/pmc_backbone_before.txt).  Deterministic; the summation order differs from round 4's.
+__global__ __launch_bounds__(1024) void mla_kvprep_kernel(const float* __restrict__ kvp, bf16_t* __restrict__ tab, int P, int G) {
+  __shared__ float red[2][3][256];
   const int bg = blockIdx.x;
   const int b = bg / G, gi = bg - b * G;
-  const int t = threadIdx.x, m = t >> 4, k = t & 15;
+  const int t = threadIdx.x & 255, part = threadIdx.x >> 8, m = t >> 4, k = t & 15;
   const float* src = kvp + ((int64_t)b * P * G + gi) * 272;
-  // eight interleaved partial sums (independent loads in flight), combined in a fixed order: deterministic
-  float s8[8], k8[8];
+  float s8[4], k8[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) s8[j] = k8[j] = 0.f;
-  for (int q0 = 0; q0 < P; q0 += 8) {
+  for (int j = 0; j < 4; ++j) s8[j] = k8[j] = 0.f;
+  for (int q0 = part; q0 < P; q0 += 16) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (q0 + j < P) {
-        s8[j] += src[(int64_t)(q0 + j) * G * 272 + m * 16 + k];
-        k8[j] += src[(int64_t)(q0 + j) * G * 272 + 256 + k];
+    for (int j = 0; j < 4; ++j) {
+      const int q = q0 + 4 * j;
+      if (q < P) {
+        s8[j] += src[(int64_t)q * G * 272 + m * 16 + k];
+        k8[j] += src[(int64_t)q * G * 272 + 256 + k];
       }
     }
   }
-  const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-  const float sk = ((k8[0] + k8[1]) + (k8[2] + k8[3])) + ((k8[4] + k8[5]) + (k8[6] + k8[7]));
+  float s = (s8[0] + s8[1]) + (s8[2] + s8[3]);
+  float sk = (k8[0] + k8[1]) + (k8[2] + k8[3]);
+  if (part) {
+    red[0][part - 1][t] = s;
+    red[1][part - 1][t] = sk;
+  }
+  __syncthreads();
+  if (part) return;
+  s = (s + red[0][0][t]) + (red[0][1][t] + red[0][2][t]);
+  sk = (sk + red[1][0][t]) + (red[1][1][t] + red[1][2][t]);
   bf16_t* o = tab + (int64_t)bg * 4 * 256;
   const int li = (m + 16 * (k >> 2)) * 4 + (k & 3);
   const bf16_t h = f32_to_bf16(s), hk = f32_to_bf16(sk);
@@ -1716,7 +1729,7 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
             auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
             o[qp] = u32x4{s0[0], s1[0], s0[1], s1[1]};
           }
-          const bool flip = (l31 >> 1) & 1;
+          const bool flip = (l31 >> 1) & 1;   // (flipping by pixel bit 2 instead measured the same: profiles/r06/flip_ab.txt)
           const u32x4 w0 = flip ? o[1] : o[0], w1v = flip ? o[0] : o[1];
           char* rowp = mid + hp * PITCH + ((ejt * 4 + g) << 4);
           *reinterpret_cast<u32x4*>(rowp + (flip ? 32 : 0)) = w0;
@@ -1929,7 +1942,7 @@ int esam3_launch_mla_fused(const void* x, void* out, const void* wqkv, int Kpq, 
     hipLaunchKernelGGL((mla1_kernel<256>), dim3((unsigned)(B * tiles)), dim3(512), lds1, stream, a);
   }
   HIP_CHECK_RET(hipGetLastError());
-  hipLaunchKernelGGL(mla_kvprep_kernel, dim3((unsigned)(B * G)), dim3(256), 0, stream, kvp, reinterpret_cast<bf16_t*>(tab), tiles * 2, G);
+  hipLaunchKernelGGL(mla_kvprep_kernel, dim3((unsigned)(B * G)), dim3(1024), 0, stream, kvp, reinterpret_cast<bf16_t*>(tab), tiles * 2, G);
   HIP_CHECK_RET(hipGetLastError());
   Mla2Params q{};
   q.qms = qms; q.tab = tab; q.wp = wproj; q.bp = bproj; q.x = x; q.out = out;

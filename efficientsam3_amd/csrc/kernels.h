@@ -80,7 +80,7 @@ int esam3_launch_stem(int dtype, const float* img_nchw, const float* w /*[27][Co
 // + Hardswish -> pointwise 16 -> 16 (wp: activation dtype, row stride ldw, bp)).  16 channels only.
 int esam3_launch_stem_dsconv(int dtype, const float* img_nchw, const float* w0, const float* b0, const float* wd,
                              const float* bd, const void* wp, int ldw, const float* bp, void* out, int B, int H, int W,
-                             hipStream_t s);
+                             hipStream_t s, int variant = 0);
 
 // depthwise k x k (k in {3,5}), stride in {1,2}, pad k/2.  w: fp32 [k*k][C]; bias fp32 or null.
 int esam3_launch_dwconv(int dtype, const void* in, int ld_in, const float* w, const float* bias,

@@ -435,6 +435,175 @@ __global__ __launch_bounds__(256) void stem_dsconv_mfma_kernel(const float* __re
   }
 }
 
+// Round 6: the same kernel as PERSISTENT workgroups.  The one-tile-per-workgroup form lived 12.7 us per 16 x 16 tile (32 768 workgroups at
+// B = 32, five resident per CU, 0.33 ms): a tile's life was the HBM latency of its image halo + ~40 scalar-ish global loads and ~300
+// VALU instructions of per-lane operand building (patch offsets, stem / depthwise / pointwise weights as MFMA operands), all in
+// front of 20 us-scale phases (profiles/r06/pmc_backbone_before.txt: 61 % of the wave time parked, matrix pipes busy 7 %).  Here a
+// workgroup builds its operands once, walks the tiles of its XCD's contiguous range, and requests the NEXT tile's image halo (5
+// 16-byte loads per thread, into registers) right after the barrier that publishes the current one -- the loads land under the three
+// compute phases.  Same arithmetic, same order: bit-identical to stem_dsconv_mfma_kernel.
+__global__ __launch_bounds__(256, 3) void stem_dsconv_mfma_p_kernel(const float* __restrict__ img, const float* __restrict__ w0,
+                                                                const float* __restrict__ b0, const float* __restrict__ wd,
+                                                                const float* __restrict__ bd, const bf16_t* __restrict__ wp, int ldw,
+                                                                const float* __restrict__ bp, bf16_t* __restrict__ out, int H, int W,
+                                                                int OH, int OW, int tiles_x, int tiles_img, unsigned ntiles) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  constexpr int C = 16, TS = 16, HS = TS + 2, IR = 2 * HS + 1, IP = 40;  // 37 input rows / columns per halo, row pitch 40
+  constexpr int NIT = (3 * IR * (IP / 4) + 255) / 256;                   // image items (plane, row, 4 columns) per thread: 5
+  __shared__ __attribute__((aligned(16))) bf16_t simg[3 * IR * IP];
+  __shared__ __attribute__((aligned(16))) bf16_t sstem[HS * HS * C];
+  __shared__ __attribute__((aligned(16))) bf16_t smid[TS * TS * C];
+  struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
+  // ---- this workgroup's tiles: XCD xcd owns the contiguous range [first, first + cnt), its workgroups stride through it ----
+  const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7, wi = blockIdx.x >> 3;
+  const unsigned nx = nwg / 8 + (xcd < nwg % 8 ? 1u : 0u);
+  const unsigned tq = ntiles / 8, tr = ntiles % 8;
+  const unsigned first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, cnt = tq + (xcd < tr ? 1u : 0u);
+  if (wi >= cnt) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  // this thread's image items: (plane c, halo row y, column group xg), fixed for all tiles; packed c << 16 | y << 8 | xg (one register each)
+  int it_pk[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    const int cy = i / (IP / 4), xg = i - cy * (IP / 4);
+    const int c = cy / IR;
+    it_pk[k] = i < 3 * IR * (IP / 4) ? (c << 16) | ((cy - c * IR) << 8) | xg : -1;
+  }
+  float pre[NIT][4];
+  auto load_img = [&](unsigned tile) {
+    const unsigned b = tile / (unsigned)tiles_img, ti = tile - b * (unsigned)tiles_img;
+    const int ty = (int)(ti / (unsigned)tiles_x), tx = (int)(ti - ty * tiles_x);
+    const int iy0 = 2 * (ty * TS) - 3, ix0 = 2 * (tx * TS) - 3;
+    const float* ib = img + (int64_t)b * 3 * H * W;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int c = it_pk[k] >> 16, y = (it_pk[k] >> 8) & 255, xg = it_pk[k] & 255;
+      const int iy = iy0 + y, ix = ix0 + 4 * xg;
+      pre[k][0] = pre[k][1] = pre[k][2] = pre[k][3] = 0.f;
+      if (it_pk[k] >= 0 && (unsigned)iy < (unsigned)H) {
+        const float* rp = ib + (c * H + iy) * W;   // 3 H W < 2^31 (checked by the launcher)
+        if (ix >= 0 && ix + 3 < W) {
+          const F4 f = *reinterpret_cast<const F4*>(rp + ix);
+          pre[k][0] = f.x; pre[k][1] = f.y; pre[k][2] = f.z; pre[k][3] = f.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if ((unsigned)(ix + e) < (unsigned)W) pre[k][e] = rp[ix + e];
+        }
+      }
+    }
+  };
+  load_img(first + wi);
+  // phase-1 constants: patch offsets of this lane's 8 k values (k = tap*3 + c, 27 valid), weights A[co = l15][k]
+  int poff[8];
+  uint32_t pmask[4], wa[4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    uint32_t m = 0u, wv = 0u;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = 2 * h + u, k = 8 * kg + e;
+      const bool valid = k < 27;
+      const int tap = valid ? k / 3 : 0, c = valid ? k - tap * 3 : 0;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      poff[e] = (c * IR + kh) * IP + kw;
+      if (valid) {
+        m |= 0xffffu << (16 * u);
+        wv |= (uint32_t)f32_to_bf16(w0[k * C + l15]) << (16 * u);
+      }
+    }
+    pmask[h] = m;
+    wa[h] = wv;
+  }
+  f32x4_v bias1, bias2, bias3;
+  s16x4 wdg[9];
+  const int cgp = (lane >> 2) & 3, pi = lane & 3;  // phase 2: channel group of the lane's block, row / pixel within the block
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    bias1[v] = b0 ? b0[4 * kg + v] : 0.f;
+    bias2[v] = bd ? bd[4 * cgp + v] : 0.f;
+    bias3[v] = bp ? bp[4 * kg + v] : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const short wb = (short)f32_to_bf16(wd[t * C + 4 * cgp + pi]);
+    wdg[t] = s16x4{(short)(pi == 0 ? wb : 0), (short)(pi == 1 ? wb : 0), (short)(pi == 2 ? wb : 0), (short)(pi == 3 ? wb : 0)};
+  }
+  const s16x4 wpa = *reinterpret_cast<const s16x4*>(wp + (int64_t)l15 * ldw + 4 * kg);  // A[co = l15][ci = 4 kg ..]
+
+  for (unsigned t = wi; t < cnt; t += nx) {
+    const unsigned tile = first + t;
+    const unsigned b = tile / (unsigned)tiles_img, ti = tile - b * (unsigned)tiles_img;
+    const int ty = (int)(ti / (unsigned)tiles_x), tx = (int)(ti - ty * tiles_x);
+    const int oy0 = ty * TS, ox0 = tx * TS;
+    // ---- phase 0: this tile's image halo (requested one tile ago) -> LDS as bf16 ----
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+      if (it_pk[k] >= 0) {
+        const int c = it_pk[k] >> 16, y = (it_pk[k] >> 8) & 255, xg = it_pk[k] & 255;
+        *reinterpret_cast<uint2*>(simg + (c * IR + y) * IP + 4 * xg) = make_uint2(pack_bf16x2(pre[k][0], pre[k][1]), pack_bf16x2(pre[k][2], pre[k][3]));
+      }
+    __syncthreads();   // also: every wave is past the previous tile's phase 3 (its reads of sstem / smid)
+    if (t + nx < cnt) load_img(tile + nx);
+    // ---- phase 1: stem conv over the 324 halo pixels, 16 per MFMA ----
+    for (int grp = wave; grp < (HS * HS + 15) / 16; grp += 4) {
+      const int hp_raw = 16 * grp + l15;
+      const int hp = hp_raw < HS * HS ? hp_raw : HS * HS - 1;
+      const int hy = hp / HS, hx = hp - hy * HS;
+      const bf16_t* pb = simg + (2 * hy) * IP + 2 * hx;
+      uint32_t xb[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h)
+        xb[h] = ((uint32_t)pb[poff[2 * h]] | ((uint32_t)pb[poff[2 * h + 1]] << 16)) & pmask[h];
+      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+      const u32x4_t av = {wa[0], wa[1], wa[2], wa[3]}, bv = {xb[0], xb[1], xb[2], xb[3]};
+      f32x4_v acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_v, av), __builtin_bit_cast(bf16x8_v, bv), bias1, 0, 0, 0);
+      float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+      act_apply_n<4>(v, ACT_HSWISH);
+      const int sy = oy0 - 1 + hy, sx = ox0 - 1 + hx;
+      const bool inside = (unsigned)sy < (unsigned)OH && (unsigned)sx < (unsigned)OW;  // outside = the depthwise conv's zero padding
+      const uint2 o = inside ? make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])) : make_uint2(0u, 0u);
+      if (hp_raw < HS * HS) *reinterpret_cast<uint2*>(sstem + hp * C + 4 * kg) = o;
+    }
+    __syncthreads();
+    // ---- phase 2: depthwise 3x3 + Hardswish; one MFMA = one tap of 16 pixels (a tile row) x 16 channels ----
+    {
+      const int px = 4 * (lane >> 4) + pi;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int py = 4 * wave + r;
+        f32x4_v acc = bias2;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const s16x4 xv = *reinterpret_cast<const s16x4*>(sstem + ((py + kh) * HS + px + kw) * C + 4 * cgp);
+            acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wdg[kh * 3 + kw], xv, acc, 0, 0, 0);
+          }
+        float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+        act_apply_n<4>(v, ACT_HSWISH);
+        *reinterpret_cast<uint2*>(smid + (py * TS + px) * C + 4 * cgp) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      }
+    }
+    __syncthreads();
+    // ---- phase 3: pointwise 16 -> 16 + identity; one MFMA = a tile row of 16 pixels ----
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int py = 4 * wave + r;
+      const s16x4 mv = *reinterpret_cast<const s16x4*>(smid + (py * TS + l15) * C + 4 * kg);
+      f32x4_v acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wpa, mv, bias3, 0, 0, 0);
+      const uint2 idn = *reinterpret_cast<const uint2*>(sstem + ((py + 1) * HS + l15 + 1) * C + 4 * kg);
+      const float o0 = acc[0] + __uint_as_float(idn.x << 16), o1 = acc[1] + __uint_as_float(idn.x & 0xffff0000u);
+      const float o2 = acc[2] + __uint_as_float(idn.y << 16), o3 = acc[3] + __uint_as_float(idn.y & 0xffff0000u);
+      const int oy = oy0 + py, ox = ox0 + l15;
+      if (oy < OH && ox < OW)
+        *reinterpret_cast<uint2*>(out + (((int64_t)b * OH + oy) * OW + ox) * C + 4 * kg) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // depthwise k x k conv (k = 3 or 5), stride 1 or 2, pad k/2, + bias + activation
 // (DSConv / MBConv depth_conv, ops.py:290-299,344-353; LiteMLA aggreg.0.0, ops.py:560-567).
@@ -2681,11 +2850,23 @@ int esam3_launch_stem(int dtype, const float* img, const float* w, const float* 
 }
 
 int esam3_launch_stem_dsconv(int dtype, const float* img, const float* w0, const float* b0, const float* wd, const float* bd,
-                             const void* wp, int ldw, const float* bp, void* out, int B, int H, int W, hipStream_t s) {
+                             const void* wp, int ldw, const float* bp, void* out, int B, int H, int W, hipStream_t s, int variant) {
   const int OH = (H + 1) / 2, OW = (W + 1) / 2;
   const int tiles_x = (OW + 15) / 16, tiles_y = (OH + 15) / 16;
   const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)B);
   static const bool valu = esam3_dev_flag("ESAM3_STEM_VALU") != 0;  // A/B timing
+  if (dtype == 1 && !valu && ldw % 4 == 0 && !(((uintptr_t)wp) & 7) && variant != 1 && (int64_t)3 * H * W < ((int64_t)1 << 31) &&
+      !esam3_dev_flag("ESAM3_STEM_OLD")) {
+    // round 6: persistent workgroups (operands built once, next tile's image halo prefetched); dev builds: ESAM3_STEM_WGS per CU
+    const unsigned ntiles = (unsigned)(tiles_x * tiles_y) * (unsigned)B;
+    const int per_cu = esam3_dev_flag("ESAM3_STEM_WGS") > 0 ? esam3_dev_flag("ESAM3_STEM_WGS") : 3;
+    unsigned g = 256u * (unsigned)per_cu;
+    if (g > ntiles) g = ntiles;
+    hipLaunchKernelGGL(stem_dsconv_mfma_p_kernel, dim3(g), dim3(256), 0, s, img, w0, b0, wd, bd, (const bf16_t*)wp, ldw, bp,
+                       (bf16_t*)out, H, W, OH, OW, tiles_x, tiles_x * tiles_y, ntiles);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
   if (dtype == 1 && !valu && ldw % 4 == 0 && !(((uintptr_t)wp) & 7)) {
     hipLaunchKernelGGL(stem_dsconv_mfma_kernel, grid, dim3(256), 0, s, img, w0, b0, wd, bd, (const bf16_t*)wp, ldw, bp, (bf16_t*)out,
                        H, W, OH, OW, tiles_x);

@@ -517,6 +517,35 @@ int esam3_op_stem(int dtype, const float* img, const float* w, const float* bias
   return 0;
 }
 
+int esam3_op_stem_dsconv(int dtype, const float* img, const float* w0, const float* b0, const float* wd, const float* bd,
+                         const float* wp, const float* bp, void* out, int B, int H, int W, int variant, void* stream) {
+  Tmp t;
+  constexpr int C = 16;
+  std::vector<float> p0(27 * (size_t)C), pd(9 * (size_t)C);
+  for (int co = 0; co < C; ++co)
+    for (int c = 0; c < 3; ++c)
+      for (int tp = 0; tp < 9; ++tp) p0[(size_t)(tp * 3 + c) * C + co] = w0[((size_t)co * 3 + c) * 9 + tp];
+  for (int c = 0; c < C; ++c)
+    for (int tp = 0; tp < 9; ++tp) pd[(size_t)tp * C + c] = wd[(size_t)c * 9 + tp];
+  const int Kp = esam3_gemm_pad_k(C, dtype == 1 ? 2 : 4), Np = esam3_gemm_pad_n(C);
+  std::vector<float> pp((size_t)Np * Kp, 0.f);
+  for (int n = 0; n < C; ++n)
+    for (int k = 0; k < C; ++k) pp[(size_t)n * Kp + k] = wp[(size_t)n * C + k];
+  float* d0 = (float*)t.up(p0.data(), p0.size() * 4);
+  float* db0 = b0 ? (float*)t.up(b0, C * 4) : nullptr;
+  float* dd = (float*)t.up(pd.data(), pd.size() * 4);
+  float* dbd = bd ? (float*)t.up(bd, C * 4) : nullptr;
+  void* dp = t.upT(dtype, pp);
+  float* dbp = bp ? (float*)t.up(bp, C * 4) : nullptr;
+  if (!d0 || !dd || !dp || (b0 && !db0) || (bd && !dbd) || (bp && !dbp)) return fail("op_stem_dsconv");
+  if (op_timed("stem_dsconv", (hipStream_t)stream, [&]() {
+        return esam3_launch_stem_dsconv(dtype, img, d0, db0, dd, dbd, dp, Kp, dbp, out, B, H, W, (hipStream_t)stream, variant);
+      }))
+    return -1;
+  HIP_CHECK_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
 int esam3_op_lite_mla(int dtype, const void* ms, void* out, int B, int N, int groups, int dim, void* stream) {
   Tmp t;
   float* kv = (float*)t.raw(sizeof(float) * (size_t)esam3_lite_mla_scratch_floats(B, N, groups, dim));

@@ -555,6 +555,14 @@ int esam3_op_dwconv(int dtype, const void* x_dev, const float* w_host, const flo
 int esam3_op_stem(int dtype, const float* img_nchw_dev, const float* w_host /*[Cout][3][3][3]*/,
                   const float* bias_host, void* out_dev, int B, int H, int W, int Cout, int act,
                   void* hip_stream);
+/* EfficientViT input stem as ONE kernel: conv 3 -> 16 k3 s2 p1 (+BN folded) + Hardswish, then ResidualBlock(DSConv): depthwise 3x3 +
+ * Hardswish, pointwise 16 -> 16, + identity.  img NCHW fp32 on the device; w0 [16][3][3][3], wd [16][1][3][3], wp [16][16] host fp32;
+ * out NHWC [B][ceil(H/2)][ceil(W/2)][16].  variant 0 = the engine's path (bf16: persistent workgroups), 1 = the one-tile-per-workgroup
+ * kernel of round 2 (kept for the bit-exactness A/B of tests/test_ops_gpu.py).
+ * Reference: sam3/backbones/efficientvit/backbone.py:48-70 (input_stem), nn/ops.py:285-306 (DSConv), :740-770 (ResidualBlock) */
+int esam3_op_stem_dsconv(int dtype, const float* img_nchw_dev, const float* w0_host, const float* b0_host, const float* wd_host,
+                         const float* bd_host, const float* wp_host, const float* bp_host, void* out_dev, int B, int H, int W,
+                         int variant, void* hip_stream);
 /* LiteMLA linear attention on a [B][N][2*3*heads*dim] multi-scale qkv tensor */
 int esam3_op_lite_mla(int dtype, const void* ms_dev, void* out_dev, int B, int N, int groups,
                       int dim, void* hip_stream);

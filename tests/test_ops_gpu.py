@@ -358,6 +358,32 @@ def test_stem(mode, Cout):
 
 
 @pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("B,H,W", [(2, 38, 42), (3, 150, 134), (1, 64, 64)])
+def test_stem_dsconv(mode, B, H, W):
+    """The fused EfficientViT input stem (backbone.py:48-70: stem conv + Hardswish -> DSConv residual block) against torch;
+    in bf16 the persistent kernel of round 6 must equal the one-tile-per-workgroup kernel bit for bit."""
+    d, tdt = U.DT[mode]
+    C = 16
+    x = _rand(B, 3, H, W, seed=1)
+    w0, b0 = _rand(C, 3, 3, 3, seed=2) / 27 ** 0.5, _rand(C, seed=3) * 0.1
+    wd, bd = _rand(C, 1, 3, 3, seed=4) / 3.0, _rand(C, seed=5) * 0.1
+    wp, bp = _rand(C, C, seed=6) / 4.0, _rand(C, seed=7) * 0.1
+    y0 = F.hardswish(F.conv2d(x, w0, b0, stride=2, padding=1))
+    y1 = F.hardswish(F.conv2d(y0, wd, bd, padding=1, groups=C))
+    ref = y0 + F.conv2d(y1, wp[:, :, None, None], bp)
+    x_d = x.to("cuda")
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    outs = []
+    for variant in (0, 1):
+        out = torch.full((B, OH, OW, C), float("nan"), dtype=tdt, device="cuda")
+        U.check(U.lib().esam3_op_stem_dsconv(d, U.P(x_d), U.H(U.np32(w0)), U.H(U.np32(b0)), U.H(U.np32(wd)), U.H(U.np32(bd)),
+                                             U.H(U.np32(wp)), U.H(U.np32(bp)), U.P(out), B, H, W, variant, None), "op_stem_dsconv")
+        U.assert_close(U.from_dev_nhwc(out), ref, mode, f"stem_dsconv variant {variant}", scale=2.0)
+        outs.append(out)
+    assert torch.equal(outs[0].view(torch.int16 if mode == "bf16" else torch.int32), outs[1].view(torch.int16 if mode == "bf16" else torch.int32))
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("B,N,heads,dim", [(2, 700, 8, 16), (1, 3969, 8, 16), (3, 1024, 16, 16), (1, 500, 6, 32)])
 def test_lite_mla(mode, B, N, heads, dim):
     """ops.py:584-621 on a [B, 2*heads groups x (q|k|v) x dim, N] tensor."""

@@ -9,7 +9,7 @@ SRC=${SRC:-gemm256p}
 for spec in "$@"; do
   name="${spec%%:*}"; flags="${spec#*:}"
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-variable $flags -c $SRC.hip -o ../../build_dev/${SRC}_$name.o
-  objs=$(ls build/*.o | grep -v "/$SRC.o")
+  objs=$(ls build/*.o | grep -v "/$SRC.o" | grep -v "/dev_")
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build_dev/libesam3_$name.so $objs ../../build_dev/${SRC}_$name.o
   echo "built build_dev/libesam3_$name.so ($flags)"
 done

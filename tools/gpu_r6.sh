@@ -222,5 +222,42 @@ r)
   } > $O/r_mla1_ab.txt 2>&1
   cat $O/r_mla1_ab.txt
   ;;
-*) echo "usage: $0 {a..r}"; exit 2 ;;
+s)
+  # round 6, GPU call S: persistent input-stem kernel -- op test (bit-equal to the round-2 kernel), then timing per workgroups-per-CU setting
+  timeout 600 python -m pytest tests/test_ops_gpu.py -q -m gpu -k "stem" --timeout 500 > $O/s_stem_tests.txt 2>&1
+  tail -5 $O/s_stem_tests.txt | cut -c1-300
+  export ESAM3_DEV_LIB=build_dev/libesam3_dev.so ESAM3_OP_REPEAT=30
+  {
+  for wgs in 2 3 4 5; do
+    echo "== ESAM3_STEM_WGS=$wgs (variant 0 = persistent, 1 = one tile per workgroup)"
+    ESAM3_STEM_WGS=$wgs timeout 120 python tools/stem_bench.py 0 1 2>&1 | grep op_timed
+  done
+  } > $O/s_stem_ab.txt 2>&1
+  cat $O/s_stem_ab.txt
+  ;;
+t)
+  # round 6, GPU call T: mla1v + the 1024-thread kvprep + the persistent stem in the engine: exactness tests, the expand-write order A/B
+  # of the fused MBConvs (flip by pixel bit 2 instead of bit 1), the headline line with its per-launch table
+  timeout 900 python -m pytest tests/test_lattice_gpu.py tests/test_ops_gpu.py -q -m gpu -k "mla or lite or stem or mbconv" --timeout 500 > $O/t_tests.txt 2>&1
+  tail -3 $O/t_tests.txt | cut -c1-300
+  timeout 900 python -m pytest tests/test_e2e_gpu.py -q -m gpu -x --timeout 800 > $O/t_e2e.txt 2>&1
+  tail -3 $O/t_e2e.txt | cut -c1-300
+  export ESAM3_OP_REPEAT=50
+  {
+  for lib in dev flip4 dev flip4; do
+    echo "== build_dev/libesam3_$lib.so"
+    ESAM3_DEV_LIB=build_dev/libesam3_$lib.so timeout 200 python tools/evit_fused_bench.py s0.1 s1.1 s2.loc s3.loc s2.ctx s3.ctx 2>&1 | grep op_timed
+  done
+  } > $O/t_flip_ab.txt 2>&1
+  cat $O/t_flip_ab.txt
+  unset ESAM3_OP_REPEAT
+  ESAM3_BENCH_PROFILE_OUT=$O/t_bench_per_launch.json timeout 400 python bench.py > $O/t_bench.json 2> $O/t_bench.err
+  python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r06/t_bench.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d["roofline"], {k: v for k, v in d["config"].items() if k.endswith("images_per_s")})
+PY
+  python tools/roofline_table.py $O/t_bench_per_launch.json > $O/t_roofline_headline.md 2>/dev/null; head -40 $O/t_roofline_headline.md | cut -c1-160
+  ;;
+*) echo "usage: $0 {a..t}"; exit 2 ;;
 esac
