@@ -1578,17 +1578,23 @@ int launch_mb3s(Mb3Params p, hipStream_t stream) {
 //   * per-channel vectors (b1, bd, the nine depthwise taps as bf16) are staged in LDS once per workgroup.
 // LDS: mid 36 KB + dwo 16 KB + W1 16 / 32 KB + W2 16 / 32 KB + vectors 6.5 / 13 KB (Cmid 512 / 1024).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int CIN>
+template <int CIN, int S = 1, int COUT = CIN>
 __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
   typedef bf16_t T;
-  constexpr int COUT = CIN, CMID = 4 * CIN, NW = 8, S = 1;
-  constexpr int TH = 8, TW = 16, OP = TH * TW, HH = 10, HW = 18, HP = HH * HW, NPT = 6, MP = NPT * 32;
+  // Round 6: also the two stride-2 blocks that open stages 3 and 4 (64 -> 256 -> 128 at 126^2 and 128 -> 512 -> 256 at 63^2), until now on the
+  // generic one-tile-per-workgroup kernel (0.147 + 0.161 ms, 0.06 - 0.08 of their floors: pixel and weight fragments re-read from L2 for
+  // every chunk).  S = 2: 8 x 8 output tile, 17 x 17 halo = 10 pixel tiles of 32 -- waves 0, 1 own two of them --, pitch 160 B.
+  constexpr int CMID = 4 * CIN, NW = 8;
+  constexpr int TH = 8, TW = S == 1 ? 16 : 8, OP = TH * TW;
+  constexpr int HH = TH * S + (S == 1 ? 2 : 1), HW = TW * S + (S == 1 ? 2 : 1), HP = HH * HW;
+  constexpr int NPT = (HP + 31) / 32, MP = NPT * 32, TPW = (NPT + NW - 1) / NW;   // pixel tiles per wave: 1 / 2
   constexpr int KS = CIN / 16, NT = COUT / 32, NCH = CMID / 64;
-  constexpr int PITCH = 192;
+  constexpr int PITCH = S == 1 ? 192 : 160;
   constexpr int W1B = 64 * CIN * 2, W2B = COUT * 128;              // bytes of one chunk's weights
+  static_assert(W1B % 8192 == 0 && W2B % 8192 == 0 && (S == 1 || S == 2) && (S == 2 || COUT == CIN), "shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* mid = smem;                                  // [192 halo px][192 B]
-  char* dwo = mid + MP * PITCH;                      // [128 px][128 B] GEMM swizzle
+  char* mid = smem;                                  // [halo px][PITCH]
+  char* dwo = mid + MP * PITCH;                      // [OP px][128 B] GEMM swizzle
   char* w1s = dwo + OP * 128;                        // [64 rows][CIN] bf16, slot ^ (row & 15)
   char* w2s = w1s + W1B;                             // [COUT rows][64] bf16, swz(row, slot)
   float* sb1 = reinterpret_cast<float*>(w2s + W2B);  // [CMID]
@@ -1619,13 +1625,16 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
   // ---- weight staging by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B -> 1 KB of LDS, lane-linear): the swizzles are
   //      applied to the SOURCE address (cdna_hip_programming.md 5.4 rule 21); wave w issues pieces w, w + 8, ...
   const uint32_t w1_lds = lds_addr(w1s), w2_lds = lds_addr(w2s);
-  auto dma_w1 = [&](int ch) {   // W1 rows ch*64 .. +64, all CIN columns -> [row][CIN] with 16-byte slot ^ (row & 15)
+  // 16-byte slot of a W1 row in LDS: rows of >= 256 B: slot ^ (row & 15); 128-byte rows (Cin = 64) hold 8 slots and two rows share a bank
+  // row: the GEMM swizzle slot ^ ((row >> 1) & 7) -- both conflict-free for the 32-row ds_read_b128 A fragments
+  auto w1slot = [](int slot, int row) { return CIN >= 128 ? slot ^ (row & 15) : slot ^ ((row >> 1) & 7); };
+  auto dma_w1 = [&](int ch) {   // W1 rows ch*64 .. +64, all CIN columns -> [row][CIN], swizzled slots
 #pragma unroll
     for (int j = 0; j < W1B / 8192; ++j) {
       const int piece = wave + 8 * j;
       const int byte = piece * 1024 + lane * 16;
       const int row = byte / (CIN * 2), pslot = (byte - row * (CIN * 2)) >> 4;
-      const uint32_t voff = (uint32_t)(((ch * 64 + row) * p.Kp1 + ((pslot ^ (row & 15)) << 3)) * 2);
+      const uint32_t voff = (uint32_t)(((ch * 64 + row) * p.Kp1 + (w1slot(pslot, row) << 3)) * 2);
       dma_piece(gw1, voff, w1_lds + (uint32_t)piece * 1024u);
     }
   };
@@ -1640,32 +1649,41 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
     }
   };
 
-  // ---- pixel fragments: waves 0..5 own halo pixel tile `wave` ----
-  u32x4 fa[KS];
-  bool xin = false;
+  // ---- pixel fragments: wave w owns the halo pixel tiles w, w + 8, ... < NPT ----
+  u32x4 fa[TPW][KS];
+  unsigned xin = 0;   // bit k: the lane's pixel of its k-th tile is inside the image
   auto load_x = [&](unsigned tile, unsigned& b_, int& oy0_, int& ox0_) {
     b_ = tile / tpi;
     const unsigned ti = tile - b_ * tpi;
     const int ty = (int)(ti / (unsigned)p.tiles_x), tx = (int)(ti - ty * p.tiles_x);
     oy0_ = ty * TH; ox0_ = tx * TW;
-    const int hp = wave * 32 + l31;
-    const int hy = hp / HW, hx = hp - hy * HW;
-    const int iy = oy0_ - 1 + hy, ix = ox0_ - 1 + hx;
-    xin = wave < NPT && hp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    const T* px = gx + (int64_t)(((b_ * (unsigned)p.H + (xin ? iy : 0)) * (unsigned)p.W + (xin ? ix : 0)) * (unsigned)CIN);
+    xin = 0;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      fa[ks] = u32x4{0u, 0u, 0u, 0u};
-      if (xin) fa[ks] = *reinterpret_cast<const u32x4*>(px + (2 * ks + g) * 8);
+    for (int k = 0; k < TPW; ++k) {
+      const int pt = wave + NW * k;
+      const int hp = pt * 32 + l31;
+      const int hy = hp / HW, hx = hp - hy * HW;
+      const int iy = oy0_ * S - 1 + hy, ix = ox0_ * S - 1 + hx;
+      const bool in = pt < NPT && hp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const T* px = gx + (int64_t)(((b_ * (unsigned)p.H + (in ? iy : 0)) * (unsigned)p.W + (in ? ix : 0)) * (unsigned)CIN);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        fa[k][ks] = u32x4{0u, 0u, 0u, 0u};
+        if (in) fa[k][ks] = *reinterpret_cast<const u32x4*>(px + (2 * ks + g) * 8);
+      }
+      if (in) xin |= 1u << k;
     }
   };
 
-  constexpr int CW = 2, NTW = NT / CW;     // project: pixel tile = wave & 3, channel tiles (wave >> 2) + 2t
-  const int ppt = wave & 3, pnt0 = wave >> 2;
-  constexpr int DROWS = 4;                 // depthwise: run of 4 columns = wave & 3, rows 4 (wave >> 2) .. + 4
+  // project: pixel tile = wave % PW, channel tiles (wave / PW) + CW t
+  constexpr int PT = OP / 32, PW = PT, CW = NW / PW, NTW = NT / CW;
+  static_assert(NT % CW == 0, "project split");
+  const int ppt = wave % PW, pnt0 = wave / PW;
+  // depthwise: run of 4 columns = wave % QN, rows DROWS (wave / QN) .. + DROWS
+  constexpr int QN = TW / 4, DROWS = TH / (NW / QN);
   const int blk = lane >> 2, pi = lane & 3;
-  const int dq = wave & 3, drow0 = (wave >> 2) * DROWS;
-  const unsigned daddr = lds_addr(mid + (drow0 * HW + 4 * dq + pi) * PITCH + blk * 8);
+  const int dq = wave % QN, drow0 = (wave / QN) * DROWS;
+  const unsigned daddr = lds_addr(mid + ((drow0 * S) * HW + (4 * dq + pi) * S) * PITCH + blk * 8);
 
   unsigned b = 0;
   int oy0 = 0, ox0 = 0;
@@ -1679,8 +1697,11 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
     const bool has_next = t + nx < cnt;
     unsigned nb = b;
     int noy0 = oy0, nox0 = ox0;
-    const bool any_out = __builtin_amdgcn_ballot_w64(!xin && wave < NPT) != 0ull;
-    const bool xin_t = xin;
+    unsigned own = 0;
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) own |= (wave + NW * k) < NPT ? 1u << k : 0u;
+    const bool any_out = __builtin_amdgcn_ballot_w64((xin & own) != own) != 0ull;
+    const unsigned xin_t = xin;
     f32x16_v accp[NTW];
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt)
@@ -1694,9 +1715,12 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
     for (int ch = 0; ch < NCH; ++ch) {
       const int c0 = ch * 64;
       dma_w2(ch);   // W2 buffer is free (barrier C of the previous chunk); lands under the expand phase
-      // ================= E (waves 0..5): mid[px tile = wave][64] =================
-      if (wave < NPT) {
-        const int hp = wave * 32 + l31;
+      // ================= E: mid[px tiles of this wave][64] =================
+#pragma unroll
+      for (int k = 0; k < TPW; ++k) {
+        const int pt = wave + NW * k;
+        if (pt >= NPT) continue;   // wave-uniform
+        const int hp = pt * 32 + l31;
 #pragma unroll
         for (int ejt = 0; ejt < 2; ++ejt) {
           f32x16_v acc;
@@ -1709,16 +1733,17 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
           const char* wrow = w1s + row * (CIN * 2);
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            const u32x4 fwv = *reinterpret_cast<const u32x4*>(wrow + (((2 * ks + g) ^ (row & 15)) << 4));
-            MmaOps<T>::mma(fwv, fa[ks], acc);
+            const u32x4 fwv = *reinterpret_cast<const u32x4*>(wrow + (w1slot(2 * ks + g, row) << 4));
+            MmaOps<T>::mma(fwv, fa[k][ks], acc);
           }
           float v[16];
 #pragma unroll
           for (int e = 0; e < 16; ++e) v[e] = acc[e];
           hsw_n<16>(v);
           if (any_out) {
+            const bool in = (xin_t >> k) & 1u;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = xin_t ? v[e] : 0.f;
+            for (int e = 0; e < 16; ++e) v[e] = in ? v[e] : 0.f;
           }
           u32x4 o[2];
 #pragma unroll
@@ -1729,7 +1754,7 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
             auto s1 = __builtin_amdgcn_permlane32_swap(a1, c1_, false, false);
             o[qp] = u32x4{s0[0], s1[0], s0[1], s1[1]};
           }
-          const bool flip = (l31 >> 1) & 1;   // (flipping by pixel bit 2 instead measured the same: profiles/r06/flip_ab.txt)
+          const bool flip = S == 1 && ((l31 >> 1) & 1);   // (flipping by pixel bit 2 instead measured the same: profiles/r06/flip_ab.txt)
           const u32x4 w0 = flip ? o[1] : o[0], w1v = flip ? o[0] : o[1];
           char* rowp = mid + hp * PITCH + ((ejt * 4 + g) << 4);
           *reinterpret_cast<u32x4*>(rowp + (flip ? 32 : 0)) = w0;
@@ -1782,7 +1807,7 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of W1(ch + 1) (and the next tile's pixels) have landed
       __syncthreads();   // C: W1(ch + 1) complete, W2 buffer free
     }
-    // ================= out = acc + b2 + x =================
+    // ================= out = acc + b2 (+ x) =================
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt) {
       const int nt = pnt0 + tt * CW;
@@ -1792,7 +1817,7 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
         const float4 bb = *reinterpret_cast<const float4*>(p.b2 + nt * 32 + 8 * q + 4 * g);
         v[4 * q + 0] = accp[tt][4 * q + 0] + bb.x; v[4 * q + 1] = accp[tt][4 * q + 1] + bb.y;
         v[4 * q + 2] = accp[tt][4 * q + 2] + bb.z; v[4 * q + 3] = accp[tt][4 * q + 3] + bb.w;
-        if (p.residual && ok) {
+        if (S == 1 && p.residual && ok) {
           const uint2 u2 = *reinterpret_cast<const uint2*>(gx + opix * CIN + nt * 32 + 8 * q + 4 * g);
           v[4 * q + 0] += __uint_as_float(u2.x << 16); v[4 * q + 1] += __uint_as_float(u2.x & 0xffff0000u);
           v[4 * q + 2] += __uint_as_float(u2.y << 16); v[4 * q + 3] += __uint_as_float(u2.y & 0xffff0000u);
@@ -1814,13 +1839,14 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
   }
 }
 
-template <int CIN>
+template <int CIN, int S = 1, int COUT = CIN>
 int launch_mb3b(Mb3Params p, hipStream_t stream) {
-  p.tiles_x = (p.OW + 15) / 16;
+  constexpr int TW = S == 1 ? 16 : 8, HP = S == 1 ? 180 : 289, MP = (HP + 31) / 32 * 32, PITCH = S == 1 ? 192 : 160;
+  p.tiles_x = (p.OW + TW - 1) / TW;
   p.tiles_y = (p.OH + 7) / 8;
   const unsigned ntiles = (unsigned)p.B * p.tiles_x * p.tiles_y;
-  constexpr size_t lds = (size_t)192 * 192 + 128 * 128 + 64 * CIN * 2 + CIN * 128 + (size_t)4 * CIN * (4 + 4 + 18);
-  auto kern = mbconv3b_kernel<CIN>;
+  constexpr size_t lds = (size_t)MP * PITCH + 8 * TW * 128 + 64 * CIN * 2 + COUT * 128 + (size_t)4 * CIN * (4 + 4 + 18);
+  auto kern = mbconv3b_kernel<CIN, S, COUT>;
   if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)) return -1;
   unsigned grid = 256;   // one persistent workgroup per CU, a multiple of the 8 XCDs
   if (grid > ntiles) grid = ntiles;
@@ -1880,7 +1906,11 @@ int esam3_launch_mbconv3(const void* x, void* out, const void* w1, int Kp1, cons
     if (stride == 2 && Cin == 32) return launch_mb3s<2, 32, 64>(q, stream);
     if (stride == 1 && Cin == 32) return launch_mb3s<1, 32, 32>(q, stream);
     if (stride == 1) return launch_mb3s<1, 64, 64>(q, stream);
-    // 64 -> 128 stride 2: 5 x 4 pixel fragments per lane do not fit next to the prefetches: generic kernel below
+    // 64 -> 128 stride 2: 5 x 4 pixel fragments per lane do not fit next to the prefetches: the 8-wave kernel below
+  }
+  if (stride == 2 && Cin >= 64 && Cmid == 4 * Cin && Cout == 2 * Cin && !esam3_dev_flag("ESAM3_MB3_GENERIC")) {   // round 6
+    if (Cin == 64) return launch_mb3b<64, 2, 128>(q, stream);
+    return launch_mb3b<128, 2, 256>(q, stream);
   }
   if (stride == 1 && Cin >= 128 && Cmid == 4 * Cin && !esam3_dev_flag("ESAM3_MB3_GENERIC")) {   // weights through LDS, resident pixels
     if (Cin == 128) return launch_mb3b<128>(q, stream);

@@ -70,6 +70,7 @@ def _same_integers(got, ref, what=""):
     (2, 21, 19, 64, 256, 128, 2, 0), (1, 16, 16, 128, 512, 128, 1, 1), (2, 63, 63, 128, 512, 128, 1, 1), (1, 31, 29, 128, 512, 256, 2, 0),
     (1, 9, 9, 256, 1024, 256, 1, 1), (2, 32, 32, 256, 1024, 256, 1, 1), (3, 64, 64, 16, 64, 32, 2, 0),
     (4, 126, 126, 64, 256, 64, 1, 1),   # many persistent-loop iterations per workgroup (tile hand-over, prefetched fragments)
+    (9, 126, 126, 64, 256, 128, 2, 0),  # round 6: the stride-2 form of the 8-wave kernel, several tiles per workgroup
 ])
 def test_mbconv3_exact_on_the_lattice(B, H, W, Cin, Cmid, Cout, stride, res):
     """every fused MBConv variant (mbconv3s / mbconv3b / mbconv3 generic) on multiples of 3: expand -> Hardswish -> depthwise ->

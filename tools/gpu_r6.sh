@@ -259,5 +259,18 @@ print(d["value"], d["ms_per_step"], d["roofline"], {k: v for k, v in d["config"]
 PY
   python tools/roofline_table.py $O/t_bench_per_launch.json > $O/t_roofline_headline.md 2>/dev/null; head -40 $O/t_roofline_headline.md | cut -c1-160
   ;;
-*) echo "usage: $0 {a..t}"; exit 2 ;;
+u)
+  # round 6, GPU call U: the stride-2 blocks of stages 3 / 4 on the 8-wave persistent kernel (mbconv3b<S = 2>): lattice + op tests, A/B vs the generic kernel
+  timeout 900 python -m pytest tests/test_lattice_gpu.py tests/test_ops_gpu.py -q -m gpu -k "mbconv" --timeout 500 > $O/u_tests.txt 2>&1
+  tail -3 $O/u_tests.txt | cut -c1-300
+  export ESAM3_OP_REPEAT=50 ESAM3_DEV_LIB=build_dev/libesam3_dev.so
+  {
+  for gen in 1 0 1 0; do
+    echo "== ESAM3_MB3_GENERIC=$gen"
+    ESAM3_MB3_GENERIC=$gen timeout 200 python tools/evit_fused_bench.py s2.0 s3.0 2>&1 | grep op_timed
+  done
+  } > $O/u_mb3b_s2_ab.txt 2>&1
+  cat $O/u_mb3b_s2_ab.txt
+  ;;
+*) echo "usage: $0 {a..u}"; exit 2 ;;
 esac
