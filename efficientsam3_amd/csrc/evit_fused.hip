@@ -1578,8 +1578,8 @@ int launch_mb3s(Mb3Params p, hipStream_t stream) {
 //   * per-channel vectors (b1, bd, the nine depthwise taps as bf16) are staged in LDS once per workgroup.
 // LDS: mid 36 KB + dwo 16 KB + W1 16 / 32 KB + W2 16 / 32 KB + vectors 6.5 / 13 KB (Cmid 512 / 1024).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int CIN, int S = 1, int COUT = CIN>
-__global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
+template <int CIN, int S = 1, int COUT = CIN, bool GELU = false>
+__global__ __launch_bounds__(512, (CIN < 64 || (CIN == 64 && S == 1)) ? 4 : 2) void mbconv3b_kernel(Mb3Params p) {
   typedef bf16_t T;
   // Round 6: also the two stride-2 blocks that open stages 3 and 4 (64 -> 256 -> 128 at 126^2 and 128 -> 512 -> 256 at 63^2), until now on the
   // generic one-tile-per-workgroup kernel (0.147 + 0.161 ms, 0.06 - 0.08 of their floors: pixel and weight fragments re-read from L2 for
@@ -1591,7 +1591,8 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
   constexpr int KS = CIN / 16, NT = COUT / 32, NCH = CMID / 64;
   constexpr int PITCH = S == 1 ? 192 : 160;
   constexpr int W1B = 64 * CIN * 2, W2B = COUT * 128;              // bytes of one chunk's weights
-  static_assert(W1B % 8192 == 0 && W2B % 8192 == 0 && (S == 1 || S == 2) && (S == 2 || COUT == CIN), "shape");
+  static_assert(W1B % 1024 == 0 && W2B % 1024 == 0 && (S == 1 || S == 2) && (S == 2 || COUT == CIN), "shape");
+  constexpr int W1P = W1B / 1024, W2P = W2B / 1024;   // 1 KB LDS-DMA pieces per chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* mid = smem;                                  // [halo px][PITCH]
   char* dwo = mid + MP * PITCH;                      // [OP px][128 B] GEMM swizzle
@@ -1627,11 +1628,15 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
   const uint32_t w1_lds = lds_addr(w1s), w2_lds = lds_addr(w2s);
   // 16-byte slot of a W1 row in LDS: rows of >= 256 B: slot ^ (row & 15); 128-byte rows (Cin = 64) hold 8 slots and two rows share a bank
   // row: the GEMM swizzle slot ^ ((row >> 1) & 7) -- both conflict-free for the 32-row ds_read_b128 A fragments
-  auto w1slot = [](int slot, int row) { return CIN >= 128 ? slot ^ (row & 15) : slot ^ ((row >> 1) & 7); };
+  // (64-byte rows, Cin = 32: four rows per bank row, slot ^ ((row >> 2) & 3); 32-byte rows, Cin = 16: eight consecutive rows already tile it)
+  auto w1slot = [](int slot, int row) {
+    return CIN >= 128 ? slot ^ (row & 15) : CIN == 64 ? slot ^ ((row >> 1) & 7) : CIN == 32 ? slot ^ ((row >> 2) & 3) : slot;
+  };
   auto dma_w1 = [&](int ch) {   // W1 rows ch*64 .. +64, all CIN columns -> [row][CIN], swizzled slots
 #pragma unroll
-    for (int j = 0; j < W1B / 8192; ++j) {
+    for (int j = 0; j < (W1P + 7) / 8; ++j) {
       const int piece = wave + 8 * j;
+      if constexpr (W1P % 8 != 0) { if (piece >= W1P) continue; }   // wave-uniform
       const int byte = piece * 1024 + lane * 16;
       const int row = byte / (CIN * 2), pslot = (byte - row * (CIN * 2)) >> 4;
       const uint32_t voff = (uint32_t)(((ch * 64 + row) * p.Kp1 + (w1slot(pslot, row) << 3)) * 2);
@@ -1640,8 +1645,9 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
   };
   auto dma_w2 = [&](int ch) {   // W2 rows 0 .. COUT, columns ch*64 .. +64 -> [row][128 B] with the GEMM swizzle
 #pragma unroll
-    for (int j = 0; j < W2B / 8192; ++j) {
+    for (int j = 0; j < (W2P + 7) / 8; ++j) {
       const int piece = wave + 8 * j;
+      if constexpr (W2P % 8 != 0) { if (piece >= W2P) continue; }   // wave-uniform
       const int byte = piece * 1024 + lane * 16;
       const int row = byte >> 7, pslot = (byte & 127) >> 4;
       const uint32_t voff = (uint32_t)((row * p.Kp2 + ch * 64 + ((pslot ^ ((row >> 1) & 7)) << 3)) * 2);
@@ -1676,8 +1682,7 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
   };
 
   // project: pixel tile = wave % PW, channel tiles (wave / PW) + CW t
-  constexpr int PT = OP / 32, PW = PT, CW = NW / PW, NTW = NT / CW;
-  static_assert(NT % CW == 0, "project split");
+  constexpr int PT = OP / 32, PW = PT, CW = NW / PW, NTW = (NT + CW - 1) / CW;   // (narrow outputs: waves with pnt0 >= NT sit the phase out)
   const int ppt = wave % PW, pnt0 = wave / PW;
   // depthwise: run of 4 columns = wave % QN, rows DROWS (wave / QN) .. + DROWS
   constexpr int QN = TW / 4, DROWS = TH / (NW / QN);
@@ -1739,7 +1744,8 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
           float v[16];
 #pragma unroll
           for (int e = 0; e < 16; ++e) v[e] = acc[e];
-          hsw_n<16>(v);
+          if constexpr (GELU) gelu_fast_n<16>(v);   // TinyViT MBConv (tiny_vit.py:73-108): GELU after conv1 / conv2 and after the shortcut add
+          else hsw_n<16>(v);
           if (any_out) {
             const bool in = (xin_t >> k) & 1u;
 #pragma unroll
@@ -1784,7 +1790,15 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
 #pragma unroll
         for (int r = 0; r < DROWS; ++r) {
           const int op = (drow0 + r) * TW + 4 * dq + pi;
-          *reinterpret_cast<uint2*>(dwo + op * 128 + swz(op, blk >> 1) + (blk & 1) * 8) = hsw_pack4(acc[r]);
+          uint2 packed;
+          if constexpr (GELU) {
+            float a4[4] = {acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+            gelu_fast_n<4>(a4);
+            packed = make_uint2(pack_bf16x2(a4[0], a4[1]), pack_bf16x2(a4[2], a4[3]));
+          } else {
+            packed = hsw_pack4(acc[r]);
+          }
+          *reinterpret_cast<uint2*>(dwo + op * 128 + swz(op, blk >> 1) + (blk & 1) * 8) = packed;
         }
       }
       __syncthreads();   // B: dwo complete
@@ -1796,6 +1810,7 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
         for (int kc = 0; kc < 4; ++kc) fd[kc] = *reinterpret_cast<const u32x4*>(dwo + prow * 128 + swz(prow, kc * 2 + g));
 #pragma unroll
         for (int tt = 0; tt < NTW; ++tt) {
+          if constexpr (NT % CW != 0) { if (pnt0 + tt * CW >= NT) continue; }   // wave-uniform
           const int wr = (pnt0 + tt * CW) * 32 + l31;
 #pragma unroll
           for (int kc = 0; kc < 4; ++kc) {
@@ -1811,6 +1826,7 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt) {
       const int nt = pnt0 + tt * CW;
+      if constexpr (NT % CW != 0) { if (nt >= NT) continue; }   // wave-uniform
       float v[16];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1823,6 +1839,7 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
           v[4 * q + 2] += __uint_as_float(u2.y << 16); v[4 * q + 3] += __uint_as_float(u2.y & 0xffff0000u);
         }
       }
+      if constexpr (GELU) gelu_fast_n<16>(v);   // the block's closing activation follows the shortcut add
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp) {
         const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
@@ -1839,16 +1856,19 @@ __global__ __launch_bounds__(512, 2) void mbconv3b_kernel(Mb3Params p) {
   }
 }
 
-template <int CIN, int S = 1, int COUT = CIN>
+template <int CIN, int S = 1, int COUT = CIN, bool GELU = false>
 int launch_mb3b(Mb3Params p, hipStream_t stream) {
   constexpr int TW = S == 1 ? 16 : 8, HP = S == 1 ? 180 : 289, MP = (HP + 31) / 32 * 32, PITCH = S == 1 ? 192 : 160;
   p.tiles_x = (p.OW + TW - 1) / TW;
   p.tiles_y = (p.OH + 7) / 8;
   const unsigned ntiles = (unsigned)p.B * p.tiles_x * p.tiles_y;
   constexpr size_t lds = (size_t)MP * PITCH + 8 * TW * 128 + 64 * CIN * 2 + COUT * 128 + (size_t)4 * CIN * (4 + 4 + 18);
-  auto kern = mbconv3b_kernel<CIN, S, COUT>;
+  auto kern = mbconv3b_kernel<CIN, S, COUT, GELU>;
   if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)) return -1;
-  unsigned grid = 256;   // one persistent workgroup per CU, a multiple of the 8 XCDs
+  // persistent: one workgroup per CU, a multiple of the 8 XCDs; the narrow blocks (<= 128 VGPRs, <= 80 KB of LDS) run TWO per CU = four
+  // waves per SIMD (profiles/r06/mb3b_small_ab.txt: 256 / 512 / 768 workgroups)
+  unsigned grid = (lds <= 80 * 1024 && (CIN < 64 || (CIN == 64 && S == 1))) ? 512 : 256;
+  if (esam3_dev_flag("ESAM3_MB3B_GRID") > 0) grid = (unsigned)esam3_dev_flag("ESAM3_MB3B_GRID");
   if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, p);
   HIP_CHECK_RET(hipGetLastError());
@@ -1898,9 +1918,18 @@ int esam3_launch_mbconv3(const void* x, void* out, const void* w1, int Kp1, cons
       esam3_set_error("mbconv3: the GELU variant is built for 64 -> 256 -> 64 channels, stride 1, with the shortcut");
       return -1;
     }
-    return launch_mb3s<1, 64, 64, true>(q, stream);
+    if (esam3_dev_flag("ESAM3_MB3S")) return launch_mb3s<1, 64, 64, true>(q, stream);
+    return launch_mb3b<64, 1, 64, true>(q, stream);
   }
-  if (Cin <= 64 && !esam3_dev_flag("ESAM3_MB3_GENERIC")) {   // persistent + prefetching variant
+  if (Cin <= 64 && Cmid == 4 * Cin && !esam3_dev_flag("ESAM3_MB3_GENERIC") && !esam3_dev_flag("ESAM3_MB3S")) {
+    // round 6: the narrow blocks too run the 8-wave LDS-weight kernel, two workgroups per CU (0.264 -> 0.236, 0.267 -> 0.232, 0.137 ->
+    // 0.122, 0.184 -> 0.142 ms against the 4-wave mbconv3s; dev builds: ESAM3_MB3S=1 selects the latter)
+    if (stride == 2 && Cin == 16) return launch_mb3b<16, 2, 32>(q, stream);
+    if (stride == 2 && Cin == 32) return launch_mb3b<32, 2, 64>(q, stream);
+    if (stride == 1 && Cin == 32) return launch_mb3b<32, 1, 32>(q, stream);
+    if (stride == 1 && Cin == 64) return launch_mb3b<64, 1, 64>(q, stream);
+  }
+  if (Cin <= 64 && !esam3_dev_flag("ESAM3_MB3_GENERIC")) {   // persistent + prefetching 4-wave variant (any expand ratio up to Cmid 256)
     if (Cmid > 256) { esam3_set_error("mbconv3s: Cmid %d > 256", Cmid); return -1; }
     if (stride == 2 && Cin == 16) return launch_mb3s<2, 16, 32>(q, stream);
     if (stride == 2 && Cin == 32) return launch_mb3s<2, 32, 64>(q, stream);

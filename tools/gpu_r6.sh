@@ -272,5 +272,51 @@ u)
   } > $O/u_mb3b_s2_ab.txt 2>&1
   cat $O/u_mb3b_s2_ab.txt
   ;;
-*) echo "usage: $0 {a..u}"; exit 2 ;;
+v)
+  # round 6, GPU call V: A/B of the 64 -> 256 -> 64 stride-1 MBConv: 4-wave mbconv3s (two per CU) vs the 8-wave LDS-weight kernel mbconv3b<64> (one / two per CU)
+  export ESAM3_OP_REPEAT=50 ESAM3_DEV_LIB=build_dev/libesam3_dev.so
+  timeout 600 python -m pytest tests/test_lattice_gpu.py -q -m gpu -k "mbconv3" --timeout 500 > $O/v_tests_default.txt 2>&1; tail -1 $O/v_tests_default.txt
+  {
+  echo "== mbconv3s"; timeout 200 python tools/evit_fused_bench.py s1.1 tv.hs 2>&1 | grep op_timed
+  for grid in 256 512; do
+    echo "== mbconv3b<64>, grid $grid"
+    ESAM3_MB3B_64=1 ESAM3_MB3B_GRID=$grid timeout 200 python tools/evit_fused_bench.py s1.1 tv.hs 2>&1 | grep op_timed
+  done
+  echo "== mbconv3s"; timeout 200 python tools/evit_fused_bench.py s1.1 tv.hs 2>&1 | grep op_timed
+  } > $O/v_mb3b64_ab.txt 2>&1
+  cat $O/v_mb3b64_ab.txt
+  ;;
+w)
+  # round 6, GPU call W: the narrow MBConvs (Cin 16 / 32) on the 8-wave LDS-weight kernel at two workgroups per CU: exactness through the dev library, A/B vs mbconv3s
+  export ESAM3_DEV_LIB=build_dev/libesam3_dev.so
+  ESAM3_MB3B_SMALL=1 ESAM3_MB3B_64=1 ESAM3_MB3B_GRID=512 timeout 300 python tools/mbconv_variant_check.py 2>&1 | grep -v amdgpu > $O/w_variant_check.txt
+  cat $O/w_variant_check.txt
+  export ESAM3_OP_REPEAT=50
+  {
+  echo "== mbconv3s"; timeout 200 python tools/evit_fused_bench.py s0.0 s0.1 s1.0 s1.1 2>&1 | grep op_timed
+  for grid in 256 512 768; do
+    echo "== mbconv3b, grid $grid"
+    ESAM3_MB3B_SMALL=1 ESAM3_MB3B_64=1 ESAM3_MB3B_GRID=$grid timeout 200 python tools/evit_fused_bench.py s0.0 s0.1 s1.0 s1.1 2>&1 | grep op_timed
+  done
+  echo "== mbconv3s"; timeout 200 python tools/evit_fused_bench.py s0.0 s0.1 s1.0 s1.1 2>&1 | grep op_timed
+  } > $O/w_mb3b_small_ab.txt 2>&1
+  cat $O/w_mb3b_small_ab.txt
+  ;;
+x)
+  # round 6, GPU call X: every fused MBConv on the 8-wave LDS-weight kernel (narrow ones two per CU, TinyViT's GELU variant included): op / lattice /
+  # student / e2e tests, headline + TinyViT-11M lines with their per-launch tables
+  timeout 1200 python -m pytest tests/test_lattice_gpu.py tests/test_ops_gpu.py tests/test_students_gpu.py tests/test_e2e_gpu.py -q -m gpu --timeout 900 > $O/x_tests.txt 2>&1
+  tail -4 $O/x_tests.txt | cut -c1-300
+  ESAM3_BENCH_PROFILE_OUT=$O/x_bench_per_launch.json timeout 400 python bench.py > $O/x_bench.json 2> $O/x_bench.err
+  ESAM3_BENCH_PROFILE_OUT=$O/x_bench_tinyvit_per_launch.json timeout 400 python bench.py --backbone tinyvit --model 11m --no-cpu-baseline > $O/x_bench_tinyvit.json 2> $O/x_bench_tinyvit.err
+  python - <<'PY'
+import json
+for f in ("x_bench", "x_bench_tinyvit"):
+    d = json.loads(open(f"gpurun_out/r06/{f}.json").read().strip().splitlines()[-1])
+    print(f, d["value"], d["ms_per_step"], d["roofline"]["avg_launch_ms"], {k: v for k, v in d["config"].items() if k.endswith("images_per_s")})
+PY
+  python tools/roofline_table.py $O/x_bench_per_launch.json > $O/x_roofline_headline.md 2>/dev/null; head -34 $O/x_roofline_headline.md | cut -c1-150
+  python tools/roofline_table.py $O/x_bench_tinyvit_per_launch.json > $O/x_roofline_tinyvit_11m.md 2>/dev/null; head -12 $O/x_roofline_tinyvit_11m.md | cut -c1-150
+  ;;
+*) echo "usage: $0 {a..x}"; exit 2 ;;
 esac
