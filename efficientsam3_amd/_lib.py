@@ -178,6 +178,18 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    path = os.environ.get("ESAM3_DEV_LIB") or LIB_PATH   # development aid: an A/B build of the SAME sources (make dev / tools/dev_variants.sh)
+    if path != LIB_PATH:
+        if not os.path.exists(path):
+            raise Esam3Error(f"ESAM3_DEV_LIB={path} does not exist")
+        lib = C.CDLL(os.path.abspath(path))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _install_scope_hooks(lib)
+        _lib = lib
+        return lib
     if not os.path.exists(LIB_PATH):
         raise Esam3Error(
             f"{LIB_PATH} is missing: build it with `python -c \"import __graft_entry__ as g; "

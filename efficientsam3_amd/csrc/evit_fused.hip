@@ -1719,7 +1719,7 @@ __global__ __launch_bounds__(512, (CIN < 64 || (CIN == 64 && S == 1)) ? 4 : 2) v
 
     for (int ch = 0; ch < NCH; ++ch) {
       const int c0 = ch * 64;
-      dma_w2(ch);   // W2 buffer is free (barrier C of the previous chunk); lands under the expand phase
+      if (!MB3_ABL(32) || (t == wi && ch == 0)) dma_w2(ch);   // W2 buffer is free (barrier C of the previous chunk); lands under the expand phase
       // ================= E: mid[px tiles of this wave][64] =================
 #pragma unroll
       for (int k = 0; k < TPW; ++k) {
@@ -1771,7 +1771,7 @@ __global__ __launch_bounds__(512, (CIN < 64 || (CIN == 64 && S == 1)) ? 4 : 2) v
       __syncthreads();   // A: mid and W2(ch) complete; W1 buffer free (expand done)
       {
         const bool last = ch + 1 == NCH;
-        if (!last || has_next) dma_w1((ch + 1) % NCH);   // flat (tile, chunk) stream; lands under depthwise + project
+        if ((!last || has_next) && !MB3_ABL(32)) dma_w1((ch + 1) % NCH);   // flat (tile, chunk) stream; lands under depthwise + project
         if (last && has_next) load_x(first + t + nx, nb, noy0, nox0);
       }
       // ================= D =================
@@ -1937,7 +1937,8 @@ int esam3_launch_mbconv3(const void* x, void* out, const void* w1, int Kp1, cons
     if (stride == 1) return launch_mb3s<1, 64, 64>(q, stream);
     // 64 -> 128 stride 2: 5 x 4 pixel fragments per lane do not fit next to the prefetches: the 8-wave kernel below
   }
-  if (stride == 2 && Cin >= 64 && Cmid == 4 * Cin && Cout == 2 * Cin && !esam3_dev_flag("ESAM3_MB3_GENERIC")) {   // round 6
+  if (stride == 2 && Cin >= 64 && Cmid == 4 * Cin && Cout == 2 * Cin && !esam3_dev_flag("ESAM3_MB3_GENERIC") &&
+      !esam3_dev_flag("ESAM3_MB3S")) {   // round 6 (dev builds: ESAM3_MB3S=1 restores the whole round-5 dispatch)
     if (Cin == 64) return launch_mb3b<64, 2, 128>(q, stream);
     return launch_mb3b<128, 2, 256>(q, stream);
   }

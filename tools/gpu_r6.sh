@@ -318,5 +318,37 @@ PY
   python tools/roofline_table.py $O/x_bench_per_launch.json > $O/x_roofline_headline.md 2>/dev/null; head -34 $O/x_roofline_headline.md | cut -c1-150
   python tools/roofline_table.py $O/x_bench_tinyvit_per_launch.json > $O/x_roofline_tinyvit_11m.md 2>/dev/null; head -12 $O/x_roofline_tinyvit_11m.md | cut -c1-150
   ;;
-*) echo "usage: $0 {a..x}"; exit 2 ;;
+y)
+  # round 6, GPU call Y: the backbone counter passes BEFORE / AFTER this round's kernel work under identical conditions: the dev library (same sources +
+  # environment switches), headline step only (batch 32), 12 steps per pass; "before" = the round-5 dispatch restored by the switches
+  # (ESAM3_MLA1_OLD, ESAM3_MB3S, ESAM3_STEM_OLD; the kvprep change cannot be switched back)
+  cd /tmp && export TMPDIR=/tmp
+  export ESAM3_DEV_LIB=$R/build_dev/libesam3_dev.so
+  for which in before after; do
+    if [ $which = before ]; then export ESAM3_MLA1_OLD=1 ESAM3_MB3S=1 ESAM3_STEM_OLD=1; else unset ESAM3_MLA1_OLD ESAM3_MB3S ESAM3_STEM_OLD; fi
+    P=$R/$O/pmc_$which
+    rm -rf $P; mkdir -p $P
+    CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --headline-only"
+    rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --kernel-trace -d $P/sq1 -o a --output-format csv -- $CMD > /dev/null 2>&1
+    rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES --kernel-trace -d $P/sq2 -o b --output-format csv -- $CMD > /dev/null 2>&1
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $P/fetch -o f --output-format csv -- $CMD > /dev/null 2>&1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $P/write -o w --output-format csv -- $CMD > /dev/null 2>&1
+    (cd $R && python tools/pmc_kernels.py --pass $P/sq1 --pass $P/sq2 --pass $P/fetch --pass $P/write \
+      --match mbconv3s,mbconv3b,mbconv3_,mla1,mla2d,kvprep,stem_dsconv --out $O/pmc_backbone_${which}_b32.txt > /dev/null 2>&1)
+    echo "== $which"; grep -A2 "dispatches per pass" $R/$O/pmc_backbone_${which}_b32.txt | grep -v "^    [A-Z]" | grep -v "^--" | cut -c1-250
+    find $P -name "*.csv" -size +2M -delete
+  done
+  ;;
+z)
+  # round 6, GPU call Z: is the wide MBConv (Cin 128 / 256) waiting for its weight DMA?  ESAM3_MB3_ABL=32 stops the stream after the first chunk (timing only)
+  export ESAM3_OP_REPEAT=50 ESAM3_DEV_LIB=build_dev/libesam3_dev.so
+  {
+  for abl in 0 32 0 32; do
+    echo "== ESAM3_MB3_ABL=$abl"
+    ESAM3_MB3_ABL=$abl timeout 200 python tools/evit_fused_bench.py s2.loc s3.loc s2.0 s3.0 s1.1 2>&1 | grep op_timed
+  done
+  } > $O/z_mb3b_dma_abl.txt 2>&1
+  cat $O/z_mb3b_dma_abl.txt
+  ;;
+*) echo "usage: $0 {a..z}"; exit 2 ;;
 esac
