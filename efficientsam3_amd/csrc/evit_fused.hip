@@ -906,31 +906,39 @@ __global__ __launch_bounds__(512, 2) void mla1v_kernel(Mla1Params p) {
 
 // kv[b][g] = sum of the tile partials in a fixed order; written as the bf16 hi / lo MFMA operands of pass 2:
 // tab[b][g][op][lane][4], op 0/1 = kv hi / lo (lane (m = dv, kq): kv[m][4kq .. 4kq+3]), op 2/3 = ksum hi / lo (every row m)
-// Round 6: 1024 threads per (image, group): the partials are summed in FOUR interleaved quarters (thread quarter j takes partials
-// j, j + 4, ...), each with up to eight independent loads in flight, and the quarters are combined through LDS in a fixed order -- the
+// Round 6: 1024 threads per (image, group), SAME summation order as the 256-thread form of round 4 (kept below for the dev-build A/B): that
+// form keeps eight interleaved partial sums s_j = p[j] + p[j + 8] + ... and combines them as ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+// here thread quarter q owns s_2q and s_2q+1 (two rows of loads in flight per step, the steps unrolled by four so that sixteen loads are
+// out before the first add), forms t_q = s_2q + s_2q+1 and the quarters meet in LDS as (t0 + t1) + (t2 + t3) -- bit-identical tables.  The
 // 256-thread form walked the 64 partials of a 63 x 63 image in 8 dependent rounds of L2 latency (13.7 us per launch, 90 % of the wave time
-// parked: profiles/r06/pmc_backbone_before.txt).  Deterministic; the summation order differs from round 4's.
+// parked: profiles/r06/pmc_backbone_before.txt); 9.4 us now.
 __global__ __launch_bounds__(1024) void mla_kvprep_kernel(const float* __restrict__ kvp, bf16_t* __restrict__ tab, int P, int G) {
   __shared__ float red[2][3][256];
   const int bg = blockIdx.x;
   const int b = bg / G, gi = bg - b * G;
   const int t = threadIdx.x & 255, part = threadIdx.x >> 8, m = t >> 4, k = t & 15;
   const float* src = kvp + ((int64_t)b * P * G + gi) * 272;
-  float s8[4], k8[4];
+  const int64_t st = (int64_t)G * 272;
+  float sa = 0.f, sb = 0.f, ka = 0.f, kb = 0.f;   // s_2q, s_2q+1 and the ksum rows of the same partials
+  const int j0 = 2 * part, j1 = 2 * part + 1;
+  int q0 = 0;
+  for (; q0 + 32 <= P; q0 += 32) {   // four steps of eight partials: all sixteen loads first, the adds in the original order
+    float va[4], vb[4], wa[4], wb[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) s8[j] = k8[j] = 0.f;
-  for (int q0 = part; q0 < P; q0 += 16) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int q = q0 + 4 * j;
-      if (q < P) {
-        s8[j] += src[(int64_t)q * G * 272 + m * 16 + k];
-        k8[j] += src[(int64_t)q * G * 272 + 256 + k];
-      }
+    for (int u = 0; u < 4; ++u) {
+      va[u] = src[(q0 + 8 * u + j0) * st + m * 16 + k];
+      vb[u] = src[(q0 + 8 * u + j1) * st + m * 16 + k];
+      wa[u] = src[(q0 + 8 * u + j0) * st + 256 + k];
+      wb[u] = src[(q0 + 8 * u + j1) * st + 256 + k];
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { sa += va[u]; sb += vb[u]; ka += wa[u]; kb += wb[u]; }
   }
-  float s = (s8[0] + s8[1]) + (s8[2] + s8[3]);
-  float sk = (k8[0] + k8[1]) + (k8[2] + k8[3]);
+  for (; q0 < P; q0 += 8) {
+    if (q0 + j0 < P) { sa += src[(q0 + j0) * st + m * 16 + k]; ka += src[(q0 + j0) * st + 256 + k]; }
+    if (q0 + j1 < P) { sb += src[(q0 + j1) * st + m * 16 + k]; kb += src[(q0 + j1) * st + 256 + k]; }
+  }
+  float s = sa + sb, sk = ka + kb;
   if (part) {
     red[0][part - 1][t] = s;
     red[1][part - 1][t] = sk;
@@ -939,6 +947,35 @@ __global__ __launch_bounds__(1024) void mla_kvprep_kernel(const float* __restric
   if (part) return;
   s = (s + red[0][0][t]) + (red[0][1][t] + red[0][2][t]);
   sk = (sk + red[1][0][t]) + (red[1][1][t] + red[1][2][t]);
+  bf16_t* o = tab + (int64_t)bg * 4 * 256;
+  const int li = (m + 16 * (k >> 2)) * 4 + (k & 3);
+  const bf16_t h = f32_to_bf16(s), hk = f32_to_bf16(sk);
+  o[li] = h;
+  o[256 + li] = f32_to_bf16(s - bf16_to_f32(h));
+  o[512 + li] = hk;
+  o[768 + li] = f32_to_bf16(sk - bf16_to_f32(hk));
+}
+
+// the round-4 form (dev builds: ESAM3_KVPREP_OLD=1)
+__global__ __launch_bounds__(256) void mla_kvprep256_kernel(const float* __restrict__ kvp, bf16_t* __restrict__ tab, int P, int G) {
+  const int bg = blockIdx.x;
+  const int b = bg / G, gi = bg - b * G;
+  const int t = threadIdx.x, m = t >> 4, k = t & 15;
+  const float* src = kvp + ((int64_t)b * P * G + gi) * 272;
+  float s8[8], k8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s8[j] = k8[j] = 0.f;
+  for (int q0 = 0; q0 < P; q0 += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (q0 + j < P) {
+        s8[j] += src[(int64_t)(q0 + j) * G * 272 + m * 16 + k];
+        k8[j] += src[(int64_t)(q0 + j) * G * 272 + 256 + k];
+      }
+    }
+  }
+  const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+  const float sk = ((k8[0] + k8[1]) + (k8[2] + k8[3])) + ((k8[4] + k8[5]) + (k8[6] + k8[7]));
   bf16_t* o = tab + (int64_t)bg * 4 * 256;
   const int li = (m + 16 * (k >> 2)) * 4 + (k & 3);
   const bf16_t h = f32_to_bf16(s), hk = f32_to_bf16(sk);
@@ -1578,6 +1615,9 @@ int launch_mb3s(Mb3Params p, hipStream_t stream) {
 //   * per-channel vectors (b1, bd, the nine depthwise taps as bf16) are staged in LDS once per workgroup.
 // LDS: mid 36 KB + dwo 16 KB + W1 16 / 32 KB + W2 16 / 32 KB + vectors 6.5 / 13 KB (Cmid 512 / 1024).
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef ESAM3_MB3B_UNITS_CIN
+#define ESAM3_MB3B_UNITS_CIN 64   // A/B builds (tools/dev_variants.sh): 0 = whole-tile ownership everywhere
+#endif
 template <int CIN, int S = 1, int COUT = CIN, bool GELU = false>
 __global__ __launch_bounds__(512, (CIN < 64 || (CIN == 64 && S == 1)) ? 4 : 2) void mbconv3b_kernel(Mb3Params p) {
   typedef bf16_t T;
@@ -1587,7 +1627,12 @@ __global__ __launch_bounds__(512, (CIN < 64 || (CIN == 64 && S == 1)) ? 4 : 2) v
   constexpr int CMID = 4 * CIN, NW = 8;
   constexpr int TH = 8, TW = S == 1 ? 16 : 8, OP = TH * TW;
   constexpr int HH = TH * S + (S == 1 ? 2 : 1), HW = TW * S + (S == 1 ? 2 : 1), HP = HH * HW;
-  constexpr int NPT = (HP + 31) / 32, MP = NPT * 32, TPW = (NPT + NW - 1) / NW;   // pixel tiles per wave: 1 / 2
+  // expand work: UNITS (narrow blocks): unit u = (pixel tile u >> 1, channel half u & 1), wave w owns units w, w + 8, ... -- its channel half is
+  // w & 1 throughout and every SIMD (waves s, s + 4) carries the same number of units (3 of 12 at stride 1, 5 of 20 at stride 2; whole-tile
+  // ownership gave SIMDs 0 / 1 four resp. six); wide blocks keep whole pixel tiles per wave (waves 0 .. NPT - 1): their fragments fill the registers
+  constexpr bool UNITS = ESAM3_MB3B_UNITS_CIN >= CIN && !(CIN == 64 && S == 1);   // (64 -> 256 -> 64 at 128 VGPRs: 39 - 55 spilled registers)
+  constexpr int NPT = (HP + 31) / 32, MP = NPT * 32;
+  constexpr int TPW = UNITS ? (2 * NPT + NW - 1) / NW : (NPT + NW - 1) / NW;   // pixel tiles a wave holds fragments of
   constexpr int KS = CIN / 16, NT = COUT / 32, NCH = CMID / 64;
   constexpr int PITCH = S == 1 ? 192 : 160;
   constexpr int W1B = 64 * CIN * 2, W2B = COUT * 128;              // bytes of one chunk's weights
@@ -1666,7 +1711,7 @@ __global__ __launch_bounds__(512, (CIN < 64 || (CIN == 64 && S == 1)) ? 4 : 2) v
     xin = 0;
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
-      const int pt = wave + NW * k;
+      const int pt = UNITS ? (wave >> 1) + (NW / 2) * k : wave + NW * k;
       const int hp = pt * 32 + l31;
       const int hy = hp / HW, hx = hp - hy * HW;
       const int iy = oy0_ * S - 1 + hy, ix = ox0_ * S - 1 + hx;
@@ -1704,7 +1749,7 @@ __global__ __launch_bounds__(512, (CIN < 64 || (CIN == 64 && S == 1)) ? 4 : 2) v
     int noy0 = oy0, nox0 = ox0;
     unsigned own = 0;
 #pragma unroll
-    for (int k = 0; k < TPW; ++k) own |= (wave + NW * k) < NPT ? 1u << k : 0u;
+    for (int k = 0; k < TPW; ++k) own |= (UNITS ? (wave >> 1) + (NW / 2) * k : wave + NW * k) < NPT ? 1u << k : 0u;
     const bool any_out = __builtin_amdgcn_ballot_w64((xin & own) != own) != 0ull;
     const unsigned xin_t = xin;
     f32x16_v accp[NTW];
@@ -1723,11 +1768,12 @@ __global__ __launch_bounds__(512, (CIN < 64 || (CIN == 64 && S == 1)) ? 4 : 2) v
       // ================= E: mid[px tiles of this wave][64] =================
 #pragma unroll
       for (int k = 0; k < TPW; ++k) {
-        const int pt = wave + NW * k;
+        const int pt = UNITS ? (wave >> 1) + (NW / 2) * k : wave + NW * k;
         if (pt >= NPT) continue;   // wave-uniform
         const int hp = pt * 32 + l31;
 #pragma unroll
-        for (int ejt = 0; ejt < 2; ++ejt) {
+        for (int ej = 0; ej < (UNITS ? 1 : 2); ++ej) {
+          const int ejt = UNITS ? (wave & 1) : ej;
           f32x16_v acc;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -2002,7 +2048,10 @@ int esam3_launch_mla_fused(const void* x, void* out, const void* wqkv, int Kpq, 
     hipLaunchKernelGGL((mla1_kernel<256>), dim3((unsigned)(B * tiles)), dim3(512), lds1, stream, a);
   }
   HIP_CHECK_RET(hipGetLastError());
-  hipLaunchKernelGGL(mla_kvprep_kernel, dim3((unsigned)(B * G)), dim3(1024), 0, stream, kvp, reinterpret_cast<bf16_t*>(tab), tiles * 2, G);
+  if (esam3_dev_flag("ESAM3_KVPREP_OLD"))
+    hipLaunchKernelGGL(mla_kvprep256_kernel, dim3((unsigned)(B * G)), dim3(256), 0, stream, kvp, reinterpret_cast<bf16_t*>(tab), tiles * 2, G);
+  else
+    hipLaunchKernelGGL(mla_kvprep_kernel, dim3((unsigned)(B * G)), dim3(1024), 0, stream, kvp, reinterpret_cast<bf16_t*>(tab), tiles * 2, G);
   HIP_CHECK_RET(hipGetLastError());
   Mla2Params q{};
   q.qms = qms; q.tab = tab; q.wp = wproj; q.bp = bproj; q.x = x; q.out = out;

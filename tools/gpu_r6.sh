@@ -350,5 +350,25 @@ z)
   } > $O/z_mb3b_dma_abl.txt 2>&1
   cat $O/z_mb3b_dma_abl.txt
   ;;
-*) echo "usage: $0 {a..z}"; exit 2 ;;
+aa)
+  # round 6, GPU call AA: expand units split (pixel tile, channel half) over the 8 waves of mbconv3b: exactness + timing per threshold (0 = whole tiles everywhere)
+  export ESAM3_OP_REPEAT=50
+  {
+  for v in u0 u16 u32 u64 u0; do
+    echo "== build_dev/libesam3_$v.so"
+    ESAM3_DEV_LIB=build_dev/libesam3_$v.so timeout 300 python tools/mbconv_variant_check.py 2>&1 | grep -E "ALL EXACT|DIFFER|differ" | grep -v " 0 of" 
+    ESAM3_DEV_LIB=build_dev/libesam3_$v.so timeout 200 python tools/evit_fused_bench.py s0.0 s0.1 s1.0 s1.1 s2.0 tv.0 2>&1 | grep op_timed
+  done
+  } > $O/aa_units_ab.txt 2>&1
+  cat $O/aa_units_ab.txt
+  ;;
+ab)
+  # round 6, GPU call AB: this round's backbone kernels vs the ones they replace, bit for bit on real data (dev library switches), then the PCS
+  # bf16 distribution test that moved (x1.33 -> x1.53 on one box) with the order-preserving kvprep
+  ESAM3_DEV_LIB=build_dev/libesam3_dev.so timeout 600 python tools/ab_bitcompare.py 2>&1 | grep -v amdgpu > $O/ab_bitcompare.txt
+  cat $O/ab_bitcompare.txt
+  timeout 900 python -m pytest tests/test_pcs.py -q -m gpu -k "distribution" -rP --timeout 800 2>&1 | grep -E "dist pcs|passed|failed" > $O/ab_pcs_dist.txt
+  grep -E "dog|passed|failed" $O/ab_pcs_dist.txt | cut -c1-200
+  ;;
+*) echo "usage: $0 {a..z aa ab}"; exit 2 ;;
 esac
