@@ -1616,7 +1616,7 @@ int launch_mb3s(Mb3Params p, hipStream_t stream) {
 // LDS: mid 36 KB + dwo 16 KB + W1 16 / 32 KB + W2 16 / 32 KB + vectors 6.5 / 13 KB (Cmid 512 / 1024).
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef ESAM3_MB3B_UNITS_CIN
-#define ESAM3_MB3B_UNITS_CIN 64   // A/B builds (tools/dev_variants.sh): 0 = whole-tile ownership everywhere
+#define ESAM3_MB3B_UNITS_CIN 0   // A/B builds (tools/dev_variants.sh -DESAM3_MB3B_UNITS_CIN=16|32|64): measured no gain (profiles/r06/mb3b_units_ab.txt), whole tiles stay
 #endif
 template <int CIN, int S = 1, int COUT = CIN, bool GELU = false>
 __global__ __launch_bounds__(512, (CIN < 64 || (CIN == 64 && S == 1)) ? 4 : 2) void mbconv3b_kernel(Mb3Params p) {
