@@ -820,8 +820,7 @@ int esam3_launch_i2t_fused(const void* x, void* out, const void* wq, int kpq, co
     esam3_set_error("i2t_fused: unsupported shape (P=%d T=%d kpq=%d kpo=%d)", P, T, kpq, kpo);
     return -1;
   }
-  static const int ok = esam3_allow_dyn_lds((const void*)i2t_block_kernel, I2T_LDS);
-  if (ok) return -1;
+  if (esam3_allow_dyn_lds((const void*)i2t_block_kernel, I2T_LDS)) return -1;   // memoised per (device, kernel): asked on every launch
   I2tParams p;
   p.x = (const bf16_t*)x; p.out = (bf16_t*)out; p.wq = (const bf16_t*)wq; p.wo = (const bf16_t*)wo; p.peq = (const bf16_t*)peq;
   p.bq = bq; p.bo = bo; p.gamma = gamma; p.beta = beta; p.tk = (const bf16_t*)tk; p.tv = (const bf16_t*)tv;
@@ -921,8 +920,7 @@ int esam3_launch_rowlin256(const void* x, const void* w, int kp, const float* bi
     esam3_set_error("rowlin256: unsupported shape (rows=%lld kp=%d P=%d)", (long long)rows, kp, P);
     return -1;
   }
-  static const int ok = esam3_allow_dyn_lds((const void*)rowlin256_kernel, RL_LDS);
-  if (ok) return -1;
+  if (esam3_allow_dyn_lds((const void*)rowlin256_kernel, RL_LDS)) return -1;   // memoised per (device, kernel): asked on every launch
   RowLinParams p;
   p.x = (const bf16_t*)x; p.w = (const bf16_t*)w; p.table = (const bf16_t*)table; p.bias = bias; p.out = (bf16_t*)out; p.rows = rows;
   p.kp = kp; p.P = P; p.abl = esam3_dev_flag("ESAM3_RL_ABL");

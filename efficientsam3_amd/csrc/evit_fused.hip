@@ -707,12 +707,18 @@ __global__ __launch_bounds__(512, 2) void mla1v_kernel(Mla1Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, g = lane >> 5, l15 = lane & 15, kg = lane >> 4;
 
-  const unsigned tpi = (unsigned)(p.tiles_x * p.tiles_y);
-  const unsigned bid = xcd_contig(blockIdx.x, gridDim.x);
-  const unsigned b = bid / tpi;
-  const unsigned ti = bid - b * tpi;
-  const int ty = (int)(ti / (unsigned)p.tiles_x), tx = (int)(ti - ty * p.tiles_x);
-  const int oy0 = ty * TH, ox0 = tx * TW;
+  // persistent: XCD xcd owns the contiguous tile range [first, first + cnt), its workgroups stride through it (63 x 63 x 128: four tiles per
+  // workgroup -- the next tile's pixel fragments are requested under the last chunk's depthwise phase, the weight / tap streams run across
+  // the tile boundary; 32 x 32 x 256: one tile each)
+  const unsigned tpi = (unsigned)(p.tiles_x * p.tiles_y), ntiles = tpi * (unsigned)p.B;
+  const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7, wi = blockIdx.x >> 3;
+  const unsigned nx = nwg / 8 + (xcd < nwg % 8 ? 1u : 0u);
+  const unsigned tq_ = ntiles / 8, tr_ = ntiles % 8;
+  const unsigned first = xcd < tr_ ? xcd * (tq_ + 1) : tr_ * (tq_ + 1) + (xcd - tr_) * tq_, cnt = tq_ + (xcd < tr_ ? 1u : 0u);
+  if (wi >= cnt) return;
+  unsigned b = 0, ti = 0;
+  int oy0 = 0, ox0 = 0;
+  bool col_in = false;
 
   const T* __restrict__ gx = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ gwq = reinterpret_cast<const T*>(p.wqkv);
@@ -751,36 +757,52 @@ __global__ __launch_bounds__(512, 2) void mla1v_kernel(Mla1Params p) {
   };
   dma_wq(0);
   load_taps(0);
-  // ---- x fragments of this wave's halo pixel tile (pixels 32 wave .. + 31), kept for all chunks ----
+  // ---- x fragments of this wave's halo pixel tile (pixels 32 wave .. + 31) of tile `tile`, kept for all its chunks ----
   u32x4 fa[KS];
   const int hp_e = wave * 32 + l31;
-  {
+  auto load_fa = [&](unsigned tile) {
+    const unsigned b_ = tile / tpi, ti_ = tile - b_ * tpi;
+    const int ty_ = (int)(ti_ / (unsigned)p.tiles_x), tx_ = (int)(ti_ - ty_ * p.tiles_x);
     const int hy = hp_e / HW, hx = hp_e - hy * HW;
-    const int iy = oy0 - 2 + hy, ix = ox0 - 2 + hx;
+    const int iy = ty_ * TH - 2 + hy, ix = tx_ * TW - 2 + hx;
     const bool in = hp_e < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    const T* px = gx + ((int64_t)(b * (unsigned)p.H + (in ? iy : 0)) * p.W + (in ? ix : 0)) * C;
+    const T* px = gx + ((int64_t)(b_ * (unsigned)p.H + (in ? iy : 0)) * p.W + (in ? ix : 0)) * C;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       fa[ks] = u32x4{0u, 0u, 0u, 0u};
       if (in) fa[ks] = *reinterpret_cast<const u32x4*>(px + (2 * ks + g) * 8);
     }
-  }
+  };
+  auto set_tile = [&](unsigned tile) {
+    b = tile / tpi;
+    ti = tile - b * tpi;
+    const int ty_ = (int)(ti / (unsigned)p.tiles_x), tx_ = (int)(ti - ty_ * p.tiles_x);
+    oy0 = ty_ * TH; ox0 = tx_ * TW;
+    col_in = (ox0 + l15) < p.W;
+  };
+  set_tile(first + wi);
+  load_fa(first + wi);
   // depthwise + grouped phase: lane = (c4 = 4-channel block of a 16-channel group, column n); the wave's run of 6 (group, row) units
   const int pi = lane & 3;
   const int wq4 = wave & 3, gi0 = (wave >> 2) * 3;
   const int giA = gi0 + (wq4 >= 2 ? (wq4 == 2 ? 1 : 2) : 0);   // group of the run's first segment
   const int giB = gi0 + (wq4 == 1 ? 1 : 2);                    // group of the second segment (waves 1, 2 of a quad)
-  const bool col_in = (ox0 + l15) < p.W;
 
   store_taps(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();   // Wqkv chunk 0 and the taps of chunk 0 are in LDS
+  static_assert(NCH % 2 == 0, "the tap table's buffer parity runs across tile boundaries");
+  constexpr bool PERSIST = C == 128;   // C = 256 is at the register limit: launched with one workgroup per tile (25 spilled registers otherwise)
+  for (unsigned t = wi; t < cnt; t += nx) {
+  const bool has_next = PERSIST && t + nx < cnt;
   for (int ch = 0; ch < NCH; ++ch) {
     const int c0 = ch * 96;   // first qkv channel of the chunk (heads 2ch, 2ch + 1)
+    const bool more = ch + 1 < NCH || has_next;   // the flat (tile, chunk) stream has a next chunk
+    const int nxt = ch + 1 < NCH ? ch + 1 : 0;
     // the grouped conv's 16 x 16 weight blocks of this wave's (at most two) groups: requested now, used after the depthwise walk
     const s16x4 wgaA = *reinterpret_cast<const s16x4*>(gwg + (int64_t)(c0 + giA * 16 + l15) * p.Kpg + 4 * kg);
     const s16x4 wgaB = *reinterpret_cast<const s16x4*>(gwg + (int64_t)(c0 + giB * 16 + l15) * p.Kpg + 4 * kg);
-    if (ch + 1 < NCH) load_taps(ch + 1);
+    if (more) load_taps(nxt);
     // ================= E: mid[halo px][96] = Wqkv[c0 .. c0+96) . x =================
     if (!MLA1_ABL(1))
 #pragma unroll
@@ -810,9 +832,10 @@ __global__ __launch_bounds__(512, 2) void mla1v_kernel(Mla1Params p) {
         *reinterpret_cast<u32x4*>(rowp + 32) = o[1];
       }
     }
-    if (ch + 1 < NCH) store_taps((ch + 1) & 1);   // read by the NEXT chunk's depthwise phase (behind two barriers)
+    if (more) store_taps((ch + 1) & 1);   // read by the NEXT chunk's depthwise phase (behind two barriers)
     __syncthreads();
-    if (ch + 1 < NCH) dma_wq(ch + 1);   // the expand phase is done with the buffer; lands under the other phases
+    if (more) dma_wq(nxt);   // the expand phase is done with the buffer; lands under the other phases
+    if (ch + 1 == NCH && has_next) load_fa(first + t + nx);   // this tile's fragments are dead: the next tile's arrive under the phases below
 
     // ================= early KVQ: scale 0 (the qkv tile itself) =================
     auto q_store = [&](int item) {   // relu(q) -> qms[b][tile][chunk][gl = scale*2 + head][tile row][px][16 ch], item = (gl, row, px, half)
@@ -901,6 +924,9 @@ __global__ __launch_bounds__(512, 2) void mla1v_kernel(Mla1Params p) {
     if (!MLA1_ABL(16) && wave >= 4) kv_partial(1, wave & 1, (wave >> 1) & 1);
     // no barrier here: these reads touch `ago` only, which the next chunk writes behind ITS first barrier; `mid`, the weight buffer and
     // the tap table the next expand phase writes were last read in front of the barrier above
+  }
+  if (!PERSIST) break;
+  if (has_next) set_tile(first + t + nx);
   }
 }
 
@@ -2035,10 +2061,10 @@ int esam3_launch_mla_fused(const void* x, void* out, const void* wqkv, int Kpq, 
   if (!esam3_dev_flag("ESAM3_MLA1_OLD")) {   // round 6: depthwise + grouped conv in registers (A/B in dev builds: the round-4 kernel)
     if (C == 128) {
       if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(mla1v_kernel<128>), (int)lds1v)) return -1;
-      hipLaunchKernelGGL((mla1v_kernel<128>), dim3((unsigned)(B * tiles)), dim3(512), lds1v, stream, a);
+      hipLaunchKernelGGL((mla1v_kernel<128>), dim3((unsigned)(B * tiles < 256 ? B * tiles : 256)), dim3(512), lds1v, stream, a);
     } else {
       if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(mla1v_kernel<256>), (int)lds1v)) return -1;
-      hipLaunchKernelGGL((mla1v_kernel<256>), dim3((unsigned)(B * tiles)), dim3(512), lds1v, stream, a);
+      hipLaunchKernelGGL((mla1v_kernel<256>), dim3((unsigned)(B * tiles)), dim3(512), lds1v, stream, a);   // one tile per workgroup (see PERSIST)
     }
   } else if (C == 128) {
     if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(mla1_kernel<128>), (int)lds1)) return -1;
