@@ -131,7 +131,8 @@ def _mla_lattice_ref(x, wqkv, wdw, wgrp, wsel, dim=16):
     return y.to(torch.bfloat16).float()
 
 
-@pytest.mark.parametrize("B,H,W,C", [(1, 8, 16, 128), (2, 21, 19, 128), (1, 63, 63, 128), (1, 9, 9, 256), (2, 32, 32, 256)])
+@pytest.mark.parametrize("B,H,W,C", [(1, 8, 16, 128), (2, 21, 19, 128), (1, 63, 63, 128), (1, 9, 9, 256), (2, 32, 32, 256),
+                                     (11, 63, 63, 128)])   # round 6: 352 tiles on 256 persistent workgroups (tile hand-over, prefetched fragments)
 def test_lite_mla_block_exact_on_the_lattice(B, H, W, C):
     """mla1 -> kvprep -> mla2 on integers: qkv GEMM, 5x5 depthwise (one random tap per channel = a shifted copy: checks every tap
     position and the halo), grouped 1x1 (a signed permutation inside each group of 16), kv / ksum sums over all pixels of the image
