@@ -595,11 +595,27 @@ __global__ void stability_count_kernel(const float* __restrict__ all_masks, int*
   const int64_t bp = blockIdx.y;
   const float* m = all_masks + bp * 4 * P;
   int ci = 0, cu = 0;
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P;
-       p += (int64_t)gridDim.x * blockDim.x) {
-    const float x = m[p];
-    ci += x > delta;
-    cu += x > -delta;
+  // round 6: 16-byte loads and 32-bit indices (the scalar form with 64-bit loop arithmetic read 10.6 MB in 46 us); counts are integers: same result
+  if (P < ((int64_t)1 << 31) && ((uintptr_t)m & 15) == 0) {
+    const unsigned n4 = (unsigned)(P >> 2), stride = gridDim.x * blockDim.x;
+    const float4* m4 = reinterpret_cast<const float4*>(m);
+    for (unsigned q = blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+      const float4 x = m4[q];
+      ci += (x.x > delta) + (x.y > delta) + (x.z > delta) + (x.w > delta);
+      cu += (x.x > -delta) + (x.y > -delta) + (x.z > -delta) + (x.w > -delta);
+    }
+    for (unsigned q = 4 * n4 + blockIdx.x * blockDim.x + threadIdx.x; q < (unsigned)P; q += stride) {
+      const float x = m[q];
+      ci += x > delta;
+      cu += x > -delta;
+    }
+  } else {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P;
+         p += (int64_t)gridDim.x * blockDim.x) {
+      const float x = m[p];
+      ci += x > delta;
+      cu += x > -delta;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { ci += __shfl_xor(ci, o); cu += __shfl_xor(cu, o); }
@@ -940,7 +956,17 @@ __global__ void cc_apply_tiled_kernel(const float* __restrict__ in, float* __res
 }
 
 // bilinear upsample (align_corners=False) of fp32 masks, optional > thr -> u8
-__global__ void upsample_masks_kernel(const float* __restrict__ in, float* __restrict__ out_f32,
+// The bilinear sample of both upsampling kernels, with the contractions written out (left to the compiler, the two kernels were fused
+// differently and disagreed in the last bit of one result in ~1e5): source coordinate = (o + 0.5) scale - 0.5 as one fma, then
+// hy (hx a + lx b) + ly (hx c + lx d) as fma(hy, fma(hx, a, lx b), ly fma(hx, c, lx d)).
+__device__ __forceinline__ float up_src_coord(int o, float scale) {
+  const float f = fmaf((float)o + 0.5f, scale, -0.5f);
+  return f < 0.f ? 0.f : f;
+}
+__device__ __forceinline__ float up_bilerp(float hy, float ly, float hx, float lx, float a, float b, float c, float d) {
+  return fmaf(hy, fmaf(hx, a, lx * b), ly * fmaf(hx, c, lx * d));
+}
+__global__ void upsample_masks_px_kernel(const float* __restrict__ in, float* __restrict__ out_f32,
                                       uint8_t* __restrict__ out_u8, int IH, int IW, int OH, int OW,
                                       float thr) {
   const int64_t n = blockIdx.y;
@@ -948,19 +974,76 @@ __global__ void upsample_masks_kernel(const float* __restrict__ in, float* __res
   if (idx >= (int64_t)OH * OW) return;
   const int ox = (int)(idx % OW), oy = (int)(idx / OW);
   const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
-  float fy = ((float)oy + 0.5f) * sy - 0.5f;
-  float fx = ((float)ox + 0.5f) * sx - 0.5f;
-  fy = fy < 0.f ? 0.f : fy;
-  fx = fx < 0.f ? 0.f : fx;
+  const float fy = up_src_coord(oy, sy), fx = up_src_coord(ox, sx);
   const int y0 = (int)fy, x0 = (int)fx;
   const int y1 = y0 + (y0 < IH - 1 ? 1 : 0), x1 = x0 + (x0 < IW - 1 ? 1 : 0);
   const float ly = fy - (float)y0, lx = fx - (float)x0;
   const float hy = 1.f - ly, hx = 1.f - lx;
   const float* s = in + n * IH * (int64_t)IW;
-  const float v = hy * (hx * s[y0 * IW + x0] + lx * s[y0 * IW + x1]) +
-                  ly * (hx * s[y1 * IW + x0] + lx * s[y1 * IW + x1]);
+  const float v = up_bilerp(hy, ly, hx, lx, s[y0 * IW + x0], s[y0 * IW + x1], s[y1 * IW + x0], s[y1 * IW + x1]);
   if (out_f32) out_f32[n * OH * (int64_t)OW + idx] = v;
   if (out_u8) out_u8[n * OH * (int64_t)OW + idx] = v > thr ? 1 : 0;
+}
+
+// Round 6: the same interpolation (expression for expression: bit-identical outputs, dev builds keep the per-pixel kernel above behind
+// ESAM3_UPSAMPLE_OLD), one thread = 8 consecutive pixels of an output row.  The per-pixel form spent its time on two 64-bit divisions per pixel
+// and on byte stores (64 bytes per wave instruction): 86.6 us for 32 masks of 1008 x 1008 = 0.37 TB/s of output.  Here grid.y = output row and
+// grid.z = mask (no divisions), the row's source rows / fractions are computed once per thread, and a thread writes its 8 mask bytes (and its
+// 8 floats) with one (two) wide stores when the row length allows it.
+__global__ __launch_bounds__(128) void upsample_masks_kernel(const float* __restrict__ in, float* __restrict__ out_f32,
+                                                             uint8_t* __restrict__ out_u8, int IH, int IW, int OH, int OW, float thr) {
+  extern __shared__ __attribute__((aligned(16))) float up_rows[];   // the two source rows of this output row: [2][IW]
+  const int64_t n = blockIdx.z;
+  const int oy = blockIdx.y;
+  const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+  const float fy = up_src_coord(oy, sy);
+  const int y0 = (int)fy;
+  const int y1 = y0 + (y0 < IH - 1 ? 1 : 0);
+  const float ly = fy - (float)y0;
+  const float hy = 1.f - ly;
+  const float* s = in + n * IH * (int64_t)IW;
+  for (int i = threadIdx.x; i < 2 * IW; i += blockDim.x) up_rows[i] = i < IW ? s[y0 * IW + i] : s[y1 * IW + (i - IW)];
+  __syncthreads();
+  for (int ox0 = threadIdx.x * 8; ox0 < OW; ox0 += blockDim.x * 8) {
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ox = ox0 + e < OW ? ox0 + e : OW - 1;
+    const float fx = up_src_coord(ox, sx);
+    const int x0 = (int)fx;
+    const int x1 = x0 + (x0 < IW - 1 ? 1 : 0);
+    const float lx = fx - (float)x0;
+    const float hx = 1.f - lx;
+    v[e] = up_bilerp(hy, ly, hx, lx, up_rows[x0], up_rows[x1], up_rows[IW + x0], up_rows[IW + x1]);
+  }
+  const int64_t o = n * OH * (int64_t)OW + (int64_t)oy * OW + ox0;
+  const bool full = ox0 + 8 <= OW;
+  if (out_f32) {
+    if (full && (OW & 3) == 0 && ((uintptr_t)out_f32 & 15) == 0) {
+      *reinterpret_cast<float4*>(out_f32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(out_f32 + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (ox0 + e < OW) out_f32[o + e] = v[e];
+    }
+  }
+  if (out_u8) {
+    if (full && (OW & 7) == 0 && ((uintptr_t)out_u8 & 7) == 0) {
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        lo |= (v[e] > thr ? 1u : 0u) << (8 * e);
+        hi |= (v[4 + e] > thr ? 1u : 0u) << (8 * e);
+      }
+      *reinterpret_cast<uint2*>(out_u8 + o) = make_uint2(lo, hi);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (ox0 + e < OW) out_u8[o + e] = v[e] > thr ? 1 : 0;
+    }
+  }
+  }
 }
 
 template <typename T>
@@ -1370,8 +1453,14 @@ int esam3_launch_fill_holes(const float* in, float* out, int* labels, int* areas
 int esam3_launch_upsample_masks(const float* in, float* out_f32, uint8_t* out_u8, int n, int IH, int IW,
                                 int OH, int OW, float thr, hipStream_t s) {
   if (n <= 0) return 0;
-  dim3 grid(blocks_for((int64_t)OH * OW, 256), (unsigned)n);
-  hipLaunchKernelGGL(upsample_masks_kernel, grid, dim3(256), 0, s, in, out_f32, out_u8, IH, IW, OH, OW,
+  if (esam3_dev_flag("ESAM3_UPSAMPLE_OLD") || OH > 65535 || n > 65535 || IW > 8192) {   // A/B (dev builds) / grid limits: one thread per pixel
+    dim3 grid(blocks_for((int64_t)OH * OW, 256), (unsigned)n);
+    hipLaunchKernelGGL(upsample_masks_px_kernel, grid, dim3(256), 0, s, in, out_f32, out_u8, IH, IW, OH, OW, thr);
+    HIP_CHECK_RET(hipGetLastError());
+    return 0;
+  }
+  dim3 grid(1, (unsigned)OH, (unsigned)n);   // one workgroup per output row: its two source rows in LDS, 8 pixels per thread and step
+  hipLaunchKernelGGL(upsample_masks_kernel, grid, dim3(128), (size_t)2 * IW * sizeof(float), s, in, out_f32, out_u8, IH, IW, OH, OW,
                      thr);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
