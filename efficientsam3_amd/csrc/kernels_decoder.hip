@@ -590,7 +590,7 @@ __global__ void mask_product_kernel(const T* __restrict__ hyper, int ld_h, const
 }
 
 // stability counters for mask 0: cnt[2*bp] = #(m > delta), cnt[2*bp+1] = #(m > -delta)
-__global__ void stability_count_kernel(const float* __restrict__ all_masks, int* __restrict__ cnt,
+__global__ __launch_bounds__(1024) void stability_count_kernel(const float* __restrict__ all_masks, int* __restrict__ cnt,
                                        int64_t P, float delta) {
   const int64_t bp = blockIdx.y;
   const float* m = all_masks + bp * 4 * P;
@@ -619,9 +619,17 @@ __global__ void stability_count_kernel(const float* __restrict__ all_masks, int*
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { ci += __shfl_xor(ci, o); cu += __shfl_xor(cu, o); }
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(cnt + 2 * bp, ci);
-    atomicAdd(cnt + 2 * bp + 1, cu);
+  // one atomic pair per WORKGROUP (round 6): 32 x 4 waves adding to the same two words per prompt serialised in L2 -- the launch took 44 us for
+  // 10.6 MB with the loads already vectorised
+  __shared__ int red[2][16];
+  const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][w] = ci; red[1][w] = cu; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int a = 0, b = 0;
+    for (int i = 0; i < nw; ++i) { a += red[0][i]; b += red[1][i]; }
+    atomicAdd(cnt + 2 * bp, a);
+    atomicAdd(cnt + 2 * bp + 1, b);
   }
 }
 
@@ -1412,7 +1420,7 @@ int esam3_launch_select_masks(int dtype, const float* all_masks, const void* all
                               int multimask, float delta, float thresh, hipStream_t s) {
   if (!multimask) {
     HIP_CHECK_RET(hipMemsetAsync(counters, 0, sizeof(int) * 2 * (size_t)Bp, s));
-    hipLaunchKernelGGL(stability_count_kernel, dim3(32, (unsigned)Bp), dim3(256), 0, s, all_masks,
+    hipLaunchKernelGGL(stability_count_kernel, dim3(8, (unsigned)Bp), dim3(1024), 0, s, all_masks,
                        counters, P, delta);
   }
   DISPATCH_T(dtype, hipLaunchKernelGGL(select_masks_kernel<T>, dim3(64, (unsigned)Bp), dim3(256), 0, s,
