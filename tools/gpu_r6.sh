@@ -370,5 +370,25 @@ ab)
   timeout 900 python -m pytest tests/test_pcs.py -q -m gpu -k "distribution" -rP --timeout 800 2>&1 | grep -E "dist pcs|passed|failed" > $O/ab_pcs_dist.txt
   grep -E "dog|passed|failed" $O/ab_pcs_dist.txt | cut -c1-200
   ;;
-*) echo "usage: $0 {a..z aa ab}"; exit 2 ;;
+final)
+  # round 6, final GPU call: the whole GPU suite, smoke(), the default bench line, the other configurations' lines
+  timeout 1300 python -m pytest tests/ -q -m gpu --durations=8 > $O/final_suite.txt 2>&1; tail -14 $O/final_suite.txt | cut -c1-200
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/final_smoke.txt 2>&1; tail -2 $O/final_smoke.txt | cut -c1-300
+  ESAM3_BENCH_PROFILE_OUT=$O/final_bench_per_launch.json timeout 400 python bench.py > $O/final_bench.json 2> $O/final_bench.err
+  ESAM3_BENCH_PROFILE_OUT=$O/final_bench_tinyvit_per_launch.json timeout 400 python bench.py --backbone tinyvit --model 11m --no-cpu-baseline > $O/final_bench_tinyvit.json 2> $O/final_bench_tinyvit.err
+  timeout 600 python bench.py --workload text --backbone sam3 --model vit_h --batch 8 --steps 3 --warmup 1 --no-cpu-baseline > $O/final_bench_text_cfg4.json 2> $O/final_bench_text_cfg4.err
+  timeout 300 python tools/bench_stage1_step.py --model b1 --batch 32 --steps 5 2>/dev/null | tail -1 > $O/final_bench_stage1_step_b1_b32.json
+  python - <<'PY'
+import json
+for f in ("final_bench", "final_bench_tinyvit", "final_bench_text_cfg4", "final_bench_stage1_step_b1_b32"):
+    try:
+        d = json.loads(open(f"gpurun_out/r06/{f}.json").read().strip().splitlines()[-1])
+        print(f, d["value"], d["ms_per_step"], {k: v for k, v in d.get("config", {}).items() if k.endswith("images_per_s")})
+    except Exception as e:
+        print(f, "FAILED", e)
+PY
+  python tools/roofline_table.py $O/final_bench_per_launch.json > $O/final_roofline_headline.md 2>/dev/null
+  python tools/roofline_table.py $O/final_bench_tinyvit_per_launch.json --merge-layers > $O/final_roofline_tinyvit_11m.md 2>/dev/null
+  ;;
+*) echo "usage: $0 {a..z aa ab final}"; exit 2 ;;
 esac
