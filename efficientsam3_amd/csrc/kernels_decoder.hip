@@ -535,10 +535,16 @@ __global__ __launch_bounds__(256) void upscale_mask_kernel(const bf16_t* __restr
         const uint2 u = *reinterpret_cast<const uint2*>(rp + 8 * q);
         const float r[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
                             __uint_as_float(u.y & 0xffff0000u)};
+        // GELU on PAIRS (round 6): gelu_fast(x) evaluates the packed form on {x, x} and keeps one half -- twice the VALU work of this
+        // VALU-bound kernel's largest term; the same function per element, bit-identical masks
+        float ge[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ge[e] = acc[4 * q + e] + bs[4 * q + e] + r[e];
+        gelu_fast_n<4>(ge);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           // the separate kernels stored this value in bf16 before the product read it back
-          const float v = to_f32<bf16_t>(from_f32<bf16_t>(gelu_fast(acc[4 * q + e] + bs[4 * q + e] + r[e])));
+          const float v = to_f32<bf16_t>(from_f32<bf16_t>(ge[e]));
 #pragma unroll
           for (int k = 0; k < 4; ++k) s4[k] = fmaf(v, hw[k][4 * q + e], s4[k]);
         }
