@@ -1205,6 +1205,26 @@ int E::tv_patch_merging(const std::string& p, const T4& x, T4* y) {
   if (!w) return -1;
   const T4 dst = alloc4(x.B, (x.H + 1) / 2, (x.W + 1) / 2, (int)w->shape[0]);
   if (!ok(dst.p)) return -1;
+  // round 6, bf16, 64 -> 128 and 128 -> 256 (TinyViT-5M / -11M): conv1 -> GELU -> depthwise 3x3 stride 2 -> GELU -> conv3 in ONE launch of the
+  // 8-wave LDS-weight MBConv kernel (evit_fused.hip: mbconv3b<S = 2> with the middle width = the output width); the layer-by-layer path wrote
+  // and re-read conv1's output at the INPUT resolution (520 MB + 520 MB at 252^2 x 128, B = 32).  A/B (dev builds): ESAM3_NO_FUSED_TV_PM
+  const int cout = (int)w->shape[0];
+  if (x.ld == x.C && esam3_patch_merging_fused_ok(dtype, x.C, cout) && !esam3_dev_flag("ESAM3_NO_FUSED_TV_PM")) {
+    PackedGemm* g1 = pk_conv(p + "conv1.c.weight", "", p + "conv1.bn");
+    PackedGemm* g2 = pk_conv(p + "conv3.c.weight", "", p + "conv3.bn");
+    PackedDw* dw = pk_dw(p + "conv2.c.weight", "", p + "conv2.bn");
+    if (!g1 || !g2 || !dw) return -1;
+    if (g1->N == cout && g1->cin == x.C && g2->N == cout && g2->cin == cout && dw->C == cout && dw->ks == 3 && g1->bias && g2->bias) {
+      *y = dst;
+      if (dry) return 0;
+      const double px = (double)x.rows(), opx = (double)dst.rows();
+      return prof_launch("patch_merging_fused:" + p.substr(p.size() > 40 ? p.size() - 40 : 0), 2.0 * px * x.C * cout + 2.0 * opx * cout * (9 + cout),
+                         (px * x.C + opx * cout) * (double)esz, [&]() {
+                           return esam3_launch_mbconv3(x.p, y->p, g1->w, g1->Kp, g1->bias, dw->w, dw->bias, g2->w, g2->Kp, g2->bias, x.B, x.H,
+                                                       x.W, x.C, cout, cout, 2, /*PatchMerging variant*/ 4, st);
+                         });
+    }
+  }
   const size_t mk = arena.mark();
   T4 a, d;
   CK(conv_bn(p + "conv1", x, 1, ACT_GELU, &a));

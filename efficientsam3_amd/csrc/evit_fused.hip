@@ -1644,13 +1644,17 @@ int launch_mb3s(Mb3Params p, hipStream_t stream) {
 #ifndef ESAM3_MB3B_UNITS_CIN
 #define ESAM3_MB3B_UNITS_CIN 0   // A/B builds (tools/dev_variants.sh -DESAM3_MB3B_UNITS_CIN=16|32|64): measured no gain (profiles/r06/mb3b_units_ab.txt), whole tiles stay
 #endif
-template <int CIN, int S = 1, int COUT = CIN, bool GELU = false>
+// ACTM: 0 = Hardswish after the expand and the depthwise conv (EfficientViT), 1 = GELU there AND after the shortcut add (TinyViT MBConv),
+// 2 = GELU there, none at the end (TinyViT PatchMerging, tiny_vit.py:128-154: conv1 + BN -> GELU -> depthwise 3x3 stride 2 + BN -> GELU ->
+// conv3 + BN; its middle width is the OUTPUT width, CMID_ = Cout, not 4 Cin).
+template <int CIN, int S = 1, int COUT = CIN, int ACTM = 0, int CMID_ = 0>
 __global__ __launch_bounds__(512, (CIN < 64 || (CIN == 64 && S == 1)) ? 4 : 2) void mbconv3b_kernel(Mb3Params p) {
+  constexpr bool GELU = ACTM != 0;
   typedef bf16_t T;
   // Round 6: also the two stride-2 blocks that open stages 3 and 4 (64 -> 256 -> 128 at 126^2 and 128 -> 512 -> 256 at 63^2), until now on the
   // generic one-tile-per-workgroup kernel (0.147 + 0.161 ms, 0.06 - 0.08 of their floors: pixel and weight fragments re-read from L2 for
   // every chunk).  S = 2: 8 x 8 output tile, 17 x 17 halo = 10 pixel tiles of 32 -- waves 0, 1 own two of them --, pitch 160 B.
-  constexpr int CMID = 4 * CIN, NW = 8;
+  constexpr int CMID = CMID_ ? CMID_ : 4 * CIN, NW = 8;
   constexpr int TH = 8, TW = S == 1 ? 16 : 8, OP = TH * TW;
   constexpr int HH = TH * S + (S == 1 ? 2 : 1), HW = TW * S + (S == 1 ? 2 : 1), HP = HH * HW;
   // expand work: UNITS (narrow blocks): unit u = (pixel tile u >> 1, channel half u & 1), wave w owns units w, w + 8, ... -- its channel half is
@@ -1911,7 +1915,7 @@ __global__ __launch_bounds__(512, (CIN < 64 || (CIN == 64 && S == 1)) ? 4 : 2) v
           v[4 * q + 2] += __uint_as_float(u2.y << 16); v[4 * q + 3] += __uint_as_float(u2.y & 0xffff0000u);
         }
       }
-      if constexpr (GELU) gelu_fast_n<16>(v);   // the block's closing activation follows the shortcut add
+      if constexpr (ACTM == 1) gelu_fast_n<16>(v);   // the block's closing activation follows the shortcut add
 #pragma unroll
       for (int qp = 0; qp < 2; ++qp) {
         const uint32_t a0 = pack_bf16x2(v[8 * qp + 0], v[8 * qp + 1]), a1 = pack_bf16x2(v[8 * qp + 2], v[8 * qp + 3]);
@@ -1928,14 +1932,14 @@ __global__ __launch_bounds__(512, (CIN < 64 || (CIN == 64 && S == 1)) ? 4 : 2) v
   }
 }
 
-template <int CIN, int S = 1, int COUT = CIN, bool GELU = false>
+template <int CIN, int S = 1, int COUT = CIN, int ACTM = 0, int CMID_ = 0>
 int launch_mb3b(Mb3Params p, hipStream_t stream) {
   constexpr int TW = S == 1 ? 16 : 8, HP = S == 1 ? 180 : 289, MP = (HP + 31) / 32 * 32, PITCH = S == 1 ? 192 : 160;
   p.tiles_x = (p.OW + TW - 1) / TW;
   p.tiles_y = (p.OH + 7) / 8;
   const unsigned ntiles = (unsigned)p.B * p.tiles_x * p.tiles_y;
-  constexpr size_t lds = (size_t)MP * PITCH + 8 * TW * 128 + 64 * CIN * 2 + COUT * 128 + (size_t)4 * CIN * (4 + 4 + 18);
-  auto kern = mbconv3b_kernel<CIN, S, COUT, GELU>;
+  constexpr size_t lds = (size_t)MP * PITCH + 8 * TW * 128 + 64 * CIN * 2 + COUT * 128 + (size_t)(CMID_ ? CMID_ : 4 * CIN) * (4 + 4 + 18);
+  auto kern = mbconv3b_kernel<CIN, S, COUT, ACTM, CMID_>;
   if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(kern), (int)lds)) return -1;
   // persistent: one workgroup per CU, a multiple of the 8 XCDs; the narrow blocks (<= 128 VGPRs, <= 80 KB of LDS) run TWO per CU = four
   // waves per SIMD (profiles/r06/mb3b_small_ab.txt: 256 / 512 / 768 workgroups)
@@ -1961,6 +1965,11 @@ int launch_mb3(Mb3Params p, hipStream_t stream) {
 }  // namespace
 
 // shapes the round-4 fused MBConv is instantiated for (bf16): EfficientViT-B1 / B0 widths
+// TinyViT PatchMerging as one launch (esam3_launch_mbconv3 with residual = 4): the two shapes of TinyViT-5M / -11M whose tiles fit the LDS
+bool esam3_patch_merging_fused_ok(int dtype, int Cin, int Cout) {
+  return dtype == 1 && ((Cin == 64 && Cout == 128) || (Cin == 128 && Cout == 256));
+}
+
 bool esam3_mbconv3_ok(int dtype, int Cin, int Cmid, int Cout, int stride) {
   if (dtype != 1 || Cmid % 64) return false;
   // the launcher's own limits (esam3_launch_mbconv3): the persistent Cin <= 64 kernels stage per-channel vectors for Cmid <= 256;
@@ -1976,6 +1985,20 @@ bool esam3_mbconv3_ok(int dtype, int Cin, int Cmid, int Cout, int stride) {
 int esam3_launch_mbconv3(const void* x, void* out, const void* w1, int Kp1, const float* b1, const float* wd, const float* bd,
                          const void* w2, int Kp2, const float* b2, int B, int H, int W, int Cin, int Cmid, int Cout, int stride,
                          int residual, hipStream_t stream) {
+  if (residual == 4) {   // TinyViT PatchMerging (round 6): Cin -> Cout (GELU) -> depthwise 3x3 stride 2 (GELU) -> Cout, no shortcut, no closing activation
+    if (!esam3_patch_merging_fused_ok(1, Cin, Cout) || Cmid != Cout || stride != 2 || Kp1 < Cin || Kp2 < Cmid ||
+        (int64_t)B * H * W * Cin >= ((int64_t)1 << 31)) {
+      esam3_set_error("mbconv3: PatchMerging variant unsupported for %d -> %d -> %d stride %d", Cin, Cmid, Cout, stride);
+      return -1;
+    }
+    Mb3Params q{};
+    q.x = x; q.out = out; q.w1 = w1; q.b1 = b1; q.wd = wd; q.bd = bd; q.w2 = w2; q.b2 = b2;
+    q.B = B; q.H = H; q.W = W; q.OH = (H + 1) / 2; q.OW = (W + 1) / 2;
+    q.Cmid = Cmid; q.Kp1 = Kp1; q.Kp2 = Kp2; q.residual = 0;
+    q.abl = esam3_dev_flag("ESAM3_MB3_ABL");
+    if (Cin == 64) return launch_mb3b<64, 2, 128, 2, 128>(q, stream);
+    return launch_mb3b<128, 2, 256, 2, 256>(q, stream);
+  }
   if (!esam3_mbconv3_ok(1, Cin, Cmid, Cout, stride) || Kp1 < Cin || Kp2 < Cmid || (int64_t)B * H * W * Cin >= ((int64_t)1 << 31)) {
     esam3_set_error("mbconv3: unsupported configuration %d -> %d -> %d stride %d", Cin, Cmid, Cout, stride);
     return -1;
@@ -1991,7 +2014,7 @@ int esam3_launch_mbconv3(const void* x, void* out, const void* w1, int Kp1, cons
       return -1;
     }
     if (esam3_dev_flag("ESAM3_MB3S")) return launch_mb3s<1, 64, 64, true>(q, stream);
-    return launch_mb3b<64, 1, 64, true>(q, stream);
+    return launch_mb3b<64, 1, 64, 1>(q, stream);
   }
   if (Cin <= 64 && Cmid == 4 * Cin && !esam3_dev_flag("ESAM3_MB3_GENERIC") && !esam3_dev_flag("ESAM3_MB3S")) {
     // round 6: the narrow blocks too run the 8-wave LDS-weight kernel, two workgroups per CU (0.264 -> 0.236, 0.267 -> 0.232, 0.137 ->

@@ -228,6 +228,7 @@ int esam3_launch_mbconv_fused(int dtype, const void* x, void* out, const void* w
 // round-4 fused MBConv (evit_fused.hip, bf16): depthwise phase on the matrix cores, channels up to 256; same arguments as
 // esam3_launch_mbconv_fused (w1 / w2 packed [N][Kp] bf16, wd fp32 [9][Cmid])
 bool esam3_mbconv3_ok(int dtype, int Cin, int Cmid, int Cout, int stride);
+bool esam3_patch_merging_fused_ok(int dtype, int Cin, int Cout);
 int esam3_launch_mbconv3(const void* x, void* out, const void* w1, int Kp1, const float* b1, const float* wd, const float* bd,
                          const void* w2, int Kp2, const float* b2, int B, int H, int W, int Cin, int Cmid, int Cout, int stride,
                          int residual, hipStream_t stream);

@@ -357,6 +357,31 @@ def test_stem(mode, Cout):
     U.assert_close(U.from_dev_nhwc(out), ref, mode, "stem")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 41, 37, 64, 128), (5, 126, 126, 64, 128), (2, 63, 63, 128, 256), (9, 40, 48, 128, 256)])
+def test_patch_merging_fused(B, H, W, Cin, Cout):
+    """TinyViT PatchMerging (tiny_vit.py:128-154: conv1 + BN -> GELU -> depthwise 3x3 stride 2 + BN -> GELU -> conv3 + BN) as ONE launch of the
+    8-wave MBConv kernel (esam3_op_mbconv3 with residual = 4) against the same chain of torch functions with the bf16 rounding points of the
+    layer-by-layer engine path (every stored tensor is bf16)."""
+    bf = lambda t: t.to(torch.bfloat16).float()
+    x = bf(_rand(B, Cin, H, W, seed=1))
+    w1, b1 = bf(_rand(Cout, Cin, seed=2) / Cin ** 0.5), _rand(Cout, seed=3) * 0.1
+    wd, bd = _rand(Cout, 1, 3, 3, seed=4) / 3.0, _rand(Cout, seed=5) * 0.1
+    w2, b2 = bf(_rand(Cout, Cout, seed=6) / Cout ** 0.5), _rand(Cout, seed=7) * 0.1
+    wdq = bf(wd)    # the kernel multiplies bf16 taps on the matrix cores
+    a = bf(F.gelu(F.conv2d(x, w1[:, :, None, None], b1)))
+    d = bf(F.gelu(F.conv2d(a, wdq, bd, stride=2, padding=1, groups=Cout)))
+    ref = F.conv2d(d, w2[:, :, None, None], b2)
+    x_d = U.to_dev_nhwc(x, torch.bfloat16)
+    OH, OW = ref.shape[-2:]
+    out = torch.full((B, OH, OW, Cout), float("nan"), dtype=torch.bfloat16, device="cuda")
+    U.check(U.lib().esam3_op_mbconv3(U.P(x_d), U.H(U.np32(w1)), U.H(U.np32(b1)), U.H(U.np32(wd)), U.H(U.np32(bd)), U.H(U.np32(w2)),
+                                     U.H(U.np32(b2)), U.P(out), B, H, W, Cin, Cout, Cout, 2, 4, None), "op_mbconv3 (PatchMerging)")
+    got = U.from_dev_nhwc(out)
+    assert torch.isfinite(got).all()
+    assert _rel_l2(got, ref) < 6e-3, _rel_l2(got, ref)
+    U.assert_close(got, ref, "bf16", f"PatchMerging {Cin}->{Cout}", scale=0.7)
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("B,H,W", [(2, 38, 42), (3, 150, 134), (1, 64, 64)])
 def test_stem_dsconv(mode, B, H, W):
