@@ -524,7 +524,10 @@ int esam3_op_mbconv_fused(int dtype, const void* x_dev, const float* w1_host, co
                           int Cout, int stride, int residual, void* hip_stream);
 /* round-4 fused MBConv on the bf16 engine (csrc/evit_fused.hip: depthwise phase on the matrix cores; EfficientViT-B0/B1 shapes
  * up to 256 channels, the local modules of the EfficientViTBlocks included); same host weight layout as esam3_op_mbconv_fused;
- * x_dev / out_dev bf16 NHWC.  Reference: backbones/efficientvit/nn/ops.py:315-367,740-770 */
+ * x_dev / out_dev bf16 NHWC.  Reference: backbones/efficientvit/nn/ops.py:315-367,740-770.
+ * residual: bit 0 = identity shortcut (stride 1, Cin == Cout); 3 = TinyViT MBConv (backbones/tiny_vit.py:73-108: GELU after conv1, conv2 and
+ * the shortcut add; 64 -> 256 -> 64); 4 = TinyViT PatchMerging (tiny_vit.py:128-154: conv1 -> GELU -> depthwise 3x3 stride 2 -> GELU -> conv3,
+ * Cmid == Cout, no shortcut, no closing activation; 64 -> 128 and 128 -> 256) */
 int esam3_op_mbconv3(const void* x_dev, const float* w1_host, const float* b1_host, const float* wd_host,
                      const float* bd_host, const float* w2_host, const float* b2_host, void* out_dev, int B, int H, int W,
                      int Cin, int Cmid, int Cout, int stride, int residual, void* hip_stream);
