@@ -158,6 +158,121 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
   }
 }
 
+// Round 6: the same stem conv as persistent workgroups (the EfficientViT stem's treatment, stem_dsconv_mfma_p_kernel): the per-lane MFMA
+// operands are built once per workgroup, tiles are walked in XCD-contiguous ranges and the next tile's 33 x 33 x 3 image halo is requested
+// into registers right after the barrier that publishes the current one.  Same arithmetic in the same order: bit-identical output.
+template <int COUT>
+__global__ __launch_bounds__(256, 3) void stem_mfma_p_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, bf16_t* __restrict__ out, int H, int W, int OH,
+                                                            int OW, int tiles_x, int tiles_img, unsigned ntiles, int act) {
+  constexpr int TS = 16, IR = 2 * TS + 1, IP = 36, NB = COUT / 16;
+  constexpr int NIT = (3 * IR * (IP / 4) + 255) / 256;   // image items (plane, row, 4 columns) per thread: 4
+  __shared__ __attribute__((aligned(16))) bf16_t simg[3 * IR * IP];
+  struct __attribute__((packed, aligned(4))) F4 { float x, y, z, w; };
+  const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7, wi = blockIdx.x >> 3;
+  const unsigned nx = nwg / 8 + (xcd < nwg % 8 ? 1u : 0u);
+  const unsigned tq = ntiles / 8, tr = ntiles % 8;
+  const unsigned first = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, cnt = tq + (xcd < tr ? 1u : 0u);
+  if (wi >= cnt) return;
+  int it_pk[NIT];
+#pragma unroll
+  for (int k = 0; k < NIT; ++k) {
+    const int i = threadIdx.x + 256 * k;
+    const int cy = i / (IP / 4), xg = i - cy * (IP / 4);
+    const int c = cy / IR;
+    it_pk[k] = i < 3 * IR * (IP / 4) ? (c << 16) | ((cy - c * IR) << 8) | xg : -1;
+  }
+  float pre[NIT][4];
+  auto load_img = [&](unsigned tile) {
+    const unsigned b = tile / (unsigned)tiles_img, ti = tile - b * (unsigned)tiles_img;
+    const int ty = (int)(ti / (unsigned)tiles_x), tx = (int)(ti - ty * tiles_x);
+    const int iy0 = 2 * (ty * TS) - 1, ix0 = 2 * (tx * TS) - 1;
+    const float* ib = img + (int64_t)b * 3 * H * W;
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int c = it_pk[k] >> 16, y = (it_pk[k] >> 8) & 255, xg = it_pk[k] & 255;
+      const int iy = iy0 + y, ix = ix0 + 4 * xg;
+      pre[k][0] = pre[k][1] = pre[k][2] = pre[k][3] = 0.f;
+      if (it_pk[k] >= 0 && (unsigned)iy < (unsigned)H) {
+        const float* rp = ib + (c * H + iy) * W;   // 3 H W < 2^31 (checked by the launcher)
+        if (ix >= 0 && ix + 3 < W) {
+          const F4 f = *reinterpret_cast<const F4*>(rp + ix);
+          pre[k][0] = f.x; pre[k][1] = f.y; pre[k][2] = f.z; pre[k][3] = f.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if ((unsigned)(ix + e) < (unsigned)W) pre[k][e] = rp[ix + e];
+        }
+      }
+    }
+  };
+  load_img(first + wi);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  int poff[8];
+  uint32_t pmask[4], wa[NB][4];
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    uint32_t m = 0u;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) wa[nb][h] = 0u;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = 2 * h + u, k = 8 * kg + e;
+      const bool valid = k < 27;
+      const int tap = valid ? k / 3 : 0, c = valid ? k - tap * 3 : 0;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      poff[e] = (c * IR + kh) * IP + kw;
+      if (valid) {
+        m |= 0xffffu << (16 * u);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) wa[nb][h] |= (uint32_t)f32_to_bf16(w[k * COUT + nb * 16 + l15]) << (16 * u);
+      }
+    }
+    pmask[h] = m;
+  }
+  f32x4_v bq[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) bq[nb][v] = bias ? bias[nb * 16 + 4 * kg + v] : 0.f;
+  typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+  for (unsigned t = wi; t < cnt; t += nx) {
+    const unsigned tile = first + t;
+    const unsigned b = tile / (unsigned)tiles_img, ti = tile - b * (unsigned)tiles_img;
+    const int ty = (int)(ti / (unsigned)tiles_x), tx = (int)(ti - ty * tiles_x);
+    const int oy0 = ty * TS, ox0 = tx * TS;
+    if (t != wi) __syncthreads();   // every wave is done reading the previous tile's halo
+#pragma unroll
+    for (int k = 0; k < NIT; ++k)
+      if (it_pk[k] >= 0) {
+        const int c = it_pk[k] >> 16, y = (it_pk[k] >> 8) & 255, xg = it_pk[k] & 255;
+        *reinterpret_cast<uint2*>(simg + (c * IR + y) * IP + 4 * xg) = make_uint2(pack_bf16x2(pre[k][0], pre[k][1]), pack_bf16x2(pre[k][2], pre[k][3]));
+      }
+    __syncthreads();
+    if (t + nx < cnt) load_img(tile + nx);
+    for (int py = wave; py < TS; py += 4) {  // one tile row = 16 pixels per MFMA
+      const bf16_t* pb = simg + (2 * py) * IP + 2 * l15;
+      uint32_t xb[4];
+#pragma unroll
+      for (int h = 0; h < 4; ++h)
+        xb[h] = ((uint32_t)pb[poff[2 * h]] | ((uint32_t)pb[poff[2 * h + 1]] << 16)) & pmask[h];
+      const u32x4_t bv = {xb[0], xb[1], xb[2], xb[3]};
+      const int oy = oy0 + py, ox = ox0 + l15;
+      const bool inside = oy < OH && ox < OW;
+      bf16_t* op = out + (((int64_t)b * OH + oy) * OW + ox) * COUT + 4 * kg;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const u32x4_t av = {wa[nb][0], wa[nb][1], wa[nb][2], wa[nb][3]};
+        const f32x4_v acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_v, av), __builtin_bit_cast(bf16x8_v, bv), bq[nb], 0, 0, 0);
+        float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+        act_apply_n<4>(v, act);
+        if (inside) *reinterpret_cast<uint2*>(op + nb * 16) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------
 // EfficientViT input stem in ONE kernel (efficientvit/backbone.py:48-70): ConvLayer 3 -> 16, 3x3 stride 2, BN, Hardswish,
 // then ResidualBlock(DSConv 16 -> 16: depthwise 3x3 + BN + Hardswish, pointwise 1x1 + BN) + identity.
@@ -2833,6 +2948,19 @@ int esam3_launch_stem(int dtype, const float* img, const float* w, const float* 
   if (dtype == 1 && !stem_valu && (Cout == 16 || Cout == 32 || Cout == 48 || Cout == 64) && !(((uintptr_t)out) & 7)) {
     const int tiles_x = (OW + 15) / 16, tiles_y = (OH + 15) / 16;
     const dim3 grid((unsigned)(tiles_x * tiles_y), (unsigned)B);
+    if ((int64_t)3 * H * W < ((int64_t)1 << 31) && !esam3_dev_flag("ESAM3_STEM_OLD")) {   // round 6: persistent workgroups, three per CU
+      const unsigned ntiles = (unsigned)(tiles_x * tiles_y) * (unsigned)B;
+      unsigned g = 256u * 3u;
+      if (g > ntiles) g = ntiles;
+#define ESAM3_STEM_MFMA_P(CO) hipLaunchKernelGGL(stem_mfma_p_kernel<CO>, dim3(g), dim3(256), 0, s, img, w, bias, (bf16_t*)out, H, W, OH, OW, tiles_x, tiles_x * tiles_y, ntiles, act)
+      if (Cout == 16) ESAM3_STEM_MFMA_P(16);
+      else if (Cout == 32) ESAM3_STEM_MFMA_P(32);
+      else if (Cout == 48) ESAM3_STEM_MFMA_P(48);
+      else ESAM3_STEM_MFMA_P(64);
+#undef ESAM3_STEM_MFMA_P
+      HIP_CHECK_RET(hipGetLastError());
+      return 0;
+    }
 #define ESAM3_STEM_MFMA(CO) hipLaunchKernelGGL(stem_mfma_kernel<CO>, grid, dim3(256), 0, s, img, w, bias, (bf16_t*)out, H, W, OH, OW, tiles_x, act)
     if (Cout == 16) ESAM3_STEM_MFMA(16);
     else if (Cout == 32) ESAM3_STEM_MFMA(32);
