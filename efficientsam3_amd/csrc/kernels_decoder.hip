@@ -1467,7 +1467,7 @@ int esam3_launch_fill_holes(const float* in, float* out, int* labels, int* areas
 int esam3_launch_upsample_masks(const float* in, float* out_f32, uint8_t* out_u8, int n, int IH, int IW,
                                 int OH, int OW, float thr, hipStream_t s) {
   if (n <= 0) return 0;
-  if (esam3_dev_flag("ESAM3_UPSAMPLE_OLD") || OH > 65535 || n > 65535 || IW > 8192) {   // A/B (dev builds) / grid limits: one thread per pixel
+  if (esam3_dev_flag("ESAM3_UPSAMPLE_OLD") || OH > 65535 || n > 65535 || IW > 4096) {   // A/B (dev builds) / grid limits: one thread per pixel
     dim3 grid(blocks_for((int64_t)OH * OW, 256), (unsigned)n);
     hipLaunchKernelGGL(upsample_masks_px_kernel, grid, dim3(256), 0, s, in, out_f32, out_u8, IH, IW, OH, OW, thr);
     HIP_CHECK_RET(hipGetLastError());
