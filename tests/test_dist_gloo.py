@@ -811,6 +811,7 @@ def _trainer_grads(sd, imgs, teacher, sync_bn):
 
 def _trainer_worker(rank, world, port, sync_bn, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // world))   # two ranks on one host: no oversubscription of the cores
     esdist.init_process_group("gloo")
     try:
         _install_trainer_standins()
@@ -898,6 +899,7 @@ def _trainer_updates(sd, imgs, teacher, sync_bn, accumulation_steps, n_updates, 
 
 def _updates_worker(rank, world, port, acc, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // world))   # two ranks on one host: no oversubscription of the cores
     esdist.init_process_group("gloo")
     try:
         _install_trainer_standins()
