@@ -49,3 +49,36 @@ for backbone, name, B in (("efficientvit", "b1", 4), ("tinyvit", "11m", 2)):
         print(f"{backbone}-{name} B{B}  {sw:18s}: " + ("bit-identical on all %d outputs" % len(ref) if not bad else f"DIFFERS {bad}"))
     for s in SWITCHES:
         os.environ.pop(s, None)
+
+
+# ---- the PCS detector (text prompts): GroupNorm of the pixel decoder finalised once per (image, group) instead of per thread ----
+sd = schema.synthetic_state_dict("efficientvit", "b1", seed=0, enable_inst_interactivity=False)
+sd.update(schema.synthetic_text_state_dict("MobileCLIP-S0", 16, seed=0))
+sd.update(schema.synthetic_pcs_state_dict(seed=0))
+model = build_efficientsam3_image_model(device="cuda", enable_inst_interactivity=False, backbone_type="efficientvit", model_name="b1",
+                                        dtype="bf16", state_dict=sd, text_encoder_type="MobileCLIP-S0", text_encoder_context_length=16)
+eng = model.engine
+B = 3
+x = torch.from_numpy(np.stack([synth.normalise_to_chw_f32(synth.smooth_image_u8(seed=s)) for s in range(2, 2 + B)])).cuda()
+tok = np.zeros((B, 16), dtype=np.int64)
+for i in range(B):
+    tok[i, :4] = [49406, 1929 + 37 * i, 2368 + i, 49407]
+tok_d = torch.from_numpy(tok).cuda()
+
+
+def ground():
+    out = eng.encode(x, want_sam3=True, want_sam2=False)
+    mem_t, _ = eng.encode_text(tok_d)
+    g = eng.ground(out["sam3_fpn"], mem_t, tok_d == 0)
+    torch.cuda.synchronize()
+    return {k: v.clone() for k, v in g.items() if torch.is_tensor(v)}
+
+
+os.environ.pop("ESAM3_GN_OLD", None)
+ref = ground()
+os.environ["ESAM3_GN_OLD"] = "1"
+got = ground()
+os.environ.pop("ESAM3_GN_OLD", None)
+bad = {k: int((got[k].contiguous().view(torch.uint8) != ref[k].contiguous().view(torch.uint8)).sum()) for k in ref}
+bad = {k: v for k, v in bad.items() if v}
+print(f"PCS ground B{B}  ESAM3_GN_OLD      : " + ("bit-identical on all %d outputs" % len(ref) if not bad else f"DIFFERS {bad}"))
