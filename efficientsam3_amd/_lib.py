@@ -125,6 +125,8 @@ SIGNATURES = {
     "esam3_train_pack_bytes": (_L, [_I, _I, _I]),
     "esam3_train_linear": (_I, [_I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "esam3_train_conv3x3": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "esam3_train_conv3x3_workspace": (_L, [_I, _I, _I, _I, _I, _I]),
+    "esam3_train_conv3x3_ws": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _L, _P]),
     "esam3_train_dwconv": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "esam3_train_dwconv_dgrad": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "esam3_stem_im2col": (_I, [_I, _P, _P, _I, _I, _I, _P]),

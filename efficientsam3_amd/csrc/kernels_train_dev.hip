@@ -153,6 +153,17 @@ __global__ void resize_bilinear_backward_kernel(const T* __restrict__ dy, T* __r
   Vec8<T>::store(dx + pix * C + cg * VEC, acc);
 }
 
+// interior copy into a buffer with a 1-pixel border (the border itself is zeroed by esam3_launch_zero_border): row (b, y) of W * C elements ->
+// row (b, y + 1) at column 1; 16 bytes per thread, grid.y = y, grid.z = b
+__global__ void pad_copy_kernel(const char* __restrict__ in, char* __restrict__ out, int H, int W, int row_bytes) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i * 16 >= W * row_bytes) return;
+  const int y = blockIdx.y, b = blockIdx.z;
+  const int64_t src = ((int64_t)b * H + y) * W * row_bytes + (int64_t)i * 16;
+  const int64_t dst = (((int64_t)b * (H + 2) + y + 1) * (W + 2) + 1) * row_bytes + (int64_t)i * 16;
+  *reinterpret_cast<uint4*>(out + dst) = *reinterpret_cast<const uint4*>(in + src);
+}
+
 int bad(const char* what) {
   esam3_set_error("%s: bad arguments", what);
   return -1;
@@ -206,6 +217,44 @@ int esam3_train_conv3x3(int dtype, const void* x, const float* w, const float* b
   p.A = x; p.Wt = ws; p.bias = bias; p.out = out; p.M = (int64_t)B * H * W; p.N = Cout; p.K = K; p.Kp = esam3_gemm_pad_k(K, esz);
   p.H = H; p.W = W; p.Cin = Cin; p.ksize = 3; p.lda = Cin; p.ldc = Cout; p.ldr = Cout; p.act = ACT_NONE; p.res_after_act = 1;
   p.korder = esam3_conv_korder(Cin, 3, esz);
+  return esam3_launch_gemm(dtype, p, s);
+}
+
+// Round 6: the same conv through the zero-bordered-input form of the implicit GEMM -- the engine's 256 x 256 tile kernel stages its 3x3 gather
+// by LDS-DMA, which needs the border in memory; the un-bordered form above runs on the register-staged 128-wide kernel (564 TFLOP/s on the head's
+// 1024 -> 1024 conv at 32^2 against 1400+ for the tile kernel: 1.1 + 1.05 ms of a B1 training step for forward + data gradient).  The workspace
+// carries the packed weights and a bordered copy of the input; with a workspace too small for the copy (or a shape the tile kernel does not
+// take) the call is esam3_train_conv3x3.
+int64_t esam3_train_conv3x3_workspace(int dtype, int B, int H, int W, int Cin, int Cout) {
+  if ((dtype != 0 && dtype != 1) || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const int esz = dtype == 0 ? 4 : 2;
+  const int64_t pack = (esam3_train_pack_bytes(dtype, Cout, 9 * Cin) + 255) & ~(int64_t)255;
+  return pack + (int64_t)B * (H + 2) * (W + 2) * Cin * esz;
+}
+
+int esam3_train_conv3x3_ws(int dtype, const void* x, const float* w, const float* bias, void* out, int B, int H, int W, int Cin, int Cout,
+                           int dgrad, void* ws, int64_t ws_bytes, void* stream) {
+  if ((dtype != 0 && dtype != 1) || !x || !w || !out || !ws || B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (dgrad && bias))
+    return bad("esam3_train_conv3x3_ws");
+  const int esz = dtype == 0 ? 4 : 2;
+  const int64_t pack = (esam3_train_pack_bytes(dtype, Cout, 9 * Cin) + 255) & ~(int64_t)255;
+  const int64_t padded = (int64_t)B * (H + 2) * (W + 2) * Cin * esz;
+  const bool tile_kernel = dtype == 1 && Cin % 64 == 0 && Cout >= 192 && ((int64_t)B * H * W) % 256 == 0 && (Cin * esz) % 16 == 0 && B <= 65535 &&
+                           H <= 65535 && ws_bytes >= pack + padded;
+  if (!tile_kernel) return esam3_train_conv3x3(dtype, x, w, bias, out, B, H, W, Cin, Cout, dgrad, ws, stream);
+  hipStream_t s = (hipStream_t)stream;
+  const int K = Cin * 9;
+  if (pack_gemm(dtype, w, ws, Cout, K, dgrad ? 3 : 2, Cin, s)) return -1;
+  char* xp = (char*)ws + pack;
+  if (esam3_launch_zero_border(dtype, xp, B, H + 2, W + 2, Cin, s)) return -1;
+  const int row_bytes = Cin * esz;
+  hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((W * (row_bytes / 16) + 255) / 256), (unsigned)H, (unsigned)B), dim3(256), 0, s, (const char*)x, xp, H, W,
+                     row_bytes);
+  HIP_CHECK_RET(hipGetLastError());
+  GemmParams p{};
+  p.A = xp; p.Wt = ws; p.bias = bias; p.out = out; p.M = (int64_t)B * H * W; p.N = Cout; p.K = K; p.Kp = esam3_gemm_pad_k(K, esz);
+  p.H = H; p.W = W; p.Cin = Cin; p.ksize = 3; p.lda = Cin; p.ldc = Cout; p.ldr = Cout; p.act = ACT_NONE; p.res_after_act = 1;
+  p.korder = esam3_conv_korder(Cin, 3, esz); p.in_pad = 1;
   return esam3_launch_gemm(dtype, p, s);
 }
 

@@ -58,10 +58,11 @@ def conv3x3_forward(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
     cout = w.shape[0]
     out = torch.empty((b, h, wd, cout), dtype=x.dtype, device=x.device)
     lib = _lib.load()
-    ws = tb._ws(lib.esam3_train_pack_bytes(_DT[x.dtype], cout, 9 * cin), x.device)
+    nb = lib.esam3_train_conv3x3_workspace(_DT[x.dtype], b, h, wd, cin, cout)   # packed weights + a bordered copy of x (the tile-GEMM form)
+    ws = tb._ws(nb, x.device)
     with torch.cuda.device(x.device):
-        _lib.check(lib.esam3_train_conv3x3(_DT[x.dtype], x.data_ptr(), tb._dev_f32(w).data_ptr(), None if bias is None else tb._dev_f32(bias).data_ptr(),
-                                           out.data_ptr(), b, h, wd, cin, cout, 0, ws.data_ptr(), _stream()), "esam3_train_conv3x3")
+        _lib.check(lib.esam3_train_conv3x3_ws(_DT[x.dtype], x.data_ptr(), tb._dev_f32(w).data_ptr(), None if bias is None else tb._dev_f32(bias).data_ptr(),
+                                              out.data_ptr(), b, h, wd, cin, cout, 0, ws.data_ptr(), nb, _stream()), "esam3_train_conv3x3_ws")
     return out
 
 
@@ -71,10 +72,11 @@ def conv3x3_dgrad(dy: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     cin = w.shape[1]
     dx = torch.empty((b, h, wd, cin), dtype=dy.dtype, device=dy.device)
     lib = _lib.load()
-    ws = tb._ws(lib.esam3_train_pack_bytes(_DT[dy.dtype], cin, 9 * cout), dy.device)
+    nb = lib.esam3_train_conv3x3_workspace(_DT[dy.dtype], b, h, wd, cout, cin)
+    ws = tb._ws(nb, dy.device)
     with torch.cuda.device(dy.device):
-        _lib.check(lib.esam3_train_conv3x3(_DT[dy.dtype], dy.data_ptr(), tb._dev_f32(w).data_ptr(), None, dx.data_ptr(), b, h, wd, cout, cin, 1,
-                                           ws.data_ptr(), _stream()), "esam3_train_conv3x3")
+        _lib.check(lib.esam3_train_conv3x3_ws(_DT[dy.dtype], dy.data_ptr(), tb._dev_f32(w).data_ptr(), None, dx.data_ptr(), b, h, wd, cout, cin, 1,
+                                              ws.data_ptr(), nb, _stream()), "esam3_train_conv3x3_ws")
     return dx
 
 

@@ -298,6 +298,12 @@ int esam3_train_linear(int dtype, const void* x_dev, const float* w_dev, const f
                        int transpose, void* workspace_dev, void* hip_stream);
 int esam3_train_conv3x3(int dtype, const void* x_dev, const float* w_dev, const float* bias_dev, void* out_dev, int B, int H, int W,
                         int Cin, int Cout, int dgrad, void* workspace_dev, void* hip_stream);
+/* the same conv through the bordered-input form of the implicit GEMM (round 6: the engine's 256 x 256 tile kernel on a bordered copy of the
+ * input kept in the workspace; bf16, Cin % 64 == 0, Cout >= 192, B H W % 256 == 0 -- any other shape, or a workspace smaller than
+ * esam3_train_conv3x3_workspace bytes, runs esam3_train_conv3x3).  Reference: the student head's 3x3 conv, stage1/model.py:386-420 */
+int64_t esam3_train_conv3x3_workspace(int dtype, int B, int H, int W, int Cin, int Cout);
+int esam3_train_conv3x3_ws(int dtype, const void* x_dev, const float* w_dev, const float* bias_dev, void* out_dev, int B, int H, int W,
+                           int Cin, int Cout, int dgrad, void* workspace_dev, int64_t workspace_bytes, void* hip_stream);
 /* the dense 3x3 (padding 1) with STRIDE 2: the second conv of RepViT's patch embedding (sam3/backbones/repvit.py:229-230), forward only
  * -- out [B][ceil(H/2)][ceil(W/2)][Cout]; workspace esam3_train_pack_bytes(dtype, Cout, 9 Cin).  Its data gradient is
  * esam3_train_conv3x3(dgrad = 1) on dy spread over the even pixels of a zero H x W grid, its weight gradient esam3_linear_wgrad per tap. */
