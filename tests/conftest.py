@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # The fp32 CPU oracle is the checker of most GPU tests.  torch takes one thread per physical core (128 on the 256-core GPU hosts) and
+    # the oracle's convolutions / GEMMs run 3.5 x SLOWER that way than on 32 threads (efficientvit-b1 distribution test: 51 s at 128 threads,
+    # 27 s at 64, 15 s at 32 -- profiles/r06/host_threads_oracle.txt); the suite's wall time is mostly oracle time.
+    try:
+        import torch
+        if torch.get_num_threads() > 32 and not os.environ.get("OMP_NUM_THREADS"):
+            torch.set_num_threads(32)
+    except Exception:  # noqa: BLE001  (torch missing: nothing to configure)
+        pass
 
 
 @pytest.fixture(scope="session")
