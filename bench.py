@@ -62,7 +62,10 @@ def cpu_baseline(sample_images: int = 5):
     from efficientsam3_amd import schema, synth
     from oracle import ref_model
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    # 32 threads: the oracle's convolutions / GEMMs at batch 1 are FASTER on 32 threads than on 64 or on torch's default of one per physical
+    # core on the 256-CPU GPU hosts (profiles/r06/host_threads_oracle.txt: 14.6 s / 25.5 s / 51.1 s for the same oracle work) -- the baseline
+    # is the best the CPU path does here, not a strawman
+    threads = min(cores, 32)
     torch.set_num_threads(threads)
     sd = schema.synthetic_state_dict("efficientvit", "b1", seed=0)
     pts, labels, boxes = synth.prompts(sample_images + 1, seed=2)
