@@ -121,6 +121,7 @@ SIGNATURES = {
     "esam3_lite_mla_backward": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "esam3_lite_mla_backward_workspace": (_L, [_I, _I, _I, _I]),
     "esam3_lite_mla_backward_ws": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _P, _P]),
+    "esam3_lite_mla_backward_ws2": (_I, [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _P, _P]),
     "esam3_dwconv_dgrad": (_I, [_I, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_train_pack_bytes": (_L, [_I, _I, _I]),
     "esam3_train_linear": (_I, [_I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),

@@ -869,7 +869,12 @@ __global__ __launch_bounds__(256) void mla_backward_part_kernel(const typename T
                                                            const typename TElem<DT>::type* __restrict__ dout,
                                                            typename TElem<DT>::type* __restrict__ dms,
                                                            typename TElem<DT>::type* __restrict__ y, int N, int G, float eps, int P, int span,
-                                                                const float* __restrict__ Sg, const float* __restrict__ dSg, float* __restrict__ part) {
+                                                                const float* __restrict__ Sg, const float* __restrict__ dSg, float* __restrict__ part,
+                                                                const typename TElem<DT>::type* __restrict__ ms1 = nullptr,
+                                                                typename TElem<DT>::type* __restrict__ dms1 = nullptr) {
+  // round 6: with `ms1` the multi-scale tensor arrives as its two halves -- head groups 0 .. G/2 - 1 in `ms` (the qkv conv's output), G/2 .. G - 1
+  // in `ms1` (the aggregated scale), each [B][N][G/2 * 3 * DIM] -- and the gradient leaves the same way (`dms`, `dms1`): the torch.cat in front of
+  // the forward and the two slice copies behind the backward (1.1 ms of a B1 batch-32 step, the ATen kernels of its trace) are gone
   constexpr int TT = 64, D1 = DIM + 1, SE = D1 * DIM;  // tokens per tile, rows of S, elements of S
   __shared__ float tq[TT][DIM + 1], tk[TT][DIM + 1], tv[TT][D1 + 1];  // relu(q), relu(k), [v; 1] of the tile (+1: bank skew)
   __shared__ float tdo[TT][D1 + 1];                                   // dO of the tile
@@ -881,7 +886,10 @@ __global__ __launch_bounds__(256) void mla_backward_part_kernel(const typename T
   const int nb = blockIdx.y * span, ne = min(N, nb + span);   // this workgroup's token range
   const int tid = threadIdx.x;
   const int C3 = G * 3 * DIM, CO = G * DIM;
-  const T* base = ms + b * N * (int64_t)C3 + g * 3 * DIM;
+  const bool hi = ms1 != nullptr && g >= G / 2;          // this group lives in the second tensor
+  const int RS = ms1 ? C3 / 2 : C3;                      // row stride of the tensor(s)
+  const int gq = hi ? g - G / 2 : g;                     // group index inside its tensor
+  const T* base = (hi ? ms1 : ms) + b * N * (int64_t)RS + gq * 3 * DIM;
   auto ldf = [](const T* p) -> float {
     if constexpr (DT == 0) return *p; else return __uint_as_float((uint32_t)*p << 16);
   };
@@ -889,7 +897,7 @@ __global__ __launch_bounds__(256) void mla_backward_part_kernel(const typename T
     for (int i = tid; i < TT * 3 * DIM; i += 256) {
       const int n = i / (3 * DIM), c = i - n * 3 * DIM;
       float v = 0.f;
-      if (n0 + n < ne) v = ldf(base + (int64_t)(n0 + n) * C3 + c);
+      if (n0 + n < ne) v = ldf(base + (int64_t)(n0 + n) * RS + c);
       if (c < DIM) tq[n][c] = v > 0.f ? v : 0.f;
       else if (c < 2 * DIM) tk[n][c - DIM] = v > 0.f ? v : 0.f;
       else tv[n][c - 2 * DIM] = v;
@@ -1026,7 +1034,7 @@ __global__ __launch_bounds__(256) void mla_backward_part_kernel(const typename T
     if (tid < TT && n0 + tid < ne) token_dD(tid);
     __syncthreads();
     if (n0 + n < ne) {
-      T* o = dms + (b * N + n0 + n) * (int64_t)C3 + g * 3 * DIM;
+      T* o = (hi ? dms1 : dms) + (b * N + n0 + n) * (int64_t)RS + gq * 3 * DIM;
       auto stf = [&](int c, float v) {
         if constexpr (DT == 0) o[c] = v; else o[c] = f32_to_bf16(v);
       };
@@ -1334,8 +1342,26 @@ int64_t esam3_lite_mla_backward_workspace(int B, int N, int groups, int dim) {
   return (int64_t)sizeof(float) * B * groups * SE * ((mla_bw_parts(N) > 2 ? mla_bw_parts(N) : 2) + 2);
 }
 
+static int mla_backward_ws_impl(int dtype, const void* ms, const void* ms1, const void* dout, void* dms, void* dms1, void* y, int B, int N, int groups,
+                               int dim, float eps, void* workspace, void* stream);
+
 int esam3_lite_mla_backward_ws(int dtype, const void* ms, const void* dout, void* dms, void* y, int B, int N, int groups, int dim, float eps,
                                void* workspace, void* stream) {
+  return mla_backward_ws_impl(dtype, ms, nullptr, dout, dms, nullptr, y, B, N, groups, dim, eps, workspace, stream);
+}
+
+// the multi-scale tensor as its two halves (see mla_backward_part_kernel): ms0 / ms1 [B][N][groups / 2 * 3 * dim], gradients dms0 / dms1 likewise
+int esam3_lite_mla_backward_ws2(int dtype, const void* ms0, const void* ms1, const void* dout, void* dms0, void* dms1, void* y, int B, int N,
+                                int groups, int dim, float eps, void* workspace, void* stream) {
+  if (!ms1 || groups % 2 || (dout && !dms1) || N <= 256) {
+    esam3_set_error("esam3_lite_mla_backward_ws2: two halves need an even group count, both gradient tensors and N > 256 tokens");
+    return -1;
+  }
+  return mla_backward_ws_impl(dtype, ms0, ms1, dout, dms0, dms1, y, B, N, groups, dim, eps, workspace, stream);
+}
+
+static int mla_backward_ws_impl(int dtype, const void* ms, const void* ms1, const void* dout, void* dms, void* dms1, void* y, int B, int N, int groups,
+                               int dim, float eps, void* workspace, void* stream) {
   const bool fwd_only = !dout;   // dout_dev NULL: the forward output y only (dms_dev is not written)
   if ((dtype != 0 && dtype != 1) || !ms || (!fwd_only && !dms) || (fwd_only && !y) || !workspace || B <= 0 || N <= 0 || groups <= 0 ||
       (dim != 16 && dim != 32)) {
@@ -1355,7 +1381,7 @@ int esam3_lite_mla_backward_ws(int dtype, const void* ms, const void* dout, void
   hipStream_t s = (hipStream_t)stream;
 #define ESAM3_MLA_PART(DT_, DIM_, T_, MODE_) \
   hipLaunchKernelGGL((mla_backward_part_kernel<DT_, DIM_, MODE_>), grid, dim3(256), 0, s, (const T_*)ms, (const T_*)dout, (T_*)dms, (T_*)y, N, groups, eps, \
-                     P, span, Sg, dSg, part)
+                     P, span, Sg, dSg, part, (const T_*)ms1, (T_*)dms1)
 #define ESAM3_MLA_ALL(DT_, DIM_, T_)                                                                                  \
   do {                                                                                                               \
     ESAM3_MLA_PART(DT_, DIM_, T_, 0);                                                                                \

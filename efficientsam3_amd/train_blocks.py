@@ -415,6 +415,28 @@ def lite_mla_forward(ms: torch.Tensor, groups: int, dim: int, eps: float = 1e-15
     return y
 
 
+def lite_mla_pair(ms0: torch.Tensor, ms1: torch.Tensor, dout, groups: int, dim: int, eps: float = 1e-15):
+    """the two functions above on the multi-scale tensor AS ITS TWO HALVES (round 6: ``esam3_lite_mla_backward_ws2``): ms0 = the qkv conv's
+    output, ms1 = the aggregated scale, each [B, N, groups / 2 * 3 * dim].  ``dout`` None: the forward output y; else (d_ms0, d_ms1).  Saves the
+    torch.cat in front of the forward and the two slice copies behind the backward."""
+    b, n, c3h = ms0.shape
+    assert ms1.shape == ms0.shape and 2 * c3h == groups * 3 * dim and ms0.is_contiguous() and ms1.is_contiguous() and n > 256
+    lib = _lib.load()
+    ws = _ws(lib.esam3_lite_mla_backward_workspace(b, n, groups, dim), ms0.device)
+    if dout is None:
+        y = torch.empty((b, n, groups * dim), dtype=ms0.dtype, device=ms0.device)
+        with torch.cuda.device(ms0.device):
+            _lib.check(lib.esam3_lite_mla_backward_ws2(_DT[ms0.dtype], ms0.data_ptr(), ms1.data_ptr(), None, None, None, y.data_ptr(), b, n, groups, dim,
+                                                       float(eps), ws.data_ptr(), _stream()), "esam3_lite_mla_backward_ws2 (forward only)")
+        return y
+    assert tuple(dout.shape) == (b, n, groups * dim) and dout.is_contiguous()
+    d0, d1, y = torch.empty_like(ms0), torch.empty_like(ms1), torch.empty_like(dout)
+    with torch.cuda.device(ms0.device):
+        _lib.check(lib.esam3_lite_mla_backward_ws2(_DT[ms0.dtype], ms0.data_ptr(), ms1.data_ptr(), dout.data_ptr(), d0.data_ptr(), d1.data_ptr(),
+                                                   y.data_ptr(), b, n, groups, dim, float(eps), ws.data_ptr(), _stream()), "esam3_lite_mla_backward_ws2")
+    return d0, d1
+
+
 def _blockdiag(wg: torch.Tensor, gs: int) -> torch.Tensor:
     """grouped 1x1 weight [C, gs, 1, 1] (group size gs) -> the dense block-diagonal [C, C] matrix the engine's GEMM runs; pure data
     movement, on the weight's own device (a device-resident weight changes every step: rebuilt per forward)"""
@@ -451,9 +473,14 @@ class LiteMLATrain:
         self.agg1 = dwconv_forward(self.qkv, self.p["aggreg.dw.weight"], 1)     # depthwise 5x5
         self.wg_dense = _blockdiag(self.p["aggreg.pw.weight"], self.dim)         # from the CURRENT grouped weight
         agg2 = linear_forward(self.agg1, self.wg_dense)                          # grouped 1x1 as a block-diagonal GEMM
-        self.ms = torch.cat([self.qkv, agg2], dim=-1).reshape(b, h * w, 6 * c).contiguous()
         self.groups = 2 * (c // self.dim)
-        att = lite_mla_forward(self.ms, self.groups, self.dim, self.eps)
+        self.pair = x.is_cuda and h * w > 256       # the kernels take the two scales as separate tensors (no concatenated copy)
+        if self.pair:
+            self.agg2 = agg2
+            att = lite_mla_pair(self.qkv.reshape(b, h * w, 3 * c), agg2.reshape(b, h * w, 3 * c), None, self.groups, self.dim, self.eps)
+        else:
+            self.ms = torch.cat([self.qkv, agg2], dim=-1).reshape(b, h * w, 6 * c).contiguous()
+            att = lite_mla_forward(self.ms, self.groups, self.dim, self.eps)
         self.att = att.reshape(b, h, w, 2 * c)
         y = self.proj.forward(self.att)
         return add(x, y)
@@ -461,9 +488,14 @@ class LiteMLATrain:
     def backward(self, dy: torch.Tensor):
         b, h, w, c = self.x.shape
         d_att, g_proj = self.proj.backward(dy)
-        d_ms, _ = lite_mla_backward(self.ms, d_att.reshape(b, h * w, 2 * c).contiguous(), self.groups, self.dim, self.eps)
-        d_ms = d_ms.reshape(b, h, w, 6 * c)
-        d_qkv_direct, d_agg2 = d_ms[..., :3 * c].contiguous(), d_ms[..., 3 * c:].contiguous()
+        if self.pair:
+            d0, d1 = lite_mla_pair(self.qkv.reshape(b, h * w, 3 * c), self.agg2.reshape(b, h * w, 3 * c),
+                                   d_att.reshape(b, h * w, 2 * c).contiguous(), self.groups, self.dim, self.eps)
+            d_qkv_direct, d_agg2 = d0.reshape(b, h, w, 3 * c), d1.reshape(b, h, w, 3 * c)
+        else:
+            d_ms, _ = lite_mla_backward(self.ms, d_att.reshape(b, h * w, 2 * c).contiguous(), self.groups, self.dim, self.eps)
+            d_ms = d_ms.reshape(b, h, w, 6 * c)
+            d_qkv_direct, d_agg2 = d_ms[..., :3 * c].contiguous(), d_ms[..., 3 * c:].contiguous()
         dense = linear_wgrad(d_agg2, self.agg1)                                  # [3C, 3C]; only its diagonal blocks are the grouped weight's
         dwg = _blockdiag_extract(dense, self.dim)
         d_agg1 = linear_dgrad(d_agg2, self.wg_dense)

@@ -274,6 +274,10 @@ int esam3_lite_mla_backward(int dtype, const void* ms_dev, const void* dout_dev,
 int64_t esam3_lite_mla_backward_workspace(int B, int N, int groups, int dim);
 int esam3_lite_mla_backward_ws(int dtype, const void* ms_dev, const void* dout_dev, void* dms_dev, void* y_dev, int B, int N, int groups,
                                int dim, float eps, void* workspace_dev, void* hip_stream);
+/* round 6: the same with the multi-scale tensor as its two halves -- ms0_dev = the qkv conv's output, ms1_dev = the aggregated scale, each
+ * [B][N][groups / 2 * 3 * dim]; gradients leave as dms0_dev / dms1_dev (no torch.cat in front, no slice copies behind); N > 256 tokens */
+int esam3_lite_mla_backward_ws2(int dtype, const void* ms0_dev, const void* ms1_dev, const void* dout_dev, void* dms0_dev, void* dms1_dev,
+                                void* y_dev, int B, int N, int groups, int dim, float eps, void* workspace_dev, void* hip_stream);
 /* dx [B][H][W][C] of the same depthwise conv from dy [B][ceil(H/s)][ceil(W/s)][C]; w_dev fp32 [C][1][k][k] ON THE DEVICE */
 int esam3_dwconv_dgrad(int dtype, const void* dy_dev, const float* w_dev, void* dx_dev, int B, int H, int W, int C, int ksize,
                        int stride, void* hip_stream);
