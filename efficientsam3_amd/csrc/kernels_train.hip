@@ -864,6 +864,41 @@ __global__ __launch_bounds__(256) void mla_backward_kernel(const typename TElem<
 // up to 3969 tokens three times were 24 % of a training step (profiles/r04/stage1_step_kernel_stats.csv).  MODE 0 writes the partial S of
 // its token range, MODE 1 (with the reduced S) the partial dS and Y, MODE 2 (with S and dS) the per-token gradients; the partial
 // matrices are summed in range order by mla_backward_reduce_kernel: deterministic, same arithmetic per token as the one-workgroup form.
+//
+// Round 6 (second form).  The four modes were 6.7 ms of a 50.7 ms B1 batch-32 step against 0.33 ms of HBM time
+// (profiles/r06/roofline_stage1_step_b1_b32_end.md): every multiply-add fetched both operands from LDS (S / dS element + token element: the
+// LDS pipe, not the VALU, set the time) and every global access was a 2-byte element with the token as the lane (64 cache lines per
+// instruction).  Now
+//   - S and dS come from the workspace through SCALAR loads: the thread layout is (token = lane, channel quarter = wave), so every S / dS
+//     index is wave-uniform -- an SGPR operand of the multiply-add, no LDS read;
+//   - a token's vectors (relu(q), dO, [v; 1], relu(k)) are read from LDS once into registers, not once per output channel;
+//   - the S / dS partial sums (outer products over the tile's tokens) run on the fp32 matrix unit: v_mfma_f32_16x16x4f32, each wave a
+//     quarter of the tile's tokens, the extra row (sum of relu(k) / of dD relu(q)) beside it on the VALU; the four
+//     waves' accumulators are added in wave order once at the end (deterministic; fp32 MFMA multiplies and adds in full precision);
+//   - the tile is staged with 16-byte loads, dY / Y / the gradients move as 8- or 16-byte pieces (a thread's own channels are contiguous).
+// Per token the operations and their order are the ones of the first form; only the S / dS sums associate differently (four token
+// quarters per tile instead of one chain).
+template <int DT, int NE> struct MlaVec;   // NE consecutive elements of a row, 8 / 16 / 32 bytes
+template <> struct MlaVec<1, 4> {
+  static __device__ inline void ld(const uint16_t* p, float* v) {
+    const uint2 q = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u); v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+  }
+  static __device__ inline void st(uint16_t* p, const float* v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])); }
+};
+template <> struct MlaVec<1, 8> {
+  static __device__ inline void ld(const uint16_t* p, float* v) { TElem<1>::load8(p, v); }
+  static __device__ inline void st(uint16_t* p, const float* v) { TElem<1>::store8(p, v); }
+};
+template <> struct MlaVec<0, 4> {
+  static __device__ inline void ld(const float* p, float* v) { const float4 q = *reinterpret_cast<const float4*>(p); v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w; }
+  static __device__ inline void st(float* p, const float* v) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct MlaVec<0, 8> {
+  static __device__ inline void ld(const float* p, float* v) { TElem<0>::load8(p, v); }
+  static __device__ inline void st(float* p, const float* v) { TElem<0>::store8(p, v); }
+};
+
 template <int DT, int DIM, int MODE>
 __global__ __launch_bounds__(256) void mla_backward_part_kernel(const typename TElem<DT>::type* __restrict__ ms,
                                                            const typename TElem<DT>::type* __restrict__ dout,
@@ -872,186 +907,232 @@ __global__ __launch_bounds__(256) void mla_backward_part_kernel(const typename T
                                                                 const float* __restrict__ Sg, const float* __restrict__ dSg, float* __restrict__ part,
                                                                 const typename TElem<DT>::type* __restrict__ ms1 = nullptr,
                                                                 typename TElem<DT>::type* __restrict__ dms1 = nullptr) {
-  // round 6: with `ms1` the multi-scale tensor arrives as its two halves -- head groups 0 .. G/2 - 1 in `ms` (the qkv conv's output), G/2 .. G - 1
+  // with `ms1` the multi-scale tensor arrives as its two halves -- head groups 0 .. G/2 - 1 in `ms` (the qkv conv's output), G/2 .. G - 1
   // in `ms1` (the aggregated scale), each [B][N][G/2 * 3 * DIM] -- and the gradient leaves the same way (`dms`, `dms1`): the torch.cat in front of
   // the forward and the two slice copies behind the backward (1.1 ms of a B1 batch-32 step, the ATen kernels of its trace) are gone
   constexpr int TT = 64, D1 = DIM + 1, SE = D1 * DIM;  // tokens per tile, rows of S, elements of S
+  constexpr int NB = DIM / 16, CPT = DIM / 4;          // 16 x 16 blocks of S per side; output channels per thread
   __shared__ float tq[TT][DIM + 1], tk[TT][DIM + 1], tv[TT][D1 + 1];  // relu(q), relu(k), [v; 1] of the tile (+1: bank skew)
   __shared__ float tdo[TT][D1 + 1];                                   // dO of the tile
-  __shared__ float S[SE], dS[SE];
   __shared__ float pdd[4][TT];                                         // the four shares of a token's dD (token_dO)
+  __shared__ float wred[(MODE == 0 || MODE == 1) ? 4 : 1][(DIM + 4) * DIM];   // the waves' partial S / dS: DIM rows + 4 shares of the extra row
   typedef typename TElem<DT>::type T;
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
   const int g = blockIdx.x % G;
   const int64_t b = blockIdx.x / G;
   const int nb = blockIdx.y * span, ne = min(N, nb + span);   // this workgroup's token range
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // the wave = the channel quarter: uniform, so S / dS indices built on it are scalar
   const int C3 = G * 3 * DIM, CO = G * DIM;
   const bool hi = ms1 != nullptr && g >= G / 2;          // this group lives in the second tensor
   const int RS = ms1 ? C3 / 2 : C3;                      // row stride of the tensor(s)
   const int gq = hi ? g - G / 2 : g;                     // group index inside its tensor
   const T* base = (hi ? ms1 : ms) + b * N * (int64_t)RS + gq * 3 * DIM;
-  auto ldf = [](const T* p) -> float {
-    if constexpr (DT == 0) return *p; else return __uint_as_float((uint32_t)*p << 16);
-  };
-  auto stage = [&](int n0) {  // tile of tokens n0 .. n0 + TT - 1 (zeros past N: they add nothing to S / dS)
-    for (int i = tid; i < TT * 3 * DIM; i += 256) {
-      const int n = i / (3 * DIM), c = i - n * 3 * DIM;
-      float v = 0.f;
-      if (n0 + n < ne) v = ldf(base + (int64_t)(n0 + n) * RS + c);
-      if (c < DIM) tq[n][c] = v > 0.f ? v : 0.f;
-      else if (c < 2 * DIM) tk[n][c - DIM] = v > 0.f ? v : 0.f;
-      else tv[n][c - 2 * DIM] = v;
-    }
-    for (int n = tid; n < TT; n += 256) tv[n][DIM] = n0 + n < ne ? 1.f : 0.f;
-  };
-  // acc[j] += sum over the tile of X[n][a] Z[n][c]  for this thread's elements e = tid + 256 j = a DIM + c
-  constexpr int NJ = (SE + 255) / 256;
-  auto outer = [&](const float (*X)[D1 + 1], const float (*Z)[DIM + 1], float* acc) {
+  const float* Sw = Sg + (int64_t)blockIdx.x * SE;       // read with wave-uniform indices only
+  const float* dSw = dSg + (int64_t)blockIdx.x * SE;
+  constexpr int EPC = DT == 0 ? 4 : 8, CPR = 3 * DIM / EPC;   // elements per 16-byte chunk, chunks per token row
+  auto stage = [&](int n0) {  // tile of tokens n0 .. n0 + TT - 1 (zeros past the range: they add nothing to S / dS)
+    for (int i = tid; i < TT * CPR; i += 256) {
+      const int n = i / CPR, c0 = (i - n * CPR) * EPC;
+      float v[EPC];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int e = tid + 256 * j;
-      if (e < SE) {
-        const int a = e / DIM, c = e - a * DIM;
-        float s_ = acc[j];
-        for (int n = 0; n < TT; ++n) s_ = fmaf(X[n][a], Z[n][c], s_);
-        acc[j] = s_;
+      for (int e = 0; e < EPC; ++e) v[e] = 0.f;
+      if (n0 + n < ne) MlaVec<DT, EPC>::ld(base + (int64_t)(n0 + n) * RS + c0, v);
+      if (c0 < DIM) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) tq[n][c0 + e] = v[e] > 0.f ? v[e] : 0.f;
+      } else if (c0 < 2 * DIM) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) tk[n][c0 - DIM + e] = v[e] > 0.f ? v[e] : 0.f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) tv[n][c0 - 2 * DIM + e] = v[e];
+      }
+    }
+    if (tid < TT) tv[tid][DIM] = n0 + tid < ne ? 1.f : 0.f;
+  };
+  // acc[ab][cb] (rows 16 ab .., columns 16 cb ..) += sum over this wave's 16 tokens of X[n][a] Z[n][c];  ext[cb] likewise for the extra row
+  // a = DIM, this lane's share (tokens 4 j + lane / 16 of the wave's sixteen)
+  f32x4_t acc[NB][NB];
+  float ext[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    ext[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  auto outer = [&](const float (*X)[D1 + 1], const float (*Z)[DIM + 1]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = wv * 16 + 4 * j + (lane >> 4);
+      float av[NB], bv[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        av[i] = X[n][16 * i + (lane & 15)];
+        bv[i] = Z[n][16 * i + (lane & 15)];
+      }
+      const float xl = X[n][DIM];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        ext[i] = fmaf(xl, bv[i], ext[i]);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) acc[i][k] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[k], acc[i][k], 0, 0, 0);
       }
     }
   };
-  // dO of token n (from S in LDS and dY) -> tdo[n][0 .. DIM]; writes Y in MODE 1.  Nothing is kept in an indexed register array: with
-  // DIM = 32 the fully unrolled form (O[33], dO[33], then 32 x 65 multiply-adds per token in one thread) spilled 12 KB of scratch per thread
-  // and MODE 2 alone was 74 ms of a 133 ms EfficientViT-B2 step (profiles/r05/stage1_step_b2_kernel_stats.csv).  Same operations in the
-  // same order per element as before.
-  // Four threads per token (thread = (n = tid & 63, quarter q = tid >> 6)): every one recomputes D (32 multiply-adds), handles the DIM / 4
-  // channels a of its quarter and leaves its share of dD in pdd[q][n]; token_dD adds the four shares in quarter order (deterministic).
-  auto token_dO = [&](int n0, int n, int q) {
+  auto flush = [&](float* mine) {   // the four waves' sums, added in wave order
+    if constexpr (MODE > 1) return;
+    else {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      wred[wv][(DIM + (lane >> 4)) * DIM + 16 * i + (lane & 15)] = ext[i];
+#pragma unroll
+      for (int k = 0; k < NB; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wred[wv][(16 * i + 4 * (lane >> 4) + r) * DIM + 16 * k + (lane & 15)] = acc[i][k][r];
+    }
+    __syncthreads();
+    for (int e = tid; e < SE; e += 256) {
+      float s_;
+      if (e < DIM * DIM) s_ = (wred[0][e] + wred[1][e]) + (wred[2][e] + wred[3][e]);
+      else {
+        s_ = 0.f;
+        for (int w = 0; w < 4; ++w)
+          for (int t = 0; t < 4; ++t) s_ += wred[w][(DIM + t) * DIM + (e - DIM * DIM)];
+      }
+      mine[e] = s_;
+    }
+    }
+  };
+  // dO of token n (from S and dY) -> tdo[n][0 .. DIM); writes Y in MODE 1.  Four threads per token (thread = (n = lane, quarter = wave)):
+  // every one recomputes D (DIM multiply-adds), handles the DIM / 4 channels a of its quarter and leaves its share of dD in pdd[wave][n];
+  // token_dD adds the four shares in quarter order (deterministic).
+  auto token_dO = [&](int n0, int n) {
+    float qv[DIM];
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) qv[c] = tq[n][c];
     float od = 0.f;
 #pragma unroll
-    for (int c = 0; c < DIM; ++c) od = fmaf(S[DIM * DIM + c], tq[n][c], od);
+    for (int c = 0; c < DIM; ++c) od = fmaf(Sw[DIM * DIM + c], qv[c], od);
     const float D = od + eps, inv = 1.f / D;
+    const int64_t at = (b * N + n0 + n) * (int64_t)CO + g * DIM + wv * CPT;
+    float dyv[CPT], yv[CPT];
+    MlaVec<DT, CPT>::ld(dout + at, dyv);
     float dD = 0.f;
-#pragma unroll 2
-    for (int k = 0; k < DIM / 4; ++k) {
-      const int a = q * (DIM / 4) + k;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+      const int a = wv * CPT + k;
       float s_ = 0.f;
 #pragma unroll
-      for (int c = 0; c < DIM; ++c) s_ = fmaf(S[a * DIM + c], tq[n][c], s_);
-      const float yv = s_ * inv;
-      const float dyv = ldf(dout + ((b * N + n0 + n) * (int64_t)CO) + g * DIM + a);
-      tdo[n][a] = dyv * inv;
-      dD = fmaf(-dyv, yv, dD);
-      if (MODE == 1 && y) {
-        if constexpr (DT == 0) y[(b * N + n0 + n) * (int64_t)CO + g * DIM + a] = yv;
-        else y[(b * N + n0 + n) * (int64_t)CO + g * DIM + a] = f32_to_bf16(yv);
-      }
+      for (int c = 0; c < DIM; ++c) s_ = fmaf(Sw[a * DIM + c], qv[c], s_);
+      yv[k] = s_ * inv;
+      tdo[n][a] = dyv[k] * inv;
+      dD = fmaf(-dyv[k], yv[k], dD);
     }
-    pdd[q][n] = dD * inv;
+    if (MODE == 1 && y) MlaVec<DT, CPT>::st(y + at, yv);
+    pdd[wv][n] = dD * inv;
   };
   auto token_dD = [&](int n) { tdo[n][DIM] = (pdd[0][n] + pdd[1][n]) + (pdd[2][n] + pdd[3][n]); };
 
-  float acc[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
   float* mine = part + ((int64_t)blockIdx.x * P + blockIdx.y) * SE;
   if constexpr (MODE == 0) {   // ---- S partial = Vp Kr^T over this range ----
     for (int n0 = nb; n0 < ne; n0 += TT) {
       __syncthreads();
       stage(n0);
       __syncthreads();
-      outer(tv, tk, acc);
+      outer(tv, tk);
     }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-      if (tid + 256 * j < SE) mine[tid + 256 * j] = acc[j];
+    flush(mine);
     return;
   }
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-    if (tid + 256 * j < SE) {
-      S[tid + 256 * j] = Sg[(int64_t)blockIdx.x * SE + tid + 256 * j];
-      if constexpr (MODE == 2) dS[tid + 256 * j] = dSg[(int64_t)blockIdx.x * SE + tid + 256 * j];
-    }
   if constexpr (MODE == 3) {   // ---- forward only: Y = O[:DIM] / (O[DIM] + eps) of this range (dout is not read) ----
     for (int n0 = nb; n0 < ne; n0 += TT) {
       __syncthreads();
       stage(n0);
       __syncthreads();
-      const int n = tid & (TT - 1), q = tid >> 6;      // four threads per token, a quarter of the output channels each
+      const int n = lane;
       if (n0 + n < ne) {
+        float qv[DIM], yv[CPT];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) qv[c] = tq[n][c];
         float od = 0.f;
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) od = fmaf(S[DIM * DIM + c], tq[n][c], od);
+        for (int c = 0; c < DIM; ++c) od = fmaf(Sw[DIM * DIM + c], qv[c], od);
         const float inv = 1.f / (od + eps);
-#pragma unroll 2
-        for (int k = 0; k < DIM / 4; ++k) {
-          const int a = q * (DIM / 4) + k;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+          const int a = wv * CPT + k;
           float s_ = 0.f;
 #pragma unroll
-          for (int c = 0; c < DIM; ++c) s_ = fmaf(S[a * DIM + c], tq[n][c], s_);
-          const float yv = s_ * inv;
-          if constexpr (DT == 0) y[(b * N + n0 + n) * (int64_t)CO + g * DIM + a] = yv;
-          else y[(b * N + n0 + n) * (int64_t)CO + g * DIM + a] = f32_to_bf16(yv);
+          for (int c = 0; c < DIM; ++c) s_ = fmaf(Sw[a * DIM + c], qv[c], s_);
+          yv[k] = s_ * inv;
         }
+        MlaVec<DT, CPT>::st(y + (b * N + n0 + n) * (int64_t)CO + g * DIM + wv * CPT, yv);
       }
     }
     return;
   }
   if constexpr (MODE == 1) {   // ---- dS partial = dO Qr^T over this range (also writes Y) ----
-  for (int n0 = nb; n0 < ne; n0 += TT) {
-    __syncthreads();
-    stage(n0);
-    __syncthreads();
-    {
-      const int n = tid & (TT - 1), q = tid >> 6;
-      if (n0 + n < ne) token_dO(n0, n, q);
-      else {
-        for (int k = 0; k < DIM / 4; ++k) tdo[n][q * (DIM / 4) + k] = 0.f;
-        pdd[q][n] = 0.f;
+    for (int n0 = nb; n0 < ne; n0 += TT) {
+      __syncthreads();
+      stage(n0);
+      __syncthreads();
+      {
+        const int n = lane;
+        if (n0 + n < ne) token_dO(n0, n);
+        else {
+          for (int k = 0; k < CPT; ++k) tdo[n][wv * CPT + k] = 0.f;
+          pdd[wv][n] = 0.f;
+        }
       }
+      __syncthreads();
+      if (tid < TT) token_dD(tid);
+      __syncthreads();
+      outer(tdo, tq);
     }
-    __syncthreads();
-    if (tid < TT) token_dD(tid);
-    __syncthreads();
-    outer(tdo, tq, acc);
+    flush(mine);
+    return;
   }
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-    if (tid + 256 * j < SE) mine[tid + 256 * j] = acc[j];
-  return;
-  }
-  // ---- MODE 2: per-token gradients of this range ----
-  // first the token's dO (into LDS, four threads per token), then the gradients with the same thread layout: thread = (token n = tid & 63,
-  // channel quarter tid >> 6), so S / dS reads stay wave-uniform (broadcasts) and each thread streams its operands from LDS instead of
-  // holding a 33-vector
-  constexpr int CPT = DIM / 4;
-  for (int n0 = nb; n0 < ne; n0 += TT) {
-    __syncthreads();
-    stage(n0);
-    __syncthreads();
-    const int n = tid & (TT - 1), c0 = (tid >> 6) * CPT;
-    if (n0 + n < ne) token_dO(n0, n, tid >> 6);
-    __syncthreads();
-    if (tid < TT && n0 + tid < ne) token_dD(tid);
-    __syncthreads();
-    if (n0 + n < ne) {
-      T* o = (hi ? dms1 : dms) + (b * N + n0 + n) * (int64_t)RS + gq * 3 * DIM;
-      auto stf = [&](int c, float v) {
-        if constexpr (DT == 0) o[c] = v; else o[c] = f32_to_bf16(v);
-      };
-#pragma unroll 2
-      for (int k = 0; k < CPT; ++k) {
-        const int c = c0 + k;
-        float dq = 0.f, dk = 0.f, dv = 0.f;
+  if constexpr (MODE == 2) {
+    // ---- per-token gradients of this range: the token's dO first (into LDS, four threads per token), then the gradients with the same
+    // thread layout; a thread's DIM / 4 channels of dq, dk, dv are contiguous in the row: three vector stores ----
+    for (int n0 = nb; n0 < ne; n0 += TT) {
+      __syncthreads();
+      stage(n0);
+      __syncthreads();
+      const int n = lane, c0 = wv * CPT;
+      if (n0 + n < ne) token_dO(n0, n);
+      __syncthreads();
+      if (tid < TT && n0 + tid < ne) token_dD(tid);
+      __syncthreads();
+      if (n0 + n < ne) {
+        float dov[D1], vv[D1], kv[DIM], oq[CPT], ok[CPT], ov[CPT];
 #pragma unroll
         for (int a = 0; a < D1; ++a) {
-          dq = fmaf(S[a * DIM + c], tdo[n][a], dq);    // dQr = S^T dO
-          dk = fmaf(dS[a * DIM + c], tv[n][a], dk);    // dKr = dS^T Vp
+          dov[a] = tdo[n][a];
+          vv[a] = tv[n][a];
         }
 #pragma unroll
-        for (int c2 = 0; c2 < DIM; ++c2) dv = fmaf(dS[c * DIM + c2], tk[n][c2], dv);  // dV = (dS Kr)[:DIM], row c
-        stf(c, tq[n][c] > 0.f ? dq : 0.f);
-        stf(DIM + c, tk[n][c] > 0.f ? dk : 0.f);
-        stf(2 * DIM + c, dv);
+        for (int c = 0; c < DIM; ++c) kv[c] = tk[n][c];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k) {
+          const int c = c0 + k;
+          float dq = 0.f, dk = 0.f, dv = 0.f;
+#pragma unroll
+          for (int a = 0; a < D1; ++a) {
+            dq = fmaf(Sw[a * DIM + c], dov[a], dq);    // dQr = S^T dO
+            dk = fmaf(dSw[a * DIM + c], vv[a], dk);    // dKr = dS^T Vp
+          }
+#pragma unroll
+          for (int c2 = 0; c2 < DIM; ++c2) dv = fmaf(dSw[c * DIM + c2], kv[c2], dv);  // dV = (dS Kr)[:DIM], row c
+          oq[k] = tq[n][c] > 0.f ? dq : 0.f;
+          ok[k] = tk[n][c] > 0.f ? dk : 0.f;
+          ov[k] = dv;
+        }
+        T* o = (hi ? dms1 : dms) + (b * N + n0 + n) * (int64_t)RS + gq * 3 * DIM + c0;
+        MlaVec<DT, CPT>::st(o, oq);
+        MlaVec<DT, CPT>::st(o + DIM, ok);
+        MlaVec<DT, CPT>::st(o + 2 * DIM, ov);
       }
     }
   }

@@ -235,9 +235,17 @@ class Stage1Trainer:
         push = push and self.reducer is not None and self._arrival_index is not None
         self._pushed = push
 
+        # one-rank / non-pushing steps: the ~190 per-parameter copies into the arena (5 us each, ~1 ms of a B1 batch-32 step, every one its own
+        # launch) are collected and issued as ONE multi-tensor copy after the backward pass; a pushing step needs each gradient in the arena the
+        # moment it is handed to the all-reduce and keeps the immediate copy
+        pending_dst, pending_src = [], []
+
         def sink(name, gval):
             dst = self.updater.grad(name)
-            if first:
+            if first and not push and gval.dtype == dst.dtype and gval.shape == dst.shape and gval.is_contiguous():  # one strided source sends the whole list down the per-tensor path
+                pending_dst.append(dst)
+                pending_src.append(gval)
+            elif first:
                 dst.copy_(gval)
             else:
                 dst.add_(gval.to(torch.float32))
@@ -247,6 +255,8 @@ class Stage1Trainer:
 
         d_feats, _ = self.head.backward(d_preds, sink=sink)
         self.trunk.backward(d_feats, sink=lambda n, gv: sink("backbone.model." + n, gv))
+        if pending_dst:
+            torch._foreach_copy_(pending_dst, pending_src)
         if self._arrival is None:
             self._arrival = order
             self._arrival_index = {n: i for i, n in enumerate(order)}

@@ -437,13 +437,23 @@ def lite_mla_pair(ms0: torch.Tensor, ms1: torch.Tensor, dout, groups: int, dim: 
     return d0, d1
 
 
+_DIAG_IDX = {}
+
+
+def _diag_idx(g: int, device) -> torch.Tensor:
+    key = (g, str(device))
+    if key not in _DIAG_IDX:
+        _DIAG_IDX[key] = torch.arange(g, device=device)
+    return _DIAG_IDX[key]
+
+
 def _blockdiag(wg: torch.Tensor, gs: int) -> torch.Tensor:
     """grouped 1x1 weight [C, gs, 1, 1] (group size gs) -> the dense block-diagonal [C, C] matrix the engine's GEMM runs; pure data
     movement, on the weight's own device (a device-resident weight changes every step: rebuilt per forward)"""
     c = wg.shape[0]
     g = c // gs
     dense = torch.zeros((g, gs, g, gs), dtype=torch.float32, device=wg.device)
-    idx = torch.arange(g, device=wg.device)
+    idx = _diag_idx(g, wg.device)
     dense[idx, :, idx, :] = wg.detach().float().reshape(g, gs, gs)
     return dense.reshape(c, c)
 
@@ -452,7 +462,7 @@ def _blockdiag_extract(dense: torch.Tensor, gs: int) -> torch.Tensor:
     """the diagonal gs x gs blocks of a dense [C, C] matrix -> [C, gs, 1, 1] (the grouped weight's gradient inside dy^T x)"""
     c = dense.shape[0]
     g = c // gs
-    idx = torch.arange(g, device=dense.device)
+    idx = _diag_idx(g, dense.device)
     return dense.reshape(g, gs, g, gs)[idx, :, idx, :].reshape(c, gs, 1, 1).contiguous()
 
 

@@ -182,6 +182,31 @@ print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["cpu_baseline"]["va
 PY
 
   ;;
+ac)
+  # round 6, GPU call AC: the training step after the gradient copies became one multi-tensor copy: tests, the B1 step, the kernel census of a step
+  mkdir -p $O
+  [ -n "$AC_SKIP_TESTS" ] || timeout 900 python -m pytest tests/test_train_blocks.py tests/test_stage1_step.py tests/test_stage1.py -q -m gpu -x --timeout 600 > $O/ac_train_tests.txt 2>&1
+  tail -3 $O/ac_train_tests.txt | cut -c1-300
+  for m in b1 repvit_m1_1 tiny_vit_11m; do
+    timeout 300 python tools/bench_stage1_step.py --model $m --batch 32 --steps 5 2>/dev/null | tail -1 > $O/ac_bench_stage1_step_${m}_b32.json
+    python -c "import json; d=json.loads(open('$O/ac_bench_stage1_step_${m}_b32.json').read()); print('$m', d['value'], d['ms_per_step'])"
+  done
+  R=$GRAFT_REPO_ROOT
+  ( cd /tmp && export TMPDIR=/tmp && timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/ac_prof -o ac --output-format csv -- python $R/tools/bench_stage1_step.py --model b1 --batch 32 --steps 5 --warmup 2 > $R/$O/ac_prof_stdout.txt 2>&1 )
+  cp $(find /tmp/ac_prof -name "*kernel_stats.csv" | head -1) $O/ac_kernel_stats_stage1_step_b1_b32.csv
+  python - <<PY
+import csv, glob
+f = glob.glob("/tmp/ac_prof/**/*kernel_trace.csv", recursive=True)[0]
+rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))), key=lambda t: t[0])
+# the last 40 % of the trace = timed steps; busy fraction and the largest gaps there
+n = len(rows); part = rows[int(n * 0.6):]
+busy = sum(e - s for s, e, _ in part); span = part[-1][1] - part[0][0]
+print("kernels", len(part), "busy ms", busy / 1e6, "span ms", span / 1e6, "busy frac", busy / span)
+gaps = sorted(((part[i + 1][0] - part[i][1], part[i][2][:60], part[i + 1][2][:60]) for i in range(len(part) - 1)), reverse=True)[:25]
+for g in gaps: print(g)
+PY
+  head -40 $O/ac_kernel_stats_stage1_step_b1_b32.csv | cut -c1-150
+  ;;
 p)
   # round 6, GPU call P: training kernels after the round's changes (stride-2 depthwise dgrad with LDS weights, vectorised colsum, stem im2col
   # kernel, depthwise wgrad without per-pixel divisions): their tests, the step pins of all students, the per-operator table again
