@@ -138,6 +138,7 @@ SIGNATURES = {
     "esam3_bn_train_backward": (_I, [_I, _P, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P]),
     "esam3_bn_act_train_forward": (_I, [_I, _P, _P, _P, _I, _L, _I, _P, _P, _P, _P, C.c_double, C.c_double, _P, _P, _P, _P]),
     "esam3_bn_act_train_backward": (_I, [_I, _P, _P, _P, _I, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "esam3_bn_act_train_backward_rc": (_I, [_I, _P, _P, _I, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "esam3_bn_train_stats": (_I, [_I, _P, _L, _I, C.c_double, _P, _P, _P, _P, _P]),
     "esam3_bn_train_apply": (_I, [_I, _P, _P, _L, _I, _P, _P, _P, _P, _P]),
     "esam3_bn_train_backward_sums": (_I, [_I, _P, _P, _L, _I, _P, _P, _P, _P, _P, _P]),

@@ -18,6 +18,11 @@ namespace {
 template <int DT> struct Elem;  // 0 f32, 1 bf16, 2 f16
 template <> struct Elem<0> {
   using type = float;
+  struct raw8 { float4 a, b; };   // 8 elements as loaded: several rows' loads can be in flight before the first is unpacked
+  static __device__ inline raw8 loadraw(const float* p) { return raw8{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)}; }
+  static __device__ inline void unpack(const raw8& q, float* v) {
+    v[0] = q.a.x; v[1] = q.a.y; v[2] = q.a.z; v[3] = q.a.w; v[4] = q.b.x; v[5] = q.b.y; v[6] = q.b.z; v[7] = q.b.w;
+  }
   static __device__ inline void load8(const float* p, float* v) {
     const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -25,6 +30,16 @@ template <> struct Elem<0> {
 };
 template <> struct Elem<1> {
   using type = uint16_t;
+  typedef uint4 raw8;
+  static __device__ inline raw8 loadraw(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ inline void unpack(const raw8& q, float* v) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
   static __device__ inline void load8(const uint16_t* p, float* v) {
     const uint4 q = *reinterpret_cast<const uint4*>(p);
     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
@@ -484,25 +499,39 @@ constexpr int BN_SPLITS = 512;
 // p is a per-channel PIVOT, the tensor's first row (stored after the partials, partial[splits][2][C] .. + C): E[x^2] - E[x]^2 on the
 // raw values cancels catastrophically when |mean| >> std (a large conv bias in front of the norm); shifted by a sample of the
 // channel, the two sums are of the order of the spread, not of the offset, and the fp64 finalize loses nothing.
+// the BatchNorm's output for one element, in ONE written-down form: the forward map stores it, the recomputing backward forms it again
+__device__ __forceinline__ float bn_affine(float v, float mean, float rstd, float gamma, float beta) { return fmaf((v - mean) * rstd, gamma, beta); }
+template <int DT> __device__ __forceinline__ float bn_stored(float v) {   // the value as the storage type holds it
+  if constexpr (DT == 1) return __uint_as_float(pack_bf16x2(v, 0.f) << 16);
+  else return v;
+}
+
 template <int DT, bool BWD>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const typename Elem<DT>::type* __restrict__ x,
                                                         const typename Elem<DT>::type* __restrict__ dy, int64_t rows, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         float* __restrict__ partial,
-                                                        const typename Elem<DT>::type* __restrict__ pre = nullptr, int act = 0) {
+                                                        const typename Elem<DT>::type* __restrict__ pre = nullptr, int act = 0,
+                                                        const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr) {
   // BWD with `pre` (round 5): dy is the gradient of act(pre), pre = the BatchNorm's own output -- g = dy act'(pre) is formed here instead of
-  // in a separate elementwise pass that wrote it out (the ConvLayer's activation derivative fused into the BatchNorm backward)
+  // in a separate elementwise pass that wrote it out (the ConvLayer's activation derivative fused into the BatchNorm backward).
+  // BWD with act and NO `pre` but gamma / beta (round 6): pre is RECOMPUTED from x exactly as the forward map formed and stored it
+  // (bn_affine, rounded to the storage type) -- the forward need not write the BatchNorm's output and the backward does not read it: two of
+  // the seven tensor passes of a fused BatchNorm + activation backward, one of the four of its forward.
   extern __shared__ float red[];  // [RL][2][C]
+  const bool rc = BWD && !pre && act != 0 && gamma && beta;
   const int CG = C >> 3, RL = 256 / CG;
   const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
   const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
-  float a[8], b[8], mu[8], rs[8], pv[8];
+  float a[8], b[8], mu[8], rs[8], pv[8], gm[8], bt[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     a[e] = 0.f; b[e] = 0.f; pv[e] = 0.f;
     mu[e] = BWD ? mean[cg * 8 + e] : 0.f;
     rs[e] = BWD ? rstd[cg * 8 + e] : 0.f;
+    gm[e] = rc ? gamma[cg * 8 + e] : 0.f;
+    bt[e] = rc ? beta[cg * 8 + e] : 0.f;
   }
   if constexpr (!BWD) {
     if (rl < RL) Elem<DT>::load8(x + cg * 8, pv);   // row 0
@@ -511,33 +540,66 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const typename Elem<DT>:
       for (int e = 0; e < 8; ++e) partial[(int64_t)gridDim.x * 2 * C + cg * 8 + e] = pv[e];
     }
   }
-  if (rl < RL)
-    for (int64_t r = r0 + rl; r < r1; r += RL) {
-      float v[8];
-      Elem<DT>::load8(x + r * C + cg * 8, v);
-      if constexpr (BWD) {
-        float g[8];
-        Elem<DT>::load8(dy + r * C + cg * 8, g);
-        if (pre) {
-          float pv2[8];
-          Elem<DT>::load8(pre + r * C + cg * 8, pv2);
+  // one row: the same operations in the same order whichever way the loop below groups the loads
+  auto accumulate = [&](const float* v, float* g, const float* pv2) {
+    if constexpr (BWD) {
+      if (pre) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) g[e] *= act_grad(pv2[e], act);
-        }
+        for (int e = 0; e < 8; ++e) g[e] *= act_grad(pv2[e], act);
+      } else if (rc) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          a[e] += g[e];
-          b[e] = fmaf(g[e], (v[e] - mu[e]) * rs[e], b[e]);
-        }
-      } else {
+        for (int e = 0; e < 8; ++e) g[e] *= act_grad(bn_stored<DT>(bn_affine(v[e], mu[e], rs[e], gm[e], bt[e])), act);
+      }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float d = v[e] - pv[e];
-          a[e] += d;
-          b[e] = fmaf(d, d, b[e]);
-        }
+      for (int e = 0; e < 8; ++e) {
+        a[e] += g[e];
+        b[e] = fmaf(g[e], (v[e] - mu[e]) * rs[e], b[e]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[e] - pv[e];
+        a[e] += d;
+        b[e] = fmaf(d, d, b[e]);
       }
     }
+  };
+  if (rl < RL) {
+    // round 6: U rows' loads in flight per thread (issued before the first is used) -- with wide channel counts a workgroup has few row
+    // lanes and each walked its rows one dependent load at a time (C = 512, 127 k rows: 1.5 TB/s); rows still accumulate in ascending order
+    int64_t r = r0 + rl;
+    constexpr int U = BWD ? 2 : 4;   // rows in flight: the backward loads two or three tensors per row
+    for (; r + (U - 1) * RL < r1; r += U * RL) {
+      typename Elem<DT>::raw8 qv[U], qg[U], qp[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        qv[u] = Elem<DT>::loadraw(x + (r + u * RL) * C + cg * 8);
+        if constexpr (BWD) {
+          qg[u] = Elem<DT>::loadraw(dy + (r + u * RL) * C + cg * 8);
+          if (pre) qp[u] = Elem<DT>::loadraw(pre + (r + u * RL) * C + cg * 8);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float v[8], g[8], pv2[8];
+        Elem<DT>::unpack(qv[u], v);
+        if constexpr (BWD) {
+          Elem<DT>::unpack(qg[u], g);
+          if (pre) Elem<DT>::unpack(qp[u], pv2);
+        }
+        accumulate(v, g, pv2);
+      }
+    }
+    for (; r < r1; r += RL) {
+      float v[8], g[8], pv2[8];
+      Elem<DT>::load8(x + r * C + cg * 8, v);
+      if constexpr (BWD) {
+        Elem<DT>::load8(dy + r * C + cg * 8, g);
+        if (pre) Elem<DT>::load8(pre + r * C + cg * 8, pv2);
+      }
+      accumulate(v, g, pv2);
+    }
+  }
   if (rl < RL) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -609,7 +671,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
 }
 
 // FWD: y = (x - mean) rstd gamma + beta.   BWD: dx = gamma rstd (dy - dbeta / n - xhat dgamma / n)
-template <int DT, bool BWD>
+template <int DT, bool BWD, bool HOIST>
 __global__ __launch_bounds__(256) void bn_map_kernel(const typename Elem<DT>::type* __restrict__ x,
                                                      const typename Elem<DT>::type* __restrict__ dy,
                                                      typename Elem<DT>::type* __restrict__ out, int64_t rows, int C,
@@ -619,13 +681,40 @@ __global__ __launch_bounds__(256) void bn_map_kernel(const typename Elem<DT>::ty
                                                      const typename Elem<DT>::type* __restrict__ pre = nullptr,
                                                      typename Elem<DT>::type* __restrict__ out_act = nullptr, int act = 0) {
   // round 5, the ConvLayer's activation in the same pass.  FWD with `out_act`: also writes act(y) (of the value as stored: rounded to bf16
-  // first in bf16 mode, so the result equals the separate pass's).  BWD with `pre`: dy is the gradient of act(pre), g = dy act'(pre).
+  // first in bf16 mode, so the result equals the separate pass's); `out` may then be NULL (round 6: the backward recomputes y, see
+  // bn_reduce_kernel).  BWD with `pre`: dy is the gradient of act(pre), g = dy act'(pre); BWD with act, no `pre` and `beta`: pre recomputed.
+  // HOIST (round 6): with 256 % (C / 8) == 0 a thread's channel group is the same in every iteration of the grid-stride loop, so its 8
+  // channels' constants live in registers -- the general form re-reads 24 - 40 of them per 16 bytes of tensor.
   const int CG = C >> 3;
   const int64_t total = rows * CG;   // invn = 1 / (rows of the whole batch): `rows` of this rank, or of all ranks under SyncBatchNorm
   const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
   int cg = (int)(i0 % CG);
   const int dcg = (int)(stride % CG);  // the channel group advances by a fixed amount per iteration: no 64-bit modulo in the loop
+  const bool rc = BWD && !pre && act != 0 && beta;
+  float pm[8], pr[8], pg[8], pb[8], pdg[8], pdb[8];
+  // a channel group's constants as 16-byte loads (written element by element they became 48 single-dword loads, each touching 16 cache lines
+  // of the wave: 3 ms of a B1 step, profiles/r06/bn_map_hoist_trace.txt)
+  auto ld8 = [](const float* p, float* v) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  };
+  auto load_params = [&](int g8) {
+    ld8(mean + g8 * 8, pm);
+    ld8(rstd + g8 * 8, pr);
+    ld8(gamma + g8 * 8, pg);
+    if (!BWD || rc) ld8(beta + g8 * 8, pb);
+    if constexpr (BWD) {
+      ld8(dgamma + g8 * 8, pdg);
+      ld8(dbeta + g8 * 8, pdb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pdb[e] *= invn;
+    }
+  };
+#pragma unroll
+  for (int e = 0; e < 8; ++e) pb[e] = 0.f;
+  if constexpr (HOIST) load_params(cg);
   for (int64_t i = i0; i < total; i += stride, cg = cg + dcg >= CG ? cg + dcg - CG : cg + dcg) {
+    if constexpr (!HOIST) load_params(cg);
     float v[8], o[8];
     Elem<DT>::load8(x + i * 8, v);
     if constexpr (BWD) {
@@ -636,32 +725,41 @@ __global__ __launch_bounds__(256) void bn_map_kernel(const typename Elem<DT>::ty
         Elem<DT>::load8(pre + i * 8, pv2);
 #pragma unroll
         for (int e = 0; e < 8; ++e) g[e] *= act_grad(pv2[e], act);
+      } else if (rc) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] *= act_grad(bn_stored<DT>(bn_affine(v[e], pm[e], pr[e], pg[e], pb[e])), act);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int c = cg * 8 + e;
-        const float xh = (v[e] - mean[c]) * rstd[c];
-        o[e] = gamma[c] * rstd[c] * (g[e] - dbeta[c] * invn - xh * dgamma[c] * invn);
+        const float xh = (v[e] - pm[e]) * pr[e];
+        o[e] = pg[e] * pr[e] * (g[e] - pdb[e] - xh * pdg[e] * invn);
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int c = cg * 8 + e;
-        o[e] = (v[e] - mean[c]) * rstd[c] * gamma[c] + beta[c];
-      }
+      for (int e = 0; e < 8; ++e) o[e] = bn_affine(v[e], pm[e], pr[e], pg[e], pb[e]);
       if (out_act) {
         float oa[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float stored = o[e];
-          if constexpr (DT == 1) stored = __uint_as_float(pack_bf16x2(o[e], 0.f) << 16);   // what `out` will hold
-          oa[e] = act_fwd(stored, act);
-        }
+        for (int e = 0; e < 8; ++e) oa[e] = act_fwd(bn_stored<DT>(o[e]), act);   // of what `out` holds (or would hold)
         Store8<DT>::st(out_act + i * 8, oa);
       }
     }
-    Store8<DT>::st(out + i * 8, o);
+    if (BWD || out) Store8<DT>::st(out + i * 8, o);
   }
+}
+
+// launches the map with the hoisted form when the channel count allows it
+template <int DT, bool BWD>
+void bn_map_launch(unsigned grid, hipStream_t s, const void* x, const void* dy, void* out, int64_t rows, int C, const float* gamma, const float* beta,
+                   const float* mean, const float* rstd, const float* dgamma, const float* dbeta, float invn, const void* pre = nullptr,
+                   void* out_act = nullptr, int act = 0) {
+  typedef typename Elem<DT>::type T;
+  if (256 % (C >> 3) == 0)   // a thread pays its constants once: fewer, longer threads (16 workgroups per CU)
+    hipLaunchKernelGGL((bn_map_kernel<DT, BWD, true>), dim3(grid < 4096 ? grid : 4096), dim3(256), 0, s, (const T*)x, (const T*)dy, (T*)out, rows, C, gamma, beta, mean, rstd,
+                       dgamma, dbeta, invn, (const T*)pre, (T*)out_act, act);
+  else
+    hipLaunchKernelGGL((bn_map_kernel<DT, BWD, false>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)dy, (T*)out, rows, C, gamma, beta, mean, rstd,
+                       dgamma, dbeta, invn, (const T*)pre, (T*)out_act, act);
 }
 
 template <int DT>
@@ -677,26 +775,26 @@ int bn_forward_t(const void* x, void* y, int64_t rows, int C, const float* gamma
                      save_mean, save_rstd, rm, rv);
   const int64_t total = rows * (C / 8);
   const unsigned grid = (unsigned)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
-  hipLaunchKernelGGL((bn_map_kernel<DT, false>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)nullptr, (T*)y, rows, C, gamma, beta,
-                     save_mean, save_rstd, (const float*)nullptr, (const float*)nullptr, 0.f, (const T*)nullptr, (T*)y_act, act);
+  bn_map_launch<DT, false>(grid, s, x, nullptr, y, rows, C, gamma, beta, save_mean, save_rstd, nullptr, nullptr, 0.f, nullptr, y_act, act);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
 
 template <int DT>
 int bn_backward_t(const void* x, const void* dy, void* dx, int64_t rows, int C, const float* gamma, const float* save_mean,
-                  const float* save_rstd, float* dgamma, float* dbeta, float* partial, hipStream_t s, const void* pre = nullptr, int act = 0) {
+                  const float* save_rstd, float* dgamma, float* dbeta, float* partial, hipStream_t s, const void* pre = nullptr, int act = 0,
+                  const float* beta = nullptr) {
+  // act with `pre` NULL and `beta` given: the BatchNorm's output is recomputed from x in both passes (bn_reduce_kernel)
   typedef typename Elem<DT>::type T;
   const int RL = 256 / (C / 8);
   const int splits = (int)(rows < BN_SPLITS ? rows : BN_SPLITS);
   hipLaunchKernelGGL((bn_reduce_kernel<DT, true>), dim3((unsigned)splits), dim3(256), sizeof(float) * 2 * (size_t)RL * C, s, (const T*)x,
-                     (const T*)dy, rows, C, save_mean, save_rstd, partial, (const T*)pre, act);
+                     (const T*)dy, rows, C, save_mean, save_rstd, partial, (const T*)pre, act, gamma, beta);
   hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, s, partial, splits, C, rows, 0.0, 0.0, dgamma,
                      dbeta, (float*)nullptr, (float*)nullptr);
   const int64_t total = rows * (C / 8);
   const unsigned grid = (unsigned)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
-  hipLaunchKernelGGL((bn_map_kernel<DT, true>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)dy, (T*)dx, rows, C, gamma,
-                     (const float*)nullptr, save_mean, save_rstd, dgamma, dbeta, 1.f / (float)rows, (const T*)pre, (T*)nullptr, act);
+  bn_map_launch<DT, true>(grid, s, x, dy, dx, rows, C, gamma, beta, save_mean, save_rstd, dgamma, dbeta, 1.f / (float)rows, pre, nullptr, act);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -719,11 +817,9 @@ int bn_stats_t(const void* x, int64_t rows, int C, double eps, float* mean, floa
 template <int DT>
 int bn_apply_t(const void* x, void* y, int64_t rows, int C, const float* gamma, const float* beta, const float* mean, const float* rstd,
                hipStream_t s) {
-  typedef typename Elem<DT>::type T;
   const int64_t total = rows * (C / 8);
   const unsigned grid = (unsigned)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
-  hipLaunchKernelGGL((bn_map_kernel<DT, false>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)nullptr, (T*)y, rows, C, gamma, beta, mean, rstd,
-                     (const float*)nullptr, (const float*)nullptr, 0.f);
+  bn_map_launch<DT, false>(grid, s, x, nullptr, y, rows, C, gamma, beta, mean, rstd, nullptr, nullptr, 0.f);
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -743,11 +839,9 @@ int bn_backward_sums_t(const void* x, const void* dy, int64_t rows, int C, const
 template <int DT>
 int bn_backward_apply_t(const void* x, const void* dy, void* dx, int64_t rows, int C, const float* gamma, const float* mean, const float* rstd,
                         const float* sum_dy_xhat, const float* sum_dy, double total_rows, hipStream_t s) {
-  typedef typename Elem<DT>::type T;
   const int64_t total = rows * (C / 8);
   const unsigned grid = (unsigned)(total / 256 + 1 < 16384 ? total / 256 + 1 : 16384);
-  hipLaunchKernelGGL((bn_map_kernel<DT, true>), dim3(grid), dim3(256), 0, s, (const T*)x, (const T*)dy, (T*)dx, rows, C, gamma, (const float*)nullptr, mean,
-                     rstd, sum_dy_xhat, sum_dy, (float)(1.0 / total_rows));
+  bn_map_launch<DT, true>(grid, s, x, dy, dx, rows, C, gamma, nullptr, mean, rstd, sum_dy_xhat, sum_dy, (float)(1.0 / total_rows));
   HIP_CHECK_RET(hipGetLastError());
   return 0;
 }
@@ -848,7 +942,7 @@ int esam3_bn_act_train_forward(int dtype, const void* x, void* y, void* y_act, i
                                float* running_mean, float* running_var, double momentum, double eps, float* save_mean, float* save_rstd,
                                void* workspace, void* stream) {
   if (!bn_args_ok("esam3_bn_act_train_forward", dtype, rows, C)) return -1;
-  if (!x || !y || !y_act || !gamma || !beta || !save_mean || !save_rstd || !workspace || !(eps >= 0.0) || act < ACT_RELU || act > ACT_SIGMOID) {
+  if (!x || !y_act || !gamma || !beta || !save_mean || !save_rstd || !workspace || !(eps >= 0.0) || act < ACT_RELU || act > ACT_SIGMOID) {   // y may be NULL
     esam3_set_error("esam3_bn_act_train_forward: bad argument (act relu | gelu | hswish | sigmoid)");
     return -1;
   }
@@ -868,6 +962,20 @@ int esam3_bn_act_train_backward(int dtype, const void* x, const void* dy, const 
   }
   return dtype == 0 ? bn_backward_t<0>(x, dy, dx, rows, C, gamma, save_mean, save_rstd, dgamma, dbeta, (float*)workspace, (hipStream_t)stream, pre, act)
                     : bn_backward_t<1>(x, dy, dx, rows, C, gamma, save_mean, save_rstd, dgamma, dbeta, (float*)workspace, (hipStream_t)stream, pre, act);
+}
+
+// the same backward WITHOUT the BatchNorm's saved output: pre = y is recomputed from x, save_mean / save_rstd, gamma and beta exactly as the
+// forward formed and stored it (the forward may then be called with y = NULL) -- two tensor reads less, and one tensor less kept per layer
+int esam3_bn_act_train_backward_rc(int dtype, const void* x, const void* dy, int act, void* dx, int64_t rows, int C, const float* gamma,
+                                   const float* beta, const float* save_mean, const float* save_rstd, float* dgamma, float* dbeta,
+                                   void* workspace, void* stream) {
+  if (!bn_args_ok("esam3_bn_act_train_backward_rc", dtype, rows, C)) return -1;
+  if (!x || !dy || !dx || !gamma || !beta || !save_mean || !save_rstd || !dgamma || !dbeta || !workspace || act < ACT_RELU || act > ACT_SIGMOID) {
+    esam3_set_error("esam3_bn_act_train_backward_rc: bad argument (act relu | gelu | hswish | sigmoid)");
+    return -1;
+  }
+  return dtype == 0 ? bn_backward_t<0>(x, dy, dx, rows, C, gamma, save_mean, save_rstd, dgamma, dbeta, (float*)workspace, (hipStream_t)stream, nullptr, act, beta)
+                    : bn_backward_t<1>(x, dy, dx, rows, C, gamma, save_mean, save_rstd, dgamma, dbeta, (float*)workspace, (hipStream_t)stream, nullptr, act, beta);
 }
 
 int esam3_bn_train_stats(int dtype, const void* x, int64_t rows, int C, double eps, float* mean, float* rstd, float* var, void* workspace,

@@ -469,16 +469,17 @@ _ACT_CODE = {"relu": 1, "gelu": 2, "hswish": 3, "sigmoid": 4}
 
 
 def bn_act_train_forward(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: torch.Tensor, running_var: torch.Tensor,
-                         momentum: float, eps: float, act: str):
-    """``bn_train_forward`` and the ConvLayer's activation in the same passes -> (y, act(y), save_mean, save_rstd) (``esam3_bn_act_train_forward``)"""
+                         momentum: float, eps: float, act: str, keep_pre: bool = True):
+    """``bn_train_forward`` and the ConvLayer's activation in the same passes -> (y, act(y), save_mean, save_rstd) (``esam3_bn_act_train_forward``);
+    ``keep_pre`` False: y is neither written nor returned (None) -- for ``bn_act_train_backward`` with ``pre=None``, which recomputes it"""
     rows, c = _bn_rows(x)
     lib = _lib.load()
-    y, y_act = torch.empty_like(x), torch.empty_like(x)
+    y, y_act = (torch.empty_like(x) if keep_pre else None), torch.empty_like(x)
     mean = torch.empty(c, dtype=torch.float32, device=x.device)
     rstd = torch.empty(c, dtype=torch.float32, device=x.device)
     ws = torch.empty(int(lib.esam3_bn_train_workspace(c)), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(lib.esam3_bn_act_train_forward(_DT[x.dtype], x.data_ptr(), y.data_ptr(), y_act.data_ptr(), _ACT_CODE[act], rows, c, gamma.data_ptr(),
+        _lib.check(lib.esam3_bn_act_train_forward(_DT[x.dtype], x.data_ptr(), None if y is None else y.data_ptr(), y_act.data_ptr(), _ACT_CODE[act], rows, c, gamma.data_ptr(),
                                                   beta.data_ptr(), None if running_mean is None else running_mean.data_ptr(),
                                                   None if running_var is None else running_var.data_ptr(), float(momentum), float(eps),
                                                   mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), torch.cuda.current_stream().cuda_stream),
@@ -487,17 +488,24 @@ def bn_act_train_forward(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tenso
 
 
 def bn_act_train_backward(x: torch.Tensor, dy: torch.Tensor, pre: torch.Tensor, act: str, gamma: torch.Tensor, save_mean: torch.Tensor,
-                          save_rstd: torch.Tensor):
+                          save_rstd: torch.Tensor, beta: torch.Tensor = None):
     """backward of act(batch_norm(x)): dy = the gradient of the activation's OUTPUT, pre = the BatchNorm's output -> (dx, dgamma, dbeta)
-    (``esam3_bn_act_train_backward``: dy act'(pre) is formed inside the two BatchNorm passes)"""
+    (``esam3_bn_act_train_backward``: dy act'(pre) is formed inside the two BatchNorm passes).  ``pre`` None with ``beta``: the BatchNorm's
+    output is recomputed from x as the forward stored it (``esam3_bn_act_train_backward_rc``)"""
     rows, c = _bn_rows(x)
-    assert dy.shape == x.shape and dy.dtype == x.dtype and dy.is_contiguous() and pre.shape == x.shape and pre.dtype == x.dtype and pre.is_contiguous()
+    assert dy.shape == x.shape and dy.dtype == x.dtype and dy.is_contiguous()
+    assert (pre is None and beta is not None) or (pre.shape == x.shape and pre.dtype == x.dtype and pre.is_contiguous())
     lib = _lib.load()
     dx = torch.empty_like(x)
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
     ws = torch.empty(int(lib.esam3_bn_train_workspace(c)), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
+        if pre is None:
+            _lib.check(lib.esam3_bn_act_train_backward_rc(_DT[x.dtype], x.data_ptr(), dy.data_ptr(), _ACT_CODE[act], dx.data_ptr(), rows, c, gamma.data_ptr(),
+                                                          beta.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                                          ws.data_ptr(), torch.cuda.current_stream().cuda_stream), "esam3_bn_act_train_backward_rc")
+            return dx, dgamma, dbeta
         _lib.check(lib.esam3_bn_act_train_backward(_DT[x.dtype], x.data_ptr(), dy.data_ptr(), pre.data_ptr(), _ACT_CODE[act], dx.data_ptr(), rows, c,
                                                    gamma.data_ptr(), save_mean.data_ptr(), save_rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                                    ws.data_ptr(), torch.cuda.current_stream().cuda_stream), "esam3_bn_act_train_backward")

@@ -93,17 +93,18 @@ FUSE_BN_ACT = True
 
 
 def bn_act_forward(x: torch.Tensor, gamma, beta, running_mean, running_var, momentum: float, eps: float, act, sync=GLOBAL):
-    """BatchNorm2d (training mode) then ``act`` -> (pre = the BatchNorm's output, act(pre), mean, rstd)"""
+    """BatchNorm2d (training mode) then ``act`` -> (pre = the BatchNorm's output, act(pre), mean, rstd); pre is None in the fused form: its
+    backward recomputes it from x (one tensor write here, two tensor reads there, and one kept tensor per layer less)"""
     if act is not None and FUSE_BN_ACT and _sync(sync) is None:
-        return _s1.bn_act_train_forward(x, gamma, beta, running_mean, running_var, momentum, eps, act)
+        return _s1.bn_act_train_forward(x, gamma, beta, running_mean, running_var, momentum, eps, act, keep_pre=False)
     pre, mean, rstd = bn_train_forward(x, gamma, beta, running_mean, running_var, momentum, eps, sync=sync)
     return pre, (act_forward(pre, act) if act else pre), mean, rstd
 
 
-def bn_act_backward(x: torch.Tensor, dy: torch.Tensor, pre: torch.Tensor, act, gamma, mean, rstd, sync=GLOBAL):
-    """its backward: dy = the gradient of act(pre) -> (dx, dgamma, dbeta)"""
+def bn_act_backward(x: torch.Tensor, dy: torch.Tensor, pre: torch.Tensor, act, gamma, mean, rstd, sync=GLOBAL, beta=None):
+    """its backward: dy = the gradient of act(pre) -> (dx, dgamma, dbeta); ``pre`` None (the fused forward's): recomputed, needs ``beta``"""
     if act is not None and FUSE_BN_ACT and _sync(sync) is None:
-        return _s1.bn_act_train_backward(x, dy, pre, act, gamma, mean, rstd)
+        return _s1.bn_act_train_backward(x, dy, pre, act, gamma, mean, rstd, beta=beta)
     return bn_train_backward(x, act_backward(pre, dy, act) if act else dy, gamma, mean, rstd, sync=sync)
 
 
@@ -323,7 +324,7 @@ class ConvLayerTrain:
         """-> (dx, {"weight": dw, "gamma" / "beta" or "bias": ...})"""
         grads = {}
         if self.norm:
-            d_conv, grads["gamma"], grads["beta"] = bn_act_backward(self.conv_out, dy, self.pre, self.act, self.gamma, self.mean, self.rstd, sync=getattr(self, "sync", GLOBAL))
+            d_conv, grads["gamma"], grads["beta"] = bn_act_backward(self.conv_out, dy, self.pre, self.act, self.gamma, self.mean, self.rstd, sync=getattr(self, "sync", GLOBAL), beta=self.beta)
         else:
             d_conv = act_backward(self.pre, dy, self.act) if self.act else dy
         if self.bias is not None:
@@ -591,7 +592,7 @@ class StemConvTrain:
         return y
 
     def backward(self, dy: torch.Tensor):
-        d_conv, dgamma, dbeta = bn_act_backward(self.conv_out, dy, self.pre, self.act, self.gamma, self.mean, self.rstd, sync=getattr(self, "sync", GLOBAL))
+        d_conv, dgamma, dbeta = bn_act_backward(self.conv_out, dy, self.pre, self.act, self.gamma, self.mean, self.rstd, sync=getattr(self, "sync", GLOBAL), beta=self.beta)
         dw = linear_wgrad(d_conv, stem_im2col(self.img, self.dtype))[:, :27].reshape(self.w.shape)
         return None, {"weight": dw, "gamma": dgamma, "beta": dbeta}
 

@@ -394,7 +394,7 @@ int esam3_bn_train_backward(int dtype, const void* x_dev, const void* dy_dev, vo
                             const float* gamma_dev, const float* save_mean_dev, const float* save_rstd_dev, float* dgamma_dev,
                             float* dbeta_dev, void* workspace_dev, void* hip_stream);
 /* The ConvLayer's activation applied in the BatchNorm's own passes (Conv2d -> BatchNorm2d -> act, backbones/efficientvit/nn/ops.py:39-81 and the
- * Conv2d_BN + activation pairs of repvit.py / tiny_vit.py): forward writes y (kept for the backward) AND y_act = act(y); backward takes dy =
+ * Conv2d_BN + activation pairs of repvit.py / tiny_vit.py): forward writes y (kept for the backward; may be NULL) AND y_act = act(y); backward takes dy =
  * the gradient of act(y) and pre = y, and uses dy act'(pre) where esam3_bn_train_backward uses dy.  act 1 ReLU, 2 GELU, 3 Hardswish, 4 sigmoid. */
 int esam3_bn_act_train_forward(int dtype, const void* x_dev, void* y_dev, void* y_act_dev, int act, int64_t rows, int C, const float* gamma_dev,
                                const float* beta_dev, float* running_mean_dev, float* running_var_dev, double momentum, double eps,
@@ -402,6 +402,12 @@ int esam3_bn_act_train_forward(int dtype, const void* x_dev, void* y_dev, void* 
 int esam3_bn_act_train_backward(int dtype, const void* x_dev, const void* dy_dev, const void* pre_dev, int act, void* dx_dev, int64_t rows, int C,
                                 const float* gamma_dev, const float* save_mean_dev, const float* save_rstd_dev, float* dgamma_dev,
                                 float* dbeta_dev, void* workspace_dev, void* hip_stream);
+/* The same backward without the BatchNorm's saved output: pre = y is recomputed from x, the saved statistics, gamma and beta exactly as the forward
+ * formed and stored it (fp32 expression, rounded to the storage dtype), so esam3_bn_act_train_forward may be called with y_dev = NULL: two of the
+ * seven tensor passes of the backward and one of the four of the forward are gone, and a layer keeps one tensor less between the two. */
+int esam3_bn_act_train_backward_rc(int dtype, const void* x_dev, const void* dy_dev, int act, void* dx_dev, int64_t rows, int C,
+                                   const float* gamma_dev, const float* beta_dev, const float* save_mean_dev, const float* save_rstd_dev,
+                                   float* dgamma_dev, float* dbeta_dev, void* workspace_dev, void* hip_stream);
 /* The same two operations in halves, for SyncBatchNorm (stage1/train_image_encoder_stage1.py:62-63 `--use-sync-bn`:
  * torch.nn.SyncBatchNorm.convert_sync_batchnorm): between the statistics and the elementwise map the host combines the ranks' values with ONE
  * collective each way, as torch's SyncBatchNorm does (efficientsam3_amd/train_blocks.py: bn_train_forward / bn_train_backward).

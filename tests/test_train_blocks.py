@@ -362,16 +362,18 @@ def test_trunk_train_vs_autograd_f32(size, fwd, worst, median):
 
 @pytest.mark.parametrize("mode", ["f32", "bf16"])
 @pytest.mark.parametrize("act", ["hswish", "gelu", "relu"])
-def test_bn_act_fused_passes_equal_the_separate_ones(mode, act):
+@pytest.mark.parametrize("C", [48, 64])   # 64: a thread's channel group is fixed (constants in registers); 48: the general map
+def test_bn_act_fused_passes_equal_the_separate_ones(mode, act, C):
     """``esam3_bn_act_train_forward / _backward`` (the ConvLayer's activation inside the BatchNorm kernels' passes) against BatchNorm then
     activation as separate kernels: same y, same act(y) bit for bit; gradients equal up to the one rounding the separate form spends on
-    storing dy act'(pre) (none in fp32)"""
+    storing dy act'(pre) (none in fp32).  The recomputing backward (no saved BatchNorm output: ``esam3_bn_act_train_backward_rc``) equals the
+    one that reads it bit for bit, and the forward that does not write y gives the same act(y)."""
     from efficientsam3_amd import stage1, train_blocks as tb
     g = torch.Generator().manual_seed(9)
-    x = (torch.randn(3, 17, 19, 48, generator=g) * 2.0 + 1.0).to(TDT[mode]).cuda()
-    dy = torch.randn(3, 17, 19, 48, generator=g).to(TDT[mode]).cuda()
-    gamma, beta = (torch.rand(48, generator=g) + 0.5).cuda(), (torch.randn(48, generator=g) * 0.5).cuda()
-    rm1, rv1, rm2, rv2 = torch.zeros(48).cuda(), torch.ones(48).cuda(), torch.zeros(48).cuda(), torch.ones(48).cuda()
+    x = (torch.randn(3, 17, 19, C, generator=g) * 2.0 + 1.0).to(TDT[mode]).cuda()
+    dy = torch.randn(3, 17, 19, C, generator=g).to(TDT[mode]).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.5).cuda()
+    rm1, rv1, rm2, rv2 = torch.zeros(C).cuda(), torch.ones(C).cuda(), torch.zeros(C).cuda(), torch.ones(C).cuda()
     y1, m1, r1 = stage1.bn_train_forward(x, gamma, beta, rm1, rv1, 0.1, 1e-5)
     a1 = tb.act_forward(y1, act)
     y2, a2, m2, r2 = stage1.bn_act_train_forward(x, gamma, beta, rm2, rv2, 0.1, 1e-5, act)
@@ -382,3 +384,8 @@ def test_bn_act_fused_passes_equal_the_separate_ones(mode, act):
     for got, ref, what in ((dx2, dx1, "dx"), (dg2, dg1, "dgamma"), (db2, db1, "dbeta")):
         d, m = float((got.float() - ref.float()).abs().max()), float(ref.float().abs().max())
         assert d <= tol * m, (what, mode, act, d, m)
+    rm3, rv3 = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    y3, a3, m3, r3 = stage1.bn_act_train_forward(x, gamma, beta, rm3, rv3, 0.1, 1e-5, act, keep_pre=False)
+    assert y3 is None and torch.equal(a3, a2) and torch.equal(m3, m2) and torch.equal(r3, r2) and torch.equal(rm3, rm2) and torch.equal(rv3, rv2)
+    dx3, dg3, db3 = stage1.bn_act_train_backward(x, dy, None, act, gamma, m2, r2, beta=beta)
+    assert torch.equal(dx3, dx2) and torch.equal(dg3, dg2) and torch.equal(db3, db2)

@@ -204,6 +204,11 @@ busy = sum(e - s for s, e, _ in part); span = part[-1][1] - part[0][0]
 print("kernels", len(part), "busy ms", busy / 1e6, "span ms", span / 1e6, "busy frac", busy / span)
 gaps = sorted(((part[i + 1][0] - part[i][1], part[i][2][:60], part[i + 1][2][:60]) for i in range(len(part) - 1)), reverse=True)[:25]
 for g in gaps: print(g)
+rr = list(csv.DictReader(open(f)))
+sel = [r for r in rr if "bn_map_kernel<1, true" in r["Kernel_Name"]]
+sel = sel[-35:]
+print("bn_map BWD calls of the last step: (us, grid, kernel)")
+for r in sel: print(round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 1), r.get("Grid_Size_X", r.get("Grid_Size", "?")), r["Kernel_Name"][40:75])
 PY
   head -40 $O/ac_kernel_stats_stage1_step_b1_b32.csv | cut -c1-150
   ;;
