@@ -109,18 +109,24 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 struct WgradGather {
   int on, zs, OH, OW, IH, IW, stride;
 };
-template <int DT>
+// TW (round 6): the tile of dW a workgroup owns, 64 x 64 or (bf16) 128 x 128 -- a wave then owns a 64 x 64 quadrant as 2 x 2 MFMA blocks.  With
+// 64 x 64 tiles every 64 channels of dy and x loaded from L2 feed 32 multiply-adds per byte: the wide weights of the last stages and the head's
+// 3x3 conv (N, K >= 128, 32 k - 127 k rows) ran at 280 - 300 TFLOP/s on L2 bandwidth (profiles/r06/roofline_stage1_step_b1_b32_end.md: the 3x3
+// alone 2.2 ms of a 42 ms step); the larger tile halves the bytes per product and the LDS reads per MFMA.
+template <int DT, int TW = 64>
 __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::type* __restrict__ dy, int ldy,
                                                     const typename TElem<DT>::type* __restrict__ x, int ldx, int64_t M, int N, int K,
                                                     int64_t rows_per_split, float* __restrict__ partial /* [splits][N][K] */,
                                                     WgradGather gt = WgradGather{0, 0, 0, 0, 0, 0, 0}) {
   // rows per step: 64 in fp32 (two 16.6 KB tiles), 128 in bf16 (round 6: half the barriers per row; a split is any multiple of 64 rows, the
   // tail of a step past the split's end is staged as zeros)
+  static_assert(TW == 64 || (TW == 128 && DT == 1), "128 x 128 tiles in bf16 only");
   constexpr int ROWS = DT == 0 ? 64 : 128, VS = ROWS * 32 + 128;
-  // fp32: plain [row][64 ch] (+1 float pad); bf16: 4 sub-tiles per operand
-  __shared__ __attribute__((aligned(16))) char sA[DT == 0 ? ROWS * 65 * 4 : 4 * VS];
-  __shared__ __attribute__((aligned(16))) char sB[DT == 0 ? ROWS * 65 * 4 : 4 * VS];
-  const int n0 = blockIdx.y * WG_TILE, k0 = blockIdx.x * WG_TILE;
+  constexpr int QW = TW / 2, NBLK = QW / 32;   // a wave's quadrant and its 32 x 32 MFMA blocks per side
+  // fp32: plain [row][64 ch] (+1 float pad); bf16: TW / 16 sub-tiles per operand
+  __shared__ __attribute__((aligned(16))) char sA[DT == 0 ? ROWS * 65 * 4 : (TW / 16) * VS];
+  __shared__ __attribute__((aligned(16))) char sB[DT == 0 ? ROWS * 65 * 4 : (TW / 16) * VS];
+  const int n0 = blockIdx.y * TW, k0 = blockIdx.x * TW;
   const int zsplit = gt.on ? (int)blockIdx.z % gt.zs : (int)blockIdx.z, tap = gt.on ? (int)blockIdx.z / gt.zs : 0;
   const int64_t r_begin = (int64_t)zsplit * rows_per_split;
   const int64_t r_end = r_begin + rows_per_split < M ? r_begin + rows_per_split : M;
@@ -128,24 +134,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::ty
   // row of the x operand for output row r: the row itself, or (GATHER) the tap's input pixel (-1: outside the image)
   auto xrow = [&](int64_t r) -> int64_t {
     if (!gt.on) return r;
-    const int64_t hw = (int64_t)gt.OH * gt.OW;
-    const int64_t b = r / hw;
-    const int rem = (int)(r - b * hw);
+    // 32-bit arithmetic (the host checks M < 2^31): the 64-bit division this replaced is a few hundred instructions, eight times per thread
+    // and 128-row step
+    const unsigned hw = (unsigned)(gt.OH * gt.OW), r32 = (unsigned)r;
+    const unsigned b = r32 / hw;
+    const int rem = (int)(r32 - b * hw);
     const int oy = rem / gt.OW, ox = rem - oy * gt.OW;
     const int iy = oy * gt.stride + gky, ix = ox * gt.stride + gkx;
     if (iy < 0 || iy >= gt.IH || ix < 0 || ix >= gt.IW) return -1;
-    return (b * gt.IH + iy) * (int64_t)gt.IW + ix;
+    return ((int64_t)b * gt.IH + iy) * (int64_t)gt.IW + ix;
   };
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, g = lane >> 5;
-  const int wn = wave >> 1, wk = wave & 1;  // this wave's quadrant: dW rows n0 + 32 wn .., columns k0 + 32 wk ..
-  f32x16_t acc;
+  const int wn = wave >> 1, wk = wave & 1;  // this wave's quadrant: dW rows n0 + QW wn .., columns k0 + QW wk ..
+  f32x16_t accs[NBLK][NBLK];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int i = 0; i < NBLK; ++i)
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accs[i][j][r] = 0.f;
+  f32x16_t& acc = accs[0][0];
 
   // Round 6: the global loads of row step s + 1 are issued BEFORE the matrix products of step s (register double buffer).  The loop used to
   // be load -> LDS -> barrier -> 4 MFMAs per wave -> barrier: one exposed trip to memory per 64 rows (0.7 ms for the 8 M-row layers of the
   // stem, 6.5 ms of a 55 ms step over 52 calls, profiles/r06/roofline_stage1_step_b1_b32.md); now the trip hides behind the products.
-  constexpr int NCH = DT == 0 ? (ROWS * 16) / 256 : (ROWS * 8) / 256;   // chunks per thread and operand: 4 (fp32) / 4 (bf16)
+  constexpr int CPRW = TW / 8;                                          // bf16: 16-byte chunks per tile row
+  constexpr int NCH = DT == 0 ? (ROWS * 16) / 256 : (ROWS * CPRW) / 256;   // chunks per thread and operand: 4 (fp32) / 4 | 8 (bf16)
   typedef typename std::conditional<DT == 0, float4, uint4>::type chunk_t;
   chunk_t ra[NCH], rb[NCH];
   auto fetch = [&](int64_t r0) {
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::ty
         }
         ra[i] = av; rb[i] = bv;
       } else {
-        const int row = c >> 3, ch8 = c & 7;
+        const int row = c / CPRW, ch8 = c % CPRW;
         uint4 av = make_uint4(0u, 0u, 0u, 0u), bv = av;
         if (r0 + row < r_end) {
           if (n0 + ch8 * 8 < N) av = *reinterpret_cast<const uint4*>(dy + (r0 + row) * ldy + n0 + ch8 * 8);
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::ty
         pa[0] = ra[i].x; pa[1] = ra[i].y; pa[2] = ra[i].z; pa[3] = ra[i].w;
         pb[0] = rb[i].x; pb[1] = rb[i].y; pb[2] = rb[i].z; pb[3] = rb[i].w;
       } else {
-        const int row = c >> 3, ch8 = c & 7;
+        const int row = c / CPRW, ch8 = c % CPRW;
         const int off = (ch8 >> 1) * VS + row * 32 + (ch8 & 1) * 16;
         *reinterpret_cast<uint4*>(sA + off) = ra[i];
         *reinterpret_cast<uint4*>(sB + off) = rb[i];
@@ -206,28 +220,42 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::ty
     } else {
       typedef __attribute__((address_space(3))) ts16x4_v* lds_v4;
       const unsigned frag = (unsigned)((l31 >> 4) * VS + (4 * g + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8);
-      const auto pa = (__attribute__((address_space(3))) char*)sA + wn * 2 * VS + frag;
-      const auto pb = (__attribute__((address_space(3))) char*)sB + wk * 2 * VS + frag;
+      const auto pa = (__attribute__((address_space(3))) char*)sA + wn * (QW / 16) * VS + frag;
+      const auto pb = (__attribute__((address_space(3))) char*)sB + wk * (QW / 16) * VS + frag;
 #pragma unroll
       for (int s = 0; s < ROWS / 16; ++s) {
         const int off = s * 16 * 32;
-        const uint2 alo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa + off)));
-        const uint2 ahi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa + off + 8 * 32)));
-        const uint2 blo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pb + off)));
-        const uint2 bhi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pb + off + 8 * 32)));
-        const u32x4 af = {alo.x, alo.y, ahi.x, ahi.y}, bf = {blo.x, blo.y, bhi.x, bhi.y};
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_v, af), __builtin_bit_cast(bf16x8_v, bf), acc, 0, 0, 0);
+        bf16x8_v af[NBLK], bf[NBLK];
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i) {   // block i = 32 channels = two 16-channel sub-tiles further on
+          const uint2 alo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa + i * 2 * VS + off)));
+          const uint2 ahi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pa + i * 2 * VS + off + 8 * 32)));
+          const uint2 blo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pb + i * 2 * VS + off)));
+          const uint2 bhi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(pb + i * 2 * VS + off + 8 * 32)));
+          const u32x4 a4 = {alo.x, alo.y, ahi.x, ahi.y}, b4 = {blo.x, blo.y, bhi.x, bhi.y};
+          af[i] = __builtin_bit_cast(bf16x8_v, a4);
+          bf[i] = __builtin_bit_cast(bf16x8_v, b4);
+        }
+#pragma unroll
+        for (int i = 0; i < NBLK; ++i)
+#pragma unroll
+          for (int j = 0; j < NBLK; ++j) accs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], accs[i][j], 0, 0, 0);
       }
     }
   }
   // accumulator layout: column = l31 (the K index), rows (r & 3) + 8 (r >> 2) + 4 g (the N index)
   float* out = partial + (int64_t)blockIdx.z * N * K;
-  const int kc = k0 + wk * 32 + l31;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int nr = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-    if (nr < N && kc < K) out[(int64_t)nr * K + kc] = acc[r];
-  }
+  for (int i = 0; i < NBLK; ++i)
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) {
+      const int kc = k0 + wk * QW + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int nr = n0 + wn * QW + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (nr < N && kc < K) out[(int64_t)nr * K + kc] = accs[i][j][r];
+      }
+    }
 }
 
 // Sum of partial[z][i] over the splits in a FIXED order that is not one dependent chain: the splits are dealt to the four waves of the
@@ -1160,11 +1188,17 @@ int wgrad_splits(int64_t M) {  // every split a whole number of 64-row tiles
 // Splits of the weight gradient's row reduction: enough workgroups to fill the chip (about 2048 with the N x K tiles), not one per 64-row
 // tile -- with 128 - 256 splits of a 1024 x 256 weight the fp32 partial tiles were 128 x the size of dW, and wgrad_reduce_kernel alone 8 %
 // of a training step (profiles/r05/stage1_step_b2_kernel_stats_mla4.csv).  A function of (M, N, K) only: the summation order stays fixed.
-int wgrad_splits_nk(int64_t M, int N, int K) {
-  const int64_t tiles_nk = (int64_t)((N + WG_TILE - 1) / WG_TILE) * ((K + WG_TILE - 1) / WG_TILE);
+int wgrad_tile(int dtype, int N, int K) { return dtype == 1 && N >= 128 && K >= 128 ? 128 : WG_TILE; }   // see wgrad_kernel: TW
+int wgrad_splits_nk(int64_t M, int N, int K, int tile = WG_TILE) {
+  const int64_t tiles_nk = (int64_t)((N + tile - 1) / tile) * ((K + tile - 1) / tile);
   int64_t want = 2048 / tiles_nk;
   if (want < 1) want = 1;
-  const int64_t most = wgrad_splits(M);
+  // round 6: up to 1024 splits (was 256, one workgroup per CU) for a weight of ONE tile (the 8 M-row layers of the first stages): 256
+  // workgroups with two 16-byte loads in flight per thread ran at 1.5 - 2 TB/s, bound by latency; four workgroups per CU now (0.36 -> 0.21 ms)
+  const int64_t tiles = (M + WG_ROWS - 1) / WG_ROWS;
+  const int64_t cap = tiles_nk == 1 ? 1024 : TRAIN_SPLITS_MAX;   // with two or more tiles the extra partial tiles cost more than they hide
+  int64_t most = tiles < cap ? (tiles < 1 ? 1 : tiles) : cap;
+  if (tile == 128 && most > (M + 1023) / 1024) most = (M + 1023) / 1024;   // at least 8 row steps per workgroup: its partial tile is 64 KB
   return (int)(want < most ? want : most);
 }
 
@@ -1200,7 +1234,8 @@ int esam3_act_backward(int dtype, const void* x, const void* dy, void* dx, int64
 
 int64_t esam3_linear_wgrad_workspace(int64_t M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return (int64_t)sizeof(float) * wgrad_splits_nk(M, N, K) * ((int64_t)N * K + N);
+  const int s64 = wgrad_splits_nk(M, N, K), s128 = wgrad_splits_nk(M, N, K, 128);   // either tile size (the dtype is not known here)
+  return (int64_t)sizeof(float) * (s64 > s128 ? s64 : s128) * ((int64_t)N * K + N);
 }
 
 int esam3_linear_wgrad(int dtype, const void* dy, const void* x, int64_t M, int N, int K, float* dw, float* dbias, void* workspace,
@@ -1210,14 +1245,16 @@ int esam3_linear_wgrad(int dtype, const void* dy, const void* x, int64_t M, int 
     return -1;
   }
   hipStream_t s = (hipStream_t)stream;
-  const int splits = wgrad_splits_nk(M, N, K);
+  const int tile = wgrad_tile(dtype, N, K);
+  const int splits = wgrad_splits_nk(M, N, K, tile);
   const int64_t tiles = (M + WG_ROWS - 1) / WG_ROWS;
   const int64_t rps = (tiles + splits - 1) / splits * WG_ROWS;
   const int zs = (int)((M + rps - 1) / rps);  // splits actually used
   float* partial = (float*)workspace;
-  const dim3 grid((unsigned)((K + WG_TILE - 1) / WG_TILE), (unsigned)((N + WG_TILE - 1) / WG_TILE), (unsigned)zs);
-  if (dtype == 0) hipLaunchKernelGGL(wgrad_kernel<0>, grid, dim3(256), 0, s, (const float*)dy, N, (const float*)x, K, M, N, K, rps, partial);
-  else hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, s, (const uint16_t*)dy, N, (const uint16_t*)x, K, M, N, K, rps, partial);
+  const dim3 grid((unsigned)((K + tile - 1) / tile), (unsigned)((N + tile - 1) / tile), (unsigned)zs);
+  if (dtype == 0) hipLaunchKernelGGL((wgrad_kernel<0, 64>), grid, dim3(256), 0, s, (const float*)dy, N, (const float*)x, K, M, N, K, rps, partial, WgradGather{0, 0, 0, 0, 0, 0, 0});
+  else if (tile == 128) hipLaunchKernelGGL((wgrad_kernel<1, 128>), grid, dim3(256), 0, s, (const uint16_t*)dy, N, (const uint16_t*)x, K, M, N, K, rps, partial, WgradGather{0, 0, 0, 0, 0, 0, 0});
+  else hipLaunchKernelGGL((wgrad_kernel<1, 64>), grid, dim3(256), 0, s, (const uint16_t*)dy, N, (const uint16_t*)x, K, M, N, K, rps, partial, WgradGather{0, 0, 0, 0, 0, 0, 0});
   const int64_t nk = (int64_t)N * K;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk + 63) / 64)), dim3(256), 0, s, partial, zs, nk, dw);
   if (dbias) {
@@ -1231,18 +1268,20 @@ int esam3_linear_wgrad(int dtype, const void* dy, const void* x, int64_t M, int 
   return 0;
 }
 
-static int conv3x3_wgrad_splits(int64_t M, int N, int K) {
-  const int64_t tiles_nk = 9 * (int64_t)((N + WG_TILE - 1) / WG_TILE) * ((K + WG_TILE - 1) / WG_TILE);
+static int conv3x3_wgrad_splits(int64_t M, int N, int K, int tile = WG_TILE) {
+  const int64_t tiles_nk = 9 * (int64_t)((N + tile - 1) / tile) * ((K + tile - 1) / tile);
   int64_t want = 2048 / tiles_nk;
   if (want < 1) want = 1;
-  const int64_t most = wgrad_splits(M);
+  int64_t most = wgrad_splits(M);
+  if (tile == 128 && most > (M + 1023) / 1024) most = (M + 1023) / 1024;
   return (int)(want < most ? want : most);
 }
 
 int64_t esam3_conv3x3_wgrad_workspace(int B, int IH, int IW, int Cin, int Cout, int stride) {
   if (B <= 0 || IH <= 0 || IW <= 0 || Cin <= 0 || Cout <= 0 || (stride != 1 && stride != 2)) return 0;
   const int64_t M = (int64_t)B * ((IH + stride - 1) / stride) * ((IW + stride - 1) / stride);
-  return (int64_t)sizeof(float) * 9 * conv3x3_wgrad_splits(M, Cout, Cin) * (int64_t)Cout * Cin;
+  const int s64 = conv3x3_wgrad_splits(M, Cout, Cin), s128 = conv3x3_wgrad_splits(M, Cout, Cin, 128);
+  return (int64_t)sizeof(float) * 9 * (s64 > s128 ? s64 : s128) * (int64_t)Cout * Cin;
 }
 
 // dw [Cout][Cin][3][3] fp32 of a dense 3x3 conv (padding 1, stride 1 | 2): x [B][IH][IW][Cin], dy [B][ceil(IH/s)][ceil(IW/s)][Cout]
@@ -1257,19 +1296,21 @@ int esam3_conv3x3_wgrad(int dtype, const void* dy, const void* x, int B, int IH,
   const int OH = (IH + stride - 1) / stride, OW = (IW + stride - 1) / stride;
   const int64_t M = (int64_t)B * OH * OW;
   const int N = Cout, K = Cin;
-  const int splits = conv3x3_wgrad_splits(M, N, K);
+  const int tile = wgrad_tile(dtype, N, K);
+  const int splits = conv3x3_wgrad_splits(M, N, K, tile);
   const int64_t tiles = (M + WG_ROWS - 1) / WG_ROWS;
   const int64_t rps = (tiles + splits - 1) / splits * WG_ROWS;
   const int zs = (int)((M + rps - 1) / rps);
-  if (9 * zs > 65535) {
-    esam3_set_error("esam3_conv3x3_wgrad: %d splits", zs);
+  if (9 * zs > 65535 || M >= ((int64_t)1 << 31)) {
+    esam3_set_error("esam3_conv3x3_wgrad: %d splits, %lld output pixels", zs, (long long)M);
     return -1;
   }
   float* partial = (float*)workspace;
   const WgradGather gt{1, zs, OH, OW, IH, IW, stride};
-  const dim3 grid((unsigned)((K + WG_TILE - 1) / WG_TILE), (unsigned)((N + WG_TILE - 1) / WG_TILE), (unsigned)(9 * zs));
-  if (dtype == 0) hipLaunchKernelGGL(wgrad_kernel<0>, grid, dim3(256), 0, s, (const float*)dy, N, (const float*)x, K, M, N, K, rps, partial, gt);
-  else hipLaunchKernelGGL(wgrad_kernel<1>, grid, dim3(256), 0, s, (const uint16_t*)dy, N, (const uint16_t*)x, K, M, N, K, rps, partial, gt);
+  const dim3 grid((unsigned)((K + tile - 1) / tile), (unsigned)((N + tile - 1) / tile), (unsigned)(9 * zs));
+  if (dtype == 0) hipLaunchKernelGGL((wgrad_kernel<0, 64>), grid, dim3(256), 0, s, (const float*)dy, N, (const float*)x, K, M, N, K, rps, partial, gt);
+  else if (tile == 128) hipLaunchKernelGGL((wgrad_kernel<1, 128>), grid, dim3(256), 0, s, (const uint16_t*)dy, N, (const uint16_t*)x, K, M, N, K, rps, partial, gt);
+  else hipLaunchKernelGGL((wgrad_kernel<1, 64>), grid, dim3(256), 0, s, (const uint16_t*)dy, N, (const uint16_t*)x, K, M, N, K, rps, partial, gt);
   const int64_t nk = (int64_t)N * K;
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((nk + 255) / 256), 9), dim3(256), 0, s, partial, zs, nk, dw);
   HIP_CHECK_RET(hipGetLastError());
