@@ -539,6 +539,91 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const typename TElem<DT>:
   }
 }
 
+// Round 6, stride 1 (the 5x5 aggregation convs of LiteMLA): the kernel above with a SLIDING window along the row.  A thread owns a contiguous
+// run of its row's pixels instead of every RL-th one, keeps the last KS - 1 input columns in registers and loads U new columns + U dy values
+// per step: 2 U loads in flight carrying U pixels, where the strided walk had KS + 1 loads in flight carrying one (0.6 - 0.7 TB/s on
+// [32][63][63][384] and [32][32][32][768], latency-bound at a handful of waves per SIMD: profiles/r06/roofline_stage1_step_b1_b32_end2.md).
+// Same grid (row splits x kernel rows), same partial layout and lane reduction; the order inside a split is rows, then the lane's pixels.
+template <int DT, int KS>
+__global__ __launch_bounds__(256) void dw_wgrad_slide_kernel(const typename TElem<DT>::type* __restrict__ x,
+                                                             const typename TElem<DT>::type* __restrict__ dy, int B, int H, int W, int C,
+                                                             float* __restrict__ partial) {
+  extern __shared__ float red[];  // [RL][KS][C]
+  constexpr int PAD = KS / 2, U = 4, NW = KS - 1 + U;
+  typedef typename TElem<DT>::vec8 raw_t;
+  const int CG = C >> 3, RL = 256 / CG;
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+  const int kh = blockIdx.y;
+  const int seg = (W + RL - 1) / RL, s0 = rl * seg, s1 = s0 + seg < W ? s0 + seg : W;   // this lane's pixels of every row
+  const int64_t nrows = (int64_t)B * H;
+  const int64_t per = (nrows + gridDim.x - 1) / gridDim.x;
+  const int64_t q0 = (int64_t)blockIdx.x * per, q1 = q0 + per < nrows ? q0 + per : nrows;
+  float acc[KS][8];
+#pragma unroll
+  for (int t = 0; t < KS; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+  if (rl < RL && s0 < s1) {
+    int b = (int)(q0 / H), oy = (int)(q0 - (int64_t)b * H);
+    for (int64_t q = q0; q < q1; ++q, oy = oy + 1 == H ? 0 : oy + 1, b += oy == 0) {
+      const int iy = oy + kh - PAD;
+      if (iy < 0 || iy >= H) continue;
+      const typename TElem<DT>::type* dyr = dy + q * W * (int64_t)C + cg * 8;
+      const typename TElem<DT>::type* xr = x + ((int64_t)b * H + iy) * (int64_t)W * C + cg * 8;
+      raw_t win[NW];   // columns s - PAD .. of the current step; 0 .. KS - 2 carried from the step before
+      float cvw[NW];   // 1 inside the image, 0 for a clamped column
+#pragma unroll
+      for (int j = 0; j < KS - 1; ++j) {
+        const int ix = s0 - PAD + j;
+        cvw[j] = (ix >= 0 && ix < W) ? 1.f : 0.f;
+        win[j] = TElem<DT>::loadraw(xr + (int64_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C);
+      }
+      for (int ox = s0; ox < s1; ox += U) {
+        raw_t graw[U];
+        float gm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ix = ox + u + PAD;
+          cvw[KS - 1 + u] = (ix >= 0 && ix < W) ? 1.f : 0.f;
+          win[KS - 1 + u] = TElem<DT>::loadraw(xr + (int64_t)(ix >= W ? W - 1 : ix) * C);
+          gm[u] = ox + u < s1 ? 1.f : 0.f;
+          graw[u] = TElem<DT>::loadraw(dyr + (int64_t)(ox + u < s1 ? ox + u : s1 - 1) * C);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          __builtin_amdgcn_sched_barrier(0);   // one pixel's unpacking at a time: hoisted, all U x KS unpacked columns cost 240 VGPRs
+          float g[8];
+          TElem<DT>::unpack(graw[u], g);
+#pragma unroll
+          for (int kw = 0; kw < KS; ++kw) {
+            float v[8];
+            TElem<DT>::unpack(win[u + kw], v);
+            const float m = gm[u] * cvw[u + kw];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[kw][e] = fmaf(g[e] * m, v[e], acc[kw][e]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < KS - 1; ++j) {
+          win[j] = win[U + j];
+          cvw[j] = cvw[U + j];
+        }
+      }
+    }
+  }
+  if (rl < RL)
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[(rl * KS + t) * C + cg * 8 + e] = acc[t][e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < KS * C; i += 256) {
+    float s = 0.f;
+    for (int l = 0; l < RL; ++l) s += red[l * KS * C + i];
+    partial[((int64_t)blockIdx.x * KS + kh) * KS * C + i] = s;
+  }
+}
+
 // Round 6, 3x3 only: ALL nine taps in one workgroup.  The kernel above runs one workgroup per kernel row, so dy and x cross the memory system
 // three times each (1.0 - 1.1 TB/s of algorithmic bytes = 3.2 TB/s of traffic: it was at the streaming rate of what it asked for); here a
 // thread keeps the 9 x 8 sums of its (8-channel group, pixel lane), reads dy once per pixel and the three input rows out of L1 / L2 (the
@@ -598,6 +683,7 @@ __global__ __launch_bounds__(256) void dw_wgrad3_kernel(const typename TElem<DT>
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
+            __builtin_amdgcn_sched_barrier(0);   // one tap's unpacking at a time (hoisted, the nine unpacked taps cost 234 VGPRs in bf16: two waves per SIMD)
             float v[8];
             TElem<DT>::unpack(raw[kh * 3 + kw], v);
             const float m = rv[kh] * cv[kw];
@@ -1426,7 +1512,15 @@ int esam3_dwconv_wgrad(int dtype, const void* x, const void* dy, int B, int H, i
     if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(dw_wgrad_kernel<DT_, KS_>), 160 * 1024)) return -1;                     \
     hipLaunchKernelGGL((dw_wgrad_kernel<DT_, KS_>), grid, dim3(256), lds, s, (const T_*)x, (const T_*)dy, B, H, W, C, stride, partial); \
   } while (0)
-  if (dtype == 0 && ksize == 3) ESAM3_DWW(0, 3, float);
+  if (ksize == 5 && stride == 1 && !esam3_dev_flag("ESAM3_DWW_OLD")) {   // round 6: sliding window along the row
+    if (dtype == 0) {
+      if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(dw_wgrad_slide_kernel<0, 5>), 160 * 1024)) return -1;
+      hipLaunchKernelGGL((dw_wgrad_slide_kernel<0, 5>), grid, dim3(256), lds, s, (const float*)x, (const float*)dy, B, H, W, C, partial);
+    } else {
+      if (esam3_allow_dyn_lds(reinterpret_cast<const void*>(dw_wgrad_slide_kernel<1, 5>), 160 * 1024)) return -1;
+      hipLaunchKernelGGL((dw_wgrad_slide_kernel<1, 5>), grid, dim3(256), lds, s, (const uint16_t*)x, (const uint16_t*)dy, B, H, W, C, partial);
+    }
+  } else if (dtype == 0 && ksize == 3) ESAM3_DWW(0, 3, float);
   else if (dtype == 0) ESAM3_DWW(0, 5, float);
   else if (ksize == 3) ESAM3_DWW(1, 3, uint16_t);
   else ESAM3_DWW(1, 5, uint16_t);
