@@ -707,6 +707,103 @@ __global__ __launch_bounds__(256) void dw_wgrad3_kernel(const typename TElem<DT>
   }
 }
 
+// Round 6, 3x3 stride 1: dw_wgrad3_kernel with the sliding window of dw_wgrad_slide_kernel -- a thread owns a contiguous run of the row's pixels,
+// keeps the last two input columns (three rows each) in registers and loads U new columns + U dy values per step: 4 U loads in flight carrying
+// U pixels where the strided walk had 10 carrying one.  Same partial layout [split][9][C], same tap-by-tap lane reduction.
+template <int DT>
+__global__ __launch_bounds__(256) void dw_wgrad3_slide_kernel(const typename TElem<DT>::type* __restrict__ x,
+                                                              const typename TElem<DT>::type* __restrict__ dy, int B, int H, int W, int C,
+                                                              float* __restrict__ partial) {
+  extern __shared__ float red[];  // [RL][C]
+  constexpr int U = 2, NW = 2 + U;
+  typedef typename TElem<DT>::vec8 raw_t;
+  const int CG = C >> 3, RL = 256 / CG;
+  const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+  const int seg = (W + RL - 1) / RL, s0 = rl * seg, s1 = s0 + seg < W ? s0 + seg : W;
+  const int64_t nrows = (int64_t)B * H;
+  const int64_t per = (nrows + gridDim.x - 1) / gridDim.x;
+  const int64_t q0 = (int64_t)blockIdx.x * per, q1 = q0 + per < nrows ? q0 + per : nrows;
+  float acc[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+  if (rl < RL && s0 < s1) {
+    int b = (int)(q0 / H), oy = (int)(q0 - (int64_t)b * H);
+    for (int64_t q = q0; q < q1; ++q, oy = oy + 1 == H ? 0 : oy + 1, b += oy == 0) {
+      const typename TElem<DT>::type* dyr = dy + q * W * (int64_t)C + cg * 8;
+      const typename TElem<DT>::type* xb = x + (int64_t)b * H * (int64_t)W * C + cg * 8;
+      float rv[3];
+      const typename TElem<DT>::type* xrow[3];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int iy = oy - 1 + kh;
+        rv[kh] = (iy >= 0 && iy < H) ? 1.f : 0.f;
+        xrow[kh] = xb + (int64_t)(iy < 0 ? 0 : (iy >= H ? H - 1 : iy)) * W * C;
+      }
+      raw_t win[3][NW];
+      float cvw[NW];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ix = s0 - 1 + j;
+        cvw[j] = (ix >= 0 && ix < W) ? 1.f : 0.f;
+        const int64_t off = (int64_t)(ix < 0 ? 0 : (ix >= W ? W - 1 : ix)) * C;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) win[kh][j] = TElem<DT>::loadraw(xrow[kh] + off);
+      }
+      for (int ox = s0; ox < s1; ox += U) {
+        raw_t graw[U];
+        float gm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int ix = ox + u + 1;
+          cvw[2 + u] = ix < W ? 1.f : 0.f;
+          const int64_t off = (int64_t)(ix >= W ? W - 1 : ix) * C;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) win[kh][2 + u] = TElem<DT>::loadraw(xrow[kh] + off);
+          gm[u] = ox + u < s1 ? 1.f : 0.f;
+          graw[u] = TElem<DT>::loadraw(dyr + (int64_t)(ox + u < s1 ? ox + u : s1 - 1) * C);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float g[8];
+          TElem<DT>::unpack(graw[u], g);
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              __builtin_amdgcn_sched_barrier(0);   // one tap's unpacking at a time
+              float v[8];
+              TElem<DT>::unpack(win[kh][u + kw], v);
+              const float m = gm[u] * rv[kh] * cvw[u + kw];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[kh * 3 + kw][e] = fmaf(g[e] * m, v[e], acc[kh * 3 + kw][e]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          cvw[j] = cvw[U + j];
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) win[kh][j] = win[kh][U + j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if (rl < RL)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[rl * C + cg * 8 + e] = acc[t][e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) {
+      float s = 0.f;
+      for (int l = 0; l < RL; ++l) s += red[l * C + i];
+      partial[((int64_t)blockIdx.x * 9 + t) * C + i] = s;
+    }
+    __syncthreads();
+  }
+}
+
 // depthwise k x k DATA gradient (k = 3 | 5), stride 1 | 2, padding k / 2: dx[b][iy][ix][c] = sum over the taps (kh, kw) whose output
 // pixel oy = (iy + k/2 - kh) / s, ox = (ix + k/2 - kw) / s exists (divisible, in range) of dy[b][oy][ox][c] w[c][kh][kw].  One thread per
 // input pixel and 8-channel group; w fp32 on the device in PyTorch's [C][1][k][k] layout (where a training engine keeps its weights).
@@ -1500,7 +1597,10 @@ int esam3_dwconv_wgrad(int dtype, const void* x, const void* dy, int B, int H, i
     const int64_t nrows = (int64_t)B * OH;
     const int sp3 = (int)(nrows < 704 ? nrows : 704);   // 704 x 9 x C floats fit the workspace sized for 256 x 25 x C
     const size_t lds3 = sizeof(float) * (size_t)RL * C;
-    if (dtype == 0) hipLaunchKernelGGL(dw_wgrad3_kernel<0>, dim3((unsigned)sp3), dim3(256), lds3, s, (const float*)x, (const float*)dy, B, H, W, C, stride, partial);
+    const bool slide = stride == 1 && C >= 64 && !esam3_dev_flag("ESAM3_DWW_OLD");   // round 6: sliding window along the row (narrow C: 32-byte runs per lane, slower)
+    if (slide && dtype == 0) hipLaunchKernelGGL(dw_wgrad3_slide_kernel<0>, dim3((unsigned)sp3), dim3(256), lds3, s, (const float*)x, (const float*)dy, B, H, W, C, partial);
+    else if (slide) hipLaunchKernelGGL(dw_wgrad3_slide_kernel<1>, dim3((unsigned)sp3), dim3(256), lds3, s, (const uint16_t*)x, (const uint16_t*)dy, B, H, W, C, partial);
+    else if (dtype == 0) hipLaunchKernelGGL(dw_wgrad3_kernel<0>, dim3((unsigned)sp3), dim3(256), lds3, s, (const float*)x, (const float*)dy, B, H, W, C, stride, partial);
     else hipLaunchKernelGGL(dw_wgrad3_kernel<1>, dim3((unsigned)sp3), dim3(256), lds3, s, (const uint16_t*)x, (const uint16_t*)dy, B, H, W, C, stride, partial);
     hipLaunchKernelGGL(dw_wgrad_finalize_kernel, dim3((unsigned)((9 * C + 63) / 64)), dim3(256), 0, s, partial, sp3, C, 9, dw);
     HIP_CHECK_RET(hipGetLastError());
