@@ -363,19 +363,30 @@ __global__ __launch_bounds__(256) void channel_scale_kernel(const typename TElem
                                                             float plus_one, const float* __restrict__ bias, int bias_bs, float bias_scale,
                                                             const typename TElem<DT>::type* __restrict__ add,
                                                             typename TElem<DT>::type* __restrict__ out, int64_t per_image8, int C8, int64_t total8) {
+  // round 6: 32-bit index arithmetic whenever the tensor allows it (the two 64-bit divisions per 8 elements were most of the loop), the
+  // multipliers / biases as 16-byte loads (element by element they compile to single-dword loads)
+  const bool small = total8 < ((int64_t)1 << 31);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
-    const int64_t b = i / per_image8;
-    const int c = (int)(i % C8) * 8;
-    float v[8], a[8], o[8];
+    int64_t b;
+    int c;
+    if (small) {
+      const unsigned iu = (unsigned)i;
+      b = (mul_bs | bias_bs) ? (int64_t)(iu / (unsigned)per_image8) : 0;
+      c = (int)(iu % (unsigned)C8) * 8;
+    } else {
+      b = i / per_image8;
+      c = (int)(i % C8) * 8;
+    }
+    float v[8], a[8], o[8], m[8], bi[8];
     TElem<DT>::load8(x + i * 8, v);
     if (add) TElem<DT>::load8(add + i * 8, a);
-    const float* m = mul + b * mul_bs + c;
-    const float* bi = bias ? bias + b * bias_bs + c : nullptr;
+    TElem<0>::load8(mul + b * mul_bs + c, m);
+    if (bias) TElem<0>::load8(bias + b * bias_bs + c, bi);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float r = v[e] * (m[e] + plus_one);
       if (add) r += a[e];
-      if (bi) r += bi[e] * bias_scale;
+      if (bias) r += bi[e] * bias_scale;
       o[e] = r;
     }
     TElem<DT>::store8(out + i * 8, o);
@@ -395,10 +406,15 @@ __global__ __launch_bounds__(256) void channel_scale_fast_kernel(const typename 
   const unsigned i0 = blockIdx.x * 256u + threadIdx.x;
   const int c = (int)(i0 % (unsigned)C8) * 8;
   float m[8], bi[8];
+  {  // 16-byte loads: written element by element these compile to single-dword loads, 16 cache lines of the wave each (see bn_map_kernel)
+    const float4 m0 = *reinterpret_cast<const float4*>(mul + c), m1 = *reinterpret_cast<const float4*>(mul + c + 4);
+    m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    m[e] = mul[c + e];
-    bi[e] = bias ? bias[c + e] : 0.f;
+    for (int e = 0; e < 8; ++e) bi[e] = 0.f;
+    if (bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(bias + c), b1 = *reinterpret_cast<const float4*>(bias + c + 4);
+      bi[0] = b0.x; bi[1] = b0.y; bi[2] = b0.z; bi[3] = b0.w; bi[4] = b1.x; bi[5] = b1.y; bi[6] = b1.z; bi[7] = b1.w;
+    }
   }
   const unsigned stride = gridDim.x * 256u;   // a multiple of C8: the channel group of a thread never changes
   for (unsigned i = i0; i < total8; i += stride) {
@@ -1537,10 +1553,10 @@ int esam3_channel_scale(int dtype, const void* x, const float* mul, int mul_per_
   hipStream_t s = (hipStream_t)stream;
   if (!mul_per_image && !bias_per_image && 256 % C8 == 0 && total8 < ((int64_t)1 << 31)) {   // one channel group per thread (round 6)
     if (dtype == 0)
-      hipLaunchKernelGGL(channel_scale_fast_kernel<0>, dim3(grid), dim3(256), 0, s, (const float*)x, mul, plus_one, bias, bias_scale, (const float*)add,
+      hipLaunchKernelGGL(channel_scale_fast_kernel<0>, dim3(grid < 4096 ? grid : 4096), dim3(256), 0, s, (const float*)x, mul, plus_one, bias, bias_scale, (const float*)add,
                          (float*)out, C8, (unsigned)total8);
     else
-      hipLaunchKernelGGL(channel_scale_fast_kernel<1>, dim3(grid), dim3(256), 0, s, (const uint16_t*)x, mul, plus_one, bias, bias_scale,
+      hipLaunchKernelGGL(channel_scale_fast_kernel<1>, dim3(grid < 4096 ? grid : 4096), dim3(256), 0, s, (const uint16_t*)x, mul, plus_one, bias, bias_scale,
                          (const uint16_t*)add, (uint16_t*)out, C8, (unsigned)total8);
     HIP_CHECK_RET(hipGetLastError());
     return 0;
