@@ -447,7 +447,31 @@ __global__ __launch_bounds__(256) void batched_coldot_kernel(const typename TEle
   const int64_t base = (int64_t)blockIdx.y * HW;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (rl < RL) {
-    for (int64_t r = r0 + rl; r < r1; r += RL) {
+    // round 6: four rows' loads in flight (the walk was one dependent load per step: 7.6 ms of a 64 ms RepViT-M1.1 step in 39 calls,
+    // profiles/r06/r06_kernel_stats_stage1_step_repvit_m1_1_b32.csv); rows still accumulate in ascending order
+    int64_t r = r0 + rl;
+    for (; r + 3 * (int64_t)RL < r1; r += 4 * (int64_t)RL) {
+      typename TElem<DT>::vec8 qa[4], qb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        qa[k] = TElem<DT>::loadraw(a + ((base + r + k * (int64_t)RL) * C8 + cg) * 8);
+        if (b2) qb[k] = TElem<DT>::loadraw(b2 + ((base + r + k * (int64_t)RL) * C8 + cg) * 8);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float u[8], w[8];
+        TElem<DT>::unpack(qa[k], u);
+        if (b2) {
+          TElem<DT>::unpack(qb[k], w);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s[e] += u[e] * w[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s[e] += u[e];
+        }
+      }
+    }
+    for (; r < r1; r += RL) {
       float u[8], w[8];
       TElem<DT>::load8(a + ((base + r) * C8 + cg) * 8, u);
       if (b2) {
@@ -483,7 +507,10 @@ int coldot_splits(int B, int64_t HW, int C) {
   const int64_t want = 1024 / B > 1 ? 1024 / B : 1;                   // >= ~1024 workgroups over the chip when the image allows it
   const int64_t most = (HW + (int64_t)RL * 8 - 1) / ((int64_t)RL * 8);  // a split has at least 8 rows per row lane
   int64_t sp = want < most ? want : most;
-  if (sp > COLDOT_SPLITS_MAX) sp = COLDOT_SPLITS_MAX;
+  // round 6: the cap is on splits x B (the workspace holds COLDOT_SPLITS_MAX x max(B, 16) partial rows): with B = 1 -- RepVGGDW's depthwise 1x1
+  // weight gradient over ALL rows of the batch -- 64 splits were 64 workgroups on 256 CUs
+  const int64_t cap = COLDOT_SPLITS_MAX * (int64_t)(B < 16 ? 16 : B) / B;
+  if (sp > cap) sp = cap;
   return (int)(sp < 1 ? 1 : sp);
 }
 
@@ -1571,7 +1598,7 @@ int esam3_channel_scale(int dtype, const void* x, const float* mul, int mul_per_
   return 0;
 }
 
-int64_t esam3_batched_coldot_workspace(int B, int C) { return B > 0 && C > 0 ? (int64_t)sizeof(float) * COLDOT_SPLITS_MAX * B * C : 0; }
+int64_t esam3_batched_coldot_workspace(int B, int C) { return B > 0 && C > 0 ? (int64_t)sizeof(float) * COLDOT_SPLITS_MAX * (B < 16 ? 16 : B) * C : 0; }
 
 int esam3_batched_coldot(int dtype, const void* a, const void* b2, int B, int64_t HW, int C, float scale, float* out, void* workspace,
                          void* stream) {

@@ -182,6 +182,16 @@ print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["cpu_baseline"]["va
 PY
 
   ;;
+al)
+  # round 6, GPU call AL: kernel census of a RepViT-M1.1 and a TinyViT-11M training step
+  mkdir -p $O
+  R=$GRAFT_REPO_ROOT
+  for m in repvit_m1_1 tiny_vit_11m; do
+    rm -rf /tmp/al_prof
+    ( cd /tmp && export TMPDIR=/tmp && timeout 500 rocprofv3 --kernel-trace --stats -d /tmp/al_prof -o al --output-format csv -- python $R/tools/bench_stage1_step.py --model $m --batch 32 --steps 5 --warmup 2 > /dev/null 2>&1 )
+    cp $(find /tmp/al_prof -name "*kernel_stats.csv" | head -1) $O/al_kernel_stats_stage1_step_${m}_b32.csv
+  done
+  ;;
 ac)
   # round 6, GPU call AC: the training step after the gradient copies became one multi-tensor copy: tests, the B1 step, the kernel census of a step
   mkdir -p $O
