@@ -148,6 +148,7 @@ SIGNATURES = {
                             _I, _I, _I, _P, _P, _P]),
     "esam3_distill_loss": (_I, [_I, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
     "esam3_distill_loss_backward": (_I, [_I, _P, _I, _P, _P, _I, _I, _I, C.c_float, C.c_float, _P, _P, _P]),
+    "esam3_distill_loss_backward_ds": (_I, [_I, _P, _I, _P, _P, _I, _I, _I, C.c_float, C.c_float, _P, _P, _P, _P]),
     "esam3_set_text_causal": (_I, [_P, _I]),
     "esam3_op_mha": (_I, [_I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "esam3_op_vit_rope": (_I, [_I, _P, _P, _L, _I, _I, _I, _I, _P]),

@@ -143,7 +143,8 @@ int launch_pixel(int teacher_dtype, const void* preds, const void* teacher, floa
 }
 
 // per image: 1 / max(#valid, 1)
-__global__ __launch_bounds__(256) void valid_recip_kernel(const uint8_t* __restrict__ valid, int HW, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void valid_recip_kernel(const uint8_t* __restrict__ valid, int HW, float* __restrict__ out,
+                                                          const float* __restrict__ scale_dev = nullptr) {
   __shared__ int sc[256];
   const int b = blockIdx.x;
   int n = 0;
@@ -154,7 +155,8 @@ __global__ __launch_bounds__(256) void valid_recip_kernel(const uint8_t* __restr
     if (threadIdx.x < o) sc[threadIdx.x] += sc[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[b] = 1.f / fmaxf((float)sc[0], 1.f);
+  // scale_dev: the loss scale read ON the device (a power of two: exact wherever it multiplies) -- no host read-back in a training step
+  if (threadIdx.x == 0) out[b] = (1.f / fmaxf((float)sc[0], 1.f)) * (scale_dev ? *scale_dev : 1.f);
 }
 
 template <int DP> struct Store8;
@@ -239,8 +241,32 @@ int launch_backward(int teacher_dtype, const void* preds, const void* teacher, c
 
 }  // namespace
 
+static int distill_loss_backward_impl(int preds_dtype, const void* preds_dev, int teacher_dtype, const void* teacher_dev,
+                                const uint8_t* valid_dev, int B, int HW, int C, float cosine_weight, float grad_scale, const float* scale_dev,
+                                void* grad_preds_dev, float* scratch_dev, void* stream);
+
 int esam3_distill_loss_backward(int preds_dtype, const void* preds_dev, int teacher_dtype, const void* teacher_dev,
                                 const uint8_t* valid_dev, int B, int HW, int C, float cosine_weight, float grad_scale,
+                                void* grad_preds_dev, float* scratch_dev, void* stream) {
+  return distill_loss_backward_impl(preds_dtype, preds_dev, teacher_dtype, teacher_dev, valid_dev, B, HW, C, cosine_weight, grad_scale, nullptr,
+                                    grad_preds_dev, scratch_dev, stream);
+}
+
+// the same gradient times a scale that lives in DEVICE memory (the AMP loss scale of the updater's state, a power of two): the training step
+// no longer reads it back to the host -- that read was the step's only synchronisation point (1 ms of idle GPU per step behind it)
+int esam3_distill_loss_backward_ds(int preds_dtype, const void* preds_dev, int teacher_dtype, const void* teacher_dev,
+                                   const uint8_t* valid_dev, int B, int HW, int C, float cosine_weight, float grad_scale,
+                                   const float* scale_dev, void* grad_preds_dev, float* scratch_dev, void* stream) {
+  if (!scale_dev) {
+    esam3_set_error("esam3_distill_loss_backward_ds: scale_dev is NULL");
+    return -1;
+  }
+  return distill_loss_backward_impl(preds_dtype, preds_dev, teacher_dtype, teacher_dev, valid_dev, B, HW, C, cosine_weight, grad_scale, scale_dev,
+                                    grad_preds_dev, scratch_dev, stream);
+}
+
+static int distill_loss_backward_impl(int preds_dtype, const void* preds_dev, int teacher_dtype, const void* teacher_dev,
+                                const uint8_t* valid_dev, int B, int HW, int C, float cosine_weight, float grad_scale, const float* scale_dev,
                                 void* grad_preds_dev, float* scratch_dev, void* stream) {
   if (!preds_dev || !teacher_dev || !valid_dev || !grad_preds_dev || !scratch_dev || B <= 0 || HW <= 0 || C <= 0 || C % 8 ||
       preds_dtype < 0 || preds_dtype > 1 || teacher_dtype < 0 || teacher_dtype > 2) {
@@ -249,7 +275,7 @@ int esam3_distill_loss_backward(int preds_dtype, const void* preds_dev, int teac
     return -1;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(valid_recip_kernel, dim3((unsigned)B), dim3(256), 0, s, valid_dev, HW, scratch_dev);
+  hipLaunchKernelGGL(valid_recip_kernel, dim3((unsigned)B), dim3(256), 0, s, valid_dev, HW, scratch_dev, scale_dev);
   const int64_t n_pix = (int64_t)B * HW;
   const float sb = grad_scale / (float)B;
   if (preds_dtype == 0) launch_backward<0>(teacher_dtype, preds_dev, teacher_dev, valid_dev, scratch_dev, grad_preds_dev, n_pix, HW, C, cosine_weight, sb, s);

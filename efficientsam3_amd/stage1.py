@@ -114,7 +114,7 @@ def distill_loss(preds: torch.Tensor, teacher: torch.Tensor, valid: torch.Tensor
 
 
 def distill_loss_backward(preds: torch.Tensor, teacher: torch.Tensor, valid: torch.Tensor, cosine_weight: float = 0.0,
-                          grad_scale: float = 1.0) -> torch.Tensor:
+                          grad_scale: float = 1.0, scale_dev: torch.Tensor = None) -> torch.Tensor:
     """dL/dpreds of ``masked_mse + cosine_weight * masked_cosine_loss`` times ``grad_scale`` (= 1 / ACCUMULATION_STEPS in
     stage1/train_image_encoder_stage1.py:186-210): [B, HW, C] in the dtype of ``preds``, zero at masked pixels -- the tensor
     ``loss.backward()`` hands to the student trunk."""
@@ -127,6 +127,13 @@ def distill_loss_backward(preds: torch.Tensor, teacher: torch.Tensor, valid: tor
     scratch = torch.empty((b,), dtype=torch.float32, device=preds.device)
     lib = _lib.load()
     with torch.cuda.device(preds.device):
+        if scale_dev is not None:   # times scale_dev[0], read on the device (the AMP loss scale: no host read-back)
+            assert scale_dev.is_cuda and scale_dev.dtype == torch.float32
+            _lib.check(lib.esam3_distill_loss_backward_ds(_DT[preds.dtype], preds.data_ptr(), _DT[teacher.dtype], teacher.data_ptr(),
+                                                          valid.data_ptr(), b, hw, c, float(cosine_weight), float(grad_scale), scale_dev.data_ptr(),
+                                                          grad.data_ptr(), scratch.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                       "esam3_distill_loss_backward_ds")
+            return grad
         _lib.check(lib.esam3_distill_loss_backward(_DT[preds.dtype], preds.data_ptr(), _DT[teacher.dtype], teacher.data_ptr(),
                                                    valid.data_ptr(), b, hw, c, float(cosine_weight), float(grad_scale),
                                                    grad.data_ptr(), scratch.data_ptr(), torch.cuda.current_stream().cuda_stream),

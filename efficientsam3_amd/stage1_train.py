@@ -270,15 +270,23 @@ class Stage1Trainer:
         b = images_nchw_f32.shape[0]
         preds = self.forward(images_nchw_f32)
         s, e = self.embed_size, preds.shape[-1]
-        valid = torch.from_numpy(valid_mask(images_nchw_f32.shape[-1], sizes_before_pad, (s, s))).to(self.device)
+        vkey = (int(images_nchw_f32.shape[-1]), tuple(tuple(int(v) for v in hw) for hw in sizes_before_pad), s)
+        if getattr(self, "_valid_key", None) != vkey:   # the mask of the last batch's sizes stays on the device (a pageable upload synchronises)
+            self._valid_key, self._valid = vkey, torch.from_numpy(valid_mask(images_nchw_f32.shape[-1], sizes_before_pad, (s, s))).to(self.device)
+        valid = self._valid
         p2, t2 = preds.reshape(b, s * s, e), teacher.reshape(b, s * s, e)
         mse, cos, _ = distill_loss(p2, t2, valid)
         loss = (mse + self.cosine_weight * cos) / self.accumulation_steps
         # d(loss x scale) / d(preds).  The loss scale lives in the updater's device state (it moves when a step is skipped / after
         # growth_interval clean steps); it is read back once per iteration -- the reference's loop synchronises every iteration too
         # (loss.item(), torch.cuda.synchronize(): train_image_encoder_stage1.py:206,226)
-        scale = float(self.updater.loss_scale) if self.updater.amp else 1.0
-        d = distill_loss_backward(p2, t2, valid, cosine_weight=self.cosine_weight, grad_scale=scale / self.accumulation_steps)
+        if self.updater.amp and p2.is_cuda:
+            # round 6: the scale is read by the kernel, from the updater's state (esam3_distill_loss_backward_ds): the step has no host
+            # synchronisation left (the read-back was one, with ~1 ms of idle GPU behind it); a power of two, so the gradient is bit-identical
+            d = distill_loss_backward(p2, t2, valid, cosine_weight=self.cosine_weight, grad_scale=1.0 / self.accumulation_steps, scale_dev=self.updater.state)
+        else:
+            scale = float(self.updater.loss_scale) if self.updater.amp else 1.0
+            d = distill_loss_backward(p2, t2, valid, cosine_weight=self.cosine_weight, grad_scale=scale / self.accumulation_steps)
         self.backward(d.reshape(b, s, s, e), push=update_grad and self._collective())
         for k in self.batches_tracked:
             self.batches_tracked[k] += 1

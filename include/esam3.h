@@ -214,6 +214,11 @@ int esam3_distill_loss(int preds_dtype, const void* preds_dev, int teacher_dtype
 int esam3_distill_loss_backward(int preds_dtype, const void* preds_dev, int teacher_dtype, const void* teacher_dev,
                                 const uint8_t* valid_dev, int B, int HW, int C, float cosine_weight, float grad_scale,
                                 void* grad_preds_dev, float* scratch_dev, void* hip_stream);
+/* The same gradient times a scale held in DEVICE memory (the AMP loss scale inside the updater's state; a power of two, so exact wherever it
+ * multiplies): a training step that calls this form never reads the scale back to the host (that read was the step's only synchronisation). */
+int esam3_distill_loss_backward_ds(int preds_dtype, const void* preds_dev, int teacher_dtype, const void* teacher_dev,
+                                   const uint8_t* valid_dev, int B, int HW, int C, float cosine_weight, float grad_scale,
+                                   const float* scale_dev, void* grad_preds_dev, float* scratch_dev, void* hip_stream);
 
 /* Gradient kernels of the layers an EfficientViT ConvLayer / DSConv / MBConv is made of (backbones/efficientvit/nn/ops.py:39-81,
  * 264-360: Conv2d without bias -> BatchNorm2d -> activation), NHWC rows, dtype 0 fp32 / 1 bf16 activations and gradients, fp32

@@ -106,6 +106,9 @@ def test_distill_loss_backward_vs_autograd(name, w_cos):
     assert gb.dtype == torch.bfloat16
     assert float((gb.float().cpu() - want).abs().max()) <= 3e-2 * scale    # bf16 inputs and output: rounding only
     assert torch.equal(stage1.distill_loss_backward(p, t, valid, w_cos, 0.5), stage1.distill_loss_backward(p, t, valid, w_cos, 0.5))
+    # the loss scale read on the device (esam3_distill_loss_backward_ds) = the same scale folded into grad_scale on the host, bit for bit
+    sd = torch.tensor([65536.0, 3.0, 7.0], dtype=torch.float32, device="cuda")
+    assert torch.equal(stage1.distill_loss_backward(p, t, valid, w_cos, 0.5, scale_dev=sd), stage1.distill_loss_backward(p, t, valid, w_cos, 0.5 * 65536.0))
 
 
 @pytest.mark.gpu
