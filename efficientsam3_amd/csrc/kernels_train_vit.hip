@@ -359,6 +359,278 @@ __global__ __launch_bounds__(256) void win_attn_backward_kernel(const typename V
   }
 }
 
+// ---- round 6: the same two operations on the matrix unit (bf16 activations) ---------------------------------------------------------------
+// The kernels above spend ~320 fp32 multiply-adds per (query, key) pair on the VALU: 37 ms of a 102 ms TinyViT-11M batch-32 step
+// (profiles/r06/r06_kernel_stats_stage1_step_tiny_vit_11m_b32.csv).  Under autocast the reference runs these products in bf16 with fp32
+// accumulation (tiny_vit.py:283-291 inside torch.autocast); so do these: v_mfma_f32_32x32x16_bf16 on 32 x 32 tiles of the N x N logits.
+// Every product is written in ONE form, C[m][n] = sum_k X[m][k] Y[n][k] with k contiguous in both operands (a lane's 8 k-values are one
+// 16-byte LDS read), which asks for
+//   - q, k, v, dO staged row-major [token][32] AND (q, k, dO; v in the forward) transposed [32][token] in LDS;
+//   - P and dS tiles rounded to bf16 and passed through a per-wave LDS scratch, written in the orientation the next product reads.
+// One workgroup per (window, head), four waves; N is padded to 32-token tiles with zero rows (their P / dS are forced to 0).
+// Backward: phase B gives a wave the key tiles J = wave, wave + 4, .. (dK_J, dV_J accumulated over all query tiles, dS written for the bias
+// gradient), phase A the query tiles (dQ_I over all key tiles); logits and probabilities are recomputed in both (4 of the 14 MFMAs per tile pair).
+typedef float wa_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int WA_P = 40;   // halves per staged row of 32 (80 bytes)
+
+__device__ __forceinline__ bf16x8_v wa_op(const uint16_t* base, int row0, int pitch, int k0, int lane) {
+  return *reinterpret_cast<const bf16x8_v*>(base + (row0 + (lane & 31)) * pitch + k0 + 8 * (lane >> 5));
+}
+// acc += X[rows x0 ..][k] Y[rows y0 ..][k] over 32 k-values starting at kx0 / ky0
+__device__ __forceinline__ wa_f32x16 wa_nt(wa_f32x16 acc, const uint16_t* X, int x0, int xp, int kx0, const uint16_t* Y, int y0, int yp, int ky0, int lane) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa_op(X, x0, xp, kx0 + 16 * s, lane), wa_op(Y, y0, yp, ky0 + 16 * s, lane), acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ int wa_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }   // accumulator register -> tile row
+__device__ __forceinline__ wa_f32x16 wa_zero() {
+  wa_f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+// rows [0, NP) of a [N][ld] bf16 matrix (32 channels from `src`) -> natural [NP][WA_P] and (if T) transposed [32][TP]; zeros past N
+__device__ __forceinline__ void wa_stage(const uint16_t* __restrict__ src, int ld, int N, int NP, uint16_t* nat, uint16_t* T, int TP) {
+  for (int c = threadIdx.x; c < NP * 4; c += 256) {
+    const int r = c >> 2, part = c & 3;
+    uint4 q = make_uint4(0u, 0u, 0u, 0u);
+    if (r < N) q = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + part * 8);
+    if (nat) *reinterpret_cast<uint4*>(nat + r * WA_P + part * 8) = q;
+    if (T) {
+      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        T[(part * 8 + 2 * e) * TP + r] = (uint16_t)(w[e] & 0xffffu);
+        T[(part * 8 + 2 * e + 1) * TP + r] = (uint16_t)(w[e] >> 16);
+      }
+    }
+  }
+}
+
+template <bool TAB>
+__global__ __launch_bounds__(256) void win_attn_forward_mfma_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ bias,
+                                                                    uint16_t* __restrict__ out, float* __restrict__ lse, int N, int heads, float scale,
+                                                                    const float* __restrict__ tab, int ws) {
+  // `tab` [heads][ws ws] (N = ws ws): the attention_biases parameter itself (tiny_vit.py:240-254: offset (|dy|, |dx|) has index |dy| ws + |dx|);
+  // the head's row is staged in LDS and indexed per pair -- with the gathered [N][N] table in global memory every tile step waited ~1.4 us for
+  // its 16 bias values with one wave per SIMD to hide it (the first MFMA form was no faster than the VALU kernels: profiles/r06/wattn_mfma_first.txt)
+  extern __shared__ __attribute__((aligned(16))) uint16_t wsm[];
+  constexpr int NTMAX = 8;
+  const int NP = (N + 31) & ~31, NT = NP >> 5, TP = NP + 8;
+  uint16_t* sQ = wsm;
+  uint16_t* sK = sQ + NP * WA_P;
+  uint16_t* sVT = sK + NP * WA_P;          // [32][TP]
+  uint16_t* scr = sVT + 32 * TP;           // [4 waves][32][WA_P]
+  float* sl = reinterpret_cast<float*>(scr + 4 * 32 * WA_P);   // [4 waves][32]
+  float* stab = sl + 4 * 32;                                    // [256]
+  uint16_t* spos = reinterpret_cast<uint16_t*>(stab + 256);     // [NP]: (row << 8) | column of the token in its window
+  const int w = blockIdx.x, h = blockIdx.y, ld = heads * 3 * HD, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint16_t* base = qkv + (int64_t)w * N * ld + h * 3 * HD;
+  if constexpr (TAB) {
+    for (int t = threadIdx.x; t < 256; t += 256) stab[t] = t < N ? tab[(int64_t)h * N + t] : 0.f;
+    for (int t = threadIdx.x; t < NP; t += 256) spos[t] = t < N ? (uint16_t)(((t / ws) << 8) | (t % ws)) : (uint16_t)0;
+  }
+  wa_stage(base, ld, N, NP, sQ, nullptr, TP);
+  wa_stage(base + HD, ld, N, NP, sK, nullptr, TP);
+  wa_stage(base + 2 * HD, ld, N, NP, nullptr, sVT, TP);
+  __syncthreads();
+  uint16_t* myscr = scr + wave * 32 * WA_P;
+  float* mysl = sl + wave * 32;
+  const float* bh = bias + (int64_t)h * N * N;
+  auto bias_at = [&](int a, int b) -> float {   // a, b < N; the table is symmetric
+    if constexpr (TAB) {
+      const int pa = spos[a], pb = spos[b];
+      const int dr = (pa >> 8) - (pb >> 8), dc = (pa & 255) - (pb & 255);
+      return stab[(dr < 0 ? -dr : dr) * ws + (dc < 0 ? -dc : dc)];
+    } else {
+      return bh[(int64_t)a * N + b];
+    }
+  };
+  for (int I = wave; I < NT; I += 4) {
+    const int i = I * 32 + (lane & 31);        // this lane's query (the tiles are S^T: column = query, rows = keys)
+    wa_f32x16 st[NTMAX];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int J = 0; J < NTMAX; ++J) {
+      if (J < NT) {
+        st[J] = wa_nt(wa_zero(), sK, J * 32, WA_P, 0, sQ, I * 32, WA_P, 0, lane);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = J * 32 + wa_row(r, lane);
+          const bool ok = j < N && i < N;
+          const float sv = ok ? st[J][r] * scale + bias_at(j, i) : -3.0e38f;   // symmetric table: [j][i] = [i][j], coalesced over i
+          st[J][r] = sv;
+          mx = fmaxf(mx, sv);
+        }
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int J = 0; J < NTMAX; ++J)
+      if (J < NT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = st[J][r] > -1.0e38f ? __expf(st[J][r] - mx) : 0.f;
+          st[J][r] = pv;
+          l += pv;
+        }
+      }
+    l += __shfl_xor(l, 32);
+    wa_f32x16 o = wa_zero();
+#pragma unroll
+    for (int J = 0; J < NTMAX; ++J)
+      if (J < NT) {
+        // P tile natural [query][key]: this lane's query row, keys 8 q4 + 4 g + (0..3): one 8-byte write per q4
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const uint32_t lo = pack_bf16x2(st[J][q4 * 4], st[J][q4 * 4 + 1]), hi = pack_bf16x2(st[J][q4 * 4 + 2], st[J][q4 * 4 + 3]);
+          *reinterpret_cast<uint2*>(myscr + (lane & 31) * WA_P + 8 * q4 + 4 * (lane >> 5)) = make_uint2(lo, hi);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        o = wa_nt(o, myscr, 0, WA_P, 0, sVT, 0, TP, J * 32, lane);   // O[i][c] += sum_j P[i][j] V[j][c]
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the reads are done before the next tile overwrites the scratch
+      }
+    if (lane < 32) mysl[lane] = l;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // o: column = channel (lane & 31), rows = queries of the tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int il = wa_row(r, lane), ig = I * 32 + il;
+      if (ig < N) out[((int64_t)w * N + ig) * (heads * HD) + h * HD + (lane & 31)] = f32_to_bf16(o[r] / mysl[il]);
+    }
+    if (lane < 32 && i < N) lse[((int64_t)w * heads + h) * N + i] = mx + __logf(l);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+template <bool TAB>
+__global__ __launch_bounds__(256) void win_attn_backward_mfma_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ bias,
+                                                                     const uint16_t* __restrict__ out, const float* __restrict__ lse,
+                                                                     const uint16_t* __restrict__ dout, uint16_t* __restrict__ dqkv,
+                                                                     float* __restrict__ ds_out, int N, int heads, float scale,
+                                                                     const float* __restrict__ tab, int ws) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t wsm[];
+  const int NP = (N + 31) & ~31, NT = NP >> 5, TP = NP + 8;
+  uint16_t* sQ = wsm;
+  uint16_t* sK = sQ + NP * WA_P;
+  uint16_t* sV = sK + NP * WA_P;
+  uint16_t* sdO = sV + NP * WA_P;
+  uint16_t* sQT = sdO + NP * WA_P;         // [32][TP]
+  uint16_t* sKT = sQT + 32 * TP;
+  uint16_t* sdOT = sKT + 32 * TP;
+  uint16_t* scr = sdOT + 32 * TP;          // [4 waves][2][32][WA_P]
+  float* slse = reinterpret_cast<float*>(scr + 4 * 2 * 32 * WA_P);   // [NP]
+  float* sd = slse + NP;                                              // [NP]
+  float* stab = sd + NP;                                              // [256]
+  uint16_t* spos = reinterpret_cast<uint16_t*>(stab + 256);           // [NP]
+  const int w = blockIdx.x, h = blockIdx.y, ld = heads * 3 * HD, ldo = heads * HD, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if constexpr (TAB) {
+    for (int t = threadIdx.x; t < 256; t += 256) stab[t] = t < N ? tab[(int64_t)h * N + t] : 0.f;
+    for (int t = threadIdx.x; t < NP; t += 256) spos[t] = t < N ? (uint16_t)(((t / ws) << 8) | (t % ws)) : (uint16_t)0;
+  }
+  const uint16_t* base = qkv + (int64_t)w * N * ld + h * 3 * HD;
+  const uint16_t* dobase = dout + (int64_t)w * N * ldo + h * HD;
+  wa_stage(base, ld, N, NP, sQ, sQT, TP);
+  wa_stage(base + HD, ld, N, NP, sK, sKT, TP);
+  wa_stage(base + 2 * HD, ld, N, NP, sV, nullptr, TP);
+  wa_stage(dobase, ldo, N, NP, sdO, sdOT, TP);
+  for (int t = threadIdx.x; t < NP; t += 256) {
+    float d = 0.f, ls = 0.f;
+    if (t < N) {
+      float a[HD], b[HD];
+      load_row<1>(dobase + (int64_t)t * ldo, a);
+      load_row<1>(out + ((int64_t)w * N + t) * ldo + h * HD, b);
+#pragma unroll
+      for (int c = 0; c < HD; ++c) d += a[c] * b[c];
+      ls = lse[((int64_t)w * heads + h) * N + t];
+    }
+    sd[t] = d;
+    slse[t] = ls;
+  }
+  __syncthreads();
+  uint16_t* s0 = scr + wave * 2 * 32 * WA_P;
+  uint16_t* s1 = s0 + 32 * WA_P;
+  const float* bh = bias + (int64_t)h * N * N;
+  const int jl = lane & 31;
+  auto bias_at = [&](int a, int b) -> float {   // a, b < N
+    if constexpr (TAB) {
+      const int pa = spos[a], pb = spos[b];
+      const int dr = (pa >> 8) - (pb >> 8), dc = (pa & 255) - (pb & 255);
+      return stab[(dr < 0 ? -dr : dr) * ws + (dc < 0 ? -dc : dc)];
+    } else {
+      return bh[(int64_t)a * N + b];
+    }
+  };
+  // ---- phase B: dK_J, dV_J, dS ----
+  for (int J = wave; J < NT; J += 4) {
+    wa_f32x16 dk = wa_zero(), dv = wa_zero();
+    const int j = J * 32 + jl;
+    for (int I = 0; I < NT; ++I) {
+      const wa_f32x16 S = wa_nt(wa_zero(), sQ, I * 32, WA_P, 0, sK, J * 32, WA_P, 0, lane);      // rows = queries, column = this lane's key
+      const wa_f32x16 dP = wa_nt(wa_zero(), sdO, I * 32, WA_P, 0, sV, J * 32, WA_P, 0, lane);
+      float pv[16], dsv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = I * 32 + wa_row(r, lane);
+        const bool ok = i < N && j < N;
+        const float p = ok ? __expf(S[r] * scale + bias_at(i, j) - slse[i]) : 0.f;
+        const float dsr = p * (dP[r] - sd[i]);
+        if (ok) ds_out[(((int64_t)w * heads + h) * N + i) * N + j] = dsr;
+        pv[r] = p;
+        dsv[r] = dsr * scale;
+      }
+      // transposed tiles [key][query]: this lane's key row, queries 8 q4 + 4 g + (0..3)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int off = jl * WA_P + 8 * q4 + 4 * (lane >> 5);
+        *reinterpret_cast<uint2*>(s0 + off) = make_uint2(pack_bf16x2(pv[q4 * 4], pv[q4 * 4 + 1]), pack_bf16x2(pv[q4 * 4 + 2], pv[q4 * 4 + 3]));
+        *reinterpret_cast<uint2*>(s1 + off) = make_uint2(pack_bf16x2(dsv[q4 * 4], dsv[q4 * 4 + 1]), pack_bf16x2(dsv[q4 * 4 + 2], dsv[q4 * 4 + 3]));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      dv = wa_nt(dv, s0, 0, WA_P, 0, sdOT, 0, TP, I * 32, lane);   // dV[j][c] += sum_i P[i][j] dO[i][c]
+      dk = wa_nt(dk, s1, 0, WA_P, 0, sQT, 0, TP, I * 32, lane);    // dK[j][c] += scale sum_i dS[i][j] q[i][c]
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jg = J * 32 + wa_row(r, lane);
+      if (jg < N) {
+        uint16_t* o = dqkv + ((int64_t)w * N + jg) * ld + h * 3 * HD + (lane & 31);
+        o[HD] = f32_to_bf16(dk[r]);
+        o[2 * HD] = f32_to_bf16(dv[r]);
+      }
+    }
+  }
+  // ---- phase A: dQ_I ----
+  for (int I = wave; I < NT; I += 4) {
+    wa_f32x16 dq = wa_zero();
+    for (int J = 0; J < NT; ++J) {
+      const int j = J * 32 + jl;
+      const wa_f32x16 S = wa_nt(wa_zero(), sQ, I * 32, WA_P, 0, sK, J * 32, WA_P, 0, lane);
+      const wa_f32x16 dP = wa_nt(wa_zero(), sdO, I * 32, WA_P, 0, sV, J * 32, WA_P, 0, lane);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int il = wa_row(r, lane), i = I * 32 + il;
+        const bool ok = i < N && j < N;
+        const float p = ok ? __expf(S[r] * scale + bias_at(i, j) - slse[i]) : 0.f;
+        s0[il * WA_P + jl] = f32_to_bf16(p * (dP[r] - sd[i]) * scale);   // natural tile [query][key]
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      dq = wa_nt(dq, s0, 0, WA_P, 0, sKT, 0, TP, J * 32, lane);    // dQ[i][c] += scale sum_j dS[i][j] k[j][c]
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ig = I * 32 + wa_row(r, lane);
+      if (ig < N) dqkv[((int64_t)w * N + ig) * ld + h * 3 * HD + (lane & 31)] = f32_to_bf16(dq[r]);
+    }
+  }
+}
+static int wa_fwd_lds(int N) { const int NP = (N + 31) & ~31; return (2 * NP * WA_P + 32 * (NP + 8) + 4 * 32 * WA_P) * 2 + 4 * 32 * 4 + 1024 + 2 * NP; }
+static int wa_bwd_lds(int N) { const int NP = (N + 31) & ~31; return (4 * NP * WA_P + 3 * 32 * (NP + 8) + 4 * 2 * 32 * WA_P) * 2 + 2 * NP * 4 + 1024 + 2 * NP; }
+
 // out[h][o] = sum over the items of offset o (CSR: start[o] .. start[o + 1]) of full[h][item]: one wavefront per (head, offset), lane l adds
 // the items l, l + 64, ... in list order, the 64 lane sums are added by the butterfly of wave_sum -- a fixed order (deterministic)
 __global__ __launch_bounds__(256) void bias_gather_sum_kernel(const float* __restrict__ full, const int* __restrict__ start, const int* __restrict__ items,
@@ -414,8 +686,21 @@ int esam3_ln_train_backward(int dtype, const void* x, const void* dy, const floa
   return 0;
 }
 
+static int win_attn_forward_impl(int dtype, const void* qkv, const float* bias, const float* tab, int ws, void* out, float* lse, int windows, int N,
+                                 int heads, float scale, void* stream);
 int esam3_win_attn_train_forward(int dtype, const void* qkv, const float* bias, void* out, float* lse, int windows, int N, int heads, float scale,
                                  void* stream) {
+  return win_attn_forward_impl(dtype, qkv, bias, nullptr, 0, out, lse, windows, N, heads, scale, stream);
+}
+// the same with the attention_biases parameter itself beside the gathered table: tab [heads][ws ws], N = ws ws, bias[h][i][j] = tab[h][|dy| ws + |dx|]
+// (tiny_vit.py:240-254).  The bf16 kernels index `tab` from LDS instead of reading `bias` from global memory; fp32 (validation mode) reads `bias`.
+int esam3_win_attn_train_forward_tab(int dtype, const void* qkv, const float* bias, const float* tab, int ws, void* out, float* lse, int windows,
+                                     int heads, float scale, void* stream) {
+  if (!tab || ws <= 0 || ws > 16) return bad("esam3_win_attn_train_forward_tab (window side 1 .. 16)");
+  return win_attn_forward_impl(dtype, qkv, bias, tab, ws, out, lse, windows, ws * ws, heads, scale, stream);
+}
+static int win_attn_forward_impl(int dtype, const void* qkv, const float* bias, const float* tab, int ws, void* out, float* lse, int windows, int N,
+                                 int heads, float scale, void* stream) {
   if ((dtype != 0 && dtype != 1) || !qkv || !bias || !out || !lse || windows <= 0 || N <= 0 || N > 256 || heads <= 0 || heads > 65535)
     return bad("esam3_win_attn_train_forward (fp32 / bf16; at most 256 tokens per window; head dim 32)");
   hipStream_t s = (hipStream_t)stream;
@@ -424,6 +709,15 @@ int esam3_win_attn_train_forward(int dtype, const void* qkv, const float* bias, 
     if (esam3_allow_dyn_lds((const void*)win_attn_forward_kernel<0>, 2 * 256 * HD * (int)sizeof(float))) return -1;
     hipLaunchKernelGGL(win_attn_forward_kernel<0>, dim3((unsigned)windows, (unsigned)heads), dim3(threads), lds, s, (const float*)qkv, bias, (float*)out, lse, N,
                        heads, scale);
+  } else if (!esam3_dev_flag("ESAM3_WATTN_OLD")) {   // round 6: on the matrix unit
+    if (esam3_allow_dyn_lds((const void*)win_attn_forward_mfma_kernel<true>, wa_fwd_lds(256))) return -1;
+    if (esam3_allow_dyn_lds((const void*)win_attn_forward_mfma_kernel<false>, wa_fwd_lds(256))) return -1;
+    if (tab)
+      hipLaunchKernelGGL(win_attn_forward_mfma_kernel<true>, dim3((unsigned)windows, (unsigned)heads), dim3(256), wa_fwd_lds(N), s, (const uint16_t*)qkv, bias,
+                         (uint16_t*)out, lse, N, heads, scale, tab, ws);
+    else
+      hipLaunchKernelGGL(win_attn_forward_mfma_kernel<false>, dim3((unsigned)windows, (unsigned)heads), dim3(256), wa_fwd_lds(N), s, (const uint16_t*)qkv, bias,
+                         (uint16_t*)out, lse, N, heads, scale, tab, ws);
   } else {
     if (esam3_allow_dyn_lds((const void*)win_attn_forward_kernel<1>, 2 * 256 * HD * (int)sizeof(float))) return -1;
     hipLaunchKernelGGL(win_attn_forward_kernel<1>, dim3((unsigned)windows, (unsigned)heads), dim3(threads), lds, s, (const uint16_t*)qkv, bias, (uint16_t*)out,
@@ -433,8 +727,19 @@ int esam3_win_attn_train_forward(int dtype, const void* qkv, const float* bias, 
   return 0;
 }
 
+static int win_attn_backward_impl(int dtype, const void* qkv, const float* bias, const float* tab, int ws, const void* out, const float* lse,
+                                  const void* dout, void* dqkv, float* ds, int windows, int N, int heads, float scale, void* stream);
 int esam3_win_attn_train_backward(int dtype, const void* qkv, const float* bias, const void* out, const float* lse, const void* dout, void* dqkv,
                                   float* ds, int windows, int N, int heads, float scale, void* stream) {
+  return win_attn_backward_impl(dtype, qkv, bias, nullptr, 0, out, lse, dout, dqkv, ds, windows, N, heads, scale, stream);
+}
+int esam3_win_attn_train_backward_tab(int dtype, const void* qkv, const float* bias, const float* tab, int ws, const void* out, const float* lse,
+                                      const void* dout, void* dqkv, float* ds, int windows, int heads, float scale, void* stream) {
+  if (!tab || ws <= 0 || ws > 16) return bad("esam3_win_attn_train_backward_tab (window side 1 .. 16)");
+  return win_attn_backward_impl(dtype, qkv, bias, tab, ws, out, lse, dout, dqkv, ds, windows, ws * ws, heads, scale, stream);
+}
+static int win_attn_backward_impl(int dtype, const void* qkv, const float* bias, const float* tab, int ws, const void* out, const float* lse,
+                                  const void* dout, void* dqkv, float* ds, int windows, int N, int heads, float scale, void* stream) {
   if ((dtype != 0 && dtype != 1) || !qkv || !bias || !out || !lse || !dout || !dqkv || !ds || windows <= 0 || N <= 0 || N > 256 || heads <= 0 ||
       heads > 65535)
     return bad("esam3_win_attn_train_backward (fp32 / bf16; at most 256 tokens per window; head dim 32)");
@@ -445,6 +750,15 @@ int esam3_win_attn_train_backward(int dtype, const void* qkv, const float* bias,
     if (esam3_allow_dyn_lds((const void*)win_attn_backward_kernel<0>, lds_max)) return -1;
     hipLaunchKernelGGL(win_attn_backward_kernel<0>, dim3((unsigned)windows, (unsigned)heads, 2), dim3(threads), lds, s, (const float*)qkv, bias, (const float*)out,
                        lse, (const float*)dout, (float*)dqkv, ds, N, heads, scale);
+  } else if (!esam3_dev_flag("ESAM3_WATTN_OLD")) {   // round 6: on the matrix unit
+    if (esam3_allow_dyn_lds((const void*)win_attn_backward_mfma_kernel<true>, wa_bwd_lds(256))) return -1;
+    if (esam3_allow_dyn_lds((const void*)win_attn_backward_mfma_kernel<false>, wa_bwd_lds(256))) return -1;
+    if (tab)
+      hipLaunchKernelGGL(win_attn_backward_mfma_kernel<true>, dim3((unsigned)windows, (unsigned)heads), dim3(256), wa_bwd_lds(N), s, (const uint16_t*)qkv, bias,
+                         (const uint16_t*)out, lse, (const uint16_t*)dout, (uint16_t*)dqkv, ds, N, heads, scale, tab, ws);
+    else
+      hipLaunchKernelGGL(win_attn_backward_mfma_kernel<false>, dim3((unsigned)windows, (unsigned)heads), dim3(256), wa_bwd_lds(N), s, (const uint16_t*)qkv, bias,
+                         (const uint16_t*)out, lse, (const uint16_t*)dout, (uint16_t*)dqkv, ds, N, heads, scale, tab, ws);
   } else {
     if (esam3_allow_dyn_lds((const void*)win_attn_backward_kernel<1>, lds_max)) return -1;
     hipLaunchKernelGGL(win_attn_backward_kernel<1>, dim3((unsigned)windows, (unsigned)heads, 2), dim3(threads), lds, s, (const uint16_t*)qkv, bias,

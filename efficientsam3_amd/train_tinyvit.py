@@ -72,12 +72,21 @@ def layernorm_backward(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, m
     return dx, dgamma, dbeta
 
 
-def win_attn_forward(qkv: torch.Tensor, bias: torch.Tensor, heads: int, scale: float):
-    """qkv [windows, N, heads * 96] (per head q | k | v), bias [heads, N, N] fp32 -> (out [windows, N, heads * 32], lse [windows, heads, N])"""
+def _tab_ok(tab, ws, n, heads) -> bool:
+    return tab is not None and ws * ws == n and ws <= 16 and tab.is_cuda and tab.dtype == torch.float32 and tab.is_contiguous() and tuple(tab.shape) == (heads, n)
+
+
+def win_attn_forward(qkv: torch.Tensor, bias: torch.Tensor, heads: int, scale: float, tab: torch.Tensor = None, ws: int = 0):
+    """qkv [windows, N, heads * 96] (per head q | k | v), bias [heads, N, N] fp32 -> (out [windows, N, heads * 32], lse [windows, heads, N]).
+    ``tab`` [heads, ws ws] = the attention_biases parameter ``bias`` was gathered from (N = ws ws): the bf16 kernels index it from LDS"""
     nw, n, _ = qkv.shape
     out = torch.empty((nw, n, heads * HEAD_DIM), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((nw, heads, n), dtype=torch.float32, device=qkv.device)
     with torch.cuda.device(qkv.device):
+        if _tab_ok(tab, ws, n, heads):
+            _lib.check(_lib.load().esam3_win_attn_train_forward_tab(_DT[qkv.dtype], qkv.data_ptr(), bias.data_ptr(), tab.data_ptr(), ws, out.data_ptr(),
+                                                                    lse.data_ptr(), nw, heads, float(scale), tb._stream()), "esam3_win_attn_train_forward_tab")
+            return out, lse
         _lib.check(_lib.load().esam3_win_attn_train_forward(_DT[qkv.dtype], qkv.data_ptr(), bias.data_ptr(), out.data_ptr(), lse.data_ptr(), nw, n, heads,
                                                             float(scale), tb._stream()), "esam3_win_attn_train_forward")
     return out, lse
@@ -86,7 +95,8 @@ def win_attn_forward(qkv: torch.Tensor, bias: torch.Tensor, heads: int, scale: f
 DS_CHUNK_BYTES = 256 << 20   # bound on the transient logits-gradient tensor of win_attn_backward
 
 
-def win_attn_backward(qkv: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, lse: torch.Tensor, dout: torch.Tensor, heads: int, scale: float):
+def win_attn_backward(qkv: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, lse: torch.Tensor, dout: torch.Tensor, heads: int, scale: float,
+                      tab: torch.Tensor = None, ws: int = 0):
     """-> (dqkv like qkv, dbias [heads, N, N] fp32 = the logits' gradient summed over the windows)"""
     nw, n, _ = qkv.shape
     assert dout.shape == out.shape and dout.dtype == qkv.dtype and dout.is_contiguous()
@@ -102,9 +112,14 @@ def win_attn_backward(qkv: torch.Tensor, bias: torch.Tensor, out: torch.Tensor, 
     with torch.cuda.device(qkv.device):
         for a in range(0, nw, chunk):
             e = min(nw, a + chunk)
-            _lib.check(lib.esam3_win_attn_train_backward(_DT[qkv.dtype], qkv[a:e].data_ptr(), bias.data_ptr(), out[a:e].data_ptr(), lse[a:e].data_ptr(),
-                                                         dout[a:e].data_ptr(), dqkv[a:e].data_ptr(), ds.data_ptr(), e - a, n, heads, float(scale),
-                                                         tb._stream()), "esam3_win_attn_train_backward")
+            if _tab_ok(tab, ws, n, heads):
+                _lib.check(lib.esam3_win_attn_train_backward_tab(_DT[qkv.dtype], qkv[a:e].data_ptr(), bias.data_ptr(), tab.data_ptr(), ws, out[a:e].data_ptr(),
+                                                                 lse[a:e].data_ptr(), dout[a:e].data_ptr(), dqkv[a:e].data_ptr(), ds.data_ptr(), e - a, heads,
+                                                                 float(scale), tb._stream()), "esam3_win_attn_train_backward_tab")
+            else:
+                _lib.check(lib.esam3_win_attn_train_backward(_DT[qkv.dtype], qkv[a:e].data_ptr(), bias.data_ptr(), out[a:e].data_ptr(), lse[a:e].data_ptr(),
+                                                             dout[a:e].data_ptr(), dqkv[a:e].data_ptr(), ds.data_ptr(), e - a, n, heads, float(scale),
+                                                             tb._stream()), "esam3_win_attn_train_backward")
             part = tb.colsum(ds[:e - a])
             dbias = part if dbias is None else dbias.add_(part)
     return dqkv, dbias.reshape(heads, n, n)
@@ -199,12 +214,12 @@ class WindowAttentionTrain:
     def forward(self, xw: torch.Tensor) -> torch.Tensor:
         self.qkv_out = self.qkv.forward(self.norm.forward(xw))
         self.ab = attn_bias_gather(self.biases, self.ws)
-        self.out, self.lse = win_attn_forward(self.qkv_out, self.ab, self.heads, self.scale)
+        self.out, self.lse = win_attn_forward(self.qkv_out, self.ab, self.heads, self.scale, tab=self.biases, ws=self.ws)
         return self.proj.forward(self.out)
 
     def backward(self, dy: torch.Tensor):
         d_out, g_proj = self.proj.backward(dy)
-        dqkv, dbias_full = win_attn_backward(self.qkv_out, self.ab, self.out, self.lse, d_out, self.heads, self.scale)
+        dqkv, dbias_full = win_attn_backward(self.qkv_out, self.ab, self.out, self.lse, d_out, self.heads, self.scale, tab=self.biases, ws=self.ws)
         d_norm, g_qkv = self.qkv.backward(dqkv)
         dx, g_norm = self.norm.backward(d_norm)
         grads = {"attention_biases": attn_bias_grad(dbias_full, self.ws)}

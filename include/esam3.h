@@ -356,6 +356,14 @@ int esam3_win_attn_train_forward(int dtype, const void* qkv_dev, const float* bi
                                  float scale, void* hip_stream);
 int esam3_win_attn_train_backward(int dtype, const void* qkv_dev, const float* bias_dev, const void* out_dev, const float* lse_dev,
                                   const void* dout_dev, void* dqkv_dev, float* ds_dev, int windows, int N, int heads, float scale, void* hip_stream);
+/* The same two operations given the attention_biases parameter itself beside the gathered table: tab_dev [heads][ws * ws], N = ws * ws tokens,
+ * bias[h][i][j] = tab[h][|dy| * ws + |dx|] (tiny_vit.py:240-254; ws <= 16).  The bf16 kernels (round 6: the products on the matrix unit, as the
+ * reference's autocast runs them) index the head's row of `tab` from LDS; fp32 reads `bias_dev` as before. */
+int esam3_win_attn_train_forward_tab(int dtype, const void* qkv_dev, const float* bias_dev, const float* tab_dev, int ws, void* out_dev, float* lse_dev,
+                                     int windows, int heads, float scale, void* hip_stream);
+int esam3_win_attn_train_backward_tab(int dtype, const void* qkv_dev, const float* bias_dev, const float* tab_dev, int ws, const void* out_dev,
+                                      const float* lse_dev, const void* dout_dev, void* dqkv_dev, float* ds_dev, int windows, int heads, float scale,
+                                      void* hip_stream);
 int esam3_attn_bias_gather_sum(const float* full_dev, const int* start_dev, const int* items_dev, float* out_dev, int heads, int NN, int n_off,
                                void* hip_stream);
 

@@ -71,6 +71,10 @@ def test_window_attention_kernels_vs_autograd(mode, nw, ws, heads):
         _close(dbias, br.grad, mode, "d attention_biases", f32=5e-5)
     else:   # D_i = dO_i . O_i uses the bf16-rounded output: an error of 2^-9 |dO| |O| on every logit gradient of the row
         assert _rel_l2(dqkv, qr.grad) <= 1.5e-2 and _rel_l2(dbias, br.grad) <= 1.5e-2, (_rel_l2(dqkv, qr.grad), _rel_l2(dbias, br.grad))
+    # the form that takes the attention_biases parameter itself (indexed from LDS by the bf16 kernels): the same results as with the gathered table
+    out_t, lse_t = tt.win_attn_forward(qkv.cuda(), ab, heads, 32 ** -0.5, tab=biases.cuda().contiguous(), ws=ws)
+    dqkv_t, dbias_full_t = tt.win_attn_backward(qkv.cuda(), ab, out, lse, dout.cuda(), heads, 32 ** -0.5, tab=biases.cuda().contiguous(), ws=ws)
+    assert torch.equal(out_t, out) and torch.equal(lse_t, lse) and torch.equal(dqkv_t, dqkv) and torch.equal(dbias_full_t, dbias_full)
     if nw >= 3:   # the chunked walk over the windows (bounded logits-gradient tensor): same d(qkv) bit for bit, the bias gradient within the
         old = tt.DS_CHUNK_BYTES                                           # rounding of another summation order
         tt.DS_CHUNK_BYTES = 2 * heads * n * n * 4                        # two windows per chunk, a ragged last chunk for odd counts
