@@ -367,7 +367,8 @@ __global__ __launch_bounds__(256) void win_attn_backward_kernel(const typename V
 // 16-byte LDS read), which asks for
 //   - q, k, v, dO staged row-major [token][32] AND (q, k, dO; v in the forward) transposed [32][token] in LDS;
 //   - P and dS tiles rounded to bf16 and passed through a per-wave LDS scratch, written in the orientation the next product reads.
-// One workgroup per (window, head), four waves; N is padded to 32-token tiles with zero rows (their P / dS are forced to 0).
+// One workgroup per (window, head), NW = 4 or 8 waves (8 when the 7 tiles of a 196-token window would otherwise take two rounds of four waves and
+// the LDS still fits); N is padded to 32-token tiles with zero rows (their P / dS are forced to 0).
 // Backward: phase B gives a wave the key tiles J = wave, wave + 4, .. (dK_J, dV_J accumulated over all query tiles, dS written for the bias
 // gradient), phase A the query tiles (dQ_I over all key tiles); logits and probabilities are recomputed in both (4 of the 14 MFMAs per tile pair).
 typedef float wa_f32x16 __attribute__((ext_vector_type(16)));
@@ -392,7 +393,7 @@ __device__ __forceinline__ wa_f32x16 wa_zero() {
 }
 // rows [0, NP) of a [N][ld] bf16 matrix (32 channels from `src`) -> natural [NP][WA_P] and (if T) transposed [32][TP]; zeros past N
 __device__ __forceinline__ void wa_stage(const uint16_t* __restrict__ src, int ld, int N, int NP, uint16_t* nat, uint16_t* T, int TP) {
-  for (int c = threadIdx.x; c < NP * 4; c += 256) {
+  for (int c = threadIdx.x; c < NP * 4; c += blockDim.x) {
     const int r = c >> 2, part = c & 3;
     uint4 q = make_uint4(0u, 0u, 0u, 0u);
     if (r < N) q = *reinterpret_cast<const uint4*>(src + (int64_t)r * ld + part * 8);
@@ -408,8 +409,8 @@ __device__ __forceinline__ void wa_stage(const uint16_t* __restrict__ src, int l
   }
 }
 
-template <bool TAB>
-__global__ __launch_bounds__(256) void win_attn_forward_mfma_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ bias,
+template <bool TAB, int NW>
+__global__ __launch_bounds__(64 * NW) void win_attn_forward_mfma_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ bias,
                                                                     uint16_t* __restrict__ out, float* __restrict__ lse, int N, int heads, float scale,
                                                                     const float* __restrict__ tab, int ws) {
   // `tab` [heads][ws ws] (N = ws ws): the attention_biases parameter itself (tiny_vit.py:240-254: offset (|dy|, |dx|) has index |dy| ws + |dx|);
@@ -421,15 +422,15 @@ __global__ __launch_bounds__(256) void win_attn_forward_mfma_kernel(const uint16
   uint16_t* sQ = wsm;
   uint16_t* sK = sQ + NP * WA_P;
   uint16_t* sVT = sK + NP * WA_P;          // [32][TP]
-  uint16_t* scr = sVT + 32 * TP;           // [4 waves][32][WA_P]
-  float* sl = reinterpret_cast<float*>(scr + 4 * 32 * WA_P);   // [4 waves][32]
-  float* stab = sl + 4 * 32;                                    // [256]
+  uint16_t* scr = sVT + 32 * TP;           // [NW waves][32][WA_P]
+  float* sl = reinterpret_cast<float*>(scr + NW * 32 * WA_P);   // [NW waves][32]
+  float* stab = sl + NW * 32;                                   // [256]
   uint16_t* spos = reinterpret_cast<uint16_t*>(stab + 256);     // [NP]: (row << 8) | column of the token in its window
   const int w = blockIdx.x, h = blockIdx.y, ld = heads * 3 * HD, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint16_t* base = qkv + (int64_t)w * N * ld + h * 3 * HD;
   if constexpr (TAB) {
-    for (int t = threadIdx.x; t < 256; t += 256) stab[t] = t < N ? tab[(int64_t)h * N + t] : 0.f;
-    for (int t = threadIdx.x; t < NP; t += 256) spos[t] = t < N ? (uint16_t)(((t / ws) << 8) | (t % ws)) : (uint16_t)0;
+    for (int t = threadIdx.x; t < 256; t += 64 * NW) stab[t] = t < N ? tab[(int64_t)h * N + t] : 0.f;
+    for (int t = threadIdx.x; t < NP; t += 64 * NW) spos[t] = t < N ? (uint16_t)(((t / ws) << 8) | (t % ws)) : (uint16_t)0;
   }
   wa_stage(base, ld, N, NP, sQ, nullptr, TP);
   wa_stage(base + HD, ld, N, NP, sK, nullptr, TP);
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(256) void win_attn_forward_mfma_kernel(const uint16
       return bh[(int64_t)a * N + b];
     }
   };
-  for (int I = wave; I < NT; I += 4) {
+  for (int I = wave; I < NT; I += NW) {
     const int i = I * 32 + (lane & 31);        // this lane's query (the tiles are S^T: column = query, rows = keys)
     wa_f32x16 st[NTMAX];
     float mx = -3.0e38f;
@@ -505,8 +506,8 @@ __global__ __launch_bounds__(256) void win_attn_forward_mfma_kernel(const uint16
   }
 }
 
-template <bool TAB>
-__global__ __launch_bounds__(256) void win_attn_backward_mfma_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ bias,
+template <bool TAB, int NW>
+__global__ __launch_bounds__(64 * NW) void win_attn_backward_mfma_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ bias,
                                                                      const uint16_t* __restrict__ out, const float* __restrict__ lse,
                                                                      const uint16_t* __restrict__ dout, uint16_t* __restrict__ dqkv,
                                                                      float* __restrict__ ds_out, int N, int heads, float scale,
@@ -520,15 +521,15 @@ __global__ __launch_bounds__(256) void win_attn_backward_mfma_kernel(const uint1
   uint16_t* sQT = sdO + NP * WA_P;         // [32][TP]
   uint16_t* sKT = sQT + 32 * TP;
   uint16_t* sdOT = sKT + 32 * TP;
-  uint16_t* scr = sdOT + 32 * TP;          // [4 waves][2][32][WA_P]
-  float* slse = reinterpret_cast<float*>(scr + 4 * 2 * 32 * WA_P);   // [NP]
+  uint16_t* scr = sdOT + 32 * TP;          // [NW waves][2][32][WA_P]
+  float* slse = reinterpret_cast<float*>(scr + NW * 2 * 32 * WA_P);   // [NP]
   float* sd = slse + NP;                                              // [NP]
   float* stab = sd + NP;                                              // [256]
   uint16_t* spos = reinterpret_cast<uint16_t*>(stab + 256);           // [NP]
   const int w = blockIdx.x, h = blockIdx.y, ld = heads * 3 * HD, ldo = heads * HD, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if constexpr (TAB) {
-    for (int t = threadIdx.x; t < 256; t += 256) stab[t] = t < N ? tab[(int64_t)h * N + t] : 0.f;
-    for (int t = threadIdx.x; t < NP; t += 256) spos[t] = t < N ? (uint16_t)(((t / ws) << 8) | (t % ws)) : (uint16_t)0;
+    for (int t = threadIdx.x; t < 256; t += 64 * NW) stab[t] = t < N ? tab[(int64_t)h * N + t] : 0.f;
+    for (int t = threadIdx.x; t < NP; t += 64 * NW) spos[t] = t < N ? (uint16_t)(((t / ws) << 8) | (t % ws)) : (uint16_t)0;
   }
   const uint16_t* base = qkv + (int64_t)w * N * ld + h * 3 * HD;
   const uint16_t* dobase = dout + (int64_t)w * N * ldo + h * HD;
@@ -536,7 +537,7 @@ __global__ __launch_bounds__(256) void win_attn_backward_mfma_kernel(const uint1
   wa_stage(base + HD, ld, N, NP, sK, sKT, TP);
   wa_stage(base + 2 * HD, ld, N, NP, sV, nullptr, TP);
   wa_stage(dobase, ldo, N, NP, sdO, sdOT, TP);
-  for (int t = threadIdx.x; t < NP; t += 256) {
+  for (int t = threadIdx.x; t < NP; t += 64 * NW) {
     float d = 0.f, ls = 0.f;
     if (t < N) {
       float a[HD], b[HD];
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(256) void win_attn_backward_mfma_kernel(const uint1
     }
   };
   // ---- phase B: dK_J, dV_J, dS ----
-  for (int J = wave; J < NT; J += 4) {
+  for (int J = wave; J < NT; J += NW) {
     wa_f32x16 dk = wa_zero(), dv = wa_zero();
     const int j = J * 32 + jl;
     for (int I = 0; I < NT; ++I) {
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(256) void win_attn_backward_mfma_kernel(const uint1
     }
   }
   // ---- phase A: dQ_I ----
-  for (int I = wave; I < NT; I += 4) {
+  for (int I = wave; I < NT; I += NW) {
     wa_f32x16 dq = wa_zero();
     for (int J = 0; J < NT; ++J) {
       const int j = J * 32 + jl;
@@ -628,8 +629,13 @@ __global__ __launch_bounds__(256) void win_attn_backward_mfma_kernel(const uint1
     }
   }
 }
-static int wa_fwd_lds(int N) { const int NP = (N + 31) & ~31; return (2 * NP * WA_P + 32 * (NP + 8) + 4 * 32 * WA_P) * 2 + 4 * 32 * 4 + 1024 + 2 * NP; }
-static int wa_bwd_lds(int N) { const int NP = (N + 31) & ~31; return (4 * NP * WA_P + 3 * 32 * (NP + 8) + 4 * 2 * 32 * WA_P) * 2 + 2 * NP * 4 + 1024 + 2 * NP; }
+static int wa_fwd_lds(int N, int NW) { const int NP = (N + 31) & ~31; return (2 * NP * WA_P + 32 * (NP + 8) + NW * 32 * WA_P) * 2 + NW * 32 * 4 + 1024 + 2 * NP; }
+static int wa_bwd_lds(int N, int NW) { const int NP = (N + 31) & ~31; return (4 * NP * WA_P + 3 * 32 * (NP + 8) + NW * 2 * 32 * WA_P) * 2 + 2 * NP * 4 + 1024 + 2 * NP; }
+static int wa_waves(int N, bool bwd, bool tab) {   // 8 waves when the window has more than four tiles and the LDS still fits 160 KB
+  const int tiles = (N + 31) / 32;
+  if (tiles <= 4 || !tab || esam3_dev_flag("ESAM3_WATTN_4W")) return 4;   // (the form reading the gathered table spills at 256 VGPRs)
+  return (bwd ? wa_bwd_lds(N, 8) : wa_fwd_lds(N, 8)) <= 160 * 1024 ? 8 : 4;
+}
 
 // out[h][o] = sum over the items of offset o (CSR: start[o] .. start[o + 1]) of full[h][item]: one wavefront per (head, offset), lane l adds
 // the items l, l + 64, ... in list order, the 64 lane sums are added by the butterfly of wave_sum -- a fixed order (deterministic)
@@ -710,14 +716,17 @@ static int win_attn_forward_impl(int dtype, const void* qkv, const float* bias, 
     hipLaunchKernelGGL(win_attn_forward_kernel<0>, dim3((unsigned)windows, (unsigned)heads), dim3(threads), lds, s, (const float*)qkv, bias, (float*)out, lse, N,
                        heads, scale);
   } else if (!esam3_dev_flag("ESAM3_WATTN_OLD")) {   // round 6: on the matrix unit
-    if (esam3_allow_dyn_lds((const void*)win_attn_forward_mfma_kernel<true>, wa_fwd_lds(256))) return -1;
-    if (esam3_allow_dyn_lds((const void*)win_attn_forward_mfma_kernel<false>, wa_fwd_lds(256))) return -1;
-    if (tab)
-      hipLaunchKernelGGL(win_attn_forward_mfma_kernel<true>, dim3((unsigned)windows, (unsigned)heads), dim3(256), wa_fwd_lds(N), s, (const uint16_t*)qkv, bias,
-                         (uint16_t*)out, lse, N, heads, scale, tab, ws);
-    else
-      hipLaunchKernelGGL(win_attn_forward_mfma_kernel<false>, dim3((unsigned)windows, (unsigned)heads), dim3(256), wa_fwd_lds(N), s, (const uint16_t*)qkv, bias,
-                         (uint16_t*)out, lse, N, heads, scale, tab, ws);
+    const int nw = wa_waves(N, false, tab != nullptr), lds_b = wa_fwd_lds(N, nw);
+#define ESAM3_WA_FWD(TAB_, NW_)                                                                                                          \
+  do {                                                                                                                                   \
+    if (esam3_allow_dyn_lds((const void*)win_attn_forward_mfma_kernel<TAB_, NW_>, 160 * 1024)) return -1;                                \
+    hipLaunchKernelGGL((win_attn_forward_mfma_kernel<TAB_, NW_>), dim3((unsigned)windows, (unsigned)heads), dim3(64 * NW_), lds_b, s,   \
+                       (const uint16_t*)qkv, bias, (uint16_t*)out, lse, N, heads, scale, tab, ws);                                       \
+  } while (0)
+    if (tab && nw == 8) ESAM3_WA_FWD(true, 8);
+    else if (tab) ESAM3_WA_FWD(true, 4);
+    else ESAM3_WA_FWD(false, 4);
+#undef ESAM3_WA_FWD
   } else {
     if (esam3_allow_dyn_lds((const void*)win_attn_forward_kernel<1>, 2 * 256 * HD * (int)sizeof(float))) return -1;
     hipLaunchKernelGGL(win_attn_forward_kernel<1>, dim3((unsigned)windows, (unsigned)heads), dim3(threads), lds, s, (const uint16_t*)qkv, bias, (uint16_t*)out,
@@ -751,14 +760,18 @@ static int win_attn_backward_impl(int dtype, const void* qkv, const float* bias,
     hipLaunchKernelGGL(win_attn_backward_kernel<0>, dim3((unsigned)windows, (unsigned)heads, 2), dim3(threads), lds, s, (const float*)qkv, bias, (const float*)out,
                        lse, (const float*)dout, (float*)dqkv, ds, N, heads, scale);
   } else if (!esam3_dev_flag("ESAM3_WATTN_OLD")) {   // round 6: on the matrix unit
-    if (esam3_allow_dyn_lds((const void*)win_attn_backward_mfma_kernel<true>, wa_bwd_lds(256))) return -1;
-    if (esam3_allow_dyn_lds((const void*)win_attn_backward_mfma_kernel<false>, wa_bwd_lds(256))) return -1;
-    if (tab)
-      hipLaunchKernelGGL(win_attn_backward_mfma_kernel<true>, dim3((unsigned)windows, (unsigned)heads), dim3(256), wa_bwd_lds(N), s, (const uint16_t*)qkv, bias,
-                         (const uint16_t*)out, lse, (const uint16_t*)dout, (uint16_t*)dqkv, ds, N, heads, scale, tab, ws);
-    else
-      hipLaunchKernelGGL(win_attn_backward_mfma_kernel<false>, dim3((unsigned)windows, (unsigned)heads), dim3(256), wa_bwd_lds(N), s, (const uint16_t*)qkv, bias,
-                         (const uint16_t*)out, lse, (const uint16_t*)dout, (uint16_t*)dqkv, ds, N, heads, scale, tab, ws);
+    const int nw = wa_waves(N, true, tab != nullptr), lds_b = wa_bwd_lds(N, nw);
+#define ESAM3_WA_BWD(TAB_, NW_)                                                                                                          \
+  do {                                                                                                                                   \
+    if (esam3_allow_dyn_lds((const void*)win_attn_backward_mfma_kernel<TAB_, NW_>, 160 * 1024)) return -1;                               \
+    hipLaunchKernelGGL((win_attn_backward_mfma_kernel<TAB_, NW_>), dim3((unsigned)windows, (unsigned)heads), dim3(64 * NW_), lds_b, s,  \
+                       (const uint16_t*)qkv, bias, (const uint16_t*)out, lse, (const uint16_t*)dout, (uint16_t*)dqkv, ds, N, heads,      \
+                       scale, tab, ws);                                                                                                  \
+  } while (0)
+    if (tab && nw == 8) ESAM3_WA_BWD(true, 8);
+    else if (tab) ESAM3_WA_BWD(true, 4);
+    else ESAM3_WA_BWD(false, 4);
+#undef ESAM3_WA_BWD
   } else {
     if (esam3_allow_dyn_lds((const void*)win_attn_backward_kernel<1>, lds_max)) return -1;
     hipLaunchKernelGGL(win_attn_backward_kernel<1>, dim3((unsigned)windows, (unsigned)heads, 2), dim3(threads), lds, s, (const uint16_t*)qkv, bias,
