@@ -633,6 +633,7 @@ static int wa_fwd_lds(int N, int NW) { const int NP = (N + 31) & ~31; return (2 
 static int wa_bwd_lds(int N, int NW) { const int NP = (N + 31) & ~31; return (4 * NP * WA_P + 3 * 32 * (NP + 8) + NW * 2 * 32 * WA_P) * 2 + 2 * NP * 4 + 1024 + 2 * NP; }
 static int wa_waves(int N, bool bwd, bool tab) {   // 8 waves when the window has more than four tiles and the LDS still fits 160 KB
   const int tiles = (N + 31) / 32;
+  if (tiles <= 2 && !esam3_dev_flag("ESAM3_WATTN_4W")) return 2;   // a 49-token window is two tiles: two of four waves would idle
   if (tiles <= 4 || !tab || esam3_dev_flag("ESAM3_WATTN_4W")) return 4;   // (the form reading the gathered table spills at 256 VGPRs)
   return (bwd ? wa_bwd_lds(N, 8) : wa_fwd_lds(N, 8)) <= 160 * 1024 ? 8 : 4;
 }
@@ -724,7 +725,9 @@ static int win_attn_forward_impl(int dtype, const void* qkv, const float* bias, 
                        (const uint16_t*)qkv, bias, (uint16_t*)out, lse, N, heads, scale, tab, ws);                                       \
   } while (0)
     if (tab && nw == 8) ESAM3_WA_FWD(true, 8);
+    else if (tab && nw == 2) ESAM3_WA_FWD(true, 2);
     else if (tab) ESAM3_WA_FWD(true, 4);
+    else if (nw == 2) ESAM3_WA_FWD(false, 2);
     else ESAM3_WA_FWD(false, 4);
 #undef ESAM3_WA_FWD
   } else {
@@ -769,7 +772,9 @@ static int win_attn_backward_impl(int dtype, const void* qkv, const float* bias,
                        scale, tab, ws);                                                                                                  \
   } while (0)
     if (tab && nw == 8) ESAM3_WA_BWD(true, 8);
+    else if (tab && nw == 2) ESAM3_WA_BWD(true, 2);
     else if (tab) ESAM3_WA_BWD(true, 4);
+    else if (nw == 2) ESAM3_WA_BWD(false, 2);
     else ESAM3_WA_BWD(false, 4);
 #undef ESAM3_WA_BWD
   } else {
