@@ -108,6 +108,11 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 // shifted, zero-padded copies the host made before: stage1_train.conv3x3_wgrad of round 4).  partial [tap][split][N][K].
 struct WgradGather {
   int on, zs, OH, OW, IH, IW, stride;
+  // round 6, XCD-aware tile order: gx > 0 = a 1-D launch of 8 ceil(gx gy gz / 8) workgroups; hardware deals consecutive workgroup ids to the 8
+  // XCDs in turn, so workgroup L takes logical tile (L % 8) ceil(T / 8) + L / 8 -- every XCD walks a contiguous range of (row split, tap)
+  // groups and the gx gy tiles of a group share ONE L2.  With the plain 3-D grid the 64 tiles of the head's 3x3 conv (one tap, one split)
+  // were spread over all eight L2s: each fetched the whole dy slab, 5 GB over the fabric per call (1.5 ms at 400 TFLOP/s).
+  int gx, gy, gz;
 };
 // TW (round 6): the tile of dW a workgroup owns, 64 x 64 or (bf16) 128 x 128 -- a wave then owns a 64 x 64 quadrant as 2 x 2 MFMA blocks.  With
 // 64 x 64 tiles every 64 channels of dy and x loaded from L2 feed 32 multiply-adds per byte: the wide weights of the last stages and the head's
@@ -117,7 +122,7 @@ template <int DT, int TW = 64>
 __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::type* __restrict__ dy, int ldy,
                                                     const typename TElem<DT>::type* __restrict__ x, int ldx, int64_t M, int N, int K,
                                                     int64_t rows_per_split, float* __restrict__ partial /* [splits][N][K] */,
-                                                    WgradGather gt = WgradGather{0, 0, 0, 0, 0, 0, 0}) {
+                                                    WgradGather gt = WgradGather{0, 0, 0, 0, 0, 0, 0, 0, 0, 0}) {
   // rows per step: 64 in fp32 (two 16.6 KB tiles), 128 in bf16 (round 6: half the barriers per row; a split is any multiple of 64 rows, the
   // tail of a step past the split's end is staged as zeros)
   static_assert(TW == 64 || (TW == 128 && DT == 1), "128 x 128 tiles in bf16 only");
@@ -126,8 +131,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::ty
   // fp32: plain [row][64 ch] (+1 float pad); bf16: TW / 16 sub-tiles per operand
   __shared__ __attribute__((aligned(16))) char sA[DT == 0 ? ROWS * 65 * 4 : (TW / 16) * VS];
   __shared__ __attribute__((aligned(16))) char sB[DT == 0 ? ROWS * 65 * 4 : (TW / 16) * VS];
-  const int n0 = blockIdx.y * TW, k0 = blockIdx.x * TW;
-  const int zsplit = gt.on ? (int)blockIdx.z % gt.zs : (int)blockIdx.z, tap = gt.on ? (int)blockIdx.z / gt.zs : 0;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (gt.gx > 0) {
+    const int T = gt.gx * gt.gy * gt.gz, T8 = (T + 7) >> 3;
+    const int M = ((int)blockIdx.x & 7) * T8 + ((int)blockIdx.x >> 3);
+    if (M >= T) return;
+    bx = M % gt.gx;
+    by = (M / gt.gx) % gt.gy;
+    bz = M / (gt.gx * gt.gy);
+  }
+  const int n0 = by * TW, k0 = bx * TW;
+  const int zsplit = gt.on ? bz % gt.zs : bz, tap = gt.on ? bz / gt.zs : 0;
   const int64_t r_begin = (int64_t)zsplit * rows_per_split;
   const int64_t r_end = r_begin + rows_per_split < M ? r_begin + rows_per_split : M;
   const int gky = tap / 3 - 1, gkx = tap % 3 - 1;
@@ -162,7 +176,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::ty
   constexpr int NCH = DT == 0 ? (ROWS * 16) / 256 : (ROWS * CPRW) / 256;   // chunks per thread and operand: 4 (fp32) / 4 | 8 (bf16)
   typedef typename std::conditional<DT == 0, float4, uint4>::type chunk_t;
   chunk_t ra[NCH], rb[NCH];
-  auto fetch = [&](int64_t r0) {
+  // GATHER: the x rows of a step's ROWS output rows, computed once per row by the first ROWS threads (round 6: every thread recomputed the
+  // row of each of its 4 - 8 chunks -- two integer divisions each, ~5 000 VALU cycles per 128-row step against 1 024 of MFMA: the 3x3 weight
+  // gradient of the head ran at 400 TFLOP/s); double-buffered: step s + 1's table is written between the two barriers of step s
+  __shared__ int xr_tab[2][ROWS];
+  auto fill = [&](int buf, int64_t r0) {
+    if (gt.on && tid < ROWS) xr_tab[buf][tid] = r0 + tid < r_end ? (int)xrow(r0 + tid) : -1;
+  };
+  auto fetch = [&](int64_t r0, int buf) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int c = tid + 256 * i;
@@ -171,7 +192,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::ty
         float4 av = make_float4(0.f, 0.f, 0.f, 0.f), bv = av;
         if (r0 + row < r_end) {
           if (n0 + ch < N) av = *reinterpret_cast<const float4*>(dy + (r0 + row) * ldy + n0 + ch);   // N, K multiples of 8
-          const int64_t xr = xrow(r0 + row);
+          const int64_t xr = gt.on ? (int64_t)xr_tab[buf][row] : r0 + row;
           if (k0 + ch < K && xr >= 0) bv = *reinterpret_cast<const float4*>(x + xr * ldx + k0 + ch);
         }
         ra[i] = av; rb[i] = bv;
@@ -180,7 +201,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::ty
         uint4 av = make_uint4(0u, 0u, 0u, 0u), bv = av;
         if (r0 + row < r_end) {
           if (n0 + ch8 * 8 < N) av = *reinterpret_cast<const uint4*>(dy + (r0 + row) * ldy + n0 + ch8 * 8);
-          const int64_t xr = xrow(r0 + row);
+          const int64_t xr = gt.on ? (int64_t)xr_tab[buf][row] : r0 + row;
           if (k0 + ch8 * 8 < K && xr >= 0) bv = *reinterpret_cast<const uint4*>(x + xr * ldx + k0 + ch8 * 8);
         }
         ra[i] = av; rb[i] = bv;
@@ -205,12 +226,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::ty
       }
     }
   };
-  if (r_begin < r_end) fetch(r_begin);
-  for (int64_t r0 = r_begin; r0 < r_end; r0 += ROWS) {
+  if (gt.on) {
+    fill(0, r_begin);
+    __syncthreads();
+  }
+  if (r_begin < r_end) fetch(r_begin, 0);
+  int step = 0;
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += ROWS, ++step) {
     __syncthreads();
     stash();
+    if (r0 + ROWS < r_end) fill((step + 1) & 1, r0 + ROWS);
     __syncthreads();
-    if (r0 + ROWS < r_end) fetch(r0 + ROWS);   // in flight under the products below
+    if (r0 + ROWS < r_end) fetch(r0 + ROWS, (step + 1) & 1);   // in flight under the products below
     if constexpr (DT == 0) {
       const float* fa = reinterpret_cast<const float*>(sA) + wn * 32 + l31;
       const float* fb = reinterpret_cast<const float*>(sB) + wk * 32 + l31;
@@ -244,7 +271,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const typename TElem<DT>::ty
     }
   }
   // accumulator layout: column = l31 (the K index), rows (r & 3) + 8 (r >> 2) + 4 g (the N index)
-  float* out = partial + (int64_t)blockIdx.z * N * K;
+  float* out = partial + (int64_t)bz * N * K;
 #pragma unroll
   for (int i = 0; i < NBLK; ++i)
 #pragma unroll
@@ -1477,10 +1504,15 @@ int esam3_linear_wgrad(int dtype, const void* dy, const void* x, int64_t M, int 
   const int64_t rps = (tiles + splits - 1) / splits * WG_ROWS;
   const int zs = (int)((M + rps - 1) / rps);  // splits actually used
   float* partial = (float*)workspace;
-  const dim3 grid((unsigned)((K + tile - 1) / tile), (unsigned)((N + tile - 1) / tile), (unsigned)zs);
-  if (dtype == 0) hipLaunchKernelGGL((wgrad_kernel<0, 64>), grid, dim3(256), 0, s, (const float*)dy, N, (const float*)x, K, M, N, K, rps, partial, WgradGather{0, 0, 0, 0, 0, 0, 0});
-  else if (tile == 128) hipLaunchKernelGGL((wgrad_kernel<1, 128>), grid, dim3(256), 0, s, (const uint16_t*)dy, N, (const uint16_t*)x, K, M, N, K, rps, partial, WgradGather{0, 0, 0, 0, 0, 0, 0});
-  else hipLaunchKernelGGL((wgrad_kernel<1, 64>), grid, dim3(256), 0, s, (const uint16_t*)dy, N, (const uint16_t*)x, K, M, N, K, rps, partial, WgradGather{0, 0, 0, 0, 0, 0, 0});
+  dim3 grid((unsigned)((K + tile - 1) / tile), (unsigned)((N + tile - 1) / tile), (unsigned)zs);
+  WgradGather gt{0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (grid.x * grid.y >= 4 && !esam3_dev_flag("ESAM3_WGRAD_NO_XCD")) {   // several tiles share the rows of a split: keep them on one XCD
+    gt.gx = (int)grid.x; gt.gy = (int)grid.y; gt.gz = zs;
+    grid = dim3((unsigned)(8 * ((gt.gx * gt.gy * gt.gz + 7) / 8)));
+  }
+  if (dtype == 0) hipLaunchKernelGGL((wgrad_kernel<0, 64>), grid, dim3(256), 0, s, (const float*)dy, N, (const float*)x, K, M, N, K, rps, partial, gt);
+  else if (tile == 128) hipLaunchKernelGGL((wgrad_kernel<1, 128>), grid, dim3(256), 0, s, (const uint16_t*)dy, N, (const uint16_t*)x, K, M, N, K, rps, partial, gt);
+  else hipLaunchKernelGGL((wgrad_kernel<1, 64>), grid, dim3(256), 0, s, (const uint16_t*)dy, N, (const uint16_t*)x, K, M, N, K, rps, partial, gt);
   const int64_t nk = (int64_t)N * K;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nk + 63) / 64)), dim3(256), 0, s, partial, zs, nk, dw);
   if (dbias) {
@@ -1532,8 +1564,12 @@ int esam3_conv3x3_wgrad(int dtype, const void* dy, const void* x, int B, int IH,
     return -1;
   }
   float* partial = (float*)workspace;
-  const WgradGather gt{1, zs, OH, OW, IH, IW, stride};
-  const dim3 grid((unsigned)((K + tile - 1) / tile), (unsigned)((N + tile - 1) / tile), (unsigned)(9 * zs));
+  WgradGather gt{1, zs, OH, OW, IH, IW, stride, 0, 0, 0};
+  dim3 grid((unsigned)((K + tile - 1) / tile), (unsigned)((N + tile - 1) / tile), (unsigned)(9 * zs));
+  if (grid.x * grid.y >= 4 && !esam3_dev_flag("ESAM3_WGRAD_NO_XCD")) {
+    gt.gx = (int)grid.x; gt.gy = (int)grid.y; gt.gz = 9 * zs;
+    grid = dim3((unsigned)(8 * ((gt.gx * gt.gy * gt.gz + 7) / 8)));
+  }
   if (dtype == 0) hipLaunchKernelGGL((wgrad_kernel<0, 64>), grid, dim3(256), 0, s, (const float*)dy, N, (const float*)x, K, M, N, K, rps, partial, gt);
   else if (tile == 128) hipLaunchKernelGGL((wgrad_kernel<1, 128>), grid, dim3(256), 0, s, (const uint16_t*)dy, N, (const uint16_t*)x, K, M, N, K, rps, partial, gt);
   else hipLaunchKernelGGL((wgrad_kernel<1, 64>), grid, dim3(256), 0, s, (const uint16_t*)dy, N, (const uint16_t*)x, K, M, N, K, rps, partial, gt);
