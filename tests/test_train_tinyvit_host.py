@@ -17,7 +17,7 @@ from tests.test_train_blocks_host import _bn, _check, _to_nchw, _to_nhwc, cpu_ke
 from tests.test_train_repvit_host import repvit_kernels  # noqa: F401
 
 
-def _attn_core(qkv, bias, heads, scale):
+def _attn_core(qkv, bias, heads, scale, tab=None, ws=0):   # tab / ws: the compact-table form of the device kernels (the stand-in reads `bias`)
     nw, n, _ = qkv.shape
     q, k, v = qkv.view(nw, n, heads, 96).split([32, 32, 32], dim=3)
     q, k, v = q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)
@@ -38,7 +38,7 @@ def install_tinyvit_kernels(monkeypatch):  # noqa: F811
         dx = rstd.reshape(x.shape[:-1] + (1,)) * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))
         return dx, (dy * xh).reshape(-1, c).sum(0), dy.reshape(-1, c).sum(0)
 
-    def attn_bwd(qkv, bias, out, lse, dout, heads, scale):
+    def attn_bwd(qkv, bias, out, lse, dout, heads, scale, tab=None, ws=0):
         qr, br = qkv.clone().requires_grad_(True), bias.clone().requires_grad_(True)
         o, _ = _attn_core(qr, br, heads, scale)
         o.backward(dout)
