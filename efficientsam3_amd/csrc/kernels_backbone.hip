@@ -2734,11 +2734,17 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const TI* __restrict
   for (int j = 0; j < NCH; ++j) {
     const int ci = sub + lpr * j;
     ok[j] = ci < nchunk;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      gm[j][e] = ok[j] ? gamma[ci * 8 + e] : 0.f;
-      bt[j][e] = ok[j] ? beta[ci * 8 + e] : 0.f;
+    // 16-byte loads (round 6: element by element these were 16 single-dword loads per chunk -- as many load instructions as the wave's whole
+    // walk over its rows; same values)
+    float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, b0 = g0, b1 = g0;
+    if (ok[j]) {
+      g0 = *reinterpret_cast<const float4*>(gamma + ci * 8);
+      g1 = *reinterpret_cast<const float4*>(gamma + ci * 8 + 4);
+      b0 = *reinterpret_cast<const float4*>(beta + ci * 8);
+      b1 = *reinterpret_cast<const float4*>(beta + ci * 8 + 4);
     }
+    gm[j][0] = g0.x; gm[j][1] = g0.y; gm[j][2] = g0.z; gm[j][3] = g0.w; gm[j][4] = g1.x; gm[j][5] = g1.y; gm[j][6] = g1.z; gm[j][7] = g1.w;
+    bt[j][0] = b0.x; bt[j][1] = b0.y; bt[j][2] = b0.z; bt[j][3] = b0.w; bt[j][4] = b1.x; bt[j][5] = b1.y; bt[j][6] = b1.z; bt[j][7] = b1.w;
   }
   const float invC = 1.f / (float)C;
   for (int it = 0; it < iters; ++it) {
@@ -3398,7 +3404,8 @@ int esam3_launch_resize_shuffle(int dtype, const void* in, const float* bias, vo
 int esam3_launch_layernorm_io(int in_dtype, int out_dtype, const void* x, const void* res, const float* gamma, const float* beta,
                               void* out, int64_t rows, int C, float eps, int act, hipStream_t s) {
   const int esz = in_dtype == 0 ? 4 : 2, osz = out_dtype == 0 ? 4 : 2;
-  const bool aligned = !(((uintptr_t)x) & 15) && !(((uintptr_t)out) & 15) && !(res && (((uintptr_t)res) & 15)) && (C * esz) % 16 == 0 &&
+  const bool aligned = !(((uintptr_t)x) & 15) && !(((uintptr_t)out) & 15) && !(res && (((uintptr_t)res) & 15)) && !(((uintptr_t)gamma) & 15) &&
+                       !(((uintptr_t)beta) & 15) && (C * esz) % 16 == 0 &&
                        (C * osz) % 16 == 0;
   static const int no_vec = esam3_dev_flag("ESAM3_NO_LNVEC", 0);  // A/B, bisecting: 1 all, else that C
   const bool mixed = in_dtype != out_dtype;
