@@ -496,15 +496,31 @@ __global__ __launch_bounds__(256) void upscale_mask_kernel(const bf16_t* __restr
       fw[j][ks] = *reinterpret_cast<const u32x4*>(wt + (int64_t)(j * 32 + l31) * kp + (2 * ks + g) * 8);
   // this lane's 16 channels are 8q + 4g + e: bias and the four hypernetwork vectors at those channels
   float bs[16], hw[4][16];
+  // round 6: 4 + 16 vector loads (the lane's channels 8q + 4g .. + 3 are contiguous) where the element-wise form compiled to 16 dword and 64
+  // two-byte loads per wave -- for three 32-pixel fragments of work; same values
+  const bool vec_ok = (ld_h & 3) == 0 && !(((uintptr_t)hyper) & 7) && !(((uintptr_t)bias) & 15);
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < 4; ++q) {
+    const int c0 = 8 * q + 4 * g;
+    if (vec_ok) {
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias) b4 = *reinterpret_cast<const float4*>(bias + c0);
+      bs[4 * q] = b4.x; bs[4 * q + 1] = b4.y; bs[4 * q + 2] = b4.z; bs[4 * q + 3] = b4.w;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = 8 * q + 4 * g + e;
-      bs[4 * q + e] = bias ? bias[c] : 0.f;
+      for (int k = 0; k < 4; ++k) {
+        const uint2 u = *reinterpret_cast<const uint2*>(hyper + ((int64_t)bp * 4 + k) * ld_h + c0);
+        hw[k][4 * q] = __uint_as_float(u.x << 16); hw[k][4 * q + 1] = __uint_as_float(u.x & 0xffff0000u);
+        hw[k][4 * q + 2] = __uint_as_float(u.y << 16); hw[k][4 * q + 3] = __uint_as_float(u.y & 0xffff0000u);
+      }
+    } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) hw[k][4 * q + e] = to_f32<bf16_t>(hyper[((int64_t)bp * 4 + k) * ld_h + c]);
+      for (int e = 0; e < 4; ++e) {
+        bs[4 * q + e] = bias ? bias[c0 + e] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hw[k][4 * q + e] = to_f32<bf16_t>(hyper[((int64_t)bp * 4 + k) * ld_h + c0 + e]);
+      }
     }
+  }
   const bf16_t* ub = u1 + (int64_t)bp * P * 64;
   const bf16_t* fb = feat + (int64_t)img * P4 * 32;
   float* mb = masks + (int64_t)bp * 4 * P4;
