@@ -278,8 +278,8 @@ class Stage1Trainer:
         mse, cos, _ = distill_loss(p2, t2, valid)
         loss = (mse + self.cosine_weight * cos) / self.accumulation_steps
         # d(loss x scale) / d(preds).  The loss scale lives in the updater's device state (it moves when a step is skipped / after
-        # growth_interval clean steps); it is read back once per iteration -- the reference's loop synchronises every iteration too
-        # (loss.item(), torch.cuda.synchronize(): train_image_encoder_stage1.py:206,226)
+        # growth_interval clean steps).  Rounds 4-5 read it back once per iteration (the reference's loop synchronises every iteration too:
+        # loss.item(), torch.cuda.synchronize(), train_image_encoder_stage1.py:206,226); on the GPU path it now stays on the device
         if self.updater.amp and p2.is_cuda:
             # round 6: the scale is read by the kernel, from the updater's state (esam3_distill_loss_backward_ds): the step has no host
             # synchronisation left (the read-back was one, with ~1 ms of idle GPU behind it); a power of two, so the gradient is bit-identical
