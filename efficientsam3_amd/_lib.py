@@ -115,6 +115,7 @@ SIGNATURES = {
     "esam3_ln_train_backward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
     "esam3_win_attn_train_forward": (_I, [_I, _P, _P, _P, _P, _I, _I, _I, C.c_float, _P]),
     "esam3_win_attn_train_backward": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, C.c_float, _P]),
+    "esam3_window_partition": (_I, [_I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "esam3_win_attn_train_forward_tab": (_I, [_I, _P, _P, _P, _I, _P, _P, _I, _I, C.c_float, _P]),
     "esam3_win_attn_train_backward_tab": (_I, [_I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, C.c_float, _P]),
     "esam3_attn_bias_gather_sum": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),

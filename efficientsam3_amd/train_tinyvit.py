@@ -337,6 +337,12 @@ class TinyViTBlockTrain:
         ws = self.ws
         if h == ws and w == ws:
             return x.reshape(b, h * w, c)
+        if x.is_cuda and x.is_contiguous() and (c * x.element_size()) % 16 == 0:   # one copy on the device (esam3_window_partition)
+            nwy, nwx = (h + ws - 1) // ws, (w + ws - 1) // ws
+            out = torch.empty((b * nwy * nwx, ws * ws, c), dtype=x.dtype, device=x.device)
+            with torch.cuda.device(x.device):
+                _lib.check(_lib.load().esam3_window_partition(_DT[x.dtype], x.data_ptr(), out.data_ptr(), b, h, w, c, ws, 0, tb._stream()), "esam3_window_partition")
+            return out
         pad_b, pad_r = (ws - h % ws) % ws, (ws - w % ws) % ws
         if pad_b or pad_r:
             x = torch.nn.functional.pad(x, (0, 0, 0, pad_r, 0, pad_b))
@@ -348,6 +354,11 @@ class TinyViTBlockTrain:
         ws = self.ws
         if h == ws and w == ws:
             return xw.reshape(b, h, w, c)
+        if xw.is_cuda and xw.is_contiguous() and (c * xw.element_size()) % 16 == 0:
+            out = torch.empty((b, h, w, c), dtype=xw.dtype, device=xw.device)
+            with torch.cuda.device(xw.device):
+                _lib.check(_lib.load().esam3_window_partition(_DT[xw.dtype], xw.data_ptr(), out.data_ptr(), b, h, w, c, ws, 1, tb._stream()), "esam3_window_partition")
+            return out
         ph, pw = (h + ws - 1) // ws * ws, (w + ws - 1) // ws * ws
         x = xw.view(b, ph // ws, pw // ws, ws, ws, c).transpose(2, 3).reshape(b, ph, pw, c)
         return x[:, :h, :w].contiguous()

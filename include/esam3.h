@@ -366,6 +366,9 @@ int esam3_win_attn_train_backward_tab(int dtype, const void* qkv_dev, const floa
                                       void* hip_stream);
 int esam3_attn_bias_gather_sum(const float* full_dev, const int* start_dev, const int* items_dev, float* out_dev, int heads, int NN, int n_off,
                                void* hip_stream);
+/* TinyViTBlock's window partition / reverse (tiny_vit.py:350-374) as one copy: x_dev [B][H][W][C] <-> windows_dev [B * ceil(H/ws) * ceil(W/ws)][ws*ws][C]
+ * (zeros in the padded rows / columns; reverse = 1 drops them).  dtype 0 fp32 / 1 bf16; rows of a multiple of 16 bytes. */
+int esam3_window_partition(int dtype, const void* src_dev, void* dst_dev, int B, int H, int W, int C, int ws, int reverse, void* hip_stream);
 
 /* Update half of the stage-1 training step: AMP loss scaler + gradient-norm clipping + AdamW on ONE flat fp32 arena.
  * Replaces, for a student whose trainable parameters live in `params` (each tensor padded to a multiple of 256 elements),

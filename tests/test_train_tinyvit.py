@@ -168,3 +168,24 @@ def test_tinyvit_conv_layers_forward_backward_vs_autograd(mode, kind):
             _close(got, ref, mode, what, 5e-4)
     else:
         _inside_autocast_yardstick(pairs, reference(True), f"TinyViT {kind}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("B,H,W,C,ws", [(2, 9, 11, 64, 7), (1, 14, 14, 32, 7), (3, 16, 15, 160, 14), (2, 63, 63, 8, 14)])
+def test_window_partition_kernel_equals_the_torch_formulation(mode, B, H, W, C, ws):
+    """esam3_window_partition (tiny_vit.py:350-374 as one copy each way) against F.pad + the transposed reshape, and its inverse against the
+    transposed reshape + the slice: bit for bit, zeros in the padding"""
+    from efficientsam3_amd import _lib
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+    x = torch.randn(B, H, W, C, generator=g).to(TDT[mode]).cuda()
+    pad_b, pad_r = (ws - H % ws) % ws, (ws - W % ws) % ws
+    ph, pw = H + pad_b, W + pad_r
+    ref = F.pad(x, (0, 0, 0, pad_r, 0, pad_b)).view(B, ph // ws, ws, pw // ws, ws, C).transpose(2, 3).reshape(B * (ph // ws) * (pw // ws), ws * ws, C).contiguous()
+    out = torch.full_like(ref, 7.0)
+    dt = 0 if mode == "f32" else 1
+    _lib.check(_lib.load().esam3_window_partition(dt, x.data_ptr(), out.data_ptr(), B, H, W, C, ws, 0, torch.cuda.current_stream().cuda_stream), "partition")
+    assert torch.equal(out, ref)
+    back = torch.full_like(x, 7.0)
+    _lib.check(_lib.load().esam3_window_partition(dt, out.data_ptr(), back.data_ptr(), B, H, W, C, ws, 1, torch.cuda.current_stream().cuda_stream), "reverse")
+    assert torch.equal(back, x)
