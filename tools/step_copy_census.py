@@ -23,7 +23,13 @@ def main():
     ap.add_argument("--model", default="b1")
     ap.add_argument("--batch", type=int, default=32)
     a = ap.parse_args()
-    sd = schema.synthetic_state_dict("efficientvit", a.model, seed=0)
+    if a.model.startswith("repvit_"):
+        family, name = "repvit", a.model[len("repvit_"):].replace("_", ".")
+    elif a.model.startswith("tiny_vit_"):
+        family, name = "tinyvit", a.model[len("tiny_vit_"):]
+    else:
+        family, name = "efficientvit", a.model
+    sd = schema.synthetic_state_dict(family, name, seed=0)
     sd = {k[len(PREFIX):]: v.clone() for k, v in sd.items() if k.startswith(PREFIX)}
     tr = Stage1Trainer(sd, a.model, embed_size=72, dtype="bf16", lr=1e-4, weight_decay=0.05, clip_grad=5.0, cosine_weight=0.5)
     g = torch.Generator().manual_seed(0)
